@@ -1,0 +1,136 @@
+/* libmlsp_hip.so -- C ABI of the MI355X (gfx950) hot path of MLSP.
+ *
+ * The reference (VITA-Group/MLSP) has no FFI/operator interface of its own: its boundary is the
+ * Python nn.Module / free-function surface of PointDA/Models.py, PointDA/model_utils.py and
+ * MLSP/mlsp.py.  This header is the native boundary underneath the Python
+ * mirror of that surface (mlsp_amd/Models.py, model_utils.py, mlsp.py): each entry point names
+ * the reference code it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors); the library never
+ *     allocates or frees caller-visible memory.  Scratch is passed in (`ws`, `ws_bytes`; size it
+ *     with mlsp_workspace_bytes).
+ *   - every call is asynchronous on `stream`, re-entrant, keeps no global mutable state, never
+ *     throws, and returns 0 on success, a negative MLSP_ERR_* code for bad arguments, or a
+ *     positive hipError_t.
+ *   - activations are POINT-major fp32 row matrices: [rows][C] with rows = B*N points (or
+ *     B*N*k edges), channels contiguous.  The reference itself moves to this layout before its
+ *     gather (model_utils.py:35).  Indices are int32, local to their cloud (0..N-1).
+ *   - act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
+ *   - bn_save is [4][C] floats: scale (= gamma*invstd), shift (= beta - mean*scale), mean, invstd.
+ */
+#ifndef MLSP_HIP_H
+#define MLSP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
+
+#define MLSP_ABI_VERSION 1
+#define MLSP_OK 0
+#define MLSP_ERR_ARG (-1)
+#define MLSP_ERR_WORKSPACE (-2)
+#define MLSP_ERR_UNSUPPORTED (-3)
+
+int mlsp_abi_version(void);
+const char* mlsp_strerror(int code);
+
+/* Upper bound of the scratch bytes any entry point needs for a problem with `rows` activation
+ * rows, `cin`/`cout` channels (pass the largest of each used with one workspace). */
+size_t mlsp_workspace_bytes(int rows, int cin, int cout);
+
+/* knn(x,k): PointDA/model_utils.py:9-16 (twin PointSegDA/Models.py:8-15).
+ * x [B][N] rows of C floats with row pitch ldx; idx [B][N][k], nearest first (canonical arithmetic,
+ * see oracle/knn_canon.c).  If rev_off != NULL also builds the reverse neighbour index used by the
+ * backward passes: rev_off [B*N+1], rev_ent [B*N*k] packed (i_local << 8 | slot), sorted. */
+int mlsp_knn_f32(const float* x, int ldx, int B, int N, int C, int k, int32_t* idx, int32_t* rev_off, int32_t* rev_ent,
+                 void* ws, size_t ws_bytes, mlsp_stream_t stream);
+
+/* reverse neighbour index alone, for caller-provided indices (get_graph_feature(..., idx=...)) */
+int mlsp_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, int32_t* rev_ent, mlsp_stream_t stream);
+
+/* get_graph_feature(x,args,k,idx): PointDA/model_utils.py:18-42, materialised edge-major:
+ * F [B*N*k][2C] = [x_j - x_i ; x_i].  (The reference's [B,2C,N,k] result is a permuted view of this.) */
+int mlsp_graph_feature_fwd_f32(const float* x, const int32_t* idx, int B, int N, int C, int k, float* F, mlsp_stream_t stream);
+int mlsp_graph_feature_bwd_f32(const float* dF, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int C, int k,
+                               float* dx, mlsp_stream_t stream);
+
+/* Fused EdgeConv block = get_graph_feature + conv_2d (1x1 Conv2d bias=False + BatchNorm2d + act) + max over k:
+ * PointDA/model_utils.py:18-63 with PointDA/Models.py:115-129.  Algebraically folded (edge.hip).
+ * W [Cout][2C] in the reference's Conv2d layout.  Saved for backward: uv [P][2Cout], msel [P][Cout],
+ * argsel [P][Cout] u8, s1 [P][Cout], bn_save [4][Cout]. */
+int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W, const float* gamma, const float* beta,
+                          float* run_mean, float* run_var, float momentum, float eps, int act, float slope, int training,
+                          int B, int N, int C, int Cout, int k, float* out, float* uv, float* msel, uint8_t* argsel,
+                          float* s1, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_edgeconv_bwd_f32(const float* dOut, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
+                          const float* W, const float* out, const float* uv, const float* msel, const uint8_t* argsel,
+                          const float* s1, const float* bn_save, int act, float slope, int training, int B, int N, int C,
+                          int Cout, int k, float* dx, float* dW, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                          mlsp_stream_t stream);
+
+/* Per-row MLP layer = Linear/1x1 conv (+bias) + BatchNorm + act + dropout:
+ * conv_2d / fc_layer (model_utils.py:45-87), conv5+bn5 (Models.py:132), head layers (Models.py:192-196,
+ * 226-230, 272-279).  W [Cout][Cin] with row pitch ldw (a column slice of a wider weight is legal).  gbias [G][Cout] (nullable) is a per-row-group bias (row r uses group r / rows_per_group):
+ * the x5-repeat half of the heads' 1536-channel input enters as a per-cloud bias (Models.py:156-160).
+ * Y = pre-BN (saved), Z = output.  gamma == NULL: no BN (Y is not written, Z = act(linear)). */
+int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                          const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
+                          float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
+                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+                          const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
+                          int n_groups, int rows_per_group, float* dX, int lddx, float* dW, float* dbias, float* dgbias,
+                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+
+/* max over the k edges of every point (`.max(dim=-1)`, model_utils.py:114) on an edge-major matrix */
+int mlsp_segmax_fwd_f32(const float* Z, int P, int k, int C, float* out, uint8_t* argk, mlsp_stream_t stream);
+int mlsp_segmax_bwd_f32(const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ, mlsp_stream_t stream);
+
+/* max over the N points of every cloud (model_utils.py:117 torch.max(dim=2); Models.py:136 adaptive_max_pool1d) */
+int mlsp_colmax_fwd_f32(const float* Z, int B, int N, int C, float* out, int32_t* arg, mlsp_stream_t stream);
+int mlsp_colmax_bwd_f32(const float* dOut, const int32_t* arg, int B, int N, int C, float* dZ, mlsp_stream_t stream);
+
+/* masked symmetric Chamfer (MLSP/mlsp.py:115-182, scaled as calc_loss :222-229):
+ * loss = scale * sum_b (A_b + B_b)/cnt_b,  scale = DefRec_weight * DefRec_SCALER / B.
+ * pred [B][N][3], gold [B][3][N], mask [B][3][N]; per_cloud [B][3], argA/argB [B][N] saved. */
+int mlsp_chamfer_masked_fwd_f32(const float* pred, const float* gold, const float* mask, int B, int N, float scale,
+                                float* per_cloud, int32_t* argA, int32_t* argB, float* loss, mlsp_stream_t stream);
+int mlsp_chamfer_masked_bwd_f32(const float* pred, const float* gold, const float* mask, int B, int N, float scale,
+                                const float* per_cloud, const int32_t* argA, const int32_t* argB, const float* grad_loss,
+                                float* dpred, mlsp_stream_t stream);
+
+/* normal loss (MLSP/mlsp.py:275-287; weighted form PointDA/trainer.py:551-556):
+ * out[0] = -weight * sum_i w_i |cos(pred_i, gt_i)| / sum_i w_i ; out[1] = sum w.  w nullable (=1). */
+int mlsp_normal_loss_fwd_f32(const float* pred, const float* gt, const float* w, int P, float weight, float* out, void* ws,
+                             size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_normal_loss_bwd_f32(const float* pred, const float* gt, const float* w, int P, float weight, const float* fwd_out,
+                             const float* grad_loss, float* dpred, mlsp_stream_t stream);
+
+/* cardinality-head tail (PointDA/Models.py:281-285): p = softmax(logits), density = p . fc2w */
+int mlsp_density_tail_fwd_f32(const float* logits, const float* fc2w, int P, int nc, float* pvec, float* dens,
+                              mlsp_stream_t stream);
+int mlsp_density_tail_bwd_f32(const float* pvec, const float* fc2w, const float* dpvec, const float* ddens, int P, int nc,
+                              float* dlogits, mlsp_stream_t stream);
+
+/* densityloss (MLSP/mlsp.py:430-454): out = {kl, mae, sum mask}; mask nullable */
+int mlsp_density_loss_fwd_f32(const float* pvec, const float* dens, const float* target_vec, const float* target,
+                              const float* mask, int P, int nc, float density_weight, float* out, void* ws, size_t ws_bytes,
+                              mlsp_stream_t stream);
+int mlsp_density_loss_bwd_f32(const float* pvec, const float* dens, const float* target_vec, const float* target,
+                              const float* mask, int P, int nc, float density_weight, const float* fwd_out,
+                              const float* grad_kl, const float* grad_mae, float* dpvec, float* ddens, mlsp_stream_t stream);
+
+/* plain fp32 GEMM on the matrix cores (exposed for tests and the 3x3 input transform):
+ * C[M][N] = opA(A) opB(B) + bias;  ta/tb as in gemm.hip */
+int mlsp_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                  const float* bias, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLSP_HIP_H */

@@ -1,0 +1,183 @@
+"""Mirror of the reference's PointDA/Models.py:82-285 (DGCNN + the three MLSP heads) on the HIP path.
+
+Same constructors, forward flags, output dict keys/shapes and state_dict keys (159 entries) as the
+reference, so PointDA/trainer.py and train_spst.py (strict load_state_dict) work unchanged.
+Parameters live in ordinary nn.Conv*/nn.Linear/nn.BatchNorm* children created in the reference's
+order (identical init under the same seed); compute runs in libmlsp_hip.so.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fh
+from .model_utils import transform_net, conv_2d, fc_layer, classifier, _bn_buffers
+
+K = 20   # Models.py:13
+
+
+def _bn_layer(X, conv, bn, training, act, p_drop=0.0, gbias=None, rows_per_group=0, W=None):
+    """Conv1d(k=1, bias=False) + BatchNorm1d + act (+dropout) on a [rows, Cin] matrix."""
+    rm, rv = _bn_buffers(bn, training)
+    if W is None:
+        W = conv.weight.view(conv.out_channels, conv.in_channels)
+    return Fh.pointmlp(X, W, bias=conv.bias, gbias=gbias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
+                       rows_per_group=rows_per_group, training=training, act=act, slope=0.2, p_drop=p_drop,
+                       momentum=bn.momentum, eps=bn.eps)
+
+
+def _first_head_layer(head, x_cat, x5, N, act, p_drop):
+    """conv1 of a head on cat(x_cat, x5 repeated over N) (Models.py:156-160) without building the
+    [B,1536,N] tensor: the x5 half of the weight acts on one row per cloud and enters as a per-cloud bias."""
+    W = head.conv1.weight.view(head.conv1.out_channels, head.conv1.in_channels)
+    Cc = x_cat.shape[1]
+    gb = Fh.pointmlp(x5, W[:, Cc:], training=head.training)            # [B, Cout]
+    return _bn_layer(x_cat, head.conv1, head.bn1, head.training, act, p_drop=p_drop, gbias=gb, rows_per_group=N,
+                     W=W[:, :Cc])
+
+
+class _RegionHead(nn.Module):
+    """Shared body of RegionReconstruction / Normal_prediction (Models.py:165-231)."""
+
+    def __init__(self, args, input_size):
+        super().__init__()
+        dropout = args if isinstance(args, float) else args.dropout
+        self.of1, self.of2, self.of3 = 256, 256, 128
+        self.bn1 = nn.BatchNorm1d(self.of1)
+        self.bn2 = nn.BatchNorm1d(self.of2)
+        self.bn3 = nn.BatchNorm1d(self.of3)
+        self.dp1 = nn.Dropout(p=dropout)
+        self.dp2 = nn.Dropout(p=dropout)
+        self.conv1 = nn.Conv1d(input_size, self.of1, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv1d(self.of1, self.of2, kernel_size=1, bias=False)
+        self.conv3 = nn.Conv1d(self.of2, self.of3, kernel_size=1, bias=False)
+        self.conv4 = nn.Conv1d(self.of3, 3, kernel_size=1, bias=False)
+
+    def _tail(self, h, B, N):
+        h = _bn_layer(h, self.conv2, self.bn2, self.training, Fh.ACT_RELU, p_drop=self.dp2.p)
+        h = _bn_layer(h, self.conv3, self.bn3, self.training, Fh.ACT_RELU)
+        h = Fh.pointmlp(h, self.conv4.weight.view(3, self.of3), training=self.training)
+        return h.view(B, N, 3)                                       # == x.permute(0,2,1) of the reference
+
+    def rows(self, x_cat, x5, B, N):
+        h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p)
+        return self._tail(h, B, N)
+
+    def forward(self, x):
+        """Reference signature: x [B,input_size,N] -> [B,N,3]."""
+        B, C, N = x.shape
+        X = x.transpose(2, 1).reshape(B * N, C)
+        h = _bn_layer(X, self.conv1, self.bn1, self.training, Fh.ACT_RELU, p_drop=self.dp1.p)
+        return self._tail(h, B, N)
+
+
+class RegionReconstruction(_RegionHead):
+    """Models.py:165-197 -- position head."""
+
+
+class Normal_prediction(_RegionHead):
+    """Models.py:199-231 -- normal head."""
+
+
+class Density_prediction(nn.Module):
+    """Models.py:233-285 -- cardinality head."""
+
+    def __init__(self, args, input_size):
+        super(Density_prediction, self).__init__()
+        dropout = args if isinstance(args, float) else args.dropout
+        self.of1 = 512
+        self.bn1 = nn.BatchNorm1d(self.of1)
+        self.dp1 = nn.Dropout(p=dropout)
+        self.conv1 = nn.Conv1d(input_size, self.of1, kernel_size=1, bias=False)
+        self.num_class = args.density_num_class
+        activate = 'leakyrelu' if args.model == 'dgcnn' else 'relu'
+        bias = True if args.model == 'dgcnn' else False
+        self.mlp1 = fc_layer(512, 256, bias=bias, activation=activate, bn=True)
+        self.dp1 = nn.Dropout(p=args.dropout)       # assigned twice in the reference too (Models.py:248,262)
+        self.mlp2 = fc_layer(256, 256, bias=True, activation=activate, bn=True)
+        self.dp2 = nn.Dropout(p=args.dropout)
+        self.mlp3 = nn.Linear(256, self.num_class)
+        self.fc2 = torch.nn.Linear(self.num_class, 1, bias=False)
+        with torch.no_grad():
+            for i in range(self.num_class):
+                self.fc2.weight[0, i] = args.pergroup * i               # Models.py:267-270
+        self.fc2.weight.requires_grad = False
+
+    def _tail(self, h):
+        h = self.mlp1(h, p_drop=self.dp1.p)                              # dp1 applied twice (:273,:278)
+        h = self.mlp2(h, p_drop=self.dp2.p)
+        logits = Fh.pointmlp(h, self.mlp3.weight, bias=self.mlp3.bias, training=self.training)
+        return Fh.density_tail(logits, self.fc2.weight)
+
+    def rows(self, x_cat, x5, B, N):
+        h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p)
+        return self._tail(h)
+
+    def forward(self, x):
+        """Reference signature: x [B,input_size,N] -> (p_vec [B*N,nc], density [B*N])."""
+        B, C, N = x.shape
+        X = x.transpose(2, 1).reshape(B * N, C)
+        h = _bn_layer(X, self.conv1, self.bn1, self.training, Fh.ACT_RELU, p_drop=self.dp1.p)
+        return self._tail(h)
+
+
+class DGCNN(nn.Module):
+    """Models.py:82-162."""
+
+    def __init__(self, args):
+        super(DGCNN, self).__init__()
+        num_class = int(args.num_class)
+        self.args = args
+        self.k = K
+        self.input_transform_net = transform_net(args, 6, 3)
+        self.conv1 = conv_2d(6, 64, kernel=1, bias=False, activation='leakyrelu')
+        self.conv2 = conv_2d(64 * 2, 64, kernel=1, bias=False, activation='leakyrelu')
+        self.conv3 = conv_2d(64 * 2, 128, kernel=1, bias=False, activation='leakyrelu')
+        self.conv4 = conv_2d(128 * 2, 256, kernel=1, bias=False, activation='leakyrelu')
+        num_f_prev = 64 + 64 + 128 + 256
+        self.bn5 = nn.BatchNorm1d(1024)
+        self.conv5 = nn.Conv1d(num_f_prev, 1024, kernel_size=1, bias=False)
+        self.C = classifier(args, num_class)
+        self.DefRec = RegionReconstruction(args, num_f_prev + 1024)
+        self.Norm_pred = Normal_prediction(args, num_f_prev + 1024)
+        self.Rec_scan = RegionReconstruction(args, num_f_prev + 1024)
+        self.Density_cls = Density_prediction(args, num_f_prev + 1024)
+
+    def forward(self, x, visualization=False, activate_DefRec=False, activate_normal=False, activate_scan=False,
+                activate_density=False, activate_density_normal_ondef=False):
+        B = x.size(0)
+        N = x.size(2)
+        k = self.k
+        logits = {}
+        x = x.float()
+        xp0 = x.transpose(2, 1).contiguous().view(B * N, 3)                 # point-major [P,3]
+
+        # T-Net on the graph feature of the raw cloud (Models.py:111-113)
+        g0 = Fh.knn_graph(xp0, B, N, k)
+        T = self.input_transform_net.rows(Fh.graph_feature(xp0, g0), B, N, k)    # [B,3,3]
+        xp = torch.bmm(xp0.view(B, N, 3), T.transpose(1, 2)).view(B * N, 3)      # (T @ x)^T
+
+        feats = []
+        h = xp
+        for conv in (self.conv1, self.conv2, self.conv3, self.conv4):              # Models.py:115-129
+            g = Fh.knn_graph(h, B, N, k)
+            h = conv.edge(h, g)
+            feats.append(h)
+        x_cat = torch.cat(feats, dim=1)                                            # [P,512]
+        y5 = _bn_layer(x_cat, self.conv5, self.bn5, self.training, Fh.ACT_LRELU)   # Models.py:132
+        x5 = Fh.colmax(y5, B, N)                                                   # [B,1024]  (:136)
+
+        logits["cls"] = self.C(x5)
+        if visualization:
+            return x5
+        if activate_DefRec:
+            logits["DefRec"] = self.DefRec.rows(x_cat, x5, B, N)
+        if activate_normal:
+            logits["Normal"] = self.Norm_pred.rows(x_cat, x5, B, N)
+        if activate_scan:
+            logits["Rec_scan"] = self.Rec_scan.rows(x_cat, x5, B, N)
+        if activate_density:
+            logits['density'], logits['density_mse'] = self.Density_cls.rows(x_cat, x5, B, N)
+        if activate_density_normal_ondef:
+            logits["DefRec"] = self.DefRec.rows(x_cat, x5, B, N)
+            logits['density'], logits['density_mse'] = self.Density_cls.rows(x_cat, x5, B, N)
+            logits["Normal"] = self.Norm_pred.rows(x_cat, x5, B, N)
+        return logits

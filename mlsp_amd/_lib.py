@@ -1,0 +1,118 @@
+"""ctypes binding of libmlsp_hip.so (C ABI: include/mlsp_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a tensor is not on a GPU,
+every op raises.  Build the library with `python -c "import __graft_entry__ as g; g.build()"`
+(or `make -C mlsp_amd/csrc`).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmlsp_hip.so")
+ABI_VERSION = 1
+
+_c = ctypes
+_P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "mlsp_abi_version": [],
+    "mlsp_strerror": [_I],
+    "mlsp_workspace_bytes": [_I, _I, _I],
+    "mlsp_knn_f32": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_knn_reverse": [_P, _I, _I, _I, _P, _P, _P],
+    "mlsp_graph_feature_fwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "mlsp_graph_feature_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mlsp_edgeconv_fwd_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _F, _I, _I, _I, _I, _I, _I,
+                              _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_edgeconv_bwd_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I,
+                              _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_pointmlp_fwd_f32": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
+                              _P, _P, _P, _P, _SZ, _P],
+    "mlsp_pointmlp_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
+                              _P, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_segmax_fwd_f32": [_P, _I, _I, _I, _P, _P, _P],
+    "mlsp_segmax_bwd_f32": [_P, _P, _I, _I, _I, _P, _P],
+    "mlsp_colmax_fwd_f32": [_P, _I, _I, _I, _P, _P, _P],
+    "mlsp_colmax_bwd_f32": [_P, _P, _I, _I, _I, _P, _P],
+    "mlsp_chamfer_masked_fwd_f32": [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P],
+    "mlsp_chamfer_masked_bwd_f32": [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
+    "mlsp_normal_loss_fwd_f32": [_P, _P, _P, _I, _F, _P, _P, _SZ, _P],
+    "mlsp_normal_loss_bwd_f32": [_P, _P, _P, _I, _F, _P, _P, _P, _P],
+    "mlsp_density_tail_fwd_f32": [_P, _P, _I, _I, _P, _P, _P],
+    "mlsp_density_tail_bwd_f32": [_P, _P, _P, _P, _I, _I, _P, _P],
+    "mlsp_density_loss_fwd_f32": [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _SZ, _P],
+    "mlsp_density_loss_bwd_f32": [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
+    "mlsp_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _SZ, _P],
+}
+_RESTYPE = {"mlsp_strerror": _c.c_char_p, "mlsp_workspace_bytes": _SZ}
+
+_lib = None
+
+
+class MlspLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmlsp_hip.so and bind every symbol of include/mlsp_hip.h.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MlspLibraryError(
+            "mlsp_amd: HIP library %s not found -- build it with `make -C mlsp_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`.  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)         # AttributeError if a declared symbol is not exported
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, _I)
+    if lib.mlsp_abi_version() != ABI_VERSION:
+        raise MlspLibraryError("mlsp_amd: ABI mismatch: library %d, python %d" % (lib.mlsp_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mlsp_strerror(rc)
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MlspLibraryError("mlsp_amd: tensor on %s -- the MI355X path needs GPU tensors; there is no CPU "
+                                   "fallback (the CPU restatement lives in oracle/ and is test-only)" % t.device)
+
+
+# one scratch buffer per device, grown on demand (all launches are stream-ordered)
+_workspaces = {}
+
+
+def workspace(device, rows, cin, cout):
+    need = load().mlsp_workspace_bytes(int(rows), int(cin), int(cout))
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(int(need), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws.data_ptr(), ws.numel()
+
+
+def release_workspaces():
+    _workspaces.clear()

@@ -1,0 +1,324 @@
+// extern "C" entry points of libmlsp_hip.so (declared in include/mlsp_hip.h).  Host-side sequencing
+// only: argument checks, workspace carving, kernel launches on the caller's stream.  No allocation,
+// no synchronisation, no global state (hipGraph-capturable).
+#include "common.h"
+#include "../../include/mlsp_hip.h"
+
+// ---- launchers implemented in the other translation units -----------------------------------
+int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats);
+size_t gemm_slab_floats(int M, int N, int K);
+int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws);
+int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent);
+int bn_stat_parts(int M);
+int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double* part);
+int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
+                       const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
+                       float* shift, float* save_mean, float* save_invstd);
+int launch_bn_eval_prepare(hipStream_t st, int C, const float* gamma, const float* beta, const float* run_mean,
+                           const float* run_var, float eps, float* scale, float* shift, float* save_mean, float* save_invstd);
+int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int C, const float* scale, const float* shift,
+                      int act, float slope, float p_drop, uint64_t seed);
+int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* scale,
+                      const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
+                      float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy);
+int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out);
+int launch_colmax_fwd(hipStream_t st, const float* Z, int B, int N, int C, float* out, int* arg);
+int launch_colmax_bwd(hipStream_t st, const float* dOut, const int* arg, int B, int N, int C, float* dZ);
+int launch_segmax_fwd(hipStream_t st, const float* Z, int P, int k, int C, float* out, uint8_t* argk);
+int launch_segmax_bwd(hipStream_t st, const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ);
+int edge_reduce_parts(int P);
+int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd);
+int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW);
+int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
+                       float* msel, uint8_t* argsel, float* s1, double* part);
+int launch_edge_select_act(hipStream_t st, const float* msel, const float* uv, int P, int Cout, const float* scale,
+                           const float* shift, int act, float slope, float* out);
+int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, const float* msel, const float* uv, int P,
+                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part);
+int launch_edge_bwd_point(hipStream_t st, const float* dOut, const float* out, const float* uv, const float* s1, int P,
+                          int Cout, int k, const float* scale, const float* mean, const float* invstd, const float* mean_dz,
+                          const float* mean_dzy, int act, float slope, float* gz, float* duv);
+int launch_edge_bwd_gather(hipStream_t st, const float* gz, const uint8_t* argsel, const float* uv, const int* rev_off,
+                           const int* rev_ent, int P, int N, int Cout, const float* scale, const float* mean,
+                           const float* invstd, const float* mean_dz, const float* mean_dzy, float* duv);
+int launch_graph_feature_fwd(hipStream_t st, const float* x, const int* idx, int P, int N, int C, int k, float* F);
+int launch_graph_feature_bwd(hipStream_t st, const float* dF, const int* rev_off, const int* rev_ent, int P, int N, int C,
+                             int k, float* dx);
+int launch_chamfer_fwd(hipStream_t st, const float* pred, const float* gold, const float* mask, int B, int N, float scale,
+                       float* per_cloud, int* argA, int* argB, float* loss);
+int launch_chamfer_bwd(hipStream_t st, const float* pred, const float* gold, const float* mask, int B, int N, float scale,
+                       const float* per_cloud, const int* argA, const int* argB, const float* gout, float* dpred);
+int launch_normal_loss_fwd(hipStream_t st, const float* pred, const float* gt, const float* w, int P, float weight,
+                           double* part, float* out);
+int launch_normal_loss_bwd(hipStream_t st, const float* pred, const float* gt, const float* w, int P, float weight,
+                           const float* fwd_out, const float* gout, float* dpred);
+int launch_density_tail_fwd(hipStream_t st, const float* logits, const float* w, int P, int nc, float* pvec, float* dens);
+int launch_density_tail_bwd(hipStream_t st, const float* pvec, const float* w, const float* dp, const float* dd, int P, int nc,
+                            float* dlogits);
+int launch_density_loss_fwd(hipStream_t st, const float* pvec, const float* dens, const float* tvec, const float* target,
+                            const float* m, int P, int nc, float dweight, double* part, float* out);
+int launch_density_loss_bwd(hipStream_t st, const float* pvec, const float* dens, const float* tvec, const float* target,
+                            const float* m, int P, int nc, float dweight, const float* fwd_out, const float* gkl,
+                            const float* gmae, float* dp, float* dd);
+int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
+                           float* mean_dz, float* mean_dzy);
+
+#define CHECK(x) do { int _r = (x); if (_r != MLSP_OK) return _r; } while (0)
+#define SLAB_BOUND_FLOATS ((size_t)16 << 20)   /* 64 MiB of fp32: bound on any split-K slab (gemm_pick_split) */
+
+extern "C" {
+
+int mlsp_abi_version(void) { return MLSP_ABI_VERSION; }
+
+const char* mlsp_strerror(int code) {
+    switch (code) {
+        case MLSP_OK: return "ok";
+        case MLSP_ERR_ARG: return "mlsp: bad argument (null pointer, non-positive or unsupported shape)";
+        case MLSP_ERR_WORKSPACE: return "mlsp: workspace too small (see mlsp_workspace_bytes)";
+        case MLSP_ERR_UNSUPPORTED: return "mlsp: unsupported size for this kernel";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "mlsp: unknown error";
+    }
+}
+
+size_t mlsp_workspace_bytes(int rows, int cin, int cout) {
+    size_t r = rows > 0 ? rows : 1, ci = cin > 0 ? cin : 1, co = cout > 0 ? cout : 1;
+    size_t act = 3 * r * co * sizeof(float) + r * sizeof(float);            // gz + duv (edgeconv bwd) / dY (mlp bwd) / xx
+    size_t parts = (r / 64 + 2) * 2 * co * sizeof(double);                  // stat partials
+    size_t wts = 4 * co * ci * sizeof(float) * 2 + 8 * co * sizeof(float);  // Wd, dWd, coefficient vectors
+    return act + parts + wts + SLAB_BOUND_FLOATS * sizeof(float) + (1 << 20);
+}
+
+int mlsp_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                  const float* bias, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    Workspace w(ws, ws_bytes);
+    size_t sf = gemm_slab_floats(M, N, K);
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (sf && !slab) sf = 0;   // launcher falls back to a single pass
+    return launch_gemm(st, ta != 0, tb != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, 0, slab, sf);
+}
+
+int mlsp_knn_f32(const float* x, int ldx, int B, int N, int C, int k, int32_t* idx, int32_t* rev_off, int32_t* rev_ent,
+                 void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (B <= 0 || N <= 0) return MLSP_ERR_ARG;
+    Workspace w(ws, ws_bytes);
+    float* xx = w.take<float>((size_t)B * N);
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    CHECK(launch_knn(st, x, ldx, B, N, C, k, idx, xx));
+    if (rev_off) CHECK(launch_knn_reverse(st, idx, B, N, k, rev_off, rev_ent));
+    return MLSP_OK;
+}
+
+int mlsp_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, int32_t* rev_ent, mlsp_stream_t st) {
+    return launch_knn_reverse(st, idx, B, N, k, rev_off, rev_ent);
+}
+
+int mlsp_graph_feature_fwd_f32(const float* x, const int32_t* idx, int B, int N, int C, int k, float* F, mlsp_stream_t st) {
+    if (!x || !idx || !F || B <= 0 || N <= 0 || C <= 0 || k <= 0) return MLSP_ERR_ARG;
+    return launch_graph_feature_fwd(st, x, idx, B * N, N, C, k, F);
+}
+int mlsp_graph_feature_bwd_f32(const float* dF, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int C, int k,
+                               float* dx, mlsp_stream_t st) {
+    if (!dF || !rev_off || !rev_ent || !dx || B <= 0 || N <= 0 || C <= 0 || k <= 0) return MLSP_ERR_ARG;
+    return launch_graph_feature_bwd(st, dF, rev_off, rev_ent, B * N, N, C, k, dx);
+}
+
+int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W, const float* gamma, const float* beta,
+                          float* run_mean, float* run_var, float momentum, float eps, int act, float slope, int training,
+                          int B, int N, int C, int Cout, int k, float* out, float* uv, float* msel, uint8_t* argsel,
+                          float* s1, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (!x || !idx || !W || !gamma || !beta || !out || !uv || !msel || !argsel || !s1 || !bn_save) return MLSP_ERR_ARG;
+    if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || k > 255 || ldx < C) return MLSP_ERR_ARG;
+    const int P = B * N;
+    Workspace w(ws, ws_bytes);
+    float* Wd = w.take<float>((size_t)2 * Cout * C);
+    int nparts = edge_reduce_parts(P);
+    double* part = w.take<double>((size_t)nparts * 2 * Cout);
+    size_t sf = gemm_slab_floats(P, 2 * Cout, C);
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
+    CHECK(launch_build_wd(st, W, Cout, C, Wd));
+    CHECK(launch_gemm(st, false, true, P, 2 * Cout, C, x, ldx, Wd, C, uv, 2 * Cout, nullptr, nullptr, 0, slab, sf));
+    CHECK(launch_edge_reduce(st, uv, idx, gamma, P, N, Cout, k, msel, argsel, s1, part));
+    if (training) {
+        CHECK(launch_bn_finalize(st, part, nparts, (double)P * k, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale,
+                                 shift, mean, invstd));
+    } else {
+        if (!run_mean || !run_var) return MLSP_ERR_ARG;
+        CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
+    }
+    CHECK(launch_edge_select_act(st, msel, uv, P, Cout, scale, shift, act, slope, out));
+    return MLSP_OK;
+}
+
+int mlsp_edgeconv_bwd_f32(const float* dOut, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
+                          const float* W, const float* out, const float* uv, const float* msel, const uint8_t* argsel,
+                          const float* s1, const float* bn_save, int act, float slope, int training, int B, int N, int C,
+                          int Cout, int k, float* dx, float* dW, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                          mlsp_stream_t st) {
+    if (!dOut || !x || !rev_off || !rev_ent || !W || !out || !uv || !msel || !argsel || !s1 || !bn_save || !dW || !dgamma ||
+        !dbeta)
+        return MLSP_ERR_ARG;
+    if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || ldx < C) return MLSP_ERR_ARG;
+    const int P = B * N;
+    Workspace w(ws, ws_bytes);
+    float* Wd = w.take<float>((size_t)2 * Cout * C);
+    float* dWd = w.take<float>((size_t)2 * Cout * C);
+    float* gz = w.take<float>((size_t)P * Cout);
+    float* duv = w.take<float>((size_t)P * 2 * Cout);
+    int nparts = (P + 511) / 512;
+    double* part = w.take<double>((size_t)nparts * 2 * Cout);
+    float* mean_dz = w.take<float>(Cout);
+    float* mean_dzy = w.take<float>(Cout);
+    size_t sf1 = gemm_slab_floats(P, C, 2 * Cout), sf2 = gemm_slab_floats(2 * Cout, C, P);
+    size_t sf = sf1 > sf2 ? sf1 : sf2;
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    const float* scale = bn_save, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
+    CHECK(launch_edge_bwd_reduce(st, dOut, out, msel, uv, P, Cout, mean, invstd, act, slope, part));
+    CHECK(launch_bn_bwd_finalize(st, part, nparts, (double)P * k, Cout, dgamma, dbeta, mean_dz, mean_dzy));
+    const float* mdz = training ? mean_dz : nullptr;
+    CHECK(launch_edge_bwd_point(st, dOut, out, uv, s1, P, Cout, k, scale, mean, invstd, mdz, mean_dzy, act, slope, gz, duv));
+    CHECK(launch_edge_bwd_gather(st, gz, argsel, uv, rev_off, rev_ent, P, N, Cout, scale, mean, invstd, mdz, mean_dzy, duv));
+    CHECK(launch_build_wd(st, W, Cout, C, Wd));
+    if (dx) CHECK(launch_gemm(st, false, false, P, C, 2 * Cout, duv, 2 * Cout, Wd, C, dx, C, nullptr, nullptr, 0, slab, sf));
+    CHECK(launch_gemm(st, true, false, 2 * Cout, C, P, duv, 2 * Cout, x, ldx, dWd, C, nullptr, nullptr, 0, slab, sf));
+    CHECK(launch_unbuild_wd(st, dWd, Cout, C, dW));
+    return MLSP_OK;
+}
+
+int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                          const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
+                          float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
+                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (!X || !W || !Z || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
+    if (gamma && (!beta || !Y || !bn_save)) return MLSP_ERR_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
+    Workspace w(ws, ws_bytes);
+    int nparts = bn_stat_parts(M);
+    double* part = gamma ? w.take<double>((size_t)nparts * 2 * Cout) : nullptr;
+    size_t sf = gemm_slab_floats(M, Cout, Cin);
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    if (!gamma) {
+        // plain Linear: the GEMM writes Z directly.  Every activated layer of the hot path has a BN.
+        if (act || p_drop > 0.f) return MLSP_ERR_UNSUPPORTED;
+        return launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Z, Cout, bias, gbias, rows_per_group, slab, sf);
+    }
+    float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
+    CHECK(launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Y, Cout, bias, gbias, rows_per_group, slab, sf));
+    if (training) {
+        CHECK(launch_colstats(st, Y, M, Cout, Cout, part));
+        CHECK(launch_bn_finalize(st, part, nparts, (double)M, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale, shift,
+                                 mean, invstd));
+    } else {
+        if (!run_mean || !run_var) return MLSP_ERR_ARG;
+        CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
+    }
+    CHECK(launch_bn_act_fwd(st, Y, Z, (size_t)M, Cout, scale, shift, act, slope, training ? p_drop : 0.f, seed));
+    return MLSP_OK;
+}
+
+int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+                          const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
+                          int n_groups, int rows_per_group, float* dX, int lddx, float* dW, float* dbias, float* dgbias,
+                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (!dZ || !X || !W || !dW || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
+    if (has_bn && (!Y || !bn_save || !dgamma || !dbeta)) return MLSP_ERR_ARG;
+    if (dgbias && (n_groups <= 0 || rows_per_group <= 0 || (long)n_groups * rows_per_group != M)) return MLSP_ERR_ARG;
+    Workspace w(ws, ws_bytes);
+    float* dY = has_bn ? w.take<float>((size_t)M * Cout) : nullptr;
+    int nparts = bn_stat_parts(M);
+    double* part = has_bn ? w.take<double>((size_t)nparts * 2 * Cout) : nullptr;
+    float* mean_dz = has_bn ? w.take<float>(Cout) : nullptr;
+    float* mean_dzy = has_bn ? w.take<float>(Cout) : nullptr;
+    size_t sf1 = dX ? gemm_slab_floats(M, Cin, Cout) : 0, sf2 = gemm_slab_floats(Cout, Cin, M);
+    size_t sf = sf1 > sf2 ? sf1 : sf2;
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    const float* g = dZ;   // gradient wrt the linear output
+    if (has_bn) {
+        const float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
+        CHECK(launch_bn_act_bwd(st, dZ, Y, dY, M, Cout, scale, shift, mean, invstd, training, act, slope,
+                                training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy));
+        g = dY;
+    }
+    if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf));
+    CHECK(launch_gemm(st, true, false, Cout, Cin, M, g, Cout, X, ldx, dW, Cin, nullptr, nullptr, 0, slab, sf));
+    if (dbias) CHECK(launch_colsum_groups(st, g, 1, M, Cout, dbias));
+    if (dgbias) CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias));
+    return MLSP_OK;
+}
+
+int mlsp_segmax_fwd_f32(const float* Z, int P, int k, int C, float* out, uint8_t* argk, mlsp_stream_t st) {
+    if (!Z || !out || !argk || P <= 0 || k <= 0 || k > 255 || C <= 0) return MLSP_ERR_ARG;
+    return launch_segmax_fwd(st, Z, P, k, C, out, argk);
+}
+int mlsp_segmax_bwd_f32(const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ, mlsp_stream_t st) {
+    if (!dOut || !argk || !dZ || P <= 0 || k <= 0 || C <= 0) return MLSP_ERR_ARG;
+    return launch_segmax_bwd(st, dOut, argk, P, k, C, dZ);
+}
+int mlsp_colmax_fwd_f32(const float* Z, int B, int N, int C, float* out, int32_t* arg, mlsp_stream_t st) {
+    if (!Z || !out || !arg || B <= 0 || N <= 0 || C <= 0) return MLSP_ERR_ARG;
+    return launch_colmax_fwd(st, Z, B, N, C, out, arg);
+}
+int mlsp_colmax_bwd_f32(const float* dOut, const int32_t* arg, int B, int N, int C, float* dZ, mlsp_stream_t st) {
+    if (!dOut || !arg || !dZ || B <= 0 || N <= 0 || C <= 0) return MLSP_ERR_ARG;
+    return launch_colmax_bwd(st, dOut, arg, B, N, C, dZ);
+}
+
+int mlsp_chamfer_masked_fwd_f32(const float* pred, const float* gold, const float* mask, int B, int N, float scale,
+                                float* per_cloud, int32_t* argA, int32_t* argB, float* loss, mlsp_stream_t st) {
+    if (!pred || !gold || !mask || !per_cloud || !argA || !argB || !loss || B <= 0 || N <= 0) return MLSP_ERR_ARG;
+    return launch_chamfer_fwd(st, pred, gold, mask, B, N, scale, per_cloud, argA, argB, loss);
+}
+int mlsp_chamfer_masked_bwd_f32(const float* pred, const float* gold, const float* mask, int B, int N, float scale,
+                                const float* per_cloud, const int32_t* argA, const int32_t* argB, const float* grad_loss,
+                                float* dpred, mlsp_stream_t st) {
+    if (!pred || !gold || !mask || !per_cloud || !argA || !argB || !grad_loss || !dpred || B <= 0 || N <= 0) return MLSP_ERR_ARG;
+    return launch_chamfer_bwd(st, pred, gold, mask, B, N, scale, per_cloud, argA, argB, grad_loss, dpred);
+}
+
+int mlsp_normal_loss_fwd_f32(const float* pred, const float* gt, const float* wgt, int P, float weight, float* out, void* ws,
+                             size_t ws_bytes, mlsp_stream_t st) {
+    if (!pred || !gt || !out || P <= 0) return MLSP_ERR_ARG;
+    Workspace w(ws, ws_bytes);
+    double* part = w.take<double>(256 * 2);
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    return launch_normal_loss_fwd(st, pred, gt, wgt, P, weight, part, out);
+}
+int mlsp_normal_loss_bwd_f32(const float* pred, const float* gt, const float* wgt, int P, float weight, const float* fwd_out,
+                             const float* grad_loss, float* dpred, mlsp_stream_t st) {
+    if (!pred || !gt || !fwd_out || !grad_loss || !dpred || P <= 0) return MLSP_ERR_ARG;
+    return launch_normal_loss_bwd(st, pred, gt, wgt, P, weight, fwd_out, grad_loss, dpred);
+}
+
+int mlsp_density_tail_fwd_f32(const float* logits, const float* fc2w, int P, int nc, float* pvec, float* dens, mlsp_stream_t st) {
+    if (!logits || !fc2w || !pvec || !dens || P <= 0 || nc <= 0) return MLSP_ERR_ARG;
+    return launch_density_tail_fwd(st, logits, fc2w, P, nc, pvec, dens);
+}
+int mlsp_density_tail_bwd_f32(const float* pvec, const float* fc2w, const float* dpvec, const float* ddens, int P, int nc,
+                              float* dlogits, mlsp_stream_t st) {
+    if (!pvec || !fc2w || !dlogits || P <= 0 || nc <= 0) return MLSP_ERR_ARG;
+    return launch_density_tail_bwd(st, pvec, fc2w, dpvec, ddens, P, nc, dlogits);
+}
+
+int mlsp_density_loss_fwd_f32(const float* pvec, const float* dens, const float* target_vec, const float* target,
+                              const float* mask, int P, int nc, float density_weight, float* out, void* ws, size_t ws_bytes,
+                              mlsp_stream_t st) {
+    if (!pvec || !dens || !target_vec || !target || !out || P <= 0 || nc <= 0) return MLSP_ERR_ARG;
+    Workspace w(ws, ws_bytes);
+    double* part = w.take<double>(256 * 3);
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    return launch_density_loss_fwd(st, pvec, dens, target_vec, target, mask, P, nc, density_weight, part, out);
+}
+int mlsp_density_loss_bwd_f32(const float* pvec, const float* dens, const float* target_vec, const float* target,
+                              const float* mask, int P, int nc, float density_weight, const float* fwd_out,
+                              const float* grad_kl, const float* grad_mae, float* dpvec, float* ddens, mlsp_stream_t st) {
+    if (!pvec || !dens || !target_vec || !target || !fwd_out || !dpvec || !ddens || P <= 0 || nc <= 0) return MLSP_ERR_ARG;
+    return launch_density_loss_bwd(st, pvec, dens, target_vec, target, mask, P, nc, density_weight, fwd_out, grad_kl, grad_mae,
+                                   dpvec, ddens);
+}
+
+}  // extern "C"

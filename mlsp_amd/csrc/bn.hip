@@ -1,0 +1,339 @@
+// BatchNorm (training & eval) + activation + dropout, and the max-reductions of the hot path.
+// Replaces the BatchNorm2d/BatchNorm1d + ReLU/LeakyReLU + Dropout modules of conv_2d / fc_layer
+// (PointDA/model_utils.py:45-87), bn5 (PointDA/Models.py:132), the head BN stacks
+// (Models.py:192-197,226-231,272-279), `.max(dim=-1)` over k (Models.py:117-129, model_utils.py:114),
+// `torch.max(x, dim=2)` (model_utils.py:117) and adaptive_max_pool1d (Models.py:136).
+//
+// All activations are POINT-major row matrices [rows][C]; BN statistics are per column.
+// These kernels are HBM-bound streaming passes: lanes run along the contiguous channel axis.
+// Column sums are accumulated in fp64 (per-thread) so that var = E[y^2]-E[y]^2 does not lose
+// precision at 655,360 rows.
+#include "common.h"
+#include <math.h>
+
+#define STAT_ROWS 512     // rows per partial-sum block
+
+// ---------------------------------------------------------------------------------------------
+// column sums of y and y^2 -> partials [nparts][2][C] (fp64)
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ Y, int M, int C, int ld,
+                                                       double* __restrict__ part) {
+    __shared__ double sh[2][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * STAT_ROWS, r1 = min(M, r0 + STAT_ROWS);
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = r0 + w; r < r1; r += 4) {
+            float v = Y[(size_t)r * ld + c];
+            s += v; q += (double)v * v;
+        }
+    sh[0][w][lane] = s; sh[1][w][lane] = q;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        double ts = sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane];
+        double tq = sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane];
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = ts;
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = tq;
+    }
+}
+
+// partials -> mean / biased var -> scale, shift, saved stats, running-stat update (torch semantics:
+// running_var uses the unbiased estimate, momentum 0.1; model_utils.py:56-58 defaults)
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int nparts, double count, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ run_mean, float* __restrict__ run_var, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nparts; ++i) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
+    double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    if (run_mean) {
+        double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void bn_eval_prepare_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ run_mean, const float* __restrict__ run_var, float eps,
+                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                                       float* __restrict__ save_invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invstd = 1.0f / sqrtf(run_var[c] + eps);
+    float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - run_mean[c] * sc;
+    save_mean[c] = run_mean[c];
+    save_invstd[c] = invstd;
+}
+
+// Z = dropout(act(Y*scale + shift)).  thresh = p * 2^32, inv_keep = 1/(1-p)
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Y, float* __restrict__ Z, size_t total,
+                                                         int C, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act, float slope,
+                                                         uint32_t thresh, float inv_keep, uint64_t seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        float a = lrelu_or_relu(fmaf(Y[i], scale[c], shift[c]), act, slope);
+        if (thresh) a = dropout_keep(seed, i, thresh) ? a * inv_keep : 0.f;
+        Z[i] = a;
+    }
+}
+
+// gradient wrt the BN output:  dz' = dZ * dropmask * act'(a),  a = Y*scale+shift
+__device__ __forceinline__ float dz_prime(float dz, float y, float sc, float sh, int act, float slope, uint32_t thresh,
+                                          float inv_keep, uint64_t seed, size_t i) {
+    if (thresh) dz = dropout_keep(seed, i, thresh) ? dz * inv_keep : 0.f;
+    if (act) {
+        float a = fmaf(y, sc, sh);
+        if (!(a > 0.f)) dz *= (act == 1 ? 0.f : slope);
+    }
+    return dz;
+}
+
+// partial column sums of dz' and dz'*yhat  (fp64 partials [nparts][2][C])
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dZ, const float* __restrict__ Y,
+                                                                int M, int C, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int act, float slope,
+                                                                uint32_t thresh, float inv_keep, uint64_t seed,
+                                                                double* __restrict__ part) {
+    __shared__ double sh[2][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * STAT_ROWS, r1 = min(M, r0 + STAT_ROWS);
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        float sc = scale[c], shf = shift[c], mu = mean[c], is = invstd[c];
+        for (int r = r0 + w; r < r1; r += 4) {
+            size_t i = (size_t)r * C + c;
+            float y = Y[i];
+            float d = dz_prime(dZ[i], y, sc, shf, act, slope, thresh, inv_keep, seed, i);
+            s += d; q += (double)d * ((y - mu) * is);
+        }
+    }
+    sh[0][w][lane] = s; sh[1][w][lane] = q;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane];
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane];
+    }
+}
+
+// dgamma = sum dz'*yhat, dbeta = sum dz'; coefficient vectors for the apply pass
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nparts, double count, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ mean_dz, float* __restrict__ mean_dzy) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nparts; ++i) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    mean_dz[c] = (float)(s / count);
+    mean_dzy[c] = (float)(q / count);
+}
+
+// dY = scale * (dz' - mean_dz - yhat*mean_dzy)   (training)   |   dY = scale*dz'   (eval: mean_dz == null)
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ dZ, const float* __restrict__ Y,
+                                                               float* __restrict__ dY, size_t total, int C,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ mean_dz,
+                                                               const float* __restrict__ mean_dzy, int act, float slope,
+                                                               uint32_t thresh, float inv_keep, uint64_t seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        float y = Y[i];
+        float d = dz_prime(dZ[i], y, scale[c], shift[c], act, slope, thresh, inv_keep, seed, i);
+        if (mean_dz) d = d - mean_dz[c] - (y - mean[c]) * invstd[c] * mean_dzy[c];
+        dY[i] = scale[c] * d;
+    }
+}
+
+// per-group column sums: out[g][c] = sum over rows of group g   (rows_per_group consecutive rows)
+__global__ __launch_bounds__(256) void colsum_groups_kernel(const float* __restrict__ X, int C, int rows_per_group,
+                                                            float* __restrict__ out) {
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, g = blockIdx.y;
+    double s = 0.0;
+    if (c < C)
+        for (int r = w; r < rows_per_group; r += 4) s += X[((size_t)g * rows_per_group + r) * C + c];
+    sh[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < C) out[(size_t)g * C + c] = (float)(sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// max over the N points of each cloud:  out[b][c] = max_n Z[b*N+n][c], arg = first n attaining it
+__global__ __launch_bounds__(256) void colmax_fwd_kernel(const float* __restrict__ Z, int N, int C,
+                                                         float* __restrict__ out, int* __restrict__ arg) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if (c < C)
+        for (int n = w; n < N; n += 4) {
+            float v = Z[((size_t)b * N + n) * C + c];
+            if (v > best) { best = v; bi = n; }
+        }
+    sv[w][lane] = best; si[w][lane] = bi;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        for (int u = 1; u < 4; ++u) {
+            float v = sv[u][lane]; int i = si[u][lane];
+            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        }
+        out[(size_t)b * C + c] = best;
+        arg[(size_t)b * C + c] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
+// dZ[b*N + arg[b][c]][c] = dOut[b][c]   (dZ pre-zeroed by the caller)
+__global__ void colmax_bwd_kernel(const float* __restrict__ dOut, const int* __restrict__ arg, int B, int N, int C,
+                                  float* __restrict__ dZ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    int b = i / C, c = i % C;
+    dZ[((size_t)b * N + arg[i]) * C + c] = dOut[i];
+}
+
+// max over the k edges of each point: out[i][c] = max_s Z[i*k+s][c], argk = first s attaining it
+__global__ __launch_bounds__(256) void segmax_fwd_kernel(const float* __restrict__ Z, int P, int k, int C,
+                                                         float* __restrict__ out, uint8_t* __restrict__ argk) {
+    size_t total = (size_t)P * C;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        size_t i = t / C; int c = (int)(t % C);
+        const float* z = Z + (i * k) * C + c;
+        float best = z[0]; int bs = 0;
+        for (int s = 1; s < k; ++s) {
+            float v = z[(size_t)s * C];
+            if (v > best) { best = v; bs = s; }
+        }
+        out[t] = best; argk[t] = (uint8_t)bs;
+    }
+}
+
+// dZ[(i*k+s)][c] = (s == argk[i][c]) ? dOut[i][c] : 0     (writes every element)
+__global__ __launch_bounds__(256) void segmax_bwd_kernel(const float* __restrict__ dOut, const uint8_t* __restrict__ argk,
+                                                         int P, int k, int C, float* __restrict__ dZ) {
+    size_t total = (size_t)P * k * C;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(t % C);
+        size_t e = t / C;
+        size_t i = e / k; int s = (int)(e % k);
+        dZ[t] = (argk[i * C + c] == s) ? dOut[i * C + c] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline int ew_blocks(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (int)(b < 4096 ? (b ? b : 1) : 4096);
+}
+static inline uint32_t drop_thresh(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+}
+
+int bn_stat_parts(int M) { return (M + STAT_ROWS - 1) / STAT_ROWS; }
+
+int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double* part) {
+    hipLaunchKernelGGL(colstats_kernel, dim3((C + 63) / 64, bn_stat_parts(M)), dim3(256), 0, st, Y, M, C, ld, part);
+    return mlsp_launch_status();
+}
+
+int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
+                       const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
+                       float* shift, float* save_mean, float* save_invstd) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, nparts, count, C, gamma, beta,
+                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    return mlsp_launch_status();
+}
+
+int launch_bn_eval_prepare(hipStream_t st, int C, const float* gamma, const float* beta, const float* run_mean,
+                           const float* run_var, float eps, float* scale, float* shift, float* save_mean,
+                           float* save_invstd) {
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 127) / 128), dim3(128), 0, st, C, gamma, beta, run_mean, run_var,
+                       eps, scale, shift, save_mean, save_invstd);
+    return mlsp_launch_status();
+}
+
+int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int C, const float* scale,
+                      const float* shift, int act, float slope, float p_drop, uint64_t seed) {
+    size_t total = rows * C;
+    float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, Y, Z, total, C, scale, shift, act,
+                       slope, drop_thresh(p_drop), inv_keep, seed);
+    return mlsp_launch_status();
+}
+
+int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* scale,
+                      const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
+                      float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz,
+                      float* mean_dzy) {
+    float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    uint32_t th = drop_thresh(p_drop);
+    int nparts = bn_stat_parts(M);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift,
+                       mean, invstd, act, slope, th, inv_keep, seed, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, nparts, (double)M, C, dgamma,
+                       dbeta, mean_dz, mean_dzy);
+    size_t total = (size_t)M * C;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dZ, Y, dY, total, C, scale, shift,
+                       mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed);
+    return mlsp_launch_status();
+}
+
+int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
+                           float* mean_dz, float* mean_dzy) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, nparts, count, C, dgamma, dbeta,
+                       mean_dz, mean_dzy);
+    return mlsp_launch_status();
+}
+
+int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out) {
+    hipLaunchKernelGGL(colsum_groups_kernel, dim3((C + 63) / 64, G), dim3(256), 0, st, X, C, rows_per_group, out);
+    return mlsp_launch_status();
+}
+
+int launch_colmax_fwd(hipStream_t st, const float* Z, int B, int N, int C, float* out, int* arg) {
+    hipLaunchKernelGGL(colmax_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, Z, N, C, out, arg);
+    return mlsp_launch_status();
+}
+
+int launch_colmax_bwd(hipStream_t st, const float* dOut, const int* arg, int B, int N, int C, float* dZ) {
+    hipError_t e = hipMemsetAsync(dZ, 0, (size_t)B * N * C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(colmax_bwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, dOut, arg, B, N, C, dZ);
+    return mlsp_launch_status();
+}
+
+int launch_segmax_fwd(hipStream_t st, const float* Z, int P, int k, int C, float* out, uint8_t* argk) {
+    hipLaunchKernelGGL(segmax_fwd_kernel, dim3(ew_blocks((size_t)P * C)), dim3(256), 0, st, Z, P, k, C, out, argk);
+    return mlsp_launch_status();
+}
+
+int launch_segmax_bwd(hipStream_t st, const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ) {
+    hipLaunchKernelGGL(segmax_bwd_kernel, dim3(ew_blocks((size_t)P * k * C)), dim3(256), 0, st, dOut, argk, P, k, C, dZ);
+    return mlsp_launch_status();
+}

@@ -1,0 +1,287 @@
+// EdgeConv on the kNN graph, algebraically folded, plus the materialising graph-feature gather.
+//
+// Reference (PointDA/model_utils.py:18-42 + conv_2d :45-63 + `.max(dim=-1)` Models.py:115-129):
+//     feat_e = [x_j - x_i ; x_i]            for every edge e = (i, j = idx[i][s])
+//     y_e    = W feat_e                     1x1 conv, W = [Wa | Wb]   ([Cout, 2C])
+//     out_i  = max_s LeakyReLU(BN(y_e))     BN statistics over all B*N*k edges
+//
+// Folding (hard parts 2 and 3):
+//     y_e = Wa x_j + (Wb - Wa) x_i = u_j + v_i       with  [u|v] = x [Wa ; Wb-Wa]^T   (ONE per-point GEMM)
+//     act(BN(.)) is monotone per channel, so  max_s act(BN(y_e)) = act(BN(v_i + max_s u_j))  when the BN scale
+//     gamma*invstd >= 0, and  act(BN(v_i + min_s u_j))  otherwise;  sum_e y, sum_e y^2 follow from
+//     s1_i = sum_s u_j and s2_i = sum_s u_j^2.  The [B,2C,N,k] and [B,Cout,N,k] tensors never exist; the
+//     per-edge work is a row gather of u (L2-resident: one cloud's u is <= 1 MB), k x fewer MACs.
+// Backward uses the same closed forms; the scatter-add onto neighbours becomes a gather over the
+// reverse index built by knn.hip (deterministic, no float atomics).
+#include "common.h"
+#include <math.h>
+
+#define EDGE_PTS_PER_WAVE 16
+
+// Wd = [Wa ; Wb - Wa]  ([2*Cout, C]) from the reference-layout weight W [Cout, 2C]
+__global__ void build_wd_kernel(const float* __restrict__ W, int Cout, int C, float* __restrict__ Wd) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Cout * C) return;
+    int o = t / C, c = t % C;
+    float wa = W[(size_t)o * 2 * C + c], wb = W[(size_t)o * 2 * C + C + c];
+    Wd[(size_t)o * C + c] = wa;
+    Wd[(size_t)(Cout + o) * C + c] = wb - wa;
+}
+// dW from dWd:  dWa = dWd_u - dWd_v,  dWb = dWd_v
+__global__ void unbuild_wd_kernel(const float* __restrict__ dWd, int Cout, int C, float* __restrict__ dW) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Cout * C) return;
+    int o = t / C, c = t % C;
+    float du = dWd[(size_t)o * C + c], dv = dWd[(size_t)(Cout + o) * C + c];
+    dW[(size_t)o * 2 * C + c] = du - dv;
+    dW[(size_t)o * 2 * C + C + c] = dv;
+}
+
+// per point: selected extreme of u over the neighbours, its slot, s1; per channel: partial sums of y and y^2
+__global__ __launch_bounds__(256) void edge_reduce_kernel(const float* __restrict__ uv, const int* __restrict__ idx,
+                                                          const float* __restrict__ gamma, int P, int N, int Cout, int k,
+                                                          float* __restrict__ msel, uint8_t* __restrict__ argsel,
+                                                          float* __restrict__ s1out, double* __restrict__ part) {
+    extern __shared__ double shd[];   // [2][4][Cout]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ld = 2 * Cout;
+    const int p0 = (blockIdx.x * 4 + w) * EDGE_PTS_PER_WAVE;
+    for (int c = lane; c < Cout; c += 64) {
+        const bool use_max = gamma[c] >= 0.f;
+        double ps = 0.0, pq = 0.0;
+        for (int pi = 0; pi < EDGE_PTS_PER_WAVE; ++pi) {
+            const int i = p0 + pi;               // wave-uniform
+            if (i >= P) break;
+            const int base = (i / N) * N;        // first point of this cloud
+            const int* irow = idx + (size_t)i * k;
+            float best = 0.f, s1 = 0.f, s2 = 0.f;
+            int bs = 0;
+            for (int s = 0; s < k; ++s) {
+                const int j = base + irow[s];    // scalar load
+                float u = uv[(size_t)j * ld + c];
+                s1 += u; s2 = fmaf(u, u, s2);
+                bool take = (s == 0) || (use_max ? (u > best) : (u < best));
+                best = take ? u : best; bs = take ? s : bs;
+            }
+            float v = uv[(size_t)i * ld + Cout + c];
+            msel[(size_t)i * Cout + c] = best;
+            argsel[(size_t)i * Cout + c] = (uint8_t)bs;
+            s1out[(size_t)i * Cout + c] = s1;
+            ps += (double)s1 + (double)k * v;
+            pq += (double)s2 + 2.0 * (double)v * s1 + (double)k * v * v;
+        }
+        shd[(0 * 4 + w) * Cout + c] = ps;
+        shd[(1 * 4 + w) * Cout + c] = pq;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cout; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int u = 0; u < 4; ++u) { a += shd[(0 * 4 + u) * Cout + c]; b += shd[(1 * 4 + u) * Cout + c]; }
+        part[((size_t)blockIdx.x * 2 + 0) * Cout + c] = a;
+        part[((size_t)blockIdx.x * 2 + 1) * Cout + c] = b;
+    }
+}
+
+// out = act(scale*(msel + v) + shift)
+__global__ __launch_bounds__(256) void edge_select_act_kernel(const float* __restrict__ msel, const float* __restrict__ uv,
+                                                              int P, int Cout, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int act, float slope,
+                                                              float* __restrict__ out) {
+    size_t total = (size_t)P * Cout;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        size_t i = t / Cout; int c = (int)(t % Cout);
+        float y = msel[t] + uv[i * 2 * Cout + Cout + c];
+        out[t] = lrelu_or_relu(fmaf(y, scale[c], shift[c]), act, slope);
+    }
+}
+
+// backward pass 1: column partial sums of dz and dz*yhat_sel (only the selected edge of each
+// (point, channel) carries an incoming gradient)
+__global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __restrict__ dOut, const float* __restrict__ out,
+                                                              const float* __restrict__ msel, const float* __restrict__ uv,
+                                                              int P, int Cout, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, int act, float slope,
+                                                              double* __restrict__ part) {
+    __shared__ double sh[2][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * 512, r1 = min(P, r0 + 512);
+    double s = 0.0, q = 0.0;
+    if (c < Cout) {
+        float mu = mean[c], is = invstd[c];
+        for (int r = r0 + w; r < r1; r += 4) {
+            size_t t = (size_t)r * Cout + c;
+            float d = dOut[t];
+            if (act && !(out[t] > 0.f)) d *= (act == 1 ? 0.f : slope);
+            float yh = (msel[t] + uv[(size_t)r * 2 * Cout + Cout + c] - mu) * is;
+            s += d; q += (double)d * yh;
+        }
+    }
+    sh[0][w][lane] = s; sh[1][w][lane] = q;
+    __syncthreads();
+    if (w == 0 && c < Cout) {
+        part[((size_t)blockIdx.y * 2 + 0) * Cout + c] = sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane];
+        part[((size_t)blockIdx.y * 2 + 1) * Cout + c] = sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane];
+    }
+}
+
+// backward pass 2 (per point):  gz = scale*dz ;  dv_i = gz - k*A - Bc*(s1 + k*v - k*mean)
+//   A = scale*mean_dz, Bc = scale*invstd*mean_dzy  (both 0 in eval mode: pass mean_dz = null)
+__global__ __launch_bounds__(256) void edge_bwd_point_kernel(const float* __restrict__ dOut, const float* __restrict__ out,
+                                                             const float* __restrict__ uv, const float* __restrict__ s1,
+                                                             int P, int Cout, int k, const float* __restrict__ scale,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ mean_dz,
+                                                             const float* __restrict__ mean_dzy, int act, float slope,
+                                                             float* __restrict__ gz, float* __restrict__ duv) {
+    size_t total = (size_t)P * Cout;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        size_t i = t / Cout; int c = (int)(t % Cout);
+        float d = dOut[t];
+        if (act && !(out[t] > 0.f)) d *= (act == 1 ? 0.f : slope);
+        float sc = scale[c];
+        float g = sc * d;
+        gz[t] = g;
+        float dv = g;
+        if (mean_dz) {
+            float A = sc * mean_dz[c], Bc = sc * invstd[c] * mean_dzy[c];
+            float v = uv[i * 2 * Cout + Cout + c];
+            dv = g - (float)k * A - Bc * (s1[t] + (float)k * (v - mean[c]));
+        }
+        duv[i * 2 * Cout + Cout + c] = dv;
+    }
+}
+
+// backward pass 3 (reverse gather, wave per destination j):
+//   du_j = sum_{(i,slot) in rev(j)} ( [argsel[i]==slot]*gz_i - Bc*v_i ) - deg_j*(A + Bc*(u_j - mean))
+__global__ __launch_bounds__(256) void edge_bwd_gather_kernel(const float* __restrict__ gz, const uint8_t* __restrict__ argsel,
+                                                              const float* __restrict__ uv, const int* __restrict__ rev_off,
+                                                              const int* __restrict__ rev_ent, int P, int N, int Cout,
+                                                              const float* __restrict__ scale, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ mean_dz,
+                                                              const float* __restrict__ mean_dzy, float* __restrict__ duv) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = blockIdx.x * 4 + w;     // wave-uniform
+    if (j >= P) return;
+    const int base = (j / N) * N;
+    const int e0 = rev_off[j], e1 = rev_off[j + 1];
+    const int ld = 2 * Cout;
+    for (int c = lane; c < Cout; c += 64) {
+        float A = 0.f, Bc = 0.f;
+        if (mean_dz) { float sc = scale[c]; A = sc * mean_dz[c]; Bc = sc * invstd[c] * mean_dzy[c]; }
+        float acc = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            int ent = rev_ent[e];                        // scalar load
+            int i = base + (ent >> 8), slot = ent & 255;
+            size_t t = (size_t)i * Cout + c;
+            float g = (argsel[t] == slot) ? gz[t] : 0.f;
+            acc += g - Bc * uv[(size_t)i * ld + Cout + c];
+        }
+        float u = uv[(size_t)j * ld + c];
+        duv[(size_t)j * ld + c] = acc - (float)(e1 - e0) * (A + Bc * (u - mean[c]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Materialising graph feature (public get_graph_feature API and the T-Net per-edge stage):
+//   F[(i,s)][0:C] = x_j - x_i ;  F[(i,s)][C:2C] = x_i          F is [P*k][2C] (edge-major)
+__global__ __launch_bounds__(256) void graph_feature_fwd_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                                int P, int N, int C, int k, float* __restrict__ F) {
+    size_t total = (size_t)P * k * C;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(t % C);
+        size_t e = t / C;
+        size_t i = e / k;
+        int j = (int)(i / N) * N + idx[e];
+        float xi = x[i * C + c];
+        F[e * 2 * C + c] = x[(size_t)j * C + c] - xi;
+        F[e * 2 * C + C + c] = xi;
+    }
+}
+
+// dx_i = sum_s (dF_ctr[(i,s)] - dF_nbr[(i,s)]) + sum_{(i',slot) in rev(i)} dF_nbr[(i',slot)]
+__global__ __launch_bounds__(256) void graph_feature_bwd_kernel(const float* __restrict__ dF, const int* __restrict__ rev_off,
+                                                                const int* __restrict__ rev_ent, int P, int N, int C, int k,
+                                                                float* __restrict__ dx) {
+    size_t total = (size_t)P * C;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(t % C);
+        size_t i = t / C;
+        int base = (int)(i / N) * N;
+        float acc = 0.f;
+        for (int s = 0; s < k; ++s) {
+            const float* r = dF + (i * k + s) * 2 * C;
+            acc += r[C + c] - r[c];
+        }
+        for (int e = rev_off[i]; e < rev_off[i + 1]; ++e) {
+            int ent = rev_ent[e];
+            size_t src = (size_t)(base + (ent >> 8)) * k + (ent & 255);
+            acc += dF[src * 2 * C + c];
+        }
+        dx[t] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline int ew_blocks2(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (int)(b < 4096 ? (b ? b : 1) : 4096);
+}
+
+int edge_reduce_parts(int P) { return (P + 4 * EDGE_PTS_PER_WAVE - 1) / (4 * EDGE_PTS_PER_WAVE); }
+
+int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd) {
+    hipLaunchKernelGGL(build_wd_kernel, dim3((Cout * C + 255) / 256), dim3(256), 0, st, W, Cout, C, Wd);
+    return mlsp_launch_status();
+}
+int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW) {
+    hipLaunchKernelGGL(unbuild_wd_kernel, dim3((Cout * C + 255) / 256), dim3(256), 0, st, dWd, Cout, C, dW);
+    return mlsp_launch_status();
+}
+int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
+                       float* msel, uint8_t* argsel, float* s1, double* part) {
+    size_t lds = (size_t)8 * Cout * sizeof(double);
+    if (lds > 64 * 1024) return MLSP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(edge_reduce_kernel, dim3(edge_reduce_parts(P)), dim3(256), lds, st, uv, idx, gamma, P, N, Cout, k,
+                       msel, argsel, s1, part);
+    return mlsp_launch_status();
+}
+int launch_edge_select_act(hipStream_t st, const float* msel, const float* uv, int P, int Cout, const float* scale,
+                           const float* shift, int act, float slope, float* out) {
+    hipLaunchKernelGGL(edge_select_act_kernel, dim3(ew_blocks2((size_t)P * Cout)), dim3(256), 0, st, msel, uv, P, Cout, scale,
+                       shift, act, slope, out);
+    return mlsp_launch_status();
+}
+int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, const float* msel, const float* uv, int P,
+                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part) {
+    hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3((Cout + 63) / 64, (P + 511) / 512), dim3(256), 0, st, dOut, out, msel, uv,
+                       P, Cout, mean, invstd, act, slope, part);
+    return mlsp_launch_status();
+}
+int launch_edge_bwd_point(hipStream_t st, const float* dOut, const float* out, const float* uv, const float* s1, int P,
+                          int Cout, int k, const float* scale, const float* mean, const float* invstd, const float* mean_dz,
+                          const float* mean_dzy, int act, float slope, float* gz, float* duv) {
+    hipLaunchKernelGGL(edge_bwd_point_kernel, dim3(ew_blocks2((size_t)P * Cout)), dim3(256), 0, st, dOut, out, uv, s1, P, Cout,
+                       k, scale, mean, invstd, mean_dz, mean_dzy, act, slope, gz, duv);
+    return mlsp_launch_status();
+}
+int launch_edge_bwd_gather(hipStream_t st, const float* gz, const uint8_t* argsel, const float* uv, const int* rev_off,
+                           const int* rev_ent, int P, int N, int Cout, const float* scale, const float* mean,
+                           const float* invstd, const float* mean_dz, const float* mean_dzy, float* duv) {
+    hipLaunchKernelGGL(edge_bwd_gather_kernel, dim3((P + 3) / 4), dim3(256), 0, st, gz, argsel, uv, rev_off, rev_ent, P, N,
+                       Cout, scale, mean, invstd, mean_dz, mean_dzy, duv);
+    return mlsp_launch_status();
+}
+int launch_graph_feature_fwd(hipStream_t st, const float* x, const int* idx, int P, int N, int C, int k, float* F) {
+    hipLaunchKernelGGL(graph_feature_fwd_kernel, dim3(ew_blocks2((size_t)P * k * C)), dim3(256), 0, st, x, idx, P, N, C, k, F);
+    return mlsp_launch_status();
+}
+int launch_graph_feature_bwd(hipStream_t st, const float* dF, const int* rev_off, const int* rev_ent, int P, int N, int C,
+                             int k, float* dx) {
+    hipLaunchKernelGGL(graph_feature_bwd_kernel, dim3(ew_blocks2((size_t)P * C)), dim3(256), 0, st, dF, rev_off, rev_ent, P, N,
+                       C, k, dx);
+    return mlsp_launch_status();
+}

@@ -1,0 +1,239 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, exact f32,
+// 157 TFLOP/s dense peak == the fp32 roof of the chip).  Every dense contraction of the hot path
+// (1x1 convs, Linears, their dgrad and wgrad) goes through this one kernel family.
+//
+//   C[M,N] = opA(A) * opB(B) (+ bias[N]) (+ gbias[row / rows_per_group][N])
+//   opA(A)[m][k] = TA ? A[k*lda + m] : A[m*lda + k]
+//   opB(B)[k][n] = TB ? B[n*ldb + k] : B[k*ldb + n]
+//
+//   forward  Y  = X  * W^T : TA=0 TB=1        (X [P,Cin] point-major, W [Cout,Cin] as torch stores it)
+//   dgrad    dX = dY * W   : TA=0 TB=0
+//   wgrad    dW = dY^T * X : TA=1 TB=0, K = P (split-K over the grid, slab + reduce: deterministic)
+//
+// Tiling: 128x128x32 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.
+// LDS holds both operand tiles K-MAJOR ([k][row]) so an MFMA operand fragment is one conflict-free
+// ds_read_b32 per lane (lanes 0-31: k even, lanes 32-63: k odd).  Row-major global sources are
+// transposed on the LDS write (stride 129 floats: the 4-row x 8-k-quad write pattern of a 32-lane
+// group lands on 32 distinct banks); k-major sources are copied with 16-byte writes (stride 128).
+// Global loads of tile t+1 are issued before the MFMA loop of tile t (register prefetch).
+// Block -> tile mapping keeps all column tiles of one 128-row panel on one XCD (blockIdx % 8 is the
+// XCD label under round-robin dispatch), so the activation panel is fetched into one L2 only.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define SROW 129   // LDS stride for operands whose global source is row-major  [rows][K]
+#define SKMJ 128   // LDS stride for operands whose global source is k-major    [K][rows]
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* gbias;
+    int M, N, K, lda, ldb, ldc, rows_per_group;
+    int ntm, ntn, nsplit, ksplit;   // tiles; split-K count; K range per split (multiple of BK)
+    int a_vec, b_vec;               // 1 if float4 global loads are legal for that operand
+};
+
+// ---- global -> registers for one 128x32 operand tile -----------------------------------------
+// SRC_KMAJOR = false: source [rows][K] (ld = row pitch). thread t: k-quad (t&7)*4, rows (t>>3)+32p.
+// SRC_KMAJOR = true : source [K][rows] (ld = k pitch).   thread t: row-quad (t&31)*4, k (t>>5)+8p.
+template <bool SRC_KMAJOR>
+__device__ __forceinline__ void g2r(f32x4 (&r)[4], const float* __restrict__ src, int ld, int row0, int nrows,
+                                    int k0, int kend, int vec_ok, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!SRC_KMAJOR) {
+            int row = row0 + (tid >> 3) + 32 * p;
+            int k = k0 + (tid & 7) * 4;
+            if (row < nrows) {
+                const float* g = src + (size_t)row * ld + k;
+                if (vec_ok && k + 3 < kend) {
+                    v = *(const f32x4*)g;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < kend) v[e] = g[e];
+                }
+            }
+        } else {
+            int k = k0 + (tid >> 5) + 8 * p;
+            int row = row0 + (tid & 31) * 4;
+            if (k < kend) {
+                const float* g = src + (size_t)k * ld + row;
+                if (vec_ok && row + 3 < nrows) {
+                    v = *(const f32x4*)g;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row + e < nrows) v[e] = g[e];
+                }
+            }
+        }
+        r[p] = v;
+    }
+}
+
+template <bool SRC_KMAJOR>
+__device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (!SRC_KMAJOR) {
+            int row = (tid >> 3) + 32 * p;
+            int k = (tid & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[(k + e) * SROW + row] = r[p][e];
+        } else {
+            int k = (tid >> 5) + 8 * p;
+            int row = (tid & 31) * 4;
+            *(f32x4*)(s + k * SKMJ + row) = r[p];
+        }
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
+    // A tile is k-major in LDS either way; its GLOBAL source is k-major iff TA.  B's source is
+    // k-major iff !TB.
+    constexpr int SA = TA ? SKMJ : SROW;
+    constexpr int SB = TB ? SROW : SKMJ;
+    __shared__ __attribute__((aligned(16))) float smem[BK * SROW * 2];
+    float* As = smem;
+    float* Bs = smem + BK * SROW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile mapping: all ntn column tiles of a row panel share blockIdx.x % 8
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = bid >> 3;
+    const int tn = q % p.ntn;
+    const int tm = (q / p.ntn) * 8 + xcd;
+    if (tm >= p.ntm) return;
+    const int split = blockIdx.y;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * p.ksplit;
+    const int kend = min(p.K, kbeg + p.ksplit);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    g2r<TA>(ra, p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid);
+    g2r<!TB>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid);
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        r2s<TA>(ra, As, tid);
+        r2s<!TB>(rb, Bs, tid);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            g2r<TA>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid);
+            g2r<!TB>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid);
+        }
+        const float* a_base = As + h * SA + wm * 64 + l31;
+        const float* b_base = Bs + h * SB + wn * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a0 = a_base[(2 * kk) * SA], a1 = a_base[(2 * kk) * SA + 32];
+            float b0 = b_base[(2 * kk) * SB], b1 = b_base[(2 * kk) * SB + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
+    const bool epi = (p.nsplit == 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int col = n0 + wn * 64 + j * 32 + l31;
+            if (col >= p.N) continue;
+            float bv = (epi && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < p.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
+                    Cout[(size_t)row * p.ldc + col] = v;
+                }
+            }
+        }
+}
+
+// sum the split-K slabs (fixed order -> bitwise reproducible) and apply the epilogue
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N, int ldc,
+                                     int nsplit, const float* __restrict__ bias, const float* __restrict__ gbias,
+                                     int rows_per_group) {
+    size_t total = (size_t)M * N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int row = (int)(i / N), col = (int)(i % N);
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += slab[(size_t)z * M * N + i];
+        if (bias) s += bias[col];
+        if (gbias) s += gbias[(size_t)(row / rows_per_group) * N + col];
+        C[(size_t)row * ldc + col] = s;
+    }
+}
+
+// How many K splits a launch will use (shared by the launcher and mlsp_workspace_bytes).
+int gemm_pick_split(int M, int N, int K) {
+    int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    long tiles = (long)ntm * ntn;
+    int ktiles = (K + BK - 1) / BK;
+    if (tiles >= 256 || ktiles < 4) return 1;
+    long want = (512 + tiles - 1) / tiles;          // aim at ~2 blocks per CU
+    int ns = (int)(want < ktiles / 2 ? want : ktiles / 2);
+    if (ns < 1) ns = 1;
+    if (ns > 256) ns = 256;
+    return ns;
+}
+
+size_t gemm_slab_floats(int M, int N, int K) {
+    int ns = gemm_pick_split(M, N, K);
+    return ns > 1 ? (size_t)ns * M * N : 0;
+}
+
+int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
+                int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
+                size_t slab_floats) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return MLSP_ERR_ARG;
+    if (gbias && rows_per_group <= 0) return MLSP_ERR_ARG;
+    GemmArgs p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.gbias = gbias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.rows_per_group = rows_per_group;
+    p.ntm = (M + BM - 1) / BM; p.ntn = (N + BN - 1) / BN;
+    int ns = gemm_pick_split(M, N, K);
+    if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;   // no slab: fall back to one pass
+    int ktiles = (K + BK - 1) / BK;
+    int kts = (ktiles + ns - 1) / ns;
+    ns = (ktiles + kts - 1) / kts;
+    p.nsplit = ns; p.ksplit = kts * BK;
+    p.a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
+    p.b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    if (ns > 1) { p.C = slab; p.ldc = N; }
+    dim3 grid(((p.ntm + 7) / 8) * 8 * p.ntn, ns);
+    if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p);
+    if (ns > 1) {
+        size_t total = (size_t)M * N;
+        int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, C, M, N, ldc, ns, bias, gbias,
+                           rows_per_group);
+    }
+    return mlsp_launch_status();
+}

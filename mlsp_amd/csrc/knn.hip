@@ -1,0 +1,249 @@
+// Brute-force self-kNN in canonical arithmetic + the reverse (transposed) neighbour index.
+// Replaces PointDA/model_utils.py:9-16 `knn` (and its PointSegDA/Models.py:8-15 twin).  The
+// [B,N,N] distance matrix of the reference never exists: distances live in registers only.
+//
+// Canonical arithmetic (bit-exact twin of oracle/knn_canon.c):
+//   dot(i,j) = fmaf chain over c ascending from +0;  xx(j) = same chain on (x_j,x_j)
+//   pd(i,j)  = fl( fl(2*dot - xx(j)) - xx(i) );  order = pd descending, ties -> lower j.
+//
+// v1 structure: one query per lane, 4 waves per workgroup share 64 queries and each scans a quarter
+// of the candidates (staged through LDS, read as wave-uniform broadcasts); each lane keeps a sorted
+// top-K list in registers; the 4 partial lists are merged through LDS under the same total order,
+// so the result does not depend on the partition.
+#include "common.h"
+#include <math.h>
+
+#define KNN_QB 64      // queries per workgroup
+#define KNN_TJ 32      // candidates per LDS tile per wave
+
+// squared norms with the canonical chain
+__global__ void sqnorm_kernel(const float* __restrict__ x, int ld, int P, int C, float* __restrict__ xx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float* r = x + (size_t)i * ld;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(r[c], r[c], acc);
+    xx[i] = acc;
+}
+
+template <int KMAX>
+struct TopK {
+    float v[KMAX];
+    int id[KMAX];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) { v[s] = -INFINITY; id[s] = 0x7fffffff; }
+    }
+    // candidate beats entry (pv,pi)?  total order: value desc, index asc
+    static __device__ __forceinline__ bool beats(float d, int j, float pv, int pi) {
+        return d > pv || (d == pv && j < pi);
+    }
+    __device__ __forceinline__ void insert(float d, int j) {
+#pragma unroll
+        for (int s = KMAX - 1; s >= 1; --s) {
+            bool up = beats(d, j, v[s - 1], id[s - 1]);
+            bool here = beats(d, j, v[s], id[s]);
+            float nv = up ? v[s - 1] : (here ? d : v[s]);
+            int ni = up ? id[s - 1] : (here ? j : id[s]);
+            v[s] = nv; id[s] = ni;
+        }
+        bool first = beats(d, j, v[0], id[0]);
+        v[0] = first ? d : v[0];
+        id[0] = first ? j : id[0];
+    }
+};
+
+// CT > 0: compile-time channel count (query in registers).  CT == 0: runtime C (query in LDS).
+template <int KMAX, int CT>
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
+                                                  int ld, int N, int C, int k, int* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * KNN_QB + lane;          // query (local index in its cloud)
+    const bool qvalid = q < N;
+    const float* xb = x + (size_t)b * N * ld;
+    const float* xxb = xx_all + (size_t)b * N;
+    const int Cr = CT > 0 ? CT : C;
+
+    // LDS carve: [4 waves][TJ][Cr] candidate tiles | [4][TJ] candidate norms | (CT==0) [64][Cr+1] queries
+    float* cand = sm + (size_t)wave * KNN_TJ * Cr;
+    float* cxx = sm + (size_t)4 * KNN_TJ * Cr + wave * KNN_TJ;
+    float* qs = sm + (size_t)4 * KNN_TJ * Cr + 4 * KNN_TJ;
+
+    float qreg[CT > 0 ? CT : 1];
+    if (CT > 0) {
+#pragma unroll
+        for (int c = 0; c < (CT > 0 ? CT : 1); ++c) qreg[c] = qvalid ? xb[(size_t)q * ld + c] : 0.f;
+    } else {
+        for (int e = tid; e < KNN_QB * Cr; e += 256) {
+            int qq = e / Cr, c = e % Cr;
+            int gq = blockIdx.x * KNN_QB + qq;
+            qs[qq * (Cr + 1) + c] = gq < N ? xb[(size_t)gq * ld + c] : 0.f;
+        }
+        __syncthreads();
+    }
+    const float xxi = qvalid ? xxb[q] : 0.f;
+
+    TopK<KMAX> top;
+    top.init();
+
+    // this wave's candidate range
+    const int per = (N + 3) / 4;
+    const int jbeg = wave * per, jend = min(N, jbeg + per);
+    for (int j0 = jbeg; j0 < jend; j0 += KNN_TJ) {
+        const int nj = min(KNN_TJ, jend - j0);
+        // stage tile (wave-private region: no workgroup barrier needed, only wave-level ordering)
+        for (int e = lane; e < nj * Cr; e += 64) cand[e] = xb[(size_t)(j0 + e / Cr) * ld + (e % Cr)];
+        if (lane < nj) cxx[lane] = xxb[j0 + lane];
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) lgkmcnt(0): LDS writes of this wave are done
+        __builtin_amdgcn_wave_barrier();
+        for (int jj = 0; jj < nj; ++jj) {
+            const float* cj = cand + jj * Cr;
+            float dot = 0.f;
+            if (CT > 0) {
+#pragma unroll
+                for (int c = 0; c < (CT > 0 ? CT : 1); ++c) dot = fmaf(qreg[c], cj[c], dot);
+            } else {
+                const float* qr = qs + lane * (Cr + 1);
+                for (int c = 0; c < Cr; ++c) dot = fmaf(qr[c], cj[c], dot);
+            }
+            float t = fmaf(2.0f, dot, -cxx[jj]);
+            float pd = t - xxi;
+            // ascending j inside a wave: a later equal value never displaces an earlier one
+            if (__any(pd > top.v[KMAX - 1])) top.insert(pd, j0 + jj);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // merge the 4 partial lists: waves 1..3 publish theirs, wave 0 inserts them
+    __syncthreads();                         // everyone is done with the candidate tiles
+    float* mv = sm;                          // [3][KMAX][64] values
+    int* mi = (int*)(sm + 3 * KMAX * 64);    // [3][KMAX][64] indices
+    if (wave > 0) {
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            mv[((wave - 1) * KMAX + s) * 64 + lane] = top.v[s];
+            mi[((wave - 1) * KMAX + s) * 64 + lane] = top.id[s];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < 3; ++w)
+            for (int s = 0; s < KMAX; ++s) {
+                float d = mv[(w * KMAX + s) * 64 + lane];
+                int j = mi[(w * KMAX + s) * 64 + lane];
+                if (__any(TopK<KMAX>::beats(d, j, top.v[KMAX - 1], top.id[KMAX - 1]))) top.insert(d, j);
+            }
+        if (qvalid) {
+            int* o = idx + ((size_t)b * N + q) * k;
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s)
+                if (s < k) o[s] = top.id[s];
+        }
+    }
+}
+
+static size_t knn_lds_bytes(int KMAX, int C, bool runtime_c) {
+    size_t tiles = (size_t)4 * KNN_TJ * C + 4 * KNN_TJ + (runtime_c ? (size_t)KNN_QB * (C + 1) : 0);
+    size_t merge = (size_t)3 * KMAX * 64 * 2;
+    return (tiles > merge ? tiles : merge) * sizeof(float);
+}
+
+template <int KMAX>
+static int launch_knn_k(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
+    dim3 grid((N + KNN_QB - 1) / KNN_QB, B), block(256);
+    if (C == 3) {
+        hipLaunchKernelGGL((knn_kernel<KMAX, 3>), grid, block, knn_lds_bytes(KMAX, 3, false), st, x, xx, ld, N, C, k, idx);
+    } else {
+        size_t lds = knn_lds_bytes(KMAX, C, true);
+        if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)knn_kernel<KMAX, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL((knn_kernel<KMAX, 0>), grid, block, lds, st, x, xx, ld, N, C, k, idx);
+    }
+    return mlsp_launch_status();
+}
+
+// xx_ws: [B*N] floats of workspace
+int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws) {
+    if (!x || !idx || !xx_ws || B <= 0 || N <= 0 || C <= 0 || k <= 0 || k > N || ld < C) return MLSP_ERR_ARG;
+    int P = B * N;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, C, xx_ws);
+    if (k <= 20) return launch_knn_k<20>(st, x, ld, xx_ws, B, N, C, k, idx);
+    if (k <= 40) return launch_knn_k<40>(st, x, ld, xx_ws, B, N, C, k, idx);
+    return MLSP_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reverse neighbour index (CSR of the transposed kNN graph), one workgroup per cloud.
+// For every point j: the list of (i, slot) with idx[i][slot] == j, sorted by i*256+slot so that the
+// backward gather-reduce that walks it sums in a fixed order (bitwise reproducible gradients).
+//   rev_off [B*N+1]  global edge offsets;  rev_ent [B*N*k]  packed (i_local << 8 | slot)
+__global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict__ idx, int N, int k,
+                                                           int* __restrict__ rev_off, int* __restrict__ rev_ent,
+                                                           int B) {
+    extern __shared__ int ism[];
+    int* cnt = ism;            // [N]
+    int* off = ism + N;        // [N+1]
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int* ib = idx + (size_t)b * N * k;
+    const int E = N * k;
+    for (int j = tid; j < N; j += nt) cnt[j] = 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += nt) atomicAdd(&cnt[ib[e]], 1);
+    __syncthreads();
+    // exclusive scan by one wave (N is a few thousand at most)
+    if (tid < 64) {
+        int chunk = (N + 63) / 64;
+        int beg = tid * chunk, end = min(N, beg + chunk);
+        int s = 0;
+        for (int j = beg; j < end; ++j) s += cnt[j];
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += t;
+        }
+        int run = incl - s;
+        for (int j = beg; j < end; ++j) { off[j] = run; run += cnt[j]; }
+        if (tid == 63) off[N] = incl;
+    }
+    __syncthreads();
+    const int gbase = b * E;
+    for (int j = tid; j < N; j += nt) { rev_off[(size_t)b * N + j] = gbase + off[j]; cnt[j] = 0; }
+    if (b == B - 1 && tid == 0) rev_off[(size_t)B * N] = gbase + E;
+    __syncthreads();
+    for (int e = tid; e < E; e += nt) {
+        int j = ib[e];
+        int pos = atomicAdd(&cnt[j], 1);
+        rev_ent[gbase + off[j] + pos] = ((e / k) << 8) | (e % k);
+    }
+    __syncthreads();
+    __threadfence_block();
+    // per-destination insertion sort (lists are ~k long)
+    for (int j = tid; j < N; j += nt) {
+        int* a = rev_ent + gbase + off[j];
+        int n = off[j + 1] - off[j];
+        for (int u = 1; u < n; ++u) {
+            int key = a[u];
+            int w = u - 1;
+            while (w >= 0 && a[w] > key) { a[w + 1] = a[w]; --w; }
+            a[w + 1] = key;
+        }
+    }
+}
+
+int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent) {
+    if (!idx || !rev_off || !rev_ent || B <= 0 || N <= 0 || k <= 0 || k > 256 || N > (1 << 22)) return MLSP_ERR_ARG;
+    size_t lds = (size_t)(2 * N + 1) * sizeof(int);
+    if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)knn_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B);
+    return mlsp_launch_status();
+}

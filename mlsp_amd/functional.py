@@ -1,0 +1,454 @@
+"""torch.autograd bindings of the HIP hot path (one Function per C-ABI block of include/mlsp_hip.h).
+
+Layout convention inside this file: activations are POINT-major [rows, C] fp32 (rows = B*N points
+or B*N*k edges).  The module layer (Models.py / model_utils.py) converts from and to the
+reference's channel-major [B, C, N] at its boundary only.
+"""
+import itertools
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+_seed_counter = itertools.count(1)
+
+
+def _next_seed():
+    # counter-based dropout stream: (torch seed, call counter) -> 64-bit key hashed per element in-kernel
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def _rows(t):
+    """[rows, C] fp32 matrix with unit channel stride (row pitch may exceed C)."""
+    assert t.dim() == 2 and t.dtype == torch.float32, (t.shape, t.dtype)
+    if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+class KnnGraph:
+    """kNN indices of one graph stage plus the reverse index needed by the backward passes."""
+    __slots__ = ("idx", "rev_off", "rev_ent", "B", "N", "k")
+
+    def __init__(self, idx, rev_off, rev_ent, B, N, k):
+        self.idx, self.rev_off, self.rev_ent, self.B, self.N, self.k = idx, rev_off, rev_ent, B, N, k
+
+
+def knn_graph(xp, B, N, k, need_reverse=True):
+    """xp [B*N, C] point-major (detached use only: indices are not differentiable,
+    PointDA/model_utils.py:15).  Returns KnnGraph with int32 idx [B*N, k] (local indices)."""
+    lib = _lib.load()
+    xp = _rows(xp.detach())
+    _lib.require_gpu(xp)
+    P, C = xp.shape
+    assert P == B * N
+    idx = torch.empty((P, k), dtype=torch.int32, device=xp.device)
+    rev_off = rev_ent = None
+    if need_reverse:
+        rev_off = torch.empty((P + 1,), dtype=torch.int32, device=xp.device)
+        rev_ent = torch.empty((P * k,), dtype=torch.int32, device=xp.device)
+    ws, wsn = _lib.workspace(xp.device, P, C, 1)
+    _lib.check(lib.mlsp_knn_f32(xp.data_ptr(), xp.stride(0), B, N, C, k, idx.data_ptr(), _lib.ptr(rev_off),
+                                _lib.ptr(rev_ent), ws, wsn, _lib.stream()), "mlsp_knn_f32")
+    return KnnGraph(idx, rev_off, rev_ent, B, N, k)
+
+
+def graph_from_indices(idx, B, N, k):
+    """Wrap caller-provided neighbour indices [B,N,k] (any integer dtype) into a KnnGraph."""
+    lib = _lib.load()
+    _lib.require_gpu(idx)
+    idx32 = idx.reshape(B * N, k).to(torch.int32).contiguous()
+    rev_off = torch.empty((B * N + 1,), dtype=torch.int32, device=idx.device)
+    rev_ent = torch.empty((B * N * k,), dtype=torch.int32, device=idx.device)
+    _lib.check(lib.mlsp_knn_reverse(idx32.data_ptr(), B, N, k, rev_off.data_ptr(), rev_ent.data_ptr(), _lib.stream()),
+               "mlsp_knn_reverse")
+    return KnnGraph(idx32, rev_off, rev_ent, B, N, k)
+
+
+class _GraphFeature(Function):
+    @staticmethod
+    def forward(ctx, xp, graph):
+        lib = _lib.load()
+        xp = xp.contiguous()
+        _lib.require_gpu(xp)
+        P, C = xp.shape
+        F = torch.empty((P * graph.k, 2 * C), dtype=torch.float32, device=xp.device)
+        _lib.check(lib.mlsp_graph_feature_fwd_f32(xp.data_ptr(), graph.idx.data_ptr(), graph.B, graph.N, C, graph.k,
+                                                  F.data_ptr(), _lib.stream()), "mlsp_graph_feature_fwd_f32")
+        ctx.graph, ctx.C = graph, C
+        return F
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dF):
+        lib = _lib.load()
+        g = ctx.graph
+        dF = dF.contiguous()
+        dx = torch.empty((g.B * g.N, ctx.C), dtype=torch.float32, device=dF.device)
+        _lib.check(lib.mlsp_graph_feature_bwd_f32(dF.data_ptr(), g.rev_off.data_ptr(), g.rev_ent.data_ptr(), g.B, g.N,
+                                                  ctx.C, g.k, dx.data_ptr(), _lib.stream()), "mlsp_graph_feature_bwd_f32")
+        return dx, None
+
+
+def graph_feature(xp, graph):
+    """[P, C] -> edge-major [P*k, 2C] = [x_j - x_i ; x_i]  (PointDA/model_utils.py:18-42)."""
+    return _GraphFeature.apply(xp, graph)
+
+
+class _EdgeConv(Function):
+    @staticmethod
+    def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps):
+        lib = _lib.load()
+        xp = _rows(xp)
+        _lib.require_gpu(xp, W2d, gamma)
+        W2d = W2d.contiguous()
+        P, C = xp.shape
+        Cout = W2d.shape[0]
+        assert W2d.shape[1] == 2 * C, (W2d.shape, C)
+        dev = xp.device
+        out = torch.empty((P, Cout), dtype=torch.float32, device=dev)
+        uv = torch.empty((P, 2 * Cout), dtype=torch.float32, device=dev)
+        msel = torch.empty((P, Cout), dtype=torch.float32, device=dev)
+        s1 = torch.empty((P, Cout), dtype=torch.float32, device=dev)
+        argsel = torch.empty((P, Cout), dtype=torch.uint8, device=dev)
+        bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, P, C, 2 * Cout)
+        _lib.check(lib.mlsp_edgeconv_fwd_f32(
+            xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+            _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, act, slope, int(training), graph.B, graph.N, C, Cout,
+            graph.k, out.data_ptr(), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(), bn_save.data_ptr(),
+            ws, wsn, _lib.stream()), "mlsp_edgeconv_fwd_f32")
+        ctx.save_for_backward(xp, W2d, out, uv, msel, argsel, s1, bn_save)
+        ctx.cfg = (graph, training, act, slope, C, Cout)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dOut):
+        lib = _lib.load()
+        xp, W2d, out, uv, msel, argsel, s1, bn_save = ctx.saved_tensors
+        graph, training, act, slope, C, Cout = ctx.cfg
+        if graph.rev_off is None:
+            raise RuntimeError("EdgeConv backward needs the reverse neighbour index (knn_graph(need_reverse=True))")
+        dOut = dOut.contiguous()
+        dev = dOut.device
+        P = xp.shape[0]
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty((P, C), dtype=torch.float32, device=dev) if need_dx else None
+        dW = torch.empty_like(W2d)
+        dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, P, C, 2 * Cout)
+        _lib.check(lib.mlsp_edgeconv_bwd_f32(
+            dOut.data_ptr(), xp.data_ptr(), xp.stride(0), graph.rev_off.data_ptr(), graph.rev_ent.data_ptr(),
+            W2d.data_ptr(), out.data_ptr(), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
+            bn_save.data_ptr(), act, slope, int(training), graph.B, graph.N, C, Cout, graph.k, _lib.ptr(dx), dW.data_ptr(),
+            dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()), "mlsp_edgeconv_bwd_f32")
+        return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def edgeconv(xp, graph, W2d, gamma, beta, run_mean, run_var, training, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5):
+    """Fused get_graph_feature + conv_2d + max over k (Models.py:115-129).  xp [P,C] -> [P,Cout]."""
+    return _EdgeConv.apply(xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps)
+
+
+class _PointMLP(Function):
+    @staticmethod
+    def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,
+                momentum, eps):
+        lib = _lib.load()
+        X = _rows(X)
+        _lib.require_gpu(X, W)
+        if W.stride(1) != 1:
+            W = W.contiguous()
+        M, Cin = X.shape
+        Cout = W.shape[0]
+        assert W.shape[1] == Cin, (W.shape, X.shape)
+        dev = X.device
+        has_bn = gamma is not None
+        Z = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+        Y = torch.empty((M, Cout), dtype=torch.float32, device=dev) if has_bn else None
+        bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev) if has_bn else None
+        if gbias is not None:
+            gbias = gbias.contiguous()
+            assert gbias.shape[1] == Cout and gbias.shape[0] * rows_per_group == M
+        if bias is not None:
+            bias = bias.contiguous()
+        p = float(p_drop) if training else 0.0
+        ws, wsn = _lib.workspace(dev, M, Cin, Cout)
+        _lib.check(lib.mlsp_pointmlp_fwd_f32(
+            X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
+            int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
+            int(training), act, slope, p, seed, _lib.ptr(Y), Z.data_ptr(), _lib.ptr(bn_save), ws, wsn, _lib.stream()),
+            "mlsp_pointmlp_fwd_f32")
+        ctx.save_for_backward(X, W, Y, bn_save)
+        ctx.cfg = (has_bn, training, act, slope, p, seed, bias is not None, gbias.shape[0] if gbias is not None else 0,
+                   int(rows_per_group))
+        return Z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dZ):
+        lib = _lib.load()
+        X, W, Y, bn_save = ctx.saved_tensors
+        has_bn, training, act, slope, p, seed, has_bias, G, rpg = ctx.cfg
+        dZ = dZ.contiguous()
+        dev = dZ.device
+        M, Cin = X.shape
+        Cout = W.shape[0]
+        dX = torch.empty((M, Cin), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+        dbias = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bias else None
+        dgbias = torch.empty((G, Cout), dtype=torch.float32, device=dev) if G else None
+        dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bn else None
+        dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bn else None
+        ws, wsn = _lib.workspace(dev, M, Cin, Cout)
+        _lib.check(lib.mlsp_pointmlp_bwd_f32(
+            dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
+            _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, dW.data_ptr(),
+            _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
+            "mlsp_pointmlp_bwd_f32")
+        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 10
+
+
+def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, run_var=None, rows_per_group=0,
+             training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5):
+    """Linear/1x1-conv (+bias, +per-group bias) [+ BatchNorm + act + dropout] on a [M,Cin] row matrix."""
+    seed = _next_seed() if (training and p_drop > 0) else 0
+    return _PointMLP.apply(X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop,
+                           seed, momentum, eps)
+
+
+class _SegMax(Function):
+    @staticmethod
+    def forward(ctx, Z, k):
+        lib = _lib.load()
+        Z = Z.contiguous()
+        _lib.require_gpu(Z)
+        E, C = Z.shape
+        P = E // k
+        out = torch.empty((P, C), dtype=torch.float32, device=Z.device)
+        argk = torch.empty((P, C), dtype=torch.uint8, device=Z.device)
+        _lib.check(lib.mlsp_segmax_fwd_f32(Z.data_ptr(), P, k, C, out.data_ptr(), argk.data_ptr(), _lib.stream()),
+                   "mlsp_segmax_fwd_f32")
+        ctx.save_for_backward(argk)
+        ctx.k = k
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dOut):
+        lib = _lib.load()
+        (argk,) = ctx.saved_tensors
+        dOut = dOut.contiguous()
+        P, C = dOut.shape
+        dZ = torch.empty((P * ctx.k, C), dtype=torch.float32, device=dOut.device)
+        _lib.check(lib.mlsp_segmax_bwd_f32(dOut.data_ptr(), argk.data_ptr(), P, ctx.k, C, dZ.data_ptr(), _lib.stream()),
+                   "mlsp_segmax_bwd_f32")
+        return dZ, None
+
+
+def segmax(Z, k):
+    """[P*k, C] edge-major -> [P, C]: max over each point's k edges (model_utils.py:114)."""
+    return _SegMax.apply(Z, k)
+
+
+class _ColMax(Function):
+    @staticmethod
+    def forward(ctx, Z, B, N):
+        lib = _lib.load()
+        Z = Z.contiguous()
+        _lib.require_gpu(Z)
+        C = Z.shape[1]
+        out = torch.empty((B, C), dtype=torch.float32, device=Z.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=Z.device)
+        _lib.check(lib.mlsp_colmax_fwd_f32(Z.data_ptr(), B, N, C, out.data_ptr(), arg.data_ptr(), _lib.stream()),
+                   "mlsp_colmax_fwd_f32")
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, N, C)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dOut):
+        lib = _lib.load()
+        (arg,) = ctx.saved_tensors
+        B, N, C = ctx.dims
+        dOut = dOut.contiguous()
+        dZ = torch.empty((B * N, C), dtype=torch.float32, device=dOut.device)
+        _lib.check(lib.mlsp_colmax_bwd_f32(dOut.data_ptr(), arg.data_ptr(), B, N, C, dZ.data_ptr(), _lib.stream()),
+                   "mlsp_colmax_bwd_f32")
+        return dZ, None, None
+
+
+def colmax(Z, B, N):
+    """[B*N, C] -> [B, C]: max over the points of each cloud (model_utils.py:117, Models.py:136)."""
+    return _ColMax.apply(Z, B, N)
+
+
+class _Chamfer(Function):
+    @staticmethod
+    def forward(ctx, pred, gold, mask, scale):
+        lib = _lib.load()
+        pred, gold, mask = pred.contiguous(), gold.contiguous().float(), mask.contiguous().float()
+        _lib.require_gpu(pred, gold, mask)
+        B, N, _ = pred.shape
+        assert gold.shape == (B, 3, N) and mask.shape == (B, 3, N), (pred.shape, gold.shape, mask.shape)
+        dev = pred.device
+        per_cloud = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        argA = torch.empty((B, N), dtype=torch.int32, device=dev)
+        argB = torch.empty((B, N), dtype=torch.int32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(lib.mlsp_chamfer_masked_fwd_f32(pred.data_ptr(), gold.data_ptr(), mask.data_ptr(), B, N, scale,
+                                                   per_cloud.data_ptr(), argA.data_ptr(), argB.data_ptr(), loss.data_ptr(),
+                                                   _lib.stream()), "mlsp_chamfer_masked_fwd_f32")
+        ctx.save_for_backward(pred, gold, mask, per_cloud, argA, argB)
+        ctx.scale = scale
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        pred, gold, mask, per_cloud, argA, argB = ctx.saved_tensors
+        B, N, _ = pred.shape
+        g = g.contiguous().float()
+        dpred = torch.empty_like(pred)
+        _lib.check(lib.mlsp_chamfer_masked_bwd_f32(pred.data_ptr(), gold.data_ptr(), mask.data_ptr(), B, N, ctx.scale,
+                                                   per_cloud.data_ptr(), argA.data_ptr(), argB.data_ptr(), g.data_ptr(),
+                                                   dpred.data_ptr(), _lib.stream()), "mlsp_chamfer_masked_bwd_f32")
+        return dpred, None, None, None
+
+
+def chamfer_masked(pred, gold, mask, scale):
+    """scale * sum_b (chamfer(gold->pred) + chamfer(pred->gold))_b / n_masked_b   (MLSP/mlsp.py:115-182)."""
+    return _Chamfer.apply(pred, gold, mask, float(scale))
+
+
+class _NormalLoss(Function):
+    @staticmethod
+    def forward(ctx, pred, gt, w, weight):
+        lib = _lib.load()
+        pred = pred.contiguous()
+        gt = gt.contiguous().float()
+        _lib.require_gpu(pred, gt, w)
+        P = pred.numel() // 3
+        if w is not None:
+            w = w.contiguous().float().reshape(-1)
+            assert w.numel() == P
+        out = torch.empty((2,), dtype=torch.float32, device=pred.device)
+        ws, wsn = _lib.workspace(pred.device, 1, 1, 1)
+        _lib.check(lib.mlsp_normal_loss_fwd_f32(pred.data_ptr(), gt.data_ptr(), _lib.ptr(w), P, weight, out.data_ptr(),
+                                                ws, wsn, _lib.stream()), "mlsp_normal_loss_fwd_f32")
+        ctx.save_for_backward(pred, gt, w, out)
+        ctx.weight = weight
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        pred, gt, w, out = ctx.saved_tensors
+        P = pred.numel() // 3
+        g = g.contiguous().float()
+        dpred = torch.empty_like(pred)
+        _lib.check(lib.mlsp_normal_loss_bwd_f32(pred.data_ptr(), gt.data_ptr(), _lib.ptr(w), P, ctx.weight, out.data_ptr(),
+                                                g.data_ptr(), dpred.data_ptr(), _lib.stream()), "mlsp_normal_loss_bwd_f32")
+        return dpred, None, None, None
+
+
+def normal_loss(pred, gt, w=None, weight=1.0):
+    """-weight * sum w|cos(pred, gt)| / sum w   (MLSP/mlsp.py:275-287; PointDA/trainer.py:551-556)."""
+    return _NormalLoss.apply(pred, gt, w, float(weight))
+
+
+class _DensityTail(Function):
+    @staticmethod
+    def forward(ctx, logits, fc2w):
+        lib = _lib.load()
+        logits = logits.contiguous()
+        fc2w = fc2w.contiguous().reshape(-1)
+        _lib.require_gpu(logits, fc2w)
+        P, nc = logits.shape
+        pvec = torch.empty_like(logits)
+        dens = torch.empty((P,), dtype=torch.float32, device=logits.device)
+        _lib.check(lib.mlsp_density_tail_fwd_f32(logits.data_ptr(), fc2w.data_ptr(), P, nc, pvec.data_ptr(), dens.data_ptr(),
+                                                 _lib.stream()), "mlsp_density_tail_fwd_f32")
+        ctx.save_for_backward(pvec, fc2w)
+        return pvec, dens
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dp, dd):
+        lib = _lib.load()
+        pvec, fc2w = ctx.saved_tensors
+        P, nc = pvec.shape
+        dp = dp.contiguous() if dp is not None else None
+        dd = dd.contiguous() if dd is not None else None
+        dl = torch.empty_like(pvec)
+        _lib.check(lib.mlsp_density_tail_bwd_f32(pvec.data_ptr(), fc2w.data_ptr(), _lib.ptr(dp), _lib.ptr(dd), P, nc,
+                                                 dl.data_ptr(), _lib.stream()), "mlsp_density_tail_bwd_f32")
+        return dl, None
+
+
+def density_tail(logits, fc2w):
+    """softmax + frozen expectation layer (PointDA/Models.py:281-285) -> (p_vec [P,nc], density [P])."""
+    return _DensityTail.apply(logits, fc2w)
+
+
+class _DensityLoss(Function):
+    @staticmethod
+    def forward(ctx, pvec, dens, tvec, target, mask, dweight):
+        lib = _lib.load()
+        pvec, dens = pvec.contiguous(), dens.contiguous()
+        tvec, target = tvec.contiguous().float(), target.contiguous().float()
+        _lib.require_gpu(pvec, dens, tvec, target, mask)
+        P, nc = pvec.shape
+        if mask is not None:
+            mask = mask.contiguous().float().reshape(-1)
+        out = torch.empty((3,), dtype=torch.float32, device=pvec.device)
+        ws, wsn = _lib.workspace(pvec.device, 1, 1, 1)
+        _lib.check(lib.mlsp_density_loss_fwd_f32(pvec.data_ptr(), dens.data_ptr(), tvec.data_ptr(), target.data_ptr(),
+                                                 _lib.ptr(mask), P, nc, dweight, out.data_ptr(), ws, wsn, _lib.stream()),
+                   "mlsp_density_loss_fwd_f32")
+        ctx.save_for_backward(pvec, dens, tvec, target, mask, out)
+        ctx.dweight = dweight
+        return out[0], out[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gkl, gmae):
+        lib = _lib.load()
+        pvec, dens, tvec, target, mask, out = ctx.saved_tensors
+        P, nc = pvec.shape
+        gkl = gkl.contiguous().float() if gkl is not None else None
+        gmae = gmae.contiguous().float() if gmae is not None else None
+        dp = torch.empty_like(pvec)
+        dd = torch.empty_like(dens)
+        _lib.check(lib.mlsp_density_loss_bwd_f32(pvec.data_ptr(), dens.data_ptr(), tvec.data_ptr(), target.data_ptr(),
+                                                 _lib.ptr(mask), P, nc, ctx.dweight, out.data_ptr(), _lib.ptr(gkl),
+                                                 _lib.ptr(gmae), dp.data_ptr(), dd.data_ptr(), _lib.stream()),
+                   "mlsp_density_loss_bwd_f32")
+        return dp, dd, None, None, None, None
+
+
+def density_loss(pvec, dens, tvec, target, mask=None, dweight=1.0):
+    """(kl, mae) of MLSP/mlsp.py:430-454."""
+    return _DensityLoss.apply(pvec, dens, tvec, target, mask, float(dweight))
+
+
+def gemm(A, B, ta=False, tb=False, bias=None):
+    """Plain fp32 GEMM on the matrix cores: opA(A) @ opB(B) (+bias).  No autograd; used by tests."""
+    lib = _lib.load()
+    A, B = A.contiguous(), B.contiguous()
+    _lib.require_gpu(A, B)
+    M, K = (A.shape[1], A.shape[0]) if ta else A.shape
+    N = B.shape[0] if tb else B.shape[1]
+    C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    ws, wsn = _lib.workspace(A.device, max(M, 1), max(K, 1), max(N, 1))
+    _lib.check(lib.mlsp_gemm_f32(int(ta), int(tb), M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0),
+                                 C.data_ptr(), N, _lib.ptr(bias), ws, wsn, _lib.stream()), "mlsp_gemm_f32")
+    return C

@@ -1,0 +1,194 @@
+"""Mirror of the reference's PointDA/model_utils.py op layer (lines 9-166) on the HIP hot path.
+
+Same names, constructor arguments, forward signatures and state_dict keys as the reference, so
+`from model_utils import transform_net, conv_2d, get_graph_feature, fc_layer, classifier` keeps
+working.  Module boundaries speak the reference's channel-major layouts ([B,C,N], [B,C,N,k]);
+inside, everything is point-major and runs in libmlsp_hip.so (mlsp_amd/functional.py).
+The nn.Conv2d / nn.Linear / nn.BatchNorm children are PARAMETER HOLDERS only (identical
+initialisation order and RNG consumption as the reference); they are never called.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fh
+
+_ACT = {"relu": Fh.ACT_RELU, "leakyrelu": Fh.ACT_LRELU}
+
+
+def knn(x, k):
+    """model_utils.py:9-16.  x [B,C,N] -> idx [B,N,k] int64, nearest first (canonical arithmetic)."""
+    B, C, N = x.shape
+    xp = x.detach().transpose(2, 1).contiguous().view(B * N, C).float()
+    g = Fh.knn_graph(xp, B, N, k, need_reverse=False)
+    return g.idx.view(B, N, k).long()
+
+
+def get_graph_feature(x, args, k=20, idx=None):
+    """model_utils.py:18-42.  x [B,C,N] -> [B,2C,N,k] = cat(x_j - x_i, x_i) (a permuted view of the
+    edge-major matrix, exactly as the reference returns a permuted view)."""
+    B = x.size(0)
+    N = x.size(2)
+    x = x.view(B, -1, N)
+    C = x.size(1)
+    xp = x.transpose(2, 1).contiguous().view(B * N, C)
+    if idx is None:
+        graph = Fh.knn_graph(xp, B, N, k)
+    else:
+        graph = Fh.graph_from_indices(idx, B, N, k)
+    F = Fh.graph_feature(xp, graph)                       # [B*N*k, 2C]
+    return F.view(B, N, k, 2 * C).permute(0, 3, 1, 2)
+
+
+def _bn_buffers(bn, training):
+    if training:
+        bn.num_batches_tracked += 1
+    return bn.running_mean, bn.running_var
+
+
+class conv_2d(nn.Module):
+    """model_utils.py:45-63: 1x1 Conv2d + BatchNorm2d + ReLU | LeakyReLU(0.2)."""
+
+    def __init__(self, in_ch, out_ch, kernel, activation='relu', bias=True):
+        super(conv_2d, self).__init__()
+        assert kernel == 1 or kernel == (1, 1), "the hot path only has 1x1 convolutions"
+        if activation == 'relu':
+            act = nn.ReLU(inplace=True)
+        elif activation == 'leakyrelu':
+            act = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        else:
+            raise ValueError(activation)
+        self.conv = nn.Sequential(nn.Conv2d(in_ch, out_ch, kernel_size=kernel, bias=bias), nn.BatchNorm2d(out_ch), act)
+        self.act = _ACT[activation]
+
+    def rows(self, X):
+        """[rows, Cin] -> [rows, Cout]  (BN statistics over all rows)."""
+        conv, bn = self.conv[0], self.conv[1]
+        rm, rv = _bn_buffers(bn, self.training)
+        return Fh.pointmlp(X, conv.weight.view(conv.out_channels, conv.in_channels), bias=conv.bias, gamma=bn.weight,
+                           beta=bn.bias, run_mean=rm, run_var=rv, training=self.training, act=self.act, slope=0.2,
+                           momentum=bn.momentum, eps=bn.eps)
+
+    def edge(self, xp, graph):
+        """Fused get_graph_feature + this conv + max over k.  xp [P,C] -> [P,Cout]."""
+        conv, bn = self.conv[0], self.conv[1]
+        if conv.bias is not None:
+            raise NotImplementedError("fused EdgeConv expects bias=False (every DGCNN edge conv)")
+        rm, rv = _bn_buffers(bn, self.training)
+        return Fh.edgeconv(xp, graph, conv.weight.view(conv.out_channels, conv.in_channels), bn.weight, bn.bias, rm, rv,
+                           self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps)
+
+    def forward(self, x):
+        """Reference signature: x [B,Cin,N,k] -> [B,Cout,N,k]."""
+        B, C, N, k = x.shape
+        X = x.permute(0, 2, 3, 1).reshape(B * N * k, C)
+        Z = self.rows(X)
+        return Z.view(B, N, k, -1).permute(0, 3, 1, 2)
+
+
+class fc_layer(nn.Module):
+    """model_utils.py:66-87: Linear + BatchNorm1d + activation."""
+
+    def __init__(self, in_ch, out_ch, bn=True, activation='relu', bias=True):
+        super(fc_layer, self).__init__()
+        if activation == 'relu':
+            self.ac = nn.ReLU(inplace=True)
+        elif activation == 'leakyrelu':
+            self.ac = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        else:
+            raise ValueError(activation)
+        if bn:
+            self.fc = nn.Sequential(nn.Linear(in_ch, out_ch, bias=bias), nn.BatchNorm1d(out_ch), self.ac)
+        else:
+            self.fc = nn.Sequential(nn.Linear(in_ch, out_ch), self.ac)
+        self.has_bn = bn
+        self.act = _ACT[activation]
+
+    def forward(self, x, p_drop=0.0):
+        """x [M,in] -> [M,out]; `p_drop` fuses the Dropout that follows this layer in the reference."""
+        lin = self.fc[0]
+        if not self.has_bn:
+            raise NotImplementedError("fc_layer(bn=False) is not on the DGCNN hot path")
+        bn = self.fc[1]
+        rm, rv = _bn_buffers(bn, self.training)
+        return Fh.pointmlp(x, lin.weight, bias=lin.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
+                           training=self.training, act=self.act, slope=0.2, p_drop=p_drop, momentum=bn.momentum, eps=bn.eps)
+
+
+class transform_net(nn.Module):
+    """model_utils.py:90-127: input transform net (T-Net), dgcnn branch."""
+
+    def __init__(self, args, in_ch, out=3):
+        super(transform_net, self).__init__()
+        self.K = out
+        self.args = args
+        dg = (args.model == 'dgcnn' or getattr(args, "encoder_type", None) == 'Dgcnn_Encoder')
+        activation = 'leakyrelu' if dg else 'relu'
+        bias = False if dg else True
+        self.conv2d1 = conv_2d(in_ch, 64, kernel=1, activation=activation, bias=bias)
+        self.conv2d2 = conv_2d(64, 128, kernel=1, activation=activation, bias=bias)
+        self.conv2d3 = conv_2d(128, 1024, kernel=1, activation=activation, bias=bias)
+        self.fc1 = fc_layer(1024, 512, activation=activation, bias=bias, bn=True)
+        self.fc2 = fc_layer(512, 256, activation=activation, bn=True)
+        self.fc3 = nn.Linear(256, out * out)
+        self.dg = dg
+
+    def rows(self, F, B, N, k):
+        """F: edge-major graph feature [B*N*k, in_ch] -> T [B,K,K]."""
+        h = self.conv2d1.rows(F)
+        h = self.conv2d2.rows(h)
+        if self.dg:
+            h = Fh.segmax(h, k)                                  # [B*N, 128]   (model_utils.py:114)
+            rows_per_cloud = N
+        else:
+            rows_per_cloud = N * k
+        h = self.conv2d3.rows(h)
+        h = Fh.colmax(h, B, rows_per_cloud)                      # [B, 1024]    (model_utils.py:117)
+        h = self.fc1(h)
+        h = self.fc2(h)
+        h = Fh.pointmlp(h, self.fc3.weight, bias=self.fc3.bias, training=self.training)
+        iden = torch.eye(self.K, device=h.device, dtype=h.dtype).view(1, self.K * self.K)
+        return (h + iden).view(B, self.K, self.K)
+
+    def forward(self, x):
+        """Reference signature: x [B,in_ch,N,k] (graph feature) -> [B,K,K]."""
+        B, C, N, k = x.shape
+        F = x.permute(0, 2, 3, 1).reshape(B * N * k, C)
+        return self.rows(F, B, N, k)
+
+
+class classifier(nn.Module):
+    """model_utils.py:129-146."""
+
+    def __init__(self, args, num_class=10):
+        super(classifier, self).__init__()
+        activate = 'leakyrelu' if args.model == 'dgcnn' else 'relu'
+        bias = True if args.model == 'dgcnn' else False
+        self.mlp1 = fc_layer(1024, 512, bias=bias, activation=activate, bn=True)
+        self.dp1 = nn.Dropout(p=args.dropout)
+        self.mlp2 = fc_layer(512, 256, bias=True, activation=activate, bn=True)
+        self.dp2 = nn.Dropout(p=args.dropout)
+        self.mlp3 = nn.Linear(256, int(num_class))
+
+    def forward(self, x):
+        x = self.mlp1(x, p_drop=self.dp1.p)
+        x2 = self.mlp2(x, p_drop=self.dp2.p)
+        return Fh.pointmlp(x2, self.mlp3.weight, bias=self.mlp3.bias, training=self.training)
+
+
+class density_classifier(nn.Module):
+    """model_utils.py:148-165 (unused by DGCNN: commented out at Models.py:256; kept for API parity)."""
+
+    def __init__(self, args, num_class=10):
+        super(density_classifier, self).__init__()
+        activate = 'leakyrelu' if args.model == 'dgcnn' else 'relu'
+        bias = True if args.model == 'dgcnn' else False
+        self.mlp1 = fc_layer(512, 256, bias=bias, activation=activate, bn=True)
+        self.dp1 = nn.Dropout(p=args.dropout)
+        self.mlp2 = fc_layer(256, 256, bias=True, activation=activate, bn=True)
+        self.dp2 = nn.Dropout(p=args.dropout)
+        self.mlp3 = nn.Linear(256, int(num_class))
+
+    def forward(self, x):
+        x = self.mlp1(x, p_drop=self.dp1.p)
+        x2 = self.mlp2(x, p_drop=self.dp2.p)
+        return Fh.pointmlp(x2, self.mlp3.weight, bias=self.mlp3.bias, training=self.training)

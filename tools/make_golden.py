@@ -1,0 +1,174 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (imported from
+/root/reference, CPU) on seeded synthetic inputs.  Build-container only; the fixtures are
+data (inputs + expected outputs) and travel to the GPU box, the reference does not.
+
+    python tools/make_golden.py
+"""
+import os
+import sys
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ref_import  # noqa: E402
+import golden_common as gc  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+GRAD_KEYS = ["conv1.conv.0.weight", "conv1.conv.1.weight", "conv4.conv.0.weight", "conv5.weight",
+             "DefRec.conv1.weight", "input_transform_net.fc3.weight", "input_transform_net.conv2d2.conv.0.weight",
+             "Density_cls.mlp3.weight", "C.mlp1.fc.0.weight", "bn5.bias"]
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def knn_case(ref_mu, seed, B, C, N, k=20):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, C, N, generator=g) * 2 - 1
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    pd = -xx - inner - xx.transpose(2, 1)
+    idx = ref_mu.knn(x, k)
+    srt = pd.sort(dim=-1, descending=True)[0]
+    if N > k:
+        gap_k = (srt[..., k - 1] - srt[..., k])          # gap between kth and (k+1)th
+    else:
+        gap_k = torch.full(srt.shape[:-1], float('inf'))
+    gap_in = (srt[..., :k - 1] - srt[..., 1:k]).min(-1)[0]   # smallest gap inside the top-k
+    return dict(x=npy(x), idx=npy(idx).astype(np.int32), gap_k=npy(gap_k), gap_in=npy(gap_in))
+
+
+def model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep_feats):
+    torch.manual_seed(seed)
+    args = gc.make_args(dropout=0.0)
+    model = RefModels.DGCNN(args)
+    gc.perturb_params(model, seed)
+    chk = gc.state_checksums(model)
+    inp = gc.make_inputs(seed, B, N)
+    out = {"x": npy(inp["x"])}
+    for k, v in chk.items():
+        out["chk/" + k] = v
+
+    # capture intermediates with forward hooks on the max-over-k outputs (conv1..4 feed x1..x4)
+    feats = {}
+    model.train()
+    # knn indices of the five graph stages, captured by wrapping the reference's knn
+    knn_log = []
+    orig_knn = ref_mu.knn
+    import model_utils as bare_mu   # Models.py:10 imported get_graph_feature from the bare module
+
+    def logging_knn(x, k):
+        i = orig_knn(x, k)
+        knn_log.append(i)
+        return i
+    bare_mu.knn = logging_knn
+    ref_mu.knn = logging_knn
+    try:
+        logits = model(inp["x"], activate_density_normal_ondef=True)
+    finally:
+        bare_mu.knn = orig_knn
+        ref_mu.knn = orig_knn
+    assert len(knn_log) == 5, len(knn_log)
+    for i, t in enumerate(knn_log):
+        out["knn%d" % i] = npy(t).astype(np.int16)
+    loss, parts = gc.total_loss(args, ref_mlsp, logits, inp)
+    model.zero_grad()
+    x_req = inp["x"]
+    loss.backward()
+    for k, v in logits.items():
+        out["train/" + k] = npy(v)
+    out["train/loss"] = npy(loss)
+    for k, v in parts.items():
+        out["train/loss_" + k] = npy(v)
+    sd = dict(model.named_parameters())
+    for k in GRAD_KEYS:
+        gk = npy(sd[k].grad)
+        if gk.size > 70000:          # keep fixtures small: first 64 output rows
+            gk = gk[:64]
+        out["grad/" + k] = gk
+    st = model.state_dict()
+    for k in ["conv1.conv.1.running_mean", "conv1.conv.1.running_var", "conv4.conv.1.running_var",
+              "bn5.running_mean", "bn5.running_var", "DefRec.bn1.running_mean", "DefRec.bn1.running_var",
+              "input_transform_net.conv2d2.conv.1.running_var", "input_transform_net.fc1.fc.1.running_mean",
+              "C.mlp2.fc.1.running_var", "Density_cls.mlp1.fc.1.running_mean"]:
+        out["run/" + k] = npy(st[k])
+
+    # eval mode (running stats just updated by the step above), all heads
+    model.eval()
+    with torch.no_grad():
+        le = model(inp["x"], activate_density_normal_ondef=True)
+        emb = model(inp["x"], visualization=True)
+    for k, v in le.items():
+        out["eval/" + k] = npy(v)
+    out["eval/embedding"] = npy(emb)
+    if keep_feats:
+        # x_cat is not returned by the reference; recompute it the reference's way in eval mode
+        with torch.no_grad():
+            x0 = ref_mu.get_graph_feature(inp["x"], args, k=20)
+            T = model.input_transform_net(x0)
+            out["eval/tnet"] = npy(T)
+            x = torch.matmul(T, inp["x"])
+            x = ref_mu.get_graph_feature(x, args, k=20)
+            x1 = model.conv1(x).max(dim=-1)[0]
+            out["eval/x1"] = npy(x1)
+    return out
+
+
+def loss_case(ref_mlsp, seed, B, N):
+    args = gc.make_args()
+    inp = gc.make_inputs(seed, B, N)
+    g = torch.Generator().manual_seed(77 + seed)
+    logits = {
+        "DefRec": (inp["gold"].permute(0, 2, 1) + 0.1 * torch.randn(B, N, 3, generator=g)).requires_grad_(True),
+        "Normal": torch.randn(B, N, 3, generator=g).requires_grad_(True),
+    }
+    lg = torch.randn(B * N, 16, generator=g).requires_grad_(True)
+    p = torch.softmax(lg, dim=1)
+    w = torch.arange(16, dtype=torch.float32) * 2.0
+    logits["density"] = p
+    logits["density_mse"] = (p * w).sum(1)
+    loss, parts = gc.total_loss(args, ref_mlsp, logits, inp)
+    loss.backward()
+    out = dict(pred=npy(logits["DefRec"]), normal=npy(logits["Normal"]), dlogits=npy(lg),
+               loss=npy(loss), g_pred=npy(logits["DefRec"].grad), g_normal=npy(logits["Normal"].grad),
+               g_dlogits=npy(lg.grad))
+    for k, v in parts.items():
+        out["loss_" + k] = npy(v)
+    # unmasked variants (MLSP/mlsp.py:275-287, :446-453 else-branches)
+    with torch.no_grad():
+        out["normal_unmasked"] = npy(ref_mlsp.calc_normal_loss(args, logits["Normal"], inp["normal_gt"]))
+        kl, mae = ref_mlsp.densityloss(args, logits, inp["dens_val"], inp["dens_vec"])
+        out["kl_unmasked"] = npy(kl)
+        out["mae_unmasked"] = npy(mae)
+    return out
+
+
+def graph_feature_case(ref_mu, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(2, 5, 64, generator=g) * 2 - 1
+    f = ref_mu.get_graph_feature(x, gc.make_args(), k=20)
+    return dict(x=npy(x), feat=npy(f.contiguous()))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    RefModels, ref_mu, ref_mlsp = ref_import.import_reference()
+    torch.set_num_threads(8)
+    for seed, B, C, N in [(0, 2, 3, 256), (1, 2, 3, 1024), (2, 2, 64, 256), (3, 1, 128, 1024), (4, 3, 3, 20), (5, 2, 64, 33)]:
+        np.savez_compressed(os.path.join(OUT, "knn_s%d_C%d_N%d.npz" % (seed, C, N)), **knn_case(ref_mu, seed, B, C, N))
+    np.savez_compressed(os.path.join(OUT, "graph_feature.npz"), **graph_feature_case(ref_mu, 0))
+    for seed, B, N in [(0, 2, 256), (1, 2, 1024)]:
+        np.savez_compressed(os.path.join(OUT, "loss_s%d_N%d.npz" % (seed, N)), **loss_case(ref_mlsp, seed, B, N))
+    for seed, B, N, keep in [(0, 6, 256, True), (1, 4, 1024, False), (2, 4, 128, False)]:
+        np.savez_compressed(os.path.join(OUT, "dgcnn_s%d_B%d_N%d.npz" % (seed, B, N)),
+                            **model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
