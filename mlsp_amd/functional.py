@@ -37,9 +37,33 @@ class KnnGraph:
         self.idx, self.rev_off, self.rev_ent, self.B, self.N, self.k = idx, rev_off, rev_ent, B, N, k
 
 
+_forced_graphs = None   # test hook: list of index tensors consumed by successive knn_graph calls
+
+
+class forced_graphs:
+    """Context manager (tests only): successive knn_graph() calls return these neighbour indices
+    instead of computing them, so that everything downstream of the (discontinuous) dynamic graph
+    can be compared tightly against fixtures."""
+
+    def __init__(self, idx_list):
+        self.idx_list = list(idx_list)
+
+    def __enter__(self):
+        global _forced_graphs
+        _forced_graphs = list(self.idx_list)
+        return self
+
+    def __exit__(self, *exc):
+        global _forced_graphs
+        _forced_graphs = None
+        return False
+
+
 def knn_graph(xp, B, N, k, need_reverse=True):
     """xp [B*N, C] point-major (detached use only: indices are not differentiable,
     PointDA/model_utils.py:15).  Returns KnnGraph with int32 idx [B*N, k] (local indices)."""
+    if _forced_graphs is not None:
+        return graph_from_indices(_forced_graphs.pop(0).to(xp.device), B, N, k)
     lib = _lib.load()
     xp = _rows(xp.detach())
     _lib.require_gpu(xp)

@@ -1,0 +1,89 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/mlsp_hip.h declares with the argument counts the ctypes binding uses; host-side mirror of the
+reference API (names, state_dict keys) is intact; the product refuses to run without a GPU."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+import golden_common as gc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_prototypes():
+    src = open(os.path.join(ROOT, "include", "mlsp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(mlsp_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(3).strip()
+        n = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
+        protos[m.group(2)] = (m.group(1), n, args)
+    return protos
+
+
+def test_library_exports_every_declared_symbol():
+    from mlsp_amd import _lib
+    lib = _lib.load()
+    protos = _header_prototypes()
+    assert len(protos) >= 24
+    assert set(protos) == set(_lib.SIGNATURES), set(protos) ^ set(_lib.SIGNATURES)
+    for name, (ret, nargs, args) in protos.items():
+        assert hasattr(lib, name), name
+        assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
+        # pointer / scalar kinds line up
+        kinds = ["p" if "*" in a or "mlsp_stream_t" in a else "s" for a in args.split(",")] if nargs else []
+        import ctypes
+        for kind, ct in zip(kinds, _lib.SIGNATURES[name]):
+            assert (ct is ctypes.c_void_p) == (kind == "p"), (name, args)
+    assert lib.mlsp_abi_version() == 1
+    assert b"workspace" in lib.mlsp_strerror(-2)
+    assert lib.mlsp_workspace_bytes(32768, 512, 1024) > 32768 * 1024 * 4
+
+
+def test_reference_api_surface_cpu():
+    from mlsp_amd import Models, model_utils, mlsp
+    for name in ("knn", "get_graph_feature", "conv_2d", "fc_layer", "transform_net", "classifier", "density_classifier"):
+        assert hasattr(model_utils, name)
+    for name in ("DGCNN", "RegionReconstruction", "Normal_prediction", "Density_prediction"):
+        assert hasattr(Models, name)
+    for name in ("calc_loss", "calc_scan_loss", "reconstruction_loss", "calc_normal_loss", "normal_prediction_loss",
+                 "densityloss", "DefRec_SCALER"):
+        assert hasattr(mlsp, name)
+    assert mlsp.DefRec_SCALER == 20.0
+    sig = inspect.signature(Models.DGCNN.forward)
+    assert list(sig.parameters)[1:] == ["x", "visualization", "activate_DefRec", "activate_normal", "activate_scan",
+                                        "activate_density", "activate_density_normal_ondef"]
+    assert list(inspect.signature(mlsp.densityloss).parameters) == ["args", "logits", "target", "target_vec", "mask"]
+    args = gc.make_args(dropout=0.5)
+    args.num_class = 10.0                                  # trainer.py:97 parses it as float
+    m = Models.DGCNN(args)
+    keys = list(m.state_dict().keys())
+    assert len(keys) == 159 and keys[0] == "input_transform_net.conv2d1.conv.0.weight"
+    assert sum(p.numel() for p in m.parameters()) == 4548915
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 4548899
+    # Adam over model.parameters() (trainer.py:258) sees the reference's parameter order
+    assert [n for n, _ in m.named_parameters()][:3] == ["input_transform_net.conv2d1.conv.0.weight",
+                                                        "input_transform_net.conv2d1.conv.1.weight",
+                                                        "input_transform_net.conv2d1.conv.1.bias"]
+
+
+def test_no_cpu_fallback():
+    from mlsp_amd import Models, model_utils, mlsp, _lib
+    m = Models.DGCNN(gc.make_args())
+    with pytest.raises(_lib.MlspLibraryError):
+        m(torch.zeros(2, 3, 64))
+    with pytest.raises(_lib.MlspLibraryError):
+        model_utils.knn(torch.zeros(1, 3, 32), 20)
+    with pytest.raises(_lib.MlspLibraryError):
+        mlsp.reconstruction_loss(torch.zeros(1, 8, 3), torch.zeros(1, 3, 8), torch.ones(1, 3, 8))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from mlsp_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmlsp_hip.so")
+    with pytest.raises(_lib.MlspLibraryError, match="no CPU fallback"):
+        _lib.load()

@@ -1,0 +1,371 @@
+"""GPU parity tests, kernel level: every C-ABI block of include/mlsp_hip.h against the oracle / a plain
+torch fp32 restatement of the same op on identical seeded inputs.  Run with `-m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_common as gc
+from oracle import knn_canon, ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mlsp_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _fh():
+    from mlsp_amd import functional as Fh
+    return Fh
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+# ----------------------------------------------------------------------------- kNN: bit-exact
+@pytest.mark.parametrize("B,N,C,k", [(2, 256, 3, 20), (2, 1024, 3, 20), (2, 256, 64, 20), (1, 1024, 128, 20),
+                                     (3, 20, 3, 20), (2, 33, 64, 20), (2, 100, 5, 7), (1, 300, 3, 40), (2, 70, 16, 1)])
+def test_knn_bit_exact_vs_oracle(dev, B, N, C, k):
+    Fh = _fh()
+    xp = _rand((B * N, C), 100 + N + C)
+    want = knn_canon.knn_point_major(xp.view(B, N, C), k)
+    g = Fh.knn_graph(xp.to(dev), B, N, k)
+    got = g.idx.view(B, N, k).cpu().numpy()
+    assert np.array_equal(got, want), "mismatching rows: %d" % int((got != want).any(-1).sum())
+    # reverse index: every (i, slot) appears exactly once under its destination, sorted
+    off = g.rev_off.cpu().numpy()
+    ent = g.rev_ent.cpu().numpy()
+    assert off[0] == 0 and off[-1] == B * N * k and np.all(np.diff(off) >= 0)
+    dest = np.repeat(np.arange(B * N), np.diff(off))
+    src = (dest // N) * N + (ent >> 8)
+    slot = ent & 255
+    assert np.array_equal(want.reshape(B * N, k)[src, slot] + (dest // N) * N, dest)
+    key = dest.astype(np.int64) * (1 << 40) + ent
+    assert np.all(np.diff(key) > 0)
+
+
+def test_knn_duplicates_and_strided_input(dev):
+    Fh = _fh()
+    x = torch.zeros(1, 64, 3)
+    x[0, :, 0] = torch.arange(64) // 2            # pairs of identical points -> ties resolved by index
+    want = knn_canon.knn_point_major(x, 20)
+    got = Fh.knn_graph(x.view(64, 3).to(dev), 1, 64, 20).idx.view(1, 64, 20).cpu().numpy()
+    assert np.array_equal(got, want)
+    # row-strided view (a column slice of a wider matrix) is read in place
+    wide = _rand((2 * 128, 96), 5).to(dev)
+    sl = wide[:, 32:96]
+    got = Fh.knn_graph(sl, 2, 128, 20).idx.view(2, 128, 20).cpu().numpy()
+    want = knn_canon.knn_point_major(sl.cpu().contiguous().view(2, 128, 64), 20)
+    assert np.array_equal(got, want)
+
+
+def test_knn_golden_reference_rows(dev, golden_dir):
+    """Against the reference's own indices (fixture): identical on every unambiguous row."""
+    Fh = _fh()
+    for f in sorted(os.listdir(golden_dir)):
+        if not f.startswith("knn_"):
+            continue
+        g = dict(np.load(os.path.join(golden_dir, f)))
+        x = torch.from_numpy(g["x"])
+        B, C, N = x.shape
+        k = g["idx"].shape[-1]
+        got = Fh.knn_graph(x.transpose(2, 1).contiguous().view(B * N, C).to(dev), B, N, k).idx.view(B, N, k).cpu().numpy()
+        eps = 8e-6 * C
+        safe = (g["gap_k"] > eps) & (g["gap_in"] > eps)
+        assert np.array_equal(got[safe], g["idx"][safe]), f
+
+
+def test_knn_public_api_and_errors(dev):
+    from mlsp_amd import model_utils as mu
+    x = _rand((2, 3, 128), 1).to(dev)
+    idx = mu.knn(x, 20)
+    assert idx.dtype == torch.int64 and idx.shape == (2, 128, 20)
+    assert torch.equal(idx[:, :, 0].cpu(), torch.arange(128).expand(2, 128))       # self is the nearest
+    with pytest.raises(RuntimeError):
+        mu.knn(x[:, :, :10], 20)                                                    # k > N
+    with pytest.raises(RuntimeError):
+        mu.knn(x.cpu(), 20)                                                         # no CPU fallback
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 300, 200, 64), (0, 1, 1024, 128, 3), (0, 0, 257, 130, 100),
+                                         (1, 0, 64, 6, 5000), (1, 0, 256, 512, 4096), (0, 1, 32, 512, 1024),
+                                         (0, 1, 4096, 2048, 512), (1, 1, 100, 70, 50), (0, 1, 5, 9, 256)])
+def test_gemm(dev, ta, tb, M, N, K):
+    Fh = _fh()
+    A = _rand((K, M) if ta else (M, K), 1)
+    B = _rand((N, K) if tb else (K, N), 2)
+    want = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    got = Fh.gemm(A.to(dev), B.to(dev), ta=bool(ta), tb=bool(tb)).cpu().double()
+    err = (got - want).abs().max().item()
+    assert err < 2e-6 * K ** 0.5 * 4 + 1e-6, err
+
+
+def test_gemm_matches_fma_chain_bitwise(dev):
+    """The f32 MFMA is a k-ordered fmaf chain (what makes an MFMA kNN canonical): check bitwise for K<=32."""
+    Fh = _fh()
+    A, B = _rand((64, 24), 3), _rand((40, 24), 4)
+    got = Fh.gemm(A.to(dev), B.to(dev), tb=True).cpu().numpy()
+    want = np.zeros((64, 40), np.float32)
+    a64, b64 = A.numpy().astype(np.float64), B.numpy().astype(np.float64)
+    acc = np.zeros((64, 40), np.float64)
+    for kk in range(24):        # fmaf: exact product + one rounding per step, emulated in float64 (exact for f32 inputs)
+        acc = (acc + np.outer(a64[:, kk], b64[:, kk])).astype(np.float32).astype(np.float64)
+    want = acc.astype(np.float32)
+    assert np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------- pointmlp (Linear + BN + act)
+def _torch_pointmlp(X, W, bias, gbias, rpg, gamma, beta, rm, rv, training, act):
+    Y = X @ W.t()
+    if bias is not None:
+        Y = Y + bias
+    if gbias is not None:
+        Y = Y + gbias.repeat_interleave(rpg, dim=0)
+    if gamma is not None:
+        Y = F.batch_norm(Y, rm, rv, gamma, beta, training, 0.1, 1e-5)
+    if act == 1:
+        Y = F.relu(Y)
+    elif act == 2:
+        Y = F.leaky_relu(Y, 0.2)
+    return Y
+
+
+@pytest.mark.parametrize("M,Cin,Cout,act,use_bias,G,training", [
+    (1000, 64, 128, 2, False, 0, True), (512, 6, 64, 2, False, 0, True), (32, 1024, 512, 2, True, 0, True),
+    (2048, 512, 256, 1, False, 4, True), (777, 100, 33, 1, True, 0, False), (640, 128, 3, 0, True, 0, True)])
+def test_pointmlp_fwd_bwd(dev, M, Cin, Cout, act, use_bias, G, training):
+    Fh = _fh()
+    has_bn = act != 0
+    X = _rand((M, Cin), 1).requires_grad_(True)
+    W = _rand((Cout, Cin), 2, 0.2).requires_grad_(True)
+    bias = _rand((Cout,), 3).requires_grad_(True) if use_bias else None
+    rpg = M // G if G else 0
+    gbias = _rand((G, Cout), 4).requires_grad_(True) if G else None
+    gamma = (_rand((Cout,), 5) + 0.2).requires_grad_(True) if has_bn else None      # includes negative scales
+    beta = _rand((Cout,), 6).requires_grad_(True) if has_bn else None
+    rm, rv = _rand((Cout,), 7) * 0.1, _rand((Cout,), 8).abs() + 0.5
+    dZ = _rand((M, Cout), 9)
+
+    rm_c, rv_c = rm.clone(), rv.clone()
+    Zc = _torch_pointmlp(X, W, bias, gbias, rpg, gamma, beta, rm_c if has_bn else None, rv_c if has_bn else None, training, act)
+    Zc.backward(dZ)
+    leaves = [t for t in (X, W, bias, gbias, gamma, beta) if t is not None]
+    want = [t.grad.clone() for t in leaves]
+
+    def d(t):
+        return t.detach().to(dev).requires_grad_(True) if t is not None else None
+    Xg, Wg, bg, gbg, gg, betag = d(X), d(W), d(bias), d(gbias), d(gamma), d(beta)
+    rm_g, rv_g = rm.to(dev), rv.to(dev)
+    Zg = Fh.pointmlp(Xg, Wg, bias=bg, gbias=gbg, gamma=gg, beta=betag, run_mean=rm_g if has_bn else None,
+                     run_var=rv_g if has_bn else None, rows_per_group=rpg, training=training, act=act)
+    Zg.backward(dZ.to(dev))
+    np.testing.assert_allclose(Zg.detach().cpu().numpy(), Zc.detach().numpy(), rtol=1e-4, atol=2e-4)
+    got = [t.grad for t in (Xg, Wg, bg, gbg, gg, betag) if t is not None]
+    names = [n for n, t in zip(["dX", "dW", "dbias", "dgbias", "dgamma", "dbeta"], (X, W, bias, gbias, gamma, beta))
+             if t is not None]
+    for gw, ww, name in zip(got, want, names):
+        scale = ww.abs().max().item() + 1e-6
+        err = (gw.cpu() - ww).abs().max().item()
+        if name == "dbias" and has_bn and training:
+            assert err < 1e-3 * (dZ.abs().sum(0).max().item()), (name, err)      # analytically zero
+        else:
+            assert err / scale < 2e-3, (name, err, scale)
+    if has_bn and training:
+        np.testing.assert_allclose(rm_g.cpu().numpy(), rm_c.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rv_g.cpu().numpy(), rv_c.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_pointmlp_weight_column_slice(dev):
+    """W passed as a column slice of a wider weight (the heads' 1536-channel conv1 split)."""
+    Fh = _fh()
+    X = _rand((256, 40), 1)
+    Wfull = _rand((16, 100), 2, 0.3)
+    Wg = Wfull.to(dev).requires_grad_(True)
+    Z = Fh.pointmlp(X.to(dev), Wg[:, :40])
+    Z.sum().backward()
+    np.testing.assert_allclose(Z.detach().cpu().numpy(), (X @ Wfull[:, :40].t()).numpy(), rtol=1e-4, atol=1e-4)
+    want = torch.zeros_like(Wfull)
+    want[:, :40] = X.sum(0, keepdim=True).expand(16, 40)
+    np.testing.assert_allclose(Wg.grad.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_dropout_statistics_and_mask_consistency(dev):
+    Fh = _fh()
+    M, C = 4096, 128
+    X = torch.ones(M, C)
+    W = torch.eye(C)
+    gamma, beta = torch.ones(C), torch.full((C,), 2.0)
+    Xg = X.to(dev).requires_grad_(True)
+    torch.manual_seed(7)
+    Z = Fh.pointmlp(Xg + 0.001 * _rand((M, C), 3).to(dev), W.to(dev), gamma=gamma.to(dev), beta=beta.to(dev),
+                    run_mean=torch.zeros(C, device=dev), run_var=torch.ones(C, device=dev), training=True, act=1, p_drop=0.5)
+    keep = (Z != 0)
+    frac = keep.float().mean().item()
+    assert abs(frac - 0.5) < 0.01, frac
+    # kept values are scaled by 1/(1-p)
+    assert (Z[keep] > 0).all()
+    col_frac = keep.float().mean(0)
+    assert (col_frac - 0.5).abs().max().item() < 0.06
+    Z.backward(torch.ones_like(Z))
+    # eval: no dropout
+    Ze = Fh.pointmlp(X.to(dev), W.to(dev), gamma=gamma.to(dev), beta=beta.to(dev), run_mean=torch.zeros(C, device=dev),
+                     run_var=torch.ones(C, device=dev), training=False, act=1, p_drop=0.5)
+    assert (Ze != 0).all()
+
+
+# ----------------------------------------------------------------------------- graph feature / max reductions
+def test_graph_feature_fwd_bwd(dev, golden_dir):
+    from mlsp_amd import model_utils as mu
+    g = dict(np.load(os.path.join(golden_dir, "graph_feature.npz")))
+    x = torch.from_numpy(g["x"])
+    xg = x.to(dev).requires_grad_(True)
+    f = mu.get_graph_feature(xg, gc.make_args(cuda=True), k=20)
+    assert f.shape == g["feat"].shape
+    np.testing.assert_allclose(f.detach().cpu().numpy(), g["feat"], rtol=0, atol=0)
+    w = _rand(tuple(f.shape), 3)
+    (f * w.to(dev)).sum().backward()
+    xc = x.clone().requires_grad_(True)
+    fc = ref_cpu.graph_feature(xc, ref_cpu.knn_reference_formula(xc, 20))
+    (fc * w).sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # caller-provided indices
+    idx = ref_cpu.knn_reference_formula(x, 20)
+    f2 = mu.get_graph_feature(x.to(dev), gc.make_args(cuda=True), k=20, idx=idx.to(dev))
+    np.testing.assert_allclose(f2.cpu().numpy(), g["feat"], rtol=0, atol=0)
+
+
+def test_segmax_colmax(dev):
+    Fh = _fh()
+    Z = _rand((50 * 20, 70), 1)
+    Zg = Z.to(dev).requires_grad_(True)
+    out = Fh.segmax(Zg, 20)
+    w = _rand((50, 70), 2)
+    (out * w.to(dev)).sum().backward()
+    Zc = Z.clone().requires_grad_(True)
+    oc = Zc.view(50, 20, 70).max(1)[0]
+    (oc * w).sum().backward()
+    assert torch.equal(out.detach().cpu(), oc.detach())
+    assert torch.equal(Zg.grad.cpu(), Zc.grad)
+    Y = _rand((3 * 100, 130), 3)
+    Yg = Y.to(dev).requires_grad_(True)
+    o2 = Fh.colmax(Yg, 3, 100)
+    w2 = _rand((3, 130), 4)
+    (o2 * w2.to(dev)).sum().backward()
+    Yc = Y.clone().requires_grad_(True)
+    o2c = Yc.view(3, 100, 130).max(1)[0]
+    (o2c * w2).sum().backward()
+    assert torch.equal(o2.detach().cpu(), o2c.detach())
+    assert torch.equal(Yg.grad.cpu(), Yc.grad)
+
+
+# ----------------------------------------------------------------------------- fused EdgeConv
+def _torch_edgeconv(xp, idx, W, gamma, beta, rm, rv, training, B, N):
+    """graph feature -> 1x1 conv -> BN2d -> LeakyReLU -> max over k, the reference's way, on [P,C]."""
+    C = xp.shape[1]
+    x = xp.view(B, N, C).transpose(2, 1)
+    f = ref_cpu.graph_feature(x, idx)                                  # [B,2C,N,k]
+    y = torch.einsum("oc,bcnk->bonk", W, f)
+    y = F.batch_norm(y, rm, rv, gamma, beta, training, 0.1, 1e-5)
+    y = F.leaky_relu(y, 0.2).max(dim=-1)[0]                            # [B,Cout,N]
+    return y.transpose(2, 1).reshape(B * N, -1)
+
+
+@pytest.mark.parametrize("B,N,C,Cout,training", [(2, 128, 3, 64, True), (2, 96, 64, 64, True), (3, 64, 64, 128, True),
+                                                 (1, 200, 128, 256, True), (2, 100, 16, 40, False)])
+def test_edgeconv_fwd_bwd(dev, B, N, C, Cout, training):
+    Fh = _fh()
+    k = 20
+    P = B * N
+    xp = _rand((P, C), 1).requires_grad_(True)
+    W = _rand((Cout, 2 * C), 2, 0.3).requires_grad_(True)
+    gamma = (_rand((Cout,), 3) + 0.3).requires_grad_(True)             # ~1/3 negative -> min branch
+    beta = _rand((Cout,), 4).requires_grad_(True)
+    rm, rv = _rand((Cout,), 5) * 0.1, _rand((Cout,), 6).abs() + 0.5
+    dOut = _rand((P, Cout), 7)
+    idx = torch.from_numpy(knn_canon.knn_point_major(xp.detach().view(B, N, C), k).astype(np.int64))
+
+    rm_c, rv_c = rm.clone(), rv.clone()
+    oc = _torch_edgeconv(xp, idx, W, gamma, beta, rm_c, rv_c, training, B, N)
+    oc.backward(dOut)
+
+    xg, Wg, gg, bg = [t.detach().to(dev).requires_grad_(True) for t in (xp, W, gamma, beta)]
+    rm_g, rv_g = rm.to(dev), rv.to(dev)
+    graph = Fh.knn_graph(xg, B, N, k)
+    assert np.array_equal(graph.idx.view(B, N, k).cpu().numpy(), idx.numpy())
+    og = Fh.edgeconv(xg, graph, Wg, gg, bg, rm_g, rv_g, training)
+    og.backward(dOut.to(dev))
+    np.testing.assert_allclose(og.detach().cpu().numpy(), oc.detach().numpy(), rtol=2e-4, atol=2e-4)
+    for got, want, name in [(xg.grad, xp.grad, "dx"), (Wg.grad, W.grad, "dW"), (gg.grad, gamma.grad, "dgamma"),
+                            (bg.grad, beta.grad, "dbeta")]:
+        scale = want.abs().max().item() + 1e-6
+        err = (got.cpu() - want).abs().max().item()
+        assert err / scale < 2e-3, (name, err, scale)
+    if training:
+        np.testing.assert_allclose(rm_g.cpu().numpy(), rm_c.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rv_g.cpu().numpy(), rv_c.numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("fname", ["loss_s0_N256.npz", "loss_s1_N1024.npz"])
+def test_losses_vs_golden(dev, golden_dir, fname):
+    from mlsp_amd import mlsp
+    Fh = _fh()
+    g = dict(np.load(os.path.join(golden_dir, fname)))
+    seed = int(fname.split("_s")[1][0])
+    N = int(fname.split("_N")[1].split(".")[0])
+    args = gc.make_args()
+    inp = {k: v.to(dev) for k, v in gc.make_inputs(seed, 2, N).items()}
+    pred = torch.from_numpy(g["pred"]).to(dev).requires_grad_(True)
+    normal = torch.from_numpy(g["normal"]).to(dev).requires_grad_(True)
+    lg = torch.from_numpy(g["dlogits"]).to(dev).requires_grad_(True)
+    fc2w = (torch.arange(16, dtype=torch.float32) * 2.0).view(1, 16).to(dev)
+    p, dens = Fh.density_tail(lg, fc2w)
+    logits = {"DefRec": pred, "Normal": normal, "density": p, "density_mse": dens}
+    loss_def = mlsp.calc_loss(args, logits, inp["gold"], inp["mask"])
+    mask_cord = inp["mask"].permute(0, 2, 1)[:, :, 0] * 26 + 1
+    nl = mlsp.calc_masked_normal_loss(args, normal, inp["normal_gt"], mask_cord)
+    kl, mae = mlsp.densityloss(args, logits, inp["dens_val"], inp["dens_vec"], mask=mask_cord.reshape(-1))
+    loss = loss_def + nl + kl + mae
+    loss.backward()
+    np.testing.assert_allclose(loss_def.item(), g["loss_DefRec"], rtol=1e-4)
+    np.testing.assert_allclose(nl.item(), g["loss_normal"], rtol=1e-4)
+    np.testing.assert_allclose(kl.item(), g["loss_kl"], rtol=1e-4)
+    np.testing.assert_allclose(mae.item(), g["loss_mae"], rtol=1e-4)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), g["g_pred"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(normal.grad.cpu().numpy(), g["g_normal"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), g["g_dlogits"], rtol=1e-3, atol=1e-7)
+    with torch.no_grad():
+        np.testing.assert_allclose(mlsp.calc_normal_loss(args, normal, inp["normal_gt"]).item(), g["normal_unmasked"], rtol=1e-4)
+        kl_u, mae_u = mlsp.densityloss(args, logits, inp["dens_val"], inp["dens_vec"])
+        np.testing.assert_allclose(kl_u.item(), g["kl_unmasked"], rtol=1e-4)
+        np.testing.assert_allclose(mae_u.item(), g["mae_unmasked"], rtol=1e-4)
+
+
+def test_chamfer_edge_cases(dev):
+    """Empty mask -> NaN like the reference (0/0, mlsp.py:152); all-masked cloud; pred == gold -> 0."""
+    from mlsp_amd import mlsp
+    B, N = 2, 64
+    gold = _rand((B, 3, N), 1)
+    pred = gold.permute(0, 2, 1).contiguous()
+    mask = torch.zeros(B, 3, N)
+    mask[0, :, :10] = 1
+    mask[1] = 1
+    l = mlsp.reconstruction_loss(pred.to(dev), gold.to(dev), mask.to(dev))
+    assert l.item() == 0.0
+    want = ref_cpu.reconstruction_loss(pred + 0.1, gold, mask)
+    got = mlsp.reconstruction_loss((pred + 0.1).to(dev), gold.to(dev), mask.to(dev))
+    np.testing.assert_allclose(got.item(), want.item(), rtol=1e-5)
+    mask[0] = 0
+    assert torch.isnan(mlsp.reconstruction_loss(pred.to(dev), gold.to(dev), mask.to(dev))).item()
