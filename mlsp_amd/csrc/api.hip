@@ -23,6 +23,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
                       const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
                       float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy);
 int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out);
+int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out);
 int launch_colmax_fwd(hipStream_t st, const float* Z, int B, int N, int C, float* out, int* arg);
 int launch_colmax_bwd(hipStream_t st, const float* dOut, const int* arg, int B, int N, int C, float* dZ);
 int launch_segmax_fwd(hipStream_t st, const float* Z, int P, int k, int C, float* out, uint8_t* argk);
@@ -230,7 +231,7 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
     Workspace w(ws, ws_bytes);
     float* dY = has_bn ? w.take<float>((size_t)M * Cout) : nullptr;
     int nparts = bn_stat_parts(M);
-    double* part = has_bn ? w.take<double>((size_t)nparts * 2 * Cout) : nullptr;
+    double* part = (has_bn || dbias) ? w.take<double>((size_t)nparts * 2 * Cout) : nullptr;
     float* mean_dz = has_bn ? w.take<float>(Cout) : nullptr;
     float* mean_dzy = has_bn ? w.take<float>(Cout) : nullptr;
     size_t sf1 = dX ? gemm_slab_floats(M, Cin, Cout) : 0, sf2 = gemm_slab_floats(Cout, Cin, M);
@@ -246,7 +247,15 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
     }
     if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf));
     CHECK(launch_gemm(st, true, false, Cout, Cin, M, g, Cout, X, ldx, dW, Cin, nullptr, nullptr, 0, slab, sf));
-    if (dbias) CHECK(launch_colsum_groups(st, g, 1, M, Cout, dbias));
+    if (dbias) {
+        if (has_bn && training) {
+            // a bias in front of a batch-stat BN has an analytically zero gradient (sum_rows dY == 0)
+            hipError_t e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        } else {
+            CHECK(launch_colsum(st, g, M, Cout, part, dbias));
+        }
+    }
     if (dgbias) CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias));
     return MLSP_OK;
 }

@@ -44,10 +44,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int nparts, 
                                    float* __restrict__ run_mean, float* __restrict__ run_var, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one wave per channel: lanes stride over the partial blocks, fixed-order butterfly -> reproducible
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int i = 0; i < nparts; ++i) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
+    for (int i = threadIdx.x; i < nparts; i += 64) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (threadIdx.x != 0) return;
     double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -137,10 +140,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nparts, double count, int C,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ mean_dz, float* __restrict__ mean_dzy) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int i = 0; i < nparts; ++i) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
+    for (int i = threadIdx.x; i < nparts; i += 64) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (threadIdx.x != 0) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
     mean_dz[c] = (float)(s / count);
@@ -265,7 +270,7 @@ int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double
 int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
                        float* shift, float* save_mean, float* save_invstd) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, nparts, count, C, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, count, C, gamma, beta,
                        run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
     return mlsp_launch_status();
 }
@@ -296,7 +301,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
     int nparts = bn_stat_parts(M);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift,
                        mean, invstd, act, slope, th, inv_keep, seed, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, nparts, (double)M, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, (double)M, C, dgamma,
                        dbeta, mean_dz, mean_dzy);
     size_t total = (size_t)M * C;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dZ, Y, dY, total, C, scale, shift,
@@ -306,8 +311,26 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
 
 int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
                            float* mean_dz, float* mean_dzy) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, nparts, count, C, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, count, C, dgamma, dbeta,
                        mean_dz, mean_dzy);
+    return mlsp_launch_status();
+}
+
+// out[c] = sum over partial blocks of the column sums (first plane of colstats partials)
+__global__ void colsum_finalize_kernel(const double* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[((size_t)i * 2) * C + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+// column sums over all M rows of a [M][C] matrix (bias gradients); part: [bn_stat_parts(M)][2][C] doubles
+int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out) {
+    int nparts = bn_stat_parts(M);
+    hipLaunchKernelGGL(colstats_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, X, M, C, C, part);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, C, out);
     return mlsp_launch_status();
 }
 

@@ -32,6 +32,7 @@ struct GemmArgs {
     int M, N, K, lda, ldb, ldc, rows_per_group;
     int ntm, ntn, nsplit, ksplit;   // tiles; split-K count; K range per split (multiple of BK)
     int a_vec, b_vec;               // 1 if float4 global loads are legal for that operand
+    int xcd_map;                    // 1: XCD-grouped block->tile map (grid padded to a multiple of 8 panels)
 };
 
 // ---- global -> registers for one 128x32 operand tile -----------------------------------------
@@ -106,12 +107,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware tile mapping: all ntn column tiles of a row panel share blockIdx.x % 8
+    // XCD-aware tile mapping (only when there are >= 8 row panels): all ntn column tiles of a row
+    // panel share blockIdx.x % 8, i.e. one XCD's L2 under round-robin dispatch.  With fewer panels
+    // (wgrad, skinny GEMMs) plain order keeps every XCD busy.
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = bid >> 3;
-    const int tn = q % p.ntn;
-    const int tm = (q / p.ntn) * 8 + xcd;
-    if (tm >= p.ntm) return;
+    int tm, tn;
+    if (p.xcd_map) {
+        const int xcd = bid & 7, q = bid >> 3;
+        tn = q % p.ntn;
+        tm = (q / p.ntn) * 8 + xcd;
+        if (tm >= p.ntm) return;
+    } else {
+        tn = bid % p.ntn;
+        tm = bid / p.ntn;
+    }
     const int split = blockIdx.y;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = split * p.ksplit;
@@ -224,7 +233,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     p.a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
     p.b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
     if (ns > 1) { p.C = slab; p.ldc = N; }
-    dim3 grid(((p.ntm + 7) / 8) * 8 * p.ntn, ns);
+    p.xcd_map = p.ntm >= 16 && p.ntn > 1;
+    dim3 grid(p.xcd_map ? ((p.ntm + 7) / 8) * 8 * p.ntn : p.ntm * p.ntn, ns);
     if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p);
     else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, p);

@@ -1,0 +1,78 @@
+"""world_size-2 gloo test (CPU) of the flat-bucket gradient exchange used for the N>1 path."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mlsp_amd.ddp import FlatGradSync
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    model[3].bias.requires_grad = False                       # a frozen parameter stays out of the bucket
+    sync = FlatGradSync(model)
+    opt = sync.wrap(torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.1))
+    assert sync.numel == sum(p.numel() for p in model.parameters() if p.requires_grad)
+    g = torch.Generator().manual_seed(100 + rank)             # different shard per rank
+    x, y = torch.randn(12, 8, generator=g), torch.randn(12, 4, generator=g)
+    opt.zero_grad()
+    ((model(x) - y) ** 2).mean().backward()
+    ((model(x) - y) ** 2).mean().backward()                   # two backwards per step accumulate, ONE all-reduce
+    local = sync.flat.clone()
+    opt.step()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    want = sum(gathered) / world
+    ok_avg = torch.allclose(sync.flat, want, atol=1e-6)
+    ok_views = sync.check_views()
+    w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    ws = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    ok_same = all(torch.equal(ws[0], t) for t in ws)          # replicas stay identical after the step
+    opt.zero_grad()
+    ok_zero = bool((sync.flat == 0).all()) and sync.check_views()
+    q.put((rank, ok_avg, ok_views, ok_same, ok_zero))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
+
+
+def test_single_process_is_identity():
+    from mlsp_amd.ddp import FlatGradSync
+    m = torch.nn.Linear(3, 2)
+    s = FlatGradSync(m)
+    m(torch.ones(4, 3)).sum().backward()
+    before = s.flat.clone()
+    s.allreduce()
+    assert torch.equal(before, s.flat) and s.world_size == 1
+    m.zero_grad(set_to_none=True)                             # a trainer doing this must not break the bucket
+    m(torch.ones(4, 3)).sum().backward()
+    s.allreduce()
+    assert s.check_views() and torch.equal(before, s.flat)
