@@ -130,6 +130,12 @@ int mlsp_density_loss_bwd_f32(const float* pvec, const float* dens, const float*
 int mlsp_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
+/* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP
+ * events on its launch stream.  mlsp_profile_end synchronises those events and fills
+ * out[4] = {total ms in the kernel, launches, sum of algorithmic 2*M*N*K, 0}.  Not for production steps. */
+int mlsp_profile_begin(void);
+int mlsp_profile_end(double* out);
+
 #ifdef __cplusplus
 }
 #endif

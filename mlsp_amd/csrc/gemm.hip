@@ -215,6 +215,42 @@ size_t gemm_slab_floats(int M, int N, int K) {
     return ns > 1 ? (size_t)ns * M * N : 0;
 }
 
+// ---- optional HIP-event profiling of the GEMM launches (bench.py roofline) -----------------------
+// Off by default.  mlsp_profile_begin() arms it; every gemm_f32_kernel launch is then bracketed by two
+// events recorded on the launch stream; mlsp_profile_end() returns {ms, launches, algorithmic FLOP}.
+#include <vector>
+static struct GemmProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev;     // pairs
+    size_t used = 0;
+    double flop = 0.0;
+} g_prof;
+#define PROF_MAX_PAIRS 4096
+
+extern "C" int mlsp_profile_begin(void) {
+    if (g_prof.ev.empty()) {
+        g_prof.ev.resize(2 * PROF_MAX_PAIRS);
+        for (auto& e : g_prof.ev)
+            if (hipEventCreate(&e) != hipSuccess) { g_prof.ev.clear(); return MLSP_ERR_UNSUPPORTED; }
+    }
+    g_prof.used = 0; g_prof.flop = 0.0; g_prof.on = true;
+    return MLSP_OK;
+}
+
+// out[0] = total milliseconds inside gemm_f32_kernel, out[1] = launches, out[2] = sum of 2*M*N*K, out[3] = dropped launches
+extern "C" int mlsp_profile_end(double* out) {
+    g_prof.on = false;
+    double ms = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
+        ms += t;
+    }
+    if (out) { out[0] = ms; out[1] = (double)g_prof.used; out[2] = g_prof.flop; out[3] = 0.0; }
+    return MLSP_OK;
+}
+
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                 size_t slab_floats) {
@@ -235,10 +271,17 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (ns > 1) { p.C = slab; p.ldc = N; }
     p.xcd_map = p.ntm >= 16 && p.ntn > 1;
     dim3 grid(p.xcd_map ? ((p.ntm + 7) / 8) * 8 * p.ntn : p.ntm * p.ntn, ns);
+    const bool prof = g_prof.on && g_prof.used < PROF_MAX_PAIRS;
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p);
     else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p);
+    if (prof) {
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
+        g_prof.used++;
+        g_prof.flop += 2.0 * M * (double)N * K;
+    }
     if (ns > 1) {
         size_t total = (size_t)M * N;
         int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
