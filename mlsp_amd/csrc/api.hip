@@ -6,7 +6,9 @@
 
 // ---- launchers implemented in the other translation units -----------------------------------
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats);
+                float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
+                double* stat_part = nullptr);
+int gemm_stat_parts(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K);
 int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws);
 int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent);
@@ -197,7 +199,9 @@ int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* 
     if (gamma && (!beta || !Y || !bn_save)) return MLSP_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
     Workspace w(ws, ws_bytes);
-    int nparts = bn_stat_parts(M);
+    // BN batch statistics: fused into the GEMM epilogue (one partial per 128-row panel) unless the GEMM splits K
+    const int fused_parts = (gamma && training) ? gemm_stat_parts(M, Cout, Cin) : 0;
+    int nparts = fused_parts ? fused_parts : bn_stat_parts(M);
     double* part = gamma ? w.take<double>((size_t)nparts * 2 * Cout) : nullptr;
     size_t sf = gemm_slab_floats(M, Cout, Cin);
     float* slab = sf ? w.take<float>(sf) : nullptr;
@@ -208,9 +212,10 @@ int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* 
         return launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Z, Cout, bias, gbias, rows_per_group, slab, sf);
     }
     float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
-    CHECK(launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Y, Cout, bias, gbias, rows_per_group, slab, sf));
+    CHECK(launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Y, Cout, bias, gbias, rows_per_group, slab, sf,
+                      fused_parts ? part : nullptr));
     if (training) {
-        CHECK(launch_colstats(st, Y, M, Cout, Cout, part));
+        if (!fused_parts) CHECK(launch_colstats(st, Y, M, Cout, Cout, part));
         CHECK(launch_bn_finalize(st, part, nparts, (double)M, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale, shift,
                                  mean, invstd));
     } else {

@@ -83,6 +83,134 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float* __restric
     }
 }
 
+
+// Vectorised form for Cout in {64,128,256}: LR = Cout/4 lanes cover one neighbour row with 16-byte loads and the
+// wave's 64/LR lane groups take different neighbours of the same point at once (4x fewer load instructions,
+// 16 B per lane in flight); groups are combined with a (value, slot) butterfly that keeps the first-occurrence rule.
+template <int LR>
+__global__ __launch_bounds__(256) void edge_reduce_vec_kernel(const float* __restrict__ uv, const int* __restrict__ idx,
+                                                              const float* __restrict__ gamma, int P, int N, int k,
+                                                              float* __restrict__ msel, uint8_t* __restrict__ argsel,
+                                                              float* __restrict__ s1out, double* __restrict__ part) {
+    constexpr int Cout = LR * 4, NP = 64 / LR;
+    __shared__ double shd[2][4][Cout];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane / LR, c = (lane % LR) * 4;
+    const int ld = 2 * Cout;
+    const int p0 = (blockIdx.x * 4 + w) * EDGE_PTS_PER_WAVE;
+    const f32x4 g4 = *(const f32x4*)(gamma + c);
+    bool use_max[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) use_max[e] = g4[e] >= 0.f;
+    double ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+    for (int pi = 0; pi < EDGE_PTS_PER_WAVE; ++pi) {
+        const int i = p0 + pi;
+        if (i >= P) break;
+        const int base = (i / N) * N;
+        const int* irow = idx + (size_t)i * k;
+        float best[4], s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+        int bs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { best[e] = use_max[e] ? -INFINITY : INFINITY; bs[e] = 255; }
+        for (int s = sub; s < k; s += NP) {
+            const int j = base + irow[s];
+            const f32x4 u = *(const f32x4*)(uv + (size_t)j * ld + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += u[e]; s2[e] = fmaf(u[e], u[e], s2[e]);
+                bool take = use_max[e] ? (u[e] > best[e]) : (u[e] < best[e]);
+                best[e] = take ? u[e] : best[e]; bs[e] = take ? s : bs[e];
+            }
+        }
+#pragma unroll
+        for (int o = LR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float ob = __shfl_xor(best[e], o, 64);
+                int os = __shfl_xor(bs[e], o, 64);
+                s1[e] += __shfl_xor(s1[e], o, 64);
+                s2[e] += __shfl_xor(s2[e], o, 64);
+                bool better = use_max[e] ? (ob > best[e]) : (ob < best[e]);
+                bool take = better || (ob == best[e] && os < bs[e]);
+                best[e] = take ? ob : best[e]; bs[e] = take ? os : bs[e];
+            }
+        }
+        if (sub == 0) {
+            const f32x4 v = *(const f32x4*)(uv + (size_t)i * ld + Cout + c);
+            f32x4 b4, s4;
+            uint32_t a4 = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                b4[e] = best[e]; s4[e] = s1[e]; a4 |= (uint32_t)(bs[e] & 255) << (8 * e);
+                ps[e] += (double)s1[e] + (double)k * v[e];
+                pq[e] += (double)s2[e] + 2.0 * (double)v[e] * s1[e] + (double)k * v[e] * v[e];
+            }
+            *(f32x4*)(msel + (size_t)i * Cout + c) = b4;
+            *(f32x4*)(s1out + (size_t)i * Cout + c) = s4;
+            *(uint32_t*)(argsel + (size_t)i * Cout + c) = a4;
+        }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { shd[0][w][c + e] = ps[e]; shd[1][w][c + e] = pq[e]; }
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < Cout; cc += 256) {
+        part[((size_t)blockIdx.x * 2 + 0) * Cout + cc] = shd[0][0][cc] + shd[0][1][cc] + shd[0][2][cc] + shd[0][3][cc];
+        part[((size_t)blockIdx.x * 2 + 1) * Cout + cc] = shd[1][0][cc] + shd[1][1][cc] + shd[1][2][cc] + shd[1][3][cc];
+    }
+}
+
+// vectorised reverse gather (same lane layout): du_j over rev(j)
+template <int LR>
+__global__ __launch_bounds__(256) void edge_bwd_gather_vec_kernel(const float* __restrict__ gz, const uint8_t* __restrict__ argsel,
+                                                                  const float* __restrict__ uv, const int* __restrict__ rev_off,
+                                                                  const int* __restrict__ rev_ent, int P, int N,
+                                                                  const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ mean_dz,
+                                                                  const float* __restrict__ mean_dzy, float* __restrict__ duv) {
+    constexpr int Cout = LR * 4, NP = 64 / LR;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = blockIdx.x * 4 + w;
+    if (j >= P) return;
+    const int sub = lane / LR, c = (lane % LR) * 4;
+    const int base = (j / N) * N;
+    const int e0 = rev_off[j], e1 = rev_off[j + 1];
+    const int ld = 2 * Cout;
+    float A[4] = {0, 0, 0, 0}, Bc[4] = {0, 0, 0, 0};
+    if (mean_dz) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float sc = scale[c + e]; A[e] = sc * mean_dz[c + e]; Bc[e] = sc * invstd[c + e] * mean_dzy[c + e]; }
+    }
+    float acc[4] = {0, 0, 0, 0};
+    for (int en = e0 + sub; en < e1; en += NP) {
+        const int ent = rev_ent[en];
+        const int i = base + (ent >> 8), slot = ent & 255;
+        const f32x4 g = *(const f32x4*)(gz + (size_t)i * Cout + c);
+        const uint32_t a4 = *(const uint32_t*)(argsel + (size_t)i * Cout + c);
+        const f32x4 v = *(const f32x4*)(uv + (size_t)i * ld + Cout + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float ge = (((a4 >> (8 * e)) & 255) == (uint32_t)slot) ? g[e] : 0.f;
+            acc[e] += ge - Bc[e] * v[e];
+        }
+    }
+#pragma unroll
+    for (int o = LR; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    if (sub == 0) {
+        const f32x4 u = *(const f32x4*)(uv + (size_t)j * ld + c);
+        f32x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = acc[e] - (float)(e1 - e0) * (A[e] + Bc[e] * (u[e] - mean[c + e]));
+        *(f32x4*)(duv + (size_t)j * ld + c) = o4;
+    }
+}
+
 // out = act(scale*(msel + v) + shift)
 __global__ __launch_bounds__(256) void edge_select_act_kernel(const float* __restrict__ msel, const float* __restrict__ uv,
                                                               int P, int Cout, const float* __restrict__ scale,
@@ -243,6 +371,14 @@ int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* 
 }
 int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
                        float* msel, uint8_t* argsel, float* s1, double* part) {
+    const bool al = (((uintptr_t)uv | (uintptr_t)msel | (uintptr_t)s1 | (uintptr_t)gamma) & 15) == 0 && (((uintptr_t)argsel) & 3) == 0;
+    if (al && (Cout == 64 || Cout == 128 || Cout == 256)) {
+        dim3 g(edge_reduce_parts(P)), b(256);
+        if (Cout == 64) hipLaunchKernelGGL((edge_reduce_vec_kernel<16>), g, b, 0, st, uv, idx, gamma, P, N, k, msel, argsel, s1, part);
+        else if (Cout == 128) hipLaunchKernelGGL((edge_reduce_vec_kernel<32>), g, b, 0, st, uv, idx, gamma, P, N, k, msel, argsel, s1, part);
+        else hipLaunchKernelGGL((edge_reduce_vec_kernel<64>), g, b, 0, st, uv, idx, gamma, P, N, k, msel, argsel, s1, part);
+        return mlsp_launch_status();
+    }
     size_t lds = (size_t)8 * Cout * sizeof(double);
     if (lds > 64 * 1024) return MLSP_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(edge_reduce_kernel, dim3(edge_reduce_parts(P)), dim3(256), lds, st, uv, idx, gamma, P, N, Cout, k,
@@ -271,6 +407,14 @@ int launch_edge_bwd_point(hipStream_t st, const float* dOut, const float* out, c
 int launch_edge_bwd_gather(hipStream_t st, const float* gz, const uint8_t* argsel, const float* uv, const int* rev_off,
                            const int* rev_ent, int P, int N, int Cout, const float* scale, const float* mean,
                            const float* invstd, const float* mean_dz, const float* mean_dzy, float* duv) {
+    const bool al = (((uintptr_t)uv | (uintptr_t)gz | (uintptr_t)duv) & 15) == 0 && (((uintptr_t)argsel) & 3) == 0;
+    if (al && (Cout == 64 || Cout == 128 || Cout == 256)) {
+        dim3 g((P + 3) / 4), b(256);
+        if (Cout == 64) hipLaunchKernelGGL((edge_bwd_gather_vec_kernel<16>), g, b, 0, st, gz, argsel, uv, rev_off, rev_ent, P, N, scale, mean, invstd, mean_dz, mean_dzy, duv);
+        else if (Cout == 128) hipLaunchKernelGGL((edge_bwd_gather_vec_kernel<32>), g, b, 0, st, gz, argsel, uv, rev_off, rev_ent, P, N, scale, mean, invstd, mean_dz, mean_dzy, duv);
+        else hipLaunchKernelGGL((edge_bwd_gather_vec_kernel<64>), g, b, 0, st, gz, argsel, uv, rev_off, rev_ent, P, N, scale, mean, invstd, mean_dz, mean_dzy, duv);
+        return mlsp_launch_status();
+    }
     hipLaunchKernelGGL(edge_bwd_gather_kernel, dim3((P + 3) / 4), dim3(256), 0, st, gz, argsel, uv, rev_off, rev_ent, P, N,
                        Cout, scale, mean, invstd, mean_dz, mean_dzy, duv);
     return mlsp_launch_status();

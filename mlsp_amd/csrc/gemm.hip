@@ -33,6 +33,7 @@ struct GemmArgs {
     int ntm, ntn, nsplit, ksplit;   // tiles; split-K count; K range per split (multiple of BK)
     int a_vec, b_vec;               // 1 if float4 global loads are legal for that operand
     int xcd_map;                    // 1: XCD-grouped block->tile map (grid padded to a multiple of 8 panels)
+    double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][N] (BN batch statistics)
 };
 
 // ---- global -> registers for one 128x32 operand tile -----------------------------------------
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
     const bool epi = (p.nsplit == 1);
+    float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -177,9 +179,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                     float v = acc[i][j][r] + bv;
                     if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
                     Cout[(size_t)row * p.ldc + col] = v;
+                    cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
                 }
             }
         }
+    if (p.stat_part) {       // fused BatchNorm statistics: one fp64 partial per 128-row panel and column
+        float* red = smem;   // [wm][sum|sq][128]  (the operand tiles are dead: the k-loop ended on a barrier)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cs[j] += __shfl_xor(cs[j], 32, 64);
+            cq[j] += __shfl_xor(cq[j], 32, 64);
+            if (h == 0) {
+                red[(wm * 2 + 0) * 128 + wn * 64 + j * 32 + l31] = cs[j];
+                red[(wm * 2 + 1) * 128 + wn * 64 + j * 32 + l31] = cq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            p.stat_part[((size_t)tm * 2 + 0) * p.N + n0 + tid] = (double)red[0 * 128 + tid] + (double)red[2 * 128 + tid];
+            p.stat_part[((size_t)tm * 2 + 1) * p.N + n0 + tid] = (double)red[1 * 128 + tid] + (double)red[3 * 128 + tid];
+        }
+    }
 }
 
 // sum the split-K slabs (fixed order -> bitwise reproducible) and apply the epilogue
@@ -209,6 +229,9 @@ int gemm_pick_split(int M, int N, int K) {
     if (ns > 256) ns = 256;
     return ns;
 }
+
+// number of BN-statistic partial rows a stats-fused launch writes (0: the launch would split K, use colstats)
+int gemm_stat_parts(int M, int N, int K) { return gemm_pick_split(M, N, K) == 1 ? (M + BM - 1) / BM : 0; }
 
 size_t gemm_slab_floats(int M, int N, int K) {
     int ns = gemm_pick_split(M, N, K);
@@ -253,7 +276,7 @@ extern "C" int mlsp_profile_end(double* out) {
 
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
-                size_t slab_floats) {
+                size_t slab_floats, double* stat_part = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return MLSP_ERR_ARG;
     if (gbias && rows_per_group <= 0) return MLSP_ERR_ARG;
     GemmArgs p;
@@ -262,6 +285,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     p.ntm = (M + BM - 1) / BM; p.ntn = (N + BN - 1) / BN;
     int ns = gemm_pick_split(M, N, K);
     if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;   // no slab: fall back to one pass
+    if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
+    p.stat_part = stat_part;
     int ktiles = (K + BK - 1) / BK;
     int kts = (ktiles + ns - 1) / ns;
     ns = (ktiles + kts - 1) / kts;
