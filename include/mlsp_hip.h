@@ -73,6 +73,22 @@ int mlsp_edgeconv_bwd_f32(const float* dOut, const float* x, int ldx, const int3
                           int Cout, int k, float* dx, float* dW, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                           mlsp_stream_t stream);
 
+/* Fused per-edge stage of the T-Net (PointDA/model_utils.py:111-115: conv2d1 6->64, conv2d2 64->128 per EDGE, max over k),
+ * dgcnn branch (bias-free convs, LeakyReLU).  x [P][C] point-major (C = 3), W1 [C1][2C], W2 [C2][C1]; requires C1 = 64, C2 = 128
+ * (returns MLSP_ERR_UNSUPPORTED otherwise: use graph_feature + pointmlp + segmax).  out [P][C2].
+ * Saved for backward: uv [P][2*C1], s1 [P][C1], bn1_save [4][C1], zsel [P][C2], argsel [P][C2] u8, bn2_save [4][C2]. */
+int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W1, const float* gamma1, const float* beta1,
+                           float* run_mean1, float* run_var1, const float* W2, const float* gamma2, const float* beta2,
+                           float* run_mean2, float* run_var2, float momentum, float eps, float slope, int training, int B, int N,
+                           int C, int C1, int C2, int k, float* out, float* uv, float* s1, float* bn1_save, float* zsel,
+                           uint8_t* argsel, float* bn2_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int32_t* idx, const int32_t* rev_off,
+                           const int32_t* rev_ent, const float* W1, const float* W2, const float* out, const float* uv,
+                           const float* s1, const float* bn1_save, const float* zsel, const uint8_t* argsel, const float* bn2_save,
+                           float slope, int training, int B, int N, int C, int C1, int C2, int k, float* dx, float* dW1,
+                           float* dgamma1, float* dbeta1, float* dW2, float* dgamma2, float* dbeta2, void* ws, size_t ws_bytes,
+                           mlsp_stream_t stream);
+
 /* Per-row MLP layer = Linear/1x1 conv (+bias) + BatchNorm + act + dropout:
  * conv_2d / fc_layer (model_utils.py:45-87), conv5+bn5 (Models.py:132), head layers (Models.py:192-196,
  * 226-230, 272-279).  W [Cout][Cin] with row pitch ldw (a column slice of a wider weight is legal).  gbias [G][Cout] (nullable) is a per-row-group bias (row r uses group r / rows_per_group):

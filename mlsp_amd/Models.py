@@ -152,7 +152,7 @@ class DGCNN(nn.Module):
 
         # T-Net on the graph feature of the raw cloud (Models.py:111-113)
         g0 = Fh.knn_graph(xp0, B, N, k)
-        T = self.input_transform_net.rows(Fh.graph_feature(xp0, g0), B, N, k)    # [B,3,3]
+        T = self.input_transform_net.points(xp0, g0, B, N, k)                    # [B,3,3]
         xp = torch.bmm(xp0.view(B, N, 3), T.transpose(1, 2)).view(B * N, 3)      # (T @ x)^T
 
         feats = []

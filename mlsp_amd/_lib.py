@@ -29,6 +29,10 @@ SIGNATURES = {
                               _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_edgeconv_bwd_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I,
                               _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_tnet_edge_fwd_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I,
+                               _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_tnet_edge_bwd_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I,
+                               _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_pointmlp_fwd_f32": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
                               _P, _P, _P, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,

@@ -67,6 +67,22 @@ int launch_density_loss_bwd(hipStream_t st, const float* pvec, const float* dens
 int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
                            float* mean_dz, float* mean_dzy);
 
+int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int nsplit);
+int tnet_grid(int ntiles);
+int tnet_points_per_tile(int k);
+int launch_tnet_edge_fwd(hipStream_t st, const float* uv, const int* idx, const float* bn1, const float* W2, const float* gamma2,
+                         int P, int N, int k, float slope, float* zsel, uint8_t* argsel, double* part);
+int launch_tnet_out(hipStream_t st, const float* zsel, const float* bn2, int P, float slope, float* out);
+int launch_tnet_bwd_reduce(hipStream_t st, const float* dT, const float* T, const float* zsel, const float* bn2, int P,
+                           float slope, double* part);
+int launch_tnet_bwd_g(hipStream_t st, const float* dT, const float* T, const float* bn2, const float* mean_dz,
+                      const float* mean_dzy, int P, float slope, float* g, float* coef);
+int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const float* bn1, const float* W2, const float* bn2,
+                         const float* g, const uint8_t* argsel, const float* coef, int P, int N, int k, float slope, float* dhp,
+                         float* dW2part, double* part1);
+int launch_tnet_edge_bwd2(hipStream_t st, const float* dhp, const float* uv, const float* s1, const float* bn1, const float* m1,
+                          const float* m2, const int* rev_off, const int* rev_ent, int P, int N, int k, float* duv);
+
 #define CHECK(x) do { int _r = (x); if (_r != MLSP_OK) return _r; } while (0)
 #define SLAB_BOUND_FLOATS ((size_t)16 << 20)   /* 64 MiB of fp32: bound on any split-K slab (gemm_pick_split) */
 
@@ -188,6 +204,97 @@ int mlsp_edgeconv_bwd_f32(const float* dOut, const float* x, int ldx, const int3
     if (dx) CHECK(launch_gemm(st, false, false, P, C, 2 * Cout, duv, 2 * Cout, Wd, C, dx, C, nullptr, nullptr, 0, slab, sf));
     CHECK(launch_gemm(st, true, false, 2 * Cout, C, P, duv, 2 * Cout, x, ldx, dWd, C, nullptr, nullptr, 0, slab, sf));
     CHECK(launch_unbuild_wd(st, dWd, Cout, C, dW));
+    return MLSP_OK;
+}
+
+int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W1, const float* gamma1, const float* beta1,
+                           float* run_mean1, float* run_var1, const float* W2, const float* gamma2, const float* beta2,
+                           float* run_mean2, float* run_var2, float momentum, float eps, float slope, int training, int B, int N,
+                           int C, int C1, int C2, int k, float* out, float* uv, float* s1, float* bn1_save, float* zsel,
+                           uint8_t* argsel, float* bn2_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (!x || !idx || !W1 || !gamma1 || !beta1 || !W2 || !gamma2 || !beta2 || !out || !uv || !s1 || !bn1_save || !zsel || !argsel ||
+        !bn2_save)
+        return MLSP_ERR_ARG;
+    if (B <= 0 || N <= 0 || C <= 0 || k <= 0 || ldx < C) return MLSP_ERR_ARG;
+    if (C1 != 64 || C2 != 128 || tnet_points_per_tile(k) <= 0) return MLSP_ERR_UNSUPPORTED;
+    const int P = B * N;
+    const int ntiles = (P + tnet_points_per_tile(k) - 1) / tnet_points_per_tile(k);
+    Workspace w(ws, ws_bytes);
+    float* Wd = w.take<float>((size_t)2 * C1 * C);
+    float* msel = w.take<float>((size_t)P * C1);
+    uint8_t* arg1 = w.take<uint8_t>((size_t)P * C1);
+    int np1 = edge_reduce_parts(P), np2 = tnet_grid(ntiles);
+    double* part = w.take<double>((size_t)(np1 > np2 ? np1 : np2) * 2 * C2);
+    size_t sf = gemm_slab_floats(P, 2 * C1, C);
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    CHECK(launch_build_wd(st, W1, C1, C, Wd));
+    CHECK(launch_gemm(st, false, true, P, 2 * C1, C, x, ldx, Wd, C, uv, 2 * C1, nullptr, nullptr, 0, slab, sf));
+    CHECK(launch_edge_reduce(st, uv, idx, gamma1, P, N, C1, k, msel, arg1, s1, part));
+    if (training) {
+        CHECK(launch_bn_finalize(st, part, np1, (double)P * k, C1, gamma1, beta1, run_mean1, run_var1, momentum, eps, bn1_save,
+                                 bn1_save + C1, bn1_save + 2 * C1, bn1_save + 3 * C1));
+    } else {
+        if (!run_mean1 || !run_var1 || !run_mean2 || !run_var2) return MLSP_ERR_ARG;
+        CHECK(launch_bn_eval_prepare(st, C1, gamma1, beta1, run_mean1, run_var1, eps, bn1_save, bn1_save + C1, bn1_save + 2 * C1,
+                                     bn1_save + 3 * C1));
+    }
+    CHECK(launch_tnet_edge_fwd(st, uv, idx, bn1_save, W2, gamma2, P, N, k, slope, zsel, argsel, part));
+    if (training) {
+        CHECK(launch_bn_finalize(st, part, np2, (double)P * k, C2, gamma2, beta2, run_mean2, run_var2, momentum, eps, bn2_save,
+                                 bn2_save + C2, bn2_save + 2 * C2, bn2_save + 3 * C2));
+    } else {
+        CHECK(launch_bn_eval_prepare(st, C2, gamma2, beta2, run_mean2, run_var2, eps, bn2_save, bn2_save + C2, bn2_save + 2 * C2,
+                                     bn2_save + 3 * C2));
+    }
+    CHECK(launch_tnet_out(st, zsel, bn2_save, P, slope, out));
+    return MLSP_OK;
+}
+
+int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int32_t* idx, const int32_t* rev_off,
+                           const int32_t* rev_ent, const float* W1, const float* W2, const float* out, const float* uv,
+                           const float* s1, const float* bn1_save, const float* zsel, const uint8_t* argsel, const float* bn2_save,
+                           float slope, int training, int B, int N, int C, int C1, int C2, int k, float* dx, float* dW1,
+                           float* dgamma1, float* dbeta1, float* dW2, float* dgamma2, float* dbeta2, void* ws, size_t ws_bytes,
+                           mlsp_stream_t st) {
+    if (!dOut || !x || !idx || !rev_off || !rev_ent || !W1 || !W2 || !out || !uv || !s1 || !bn1_save || !zsel || !argsel || !bn2_save ||
+        !dW1 || !dgamma1 || !dbeta1 || !dW2 || !dgamma2 || !dbeta2)
+        return MLSP_ERR_ARG;
+    if (B <= 0 || N <= 0 || C <= 0 || k <= 0 || ldx < C) return MLSP_ERR_ARG;
+    if (C1 != 64 || C2 != 128 || tnet_points_per_tile(k) <= 0) return MLSP_ERR_UNSUPPORTED;
+    const int P = B * N;
+    const size_t E = (size_t)P * k;
+    const int ntiles = (P + tnet_points_per_tile(k) - 1) / tnet_points_per_tile(k);
+    const int nb = tnet_grid(ntiles);
+    Workspace w(ws, ws_bytes);
+    float* Wd = w.take<float>((size_t)2 * C1 * C);
+    float* dWd = w.take<float>((size_t)2 * C1 * C);
+    float* g = w.take<float>((size_t)P * C2);
+    float* coef = w.take<float>(2 * C2);
+    float* dhp = w.take<float>(E * C1);
+    float* dW2part = w.take<float>((size_t)nb * C2 * C1);
+    int npr = (P + 511) / 512;
+    double* part = w.take<double>((size_t)(npr > nb ? npr : nb) * 2 * C2);
+    float* mean_dz = w.take<float>(C2);
+    float* mean_dzy = w.take<float>(C2);
+    float* m1 = w.take<float>(C1);
+    float* m2 = w.take<float>(C1);
+    float* duv = w.take<float>((size_t)P * 2 * C1);
+    size_t sf1 = gemm_slab_floats(P, C, 2 * C1), sf2 = gemm_slab_floats(2 * C1, C, P);
+    size_t sf = sf1 > sf2 ? sf1 : sf2;
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    CHECK(launch_tnet_bwd_reduce(st, dOut, out, zsel, bn2_save, P, slope, part));
+    CHECK(launch_bn_bwd_finalize(st, part, npr, (double)E, C2, dgamma2, dbeta2, mean_dz, mean_dzy));
+    CHECK(launch_tnet_bwd_g(st, dOut, out, bn2_save, training ? mean_dz : nullptr, mean_dzy, P, slope, g, coef));
+    CHECK(launch_tnet_edge_bwd(st, uv, idx, bn1_save, W2, bn2_save, g, argsel, coef, P, N, k, slope, dhp, dW2part, part));
+    CHECK(launch_slab_reduce(st, dW2part, dW2, C2, C1, C1, nb));
+    CHECK(launch_bn_bwd_finalize(st, part, nb, (double)E, C1, dgamma1, dbeta1, m1, m2));
+    CHECK(launch_tnet_edge_bwd2(st, dhp, uv, s1, bn1_save, training ? m1 : nullptr, m2, rev_off, rev_ent, P, N, k, duv));
+    CHECK(launch_build_wd(st, W1, C1, C, Wd));
+    if (dx) CHECK(launch_gemm(st, false, false, P, C, 2 * C1, duv, 2 * C1, Wd, C, dx, C, nullptr, nullptr, 0, slab, sf));
+    CHECK(launch_gemm(st, true, false, 2 * C1, C, P, duv, 2 * C1, x, ldx, dWd, C, nullptr, nullptr, 0, slab, sf));
+    CHECK(launch_unbuild_wd(st, dWd, C1, C, dW1));
     return MLSP_OK;
 }
 

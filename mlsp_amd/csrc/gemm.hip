@@ -217,6 +217,14 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
     }
 }
 
+int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int nsplit) {
+    size_t total = (size_t)M * N;
+    int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, C, M, N, ldc, nsplit, (const float*)nullptr,
+                       (const float*)nullptr, 0);
+    return mlsp_launch_status();
+}
+
 // How many K splits a launch will use (shared by the launcher and mlsp_workspace_bytes).
 int gemm_pick_split(int M, int N, int K) {
     int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;

@@ -1,0 +1,432 @@
+// Fused per-edge stage of the input transform net (T-Net), dgcnn branch:
+//   PointDA/model_utils.py:111-115   x = conv2d1(x0) ; x = conv2d2(x) ; x = x.max(dim=-1)
+// i.e.  t_i = max_s LeakyReLU(BN2( W2 . LeakyReLU(BN1( W1 . [x_j - x_i ; x_i] )) ))   over the k edges of point i.
+//
+// The first conv folds exactly like EdgeConv (edge.hip): hpre_e = u_j + v_i with [u|v] = x [W1a ; W1b-W1a]^T.
+// The second conv (64 -> 128 per edge) cannot be folded; it is the one genuine per-edge contraction of the
+// network and runs here on the matrix cores with everything LDS-resident:
+//   workgroup tile = TP points x k edges (<= 128 rows; 6 x 20 = 120 at k = 20)
+//   Hs [64][129]  hpre, k-major     (gathered from the L2-resident u rows; BN1 + LeakyReLU applied at fragment read)
+//   Ws [128][65]  W2                (odd stride: conflict-free for both the Z and the dH products)
+//   Zs [128][129] Z = H W2^T        (then the per-point max/min over its k rows, BN2 statistics)
+// Neither [E,64] nor [E,128] ever reaches HBM in the forward pass.  Backward recomputes H and Z per tile, forms
+// dZ in LDS from the closed-form BN2 backward, and runs dH = dZ W2 and dW2 += dZ^T H on the matrix cores; only
+// dh' = dH * act'(a) ([E,64]) is written out because BN1's backward needs its global sums before it can be
+// folded onto the points (tnet_edge_bwd2_kernel, a gather over the reverse neighbour index).
+#include "common.h"
+#include <math.h>
+
+#define TN_C1 64
+#define TN_C2 128
+#define TN_ROWS 128
+#define TN_SH 129
+#define TN_SZ 129
+#define TN_SW 65
+#define TN_MAXTP 8
+#define TN_LDS_FLOATS (TN_C1 * TN_SH + TN_C2 * TN_SW + TN_ROWS * TN_SZ + 4 * TN_C1 + 4 * TN_C2 + TN_ROWS + TN_MAXTP * TN_C2 + TN_MAXTP * TN_C2 / 4)
+
+__device__ __forceinline__ float lrelu(float a, float slope) { return a > 0.f ? a : a * slope; }
+
+// gather hpre = u_j + v_i for the rows of one tile into Hs (k-major); invalid rows are zero
+__device__ __forceinline__ void tn_build_h(float* __restrict__ Hs, const float* __restrict__ uv, const int* __restrict__ idx,
+                                           int tile, int TP, int k, int P, int N, int tid) {
+    const int row = tid >> 1, half = tid & 1;
+    const int pt = row / k, s = row - pt * k;
+    const int i = tile * TP + pt;
+    f32x4 hv[8];
+    if (pt < TP && i < P) {
+        const int j = (i / N) * N + idx[(size_t)i * k + s];
+        const f32x4* ur = (const f32x4*)(uv + (size_t)j * 2 * TN_C1 + 32 * half);
+        const f32x4* vr = (const f32x4*)(uv + (size_t)i * 2 * TN_C1 + TN_C1 + 32 * half);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hv[q] = ur[q] + vr[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Hs[(32 * half + 4 * q + e) * TN_SH + row] = hv[q][e];
+}
+
+// Z tile = H W2^T  (H = LeakyReLU(scale1*hpre + shift1), zero on invalid rows) -> Zs[row][o]
+__device__ __forceinline__ void tn_compute_z(const float* __restrict__ Hs, const float* __restrict__ Ws,
+                                             const float* __restrict__ S1, float* __restrict__ Zs, int nvalid, float slope,
+                                             int wm, int wn, int l31, int h) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int r0 = wm * 64 + l31, r1 = r0 + 32;
+    const bool v0 = r0 < nvalid, v1 = r1 < nvalid;
+    const int o0 = wn * 64 + l31, o1 = o0 + 32;
+#pragma unroll 8
+    for (int t = 0; t < TN_C1 / 2; ++t) {
+        const int c = 2 * t + h;
+        const float sc = S1[c], sh = S1[TN_C1 + c];
+        float a0 = v0 ? lrelu(fmaf(Hs[c * TN_SH + r0], sc, sh), slope) : 0.f;
+        float a1 = v1 ? lrelu(fmaf(Hs[c * TN_SH + r1], sc, sh), slope) : 0.f;
+        float b0 = Ws[o0 * TN_SW + c], b1 = Ws[o1 * TN_SW + c];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Zs[row * TN_SZ + wn * 64 + j * 32 + l31] = acc[i][j][r];
+            }
+}
+
+struct TnetFwdArgs {
+    const float* uv; const int* idx; const float* bn1; const float* W2; const float* gamma2;
+    float* zsel; uint8_t* argsel; double* part;    // part: [gridDim.x][2][128]
+    int P, N, k, TP, ntiles; float slope;
+};
+
+__global__ __launch_bounds__(256) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Hs = sm;
+    float* Ws = Hs + TN_C1 * TN_SH;
+    float* Zs = Ws + TN_C2 * TN_SW;
+    float* S1 = Zs + TN_ROWS * TN_SZ;               // scale1[64], shift1[64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    for (int e = tid; e < TN_C2 * TN_C1; e += 256) Ws[(e >> 6) * TN_SW + (e & 63)] = p.W2[e];
+    if (tid < 2 * TN_C1) S1[tid] = p.bn1[tid];
+    const int o = tid & 127;
+    const bool use_max = p.gamma2[o] >= 0.f;
+    double ssum = 0.0, ssq = 0.0;
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();
+        tn_build_h(Hs, p.uv, p.idx, tile, p.TP, p.k, p.P, p.N, tid);
+        __syncthreads();
+        const int npts = min(p.TP, p.P - tile * p.TP);
+        tn_compute_z(Hs, Ws, S1, Zs, npts * p.k, p.slope, wm, wn, l31, h);
+        __syncthreads();
+        for (int item = tid; item < npts * TN_C2; item += 256) {
+            const int pt = item >> 7;
+            const size_t i = (size_t)tile * p.TP + pt;
+            const float* z = Zs + (pt * p.k) * TN_SZ + o;
+            float best = z[0], s1 = z[0], s2 = z[0] * z[0];
+            int bs = 0;
+            for (int s = 1; s < p.k; ++s) {
+                float v = z[s * TN_SZ];
+                s1 += v; s2 = fmaf(v, v, s2);
+                bool take = use_max ? (v > best) : (v < best);
+                best = take ? v : best; bs = take ? s : bs;
+            }
+            p.zsel[i * TN_C2 + o] = best;
+            p.argsel[i * TN_C2 + o] = (uint8_t)bs;
+            ssum += s1; ssq += s2;
+        }
+    }
+    __syncthreads();
+    double* red = (double*)Zs;                       // [2][256]
+    red[tid] = ssum; red[256 + tid] = ssq;
+    __syncthreads();
+    if (tid < TN_C2) {
+        p.part[((size_t)blockIdx.x * 2 + 0) * TN_C2 + tid] = red[tid] + red[tid + 128];
+        p.part[((size_t)blockIdx.x * 2 + 1) * TN_C2 + tid] = red[256 + tid] + red[256 + tid + 128];
+    }
+}
+
+// t = act(scale2 * zsel + shift2)        [P][128]
+__global__ __launch_bounds__(256) void tnet_out_kernel(const float* __restrict__ zsel, const float* __restrict__ bn2, size_t total,
+                                                       float slope, float* __restrict__ out) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(t & (TN_C2 - 1));
+        out[t] = lrelu(fmaf(zsel[t], bn2[c], bn2[TN_C2 + c]), slope);
+    }
+}
+
+// backward pre-pass over the points: partial sums of dz and dz*zhat_sel (BN2), dz = dt * act'(t)
+__global__ __launch_bounds__(256) void tnet_bwd_reduce_kernel(const float* __restrict__ dT, const float* __restrict__ T,
+                                                              const float* __restrict__ zsel, const float* __restrict__ bn2,
+                                                              int P, float slope, double* __restrict__ part) {
+    __shared__ double sh[2][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * 512, r1 = min(P, r0 + 512);
+    const float mu = bn2[2 * TN_C2 + c], is = bn2[3 * TN_C2 + c];
+    double s = 0.0, q = 0.0;
+    for (int r = r0 + w; r < r1; r += 4) {
+        size_t t = (size_t)r * TN_C2 + c;
+        float d = dT[t];
+        if (!(T[t] > 0.f)) d *= slope;
+        s += d; q += (double)d * ((zsel[t] - mu) * is);
+    }
+    sh[0][w][lane] = s; sh[1][w][lane] = q;
+    __syncthreads();
+    if (w == 0) {
+        part[((size_t)blockIdx.y * 2 + 0) * TN_C2 + c] = sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane];
+        part[((size_t)blockIdx.y * 2 + 1) * TN_C2 + c] = sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane];
+    }
+}
+
+// g = scale2 * dz  [P][128];  coef[0..127] = A2 = scale2*mean_dz, coef[128..255] = B2 = scale2*invstd2*mean_dzy
+__global__ __launch_bounds__(256) void tnet_bwd_g_kernel(const float* __restrict__ dT, const float* __restrict__ T,
+                                                         const float* __restrict__ bn2, const float* __restrict__ mean_dz,
+                                                         const float* __restrict__ mean_dzy, size_t total, float slope,
+                                                         float* __restrict__ g, float* __restrict__ coef) {
+    size_t t0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t0 < TN_C2) {
+        float sc = bn2[t0];
+        coef[t0] = mean_dz ? sc * mean_dz[t0] : 0.f;
+        coef[TN_C2 + t0] = mean_dz ? sc * bn2[3 * TN_C2 + t0] * mean_dzy[t0] : 0.f;
+    }
+    for (size_t t = t0; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(t & (TN_C2 - 1));
+        float d = dT[t];
+        if (!(T[t] > 0.f)) d *= slope;
+        g[t] = bn2[c] * d;
+    }
+}
+
+struct TnetBwdArgs {
+    const float* uv; const int* idx; const float* bn1; const float* W2; const float* bn2;
+    const float* g; const uint8_t* argsel; const float* coef;    // coef: A2[128], B2[128]
+    float* dhp;            // [E][64]  dh' = dH * act'(a)
+    float* dW2part;        // [gridDim.x][128*64]
+    double* part1;         // [gridDim.x][2][64]   sums of dh' and dh'*hhat (BN1 backward)
+    int P, N, k, TP, ntiles; float slope;
+};
+
+__global__ __launch_bounds__(256) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Hs = sm;
+    float* Ws = Hs + TN_C1 * TN_SH;
+    float* Zs = Ws + TN_C2 * TN_SW;
+    float* S1 = Zs + TN_ROWS * TN_SZ;               // scale1, shift1, mean1, invstd1   [4][64]
+    float* C2 = S1 + 4 * TN_C1;                     // A2, B2, mean2, (unused)          [4][128]
+    int* rowpt = (int*)(C2 + 4 * TN_C2);            // [128]  packed (pt << 8 | s), -1 = invalid
+    float* gs = (float*)(rowpt + TN_ROWS);          // [TP<=8][128] g tile
+    uint8_t* as = (uint8_t*)(gs + TN_MAXTP * TN_C2);   // [TP<=8][128] argsel tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    for (int e = tid; e < TN_C2 * TN_C1; e += 256) Ws[(e >> 6) * TN_SW + (e & 63)] = p.W2[e];
+    S1[tid] = p.bn1[tid];                            // 256 = 4*64
+    if (tid < 2 * TN_C2) C2[tid] = p.coef[tid];
+    if (tid < TN_C2) C2[2 * TN_C2 + tid] = p.bn2[2 * TN_C2 + tid];
+
+    f32x16 accW[2];                                   // dW2 rows o = 32*wave + map(r,h), cols c = 32*ct + l31
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[ct][r] = 0.f;
+    double sd[2] = {0.0, 0.0}, sdh[2] = {0.0, 0.0};
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();
+        const int npts = min(p.TP, p.P - tile * p.TP);
+        const int nvalid = npts * p.k;
+        tn_build_h(Hs, p.uv, p.idx, tile, p.TP, p.k, p.P, p.N, tid);
+        if (tid < TN_ROWS) {
+            int pt = tid / p.k, s = tid - pt * p.k;
+            rowpt[tid] = tid < nvalid ? ((pt << 8) | s) : -1;
+        }
+        for (int e = tid; e < npts * TN_C2; e += 256) {
+            size_t gi = (size_t)tile * p.TP * TN_C2 + e;
+            gs[e] = p.g[gi];
+            as[e] = p.argsel[gi];
+        }
+        __syncthreads();
+        tn_compute_z(Hs, Ws, S1, Zs, nvalid, p.slope, wm, wn, l31, h);
+        __syncthreads();
+        // dZ in place:  g*[s == argsel] - A2 - B2*(Z - mean2)   on valid rows, 0 elsewhere
+        {
+            const int o = tid & 127;
+            const float A2 = C2[o], B2 = C2[TN_C2 + o], m2 = C2[2 * TN_C2 + o];
+            for (int row = tid >> 7; row < TN_ROWS; row += 2) {
+                const int rp = rowpt[row];
+                float dz = 0.f;
+                if (rp >= 0) {
+                    const int pt = rp >> 8, s = rp & 255;
+                    const float z = Zs[row * TN_SZ + o];
+                    dz = ((int)as[pt * TN_C2 + o] == s ? gs[pt * TN_C2 + o] : 0.f) - A2 - B2 * (z - m2);
+                }
+                Zs[row * TN_SZ + o] = dz;
+            }
+        }
+        __syncthreads();
+        // dH[row][c] = sum_o dZ[row][o] W2[o][c]        wave w: rows 32w.., both 32-column halves
+        f32x16 accH[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accH[ct][r] = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < TN_C2 / 2; ++t) {
+            const int o = 2 * t + h;
+            float a = Zs[(32 * wave + l31) * TN_SZ + o];
+            float b0 = Ws[o * TN_SW + l31], b1 = Ws[o * TN_SW + 32 + l31];
+            accH[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accH[0], 0, 0, 0);
+            accH[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, accH[1], 0, 0, 0);
+        }
+        // dW2[o][c] += sum_row dZ[row][o] H[row][c]      wave w: o-tile w
+        {
+            const float sc0 = S1[l31], sh0 = S1[TN_C1 + l31], sc1 = S1[32 + l31], sh1 = S1[TN_C1 + 32 + l31];
+#pragma unroll 8
+            for (int t = 0; t < TN_ROWS / 2; ++t) {
+                const int row = 2 * t + h;
+                const bool v = row < nvalid;
+                float a = Zs[row * TN_SZ + 32 * wave + l31];
+                float b0 = v ? lrelu(fmaf(Hs[l31 * TN_SH + row], sc0, sh0), p.slope) : 0.f;
+                float b1 = v ? lrelu(fmaf(Hs[(32 + l31) * TN_SH + row], sc1, sh1), p.slope) : 0.f;
+                accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accW[0], 0, 0, 0);
+                accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, accW[1], 0, 0, 0);
+            }
+        }
+        // dh' = dH * act'(a), write valid rows; BN1-backward sums
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int c = 32 * ct + l31;
+            const float sc = S1[c], sh = S1[TN_C1 + c], mu = S1[2 * TN_C1 + c], is = S1[3 * TN_C1 + c];
+            float lsd = 0.f, lsdh = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < nvalid) {
+                    const float hp = Hs[c * TN_SH + row];
+                    const float a = fmaf(hp, sc, sh);
+                    const float d = accH[ct][r] * (a > 0.f ? 1.f : p.slope);
+                    p.dhp[((size_t)tile * p.TP * p.k + row) * TN_C1 + c] = d;
+                    lsd += d; lsdh = fmaf(d, (hp - mu) * is, lsdh);
+                }
+            }
+            sd[ct] += lsd; sdh[ct] += lsdh;
+        }
+    }
+    // write the per-block partials
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            p.dW2part[(size_t)blockIdx.x * TN_C2 * TN_C1 + o * TN_C1 + 32 * ct + l31] = accW[ct][r];
+        }
+    __syncthreads();
+    double* red = (double*)Zs;                       // [4 waves][2 kinds][64 c]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        double a = sd[ct] + __shfl_xor(sd[ct], 32, 64);
+        double b = sdh[ct] + __shfl_xor(sdh[ct], 32, 64);
+        if (h == 0) { red[(wave * 2 + 0) * 64 + 32 * ct + l31] = a; red[(wave * 2 + 1) * 64 + 32 * ct + l31] = b; }
+    }
+    __syncthreads();
+    if (tid < 2 * TN_C1) {
+        const int kind = tid >> 6, c = tid & 63;
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += red[(w * 2 + kind) * 64 + c];
+        p.part1[((size_t)blockIdx.x * 2 + kind) * TN_C1 + c] = s;
+    }
+}
+
+// Fold dh' onto the points (BN1 backward in closed form), wave per point, lane = channel (64):
+//   g_e = scale1*(dh'_e - m1 - hhat_e*m2);  dv_i = sum_s g_(i,s);  du_j = sum_{e in rev(j)} g_e
+__global__ __launch_bounds__(256) void tnet_edge_bwd2_kernel(const float* __restrict__ dhp, const float* __restrict__ uv,
+                                                             const float* __restrict__ s1, const float* __restrict__ bn1,
+                                                             const float* __restrict__ m1v, const float* __restrict__ m2v,
+                                                             const int* __restrict__ rev_off, const int* __restrict__ rev_ent,
+                                                             int P, int N, int k, float* __restrict__ duv) {
+    const int c = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = blockIdx.x * 4 + w;
+    if (j >= P) return;
+    const int base = (j / N) * N;
+    const float sc = bn1[c], mu = bn1[2 * TN_C1 + c], is = bn1[3 * TN_C1 + c];
+    const float m1 = m1v ? m1v[c] : 0.f, m2 = m1v ? m2v[c] : 0.f;
+    const float u = uv[(size_t)j * 2 * TN_C1 + c], v = uv[(size_t)j * 2 * TN_C1 + TN_C1 + c];
+    float S = 0.f;
+    for (int s = 0; s < k; ++s) S += dhp[((size_t)j * k + s) * TN_C1 + c];
+    const float fk = (float)k;
+    float dv = sc * (S - fk * m1 - m2 * is * (s1[(size_t)j * TN_C1 + c] + fk * (v - mu)));
+    const int e0 = rev_off[j], e1 = rev_off[j + 1];
+    float R = 0.f, Vs = 0.f;
+    for (int e = e0; e < e1; ++e) {
+        const int ent = rev_ent[e];
+        const int i = base + (ent >> 8);
+        R += dhp[((size_t)i * k + (ent & 255)) * TN_C1 + c];
+        Vs += uv[(size_t)i * 2 * TN_C1 + TN_C1 + c];
+    }
+    const float deg = (float)(e1 - e0);
+    float du = sc * (R - deg * m1 - m2 * is * (deg * (u - mu) + Vs));
+    duv[(size_t)j * 2 * TN_C1 + c] = du;
+    duv[(size_t)j * 2 * TN_C1 + TN_C1 + c] = dv;
+}
+
+// ---------------------------------------------------------------------------------------------
+int tnet_grid(int ntiles) { return ntiles < 512 ? ntiles : 512; }
+int tnet_points_per_tile(int k) { return k > 0 && k <= TN_ROWS ? (TN_ROWS / k > 8 ? 8 : TN_ROWS / k) : 0; }
+
+static int tnet_set_lds(const void* fn) {
+    size_t lds = (size_t)TN_LDS_FLOATS * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return e == hipSuccess ? MLSP_OK : (int)e;
+}
+
+int launch_tnet_edge_fwd(hipStream_t st, const float* uv, const int* idx, const float* bn1, const float* W2, const float* gamma2,
+                         int P, int N, int k, float slope, float* zsel, uint8_t* argsel, double* part) {
+    TnetFwdArgs a;
+    a.uv = uv; a.idx = idx; a.bn1 = bn1; a.W2 = W2; a.gamma2 = gamma2; a.zsel = zsel; a.argsel = argsel; a.part = part;
+    a.P = P; a.N = N; a.k = k; a.TP = tnet_points_per_tile(k); a.slope = slope;
+    if (a.TP <= 0) return MLSP_ERR_UNSUPPORTED;
+    a.ntiles = (P + a.TP - 1) / a.TP;
+    int rc = tnet_set_lds((const void*)tnet_edge_fwd_kernel);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tnet_edge_fwd_kernel, dim3(tnet_grid(a.ntiles)), dim3(256), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
+    return mlsp_launch_status();
+}
+
+int launch_tnet_out(hipStream_t st, const float* zsel, const float* bn2, int P, float slope, float* out) {
+    size_t total = (size_t)P * TN_C2;
+    size_t b = (total + 255) / 256;
+    hipLaunchKernelGGL(tnet_out_kernel, dim3((unsigned)(b < 4096 ? b : 4096)), dim3(256), 0, st, zsel, bn2, total, slope, out);
+    return mlsp_launch_status();
+}
+
+int launch_tnet_bwd_reduce(hipStream_t st, const float* dT, const float* T, const float* zsel, const float* bn2, int P,
+                           float slope, double* part) {
+    hipLaunchKernelGGL(tnet_bwd_reduce_kernel, dim3(TN_C2 / 64, (P + 511) / 512), dim3(256), 0, st, dT, T, zsel, bn2, P, slope, part);
+    return mlsp_launch_status();
+}
+
+int launch_tnet_bwd_g(hipStream_t st, const float* dT, const float* T, const float* bn2, const float* mean_dz,
+                      const float* mean_dzy, int P, float slope, float* g, float* coef) {
+    size_t total = (size_t)P * TN_C2;
+    size_t b = (total + 255) / 256;
+    hipLaunchKernelGGL(tnet_bwd_g_kernel, dim3((unsigned)(b < 4096 ? b : 4096)), dim3(256), 0, st, dT, T, bn2, mean_dz, mean_dzy,
+                       total, slope, g, coef);
+    return mlsp_launch_status();
+}
+
+int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const float* bn1, const float* W2, const float* bn2,
+                         const float* g, const uint8_t* argsel, const float* coef, int P, int N, int k, float slope, float* dhp,
+                         float* dW2part, double* part1) {
+    TnetBwdArgs a;
+    a.uv = uv; a.idx = idx; a.bn1 = bn1; a.W2 = W2; a.bn2 = bn2; a.g = g; a.argsel = argsel; a.coef = coef;
+    a.dhp = dhp; a.dW2part = dW2part; a.part1 = part1;
+    a.P = P; a.N = N; a.k = k; a.TP = tnet_points_per_tile(k); a.slope = slope;
+    if (a.TP <= 0) return MLSP_ERR_UNSUPPORTED;
+    a.ntiles = (P + a.TP - 1) / a.TP;
+    int rc = tnet_set_lds((const void*)tnet_edge_bwd_kernel);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tnet_edge_bwd_kernel, dim3(tnet_grid(a.ntiles)), dim3(256), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
+    return mlsp_launch_status();
+}
+
+int launch_tnet_edge_bwd2(hipStream_t st, const float* dhp, const float* uv, const float* s1, const float* bn1, const float* m1,
+                          const float* m2, const int* rev_off, const int* rev_ent, int P, int N, int k, float* duv) {
+    hipLaunchKernelGGL(tnet_edge_bwd2_kernel, dim3((P + 3) / 4), dim3(256), 0, st, dhp, uv, s1, bn1, m1, m2, rev_off, rev_ent, P, N,
+                       k, duv);
+    return mlsp_launch_status();
+}

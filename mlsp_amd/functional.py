@@ -179,6 +179,68 @@ def edgeconv(xp, graph, W2d, gamma, beta, run_mean, run_var, training, act=ACT_L
     return _EdgeConv.apply(xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps)
 
 
+class _TnetEdge(Function):
+    @staticmethod
+    def forward(ctx, xp, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, graph, training, slope, momentum, eps):
+        lib = _lib.load()
+        xp = _rows(xp)
+        _lib.require_gpu(xp, W1, W2)
+        W1, W2 = W1.contiguous(), W2.contiguous()
+        P, C = xp.shape
+        C1, C2 = W1.shape[0], W2.shape[0]
+        assert W1.shape[1] == 2 * C and W2.shape[1] == C1
+        dev = xp.device
+        out = torch.empty((P, C2), dtype=torch.float32, device=dev)
+        uv = torch.empty((P, 2 * C1), dtype=torch.float32, device=dev)
+        s1 = torch.empty((P, C1), dtype=torch.float32, device=dev)
+        bn1 = torch.empty((4, C1), dtype=torch.float32, device=dev)
+        zsel = torch.empty((P, C2), dtype=torch.float32, device=dev)
+        argsel = torch.empty((P, C2), dtype=torch.uint8, device=dev)
+        bn2 = torch.empty((4, C2), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, P * graph.k, C1, C1)
+        _lib.check(lib.mlsp_tnet_edge_fwd_f32(
+            xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W1.data_ptr(), g1.data_ptr(), b1.data_ptr(), _lib.ptr(rm1),
+            _lib.ptr(rv1), W2.data_ptr(), g2.data_ptr(), b2.data_ptr(), _lib.ptr(rm2), _lib.ptr(rv2), momentum, eps, slope,
+            int(training), graph.B, graph.N, C, C1, C2, graph.k, out.data_ptr(), uv.data_ptr(), s1.data_ptr(), bn1.data_ptr(),
+            zsel.data_ptr(), argsel.data_ptr(), bn2.data_ptr(), ws, wsn, _lib.stream()), "mlsp_tnet_edge_fwd_f32")
+        ctx.save_for_backward(xp, W1, W2, out, uv, s1, bn1, zsel, argsel, bn2)
+        ctx.cfg = (graph, training, slope, C, C1, C2)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dOut):
+        lib = _lib.load()
+        xp, W1, W2, out, uv, s1, bn1, zsel, argsel, bn2 = ctx.saved_tensors
+        graph, training, slope, C, C1, C2 = ctx.cfg
+        dOut = dOut.contiguous()
+        dev = dOut.device
+        P = xp.shape[0]
+        dx = torch.empty((P, C), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dW1, dW2 = torch.empty_like(W1), torch.empty_like(W2)
+        dg1 = torch.empty((C1,), dtype=torch.float32, device=dev)
+        db1 = torch.empty((C1,), dtype=torch.float32, device=dev)
+        dg2 = torch.empty((C2,), dtype=torch.float32, device=dev)
+        db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, P * graph.k, C1, C1)
+        _lib.check(lib.mlsp_tnet_edge_bwd_f32(
+            dOut.data_ptr(), xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), graph.rev_off.data_ptr(),
+            graph.rev_ent.data_ptr(), W1.data_ptr(), W2.data_ptr(), out.data_ptr(), uv.data_ptr(), s1.data_ptr(), bn1.data_ptr(),
+            zsel.data_ptr(), argsel.data_ptr(), bn2.data_ptr(), slope, int(training), graph.B, graph.N, C, C1, C2, graph.k,
+            _lib.ptr(dx), dW1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
+            ws, wsn, _lib.stream()), "mlsp_tnet_edge_bwd_f32")
+        return (dx, dW1, dg1, db1, None, None, dW2, dg2, db2) + (None,) * 7
+
+
+def tnet_edge(xp, graph, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, training, slope=0.2, momentum=0.1, eps=1e-5):
+    """Fused T-Net per-edge stage (model_utils.py:111-115): [P,C] -> [P,128]; needs C1 = 64, C2 = 128."""
+    return _TnetEdge.apply(xp, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, graph, training, slope, momentum, eps)
+
+
+def tnet_edge_supported(W1, W2, k):
+    return W1.shape[0] == 64 and tuple(W2.shape) == (128, 64) and 1 <= k <= 128
+
+
 class _PointMLP(Function):
     @staticmethod
     def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,

@@ -141,6 +141,26 @@ class transform_net(nn.Module):
             rows_per_cloud = N
         else:
             rows_per_cloud = N * k
+        return self._tail(h, B, rows_per_cloud)
+
+    def points(self, xp, graph, B, N, k):
+        """xp [B*N, in_ch/2] raw points + their kNN graph -> T [B,K,K].  Uses the fused LDS-resident per-edge
+        kernel (tnet.hip) when the layer sizes are the DGCNN ones, else the materialised graph feature."""
+        c1, b1 = self.conv2d1.conv[0], self.conv2d1.conv[1]
+        c2, b2 = self.conv2d2.conv[0], self.conv2d2.conv[1]
+        W1 = c1.weight.view(c1.out_channels, c1.in_channels)
+        W2 = c2.weight.view(c2.out_channels, c2.in_channels)
+        fused = (self.dg and c1.bias is None and c2.bias is None and W1.shape[1] == 2 * xp.shape[1] and
+                 self.conv2d1.act == Fh.ACT_LRELU and Fh.tnet_edge_supported(W1, W2, k))
+        if not fused:
+            return self.rows(Fh.graph_feature(xp, graph), B, N, k)
+        rm1, rv1 = _bn_buffers(b1, self.training)
+        rm2, rv2 = _bn_buffers(b2, self.training)
+        h = Fh.tnet_edge(xp, graph, W1, b1.weight, b1.bias, rm1, rv1, W2, b2.weight, b2.bias, rm2, rv2, self.training,
+                         slope=0.2, momentum=b1.momentum, eps=b1.eps)
+        return self._tail(h, B, N)
+
+    def _tail(self, h, B, rows_per_cloud):
         h = self.conv2d3.rows(h)
         h = Fh.colmax(h, B, rows_per_cloud)                      # [B, 1024]    (model_utils.py:117)
         h = self.fc1(h)

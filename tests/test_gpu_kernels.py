@@ -369,3 +369,48 @@ def test_chamfer_edge_cases(dev):
     np.testing.assert_allclose(got.item(), want.item(), rtol=1e-5)
     mask[0] = 0
     assert torch.isnan(mlsp.reconstruction_loss(pred.to(dev), gold.to(dev), mask.to(dev))).item()
+
+
+# ----------------------------------------------------------------------------- fused T-Net per-edge stage
+@pytest.mark.parametrize("B,N,k,training", [(2, 128, 20, True), (3, 50, 20, True), (1, 77, 7, True), (2, 64, 20, False)])
+def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
+    """tnet.hip (LDS-resident gather + MFMA) against the reference's op sequence in torch on the CPU:
+    graph feature -> conv 6->64 + BN + LReLU -> conv 64->128 + BN + LReLU -> max over k."""
+    Fh = _fh()
+    P = B * N
+    xp = _rand((P, 3), 1).requires_grad_(True)
+    W1 = _rand((64, 6), 2, 0.5).requires_grad_(True)
+    W2 = _rand((128, 64), 3, 0.2).requires_grad_(True)
+    g1 = (_rand((64,), 4) + 0.3).requires_grad_(True)
+    b1 = _rand((64,), 5).requires_grad_(True)
+    g2 = (_rand((128,), 6) + 0.3).requires_grad_(True)
+    b2 = _rand((128,), 7).requires_grad_(True)
+    rms = [_rand((64,), 8) * 0.1, _rand((64,), 9).abs() + 0.5, _rand((128,), 10) * 0.1, _rand((128,), 11).abs() + 0.5]
+    dOut = _rand((P, 128), 12)
+    idx = torch.from_numpy(knn_canon.knn_point_major(xp.detach().view(B, N, 3), k).astype(np.int64))
+
+    rc = [t.clone() for t in rms]
+    x = xp.view(B, N, 3).transpose(2, 1)
+    f = ref_cpu.graph_feature(x, idx)
+    y = torch.einsum("oc,bcnk->bonk", W1, f)
+    y = F.leaky_relu(F.batch_norm(y, rc[0], rc[1], g1, b1, training, 0.1, 1e-5), 0.2)
+    z = torch.einsum("oc,bcnk->bonk", W2, y)
+    z = F.leaky_relu(F.batch_norm(z, rc[2], rc[3], g2, b2, training, 0.1, 1e-5), 0.2)
+    oc = z.max(dim=-1)[0].transpose(2, 1).reshape(P, 128)
+    oc.backward(dOut)
+
+    leaves = [xp, W1, g1, b1, W2, g2, b2]
+    gl = [t.detach().to(dev).requires_grad_(True) for t in leaves]
+    rg = [t.to(dev) for t in rms]
+    graph = Fh.knn_graph(gl[0], B, N, k)
+    assert np.array_equal(graph.idx.view(B, N, k).cpu().numpy(), idx.numpy())
+    og = Fh.tnet_edge(gl[0], graph, gl[1], gl[2], gl[3], rg[0], rg[1], gl[4], gl[5], gl[6], rg[2], rg[3], training)
+    og.backward(dOut.to(dev))
+    np.testing.assert_allclose(og.detach().cpu().numpy(), oc.detach().numpy(), rtol=3e-4, atol=3e-4)
+    for got, want, name in zip([t.grad for t in gl], [t.grad for t in leaves], ["dx", "dW1", "dg1", "db1", "dW2", "dg2", "db2"]):
+        scale = want.abs().max().item() + 1e-6
+        err = (got.cpu() - want).abs().max().item()
+        assert err / scale < 3e-3, (name, err, scale)
+    if training:
+        for a, b in zip(rg, rc):
+            np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
