@@ -13,6 +13,7 @@ size_t gemm_slab_floats(int M, int N, int K);
 int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws);
 int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent);
 int bn_stat_parts(int M);
+int bn_parts_max(int M);
 int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double* part);
 int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
@@ -31,6 +32,7 @@ int launch_colmax_bwd(hipStream_t st, const float* dOut, const int* arg, int B, 
 int launch_segmax_fwd(hipStream_t st, const float* Z, int P, int k, int C, float* out, uint8_t* argk);
 int launch_segmax_bwd(hipStream_t st, const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ);
 int edge_reduce_parts(int P);
+int edge_bwd_reduce_parts(int P, int Cout, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f);
 int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd);
 int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW);
 int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
@@ -186,7 +188,7 @@ int mlsp_edgeconv_bwd_f32(const float* dOut, const float* x, int ldx, const int3
     float* dWd = w.take<float>((size_t)2 * Cout * C);
     float* gz = w.take<float>((size_t)P * Cout);
     float* duv = w.take<float>((size_t)P * 2 * Cout);
-    int nparts = (P + 511) / 512;
+    int nparts = bn_parts_max(P);
     double* part = w.take<double>((size_t)nparts * 2 * Cout);
     float* mean_dz = w.take<float>(Cout);
     float* mean_dzy = w.take<float>(Cout);
@@ -196,7 +198,8 @@ int mlsp_edgeconv_bwd_f32(const float* dOut, const float* x, int ldx, const int3
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float* scale = bn_save, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
     CHECK(launch_edge_bwd_reduce(st, dOut, out, msel, uv, P, Cout, mean, invstd, act, slope, part));
-    CHECK(launch_bn_bwd_finalize(st, part, nparts, (double)P * k, Cout, dgamma, dbeta, mean_dz, mean_dzy));
+    CHECK(launch_bn_bwd_finalize(st, part, edge_bwd_reduce_parts(P, Cout, dOut, out, msel, uv, mean, invstd), (double)P * k, Cout,
+                                 dgamma, dbeta, mean_dz, mean_dzy));
     const float* mdz = training ? mean_dz : nullptr;
     CHECK(launch_edge_bwd_point(st, dOut, out, uv, s1, P, Cout, k, scale, mean, invstd, mdz, mean_dzy, act, slope, gz, duv));
     CHECK(launch_edge_bwd_gather(st, gz, argsel, uv, rev_off, rev_ent, P, N, Cout, scale, mean, invstd, mdz, mean_dzy, duv));
@@ -342,7 +345,7 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
     if (dgbias && (n_groups <= 0 || rows_per_group <= 0 || (long)n_groups * rows_per_group != M)) return MLSP_ERR_ARG;
     Workspace w(ws, ws_bytes);
     float* dY = has_bn ? w.take<float>((size_t)M * Cout) : nullptr;
-    int nparts = bn_stat_parts(M);
+    int nparts = bn_parts_max(M);
     double* part = (has_bn || dbias) ? w.take<double>((size_t)nparts * 2 * Cout) : nullptr;
     float* mean_dz = has_bn ? w.take<float>(Cout) : nullptr;
     float* mean_dzy = has_bn ? w.take<float>(Cout) : nullptr;

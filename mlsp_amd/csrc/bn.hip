@@ -171,6 +171,122 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Vectorised forms (C % 4 == 0, C <= 1024, 16-byte aligned, ld == C): a thread owns 4 consecutive columns
+// and walks rows; C/4 threads cover a row with one 16-byte load each, 256/(C/4) rows per pass.
+#define VROWS 64      // rows per partial block of the vectorised reductions (512 blocks at 32,768 rows)
+
+__device__ __forceinline__ void vec_block_reduce_write(double (&s)[4], double (&q)[4], int C, int tpr, int tid, double* shd,
+                                                       double* __restrict__ part, int pblock) {
+    // shd: [256][8] doubles.  thread (rg = tid / tpr, cg = tid % tpr) -> sum over rg
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { shd[tid * 8 + e] = s[e]; shd[tid * 8 + 4 + e] = q[e]; }
+    __syncthreads();
+    if (tid < tpr) {
+        const int nrg = 256 / tpr;
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < nrg; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += shd[(g * tpr + tid) * 8 + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            part[((size_t)pblock * 2 + 0) * C + tid * 4 + e] = a[e];
+            part[((size_t)pblock * 2 + 1) * C + tid * 4 + e] = a[4 + e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_vec_kernel(const float* __restrict__ dZ, const float* __restrict__ Y,
+                                                                    int M, int C, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, int act, float slope,
+                                                                    uint32_t thresh, float inv_keep, uint64_t seed,
+                                                                    double* __restrict__ part) {
+    __shared__ double shd[256 * 8];
+    const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
+    const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (rg < nrg) {
+        const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+        const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+        const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
+        for (int r = r0 + rg; r < r1; r += nrg) {
+            const size_t i = (size_t)r * C + c;
+            const f32x4 y = *(const f32x4*)(Y + i), dz = *(const f32x4*)(dZ + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = dz_prime(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, seed, i + e);
+                s[e] += d; q[e] += (double)d * ((y[e] - mu[e]) * is[e]);
+            }
+        }
+    }
+    vec_block_reduce_write(s, q, C, tpr, tid, shd, part, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void colstats_vec_kernel(const float* __restrict__ Y, int M, int C, double* __restrict__ part) {
+    __shared__ double shd[256 * 8];
+    const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
+    const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (rg < nrg) {
+        const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
+        for (int r = r0 + rg; r < r1; r += nrg) {
+            const f32x4 y = *(const f32x4*)(Y + (size_t)r * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += y[e]; q[e] += (double)y[e] * y[e]; }
+        }
+    }
+    vec_block_reduce_write(s, q, C, tpr, tid, shd, part, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __restrict__ Y, float* __restrict__ Z, size_t total4,
+                                                             int C4, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int act, float slope,
+                                                             uint32_t thresh, float inv_keep, uint64_t seed) {
+    for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(v % C4) * 4;
+        const f32x4 y = *(const f32x4*)(Y + v * 4), sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = lrelu_or_relu(fmaf(y[e], sc[e], sh[e]), act, slope);
+            if (thresh) a = dropout_keep(seed, v * 4 + e, thresh) ? a * inv_keep : 0.f;
+            o[e] = a;
+        }
+        *(f32x4*)(Z + v * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const float* __restrict__ dZ, const float* __restrict__ Y,
+                                                                   float* __restrict__ dY, size_t total4, int C4,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ mean_dz,
+                                                                   const float* __restrict__ mean_dzy, int act, float slope,
+                                                                   uint32_t thresh, float inv_keep, uint64_t seed) {
+    for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(v % C4) * 4;
+        const f32x4 y = *(const f32x4*)(Y + v * 4), dz = *(const f32x4*)(dZ + v * 4);
+        const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = dz_prime(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, seed, v * 4 + e);
+            if (mean_dz) d = d - mean_dz[c + e] - (y[e] - mean[c + e]) * invstd[c + e] * mean_dzy[c + e];
+            o[e] = sc[e] * d;
+        }
+        *(f32x4*)(dY + v * 4) = o;
+    }
+}
+
+static inline bool vec_ok(int C, const void* a, const void* b = nullptr, const void* c = nullptr) {
+    uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
+    return C % 4 == 0 && C >= 4 && C <= 1024 && (256 % (C / 4) == 0 || C / 4 > 128) && (m & 15) == 0;
+}
+int bn_vec_parts(int M) { return (M + VROWS - 1) / VROWS; }
+
 // per-group column sums: out[g][c] = sum over rows of group g   (rows_per_group consecutive rows)
 __global__ __launch_bounds__(256) void colsum_groups_kernel(const float* __restrict__ X, int C, int rows_per_group,
                                                             float* __restrict__ out) {
@@ -261,6 +377,20 @@ static inline uint32_t drop_thresh(float p) {
 }
 
 int bn_stat_parts(int M) { return (M + STAT_ROWS - 1) / STAT_ROWS; }
+// upper bound on the partial rows any BN reduction over M rows writes (vectorised form uses 64-row blocks)
+int bn_parts_max(int M) { return (M + 63) / 64; }
+
+// NOTE: returns the number of partial rows written through *nparts_out (vectorised and scalar forms differ)
+int launch_colstats_n(hipStream_t st, const float* Y, int M, int C, int ld, double* part, int* nparts_out) {
+    if (ld == C && vec_ok(C, Y) && 256 % (C / 4) == 0) {
+        *nparts_out = bn_vec_parts(M);
+        hipLaunchKernelGGL(colstats_vec_kernel, dim3(*nparts_out), dim3(256), 0, st, Y, M, C, part);
+        return mlsp_launch_status();
+    }
+    *nparts_out = bn_stat_parts(M);
+    hipLaunchKernelGGL(colstats_kernel, dim3((C + 63) / 64, bn_stat_parts(M)), dim3(256), 0, st, Y, M, C, ld, part);
+    return mlsp_launch_status();
+}
 
 int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double* part) {
     hipLaunchKernelGGL(colstats_kernel, dim3((C + 63) / 64, bn_stat_parts(M)), dim3(256), 0, st, Y, M, C, ld, part);
@@ -287,6 +417,11 @@ int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int
                       const float* shift, int act, float slope, float p_drop, uint64_t seed) {
     size_t total = rows * C;
     float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    if (C % 4 == 0 && ((((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0)) {
+        hipLaunchKernelGGL(bn_act_fwd_vec_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, st, Y, Z, total / 4, C / 4, scale, shift,
+                           act, slope, drop_thresh(p_drop), inv_keep, seed);
+        return mlsp_launch_status();
+    }
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, Y, Z, total, C, scale, shift, act,
                        slope, drop_thresh(p_drop), inv_keep, seed);
     return mlsp_launch_status();
@@ -299,11 +434,24 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
     float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     uint32_t th = drop_thresh(p_drop);
     int nparts = bn_stat_parts(M);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift,
-                       mean, invstd, act, slope, th, inv_keep, seed, part);
+    const bool vec = vec_ok(C, dZ, Y, dY) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0);
+    if (vec) {
+        nparts = bn_vec_parts(M);
+        hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift, mean, invstd,
+                           act, slope, th, inv_keep, seed, part);
+    } else {
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift,
+                           mean, invstd, act, slope, th, inv_keep, seed, part);
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, (double)M, C, dgamma,
                        dbeta, mean_dz, mean_dzy);
     size_t total = (size_t)M * C;
+    if (vec) {
+        hipLaunchKernelGGL(bn_act_bwd_apply_vec_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, st, dZ, Y, dY, total / 4, C / 4,
+                           scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th,
+                           inv_keep, seed);
+        return mlsp_launch_status();
+    }
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dZ, Y, dY, total, C, scale, shift,
                        mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed);
     return mlsp_launch_status();

@@ -281,6 +281,94 @@ __global__ __launch_bounds__(256) void edge_bwd_point_kernel(const float* __rest
     }
 }
 
+
+// ---- vectorised (16 B per lane) forms of the per-point passes; Cout % 4 == 0, Cout <= 1024, 256 % (Cout/4) == 0 ----
+#define EVROWS 64
+__global__ __launch_bounds__(256) void edge_bwd_reduce_vec_kernel(const float* __restrict__ dOut, const float* __restrict__ out,
+                                                                  const float* __restrict__ msel, const float* __restrict__ uv,
+                                                                  int P, int Cout, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, int act, float slope,
+                                                                  double* __restrict__ part) {
+    __shared__ double shd[256 * 8];
+    const int tid = threadIdx.x, tpr = Cout >> 2, nrg = 256 / tpr;
+    const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+    const int r0 = blockIdx.x * EVROWS, r1 = min(P, r0 + EVROWS);
+    for (int r = r0 + rg; r < r1; r += nrg) {
+        const size_t t = (size_t)r * Cout + c;
+        const f32x4 d4 = *(const f32x4*)(dOut + t), o4 = *(const f32x4*)(out + t), m4 = *(const f32x4*)(msel + t);
+        const f32x4 v4 = *(const f32x4*)(uv + (size_t)r * 2 * Cout + Cout + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = d4[e];
+            if (act && !(o4[e] > 0.f)) d *= (act == 1 ? 0.f : slope);
+            s[e] += d; q[e] += (double)d * ((m4[e] + v4[e] - mu[e]) * is[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { shd[tid * 8 + e] = s[e]; shd[tid * 8 + 4 + e] = q[e]; }
+    __syncthreads();
+    if (tid < tpr) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < nrg; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += shd[(g * tpr + tid) * 8 + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            part[((size_t)blockIdx.x * 2 + 0) * Cout + tid * 4 + e] = a[e];
+            part[((size_t)blockIdx.x * 2 + 1) * Cout + tid * 4 + e] = a[4 + e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_select_act_vec_kernel(const float* __restrict__ msel, const float* __restrict__ uv,
+                                                                  size_t total4, int C4, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int act, float slope,
+                                                                  float* __restrict__ out) {
+    for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = v / C4; const int c = (int)(v % C4) * 4;
+        const f32x4 m = *(const f32x4*)(msel + v * 4), vv = *(const f32x4*)(uv + i * 8 * C4 + 4 * C4 + c);
+        const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = lrelu_or_relu(fmaf(m[e] + vv[e], sc[e], sh[e]), act, slope);
+        *(f32x4*)(out + v * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_bwd_point_vec_kernel(const float* __restrict__ dOut, const float* __restrict__ out,
+                                                                 const float* __restrict__ uv, const float* __restrict__ s1,
+                                                                 size_t total4, int C4, int k, const float* __restrict__ scale,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ mean_dz, const float* __restrict__ mean_dzy,
+                                                                 int act, float slope, float* __restrict__ gz,
+                                                                 float* __restrict__ duv) {
+    const float fk = (float)k;
+    for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = v / C4; const int c = (int)(v % C4) * 4;
+        const f32x4 d4 = *(const f32x4*)(dOut + v * 4), o4 = *(const f32x4*)(out + v * 4);
+        const f32x4 sc = *(const f32x4*)(scale + c);
+        f32x4 g, dv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = d4[e];
+            if (act && !(o4[e] > 0.f)) d *= (act == 1 ? 0.f : slope);
+            g[e] = sc[e] * d; dv[e] = g[e];
+        }
+        if (mean_dz) {
+            const f32x4 vv = *(const f32x4*)(uv + i * 8 * C4 + 4 * C4 + c), s4 = *(const f32x4*)(s1 + v * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float A = sc[e] * mean_dz[c + e], Bc = sc[e] * invstd[c + e] * mean_dzy[c + e];
+                dv[e] = g[e] - fk * A - Bc * (s4[e] + fk * (vv[e] - mean[c + e]));
+            }
+        }
+        *(f32x4*)(gz + v * 4) = g;
+        *(f32x4*)(duv + i * 8 * C4 + 4 * C4 + c) = dv;
+    }
+}
+
 // backward pass 3 (reverse gather, wave per destination j):
 //   du_j = sum_{(i,slot) in rev(j)} ( [argsel[i]==slot]*gz_i - Bc*v_i ) - deg_j*(A + Bc*(u_j - mean))
 __global__ __launch_bounds__(256) void edge_bwd_gather_kernel(const float* __restrict__ gz, const uint8_t* __restrict__ argsel,
@@ -359,6 +447,12 @@ static inline int ew_blocks2(size_t total) {
     return (int)(b < 4096 ? (b ? b : 1) : 4096);
 }
 
+// number of partial rows launch_edge_bwd_reduce writes for this shape
+int edge_bwd_reduce_parts(int P, int Cout, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
+    bool vec = Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 &&
+               ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f) & 15) == 0);
+    return vec ? (P + EVROWS - 1) / EVROWS : (P + 511) / 512;
+}
 int edge_reduce_parts(int P) { return (P + 4 * EDGE_PTS_PER_WAVE - 1) / (4 * EDGE_PTS_PER_WAVE); }
 
 int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd) {
@@ -387,12 +481,25 @@ int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const fl
 }
 int launch_edge_select_act(hipStream_t st, const float* msel, const float* uv, int P, int Cout, const float* scale,
                            const float* shift, int act, float slope, float* out) {
+    if (Cout % 4 == 0 && ((((uintptr_t)msel | (uintptr_t)uv | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0)) {
+        size_t t4 = (size_t)P * Cout / 4;
+        hipLaunchKernelGGL(edge_select_act_vec_kernel, dim3(ew_blocks2(t4)), dim3(256), 0, st, msel, uv, t4, Cout / 4, scale, shift,
+                           act, slope, out);
+        return mlsp_launch_status();
+    }
     hipLaunchKernelGGL(edge_select_act_kernel, dim3(ew_blocks2((size_t)P * Cout)), dim3(256), 0, st, msel, uv, P, Cout, scale,
                        shift, act, slope, out);
     return mlsp_launch_status();
 }
 int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, const float* msel, const float* uv, int P,
                            int Cout, const float* mean, const float* invstd, int act, float slope, double* part) {
+    if (Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 &&
+        ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)msel | (uintptr_t)uv | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)) {
+        // NOTE: writes (P+1023)/1024 partial rows -- callers size `part` for (P+511)/512 and pass the count below
+        hipLaunchKernelGGL(edge_bwd_reduce_vec_kernel, dim3((P + EVROWS - 1) / EVROWS), dim3(256), 0, st, dOut, out, msel, uv, P, Cout,
+                           mean, invstd, act, slope, part);
+        return mlsp_launch_status();
+    }
     hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3((Cout + 63) / 64, (P + 511) / 512), dim3(256), 0, st, dOut, out, msel, uv,
                        P, Cout, mean, invstd, act, slope, part);
     return mlsp_launch_status();
@@ -400,6 +507,13 @@ int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, 
 int launch_edge_bwd_point(hipStream_t st, const float* dOut, const float* out, const float* uv, const float* s1, int P,
                           int Cout, int k, const float* scale, const float* mean, const float* invstd, const float* mean_dz,
                           const float* mean_dzy, int act, float slope, float* gz, float* duv) {
+    if (Cout % 4 == 0 && ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)uv | (uintptr_t)s1 | (uintptr_t)gz | (uintptr_t)duv |
+                            (uintptr_t)scale) & 15) == 0)) {
+        size_t t4 = (size_t)P * Cout / 4;
+        hipLaunchKernelGGL(edge_bwd_point_vec_kernel, dim3(ew_blocks2(t4)), dim3(256), 0, st, dOut, out, uv, s1, t4, Cout / 4, k, scale,
+                           mean, invstd, mean_dz, mean_dzy, act, slope, gz, duv);
+        return mlsp_launch_status();
+    }
     hipLaunchKernelGGL(edge_bwd_point_kernel, dim3(ew_blocks2((size_t)P * Cout)), dim3(256), 0, st, dOut, out, uv, s1, P, Cout,
                        k, scale, mean, invstd, mean_dz, mean_dzy, act, slope, gz, duv);
     return mlsp_launch_status();
