@@ -241,43 +241,61 @@ __global__ __launch_bounds__(256) void colstats_vec_kernel(const float* __restri
     vec_block_reduce_write(s, q, C, tpr, tid, shd, part, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __restrict__ Y, float* __restrict__ Z, size_t total4,
-                                                             int C4, const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, int act, float slope,
-                                                             uint32_t thresh, float inv_keep, uint64_t seed) {
-    for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(v % C4) * 4;
-        const f32x4 y = *(const f32x4*)(Y + v * 4), sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+// column-stationary elementwise passes: a thread keeps its 4 columns' constants in registers and walks rows
+__global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __restrict__ Y, float* __restrict__ Z, int M, int C,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int act, float slope, uint32_t thresh, float inv_keep,
+                                                             uint64_t seed) {
+    const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
+    const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
+    if (rg >= nrg) return;
+    const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+    const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
+    for (int r = r0 + rg; r < r1; r += nrg) {
+        const size_t i = (size_t)r * C + c;
+        const f32x4 y = *(const f32x4*)(Y + i);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a = lrelu_or_relu(fmaf(y[e], sc[e], sh[e]), act, slope);
-            if (thresh) a = dropout_keep(seed, v * 4 + e, thresh) ? a * inv_keep : 0.f;
+            if (thresh) a = dropout_keep(seed, i + e, thresh) ? a * inv_keep : 0.f;
             o[e] = a;
         }
-        *(f32x4*)(Z + v * 4) = o;
+        *(f32x4*)(Z + i) = o;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const float* __restrict__ dZ, const float* __restrict__ Y,
-                                                                   float* __restrict__ dY, size_t total4, int C4,
+                                                                   float* __restrict__ dY, int M, int C,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    const float* __restrict__ mean_dz,
                                                                    const float* __restrict__ mean_dzy, int act, float slope,
                                                                    uint32_t thresh, float inv_keep, uint64_t seed) {
-    for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(v % C4) * 4;
-        const f32x4 y = *(const f32x4*)(Y + v * 4), dz = *(const f32x4*)(dZ + v * 4);
-        const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+    const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
+    const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
+    if (rg >= nrg) return;
+    const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+    f32x4 mu = {0, 0, 0, 0}, k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0};      // d - k1 - (y - mu)*k2
+    if (mean_dz) {
+        mu = *(const f32x4*)(mean + c);
+        k1 = *(const f32x4*)(mean_dz + c);
+        const f32x4 is = *(const f32x4*)(invstd + c), mz = *(const f32x4*)(mean_dzy + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k2[e] = is[e] * mz[e];
+    }
+    const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
+    for (int r = r0 + rg; r < r1; r += nrg) {
+        const size_t i = (size_t)r * C + c;
+        const f32x4 y = *(const f32x4*)(Y + i), dz = *(const f32x4*)(dZ + i);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float d = dz_prime(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, seed, v * 4 + e);
-            if (mean_dz) d = d - mean_dz[c + e] - (y[e] - mean[c + e]) * invstd[c + e] * mean_dzy[c + e];
+            float d = dz_prime(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, seed, i + e);
+            d = d - k1[e] - (y[e] - mu[e]) * k2[e];
             o[e] = sc[e] * d;
         }
-        *(f32x4*)(dY + v * 4) = o;
+        *(f32x4*)(dY + i) = o;
     }
 }
 
@@ -417,8 +435,8 @@ int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int
                       const float* shift, int act, float slope, float p_drop, uint64_t seed) {
     size_t total = rows * C;
     float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-    if (C % 4 == 0 && ((((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0)) {
-        hipLaunchKernelGGL(bn_act_fwd_vec_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, st, Y, Z, total / 4, C / 4, scale, shift,
+    if (rows < (size_t)1 << 30 && vec_ok(C, Y, Z) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0)) {
+        hipLaunchKernelGGL(bn_act_fwd_vec_kernel, dim3(bn_vec_parts((int)rows)), dim3(256), 0, st, Y, Z, (int)rows, C, scale, shift,
                            act, slope, drop_thresh(p_drop), inv_keep, seed);
         return mlsp_launch_status();
     }
@@ -447,7 +465,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
                        dbeta, mean_dz, mean_dzy);
     size_t total = (size_t)M * C;
     if (vec) {
-        hipLaunchKernelGGL(bn_act_bwd_apply_vec_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, st, dZ, Y, dY, total / 4, C / 4,
+        hipLaunchKernelGGL(bn_act_bwd_apply_vec_kernel, dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C,
                            scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th,
                            inv_keep, seed);
         return mlsp_launch_status();

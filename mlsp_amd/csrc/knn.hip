@@ -315,6 +315,186 @@ static int launch_knn_mfma(hipStream_t st, const float* x, int ld, const float* 
     return MLSP_ERR_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------------
+// v3: lane-distributed sorted lists.  The distance tile is computed TRANSPOSED, D[query 32][cand 32]
+// (A = queries in registers, B = candidate tile from LDS), so accumulator register r of a lane holds
+// query row rho(r, half) against candidate (lane & 31): the 32 lanes of a half-wave hold one query's 32
+// candidates of the tile.  Each query's running top-32 list lives SORTED ACROSS those 32 lanes (entry
+// rank = lane & 31), one register per query row.  Per tile and query: one compare + ballot finds the
+// candidates that beat the current k-th value (usually none after the first tiles); each survivor is
+// inserted with a constant number of wave instructions (broadcast it, shift the worse tail down by one
+// lane, drop it in place).  The two half-waves work on different queries in the same instructions.
+// The next tile's MFMA chain is issued in slices between the per-query selection steps so the matrix
+// pipe runs under the VALU work.  Same canonical arithmetic and total order as v1/v2 -> identical output.
+template <int CT>
+__global__ __launch_bounds__(256) void knn_mfma3_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
+                                                        int ld, int N, int C, int k, int vec_ok, int* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int TILE = CT * KM_STRIDE;
+    constexpr int NSTEP = CT / 2;
+    constexpr int SPR = NSTEP >= 16 ? NSTEP / 16 : 1;       // MFMA steps issued per query row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * N * ld;
+    const float* xxb = xx_all + (size_t)b * N;
+    float* tiles = sm;                                    // [2][CT][33]
+    float* cxx = sm + 2 * TILE;                           // [3][32]  (norms of tiles t, t+1, t+2 are live at once)
+
+    const int q0 = blockIdx.x * 128 + wave * 32;          // first query of this wave
+    float qa[NSTEP];
+    {
+        const int q = q0 + l31;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            int c = 2 * s + h;
+            qa[s] = (q < N && c < C) ? xb[(size_t)q * ld + c] : 0.f;
+        }
+    }
+    float xxq[16], lv[16], thr[16];
+    int li[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        xxq[r] = q < N ? xxb[q] : 0.f;
+        lv[r] = -INFINITY; thr[r] = -INFINITY; li[r] = 0x7fffffff;
+    }
+
+    const int ntiles = (N + 31) / 32;
+    constexpr int NLD = (32 * CT / 4 + 255) / 256;
+    f32x4 stage[NLD];
+    auto g2r_tile = [&](int t) {
+        const int j0 = t * 32;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            int f = tid + 256 * p;
+            int cand = f / (CT / 4), c = (f % (CT / 4)) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f < 32 * CT / 4 && t < ntiles && j0 + cand < N) {
+                const float* g = xb + (size_t)(j0 + cand) * ld + c;
+                if (vec_ok && c + 3 < C) v = *(const f32x4*)g;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (c + e < C) v[e] = g[e];
+                }
+            }
+            stage[p] = v;
+        }
+    };
+    auto r2s_tile = [&](int buf, int t) {
+        float* T = tiles + buf * TILE;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            int f = tid + 256 * p;
+            if (f < 32 * CT / 4) {
+                int cand = f / (CT / 4), c = (f % (CT / 4)) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(c + e) * KM_STRIDE + cand] = stage[p][e];
+            }
+        }
+        if (tid < 32) {
+            int j = t * 32 + tid;
+            cxx[(t % 3) * 32 + tid] = (t < ntiles && j < N) ? xxb[j] : 0.f;
+        }
+    };
+
+    f32x16 accCur, accNext;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accCur[r] = 0.f; accNext[r] = 0.f; }
+    // prologue: tile 0 -> buf 0, compute it; tile 1 -> buf 1
+    g2r_tile(0);
+    r2s_tile(0, 0);
+    __syncthreads();
+    {
+        const float* T = tiles + h * KM_STRIDE + l31;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s)
+            accCur = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], T[(2 * s) * KM_STRIDE], accCur, 0, 0, 0);
+    }
+    g2r_tile(1);
+    r2s_tile(1, 1);
+
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();                       // tile t+1 visible in buf (t+1)&1; buf t&1 free for tile t+2
+        const bool have_next = t + 1 < ntiles;
+        if (t + 2 < ntiles) g2r_tile(t + 2);
+        const float* T = tiles + ((t + 1) & 1) * TILE + h * KM_STRIDE + l31;
+        const float xxc = cxx[(t % 3) * 32 + l31];
+        const int j = t * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accNext[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // slice of the next tile's MFMA chain
+            if (have_next && r * SPR < NSTEP) {
+#pragma unroll
+                for (int u = 0; u < SPR; ++u) {
+                    const int s = r * SPR + u;
+                    accNext = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], T[(2 * s) * KM_STRIDE], accNext, 0, 0, 0);
+                }
+            }
+            // selection for query row r of the current tile
+            float pd = fmaf(2.0f, accCur[r], -xxc) - xxq[r];
+            if (j >= N) pd = -INFINITY;
+            unsigned long long m = __ballot(pd > thr[r]);
+            if (m) {
+                unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
+                bool touched = false;
+                while (__any(mh != 0)) {
+                    const bool active = mh != 0;
+                    const int src = active ? (__builtin_ctz(mh) + 32 * h) : lane;
+                    const float xv = __shfl(pd, src, 64);
+                    const int xj = t * 32 + (src & 31);
+                    const float upv = __shfl_up(lv[r], 1, 64);
+                    const int upi = __shfl_up(li[r], 1, 64);
+                    const bool lt = lv[r] < xv;                       // ties keep the earlier (lower index) entry ahead
+                    const bool uplt = (l31 > 0) && (upv < xv);
+                    if (active && lt) { lv[r] = uplt ? upv : xv; li[r] = uplt ? upi : xj; }
+                    mh &= mh - 1;
+                    touched = true;
+                }
+                if (touched) thr[r] = __shfl(lv[r], (k - 1) + 32 * h, 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t + 2 < ntiles) r2s_tile(t & 1, t + 2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accCur[r] = accNext[r];
+    }
+
+    // lane l31 < k of each half holds rank l31 of query row rho(r,h)
+    if (l31 < k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (q < N) idx[((size_t)b * N + q) * k + l31] = li[r];
+        }
+    }
+}
+
+template <int CT>
+static int launch_knn_mfma3_ct(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
+    size_t lds = ((size_t)2 * CT * KM_STRIDE + 96) * sizeof(float);
+    if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)knn_mfma3_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    int vec_ok = (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    dim3 grid((N + 127) / 128, B);
+    hipLaunchKernelGGL((knn_mfma3_kernel<CT>), grid, dim3(256), lds, st, x, xx, ld, N, C, k, vec_ok, idx);
+    return mlsp_launch_status();
+}
+
+static int launch_knn_mfma3(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
+    if (C <= 4) return launch_knn_mfma3_ct<4>(st, x, ld, xx, B, N, C, k, idx);
+    if (C <= 16) return launch_knn_mfma3_ct<16>(st, x, ld, xx, B, N, C, k, idx);
+    if (C <= 64) return launch_knn_mfma3_ct<64>(st, x, ld, xx, B, N, C, k, idx);
+    if (C <= 128) return launch_knn_mfma3_ct<128>(st, x, ld, xx, B, N, C, k, idx);
+    if (C <= 256) return launch_knn_mfma3_ct<256>(st, x, ld, xx, B, N, C, k, idx);
+    return MLSP_ERR_UNSUPPORTED;
+}
+
 static size_t knn_lds_bytes(int KMAX, int C, bool runtime_c) {
     size_t tiles = (size_t)4 * KNN_TJ * C + 4 * KNN_TJ + (runtime_c ? (size_t)KNN_QB * (C + 1) : 0);
     size_t merge = (size_t)3 * KMAX * 64 * 2;
@@ -345,6 +525,7 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
     hipLaunchKernelGGL(sqnorm_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, C, xx_ws);
     // matrix-core path for every C <= 256; the v1 VALU kernel remains for wider features
     if (C <= 256) {
+        if (k <= 32) return launch_knn_mfma3(st, x, ld, xx_ws, B, N, C, k, idx);      // lane-distributed lists
         if (k <= 20) return launch_knn_mfma<20>(st, x, ld, xx_ws, B, N, C, k, idx);
         if (k <= 40) return launch_knn_mfma<40>(st, x, ld, xx_ws, B, N, C, k, idx);
         return MLSP_ERR_UNSUPPORTED;
