@@ -103,6 +103,20 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
                           int n_groups, int rows_per_group, float* dX, int lddx, float* dW, float* dbias, float* dgbias,
                           float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
+/* Fused per-point conv (bias-free) + BatchNorm + act + max over the N points of each cloud:
+ * conv5/bn5/LeakyReLU/adaptive_max_pool1d (PointDA/Models.py:132-136) and the T-Net's conv2d3 + torch.max(dim=2)
+ * (PointDA/model_utils.py:116-117).  out [B][Cout].  Backward is closed-form through the Gram matrix X^T X (colmax.hip):
+ * the dense [P][Cout] gradient is never formed.  Saved: ysel [B][Cout], arg [B][Cout], bn_save [4][Cout].  X must be
+ * contiguous (ldx == Cin) for the backward. */
+int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw, int Cout,
+                                 const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                                 int training, int act, float slope, float* out, float* ysel, int32_t* arg, float* bn_save, void* ws,
+                                 size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw,
+                                 int Cout, const float* out, const float* ysel, const int32_t* arg, const float* bn_save,
+                                 int training, int act, float slope, float* dX, float* dW, float* dgamma, float* dbeta, void* ws,
+                                 size_t ws_bytes, mlsp_stream_t stream);
+
 /* max over the k edges of every point (`.max(dim=-1)`, model_utils.py:114) on an edge-major matrix */
 int mlsp_segmax_fwd_f32(const float* Z, int P, int k, int C, float* out, uint8_t* argk, mlsp_stream_t stream);
 int mlsp_segmax_bwd_f32(const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ, mlsp_stream_t stream);

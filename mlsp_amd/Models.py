@@ -162,8 +162,10 @@ class DGCNN(nn.Module):
             h = conv.edge(h, g)
             feats.append(h)
         x_cat = torch.cat(feats, dim=1)                                            # [P,512]
-        y5 = _bn_layer(x_cat, self.conv5, self.bn5, self.training, Fh.ACT_LRELU)   # Models.py:132
-        x5 = Fh.colmax(y5, B, N)                                                   # [B,1024]  (:136)
+        rm5, rv5 = _bn_buffers(self.bn5, self.training)                             # conv5+bn5+LReLU+max (Models.py:132-136)
+        x5 = Fh.pointmlp_colmax(x_cat, self.conv5.weight.view(1024, -1), self.bn5.weight, self.bn5.bias, rm5, rv5, B, N,
+                                training=self.training, act=Fh.ACT_LRELU, slope=0.2, momentum=self.bn5.momentum,
+                                eps=self.bn5.eps)                                  # [B,1024]
 
         logits["cls"] = self.C(x5)
         if visualization:

@@ -85,6 +85,19 @@ int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const 
 int launch_tnet_edge_bwd2(hipStream_t st, const float* dhp, const float* uv, const float* s1, const float* bn1, const float* m1,
                           const float* m2, const int* rev_off, const int* rev_ent, int P, int N, int k, float* duv);
 
+int launch_colsel(hipStream_t st, const float* Y, const float* gamma, int B, int N, int C, float* ysel, int* arg);
+int launch_colsel_out(hipStream_t st, const float* ysel, const float* bn, int B, int C, int act, float slope, float* out);
+int launch_colmax_bwd_coef(hipStream_t st, const float* dOut, const float* out, const float* ysel, const float* bn, int B, int C,
+                           double count, int act, float slope, int training, float* g, float* coef, float* dgamma, float* dbeta);
+int launch_scale_rows(hipStream_t st, const float* W, int ldw, const float* rowscale, int Cout, int Cin, float* Wb);
+int launch_wt_vec_neg(hipStream_t st, const float* W, int ldw, const float* v, int Cout, int Cin, float* negr);
+int launch_colmax_gather_rows(hipStream_t st, const float* g, const int* arg, const float* X, int ldx, int B, int N, int Cout,
+                              int Cin, float* S);
+int launch_colmax_dw(hipStream_t st, const float* S, const float* WG, const float* sx, const float* coef, const float* bn, int Cout,
+                     int Cin, float* dW);
+int launch_colmax_scatter_rows(hipStream_t st, const float* g, const int* arg, const float* W, int ldw, int B, int N, int Cout,
+                               int Cin, float* dX, int lddx);
+
 #define CHECK(x) do { int _r = (x); if (_r != MLSP_OK) return _r; } while (0)
 #define SLAB_BOUND_FLOATS ((size_t)16 << 20)   /* 64 MiB of fp32: bound on any split-K slab (gemm_pick_split) */
 
@@ -372,6 +385,88 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
         }
     }
     if (dgbias) CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias));
+    return MLSP_OK;
+}
+
+int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw, int Cout,
+                                 const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                                 int training, int act, float slope, float* out, float* ysel, int32_t* arg, float* bn_save, void* ws,
+                                 size_t ws_bytes, mlsp_stream_t st) {
+    if (!X || !W || !gamma || !beta || !out || !ysel || !arg || !bn_save) return MLSP_ERR_ARG;
+    if (B <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
+    const int P = B * N;
+    Workspace w(ws, ws_bytes);
+    float* Y = w.take<float>((size_t)P * Cout);
+    const int fused_parts = training ? gemm_stat_parts(P, Cout, Cin) : 0;
+    int nparts = fused_parts ? fused_parts : bn_stat_parts(P);
+    double* part = w.take<double>((size_t)nparts * 2 * Cout);
+    size_t sf = gemm_slab_floats(P, Cout, Cin);
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    CHECK(launch_gemm(st, false, true, P, Cout, Cin, X, ldx, W, ldw, Y, Cout, nullptr, nullptr, 0, slab, sf,
+                      fused_parts ? part : nullptr));
+    if (training) {
+        if (!fused_parts) CHECK(launch_colstats(st, Y, P, Cout, Cout, part));
+        CHECK(launch_bn_finalize(st, part, nparts, (double)P, Cout, gamma, beta, run_mean, run_var, momentum, eps, bn_save,
+                                 bn_save + Cout, bn_save + 2 * Cout, bn_save + 3 * Cout));
+    } else {
+        if (!run_mean || !run_var) return MLSP_ERR_ARG;
+        CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, bn_save, bn_save + Cout, bn_save + 2 * Cout,
+                                     bn_save + 3 * Cout));
+    }
+    CHECK(launch_colsel(st, Y, gamma, B, N, Cout, ysel, arg));
+    CHECK(launch_colsel_out(st, ysel, bn_save, B, Cout, act, slope, out));
+    return MLSP_OK;
+}
+
+int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw,
+                                 int Cout, const float* out, const float* ysel, const int32_t* arg, const float* bn_save,
+                                 int training, int act, float slope, float* dX, float* dW, float* dgamma, float* dbeta, void* ws,
+                                 size_t ws_bytes, mlsp_stream_t st) {
+    if (!dOut || !X || !W || !out || !ysel || !arg || !bn_save || !dW || !dgamma || !dbeta) return MLSP_ERR_ARG;
+    if (B <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || ldx != Cin || ldw < Cin) return MLSP_ERR_ARG;
+    const int P = B * N;
+    Workspace w(ws, ws_bytes);
+    float* g = w.take<float>((size_t)B * Cout);
+    float* coef = w.take<float>((size_t)4 * Cout);
+    float* S = w.take<float>((size_t)Cout * Cin);
+    float* sx = w.take<float>(Cin);
+    double* part = w.take<double>((size_t)bn_parts_max(P) * 2 * Cin);
+    float* G = w.take<float>((size_t)Cin * Cin);
+    float* WG = w.take<float>((size_t)Cout * Cin);
+    float* Wb = w.take<float>((size_t)Cout * Cin);
+    float* Mneg = w.take<float>((size_t)Cin * Cin);
+    float* negr = w.take<float>(Cin);
+    size_t sf = gemm_slab_floats(Cin, Cin, P), s2 = gemm_slab_floats(Cout, Cin, Cin), s3 = gemm_slab_floats(Cin, Cin, Cout),
+           s4 = gemm_slab_floats(P, Cin, Cin);
+    if (s2 > sf) sf = s2;
+    if (s3 > sf) sf = s3;
+    if (s4 > sf) sf = s4;
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    CHECK(launch_colmax_bwd_coef(st, dOut, out, ysel, bn_save, B, Cout, (double)P, act, slope, training, g, coef, dgamma, dbeta));
+    CHECK(launch_colmax_gather_rows(st, g, arg, X, ldx, B, N, Cout, Cin, S));
+    if (training) {
+        CHECK(launch_colsum(st, X, P, Cin, part, sx));
+        CHECK(launch_gemm(st, true, false, Cin, Cin, P, X, ldx, X, ldx, G, Cin, nullptr, nullptr, 0, slab, sf));
+        CHECK(launch_gemm(st, false, false, Cout, Cin, Cin, W, ldw, G, Cin, WG, Cin, nullptr, nullptr, 0, slab, sf));
+        CHECK(launch_colmax_dw(st, S, WG, sx, coef, bn_save, Cout, Cin, dW));
+    } else {
+        hipError_t e = hipMemcpyAsync(dW, S, (size_t)Cout * Cin * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (dX) {
+        if (training) {
+            CHECK(launch_scale_rows(st, W, ldw, coef + 3 * Cout, Cout, Cin, Wb));                     // -Bc * W
+            CHECK(launch_gemm(st, true, false, Cin, Cin, Cout, Wb, Cin, W, ldw, Mneg, Cin, nullptr, nullptr, 0, slab, sf));
+            CHECK(launch_wt_vec_neg(st, W, ldw, coef + 2 * Cout, Cout, Cin, negr));
+            CHECK(launch_gemm(st, false, false, P, Cin, Cin, X, ldx, Mneg, Cin, dX, Cin, negr, nullptr, 0, slab, sf));
+        } else {
+            hipError_t e = hipMemsetAsync(dX, 0, (size_t)P * Cin * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        CHECK(launch_colmax_scatter_rows(st, g, arg, W, ldw, B, N, Cout, Cin, dX, Cin));
+    }
     return MLSP_OK;
 }
 

@@ -436,24 +436,34 @@ __global__ __launch_bounds__(256) void knn_mfma3_kernel(const float* __restrict_
             // selection for query row r of the current tile
             float pd = fmaf(2.0f, accCur[r], -xxc) - xxq[r];
             if (j >= N) pd = -INFINITY;
+#ifdef KNN_PROBE_NOSELECT
+            unsigned long long m = 0; lv[r] = fmaxf(lv[r], pd);
+#else
             unsigned long long m = __ballot(pd > thr[r]);
+#endif
             if (m) {
-                unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
-                bool touched = false;
-                while (__any(mh != 0)) {
-                    const bool active = mh != 0;
-                    const int src = active ? (__builtin_ctz(mh) + 32 * h) : lane;
-                    const float xv = __shfl(pd, src, 64);
-                    const int xj = t * 32 + (src & 31);
-                    const float upv = __shfl_up(lv[r], 1, 64);
-                    const int upi = __shfl_up(li[r], 1, 64);
+                // everything that steers the insertion is wave-uniform (the ballot is an SGPR pair): the survivor of
+                // each half is broadcast with v_readlane, the tail shifts down one lane with a DPP wave_shr -- no
+                // LDS-routed shuffles on this path
+                unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+                const int pdi = __float_as_int(pd);
+                while (lo | hi) {
+                    const int s0 = lo ? __builtin_ctz(lo) : 0, s1 = hi ? __builtin_ctz(hi) : 0;
+                    const float x0 = __int_as_float(__builtin_amdgcn_readlane(pdi, s0));
+                    const float x1 = __int_as_float(__builtin_amdgcn_readlane(pdi, 32 + s1));
+                    const bool active = h ? (hi != 0) : (lo != 0);
+                    const float xv = h ? x1 : x0;
+                    const int xj = t * 32 + (h ? s1 : s0);
+                    const float upv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv[r]), 0x138, 0xf, 0xf, false));
+                    const int upi = __builtin_amdgcn_update_dpp(0, li[r], 0x138, 0xf, 0xf, false);
                     const bool lt = lv[r] < xv;                       // ties keep the earlier (lower index) entry ahead
                     const bool uplt = (l31 > 0) && (upv < xv);
                     if (active && lt) { lv[r] = uplt ? upv : xv; li[r] = uplt ? upi : xj; }
-                    mh &= mh - 1;
-                    touched = true;
+                    lo &= lo - 1; hi &= hi - 1;
                 }
-                if (touched) thr[r] = __shfl(lv[r], (k - 1) + 32 * h, 64);
+                const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), k - 1));
+                const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), 32 + k - 1));
+                thr[r] = h ? t1 : t0;
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -308,6 +308,59 @@ def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, 
                            seed, momentum, eps)
 
 
+class _PointMLPColMax(Function):
+    @staticmethod
+    def forward(ctx, X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps):
+        lib = _lib.load()
+        X = X.contiguous()
+        _lib.require_gpu(X, W)
+        if W.stride(1) != 1:
+            W = W.contiguous()
+        P, Cin = X.shape
+        Cout = W.shape[0]
+        assert P == B * N and W.shape[1] == Cin
+        dev = X.device
+        out = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+        ysel = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, Cout), dtype=torch.int32, device=dev)
+        bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, P, Cin, Cout)
+        _lib.check(lib.mlsp_pointmlp_colmax_fwd_f32(
+            X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, gamma.data_ptr(), beta.data_ptr(),
+            _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, int(training), act, slope, out.data_ptr(), ysel.data_ptr(),
+            arg.data_ptr(), bn_save.data_ptr(), ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_fwd_f32")
+        ctx.save_for_backward(X, W, out, ysel, arg, bn_save)
+        ctx.cfg = (B, N, training, act, slope)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dOut):
+        lib = _lib.load()
+        X, W, out, ysel, arg, bn_save = ctx.saved_tensors
+        B, N, training, act, slope = ctx.cfg
+        dOut = dOut.contiguous()
+        dev = dOut.device
+        P, Cin = X.shape
+        Cout = W.shape[0]
+        dX = torch.empty((P, Cin), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+        dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, max(P, Cout), Cin, max(Cout, Cin))
+        _lib.check(lib.mlsp_pointmlp_colmax_bwd_f32(
+            dOut.data_ptr(), X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, out.data_ptr(),
+            ysel.data_ptr(), arg.data_ptr(), bn_save.data_ptr(), int(training), act, slope, _lib.ptr(dX), dW.data_ptr(),
+            dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_bwd_f32")
+        return (dX, dW, dgamma, dbeta) + (None,) * 9
+
+
+def pointmlp_colmax(X, W, gamma, beta, run_mean, run_var, B, N, training=True, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5):
+    """conv (bias-free) + BN + act + max over the N rows of each of the B clouds: [B*N, Cin] -> [B, Cout]
+    (Models.py:132-136; model_utils.py:116-117).  Closed-form backward through the Gram matrix (colmax.hip)."""
+    return _PointMLPColMax.apply(X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps)
+
+
 class _SegMax(Function):
     @staticmethod
     def forward(ctx, Z, k):

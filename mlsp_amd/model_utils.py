@@ -68,6 +68,15 @@ class conv_2d(nn.Module):
                            beta=bn.bias, run_mean=rm, run_var=rv, training=self.training, act=self.act, slope=0.2,
                            momentum=bn.momentum, eps=bn.eps)
 
+    def rows_colmax(self, X, B, N):
+        """[B*N, Cin] -> [B, Cout]: this conv + BN + act followed by the max over the N rows of each cloud."""
+        conv, bn = self.conv[0], self.conv[1]
+        if conv.bias is not None:
+            return Fh.colmax(self.rows(X), B, N)
+        rm, rv = _bn_buffers(bn, self.training)
+        return Fh.pointmlp_colmax(X, conv.weight.view(conv.out_channels, conv.in_channels), bn.weight, bn.bias, rm, rv, B, N,
+                                  training=self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps)
+
     def edge(self, xp, graph):
         """Fused get_graph_feature + this conv + max over k.  xp [P,C] -> [P,Cout]."""
         conv, bn = self.conv[0], self.conv[1]
@@ -161,8 +170,7 @@ class transform_net(nn.Module):
         return self._tail(h, B, N)
 
     def _tail(self, h, B, rows_per_cloud):
-        h = self.conv2d3.rows(h)
-        h = Fh.colmax(h, B, rows_per_cloud)                      # [B, 1024]    (model_utils.py:117)
+        h = self.conv2d3.rows_colmax(h, B, rows_per_cloud)       # conv2d3 + max over points (model_utils.py:116-117)
         h = self.fc1(h)
         h = self.fc2(h)
         h = Fh.pointmlp(h, self.fc3.weight, bias=self.fc3.bias, training=self.training)

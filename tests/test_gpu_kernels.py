@@ -414,3 +414,34 @@ def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
     if training:
         for a, b in zip(rg, rc):
             np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- conv + BN + act + max over N (Gram backward)
+@pytest.mark.parametrize("B,N,Cin,Cout,training", [(4, 100, 64, 96, True), (3, 128, 128, 256, True), (2, 64, 512, 1024, True),
+                                                   (3, 50, 40, 70, False)])
+def test_pointmlp_colmax_fwd_bwd(dev, B, N, Cin, Cout, training):
+    Fh = _fh()
+    P = B * N
+    X = _rand((P, Cin), 1).requires_grad_(True)
+    W = _rand((Cout, Cin), 2, 0.2).requires_grad_(True)
+    gamma = (_rand((Cout,), 3) + 0.3).requires_grad_(True)
+    beta = _rand((Cout,), 4).requires_grad_(True)
+    rm, rv = _rand((Cout,), 5) * 0.1, _rand((Cout,), 6).abs() + 0.5
+    dOut = _rand((B, Cout), 7)
+    rm_c, rv_c = rm.clone(), rv.clone()
+    Y = F.batch_norm(X @ W.t(), rm_c, rv_c, gamma, beta, training, 0.1, 1e-5)
+    oc = F.leaky_relu(Y, 0.2).view(B, N, Cout).max(dim=1)[0]
+    oc.backward(dOut)
+    leaves = [X, W, gamma, beta]
+    gl = [t.detach().to(dev).requires_grad_(True) for t in leaves]
+    rm_g, rv_g = rm.to(dev), rv.to(dev)
+    og = Fh.pointmlp_colmax(gl[0], gl[1], gl[2], gl[3], rm_g, rv_g, B, N, training=training)
+    og.backward(dOut.to(dev))
+    np.testing.assert_allclose(og.detach().cpu().numpy(), oc.detach().numpy(), rtol=2e-4, atol=2e-4)
+    for got, want, name in zip([t.grad for t in gl], [t.grad for t in leaves], ["dX", "dW", "dgamma", "dbeta"]):
+        scale = want.abs().max().item() + 1e-6
+        err = (got.cpu() - want).abs().max().item()
+        assert err / scale < 3e-3, (name, err, scale)
+    if training:
+        np.testing.assert_allclose(rm_g.cpu().numpy(), rm_c.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rv_g.cpu().numpy(), rv_c.numpy(), rtol=1e-4, atol=1e-5)
