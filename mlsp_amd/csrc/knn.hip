@@ -505,6 +505,268 @@ static int launch_knn_mfma3(hipStream_t st, const float* x, int ld, const float*
     return MLSP_ERR_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------------
+// v4: two-pass threshold select on top of the v3 tile pipeline (same canonical distances, same total order).
+//   pass A  every lane keeps the running max of ITS column of the distance tiles (one v_max per value): 32 disjoint
+//           chunk maxima per query.  The k-th largest of them, tau, is a lower bound of the k-th best distance (k
+//           chunks each hold a value >= tau), so only candidates with pd >= tau can be in the answer (~30 of 1024).
+//   pass B  recompute the tiles (the MFMA sweep is 20-60 us, the selection was 300); survivors are appended to a
+//           per-query LDS buffer by ballot + prefix count -- no per-candidate loop.
+//   final   exact rank of every survivor by counting (value desc, index asc): rank < k -> idx[q][rank].
+// If any query of the workgroup overflows its 64-entry buffer (massive ties) the workgroup re-runs the v3
+// sequential insertion (pass C), which is exact for any input.
+#define KNN4_CAP 64
+
+template <int CT>
+__global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
+                                                        int ld, int N, int C, int k, int vec_ok, int* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int TILE = CT * KM_STRIDE;
+    constexpr int NSTEP = CT / 2;
+    constexpr int SPR = NSTEP >= 16 ? NSTEP / 16 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * N * ld;
+    const float* xxb = xx_all + (size_t)b * N;
+    float* tiles = sm;                                    // [2][CT][33]
+    float* cxx = sm + 2 * TILE;                           // [3][32]
+    float* bufv = cxx + 96 + wave * 32 * KNN4_CAP;        // [32 queries][CAP] survivor values of this wave
+    int* bufj = (int*)(cxx + 96 + 4 * 32 * KNN4_CAP) + wave * 32 * KNN4_CAP;
+
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    float qa[NSTEP];
+    {
+        const int q = q0 + l31;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            int c = 2 * s + h;
+            qa[s] = (q < N && c < C) ? xb[(size_t)q * ld + c] : 0.f;
+        }
+    }
+    float xxq[16], thr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        xxq[r] = q < N ? xxb[q] : 0.f;
+        thr[r] = -INFINITY;
+    }
+
+    const int ntiles = (N + 31) / 32;
+    constexpr int NLD = (32 * CT / 4 + 255) / 256;
+    f32x4 stage[NLD];
+    auto g2r_tile = [&](int t) {
+        const int j0 = t * 32;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            int f = tid + 256 * p;
+            int cand = f / (CT / 4), c = (f % (CT / 4)) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f < 32 * CT / 4 && t < ntiles && j0 + cand < N) {
+                const float* g = xb + (size_t)(j0 + cand) * ld + c;
+                if (vec_ok && c + 3 < C) v = *(const f32x4*)g;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (c + e < C) v[e] = g[e];
+                }
+            }
+            stage[p] = v;
+        }
+    };
+    auto r2s_tile = [&](int buf, int t) {
+        float* T = tiles + buf * TILE;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            int f = tid + 256 * p;
+            if (f < 32 * CT / 4) {
+                int cand = f / (CT / 4), c = (f % (CT / 4)) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(c + e) * KM_STRIDE + cand] = stage[p][e];
+            }
+        }
+        if (tid < 32) {
+            int j = t * 32 + tid;
+            cxx[(t % 3) * 32 + tid] = (t < ntiles && j < N) ? xxb[j] : 0.f;
+        }
+    };
+
+    // one full sweep over the candidate tiles; sel(r, pd, t) is invoked for every query row of every tile
+    auto sweep = [&](auto&& sel) {
+        f32x16 accCur, accNext;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accCur[r] = 0.f; accNext[r] = 0.f; }
+        __syncthreads();                       // previous sweep is done with the tile buffers
+        g2r_tile(0);
+        r2s_tile(0, 0);
+        __syncthreads();
+        {
+            const float* T = tiles + h * KM_STRIDE + l31;
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s)
+                accCur = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], T[(2 * s) * KM_STRIDE], accCur, 0, 0, 0);
+        }
+        g2r_tile(1);
+        r2s_tile(1, 1);
+        for (int t = 0; t < ntiles; ++t) {
+            __syncthreads();
+            const bool have_next = t + 1 < ntiles;
+            if (t + 2 < ntiles) g2r_tile(t + 2);
+            const float* T = tiles + ((t + 1) & 1) * TILE + h * KM_STRIDE + l31;
+            const float xxc = cxx[(t % 3) * 32 + l31];
+            const int j = t * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accNext[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (have_next && r * SPR < NSTEP) {
+#pragma unroll
+                    for (int u = 0; u < SPR; ++u) {
+                        const int s = r * SPR + u;
+                        accNext = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], T[(2 * s) * KM_STRIDE], accNext, 0, 0, 0);
+                    }
+                }
+                float pd = fmaf(2.0f, accCur[r], -xxc) - xxq[r];
+                if (j >= N) pd = -INFINITY;
+                sel(r, pd, t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t + 2 < ntiles) r2s_tile(t & 1, t + 2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accCur[r] = accNext[r];
+        }
+    };
+
+    // ---- pass A: per-lane chunk maxima -> tau = k-th largest of the 32 lane values of each query
+    float cm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
+    sweep([&](int r, float pd, int) { cm[r] = fmaxf(cm[r], pd); });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ci = __float_as_int(cm[r]);
+        int rank = 0;
+        for (int i = 0; i < 32; ++i) {
+            const float x0 = __int_as_float(__builtin_amdgcn_readlane(ci, i));
+            const float x1 = __int_as_float(__builtin_amdgcn_readlane(ci, 32 + i));
+            const float xv = h ? x1 : x0;
+            rank += (xv > cm[r] || (xv == cm[r] && i < l31)) ? 1 : 0;
+        }
+        const unsigned long long m = __ballot(rank == k - 1);
+        const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+        const float t0 = __int_as_float(__builtin_amdgcn_readlane(ci, lo ? __builtin_ctz(lo) : 0));
+        const float t1 = __int_as_float(__builtin_amdgcn_readlane(ci, 32 + (hi ? __builtin_ctz(hi) : 0)));
+        thr[r] = h ? t1 : t0;
+    }
+
+    // ---- pass B: ballot-compaction of the survivors (pd >= tau) into the per-query buffers
+    int cnt[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cnt[r] = 0;
+    sweep([&](int r, float pd, int t) {
+        const bool pass = pd >= thr[r];
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+            const unsigned mine = h ? (unsigned)(m >> 32) : (unsigned)m;
+            const int pos = cnt[r] + __builtin_popcount(mine & ((1u << l31) - 1u));
+            if (pass && pos < KNN4_CAP) {
+                const int qrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                bufv[qrow * KNN4_CAP + pos] = pd;
+                bufj[qrow * KNN4_CAP + pos] = t * 32 + l31;
+            }
+            cnt[r] += __builtin_popcount(mine);
+        }
+    });
+    bool over = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) over |= cnt[r] > KNN4_CAP;
+
+    if (!__syncthreads_or(over ? 1 : 0)) {
+        // ---- exact rank select among the survivors
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int q = q0 + qrow;
+            const int n = cnt[r];
+            const float* bv = bufv + qrow * KNN4_CAP;
+            const int* bj = bufj + qrow * KNN4_CAP;
+            const float v0 = l31 < n ? bv[l31] : -INFINITY, v1 = l31 + 32 < n ? bv[l31 + 32] : -INFINITY;
+            const int j0 = l31 < n ? bj[l31] : 0x7fffffff, j1 = l31 + 32 < n ? bj[l31 + 32] : 0x7fffffff;
+            const int nmax = max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 32));
+            int rank0 = 0, rank1 = 0;
+            for (int i = 0; i < nmax; ++i) {
+                const float xv = i < n ? bv[i] : -INFINITY;
+                const int xj = i < n ? bj[i] : 0x7fffffff;
+                rank0 += (xv > v0 || (xv == v0 && xj < j0)) ? 1 : 0;
+                rank1 += (xv > v1 || (xv == v1 && xj < j1)) ? 1 : 0;
+            }
+            if (q < N) {
+                if (l31 < n && rank0 < k) idx[((size_t)b * N + q) * k + rank0] = j0;
+                if (l31 + 32 < n && rank1 < k) idx[((size_t)b * N + q) * k + rank1] = j1;
+            }
+        }
+        return;
+    }
+
+    // ---- pass C (fallback, exact for any input): v3 sequential insertion into lane-distributed sorted lists
+    float lv[16];
+    int li[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { lv[r] = -INFINITY; li[r] = 0x7fffffff; thr[r] = -INFINITY; }
+    sweep([&](int r, float pd, int t) {
+        unsigned long long m = __ballot(pd > thr[r]);
+        if (m) {
+            unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+            const int pdi = __float_as_int(pd);
+            while (lo | hi) {
+                const int s0 = lo ? __builtin_ctz(lo) : 0, s1 = hi ? __builtin_ctz(hi) : 0;
+                const float x0 = __int_as_float(__builtin_amdgcn_readlane(pdi, s0));
+                const float x1 = __int_as_float(__builtin_amdgcn_readlane(pdi, 32 + s1));
+                const bool active = h ? (hi != 0) : (lo != 0);
+                const float xv = h ? x1 : x0;
+                const int xj = t * 32 + (h ? s1 : s0);
+                const float upv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv[r]), 0x138, 0xf, 0xf, false));
+                const int upi = __builtin_amdgcn_update_dpp(0, li[r], 0x138, 0xf, 0xf, false);
+                const bool lt = lv[r] < xv;
+                const bool uplt = (l31 > 0) && (upv < xv);
+                if (active && lt) { lv[r] = uplt ? upv : xv; li[r] = uplt ? upi : xj; }
+                lo &= lo - 1; hi &= hi - 1;
+            }
+            const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), k - 1));
+            const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), 32 + k - 1));
+            thr[r] = h ? t1 : t0;
+        }
+    });
+    if (l31 < k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (q < N) idx[((size_t)b * N + q) * k + l31] = li[r];
+        }
+    }
+}
+
+template <int CT>
+static int launch_knn_mfma4_ct(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
+    size_t lds = ((size_t)2 * CT * KM_STRIDE + 96 + 2 * 4 * 32 * KNN4_CAP) * sizeof(float);
+    if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)knn_mfma4_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    int vec_ok = (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    dim3 grid((N + 127) / 128, B);
+    hipLaunchKernelGGL((knn_mfma4_kernel<CT>), grid, dim3(256), lds, st, x, xx, ld, N, C, k, vec_ok, idx);
+    return mlsp_launch_status();
+}
+
+static int launch_knn_mfma4(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
+    if (C <= 4) return launch_knn_mfma4_ct<4>(st, x, ld, xx, B, N, C, k, idx);
+    if (C <= 16) return launch_knn_mfma4_ct<16>(st, x, ld, xx, B, N, C, k, idx);
+    if (C <= 64) return launch_knn_mfma4_ct<64>(st, x, ld, xx, B, N, C, k, idx);
+    if (C <= 128) return launch_knn_mfma4_ct<128>(st, x, ld, xx, B, N, C, k, idx);
+    return MLSP_ERR_UNSUPPORTED;
+}
+
 static size_t knn_lds_bytes(int KMAX, int C, bool runtime_c) {
     size_t tiles = (size_t)4 * KNN_TJ * C + 4 * KNN_TJ + (runtime_c ? (size_t)KNN_QB * (C + 1) : 0);
     size_t merge = (size_t)3 * KMAX * 64 * 2;
@@ -535,6 +797,8 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
     hipLaunchKernelGGL(sqnorm_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, C, xx_ws);
     // matrix-core path for every C <= 256; the v1 VALU kernel remains for wider features
     if (C <= 256) {
+        // two-pass threshold select pays once there are enough candidates per query; small clouds keep v3
+        if (k <= 32 && C <= 128 && N >= 256) return launch_knn_mfma4(st, x, ld, xx_ws, B, N, C, k, idx);
         if (k <= 32) return launch_knn_mfma3(st, x, ld, xx_ws, B, N, C, k, idx);      // lane-distributed lists
         if (k <= 20) return launch_knn_mfma<20>(st, x, ld, xx_ws, B, N, C, k, idx);
         if (k <= 40) return launch_knn_mfma<40>(st, x, ld, xx_ws, B, N, C, k, idx);

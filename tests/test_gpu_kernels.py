@@ -445,3 +445,22 @@ def test_pointmlp_colmax_fwd_bwd(dev, B, N, Cin, Cout, training):
     if training:
         np.testing.assert_allclose(rm_g.cpu().numpy(), rm_c.numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(rv_g.cpu().numpy(), rv_c.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_knn_two_pass_overflow_fallback(dev):
+    """v4 threshold select: massive ties overflow the survivor buffers and must fall back to the exact
+    sequential path (all-identical points; few distinct points; a cloud that mixes both with random points)."""
+    Fh = _fh()
+    B, N, k = 3, 512, 20
+    x = torch.zeros(B, N, 3)
+    x[1] = (torch.arange(N) % 4).float().view(N, 1).expand(N, 3) * 0.25      # 4 distinct points, 128 copies each
+    x[2] = _rand((N, 3), 9)
+    x[2, 100:400] = x[2, 100:101]                                            # 300 duplicates inside a random cloud
+    want = knn_canon.knn_point_major(x, k)
+    got = Fh.knn_graph(x.view(B * N, 3).to(dev), B, N, k).idx.view(B, N, k).cpu().numpy()
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+    xf = _rand((2 * 1024, 64), 3)
+    xf[:1024, :] = xf[:1, :]                                                 # feature-space stage, one cloud degenerate
+    want = knn_canon.knn_point_major(xf.view(2, 1024, 64), k)
+    got = Fh.knn_graph(xf.to(dev), 2, 1024, k).idx.view(2, 1024, k).cpu().numpy()
+    assert np.array_equal(got, want)
