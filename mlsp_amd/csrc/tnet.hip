@@ -27,64 +27,58 @@
 
 __device__ __forceinline__ float lrelu(float a, float slope) { return a > 0.f ? a : a * slope; }
 
-// gather hpre = u_j + v_i for the rows of one tile into Hs (k-major); invalid rows are zero
+// gather hpre = u_j + v_i for the rows of one tile into Hs (k-major); invalid rows are zero.  512 threads: 4 per row.
 __device__ __forceinline__ void tn_build_h(float* __restrict__ Hs, const float* __restrict__ uv, const int* __restrict__ idx,
                                            int tile, int TP, int k, int P, int N, int tid) {
-    const int row = tid >> 1, half = tid & 1;
+    const int row = tid >> 2, qt = tid & 3;
     const int pt = row / k, s = row - pt * k;
     const int i = tile * TP + pt;
-    f32x4 hv[8];
+    f32x4 hv[4];
     if (pt < TP && i < P) {
         const int j = (i / N) * N + idx[(size_t)i * k + s];
-        const f32x4* ur = (const f32x4*)(uv + (size_t)j * 2 * TN_C1 + 32 * half);
-        const f32x4* vr = (const f32x4*)(uv + (size_t)i * 2 * TN_C1 + TN_C1 + 32 * half);
+        const f32x4* ur = (const f32x4*)(uv + (size_t)j * 2 * TN_C1 + 16 * qt);
+        const f32x4* vr = (const f32x4*)(uv + (size_t)i * 2 * TN_C1 + TN_C1 + 16 * qt);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) hv[q] = ur[q] + vr[q];
+        for (int q = 0; q < 4; ++q) hv[q] = ur[q] + vr[q];
     } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) hv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) hv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Hs[(32 * half + 4 * q + e) * TN_SH + row] = hv[q][e];
+        for (int e = 0; e < 4; ++e) Hs[(16 * qt + 4 * q + e) * TN_SH + row] = hv[q][e];
 }
 
-// Z tile = H W2^T  (H = LeakyReLU(scale1*hpre + shift1), zero on invalid rows) -> Zs[row][o]
+// Z tile = H W2^T  (H = LeakyReLU(scale1*hpre + shift1), zero on invalid rows) -> Zs[row][o].
+// 8 waves: wave (wm = 0..3, wn = 0..1) owns rows 32*wm.. and columns 64*wn..
 __device__ __forceinline__ void tn_compute_z(const float* __restrict__ Hs, const float* __restrict__ Ws,
                                              const float* __restrict__ S1, float* __restrict__ Zs, int nvalid, float slope,
                                              int wm, int wn, int l31, int h) {
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int r0 = wm * 64 + l31, r1 = r0 + 32;
-    const bool v0 = r0 < nvalid, v1 = r1 < nvalid;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int r0 = wm * 32 + l31;
+    const bool v0 = r0 < nvalid;
     const int o0 = wn * 64 + l31, o1 = o0 + 32;
 #pragma unroll 8
     for (int t = 0; t < TN_C1 / 2; ++t) {
         const int c = 2 * t + h;
         const float sc = S1[c], sh = S1[TN_C1 + c];
         float a0 = v0 ? lrelu(fmaf(Hs[c * TN_SH + r0], sc, sh), slope) : 0.f;
-        float a1 = v1 ? lrelu(fmaf(Hs[c * TN_SH + r1], sc, sh), slope) : 0.f;
         float b0 = Ws[o0 * TN_SW + c], b1 = Ws[o1 * TN_SW + c];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                Zs[row * TN_SZ + wn * 64 + j * 32 + l31] = acc[i][j][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            Zs[row * TN_SZ + wn * 64 + j * 32 + l31] = acc[j][r];
+        }
 }
 
 struct TnetFwdArgs {
@@ -93,7 +87,7 @@ struct TnetFwdArgs {
     int P, N, k, TP, ntiles; float slope;
 };
 
-__global__ __launch_bounds__(256) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
+__global__ __launch_bounds__(512) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Hs = sm;
     float* Ws = Hs + TN_C1 * TN_SH;
@@ -101,7 +95,7 @@ __global__ __launch_bounds__(256) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
     float* S1 = Zs + TN_ROWS * TN_SZ;               // scale1[64], shift1[64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    for (int e = tid; e < TN_C2 * TN_C1; e += 256) Ws[(e >> 6) * TN_SW + (e & 63)] = p.W2[e];
+    for (int e = tid; e < TN_C2 * TN_C1; e += 512) Ws[(e >> 6) * TN_SW + (e & 63)] = p.W2[e];
     if (tid < 2 * TN_C1) S1[tid] = p.bn1[tid];
     const int o = tid & 127;
     const bool use_max = p.gamma2[o] >= 0.f;
@@ -113,7 +107,7 @@ __global__ __launch_bounds__(256) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
         const int npts = min(p.TP, p.P - tile * p.TP);
         tn_compute_z(Hs, Ws, S1, Zs, npts * p.k, p.slope, wm, wn, l31, h);
         __syncthreads();
-        for (int item = tid; item < npts * TN_C2; item += 256) {
+        for (int item = tid; item < npts * TN_C2; item += 512) {
             const int pt = item >> 7;
             const size_t i = (size_t)tile * p.TP + pt;
             const float* z = Zs + (pt * p.k) * TN_SZ + o;
@@ -131,12 +125,12 @@ __global__ __launch_bounds__(256) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
         }
     }
     __syncthreads();
-    double* red = (double*)Zs;                       // [2][256]
-    red[tid] = ssum; red[256 + tid] = ssq;
+    double* red = (double*)Zs;                       // [2][512]
+    red[tid] = ssum; red[512 + tid] = ssq;
     __syncthreads();
     if (tid < TN_C2) {
-        p.part[((size_t)blockIdx.x * 2 + 0) * TN_C2 + tid] = red[tid] + red[tid + 128];
-        p.part[((size_t)blockIdx.x * 2 + 1) * TN_C2 + tid] = red[256 + tid] + red[256 + tid + 128];
+        p.part[((size_t)blockIdx.x * 2 + 0) * TN_C2 + tid] = red[tid] + red[tid + 128] + red[tid + 256] + red[tid + 384];
+        p.part[((size_t)blockIdx.x * 2 + 1) * TN_C2 + tid] = red[512 + tid] + red[512 + tid + 128] + red[512 + tid + 256] + red[512 + tid + 384];
     }
 }
 
@@ -201,7 +195,7 @@ struct TnetBwdArgs {
     int P, N, k, TP, ntiles; float slope;
 };
 
-__global__ __launch_bounds__(256) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
+__global__ __launch_bounds__(512) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Hs = sm;
     float* Ws = Hs + TN_C1 * TN_SH;
@@ -213,17 +207,16 @@ __global__ __launch_bounds__(256) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
     uint8_t* as = (uint8_t*)(gs + TN_MAXTP * TN_C2);   // [TP<=8][128] argsel tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    for (int e = tid; e < TN_C2 * TN_C1; e += 256) Ws[(e >> 6) * TN_SW + (e & 63)] = p.W2[e];
-    S1[tid] = p.bn1[tid];                            // 256 = 4*64
+    const int rt = wave & 3, ct = wave >> 2;        // dH: row tile rt, channel tile ct;  dW2: o tile rt, channel tile ct
+    for (int e = tid; e < TN_C2 * TN_C1; e += 512) Ws[(e >> 6) * TN_SW + (e & 63)] = p.W2[e];
+    if (tid < 4 * TN_C1) S1[tid] = p.bn1[tid];
     if (tid < 2 * TN_C2) C2[tid] = p.coef[tid];
     if (tid < TN_C2) C2[2 * TN_C2 + tid] = p.bn2[2 * TN_C2 + tid];
 
-    f32x16 accW[2];                                   // dW2 rows o = 32*wave + map(r,h), cols c = 32*ct + l31
+    f32x16 accW;                                      // dW2 rows o = 32*rt + map(r,h), cols c = 32*ct + l31
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accW[ct][r] = 0.f;
-    double sd[2] = {0.0, 0.0}, sdh[2] = {0.0, 0.0};
+    for (int r = 0; r < 16; ++r) accW[r] = 0.f;
+    double sd = 0.0, sdh = 0.0;
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         __syncthreads();
@@ -234,7 +227,7 @@ __global__ __launch_bounds__(256) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
             int pt = tid / p.k, s = tid - pt * p.k;
             rowpt[tid] = tid < nvalid ? ((pt << 8) | s) : -1;
         }
-        for (int e = tid; e < npts * TN_C2; e += 256) {
+        for (int e = tid; e < npts * TN_C2; e += 512) {
             size_t gi = (size_t)tile * p.TP * TN_C2 + e;
             gs[e] = p.g[gi];
             as[e] = p.argsel[gi];
@@ -246,7 +239,7 @@ __global__ __launch_bounds__(256) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
         {
             const int o = tid & 127;
             const float A2 = C2[o], B2 = C2[TN_C2 + o], m2 = C2[2 * TN_C2 + o];
-            for (int row = tid >> 7; row < TN_ROWS; row += 2) {
+            for (int row = tid >> 7; row < TN_ROWS; row += 4) {
                 const int rp = rowpt[row];
                 float dz = 0.f;
                 if (rp >= 0) {
@@ -258,75 +251,67 @@ __global__ __launch_bounds__(256) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
             }
         }
         __syncthreads();
-        // dH[row][c] = sum_o dZ[row][o] W2[o][c]        wave w: rows 32w.., both 32-column halves
-        f32x16 accH[2];
+        // dH[row][c] = sum_o dZ[row][o] W2[o][c]        wave: rows 32*rt.., channels 32*ct..
+        f32x16 accH;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accH[ct][r] = 0.f;
+        for (int r = 0; r < 16; ++r) accH[r] = 0.f;
 #pragma unroll 8
         for (int t = 0; t < TN_C2 / 2; ++t) {
             const int o = 2 * t + h;
-            float a = Zs[(32 * wave + l31) * TN_SZ + o];
-            float b0 = Ws[o * TN_SW + l31], b1 = Ws[o * TN_SW + 32 + l31];
-            accH[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accH[0], 0, 0, 0);
-            accH[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, accH[1], 0, 0, 0);
+            float a = Zs[(32 * rt + l31) * TN_SZ + o];
+            float b0 = Ws[o * TN_SW + 32 * ct + l31];
+            accH = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accH, 0, 0, 0);
         }
-        // dW2[o][c] += sum_row dZ[row][o] H[row][c]      wave w: o-tile w
+        // dW2[o][c] += sum_row dZ[row][o] H[row][c]      wave: o tile rt, channel tile ct
         {
-            const float sc0 = S1[l31], sh0 = S1[TN_C1 + l31], sc1 = S1[32 + l31], sh1 = S1[TN_C1 + 32 + l31];
+            const int c = 32 * ct + l31;
+            const float sc0 = S1[c], sh0 = S1[TN_C1 + c];
 #pragma unroll 8
             for (int t = 0; t < TN_ROWS / 2; ++t) {
                 const int row = 2 * t + h;
-                const bool v = row < nvalid;
-                float a = Zs[row * TN_SZ + 32 * wave + l31];
-                float b0 = v ? lrelu(fmaf(Hs[l31 * TN_SH + row], sc0, sh0), p.slope) : 0.f;
-                float b1 = v ? lrelu(fmaf(Hs[(32 + l31) * TN_SH + row], sc1, sh1), p.slope) : 0.f;
-                accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accW[0], 0, 0, 0);
-                accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, accW[1], 0, 0, 0);
+                float a = Zs[row * TN_SZ + 32 * rt + l31];
+                float b0 = row < nvalid ? lrelu(fmaf(Hs[c * TN_SH + row], sc0, sh0), p.slope) : 0.f;
+                accW = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accW, 0, 0, 0);
             }
         }
         // dh' = dH * act'(a), write valid rows; BN1-backward sums
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        {
             const int c = 32 * ct + l31;
             const float sc = S1[c], sh = S1[TN_C1 + c], mu = S1[2 * TN_C1 + c], is = S1[3 * TN_C1 + c];
             float lsd = 0.f, lsdh = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < nvalid) {
                     const float hp = Hs[c * TN_SH + row];
                     const float a = fmaf(hp, sc, sh);
-                    const float d = accH[ct][r] * (a > 0.f ? 1.f : p.slope);
+                    const float d = accH[r] * (a > 0.f ? 1.f : p.slope);
                     p.dhp[((size_t)tile * p.TP * p.k + row) * TN_C1 + c] = d;
                     lsd += d; lsdh = fmaf(d, (hp - mu) * is, lsdh);
                 }
             }
-            sd[ct] += lsd; sdh[ct] += lsdh;
+            sd += lsd; sdh += lsdh;
         }
     }
-    // write the per-block partials
+    // per-block partials
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-            p.dW2part[(size_t)blockIdx.x * TN_C2 * TN_C1 + o * TN_C1 + 32 * ct + l31] = accW[ct][r];
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int o = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        p.dW2part[(size_t)blockIdx.x * TN_C2 * TN_C1 + o * TN_C1 + 32 * ct + l31] = accW[r];
+    }
     __syncthreads();
-    double* red = (double*)Zs;                       // [4 waves][2 kinds][64 c]
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        double a = sd[ct] + __shfl_xor(sd[ct], 32, 64);
-        double b = sdh[ct] + __shfl_xor(sdh[ct], 32, 64);
-        if (h == 0) { red[(wave * 2 + 0) * 64 + 32 * ct + l31] = a; red[(wave * 2 + 1) * 64 + 32 * ct + l31] = b; }
+    double* red = (double*)Zs;                       // [8 waves][2 kinds][32 lanes]
+    {
+        double a = sd + __shfl_xor(sd, 32, 64);
+        double b = sdh + __shfl_xor(sdh, 32, 64);
+        if (h == 0) { red[(wave * 2 + 0) * 32 + l31] = a; red[(wave * 2 + 1) * 32 + l31] = b; }
     }
     __syncthreads();
     if (tid < 2 * TN_C1) {
         const int kind = tid >> 6, c = tid & 63;
+        const int cti = c >> 5, cl = c & 31;
         double s = 0.0;
-        for (int w = 0; w < 4; ++w) s += red[(w * 2 + kind) * 64 + c];
+        for (int r4 = 0; r4 < 4; ++r4) s += red[((cti * 4 + r4) * 2 + kind) * 32 + cl];
         p.part1[((size_t)blockIdx.x * 2 + kind) * TN_C1 + c] = s;
     }
 }
@@ -383,7 +368,7 @@ int launch_tnet_edge_fwd(hipStream_t st, const float* uv, const int* idx, const 
     a.ntiles = (P + a.TP - 1) / a.TP;
     int rc = tnet_set_lds((const void*)tnet_edge_fwd_kernel);
     if (rc) return rc;
-    hipLaunchKernelGGL(tnet_edge_fwd_kernel, dim3(tnet_grid(a.ntiles)), dim3(256), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
+    hipLaunchKernelGGL(tnet_edge_fwd_kernel, dim3(tnet_grid(a.ntiles)), dim3(512), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
     return mlsp_launch_status();
 }
 
@@ -420,7 +405,7 @@ int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const 
     a.ntiles = (P + a.TP - 1) / a.TP;
     int rc = tnet_set_lds((const void*)tnet_edge_bwd_kernel);
     if (rc) return rc;
-    hipLaunchKernelGGL(tnet_edge_bwd_kernel, dim3(tnet_grid(a.ntiles)), dim3(256), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
+    hipLaunchKernelGGL(tnet_edge_bwd_kernel, dim3(tnet_grid(a.ntiles)), dim3(512), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
     return mlsp_launch_status();
 }
 
