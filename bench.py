@@ -133,7 +133,7 @@ def main():
     torch.manual_seed(0)                                   # identical replicas on every rank
     model = Models.DGCNN(args).to(dev).train()
     sync = FlatGradSync(model)
-    opt = sync.wrap(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, foreach=True))
+    opt = sync.wrap(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, fused=True))   # trainer.py:258-259
     batch = synth_batch(B_PER_GPU, NPTS, dev, seed=1000 + rank)
 
     for _ in range(a.warmup):

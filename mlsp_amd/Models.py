@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fh
-from .model_utils import transform_net, conv_2d, fc_layer, classifier, _bn_buffers
+from .model_utils import transform_net, conv_2d, fc_layer, classifier, _bn_buffers, flushing_forward
 
 K = 20   # Models.py:13
 
@@ -61,6 +61,7 @@ class _RegionHead(nn.Module):
         h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p)
         return self._tail(h, B, N)
 
+    @flushing_forward
     def forward(self, x):
         """Reference signature: x [B,input_size,N] -> [B,N,3]."""
         B, C, N = x.shape
@@ -111,6 +112,7 @@ class Density_prediction(nn.Module):
         h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p)
         return self._tail(h)
 
+    @flushing_forward
     def forward(self, x):
         """Reference signature: x [B,input_size,N] -> (p_vec [B*N,nc], density [B*N])."""
         B, C, N = x.shape
@@ -141,6 +143,7 @@ class DGCNN(nn.Module):
         self.Rec_scan = RegionReconstruction(args, num_f_prev + 1024)
         self.Density_cls = Density_prediction(args, num_f_prev + 1024)
 
+    @flushing_forward
     def forward(self, x, visualization=False, activate_DefRec=False, activate_normal=False, activate_scan=False,
                 activate_density=False, activate_density_normal_ondef=False):
         B = x.size(0)

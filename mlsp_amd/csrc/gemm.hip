@@ -11,10 +11,10 @@
 //   wgrad    dW = dY^T * X : TA=1 TB=0, K = P (split-K over the grid, slab + reduce: deterministic)
 //
 // Tiling: 128x128x32 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.
-// LDS holds both operand tiles K-MAJOR ([k][row]) so an MFMA operand fragment is one conflict-free
-// ds_read_b32 per lane (lanes 0-31: k even, lanes 32-63: k odd).  Row-major global sources are
-// transposed on the LDS write (stride 129 floats: the 4-row x 8-k-quad write pattern of a 32-lane
-// group lands on 32 distinct banks); k-major sources are copied with 16-byte writes (stride 128).
+// LDS images follow the global layout of each operand, so staging is 16-byte loads and 16-byte LDS writes only:
+// row-major sources -> [row][32+4] (an operand fragment is ONE ds_read_b64 per two MFMA steps), k-major sources ->
+// [k][128] (ds_read_b32 per value).  K is consumed in groups of four (k = 4m+2h, then 4m+2h+1) so that both images
+// feed the same k to the A and the B side.
 // Global loads of tile t+1 are issued before the MFMA loop of tile t (register prefetch).
 // Block -> tile mapping keeps all column tiles of one 128-row panel on one XCD (blockIdx % 8 is the
 // XCD label under round-robin dispatch), so the activation panel is fetched into one L2 only.
@@ -23,7 +23,7 @@
 #define BM 128
 #define BN 128
 #define BK 32
-#define SROW 129   // LDS stride for operands whose global source is row-major  [rows][K]
+#define SROW 36    // LDS row pitch (floats) for operands whose global source is row-major: image [rows][BK+4]
 #define SKMJ 128   // LDS stride for operands whose global source is k-major    [K][rows]
 
 struct GemmArgs {
@@ -83,8 +83,7 @@ __device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, 
         if (!SRC_KMAJOR) {
             int row = (tid >> 3) + 32 * p;
             int k = (tid & 7) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[(k + e) * SROW + row] = r[p][e];
+            *(f32x4*)(s + row * SROW + k) = r[p];
         } else {
             int k = (tid >> 5) + 8 * p;
             int row = (tid & 31) * 4;
@@ -97,11 +96,9 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     // A tile is k-major in LDS either way; its GLOBAL source is k-major iff TA.  B's source is
     // k-major iff !TB.
-    constexpr int SA = TA ? SKMJ : SROW;
-    constexpr int SB = TB ? SROW : SKMJ;
-    __shared__ __attribute__((aligned(16))) float smem[BK * SROW * 2];
+    __shared__ __attribute__((aligned(16))) float smem[BM * SROW * 2];
     float* As = smem;
-    float* Bs = smem + BK * SROW;
+    float* Bs = smem + BM * SROW;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -147,16 +144,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
             g2r<TA>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid);
             g2r<!TB>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid);
         }
-        const float* a_base = As + h * SA + wm * 64 + l31;
-        const float* b_base = Bs + h * SB + wn * 64 + l31;
+        // Fragment reads.  K is consumed in groups of 4: MFMA step 2m takes k = 4m + 2h, step 2m+1 takes k = 4m + 2h + 1
+        // (h = lane >> 5), so a row-major image gives each lane its two values with ONE 8-byte read; a k-major image is
+        // read per value.  Both operands use the same k assignment, so every (TA, TB) combination is consistent.
+        const int arow = wm * 64 + l31, bcol = wn * 64 + l31;
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a0 = a_base[(2 * kk) * SA], a1 = a_base[(2 * kk) * SA + 32];
-            float b0 = b_base[(2 * kk) * SB], b1 = b_base[(2 * kk) * SB + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int m = 0; m < BK / 4; ++m) {
+            const int kq = 4 * m + 2 * h;
+            float a0s0, a0s1, a1s0, a1s1, b0s0, b0s1, b1s0, b1s1;
+            if (!TA) {
+                const float2 t0 = *(const float2*)(As + arow * SROW + kq), t1 = *(const float2*)(As + (arow + 32) * SROW + kq);
+                a0s0 = t0.x; a0s1 = t0.y; a1s0 = t1.x; a1s1 = t1.y;
+            } else {
+                a0s0 = As[kq * SKMJ + arow]; a0s1 = As[(kq + 1) * SKMJ + arow];
+                a1s0 = As[kq * SKMJ + arow + 32]; a1s1 = As[(kq + 1) * SKMJ + arow + 32];
+            }
+            if (TB) {
+                const float2 t0 = *(const float2*)(Bs + bcol * SROW + kq), t1 = *(const float2*)(Bs + (bcol + 32) * SROW + kq);
+                b0s0 = t0.x; b0s1 = t0.y; b1s0 = t1.x; b1s1 = t1.y;
+            } else {
+                b0s0 = Bs[kq * SKMJ + bcol]; b0s1 = Bs[(kq + 1) * SKMJ + bcol];
+                b1s0 = Bs[kq * SKMJ + bcol + 32]; b1s1 = Bs[(kq + 1) * SKMJ + bcol + 32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s0, b0s0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s0, b1s0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s0, b0s0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s0, b1s0, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s1, b0s1, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s1, b1s1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s1, b0s1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s1, b1s1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }

@@ -13,69 +13,67 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
-    """Re-homes every trainable parameter's .grad into one flat buffer and all-reduces it once.
+    """One flat fp32 bucket for every trainable gradient, all-reduced once per optimizer step.
 
         sync = FlatGradSync(model)            # after model.to(device)
         opt = sync.wrap(torch.optim.Adam(model.parameters(), ...))
         ...  loss.backward() (any number of times) ...
-        opt.step()                            # all-reduce(sum)/world_size, then the optimizer step
-        opt.zero_grad()                       # zeroes the bucket in place (grads stay views)
+        opt.step()                            # flatten -> ONE all-reduce(sum) -> /world_size -> inner optimizer step
+        opt.zero_grad()                       # grads -> None (autograd then assigns instead of accumulating)
+
+    Gradients are NOT pre-homed in the bucket during backward: autograd would then issue one `grad += new`
+    kernel per parameter (77 launches, ~0.4 ms per step on MI355X).  Instead the gradients autograd produced
+    are packed into the bucket by one multi-tensor copy right before the collective, and `.grad` is re-pointed
+    at the bucket views for the optimizer.  With world_size == 1 nothing is copied at all.
     """
 
     def __init__(self, model, process_group=None):
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.group = process_group
-        n = sum(p.numel() for p in self.params)
+        self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.numel = n
 
     @property
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def check_views(self):
-        """Gradients must still alias the bucket (zero_grad(set_to_none=True) would break that)."""
-        off = 0
-        for p in self.params:
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
-                return False
-            off += p.numel()
-        return True
-
-    def rehome(self):
-        off = 0
-        for p in self.params:
-            view = self.flat[off:off + p.numel()].view_as(p)
-            if p.grad is None:
-                view.zero_()
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-            p.grad = view
-            off += p.numel()
+    def pack(self):
+        """Copy the present gradients into the bucket (absent ones count as zero) and alias .grad to the bucket."""
+        present = [(v, p) for v, p in zip(self.views, self.params) if p.grad is not None]
+        if len(present) != len(self.params):
+            self.flat.zero_()
+        src = [p.grad for _, p in present if p.grad.data_ptr() != _.data_ptr()]
+        dst = [v for v, p in present if p.grad.data_ptr() != v.data_ptr()]
+        if src:
+            torch._foreach_copy_(dst, src)
+        for v, p in present:
+            p.grad = v
+        return self.flat
 
     def allreduce(self):
-        if not self.check_views():
-            self.rehome()
         ws = self.world_size
         if ws > 1:
+            self.pack()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(ws)
         return self.flat
 
     def zero_grad(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def wrap(self, optimizer):
         return _SyncedOptimizer(optimizer, self)
 
 
 class _SyncedOptimizer:
-    """Optimizer facade: step() = one flat all-reduce + inner step; zero_grad() keeps the bucket views."""
+    """Optimizer facade: step() = one flat all-reduce + inner step; zero_grad() drops the gradients."""
 
     def __init__(self, inner, sync):
         self.inner, self.sync = inner, sync
@@ -84,7 +82,7 @@ class _SyncedOptimizer:
         self.sync.allreduce()
         return self.inner.step(*a, **kw)
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=True):
         self.sync.zero_grad()
 
     def __getattr__(self, name):

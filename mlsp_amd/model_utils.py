@@ -39,10 +39,42 @@ def get_graph_feature(x, args, k=20, idx=None):
     return F.view(B, N, k, 2 * C).permute(0, 3, 1, 2)
 
 
+_pending_nbt = []
+
+
 def _bn_buffers(bn, training):
+    """Running-stat buffers of a BatchNorm holder; in training mode its num_batches_tracked is queued for ONE
+    multi-tensor increment per forward (flush_bn_counters) instead of one tiny kernel per layer."""
     if training:
-        bn.num_batches_tracked += 1
+        _pending_nbt.append(bn.num_batches_tracked)
     return bn.running_mean, bn.running_var
+
+
+def flush_bn_counters():
+    if _pending_nbt:
+        torch._foreach_add_(_pending_nbt, 1)
+        _pending_nbt.clear()
+
+
+_fwd_depth = 0
+
+
+def flushing_forward(fn):
+    """Decorator for the public forward() of every module here: the outermost call flushes the queued
+    num_batches_tracked increments on exit, so state_dict() is exact after any forward."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        global _fwd_depth
+        _fwd_depth += 1
+        try:
+            return fn(self, *a, **k)
+        finally:
+            _fwd_depth -= 1
+            if _fwd_depth == 0:
+                flush_bn_counters()
+    return wrapper
 
 
 class conv_2d(nn.Module):
@@ -86,6 +118,7 @@ class conv_2d(nn.Module):
         return Fh.edgeconv(xp, graph, conv.weight.view(conv.out_channels, conv.in_channels), bn.weight, bn.bias, rm, rv,
                            self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps)
 
+    @flushing_forward
     def forward(self, x):
         """Reference signature: x [B,Cin,N,k] -> [B,Cout,N,k]."""
         B, C, N, k = x.shape
@@ -112,6 +145,7 @@ class fc_layer(nn.Module):
         self.has_bn = bn
         self.act = _ACT[activation]
 
+    @flushing_forward
     def forward(self, x, p_drop=0.0):
         """x [M,in] -> [M,out]; `p_drop` fuses the Dropout that follows this layer in the reference."""
         lin = self.fc[0]
@@ -177,6 +211,7 @@ class transform_net(nn.Module):
         iden = torch.eye(self.K, device=h.device, dtype=h.dtype).view(1, self.K * self.K)
         return (h + iden).view(B, self.K, self.K)
 
+    @flushing_forward
     def forward(self, x):
         """Reference signature: x [B,in_ch,N,k] (graph feature) -> [B,K,K]."""
         B, C, N, k = x.shape
@@ -197,6 +232,7 @@ class classifier(nn.Module):
         self.dp2 = nn.Dropout(p=args.dropout)
         self.mlp3 = nn.Linear(256, int(num_class))
 
+    @flushing_forward
     def forward(self, x):
         x = self.mlp1(x, p_drop=self.dp1.p)
         x2 = self.mlp2(x, p_drop=self.dp2.p)
@@ -216,6 +252,7 @@ class density_classifier(nn.Module):
         self.dp2 = nn.Dropout(p=args.dropout)
         self.mlp3 = nn.Linear(256, int(num_class))
 
+    @flushing_forward
     def forward(self, x):
         x = self.mlp1(x, p_drop=self.dp1.p)
         x2 = self.mlp2(x, p_drop=self.dp2.p)

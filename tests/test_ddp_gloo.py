@@ -31,19 +31,19 @@ def _worker(rank, world, port, q):
     opt.zero_grad()
     ((model(x) - y) ** 2).mean().backward()
     ((model(x) - y) ** 2).mean().backward()                   # two backwards per step accumulate, ONE all-reduce
-    local = sync.flat.clone()
+    local = sync.pack().clone()
     opt.step()
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     want = sum(gathered) / world
     ok_avg = torch.allclose(sync.flat, want, atol=1e-6)
-    ok_views = sync.check_views()
+    ok_views = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
     w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     ws = [torch.zeros_like(w) for _ in range(world)]
     dist.all_gather(ws, w)
     ok_same = all(torch.equal(ws[0], t) for t in ws)          # replicas stay identical after the step
     opt.zero_grad()
-    ok_zero = bool((sync.flat == 0).all()) and sync.check_views()
+    ok_zero = all(p.grad is None for p in sync.params)
     q.put((rank, ok_avg, ok_views, ok_same, ok_zero))
     dist.barrier()
     dist.destroy_process_group()
@@ -69,10 +69,11 @@ def test_single_process_is_identity():
     m = torch.nn.Linear(3, 2)
     s = FlatGradSync(m)
     m(torch.ones(4, 3)).sum().backward()
-    before = s.flat.clone()
-    s.allreduce()
-    assert torch.equal(before, s.flat) and s.world_size == 1
+    g0 = [p.grad.clone() for p in m.parameters()]
+    s.allreduce()                                             # world size 1: nothing is copied, grads untouched
+    assert s.world_size == 1 and all(torch.equal(a, p.grad) for a, p in zip(g0, m.parameters()))
+    flat = s.pack().clone()                                   # explicit packing still works and aliases .grad
+    assert torch.equal(flat, torch.cat([g.reshape(-1) for g in g0]))
     m.zero_grad(set_to_none=True)                             # a trainer doing this must not break the bucket
     m(torch.ones(4, 3)).sum().backward()
-    s.allreduce()
-    assert s.check_views() and torch.equal(before, s.flat)
+    assert torch.equal(s.pack(), flat)

@@ -112,14 +112,16 @@ def test_gemm(dev, ta, tb, M, N, K):
 
 
 def test_gemm_matches_fma_chain_bitwise(dev):
-    """The f32 MFMA is a k-ordered fmaf chain (what makes an MFMA kNN canonical): check bitwise for K<=32."""
+    """The f32 MFMA is a fmaf chain in issue order (what makes the MFMA kNN canonical).  The GEMM kernel feeds K in
+    groups of four as (4m, 4m+2, 4m+1, 4m+3) -- see gemm.hip -- so emulate exactly that chain and compare bitwise."""
     Fh = _fh()
     A, B = _rand((64, 24), 3), _rand((40, 24), 4)
     got = Fh.gemm(A.to(dev), B.to(dev), tb=True).cpu().numpy()
     want = np.zeros((64, 40), np.float32)
     a64, b64 = A.numpy().astype(np.float64), B.numpy().astype(np.float64)
     acc = np.zeros((64, 40), np.float64)
-    for kk in range(24):        # fmaf: exact product + one rounding per step, emulated in float64 (exact for f32 inputs)
+    order = [4 * m + d for m in range(6) for d in (0, 2, 1, 3)]
+    for kk in order:            # fmaf: exact product + one rounding per step, emulated in float64 (exact for f32 inputs)
         acc = (acc + np.outer(a64[:, kk], b64[:, kk])).astype(np.float32).astype(np.float64)
     want = acc.astype(np.float32)
     assert np.array_equal(got, want)
