@@ -614,6 +614,10 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
             const float* T = tiles + ((t + 1) & 1) * TILE + h * KM_STRIDE + l31;
             const float xxc = cxx[(t % 3) * 32 + l31];
             const int j = t * 32 + l31;
+            // all B fragments of the next tile are fetched up front: the MFMA slices below then never wait on LDS
+            float bf[NSTEP];
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) bf[s] = T[(2 * s) * KM_STRIDE];
 #pragma unroll
             for (int r = 0; r < 16; ++r) accNext[r] = 0.f;
 #pragma unroll
@@ -622,13 +626,15 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
 #pragma unroll
                     for (int u = 0; u < SPR; ++u) {
                         const int s = r * SPR + u;
-                        accNext = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], T[(2 * s) * KM_STRIDE], accNext, 0, 0, 0);
+                        accNext = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], bf[s], accNext, 0, 0, 0);
                     }
                 }
                 float pd = fmaf(2.0f, accCur[r], -xxc) - xxq[r];
                 if (j >= N) pd = -INFINITY;
                 sel(r, pd, t);
+#ifndef KNN4_NO_SCHED_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             if (t + 2 < ntiles) r2s_tile(t & 1, t + 2);
 #pragma unroll
@@ -658,6 +664,10 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
         thr[r] = h ? t1 : t0;
     }
 
+#if defined(KNN4_PROBE) && KNN4_PROBE == 1
+    if (thr[0] == 12345.f) idx[0] = 1;
+    return;
+#endif
     // ---- pass B: ballot-compaction of the survivors (pd >= tau) into the per-query buffers
     int cnt[16];
 #pragma unroll
@@ -679,6 +689,10 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
     bool over = false;
 #pragma unroll
     for (int r = 0; r < 16; ++r) over |= cnt[r] > KNN4_CAP;
+#if defined(KNN4_PROBE) && KNN4_PROBE == 2
+    if (over) idx[0] = cnt[3];
+    return;
+#endif
 
     if (!__syncthreads_or(over ? 1 : 0)) {
         // ---- exact rank select among the survivors

@@ -32,7 +32,7 @@ def time_lib(path, C, B=32, N=1024, k=20, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 if __name__ == "__main__":
-    variants = {"base": [], "noselect": ["-DKNN_PROBE_NOSELECT"]}
+    variants = {"base": []}
     for name, fl in variants.items():
         out = "/tmp/libknn_%s.so" % name
         build(fl, out)
