@@ -7,7 +7,9 @@
 // ---- launchers implemented in the other translation units -----------------------------------
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
-                double* stat_part = nullptr);
+                double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr, int* sel_row = nullptr);
+int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, float* ysel,
+                         int* arg);
 int gemm_stat_parts(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K);
 int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws);
@@ -396,15 +398,20 @@ int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin,
     if (B <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
     const int P = B * N;
     Workspace w(ws, ws_bytes);
-    float* Y = w.take<float>((size_t)P * Cout);
     const int fused_parts = training ? gemm_stat_parts(P, Cout, Cin) : 0;
+    // fully fused path: statistics AND the per-cloud column extreme come out of the GEMM epilogue, Y is never written
+    const bool fuse_sel = (N % 128 == 0) && gemm_stat_parts(P, Cout, Cin) > 0;
+    float* Y = fuse_sel ? nullptr : w.take<float>((size_t)P * Cout);
+    const int ntm = (P + 127) / 128;
+    float* pv = fuse_sel ? w.take<float>((size_t)ntm * Cout) : nullptr;
+    int* pr = fuse_sel ? w.take<int>((size_t)ntm * Cout) : nullptr;
     int nparts = fused_parts ? fused_parts : bn_stat_parts(P);
     double* part = w.take<double>((size_t)nparts * 2 * Cout);
     size_t sf = gemm_slab_floats(P, Cout, Cin);
     float* slab = sf ? w.take<float>(sf) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     CHECK(launch_gemm(st, false, true, P, Cout, Cin, X, ldx, W, ldw, Y, Cout, nullptr, nullptr, 0, slab, sf,
-                      fused_parts ? part : nullptr));
+                      fused_parts ? part : nullptr, fuse_sel ? gamma : nullptr, pv, pr));
     if (training) {
         if (!fused_parts) CHECK(launch_colstats(st, Y, P, Cout, Cout, part));
         CHECK(launch_bn_finalize(st, part, nparts, (double)P, Cout, gamma, beta, run_mean, run_var, momentum, eps, bn_save,
@@ -414,7 +421,8 @@ int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin,
         CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, bn_save, bn_save + Cout, bn_save + 2 * Cout,
                                      bn_save + 3 * Cout));
     }
-    CHECK(launch_colsel(st, Y, gamma, B, N, Cout, ysel, arg));
+    if (fuse_sel) CHECK(launch_colsel_panels(st, pv, pr, gamma, B, N, Cout, ysel, arg));
+    else CHECK(launch_colsel(st, Y, gamma, B, N, Cout, ysel, arg));
     CHECK(launch_colsel_out(st, ysel, bn_save, B, Cout, act, slope, out));
     return MLSP_OK;
 }

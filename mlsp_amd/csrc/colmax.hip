@@ -44,6 +44,25 @@ __global__ __launch_bounds__(256) void colsel_kernel(const float* __restrict__ Y
     }
 }
 
+// reduce the per-panel extremes written by the GEMM epilogue over the N/128 panels of each cloud
+__global__ void colsel_panels_kernel(const float* __restrict__ pv, const int* __restrict__ pr, const float* __restrict__ gamma,
+                                     int B, int N, int C, int panels_per_cloud, float* __restrict__ ysel, int* __restrict__ arg) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    int b = t / C, c = t % C;
+    const bool use_max = gamma[c] >= 0.f;
+    float best = use_max ? -INFINITY : INFINITY;
+    int brow = 0x7fffffff;
+    for (int u = 0; u < panels_per_cloud; ++u) {
+        size_t q = (size_t)(b * panels_per_cloud + u) * C + c;
+        float v = pv[q]; int r = pr[q];
+        bool better = use_max ? (v > best) : (v < best);
+        if (better || (v == best && r < brow)) { best = v; brow = r; }
+    }
+    ysel[t] = best;
+    arg[t] = brow - b * N;
+}
+
 // out = act(scale*ysel + shift)      [B][C]
 __global__ void colsel_out_kernel(const float* __restrict__ ysel, const float* __restrict__ bn, int total, int C, int act,
                                   float slope, float* __restrict__ out) {
@@ -202,6 +221,11 @@ __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* 
 // ---------------------------------------------------------------------------------------------
 int launch_colsel(hipStream_t st, const float* Y, const float* gamma, int B, int N, int C, float* ysel, int* arg) {
     hipLaunchKernelGGL(colsel_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, Y, gamma, N, C, ysel, arg);
+    return mlsp_launch_status();
+}
+int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, float* ysel,
+                         int* arg) {
+    hipLaunchKernelGGL(colsel_panels_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, pv, pr, gamma, B, N, C, N / 128, ysel, arg);
     return mlsp_launch_status();
 }
 int launch_colsel_out(hipStream_t st, const float* ysel, const float* bn, int B, int C, int act, float slope, float* out) {

@@ -34,6 +34,8 @@ struct GemmArgs {
     int a_vec, b_vec;               // 1 if float4 global loads are legal for that operand
     int xcd_map;                    // 1: XCD-grouped block->tile map (grid padded to a multiple of 8 panels)
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][N] (BN batch statistics)
+    const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
+    float* sel_val; int* sel_row;   // [ntm][N] extreme of each 128-row panel and the global row attaining it (first occurrence)
 };
 
 // ---- global -> registers for one 128x32 operand tile -----------------------------------------
@@ -195,11 +197,53 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                 if (row < p.M) {
                     float v = acc[i][j][r] + bv;
                     if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
-                    Cout[(size_t)row * p.ldc + col] = v;
+                    if (p.C) Cout[(size_t)row * p.ldc + col] = v;
                     cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
+                    acc[i][j][r] = v;
                 }
             }
         }
+    if (p.sel_gamma) {       // fused column extreme (max over points follows this layer): per panel, per column
+        float bv[2]; int br[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            const bool use_max = col < p.N ? p.sel_gamma[col] >= 0.f : true;
+            float best = use_max ? -INFINITY : INFINITY;
+            int brow = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = acc[i][j][r];
+                    const bool take = row < p.M && (use_max ? (v > best) : (v < best));
+                    best = take ? v : best; brow = take ? row : brow;
+                }
+            const float ob = __shfl_xor(best, 32, 64);
+            const int orow = __shfl_xor(brow, 32, 64);
+            const bool better = use_max ? (ob > best) : (ob < best);
+            if (better || (ob == best && orow < brow)) { best = ob; brow = orow; }
+            bv[j] = best; br[j] = brow;
+        }
+        __syncthreads();                                  // smem is reused below (and by the statistics block)
+        float* sv = smem + 1024;                          // [wm][128] values, then rows
+        int* sr = (int*)(smem + 1024 + 256);
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { sv[wm * 128 + wn * 64 + j * 32 + l31] = bv[j]; sr[wm * 128 + wn * 64 + j * 32 + l31] = br[j]; }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const bool use_max = p.sel_gamma[n0 + tid] >= 0.f;
+            float a = sv[tid], b2 = sv[128 + tid];
+            int ra = sr[tid], rb = sr[128 + tid];
+            const bool better = use_max ? (b2 > a) : (b2 < a);
+            if (better || (b2 == a && rb < ra)) { a = b2; ra = rb; }
+            p.sel_val[(size_t)tm * p.N + n0 + tid] = a;
+            p.sel_row[(size_t)tm * p.N + n0 + tid] = ra;
+        }
+    }
     if (p.stat_part) {       // fused BatchNorm statistics: one fp64 partial per 128-row panel and column
         float* red = smem;   // [wm][sum|sq][128]  (the operand tiles are dead: the k-loop ended on a barrier)
 #pragma unroll
@@ -341,8 +385,10 @@ extern "C" int mlsp_profile_end(double* out) {
 
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
-                size_t slab_floats, double* stat_part = nullptr) {
-    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return MLSP_ERR_ARG;
+                size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
+                int* sel_row = nullptr) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
+    if (sel_gamma && (!sel_val || !sel_row || gemm_pick_split(M, N, K) != 1)) return MLSP_ERR_ARG;
     if (gbias && rows_per_group <= 0) return MLSP_ERR_ARG;
     GemmArgs p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.gbias = gbias;
@@ -352,6 +398,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;   // no slab: fall back to one pass
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
     p.stat_part = stat_part;
+    p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
     int ktiles = (K + BK - 1) / BK;
     int kts = (ktiles + ns - 1) / ns;
     ns = (ktiles + kts - 1) / kts;
