@@ -27,7 +27,7 @@ int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int
 int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* scale,
                       const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
                       float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy);
-int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out);
+int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out, float* scratch = nullptr);
 int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out);
 int launch_colmax_fwd(hipStream_t st, const float* Z, int B, int N, int C, float* out, int* arg);
 int launch_colmax_bwd(hipStream_t st, const float* dOut, const int* arg, int B, int N, int C, float* dZ);
@@ -367,6 +367,7 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
     size_t sf1 = dX ? gemm_slab_floats(M, Cin, Cout) : 0, sf2 = gemm_slab_floats(Cout, Cin, M);
     size_t sf = sf1 > sf2 ? sf1 : sf2;
     float* slab = sf ? w.take<float>(sf) : nullptr;
+    float* gscratch = dgbias ? w.take<float>((size_t)n_groups * 16 * Cout) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float* g = dZ;   // gradient wrt the linear output
     if (has_bn) {
@@ -386,7 +387,7 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
             CHECK(launch_colsum(st, g, M, Cout, part, dbias));
         }
     }
-    if (dgbias) CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias));
+    if (dgbias) CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias, gscratch));
     return MLSP_OK;
 }
 

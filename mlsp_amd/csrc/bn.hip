@@ -500,7 +500,46 @@ int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, fl
     return mlsp_launch_status();
 }
 
-int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out) {
+// vectorised per-group column sums: block = (64-row slab of a group); partial sums combined by a second tiny pass
+__global__ __launch_bounds__(256) void colsum_groups_vec_kernel(const float* __restrict__ X, int C, int rows_per_group, int slabs,
+                                                                float* __restrict__ part) {
+    __shared__ float shd[256 * 4];
+    const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
+    const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
+    const int g = blockIdx.y, slab = blockIdx.x;
+    const int rows_per_slab = (rows_per_group + slabs - 1) / slabs;
+    const int r0 = slab * rows_per_slab, r1 = min(rows_per_group, r0 + rows_per_slab);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (rg < nrg)
+        for (int r = r0 + rg; r < r1; r += nrg) s = s + *(const f32x4*)(X + ((size_t)g * rows_per_group + r) * C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) shd[tid * 4 + e] = s[e];
+    __syncthreads();
+    if (tid < tpr) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < nrg; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += shd[(q * tpr + tid) * 4 + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[((size_t)g * slabs + slab) * C + tid * 4 + e] = a[e];
+    }
+}
+__global__ void colsum_groups_fin_kernel(const float* __restrict__ part, int G, int C, int slabs, float* __restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * C) return;
+    int g = t / C, c = t % C;
+    float s = 0.f;
+    for (int u = 0; u < slabs; ++u) s += part[((size_t)g * slabs + u) * C + c];
+    out[t] = s;
+}
+
+int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out, float* scratch = nullptr) {
+    if (scratch && vec_ok(C, X) && 256 % (C / 4) == 0 && rows_per_group >= 256) {
+        const int slabs = 16;                       // scratch: [G][16][C] floats
+        hipLaunchKernelGGL(colsum_groups_vec_kernel, dim3(slabs, G), dim3(256), 0, st, X, C, rows_per_group, slabs, scratch);
+        hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 255) / 256), dim3(256), 0, st, scratch, G, C, slabs, out);
+        return mlsp_launch_status();
+    }
     hipLaunchKernelGGL(colsum_groups_kernel, dim3((C + 63) / 64, G), dim3(256), 0, st, X, C, rows_per_group, out);
     return mlsp_launch_status();
 }

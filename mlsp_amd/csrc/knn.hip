@@ -828,13 +828,17 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 // For every point j: the list of (i, slot) with idx[i][slot] == j, sorted by i*256+slot so that the
 // backward gather-reduce that walks it sums in a fixed order (bitwise reproducible gradients).
 //   rev_off [B*N+1]  global edge offsets;  rev_ent [B*N*k]  packed (i_local << 8 | slot)
+#define RV_SPLIT 4
 __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict__ idx, int N, int k,
                                                            int* __restrict__ rev_off, int* __restrict__ rev_ent,
                                                            int B) {
     extern __shared__ int ism[];
     int* cnt = ism;            // [N]
     int* off = ism + N;        // [N+1]
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    // RV_SPLIT workgroups per cloud: each builds the (cheap) histogram + scan of the whole cloud, then fills and sorts
+    // only its own slice of destinations
+    const int b = blockIdx.x / RV_SPLIT, part = blockIdx.x % RV_SPLIT, tid = threadIdx.x, nt = blockDim.x;
+    const int dper = (N + RV_SPLIT - 1) / RV_SPLIT, d0 = part * dper, d1 = min(N, d0 + dper);
     const int* ib = idx + (size_t)b * N * k;
     const int E = N * k;
     for (int j = tid; j < N; j += nt) cnt[j] = 0;
@@ -859,18 +863,21 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     }
     __syncthreads();
     const int gbase = b * E;
-    for (int j = tid; j < N; j += nt) { rev_off[(size_t)b * N + j] = gbase + off[j]; cnt[j] = 0; }
-    if (b == B - 1 && tid == 0) rev_off[(size_t)B * N] = gbase + E;
+    for (int j = d0 + tid; j < d1; j += nt) rev_off[(size_t)b * N + j] = gbase + off[j];
+    for (int j = tid; j < N; j += nt) cnt[j] = 0;
+    if (b == B - 1 && part == RV_SPLIT - 1 && tid == 0) rev_off[(size_t)B * N] = gbase + E;
     __syncthreads();
     for (int e = tid; e < E; e += nt) {
         int j = ib[e];
-        int pos = atomicAdd(&cnt[j], 1);
-        rev_ent[gbase + off[j] + pos] = ((e / k) << 8) | (e % k);
+        if (j >= d0 && j < d1) {
+            int pos = atomicAdd(&cnt[j], 1);
+            rev_ent[gbase + off[j] + pos] = ((e / k) << 8) | (e % k);
+        }
     }
     __syncthreads();
     __threadfence_block();
     // per-destination insertion sort (lists are ~k long)
-    for (int j = tid; j < N; j += nt) {
+    for (int j = d0 + tid; j < d1; j += nt) {
         int* a = rev_ent + gbase + off[j];
         int n = off[j + 1] - off[j];
         for (int u = 1; u < n; ++u) {
@@ -890,6 +897,6 @@ int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int*
         hipError_t e = hipFuncSetAttribute((const void*)knn_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B);
+    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B);
     return mlsp_launch_status();
 }
