@@ -113,13 +113,19 @@ __global__ __launch_bounds__(256) void edge_reduce_vec_kernel(const float* __res
         int bs[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { best[e] = use_max[e] ? -INFINITY : INFINITY; bs[e] = 255; }
-        for (int s = sub; s < k; s += NP) {
-            const int j = base + irow[s];
+        // one coalesced load of the point's index row, then every neighbour row address comes from a lane shuffle:
+        // the k row gathers are independent and issue back-to-back instead of chaining index -> row per neighbour
+        const int jv = lane < k ? base + irow[lane] : base;
+        for (int s0 = 0; s0 < k; s0 += NP) {            // wave-uniform trip count: every lane takes part in the shuffle
+            const int s = s0 + sub;
+            const bool ok = s < k;
+            const int j = __shfl(jv, ok ? s : 0, 64);
             const f32x4 u = *(const f32x4*)(uv + (size_t)j * ld + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s1[e] += u[e]; s2[e] = fmaf(u[e], u[e], s2[e]);
-                bool take = use_max[e] ? (u[e] > best[e]) : (u[e] < best[e]);
+                const float ue = ok ? u[e] : 0.f;
+                s1[e] += ue; s2[e] = fmaf(ue, ue, s2[e]);
+                bool take = ok && (use_max[e] ? (u[e] > best[e]) : (u[e] < best[e]));
                 best[e] = take ? u[e] : best[e]; bs[e] = take ? s : bs[e];
             }
         }
@@ -186,16 +192,22 @@ __global__ __launch_bounds__(256) void edge_bwd_gather_vec_kernel(const float* _
         for (int e = 0; e < 4; ++e) { float sc = scale[c + e]; A[e] = sc * mean_dz[c + e]; Bc[e] = sc * invstd[c + e] * mean_dzy[c + e]; }
     }
     float acc[4] = {0, 0, 0, 0};
-    for (int en = e0 + sub; en < e1; en += NP) {
-        const int ent = rev_ent[en];
-        const int i = base + (ent >> 8), slot = ent & 255;
-        const f32x4 g = *(const f32x4*)(gz + (size_t)i * Cout + c);
-        const uint32_t a4 = *(const uint32_t*)(argsel + (size_t)i * Cout + c);
-        const f32x4 v = *(const f32x4*)(uv + (size_t)i * ld + Cout + c);
+    for (int ec = e0; ec < e1; ec += 64) {              // chunks of 64 reverse entries: one coalesced load, then shuffles
+        const int nent = min(64, e1 - ec);
+        const int entv = lane < nent ? rev_ent[ec + lane] : 0;
+        for (int t0 = 0; t0 < nent; t0 += NP) {          // wave-uniform trip count (see edge_reduce_vec_kernel)
+            const int t = t0 + sub;
+            const bool ok = t < nent;
+            const int ent = __shfl(entv, ok ? t : 0, 64);
+            const int i = base + (ent >> 8), slot = ent & 255;
+            const f32x4 g = *(const f32x4*)(gz + (size_t)i * Cout + c);
+            const uint32_t a4 = *(const uint32_t*)(argsel + (size_t)i * Cout + c);
+            const f32x4 v = *(const f32x4*)(uv + (size_t)i * ld + Cout + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float ge = (((a4 >> (8 * e)) & 255) == (uint32_t)slot) ? g[e] : 0.f;
-            acc[e] += ge - Bc[e] * v[e];
+            for (int e = 0; e < 4; ++e) {
+                float ge = (((a4 >> (8 * e)) & 255) == (uint32_t)slot) ? g[e] : 0.f;
+                acc[e] += ok ? (ge - Bc[e] * v[e]) : 0.f;
+            }
         }
     }
 #pragma unroll
