@@ -65,10 +65,15 @@ class _Ctx:
             mean = y.mean(dim=reduce_dims)
             var = y.var(dim=reduce_dims, unbiased=False)
             with torch.no_grad():
-                rm, rv = self.p[prefix + ".running_mean"], self.p[prefix + ".running_var"]
-                self.new_buffers[prefix + ".running_mean"] = (1 - BN_MOM) * rm + BN_MOM * mean
-                self.new_buffers[prefix + ".running_var"] = (1 - BN_MOM) * rv + BN_MOM * var * (n / max(n - 1, 1))
-                self.new_buffers[prefix + ".num_batches_tracked"] = self.p[prefix + ".num_batches_tracked"] + 1
+                # chained: a module invoked twice in one forward (DefRec under activate_DefRec + ..._ondef,
+                # PointSegDA/Models.py:227-236) updates its running statistics twice, as nn.BatchNorm does
+                nb = self.new_buffers
+                rm = nb.get(prefix + ".running_mean", self.p[prefix + ".running_mean"])
+                rv = nb.get(prefix + ".running_var", self.p[prefix + ".running_var"])
+                nt = nb.get(prefix + ".num_batches_tracked", self.p[prefix + ".num_batches_tracked"])
+                nb[prefix + ".running_mean"] = (1 - BN_MOM) * rm + BN_MOM * mean
+                nb[prefix + ".running_var"] = (1 - BN_MOM) * rv + BN_MOM * var * (n / max(n - 1, 1))
+                nb[prefix + ".num_batches_tracked"] = nt + 1
         else:
             mean, var = self.p[prefix + ".running_mean"], self.p[prefix + ".running_var"]
         yhat = (y - mean.view(shape)) / torch.sqrt(var.view(shape) + BN_EPS)

@@ -18,6 +18,12 @@ def make_args(dropout=0.0, cuda=False):
                               Scan_Rec_weight=0.5)
 
 
+def make_seg_args(dropout=0.0, gpu=False):
+    # fields read by PointSegDA/Models.py (:25-28 gpus, :257-258 dropout, :353 density_num_class, :370 pergroup)
+    return argparse.Namespace(gpus=[0] if gpu else [-1], dropout=dropout, density_num_class=16, pergroup=2.0,
+                              DefRec_weight=0.5, normal_pred_weight=0.5, Density_weight=0.05)
+
+
 @torch.no_grad()
 def perturb_params(model, seed):
     """Deterministically move parameters off their init so that BN affine terms, biases and

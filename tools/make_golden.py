@@ -154,6 +154,75 @@ def graph_feature_case(ref_mu, seed):
     return dict(x=npy(x), feat=npy(f.contiguous()))
 
 
+def import_seg_reference():
+    """PointSegDA/Models.py imports with torch + numpy only -- load it under its own module name."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_seg_models", ref_import.REF_ROOT + "/PointSegDA/Models.py")
+    mod = importlib.util.module_from_spec(spec)
+    import warnings
+    warnings.filterwarnings("ignore")
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def seg_case(seg, seed, B, N):
+    """DGCNN_DefRec (PointSegDA/Models.py:197-242): all heads, train mode (dropout 0) + eval mode, grads of a fixed
+    linear functional of the outputs, kNN indices of the four graph stages."""
+    torch.manual_seed(seed)
+    args = gc.make_seg_args(dropout=0.0)
+    model = seg.DGCNN_DefRec(args, in_size=3, num_classes=8)
+    gc.perturb_params(model, seed)
+    chk = gc.state_checksums(model)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, N, generator=g) * 2 - 1
+    out = {"x": npy(x)}
+    for k, v in chk.items():
+        out["chk/" + k] = v
+    knn_log = []
+    orig = seg.knn
+
+    def logging_knn(xx, k):
+        i = orig(xx, k)
+        knn_log.append(i)
+        return i
+    seg.knn = logging_knn
+    model.train()
+    try:
+        logits = model(x, make_seg=True, activate_DefRec=True, activate_density_normal_ondef=True)
+    finally:
+        seg.knn = orig
+    assert len(knn_log) == 4, len(knn_log)
+    for i, t in enumerate(knn_log):
+        out["knn%d" % i] = npy(t).astype(np.int16)
+    loss = 0.0
+    wg = torch.Generator().manual_seed(500 + seed)
+    for key in ("seg", "DefRec", "Normal", "density", "density_mse"):
+        w = torch.randn(logits[key].shape, generator=wg)
+        out["w/" + key] = npy(w)
+        loss = loss + (logits[key] * w).sum() / logits[key].numel()
+        out["train/" + key] = npy(logits[key])
+    out["train/loss"] = npy(loss)
+    loss.backward()
+    sd = dict(model.named_parameters())
+    for k in ["shared_layers.conv1.weight", "shared_layers.conv2.bias", "shared_layers.conv4.weight", "shared_layers.conv5.weight",
+              "shared_layers.conv6.weight", "shared_layers.conv6.bias", "input_transform_net.conv2d2.conv.0.weight",
+              "input_transform_net.fc1.fc.0.weight", "input_transform_net.fc3.bias", "seg.conv1.weight", "seg.conv4.bias",
+              "DefRec.conv1.weight", "Density_cls.mlp3.weight", "Norm_pred.conv2.weight"]:
+        gk = npy(sd[k].grad)
+        if gk.size > 70000:
+            gk = gk[:64]
+        out["grad/" + k] = gk
+    st = model.state_dict()
+    for k in ["seg.bn1.running_mean", "seg.bn1.running_var", "DefRec.bn3.running_var", "Density_cls.mlp2.fc.1.running_mean"]:
+        out["run/" + k] = npy(st[k])
+    model.eval()
+    with torch.no_grad():
+        le = model(x, make_seg=True, activate_DefRec=True, activate_density_normal_ondef=True)
+    for k, v in le.items():
+        out["eval/" + k] = npy(v)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     RefModels, ref_mu, ref_mlsp = ref_import.import_reference()
@@ -166,6 +235,9 @@ def main():
     for seed, B, N, keep in [(0, 6, 256, True), (1, 4, 1024, False), (2, 4, 128, False)]:
         np.savez_compressed(os.path.join(OUT, "dgcnn_s%d_B%d_N%d.npz" % (seed, B, N)),
                             **model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep))
+    seg = import_seg_reference()
+    for seed, B, N in [(0, 4, 256), (1, 3, 512)]:
+        np.savez_compressed(os.path.join(OUT, "segda_s%d_B%d_N%d.npz" % (seed, B, N)), **seg_case(seg, seed, B, N))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
