@@ -160,6 +160,13 @@ int mlsp_density_loss_bwd_f32(const float* pvec, const float* dens, const float*
 int mlsp_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
+/* Label generators of the target branch (python-pcl in the reference, PARITY UNPINNED -- see labels.hip):
+ * radius neighbour count behind cal_density (MLSP/mlsp.py:240-272; count excludes cloud index 0, capped at max_nn) and
+ * k-neighbourhood PCA normals behind kSearchNormalEstimation (PointDA/trainer.py:173-188; idx from mlsp_knn_f32, self
+ * included; oriented towards the origin).  x [B][N] rows of >= 3 floats, row pitch ldx. */
+int mlsp_radius_count_f32(const float* x, int ldx, int B, int N, float radius, int max_nn, int32_t* count, mlsp_stream_t stream);
+int mlsp_knn_normals_f32(const float* x, int ldx, const int32_t* idx, int B, int N, int k, float* normals, mlsp_stream_t stream);
+
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP
  * events on its launch stream.  mlsp_profile_end synchronises those events and fills
  * out[4] = {total ms in the kernel, launches, sum of algorithmic 2*M*N*K, 0}.  Not for production steps. */

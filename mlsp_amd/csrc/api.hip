@@ -100,6 +100,9 @@ int launch_colmax_dw(hipStream_t st, const float* S, const float* WG, const floa
 int launch_colmax_scatter_rows(hipStream_t st, const float* g, const int* arg, const float* W, int ldw, int B, int N, int Cout,
                                int Cin, float* dX, int lddx);
 
+int launch_radius_count(hipStream_t st, const float* x, int ld, int B, int N, float radius, int max_nn, int* count);
+int launch_knn_normals(hipStream_t st, const float* x, int ld, const int* idx, int B, int N, int k, float* normals);
+
 #define CHECK(x) do { int _r = (x); if (_r != MLSP_OK) return _r; } while (0)
 #define SLAB_BOUND_FLOATS ((size_t)16 << 20)   /* 64 MiB of fp32: bound on any split-K slab (gemm_pick_split) */
 
@@ -477,6 +480,15 @@ int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int
         CHECK(launch_colmax_scatter_rows(st, g, arg, W, ldw, B, N, Cout, Cin, dX, Cin));
     }
     return MLSP_OK;
+}
+
+int mlsp_radius_count_f32(const float* x, int ldx, int B, int N, float radius, int max_nn, int32_t* count, mlsp_stream_t st) {
+    if (!x || !count || B <= 0 || N <= 0 || ldx < 3 || !(radius > 0.f) || max_nn <= 0) return MLSP_ERR_ARG;
+    return launch_radius_count(st, x, ldx, B, N, radius, max_nn, count);
+}
+int mlsp_knn_normals_f32(const float* x, int ldx, const int32_t* idx, int B, int N, int k, float* normals, mlsp_stream_t st) {
+    if (!x || !idx || !normals || B <= 0 || N <= 0 || k < 3 || ldx < 3) return MLSP_ERR_ARG;
+    return launch_knn_normals(st, x, ldx, idx, B, N, k, normals);
 }
 
 int mlsp_segmax_fwd_f32(const float* Z, int P, int k, int C, float* out, uint8_t* argk, mlsp_stream_t st) {

@@ -2,12 +2,13 @@
 
 Same function names, argument order and return conventions (0-dim tensors supporting .item() and
 .backward()) as MLSP/mlsp.py:115-238, 275-287, 430-454.  Host-side input corruption and the pcl-based
-label generators of that file (deform_input, cal_density, ...) are out of this path's scope
-(SURVEY.md section 8 f-1/f-3).
+corruption of that file (deform_input, scan_input) is out of this path's scope (SURVEY.md section 8 f-3);
+`cal_density` is provided on device by mlsp_amd/labels.py (f-1, parity unpinned: python-pcl is third-party).
 """
 import torch
 
 from . import functional as Fh
+from .labels import cal_density, cal_density_gpu, estimate_normals   # noqa: F401  (SURVEY 8 f-1; mlsp.py:240-272)
 
 DefRec_SCALER = 20.0   # MLSP/mlsp.py:7
 
