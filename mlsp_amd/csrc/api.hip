@@ -8,8 +8,9 @@
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
                 double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr, int* sel_row = nullptr);
-int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, float* ysel,
-                         int* arg);
+int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, int panel_rows,
+                         float* ysel, int* arg);
+int gemm_panel_rows(int M, int N, int K);
 int gemm_stat_parts(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K);
 int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws);
@@ -404,9 +405,10 @@ int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin,
     Workspace w(ws, ws_bytes);
     const int fused_parts = training ? gemm_stat_parts(P, Cout, Cin) : 0;
     // fully fused path: statistics AND the per-cloud column extreme come out of the GEMM epilogue, Y is never written
-    const bool fuse_sel = (N % 128 == 0) && gemm_stat_parts(P, Cout, Cin) > 0;
+    const int prow = gemm_panel_rows(P, Cout, Cin);
+    const bool fuse_sel = (N % prow == 0) && gemm_stat_parts(P, Cout, Cin) > 0;
     float* Y = fuse_sel ? nullptr : w.take<float>((size_t)P * Cout);
-    const int ntm = (P + 127) / 128;
+    const int ntm = (P + prow - 1) / prow;
     float* pv = fuse_sel ? w.take<float>((size_t)ntm * Cout) : nullptr;
     int* pr = fuse_sel ? w.take<int>((size_t)ntm * Cout) : nullptr;
     int nparts = fused_parts ? fused_parts : bn_stat_parts(P);
@@ -425,7 +427,7 @@ int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin,
         CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, bn_save, bn_save + Cout, bn_save + 2 * Cout,
                                      bn_save + 3 * Cout));
     }
-    if (fuse_sel) CHECK(launch_colsel_panels(st, pv, pr, gamma, B, N, Cout, ysel, arg));
+    if (fuse_sel) CHECK(launch_colsel_panels(st, pv, pr, gamma, B, N, Cout, prow, ysel, arg));
     else CHECK(launch_colsel(st, Y, gamma, B, N, Cout, ysel, arg));
     CHECK(launch_colsel_out(st, ysel, bn_save, B, Cout, act, slope, out));
     return MLSP_OK;

@@ -223,9 +223,10 @@ int launch_colsel(hipStream_t st, const float* Y, const float* gamma, int B, int
     hipLaunchKernelGGL(colsel_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, Y, gamma, N, C, ysel, arg);
     return mlsp_launch_status();
 }
-int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, float* ysel,
-                         int* arg) {
-    hipLaunchKernelGGL(colsel_panels_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, pv, pr, gamma, B, N, C, N / 128, ysel, arg);
+int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, int panel_rows,
+                         float* ysel, int* arg) {
+    hipLaunchKernelGGL(colsel_panels_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, pv, pr, gamma, B, N, C, N / panel_rows, ysel,
+                       arg);
     return mlsp_launch_status();
 }
 int launch_colsel_out(hipStream_t st, const float* ysel, const float* bn, int B, int C, int act, float slope, float* out) {

@@ -41,11 +41,11 @@ struct GemmArgs {
 // ---- global -> registers for one 128x32 operand tile -----------------------------------------
 // SRC_KMAJOR = false: source [rows][K] (ld = row pitch). thread t: k-quad (t&7)*4, rows (t>>3)+32p.
 // SRC_KMAJOR = true : source [K][rows] (ld = k pitch).   thread t: row-quad (t&31)*4, k (t>>5)+8p.
-template <bool SRC_KMAJOR>
+template <bool SRC_KMAJOR, int NP>
 __device__ __forceinline__ void g2r(f32x4 (&r)[4], const float* __restrict__ src, int ld, int row0, int nrows,
                                     int k0, int kend, int vec_ok, int tid) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!SRC_KMAJOR) {
             int row = row0 + (tid >> 3) + 32 * p;
@@ -61,8 +61,9 @@ __device__ __forceinline__ void g2r(f32x4 (&r)[4], const float* __restrict__ src
                 }
             }
         } else {
-            int k = k0 + (tid >> 5) + 8 * p;
-            int row = row0 + (tid & 31) * 4;
+            // NP == 4: 128 rows (32 threads per k-row, 8 k-rows per pass); NP == 2: 64 rows (16 threads per k-row, 16 per pass)
+            int k = k0 + (NP == 4 ? (tid >> 5) + 8 * p : (tid >> 4) + 16 * p);
+            int row = row0 + (NP == 4 ? (tid & 31) : (tid & 15)) * 4;
             if (k < kend) {
                 const float* g = src + (size_t)k * ld + row;
                 if (vec_ok && row + 3 < nrows) {
@@ -78,24 +79,27 @@ __device__ __forceinline__ void g2r(f32x4 (&r)[4], const float* __restrict__ src
     }
 }
 
-template <bool SRC_KMAJOR>
+template <bool SRC_KMAJOR, int NP>
 __device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, int tid) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         if (!SRC_KMAJOR) {
             int row = (tid >> 3) + 32 * p;
             int k = (tid & 7) * 4;
             *(f32x4*)(s + row * SROW + k) = r[p];
         } else {
-            int k = (tid >> 5) + 8 * p;
-            int row = (tid & 31) * 4;
+            int k = NP == 4 ? (tid >> 5) + 8 * p : (tid >> 4) + 16 * p;
+            int row = (NP == 4 ? (tid & 31) : (tid & 15)) * 4;
             *(f32x4*)(s + k * SKMJ + row) = r[p];
         }
     }
 }
 
-template <bool TA, bool TB>
+// WM = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile; 1 -> 64x128 (twice the workgroups, for launches whose
+// 128-row grid is too small to keep ~3 workgroups per CU in flight and out of phase)
+template <bool TA, bool TB, int WM>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
+    constexpr int BMT = 64 * WM, NPA = 2 * WM;
     // A tile is k-major in LDS either way; its GLOBAL source is k-major iff TA.  B's source is
     // k-major iff !TB.
     __shared__ __attribute__((aligned(16))) float smem[BM * SROW * 2];
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
         tm = bid / p.ntn;
     }
     const int split = blockIdx.y;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BMT, n0 = tn * BN;
     const int kbeg = split * p.ksplit;
     const int kend = min(p.K, kbeg + p.ksplit);
 
@@ -135,31 +139,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[4], rb[4];
-    g2r<TA>(ra, p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid);
-    g2r<!TB>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid);
+    g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid);
+    g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid);
 
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        r2s<TA>(ra, As, tid);
-        r2s<!TB>(rb, Bs, tid);
+        r2s<TA, NPA>(ra, As, tid);
+        r2s<!TB, 4>(rb, Bs, tid);
         __syncthreads();
         if (k0 + BK < kend) {
-            g2r<TA>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid);
-            g2r<!TB>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid);
+            g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid);
+            g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid);
         }
         // Fragment reads.  K is consumed in groups of 4: MFMA step 2m takes k = 4m + 2h, step 2m+1 takes k = 4m + 2h + 1
         // (h = lane >> 5), so a row-major image gives each lane its two values with ONE 8-byte read; a k-major image is
         // read per value.  Both operands use the same k assignment, so every (TA, TB) combination is consistent.
-        const int arow = wm * 64 + l31, bcol = wn * 64 + l31;
+        const int arow = wm * (32 * WM) + l31, bcol = wn * 64 + l31;
 #pragma unroll
         for (int m = 0; m < BK / 4; ++m) {
             const int kq = 4 * m + 2 * h;
             float a0s0, a0s1, a1s0, a1s1, b0s0, b0s1, b1s0, b1s1;
+            a1s0 = 0.f; a1s1 = 0.f;
             if (!TA) {
-                const float2 t0 = *(const float2*)(As + arow * SROW + kq), t1 = *(const float2*)(As + (arow + 32) * SROW + kq);
-                a0s0 = t0.x; a0s1 = t0.y; a1s0 = t1.x; a1s1 = t1.y;
+                const float2 t0 = *(const float2*)(As + arow * SROW + kq);
+                a0s0 = t0.x; a0s1 = t0.y;
+                if (WM == 2) { const float2 t1 = *(const float2*)(As + (arow + 32) * SROW + kq); a1s0 = t1.x; a1s1 = t1.y; }
             } else {
                 a0s0 = As[kq * SKMJ + arow]; a0s1 = As[(kq + 1) * SKMJ + arow];
-                a1s0 = As[kq * SKMJ + arow + 32]; a1s1 = As[(kq + 1) * SKMJ + arow + 32];
+                if (WM == 2) { a1s0 = As[kq * SKMJ + arow + 32]; a1s1 = As[(kq + 1) * SKMJ + arow + 32]; }
             }
             if (TB) {
                 const float2 t0 = *(const float2*)(Bs + bcol * SROW + kq), t1 = *(const float2*)(Bs + (bcol + 32) * SROW + kq);
@@ -170,12 +176,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
             }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s0, b0s0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s0, b1s0, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s0, b0s0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s0, b1s0, acc[1][1], 0, 0, 0);
+            if (WM == 2) {
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s0, b0s0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s0, b1s0, acc[1][1], 0, 0, 0);
+            }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s1, b0s1, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s1, b1s1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s1, b0s1, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s1, b1s1, acc[1][1], 0, 0, 0);
+            if (WM == 2) {
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s1, b0s1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s1, b1s1, acc[1][1], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     const bool epi = (p.nsplit == 1);
     float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int col = n0 + wn * 64 + j * 32 + l31;
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
             float bv = (epi && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < p.M) {
                     float v = acc[i][j][r] + bv;
                     if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
@@ -212,10 +222,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
             float best = use_max ? -INFINITY : INFINITY;
             int brow = 0x7fffffff;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float v = acc[i][j][r];
                     const bool take = row < p.M && (use_max ? (v > best) : (v < best));
                     best = take ? v : best; brow = take ? row : brow;
@@ -340,7 +350,17 @@ int gemm_pick_split(int M, int N, int K) {
 }
 
 // number of BN-statistic partial rows a stats-fused launch writes (0: the launch would split K, use colstats)
-int gemm_stat_parts(int M, int N, int K) { return gemm_pick_split(M, N, K) == 1 ? (M + BM - 1) / BM : 0; }
+// 64-row tiles when the 128-row grid is too small to keep ~3 workgroups per CU busy (and K is not split)
+static int gemm_pick_bm(int M, int N, int K) {
+    long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN);
+    return (gemm_pick_split(M, N, K) == 1 && tiles128 < 1536 && M >= 256) ? 64 : 128;
+}
+int gemm_stat_parts(int M, int N, int K) {
+    if (gemm_pick_split(M, N, K) != 1) return 0;
+    int bm = gemm_pick_bm(M, N, K);
+    return (M + bm - 1) / bm;
+}
+int gemm_panel_rows(int M, int N, int K) { return gemm_pick_bm(M, N, K); }
 
 size_t gemm_slab_floats(int M, int N, int K) {
     int ns = gemm_pick_split(M, N, K);
@@ -393,7 +413,6 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     GemmArgs p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.gbias = gbias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.rows_per_group = rows_per_group;
-    p.ntm = (M + BM - 1) / BM; p.ntn = (N + BN - 1) / BN;
     int ns = gemm_pick_split(M, N, K);
     if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;   // no slab: fall back to one pass
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
@@ -402,6 +421,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     int ktiles = (K + BK - 1) / BK;
     int kts = (ktiles + ns - 1) / ns;
     ns = (ktiles + kts - 1) / kts;
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
+    p.ntm = (M + bm - 1) / bm; p.ntn = (N + BN - 1) / BN;
     p.nsplit = ns; p.ksplit = kts * BK;
     p.a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
     p.b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
@@ -410,10 +431,17 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     dim3 grid(p.xcd_map ? ((p.ntm + 7) / 8) * 8 * p.ntn : p.ntm * p.ntn, ns);
     const bool prof = g_prof.on && g_prof.used < PROF_MAX_PAIRS;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
-    if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p);
+    if (bm == 128) {
+        if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2>), grid, dim3(256), 0, st, p);
+        else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2>), grid, dim3(256), 0, st, p);
+        else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<true, true, 2>), grid, dim3(256), 0, st, p);
+    } else {
+        if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1>), grid, dim3(256), 0, st, p);
+        else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1>), grid, dim3(256), 0, st, p);
+        else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<true, true, 1>), grid, dim3(256), 0, st, p);
+    }
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
         g_prof.used++;
