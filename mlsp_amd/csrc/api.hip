@@ -240,7 +240,7 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
     if (B <= 0 || N <= 0 || C <= 0 || k <= 0 || ldx < C) return MLSP_ERR_ARG;
     if (C1 != 64 || C2 != 128 || tnet_points_per_tile(k) <= 0) return MLSP_ERR_UNSUPPORTED;
     const int P = B * N;
-    const int ntiles = (P + tnet_points_per_tile(k) - 1) / tnet_points_per_tile(k);
+    const int ntiles = B * ((N + tnet_points_per_tile(k) - 1) / tnet_points_per_tile(k));
     Workspace w(ws, ws_bytes);
     float* Wd = w.take<float>((size_t)2 * C1 * C);
     float* msel = w.take<float>((size_t)P * C1);
@@ -286,7 +286,7 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
     if (C1 != 64 || C2 != 128 || tnet_points_per_tile(k) <= 0) return MLSP_ERR_UNSUPPORTED;
     const int P = B * N;
     const size_t E = (size_t)P * k;
-    const int ntiles = (P + tnet_points_per_tile(k) - 1) / tnet_points_per_tile(k);
+    const int ntiles = B * ((N + tnet_points_per_tile(k) - 1) / tnet_points_per_tile(k));
     const int nb = tnet_grid(ntiles);
     Workspace w(ws, ws_bytes);
     float* Wd = w.take<float>((size_t)2 * C1 * C);

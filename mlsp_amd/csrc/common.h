@@ -35,6 +35,18 @@ struct Workspace {
     bool ok() const { return off <= size; }
 };
 
+// Linear block id -> (cloud, chunk) such that every chunk of a cloud has the same blockIdx % 8, i.e. lands on one XCD (and one
+// 4 MiB L2) under the observed round-robin dispatch: per-cloud kernels (kNN candidates, neighbour-row gathers) then re-read
+// their cloud from L2 instead of the fabric.  Placement only affects speed; B % 8 != 0 falls back to cloud-major order.
+__device__ __forceinline__ void xcd_cloud_map(int bid, int bpc, int B, int& cloud, int& chunk) {
+    if ((B & 7) == 0) {
+        const int g = bid / (8 * bpc), r = bid - g * 8 * bpc;
+        cloud = 8 * g + (r & 7); chunk = r >> 3;
+    } else {
+        cloud = bid / bpc; chunk = bid - cloud * bpc;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -98,7 +98,12 @@ __global__ __launch_bounds__(256) void edge_reduce_vec_kernel(const float* __res
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane / LR, c = (lane % LR) * 4;
     const int ld = 2 * Cout;
-    const int p0 = (blockIdx.x * 4 + w) * EDGE_PTS_PER_WAVE;
+    int p0 = (blockIdx.x * 4 + w) * EDGE_PTS_PER_WAVE;
+    if (N % (4 * EDGE_PTS_PER_WAVE) == 0) {              // whole clouds per XCD (see xcd_cloud_map)
+        int cloud, chunk;
+        xcd_cloud_map(blockIdx.x, N / (4 * EDGE_PTS_PER_WAVE), P / N, cloud, chunk);
+        p0 = cloud * N + (chunk * 4 + w) * EDGE_PTS_PER_WAVE;
+    }
     const f32x4 g4 = *(const f32x4*)(gamma + c);
     bool use_max[4];
 #pragma unroll
@@ -180,7 +185,12 @@ __global__ __launch_bounds__(256) void edge_bwd_gather_vec_kernel(const float* _
     constexpr int Cout = LR * 4, NP = 64 / LR;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = blockIdx.x * 4 + w;
+    int j = blockIdx.x * 4 + w;
+    if (N % 4 == 0) {
+        int cloud, chunk;
+        xcd_cloud_map(blockIdx.x, N / 4, P / N, cloud, chunk);
+        j = cloud * N + chunk * 4 + w;
+    }
     if (j >= P) return;
     const int sub = lane / LR, c = (lane % LR) * 4;
     const int base = (j / N) * N;

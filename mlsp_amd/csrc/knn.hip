@@ -519,14 +519,15 @@ static int launch_knn_mfma3(hipStream_t st, const float* x, int ld, const float*
 
 template <int CT>
 __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
-                                                        int ld, int N, int C, int k, int vec_ok, int* __restrict__ idx) {
+                                                        int ld, int N, int C, int k, int vec_ok, int* __restrict__ idx, int B) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TILE = CT * KM_STRIDE;
     constexpr int NSTEP = CT / 2;
     constexpr int SPR = NSTEP >= 16 ? NSTEP / 16 : 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
+    int b, chunk;
+    xcd_cloud_map(blockIdx.x, (N + 127) / 128, B, b, chunk);
     const float* xb = x + (size_t)b * N * ld;
     const float* xxb = xx_all + (size_t)b * N;
     float* tiles = sm;                                    // [2][CT][33]
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
     float* bufv = cxx + 96 + wave * 32 * KNN4_CAP;        // [32 queries][CAP] survivor values of this wave
     int* bufj = (int*)(cxx + 96 + 4 * 32 * KNN4_CAP) + wave * 32 * KNN4_CAP;
 
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = chunk * 128 + wave * 32;
     float qa[NSTEP];
     {
         const int q = q0 + l31;
@@ -768,8 +769,8 @@ static int launch_knn_mfma4_ct(hipStream_t st, const float* x, int ld, const flo
         if (e != hipSuccess) return (int)e;
     }
     int vec_ok = (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
-    dim3 grid((N + 127) / 128, B);
-    hipLaunchKernelGGL((knn_mfma4_kernel<CT>), grid, dim3(256), lds, st, x, xx, ld, N, C, k, vec_ok, idx);
+    dim3 grid(((N + 127) / 128) * B);
+    hipLaunchKernelGGL((knn_mfma4_kernel<CT>), grid, dim3(256), lds, st, x, xx, ld, N, C, k, vec_ok, idx, B);
     return mlsp_launch_status();
 }
 
@@ -837,7 +838,9 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     int* off = ism + N;        // [N+1]
     // RV_SPLIT workgroups per cloud: each builds the (cheap) histogram + scan of the whole cloud, then fills and sorts
     // only its own slice of destinations
-    const int b = blockIdx.x / RV_SPLIT, part = blockIdx.x % RV_SPLIT, tid = threadIdx.x, nt = blockDim.x;
+    int b, part;
+    xcd_cloud_map(blockIdx.x, RV_SPLIT, B, b, part);      // the RV_SPLIT workgroups of a cloud share an XCD (they read the same idx)
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int dper = (N + RV_SPLIT - 1) / RV_SPLIT, d0 = part * dper, d1 = min(N, d0 + dper);
     const int* ib = idx + (size_t)b * N * k;
     const int E = N * k;

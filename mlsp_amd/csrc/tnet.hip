@@ -27,14 +27,35 @@
 
 __device__ __forceinline__ float lrelu(float a, float slope) { return a > 0.f ? a : a * slope; }
 
+// Tiles never straddle clouds (tpc = ceil(N / TP) tiles per cloud) and the persistent workgroups of one XCD (blockIdx % 8)
+// walk only the clouds c with c % 8 == that label, so the neighbour rows a tile gathers stay in that XCD's L2.
+// m-th tile of this workgroup -> first point index and point count; returns false when the workgroup is done.
+__device__ __forceinline__ bool tn_tile(int m, int B, int N, int TP, int& pt0, int& npts) {
+    const int tpc = (N + TP - 1) / TP;
+    int cloud, tic;
+    if ((B & 7) == 0 && (gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7, q = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int L = q + m * per;
+        if (L >= (B >> 3) * tpc) return false;
+        cloud = x + 8 * (L / tpc); tic = L % tpc;
+    } else {
+        const int L = blockIdx.x + m * gridDim.x;
+        if (L >= B * tpc) return false;
+        cloud = L / tpc; tic = L % tpc;
+    }
+    pt0 = cloud * N + tic * TP;
+    npts = min(TP, N - tic * TP);
+    return true;
+}
+
 // gather hpre = u_j + v_i for the rows of one tile into Hs (k-major); invalid rows are zero.  512 threads: 4 per row.
 __device__ __forceinline__ void tn_build_h(float* __restrict__ Hs, const float* __restrict__ uv, const int* __restrict__ idx,
-                                           int tile, int TP, int k, int P, int N, int tid) {
+                                           int pt0, int npts, int k, int N, int tid) {
     const int row = tid >> 2, qt = tid & 3;
     const int pt = row / k, s = row - pt * k;
-    const int i = tile * TP + pt;
+    const int i = pt0 + pt;
     f32x4 hv[4];
-    if (pt < TP && i < P) {
+    if (pt < npts) {
         const int j = (i / N) * N + idx[(size_t)i * k + s];
         const f32x4* ur = (const f32x4*)(uv + (size_t)j * 2 * TN_C1 + 16 * qt);
         const f32x4* vr = (const f32x4*)(uv + (size_t)i * 2 * TN_C1 + TN_C1 + 16 * qt);
@@ -100,16 +121,16 @@ __global__ __launch_bounds__(512) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
     const int o = tid & 127;
     const bool use_max = p.gamma2[o] >= 0.f;
     double ssum = 0.0, ssq = 0.0;
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int pt0, npts;
+    for (int m = 0; tn_tile(m, p.P / p.N, p.N, p.TP, pt0, npts); ++m) {
         __syncthreads();
-        tn_build_h(Hs, p.uv, p.idx, tile, p.TP, p.k, p.P, p.N, tid);
+        tn_build_h(Hs, p.uv, p.idx, pt0, npts, p.k, p.N, tid);
         __syncthreads();
-        const int npts = min(p.TP, p.P - tile * p.TP);
         tn_compute_z(Hs, Ws, S1, Zs, npts * p.k, p.slope, wm, wn, l31, h);
         __syncthreads();
         for (int item = tid; item < npts * TN_C2; item += 512) {
             const int pt = item >> 7;
-            const size_t i = (size_t)tile * p.TP + pt;
+            const size_t i = (size_t)pt0 + pt;
             const float* z = Zs + (pt * p.k) * TN_SZ + o;
             float best = z[0], s1 = z[0], s2 = z[0] * z[0];
             int bs = 0;
@@ -218,17 +239,17 @@ __global__ __launch_bounds__(512) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
     for (int r = 0; r < 16; ++r) accW[r] = 0.f;
     double sd = 0.0, sdh = 0.0;
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int pt0, npts;
+    for (int m = 0; tn_tile(m, p.P / p.N, p.N, p.TP, pt0, npts); ++m) {
         __syncthreads();
-        const int npts = min(p.TP, p.P - tile * p.TP);
         const int nvalid = npts * p.k;
-        tn_build_h(Hs, p.uv, p.idx, tile, p.TP, p.k, p.P, p.N, tid);
+        tn_build_h(Hs, p.uv, p.idx, pt0, npts, p.k, p.N, tid);
         if (tid < TN_ROWS) {
             int pt = tid / p.k, s = tid - pt * p.k;
             rowpt[tid] = tid < nvalid ? ((pt << 8) | s) : -1;
         }
         for (int e = tid; e < npts * TN_C2; e += 512) {
-            size_t gi = (size_t)tile * p.TP * TN_C2 + e;
+            size_t gi = (size_t)pt0 * TN_C2 + e;
             gs[e] = p.g[gi];
             as[e] = p.argsel[gi];
         }
@@ -286,7 +307,7 @@ __global__ __launch_bounds__(512) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
                     const float hp = Hs[c * TN_SH + row];
                     const float a = fmaf(hp, sc, sh);
                     const float d = accH[r] * (a > 0.f ? 1.f : p.slope);
-                    p.dhp[((size_t)tile * p.TP * p.k + row) * TN_C1 + c] = d;
+                    p.dhp[((size_t)pt0 * p.k + row) * TN_C1 + c] = d;
                     lsd += d; lsdh = fmaf(d, (hp - mu) * is, lsdh);
                 }
             }
@@ -325,7 +346,12 @@ __global__ __launch_bounds__(256) void tnet_edge_bwd2_kernel(const float* __rest
                                                              int P, int N, int k, float* __restrict__ duv) {
     const int c = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = blockIdx.x * 4 + w;
+    int j = blockIdx.x * 4 + w;
+    if (N % 4 == 0) {
+        int cloud, chunk;
+        xcd_cloud_map(blockIdx.x, N / 4, P / N, cloud, chunk);
+        j = cloud * N + chunk * 4 + w;
+    }
     if (j >= P) return;
     const int base = (j / N) * N;
     const float sc = bn1[c], mu = bn1[2 * TN_C1 + c], is = bn1[3 * TN_C1 + c];
@@ -350,7 +376,7 @@ __global__ __launch_bounds__(256) void tnet_edge_bwd2_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-int tnet_grid(int ntiles) { return ntiles < 512 ? ntiles : 512; }
+int tnet_grid(int ntiles) { return ntiles < 512 ? ((ntiles + 7) / 8) * 8 : 512; }
 int tnet_points_per_tile(int k) { return k > 0 && k <= TN_ROWS ? (TN_ROWS / k > 8 ? 8 : TN_ROWS / k) : 0; }
 
 static int tnet_set_lds(const void* fn) {
@@ -365,7 +391,7 @@ int launch_tnet_edge_fwd(hipStream_t st, const float* uv, const int* idx, const 
     a.uv = uv; a.idx = idx; a.bn1 = bn1; a.W2 = W2; a.gamma2 = gamma2; a.zsel = zsel; a.argsel = argsel; a.part = part;
     a.P = P; a.N = N; a.k = k; a.TP = tnet_points_per_tile(k); a.slope = slope;
     if (a.TP <= 0) return MLSP_ERR_UNSUPPORTED;
-    a.ntiles = (P + a.TP - 1) / a.TP;
+    a.ntiles = (P / N) * ((N + a.TP - 1) / a.TP);
     int rc = tnet_set_lds((const void*)tnet_edge_fwd_kernel);
     if (rc) return rc;
     hipLaunchKernelGGL(tnet_edge_fwd_kernel, dim3(tnet_grid(a.ntiles)), dim3(512), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
@@ -402,7 +428,7 @@ int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const 
     a.dhp = dhp; a.dW2part = dW2part; a.part1 = part1;
     a.P = P; a.N = N; a.k = k; a.TP = tnet_points_per_tile(k); a.slope = slope;
     if (a.TP <= 0) return MLSP_ERR_UNSUPPORTED;
-    a.ntiles = (P + a.TP - 1) / a.TP;
+    a.ntiles = (P / N) * ((N + a.TP - 1) / a.TP);
     int rc = tnet_set_lds((const void*)tnet_edge_bwd_kernel);
     if (rc) return rc;
     hipLaunchKernelGGL(tnet_edge_bwd_kernel, dim3(tnet_grid(a.ntiles)), dim3(512), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
