@@ -371,17 +371,22 @@ size_t gemm_slab_floats(int M, int N, int K) {
 // Off by default.  mlsp_profile_begin() arms it; every gemm_f32_kernel launch is then bracketed by two
 // events recorded on the launch stream; mlsp_profile_end() returns {ms, launches, algorithmic FLOP}.
 #include <vector>
+#include <cstdlib>
+#include <cstdio>
 static struct GemmProf {
     bool on = false;
     std::vector<hipEvent_t> ev;     // pairs
     size_t used = 0;
     double flop = 0.0;
+    struct Rec { int M, N, K, ta, tb, ns, bm, fused; };
+    std::vector<Rec> rec;           // one per pair, for the MLSP_PROF_DUMP listing
 } g_prof;
 #define PROF_MAX_PAIRS 4096
 
 extern "C" int mlsp_profile_begin(void) {
     if (g_prof.ev.empty()) {
         g_prof.ev.resize(2 * PROF_MAX_PAIRS);
+        g_prof.rec.resize(PROF_MAX_PAIRS);
         for (auto& e : g_prof.ev)
             if (hipEventCreate(&e) != hipSuccess) { g_prof.ev.clear(); return MLSP_ERR_UNSUPPORTED; }
     }
@@ -393,11 +398,17 @@ extern "C" int mlsp_profile_begin(void) {
 extern "C" int mlsp_profile_end(double* out) {
     g_prof.on = false;
     double ms = 0.0;
+    const bool dump = getenv("MLSP_PROF_DUMP") != nullptr;    // debug listing: one line per profiled launch
     for (size_t i = 0; i < g_prof.used; ++i) {
         float t = 0.f;
         if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
         if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
         ms += t;
+        if (dump) {
+            const auto& r = g_prof.rec[i];
+            fprintf(stderr, "gemm %c%c M=%d N=%d K=%d split=%d bm=%d epi=%d  %.1f us  %.1f TF\n", r.ta ? 'T' : 'N', r.tb ? 'T' : 'N',
+                    r.M, r.N, r.K, r.ns, r.bm, r.fused, t * 1e3, 2.0 * r.M * r.N * r.K / (t * 1e-3) / 1e12);
+        }
     }
     if (out) { out[0] = ms; out[1] = (double)g_prof.used; out[2] = g_prof.flop; out[3] = 0.0; }
     return MLSP_OK;
@@ -444,6 +455,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     }
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
+        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0)};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;
     }

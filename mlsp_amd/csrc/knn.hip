@@ -556,8 +556,12 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
     const int ntiles = (N + 31) / 32;
     constexpr int NLD = (32 * CT / 4 + 255) / 256;
     f32x4 stage[NLD];
+    float xxstage = 0.f;                                  // candidate norms travel with the tile (no exposed load in r2s)
     auto g2r_tile = [&](int t) {
         const int j0 = t * 32;
+#ifndef KNN4_NO_XXPF
+        if (tid < 32) xxstage = (t < ntiles && j0 + tid < N) ? xxb[j0 + tid] : 0.f;
+#endif
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             int f = tid + 256 * p;
@@ -585,15 +589,22 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
                 for (int e = 0; e < 4; ++e) T[(c + e) * KM_STRIDE + cand] = stage[p][e];
             }
         }
+#ifndef KNN4_NO_XXPF
+        if (tid < 32) cxx[(t % 3) * 32 + tid] = xxstage;
+#else
         if (tid < 32) {
             int j = t * 32 + tid;
             cxx[(t % 3) * 32 + tid] = (t < ntiles && j < N) ? xxb[j] : 0.f;
         }
+#endif
     };
 
     // one full sweep over the candidate tiles; sel(r, pd, t) is invoked for every query row of every tile
     auto sweep = [&](auto&& sel) {
         f32x16 accCur, accNext;
+#ifdef KNN4_PROBE_NOSEL
+        float cmx = -INFINITY;
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accCur[r] = 0.f; accNext[r] = 0.f; }
         __syncthreads();                       // previous sweep is done with the tile buffers
@@ -611,7 +622,9 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
         for (int t = 0; t < ntiles; ++t) {
             __syncthreads();
             const bool have_next = t + 1 < ntiles;
+#ifndef KNN4_PROBE_NOGLOBAL
             if (t + 2 < ntiles) g2r_tile(t + 2);
+#endif
             const float* T = tiles + ((t + 1) & 1) * TILE + h * KM_STRIDE + l31;
             const float xxc = cxx[(t % 3) * 32 + l31];
             const int j = t * 32 + l31;
@@ -632,7 +645,11 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
                 }
                 float pd = fmaf(2.0f, accCur[r], -xxc) - xxq[r];
                 if (j >= N) pd = -INFINITY;
+#ifdef KNN4_PROBE_NOSEL
+                cmx = fmaxf(cmx, pd);
+#else
                 sel(r, pd, t);
+#endif
 #ifndef KNN4_NO_SCHED_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -641,6 +658,9 @@ __global__ __launch_bounds__(256) void knn_mfma4_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) accCur[r] = accNext[r];
         }
+#ifdef KNN4_PROBE_NOSEL
+        if (cmx == 12345.f) idx[1] = 1;
+#endif
     };
 
     // ---- pass A: per-lane chunk maxima -> tau = k-th largest of the 32 lane values of each query
@@ -782,6 +802,402 @@ static int launch_knn_mfma4(hipStream_t st, const float* x, int ld, const float*
     return MLSP_ERR_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------------
+// v5: the v4 two-pass threshold select with the candidates of a query split over TWO waves.
+// A workgroup is 8 waves = 4 query groups (32 queries each) x 2 candidate halves, so every SIMD holds two waves and one
+// wave's LDS / barrier / selection latency is covered by the other's MFMA work (v4 ran one wave per SIMD: its sweeps took
+// 2x the MFMA-bound time).  Same canonical distances and the same total order (pd desc, index asc) as v1-v4:
+//   pass A  per-lane running maxima over the wave's half: 2 x 32 chunk maxima per query, exchanged through LDS;
+//           tau = k-th largest of the 64 (a lower bound of the k-th best distance, ~24 survivors of 1024 expected).
+//   pass B  survivors (pd >= tau) of each half are appended, as 64-bit sortable keys, to that wave's 32-entry buffer.
+//   final   rank of every key among the <= 64 keys of the query by counting; rank < k -> idx[q][rank].
+//   pass C  (any buffer overflowed: massive ties) each wave runs the v3 sequential insertion over its half and
+//           publishes its exact top-k as keys; the same final merges the two halves.
+// RES (CT <= 16): the whole cloud's candidates stay in LDS for both passes, no per-tile barriers.
+// Requires N % 128 == 0 (full query chunks, an even number of 32-candidate tiles); everything else stays on v4.
+#define KNN5_CAP 32
+#define KNN5_XS 68                 // row stride (floats) of the pass-A exchange image: 16 B aligned rows, 2-way banked
+typedef unsigned long long u64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u64 knn_key(float pd, int j) {
+    pd += 0.0f;                                            // -0 -> +0: keys order exactly like the float compare
+    unsigned u = (unsigned)__float_as_int(pd);
+    u ^= (unsigned)((int)u >> 31) | 0x80000000u;           // monotone float -> unsigned
+    return ((u64)u << 32) | (unsigned)(~j);                // larger key = (larger pd, then smaller index)
+}
+
+template <int CT, bool VEC, bool RES>
+__global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
+                                                        int ld, int N, int C, int k, int* __restrict__ idx, int B) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int TILE = CT * KM_STRIDE;
+    constexpr int NSTEP = CT / 2;
+    constexpr int SPR = NSTEP >= 16 ? NSTEP / 16 : 1;      // MFMA steps issued per query row of the select loop
+    constexpr int GS = NSTEP >= 16 ? 16 : NSTEP;           // B fragments fetched per group
+    constexpr int NG = NSTEP / GS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int qg = wave & 3, ch = wave >> 2, ht = tid & 255;
+    int b, chunk;
+    xcd_cloud_map(blockIdx.x, N / 128, B, b, chunk);
+    const float* xb = x + (size_t)b * N * ld;
+    const float* xxb = xx_all + (size_t)b * N;
+    const int ntiles = N / 32, nt2 = ntiles / 2;
+
+    float* tiles = sm;                                           // RES: [ntiles][CT][33]   else [2 halves][2][CT][33]
+    float* cxx = tiles + (RES ? (size_t)ntiles * TILE : (size_t)4 * TILE);   // RES: [N]   else [2 halves][3][32]
+    u64* bufk = (u64*)(cxx + (RES ? N : 192));                   // [4 qg][2 ch][32 queries][CAP] survivor keys
+    float* xch = (float*)bufk;                                   // pass-A exchange [4][2][16][64], dead before pass B
+    float* tau = (float*)(bufk + 4 * 2 * 32 * KNN5_CAP);         // [4 qg][16 rows][2 h]
+    int* cnts = (int*)(tau + 128);                               // [4 qg][2 ch][32 queries]
+
+    const int q0 = chunk * 128 + qg * 32;
+    float qa[NSTEP];
+    {
+        const int q = q0 + l31;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            int c = 2 * s + h;
+            qa[s] = (c < C) ? xb[(size_t)q * ld + c] : 0.f;
+        }
+    }
+    float xxq[16], thr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        xxq[r] = xxb[q0 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        thr[r] = -INFINITY;
+    }
+
+    if (RES) {
+        // the whole cloud, once: tile t at tiles + t*TILE, k-major [c][33]
+        if (VEC) {
+            for (int f = tid; f < N * (CT / 4); f += 512) {
+                const int cand = f / (CT / 4), c = (f % (CT / 4)) * 4;
+                const f32x4 v = *(const f32x4*)(xb + (size_t)cand * ld + c);
+                float* T = tiles + (cand >> 5) * TILE + (cand & 31);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(c + e) * KM_STRIDE] = v[e];
+            }
+        } else {
+            for (int f = tid; f < N * CT; f += 512) {
+                const int cand = f / CT, c = f % CT;
+                tiles[(cand >> 5) * TILE + c * KM_STRIDE + (cand & 31)] = c < C ? xb[(size_t)cand * ld + c] : 0.f;
+            }
+        }
+        for (int j = tid; j < N; j += 512) cxx[j] = xxb[j];
+    }
+
+#if defined(KNN5_PROBE) && KNN5_PROBE == 3
+    __syncthreads();
+    if (tiles[tid] == 12345.f) idx[0] = 1;
+    return;
+#endif
+    // streaming mode: the 256 threads of a half stage that half's tiles (registers -> LDS, k-major)
+    constexpr int NLD = VEC ? (32 * CT / 4 + 255) / 256 : (32 * CT + 255) / 256;
+    f32x4 stagev[VEC ? NLD : 1];
+    float stages[VEC ? 1 : NLD];
+    float xxstage = 0.f;
+    float* htiles = tiles + ch * 2 * TILE;
+    float* hcxx = cxx + ch * 96;
+    auto g2r_tile = [&](int tl) {                          // tl: tile index inside the half, < nt2
+        const int j0 = (ch * nt2 + tl) * 32;
+        if (ht < 32) xxstage = xxb[j0 + ht];
+        if (VEC) {
+#pragma unroll
+            for (int p = 0; p < NLD; ++p) {
+                const int f = ht + 256 * p;
+                if (32 * CT / 4 >= 256 * (p + 1) || f < 32 * CT / 4)
+                    stagev[p] = *(const f32x4*)(xb + (size_t)(j0 + f / (CT / 4)) * ld + (f % (CT / 4)) * 4);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NLD; ++p) {
+                const int f = ht + 256 * p;
+                const int cand = f / CT, c = f % CT;
+                stages[p] = (f < 32 * CT && c < C) ? xb[(size_t)(j0 + cand) * ld + c] : 0.f;
+            }
+        }
+    };
+    auto r2s_tile = [&](int buf, int tl) {
+        float* T = htiles + buf * TILE;
+        if (VEC) {
+#pragma unroll
+            for (int p = 0; p < NLD; ++p) {
+                const int f = ht + 256 * p;
+                if (32 * CT / 4 >= 256 * (p + 1) || f < 32 * CT / 4) {
+                    const int cand = f / (CT / 4), c = (f % (CT / 4)) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) T[(c + e) * KM_STRIDE + cand] = stagev[p][e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NLD; ++p) {
+                const int f = ht + 256 * p;
+                if (f < 32 * CT) T[(f % CT) * KM_STRIDE + f / CT] = stages[p];
+            }
+        }
+        if (ht < 32) hcxx[(tl % 3) * 32 + ht] = xxstage;
+    };
+    auto tile_ptr = [&](int tl) -> const float* {          // B-fragment base of tile tl of this wave's half
+        return (RES ? tiles + (size_t)(ch * nt2 + tl) * TILE : htiles + (tl & 1) * TILE) + h * KM_STRIDE + l31;
+    };
+
+    // one sweep over the wave's half; sel(r, pd, j) sees every (query row, candidate) distance once
+    auto sweep = [&](auto&& sel) {
+        f32x16 accCur, accNext;
+#ifdef KNN5_PROBE_NOSEL
+        float cmx = -INFINITY;
+#endif
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accCur[r] = 0.f; accNext[r] = 0.f; }
+        __syncthreads();                       // previous sweep is done with the tile buffers / RES image is complete
+        if (!RES) {
+            g2r_tile(0);
+            r2s_tile(0, 0);
+            __syncthreads();
+        }
+        {
+            const float* T = tile_ptr(0);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s)
+                accCur = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], T[(2 * s) * KM_STRIDE], accCur, 0, 0, 0);
+        }
+        if (!RES) {
+            g2r_tile(1);                       // nt2 >= 2 (N >= 128)
+            r2s_tile(1, 1);
+        }
+        for (int tl = 0; tl < nt2; ++tl) {
+            if (!RES) __syncthreads();
+            const bool have_next = tl + 1 < nt2;
+            if (!RES && tl + 2 < nt2) g2r_tile(tl + 2);
+            const float* T = tile_ptr(tl + 1);
+            const int j = (ch * nt2 + tl) * 32 + l31;
+            const float xxc = RES ? cxx[j] : hcxx[(tl % 3) * 32 + l31];
+            float bf[2][GS];
+            if (have_next) {
+#pragma unroll
+                for (int s = 0; s < GS; ++s) bf[0][s] = T[(2 * s) * KM_STRIDE];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accNext[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (have_next) {
+                    if (NSTEP >= 16) {
+                        const int s0 = r * SPR, g = s0 / GS;
+                        if (s0 % GS == 0 && g + 1 < NG) {
+#pragma unroll
+                            for (int s = 0; s < GS; ++s) bf[(g + 1) & 1][s] = T[(2 * ((g + 1) * GS + s)) * KM_STRIDE];
+                        }
+#pragma unroll
+                        for (int u = 0; u < SPR; ++u)
+                            accNext = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s0 + u], bf[g & 1][(s0 + u) % GS], accNext, 0, 0, 0);
+                    } else if (r < NSTEP) {
+                        accNext = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[r], bf[0][r], accNext, 0, 0, 0);
+                    }
+                }
+                const float pd = fmaf(2.0f, accCur[r], -xxc) - xxq[r];
+#ifdef KNN5_PROBE_NOSEL
+                cmx = fmaxf(cmx, pd);
+#else
+                sel(r, pd, j);
+#endif
+#ifndef KNN5_NO_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            if (!RES && tl + 2 < nt2) r2s_tile(tl & 1, tl + 2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accCur[r] = accNext[r];
+        }
+#ifdef KNN5_PROBE_NOSEL
+        if (cmx == 12345.f) idx[1] = 1;
+#endif
+    };
+
+    // ---- pass A: chunk maxima of this half
+    {
+        float cm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
+        sweep([&](int r, float pd, int) { cm[r] = fmaxf(cm[r], pd); });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[((qg * 2 + ch) * 16 + r) * KNN5_XS + lane] = cm[r];
+    }
+    __syncthreads();
+#if defined(KNN5_PROBE) && KNN5_PROBE == 4
+    if (xch[tid] == 12345.f) idx[0] = 1;
+    return;
+#endif
+    // tau = k-th largest of a query's 64 chunk maxima.  One lane per query: the first 32 lanes of waves 0-3 (one per
+    // SIMD) pull the 64 values of "their" query into registers and run a bitonic sorting network (672 min/max pairs,
+    // no cross-lane traffic, no data-dependent control).
+    if (ch == 0 && lane < 32) {
+        const int r = (lane & 3) + 4 * (lane >> 3), hq = (lane >> 2) & 1;     // lane = query row of the group
+        float v[64];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i4 = 0; i4 < 8; ++i4) {
+                const f32x4 t = *(const f32x4*)(xch + ((qg * 2 + c) * 16 + r) * KNN5_XS + hq * 32 + 4 * i4);
+                v[c * 32 + 4 * i4 + 0] = t[0]; v[c * 32 + 4 * i4 + 1] = t[1];
+                v[c * 32 + 4 * i4 + 2] = t[2]; v[c * 32 + 4 * i4 + 3] = t[3];
+            }
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1)
+#pragma unroll
+            for (int j = k2 >> 1; j > 0; j >>= 1)
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const float lo = fminf(v[i], v[l]), hi = fmaxf(v[i], v[l]);
+                        if ((i & k2) == 0) { v[i] = hi; v[l] = lo; }           // descending overall
+                        else { v[i] = lo; v[l] = hi; }
+                    }
+                }
+        float t = v[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) t = (i == k - 1) ? v[i] : t;
+        tau[(qg * 16 + r) * 2 + hq] = t;
+    }
+    __syncthreads();                           // tau complete; xch (aliases bufk) is dead from here on
+#pragma unroll
+    for (int r = 0; r < 16; ++r) thr[r] = tau[(qg * 16 + r) * 2 + h];
+
+#if defined(KNN5_PROBE) && KNN5_PROBE == 1
+    if (thr[0] == 12345.f) idx[0] = 1;
+    return;
+#endif
+    // ---- pass B: survivors of this half -> this wave's key buffers
+    u64* mybuf = bufk + (size_t)(qg * 2 + ch) * 32 * KNN5_CAP;
+    int cnt[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cnt[r] = 0;
+    sweep([&](int r, float pd, int j) {
+        const bool pass = pd >= thr[r];
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+            const unsigned mine = h ? (unsigned)(m >> 32) : (unsigned)m;
+            const int pos = cnt[r] + __builtin_popcount(mine & ((1u << l31) - 1u));
+            if (pass && pos < KNN5_CAP) mybuf[((r & 3) + 8 * (r >> 2) + 4 * h) * KNN5_CAP + pos] = knn_key(pd, j);
+            cnt[r] += __builtin_popcount(mine);
+        }
+    });
+    bool over = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) over |= cnt[r] > KNN5_CAP;
+
+#if defined(KNN5_PROBE) && KNN5_PROBE == 2
+    if (over) idx[0] = cnt[3];
+    return;
+#endif
+    if (__syncthreads_or(over ? 1 : 0)) {
+        // ---- pass C (exact for any input): sequential insertion over this half, lane-distributed sorted lists
+        float lv[16];
+        int li[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { lv[r] = -INFINITY; li[r] = 0x7fffffff; thr[r] = -INFINITY; }
+        sweep([&](int r, float pd, int j) {
+            unsigned long long m = __ballot(pd > thr[r]);
+            if (m) {
+                unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+                const int pdi = __float_as_int(pd);
+                const int jbase = j - l31;
+                while (lo | hi) {
+                    const int s0 = lo ? __builtin_ctz(lo) : 0, s1 = hi ? __builtin_ctz(hi) : 0;
+                    const float x0 = __int_as_float(__builtin_amdgcn_readlane(pdi, s0));
+                    const float x1 = __int_as_float(__builtin_amdgcn_readlane(pdi, 32 + s1));
+                    const bool active = h ? (hi != 0) : (lo != 0);
+                    const float xv = h ? x1 : x0;
+                    const int xj = jbase + (h ? s1 : s0);
+                    const float upv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv[r]), 0x138, 0xf, 0xf, false));
+                    const int upi = __builtin_amdgcn_update_dpp(0, li[r], 0x138, 0xf, 0xf, false);
+                    const bool lt = lv[r] < xv;
+                    const bool uplt = (l31 > 0) && (upv < xv);
+                    if (active && lt) { lv[r] = uplt ? upv : xv; li[r] = uplt ? upi : xj; }
+                    lo &= lo - 1; hi &= hi - 1;
+                }
+                const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), k - 1));
+                const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), 32 + k - 1));
+                thr[r] = h ? t1 : t0;
+            }
+        });
+        // a half with fewer than k candidates (N/2 < k) leaves -inf/0x7fffffff fillers: they are not published
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool valid = l31 < k && li[r] != 0x7fffffff;
+            if (valid) mybuf[((r & 3) + 8 * (r >> 2) + 4 * h) * KNN5_CAP + l31] = knn_key(lv[r], li[r]);
+            const unsigned long long m = __ballot(valid);
+            cnt[r] = __builtin_popcount(h ? (unsigned)(m >> 32) : (unsigned)m);
+        }
+    }
+    if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cnts[(qg * 2 + ch) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = cnt[r];
+    }
+    __syncthreads();
+
+    // ---- final: exact rank among the <= 64 keys of a query; this wave finishes 8 of the group's 16 rows
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = ch * 8 + rr;
+        const int qrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int n0 = cnts[(qg * 2 + 0) * 32 + qrow], n1 = cnts[(qg * 2 + 1) * 32 + qrow];
+        const u64* K0 = bufk + ((size_t)(qg * 2 + 0) * 32 + qrow) * KNN5_CAP;
+        const u64* K1 = bufk + ((size_t)(qg * 2 + 1) * 32 + qrow) * KNN5_CAP;
+        const u64 m0 = l31 < n0 ? K0[l31] : 0ull, m1 = l31 < n1 ? K1[l31] : 0ull;
+        int nm = max(n0, n1);
+        nm = max(__builtin_amdgcn_readlane(nm, 0), __builtin_amdgcn_readlane(nm, 32));
+        int rank0 = 0, rank1 = 0;
+        for (int i = 0; i < nm; i += 2) {
+            const u32x4 p0 = *(const u32x4*)(K0 + i), p1 = *(const u32x4*)(K1 + i);
+            const u64 a0 = i < n0 ? ((u64)p0[1] << 32 | p0[0]) : 0ull, a1 = i + 1 < n0 ? ((u64)p0[3] << 32 | p0[2]) : 0ull;
+            const u64 c0 = i < n1 ? ((u64)p1[1] << 32 | p1[0]) : 0ull, c1 = i + 1 < n1 ? ((u64)p1[3] << 32 | p1[2]) : 0ull;
+            rank0 += (a0 > m0) + (a1 > m0) + (c0 > m0) + (c1 > m0);
+            rank1 += (a0 > m1) + (a1 > m1) + (c0 > m1) + (c1 > m1);
+        }
+        int* out = idx + ((size_t)b * N + q0 + qrow) * k;
+        if (l31 < n0 && rank0 < k) out[rank0] = ~(int)(unsigned)m0;
+        if (l31 < n1 && rank1 < k) out[rank1] = ~(int)(unsigned)m1;
+    }
+}
+
+template <int CT, bool VEC, bool RES>
+static int launch_knn_mfma5_ct(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx,
+                               size_t lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)knn_mfma5_kernel<CT, VEC, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((knn_mfma5_kernel<CT, VEC, RES>), dim3((N / 128) * B), dim3(512), lds, st, x, xx, ld, N, C, k, idx, B);
+    return mlsp_launch_status();
+}
+
+static size_t knn5_lds_bytes(int CT, int N, bool res) {
+    const size_t tile = (size_t)CT * KM_STRIDE;
+    const size_t fl = (res ? (size_t)(N / 32) * tile + N : 4 * tile + 192) + (size_t)2 * 4 * 2 * 32 * KNN5_CAP + 128 + 256;
+    return fl * sizeof(float);
+}
+
+// returns MLSP_ERR_UNSUPPORTED when the shape is outside v5's fast path (caller falls back to v4)
+static int launch_knn_mfma5(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
+    if (N % 128 != 0 || k > 32 || C > 128) return MLSP_ERR_UNSUPPORTED;
+    const int CT = C <= 4 ? 4 : C <= 16 ? 16 : C <= 64 ? 64 : 128;
+    const bool vec = (C == CT) && (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    const bool res = CT <= 16 && knn5_lds_bytes(CT, N, true) <= 160 * 1024;
+    const size_t lds = knn5_lds_bytes(CT, N, res);
+    if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
+#define KNN5_GO(CTV, VECV, RESV) return launch_knn_mfma5_ct<CTV, VECV, RESV>(st, x, ld, xx, B, N, C, k, idx, lds)
+    if (CT == 4) { if (res) { if (vec) KNN5_GO(4, true, true); KNN5_GO(4, false, true); } if (vec) KNN5_GO(4, true, false); KNN5_GO(4, false, false); }
+    if (CT == 16) { if (res) { if (vec) KNN5_GO(16, true, true); KNN5_GO(16, false, true); } if (vec) KNN5_GO(16, true, false); KNN5_GO(16, false, false); }
+    if (CT == 64) { if (vec) KNN5_GO(64, true, false); KNN5_GO(64, false, false); }
+    if (vec) KNN5_GO(128, true, false);
+    KNN5_GO(128, false, false);
+#undef KNN5_GO
+}
+
 static size_t knn_lds_bytes(int KMAX, int C, bool runtime_c) {
     size_t tiles = (size_t)4 * KNN_TJ * C + 4 * KNN_TJ + (runtime_c ? (size_t)KNN_QB * (C + 1) : 0);
     size_t merge = (size_t)3 * KMAX * 64 * 2;
@@ -813,7 +1229,13 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
     // matrix-core path for every C <= 256; the v1 VALU kernel remains for wider features
     if (C <= 256) {
         // two-pass threshold select pays once there are enough candidates per query; small clouds keep v3
-        if (k <= 32 && C <= 128 && N >= 256) return launch_knn_mfma4(st, x, ld, xx_ws, B, N, C, k, idx);
+        if (k <= 32 && C <= 128 && N >= 256) {
+#ifndef KNN_NO_V5
+            const int rc = launch_knn_mfma5(st, x, ld, xx_ws, B, N, C, k, idx);
+            if (rc != MLSP_ERR_UNSUPPORTED) return rc;
+#endif
+            return launch_knn_mfma4(st, x, ld, xx_ws, B, N, C, k, idx);
+        }
         if (k <= 32) return launch_knn_mfma3(st, x, ld, xx_ws, B, N, C, k, idx);      // lane-distributed lists
         if (k <= 20) return launch_knn_mfma<20>(st, x, ld, xx_ws, B, N, C, k, idx);
         if (k <= 40) return launch_knn_mfma<40>(st, x, ld, xx_ws, B, N, C, k, idx);

@@ -34,7 +34,10 @@ def _rand(shape, seed, scale=1.0):
 
 # ----------------------------------------------------------------------------- kNN: bit-exact
 @pytest.mark.parametrize("B,N,C,k", [(2, 256, 3, 20), (2, 1024, 3, 20), (2, 256, 64, 20), (1, 1024, 128, 20),
-                                     (3, 20, 3, 20), (2, 33, 64, 20), (2, 100, 5, 7), (1, 300, 3, 40), (2, 70, 16, 1)])
+                                     (3, 20, 3, 20), (2, 33, 64, 20), (2, 100, 5, 7), (1, 300, 3, 40), (2, 70, 16, 1),
+                                     # v5 (two waves per query group) paths: LDS-resident / streamed, vector / scalar loads
+                                     (2, 384, 16, 20), (2, 256, 5, 32), (1, 512, 100, 20), (1, 2048, 3, 20),
+                                     (1, 4096, 16, 8), (2, 640, 64, 32), (8, 128, 64, 20), (9, 256, 128, 20)])
 def test_knn_bit_exact_vs_oracle(dev, B, N, C, k):
     Fh = _fh()
     xp = _rand((B * N, C), 100 + N + C)
