@@ -79,6 +79,17 @@ __device__ __forceinline__ void g2r(f32x4 (&r)[4], const float* __restrict__ src
     }
 }
 
+// FAST path (every tile interior, 16-byte loads legal): no predicates, the per-thread source pointer just advances by one
+// K-tile per iteration.  `base` already points at this thread's first element of the tile at k0.
+template <bool SRC_KMAJOR, int NP>
+__device__ __forceinline__ void g2r_fast(f32x4 (&r)[4], const float* __restrict__ base, int ld) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (!SRC_KMAJOR) r[p] = *(const f32x4*)(base + (size_t)(32 * p) * ld);
+        else r[p] = *(const f32x4*)(base + (size_t)((NP == 4 ? 8 : 16) * p) * ld);
+    }
+}
+
 template <bool SRC_KMAJOR, int NP>
 __device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, int tid) {
 #pragma unroll
@@ -97,12 +108,16 @@ __device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, 
 
 // WM = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile; 1 -> 64x128 (twice the workgroups, for launches whose
 // 128-row grid is too small to keep ~3 workgroups per CU in flight and out of phase)
-template <bool TA, bool TB, int WM>
+template <bool TA, bool TB, int WM, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     constexpr int BMT = 64 * WM, NPA = 2 * WM;
     // A tile is k-major in LDS either way; its GLOBAL source is k-major iff TA.  B's source is
     // k-major iff !TB.
+#ifdef GP_LDSPAD
+    __shared__ __attribute__((aligned(16))) float smem[BM * SROW * 2 + GP_LDSPAD];
+#else
     __shared__ __attribute__((aligned(16))) float smem[BM * SROW * 2];
+#endif
     float* As = smem;
     float* Bs = smem + BM * SROW;
 
@@ -139,23 +154,57 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[4], rb[4];
-    g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid);
-    g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid);
+    // FAST: this thread's source pointers (advance by one K-tile per iteration)
+    const float* pa = nullptr;
+    const float* pb = nullptr;
+    if (FAST) {
+        pa = TA ? p.A + (size_t)(kbeg + (NPA == 4 ? (tid >> 5) : (tid >> 4))) * p.lda + m0 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 4
+                : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
+        pb = !TB ? p.B + (size_t)(kbeg + (tid >> 5)) * p.ldb + n0 + (tid & 31) * 4
+                 : p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + kbeg + (tid & 7) * 4;
+        g2r_fast<TA, NPA>(ra, pa, p.lda);
+        g2r_fast<!TB, 4>(rb, pb, p.ldb);
+    } else {
+        g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid);
+        g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid);
+    }
 
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#ifdef GP_NOR2S
+        if (k0 == kbeg)
+#endif
+        {
         r2s<TA, NPA>(ra, As, tid);
         r2s<!TB, 4>(rb, Bs, tid);
+        }
         __syncthreads();
+#ifdef GP_NOGLOBAL
+        if (false) {
+#else
         if (k0 + BK < kend) {
-            g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid);
-            g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid);
+#endif
+            if (FAST) {
+                pa += TA ? (size_t)BK * p.lda : BK;
+                pb += !TB ? (size_t)BK * p.ldb : BK;
+                g2r_fast<TA, NPA>(ra, pa, p.lda);
+                g2r_fast<!TB, 4>(rb, pb, p.ldb);
+            } else {
+                g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid);
+                g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid);
+            }
         }
         // Fragment reads.  K is consumed in groups of 4: MFMA step 2m takes k = 4m + 2h, step 2m+1 takes k = 4m + 2h + 1
         // (h = lane >> 5), so a row-major image gives each lane its two values with ONE 8-byte read; a k-major image is
         // read per value.  Both operands use the same k assignment, so every (TA, TB) combination is consistent.
         const int arow = wm * (32 * WM) + l31, bcol = wn * 64 + l31;
+#ifdef GP_PRIO
+        __builtin_amdgcn_s_setprio(GP_PRIO);
+#endif
 #pragma unroll
         for (int m = 0; m < BK / 4; ++m) {
+#ifdef GP_IGLP
+            __builtin_amdgcn_iglp_opt(GP_IGLP);
+#endif
             const int kq = 4 * m + 2 * h;
             float a0s0, a0s1, a1s0, a1s1, b0s0, b0s1, b1s0, b1s1;
             a1s0 = 0.f; a1s1 = 0.f;
@@ -187,7 +236,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s1, b1s1, acc[1][1], 0, 0, 0);
             }
         }
+#ifdef GP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#ifndef GP_NOBAR
         __syncthreads();
+#endif
     }
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -199,15 +253,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int col = n0 + wn * 64 + j * 32 + l31;
-            if (col >= p.N) continue;
+            if (!FAST && col >= p.N) continue;
             float bv = (epi && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < p.M) {
+                if (FAST || row < p.M) {
                     float v = acc[i][j][r] + bv;
                     if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
+#ifdef GP_NOSTORE
+                    if (p.C && v == 12345.678f) Cout[(size_t)row * p.ldc + col] = v;
+#else
                     if (p.C) Cout[(size_t)row * p.ldc + col] = v;
+#endif
                     cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
                     acc[i][j][r] = v;
                 }
@@ -442,17 +500,22 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     dim3 grid(p.xcd_map ? ((p.ntm + 7) / 8) * 8 * p.ntn : p.ntm * p.ntn, ns);
     const bool prof = g_prof.on && g_prof.used < PROF_MAX_PAIRS;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
+    // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
+    const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+#define GEMM_GO(TA_, TB_, WM_) do { if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
+                                     else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
     if (bm == 128) {
-        if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2>), grid, dim3(256), 0, st, p);
-        else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2>), grid, dim3(256), 0, st, p);
-        else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_f32_kernel<true, true, 2>), grid, dim3(256), 0, st, p);
+        if (!ta && tb) GEMM_GO(false, true, 2);
+        else if (!ta && !tb) GEMM_GO(false, false, 2);
+        else if (ta && !tb) GEMM_GO(true, false, 2);
+        else GEMM_GO(true, true, 2);
     } else {
-        if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1>), grid, dim3(256), 0, st, p);
-        else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1>), grid, dim3(256), 0, st, p);
-        else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_f32_kernel<true, true, 1>), grid, dim3(256), 0, st, p);
+        if (!ta && tb) GEMM_GO(false, true, 1);
+        else if (!ta && !tb) GEMM_GO(false, false, 1);
+        else if (ta && !tb) GEMM_GO(true, false, 1);
+        else GEMM_GO(true, true, 1);
     }
+#undef GEMM_GO
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
         g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0)};

@@ -29,4 +29,19 @@ for name, ta, tb, M, N, K in shapes:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print("%-20s M=%7d N=%5d K=%7d  %8.1f us  %6.1f TF/s" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
+    # library reference point (rocBLAS / hipBLASLt through torch.mm), same operand layouts
+    lib_ms = float("nan")
+    if "--lib" in sys.argv:
+        a = A.t() if ta else A
+        b = B.t() if tb else B
+        for _ in range(3):
+            torch.mm(a, b)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            torch.mm(a, b)
+        e1.record()
+        torch.cuda.synchronize()
+        lib_ms = e0.elapsed_time(e1) / reps
+    print("%-20s M=%7d N=%5d K=%7d  %8.1f us  %6.1f TF/s   torch.mm %8.1f us %6.1f TF/s" %
+          (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9, lib_ms * 1e3, 2.0 * M * N * K / lib_ms / 1e9))

@@ -1,0 +1,64 @@
+"""Times mlsp_gemm_f32 for probe variants of gemm.hip built on the box with -D flags (kernel-design experiments)."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+SRC = os.path.join(ROOT, "mlsp_amd", "csrc")
+FILES = ("api.hip", "gemm.hip", "knn.hip", "bn.hip", "edge.hip", "loss.hip", "tnet.hip", "colmax.hip", "labels.hip")
+
+
+def build(flags, out):
+    # only gemm.hip changes between variants: the other objects are compiled once
+    os.makedirs("/tmp/gp", exist_ok=True)
+    objs = []
+    for f in FILES:
+        o = "/tmp/gp/%s.o" % f if f != "gemm.hip" else out + ".gemm.o"
+        if f == "gemm.hip" or not os.path.exists(o):
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                                   "-c", "-o", o] + (flags if f == "gemm.hip" else []) + [os.path.join(SRC, f)])
+        objs.append(o)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + objs)
+
+
+SHAPES = [("NT", 0, 1, 32768, 512, 512), ("NT", 0, 1, 32768, 1024, 512), ("NT", 0, 1, 32768, 256, 256), ("NT", 0, 1, 32768, 128, 256),
+          ("NN", 0, 0, 32768, 512, 512), ("NN", 0, 0, 32768, 256, 256), ("TN", 1, 0, 512, 512, 32768), ("TN", 1, 0, 256, 256, 32768)]
+
+
+def time_lib(path):
+    lib = ctypes.CDLL(path)
+    P = ctypes.c_void_p
+    I = ctypes.c_int
+    lib.mlsp_gemm_f32.argtypes = [I, I, I, I, I, P, I, P, I, P, I, P, P, ctypes.c_size_t, P]
+    dev = torch.device("cuda:0")
+    ws = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    out = []
+    for name, ta, tb, M, N, K in SHAPES:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        B = torch.randn((N, K) if tb else (K, N), device=dev)
+        C = torch.empty(M, N, device=dev)
+        def run():
+            rc = lib.mlsp_gemm_f32(ta, tb, M, N, K, A.data_ptr(), A.shape[1], B.data_ptr(), B.shape[1], C.data_ptr(), N, None,
+                                   ws.data_ptr(), ws.numel(), st)
+            assert rc == 0, rc
+        for _ in range(3): run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        out.append("%s %dx%dx%d %.0fus %.0fTF" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
+    return out
+
+
+if __name__ == "__main__":
+    variants = {"base": []}
+    for a in sys.argv[1:]:
+        name, _, fl = a.partition("=")
+        variants[name] = fl.split(",") if fl else []
+    for name, fl in variants.items():
+        out = "/tmp/gp/lib_%s.so" % name
+        build(fl, out)
+        print(name, " | ".join(time_lib(out)), flush=True)
