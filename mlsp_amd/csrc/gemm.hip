@@ -354,29 +354,65 @@ int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N
     return mlsp_launch_status();
 }
 
-// vectorised slab reduce: 16 bytes per lane, 4 slabs in flight per thread (contiguous C only)
+// vectorised slab reduce (contiguous C only): 16 bytes per lane.  A workgroup covers 256/ZG consecutive float4 outputs;
+// its ZG thread groups each sum the slabs z = g, g+ZG, ... (8 loads in flight), then the groups are added in order through
+// LDS.  The order is fixed by (nsplit, ZG) alone -> bitwise reproducible.
+template <int ZG>
 __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ slab, float* __restrict__ C, size_t total4,
                                                                 int N4, int nsplit, const float* __restrict__ bias,
                                                                 const float* __restrict__ gbias, int rows_per_group) {
-    const size_t stride4 = total4;    // float4 elements per slab
-    for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
+    constexpr int EPB = 256 / ZG;                 // float4 outputs per workgroup
+    __shared__ f32x4 part[ZG > 1 ? 256 : 1];
+    const int e = threadIdx.x % EPB, g = threadIdx.x / EPB;
+    const size_t v = (size_t)blockIdx.x * EPB + e;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (v < total4) {
         const f32x4* p = (const f32x4*)slab + v;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        int z = 0;
-        for (; z + 4 <= nsplit; z += 4) {
-            f32x4 a = p[(size_t)z * stride4], b = p[(size_t)(z + 1) * stride4], c = p[(size_t)(z + 2) * stride4],
-                  d = p[(size_t)(z + 3) * stride4];
-            s = (((s + a) + b) + c) + d;               // same left-to-right order as the scalar kernel
+        int z = g;
+        for (; z + 7 * ZG < nsplit; z += 8 * ZG) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(z + u * ZG) * total4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = s + t[u];
         }
-        for (; z < nsplit; ++z) s = s + p[(size_t)z * stride4];
-        const int col = (int)(v % N4) * 4;
-        if (bias) { const f32x4 bv = *(const f32x4*)(bias + col); s = s + bv; }
-        if (gbias) {
-            const size_t row = v / N4;
-            const f32x4 gv = *(const f32x4*)(gbias + (row / rows_per_group) * (size_t)N4 * 4 + col);
-            s = s + gv;
+        for (; z < nsplit; z += ZG) s = s + p[(size_t)z * total4];
+    }
+    if (ZG > 1) {
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (g != 0) return;
+#pragma unroll
+        for (int q = 1; q < ZG; ++q) s = s + part[q * EPB + e];
+    }
+    if (v >= total4) return;
+    const int col = (int)(v % N4) * 4;
+    if (bias) { const f32x4 bv = *(const f32x4*)(bias + col); s = s + bv; }
+    if (gbias) {
+        const size_t row = v / N4;
+        const f32x4 gv = *(const f32x4*)(gbias + (row / rows_per_group) * (size_t)N4 * 4 + col);
+        s = s + gv;
+    }
+    ((f32x4*)C)[v] = s;
+}
+
+// scalar outputs with many slabs (N = 3 wgrads ...): one wave per output element, lanes stride the slabs, fixed shuffle tree
+__global__ __launch_bounds__(256) void splitk_reduce_wave_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N,
+                                                                 int ldc, int nsplit, const float* __restrict__ bias,
+                                                                 const float* __restrict__ gbias, int rows_per_group) {
+    const size_t total = (size_t)M * N;
+    const int lane = threadIdx.x & 63;
+    for (size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (size_t)gridDim.x * 4) {
+        float s = 0.f;
+        for (int z = lane; z < nsplit; z += 64) s += slab[(size_t)z * total + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            const int row = (int)(i / N), col = (int)(i % N);
+            if (bias) s += bias[col];
+            if (gbias) s += gbias[(size_t)(row / rows_per_group) * N + col];
+            C[(size_t)row * ldc + col] = s;
         }
-        ((f32x4*)C)[v] = s;
     }
 }
 
@@ -386,8 +422,16 @@ static void launch_splitk_reduce_any(hipStream_t st, const float* slab, float* C
     const bool vec = (N % 4 == 0) && ldc == N && ((((uintptr_t)slab | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)gbias) & 15) == 0);
     if (vec) {
         size_t t4 = total / 4;
-        int blocks = (int)((t4 + 255) / 256 < 2048 ? (t4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, slab, C, t4, N / 4, ns, bias, gbias, rows_per_group);
+        // enough workgroups to fill the chip: more slab groups per workgroup when the output is small
+        if (ns >= 32 && t4 <= 64 * 1024)
+            hipLaunchKernelGGL((splitk_reduce_vec_kernel<8>), dim3((unsigned)((t4 + 31) / 32)), dim3(256), 0, st, slab, C, t4, N / 4, ns, bias, gbias, rows_per_group);
+        else if (ns >= 8)
+            hipLaunchKernelGGL((splitk_reduce_vec_kernel<4>), dim3((unsigned)((t4 + 63) / 64)), dim3(256), 0, st, slab, C, t4, N / 4, ns, bias, gbias, rows_per_group);
+        else
+            hipLaunchKernelGGL((splitk_reduce_vec_kernel<1>), dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, st, slab, C, t4, N / 4, ns, bias, gbias, rows_per_group);
+    } else if (ns >= 32 && total <= 256 * 1024) {
+        int blocks = (int)((total + 3) / 4 < 4096 ? (total + 3) / 4 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_wave_kernel, dim3(blocks), dim3(256), 0, st, slab, C, M, N, ldc, ns, bias, gbias, rows_per_group);
     } else {
         int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, C, M, N, ldc, ns, bias, gbias, rows_per_group);

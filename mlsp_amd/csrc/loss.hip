@@ -183,10 +183,19 @@ __global__ __launch_bounds__(256) void normal_loss_partial_kernel(const float* _
 }
 
 // out[0] = loss, out[1] = sum w  (kept for backward)
-__global__ void normal_loss_finalize_kernel(const double* __restrict__ part, int nparts, float weight, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0, sw = 0;
-        for (int i = 0; i < nparts; ++i) { s += part[i * 2]; sw += part[i * 2 + 1]; }
+// (one wave: lanes stride the partials, then a fixed fp64 shuffle tree -- reproducible)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void normal_loss_finalize_kernel(const double* __restrict__ part, int nparts, float weight,
+                                                                  float* __restrict__ out) {
+    double s = 0, sw = 0;
+    for (int i = threadIdx.x; i < nparts; i += 64) { s += part[i * 2]; sw += part[i * 2 + 1]; }
+    s = wave_sum_f64(s); sw = wave_sum_f64(sw);
+    if (threadIdx.x == 0) {
         out[0] = (float)(-(double)weight * s / sw);
         out[1] = (float)sw;
     }
@@ -268,10 +277,12 @@ __global__ __launch_bounds__(256) void density_loss_partial_kernel(const float* 
 }
 
 // out = {kl, mae, sum m}:  kl = -Dw * a / sm ;  mae = Dw * 0.05 * b / sm
-__global__ void density_loss_finalize_kernel(const double* __restrict__ part, int nparts, float dweight, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double a = 0, b = 0, sm = 0;
-        for (int i = 0; i < nparts; ++i) { a += part[i * 3]; b += part[i * 3 + 1]; sm += part[i * 3 + 2]; }
+__global__ __launch_bounds__(64) void density_loss_finalize_kernel(const double* __restrict__ part, int nparts, float dweight,
+                                                                   float* __restrict__ out) {
+    double a = 0, b = 0, sm = 0;
+    for (int i = threadIdx.x; i < nparts; i += 64) { a += part[i * 3]; b += part[i * 3 + 1]; sm += part[i * 3 + 2]; }
+    a = wave_sum_f64(a); b = wave_sum_f64(b); sm = wave_sum_f64(sm);
+    if (threadIdx.x == 0) {
         out[0] = (float)(-(double)dweight * a / sm);
         out[1] = (float)((double)dweight * 0.05 * b / sm);
         out[2] = (float)sm;
