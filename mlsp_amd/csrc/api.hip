@@ -17,6 +17,12 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent);
 int bn_stat_parts(int M);
 int bn_parts_max(int M);
+int launch_skinny_linear_bn_act(hipStream_t st, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout,
+                                const float* bias, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                                float momentum, float eps, int training, int act, float slope, float p_drop, uint64_t seed, float* Y,
+                                float* Z, float* bn_save);
+int launch_skinny_bn_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* bn_save, int training,
+                         int act, float slope, float p_drop, uint64_t seed, float* dgamma, float* dbeta);
 int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double* part);
 int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
@@ -327,6 +333,10 @@ int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* 
     if (!X || !W || !Z || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
     if (gamma && (!beta || !Y || !bn_save)) return MLSP_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
+    // per-cloud layers (batch <= 32 rows): Linear + BatchNorm1d + activation + dropout in ONE kernel (skinny.hip)
+    if (gamma && !gbias && M <= 32)
+        return launch_skinny_linear_bn_act(st, X, ldx, M, Cin, W, ldw, Cout, bias, gamma, beta, run_mean, run_var, momentum, eps,
+                                           training, act, slope, p_drop, seed, Y, Z, bn_save);
     Workspace w(ws, ws_bytes);
     // BN batch statistics: fused into the GEMM epilogue (one partial per 128-row panel) unless the GEMM splits K
     const int fused_parts = (gamma && training) ? gemm_stat_parts(M, Cout, Cin) : 0;
@@ -374,7 +384,10 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
     float* gscratch = dgbias ? w.take<float>((size_t)n_groups * 16 * Cout) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float* g = dZ;   // gradient wrt the linear output
-    if (has_bn) {
+    if (has_bn && M <= 32) {
+        CHECK(launch_skinny_bn_bwd(st, dZ, Y, dY, M, Cout, bn_save, training, act, slope, p_drop, seed, dgamma, dbeta));
+        g = dY;
+    } else if (has_bn) {
         const float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
         CHECK(launch_bn_act_bwd(st, dZ, Y, dY, M, Cout, scale, shift, mean, invstd, training, act, slope,
                                 training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy));

@@ -493,13 +493,6 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ part, int npar
 }
 
 // column sums over all M rows of a [M][C] matrix (bias gradients); part: [bn_stat_parts(M)][2][C] doubles
-int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out) {
-    int nparts = bn_stat_parts(M);
-    hipLaunchKernelGGL(colstats_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, X, M, C, C, part);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, C, out);
-    return mlsp_launch_status();
-}
-
 // vectorised per-group column sums: block = (64-row slab of a group); partial sums combined by a second tiny pass
 __global__ __launch_bounds__(256) void colsum_groups_vec_kernel(const float* __restrict__ X, int C, int rows_per_group, int slabs,
                                                                 float* __restrict__ part) {
@@ -529,6 +522,7 @@ __global__ void colsum_groups_fin_kernel(const float* __restrict__ part, int G, 
     if (t >= G * C) return;
     int g = t / C, c = t % C;
     float s = 0.f;
+#pragma unroll 8
     for (int u = 0; u < slabs; ++u) s += part[((size_t)g * slabs + u) * C + c];
     out[t] = s;
 }
@@ -541,6 +535,22 @@ int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_gro
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(colsum_groups_kernel, dim3((C + 63) / 64, G), dim3(256), 0, st, X, C, rows_per_group, out);
+    return mlsp_launch_status();
+}
+
+// column sums over all M rows of a [M][C] matrix (bias gradients, Gram-matrix terms); part: [bn_stat_parts(M)][2][C] doubles
+int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out) {
+    int nparts = bn_stat_parts(M);
+    if (vec_ok(C, X) && 256 % (C / 4) == 0 && M >= 4096) {
+        // streaming shape: 16-byte column-stationary partial sums over 4*nparts row slabs (the fp64 partial buffer reused as floats)
+        const int slabs = 4 * nparts;
+        float* scratch = (float*)part;
+        hipLaunchKernelGGL(colsum_groups_vec_kernel, dim3(slabs, 1), dim3(256), 0, st, X, C, M, slabs, scratch);
+        hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, 1, C, slabs, out);
+        return mlsp_launch_status();
+    }
+    hipLaunchKernelGGL(colstats_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, X, M, C, C, part);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, C, out);
     return mlsp_launch_status();
 }
 

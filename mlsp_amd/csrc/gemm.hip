@@ -516,11 +516,19 @@ extern "C" int mlsp_profile_end(double* out) {
     return MLSP_OK;
 }
 
+int launch_skinny_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                       float* C, int ldc, const float* bias);
+
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                 size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
                 int* sel_row = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
+    // per-cloud layers (<= 32 rows, or a 32-deep wgrad): one-pass skinny kernels, no split-K slab (skinny.hip)
+    if (!gbias && !stat_part && !sel_gamma && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
+        const int rc = launch_skinny_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias);
+        if (rc != MLSP_ERR_UNSUPPORTED) return rc;
+    }
     if (sel_gamma && (!sel_val || !sel_row || gemm_pick_split(M, N, K) != 1)) return MLSP_ERR_ARG;
     if (gbias && rows_per_group <= 0) return MLSP_ERR_ARG;
     GemmArgs p;

@@ -103,7 +103,10 @@ def test_knn_public_api_and_errors(dev):
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 300, 200, 64), (0, 1, 1024, 128, 3), (0, 0, 257, 130, 100),
                                          (1, 0, 64, 6, 5000), (1, 0, 256, 512, 4096), (0, 1, 32, 512, 1024),
-                                         (0, 1, 4096, 2048, 512), (1, 1, 100, 70, 50), (0, 1, 5, 9, 256)])
+                                         (0, 1, 4096, 2048, 512), (1, 1, 100, 70, 50), (0, 1, 5, 9, 256),
+                                         # skinny.hip: <= 32 rows (fwd / dgrad) and 32-deep wgrads, ragged edges
+                                         (0, 1, 32, 256, 1024), (0, 1, 17, 33, 100), (0, 0, 32, 1024, 256), (0, 0, 7, 50, 9),
+                                         (1, 0, 256, 1024, 32), (1, 0, 9, 256, 20), (1, 0, 70, 33, 3)])
 def test_gemm(dev, ta, tb, M, N, K):
     Fh = _fh()
     A = _rand((K, M) if ta else (M, K), 1)
@@ -148,7 +151,10 @@ def _torch_pointmlp(X, W, bias, gbias, rpg, gamma, beta, rm, rv, training, act):
 
 @pytest.mark.parametrize("M,Cin,Cout,act,use_bias,G,training", [
     (1000, 64, 128, 2, False, 0, True), (512, 6, 64, 2, False, 0, True), (32, 1024, 512, 2, True, 0, True),
-    (2048, 512, 256, 1, False, 4, True), (777, 100, 33, 1, True, 0, False), (640, 128, 3, 0, True, 0, True)])
+    (2048, 512, 256, 1, False, 4, True), (777, 100, 33, 1, True, 0, False), (640, 128, 3, 0, True, 0, True),
+    # per-cloud layers (skinny.hip): fused Linear + BN1d + act over <= 32 rows; eval mode; ragged sizes; plain Linear
+    (32, 512, 256, 2, False, 0, True), (20, 300, 70, 1, True, 0, False), (5, 64, 40, 2, True, 0, True),
+    (32, 256, 9, 0, True, 0, True), (32, 256, 10, 0, True, 0, False)])
 def test_pointmlp_fwd_bwd(dev, M, Cin, Cout, act, use_bias, G, training):
     Fh = _fh()
     has_bn = act != 0
@@ -227,6 +233,28 @@ def test_dropout_statistics_and_mask_consistency(dev):
     Ze = Fh.pointmlp(X.to(dev), W.to(dev), gamma=gamma.to(dev), beta=beta.to(dev), run_mean=torch.zeros(C, device=dev),
                      run_var=torch.ones(C, device=dev), training=False, act=1, p_drop=0.5)
     assert (Ze != 0).all()
+
+
+def test_skinny_dropout_mask_consistent_fwd_bwd(dev):
+    """Per-cloud FC layer (32 rows, skinny.hip) with dropout: the backward must regenerate the forward's keep mask."""
+    Fh = _fh()
+    M, Cin, C = 32, 64, 256
+    X, W = _rand((M, Cin), 1).requires_grad_(True), _rand((C, Cin), 2, 0.3).requires_grad_(True)
+    gamma, beta = (_rand((C,), 3) + 0.3).requires_grad_(True), _rand((C,), 4).requires_grad_(True)
+    dZ = _rand((M, C), 5)
+    Xg, Wg, gg, bg = (t.detach().to(dev).requires_grad_(True) for t in (X, W, gamma, beta))
+    Z = Fh.pointmlp(Xg, Wg, gamma=gg, beta=bg, run_mean=torch.zeros(C, device=dev), run_var=torch.ones(C, device=dev),
+                    training=True, act=2, p_drop=0.5)
+    Z.backward(dZ.to(dev))
+    mask = (Z.detach().cpu() != 0).float()
+    assert abs(mask.mean().item() - 0.5) < 0.03
+    A = F.leaky_relu(F.batch_norm(X @ W.t(), None, None, gamma, beta, True, 0.1, 1e-5), 0.2)
+    Zc = A * mask * 2.0
+    Zc.backward(dZ)
+    np.testing.assert_allclose(Z.detach().cpu().numpy(), Zc.detach().numpy(), rtol=1e-4, atol=2e-4)
+    for got, want, name in ((Xg.grad, X.grad, "dX"), (Wg.grad, W.grad, "dW"), (gg.grad, gamma.grad, "dgamma"), (bg.grad, beta.grad, "dbeta")):
+        err = (got.cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-6)
+        assert err < 2e-3, (name, err)
 
 
 # ----------------------------------------------------------------------------- graph feature / max reductions
