@@ -157,7 +157,7 @@ __global__ void colmax_dw_kernel(const float* __restrict__ S, const float* __res
 // dX[b*N + p][:] += sum_{c : arg[b][c] == p} g[b][c] * W[c][:]
 // One workgroup per (row range, cloud): counting-sort the cloud's Cout (row, channel) pairs by row in LDS (ranks by
 // ascending channel -> fixed summation order), then one wave per touched row accumulates its few W rows.
-#define CSR_SPLIT 4
+#define CSR_SPLIT 16     // workgroups per cloud: each repeats the (cheap) sort and accumulates N/16 rows (latency-bound loop)
 __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* __restrict__ g, const int* __restrict__ arg,
                                                                   const float* __restrict__ W, int ldw, int N, int Cout, int Cin,
                                                                   float* __restrict__ dX, int lddx) {
@@ -199,7 +199,12 @@ __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* 
         if (e0 == e1) continue;
         float* o = dX + ((size_t)b * N + p) * lddx;
         for (int i0 = 0; i0 < Cin; i0 += 256) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            float acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                 // the read of the read-modify-write goes out with the W loads
+                int i = i0 + lane + 64 * u;
+                acc[u] = i < Cin ? o[i] : 0.f;
+            }
             for (int e = e0; e < e1; ++e) {
                 const int c = lst[e];
                 const float gv = gb[c];
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int i = i0 + lane + 64 * u;
-                if (i < Cin) o[i] += acc[u];
+                if (i < Cin) o[i] = acc[u];
             }
         }
     }

@@ -1254,7 +1254,7 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 #define RV_SPLIT 4
 __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict__ idx, int N, int k,
                                                            int* __restrict__ rev_off, int* __restrict__ rev_ent,
-                                                           int B) {
+                                                           int B, int ent_in_lds) {
     extern __shared__ int ism[];
     int* cnt = ism;            // [N]
     int* off = ism + N;        // [N+1]
@@ -1292,18 +1292,23 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     for (int j = tid; j < N; j += nt) cnt[j] = 0;
     if (b == B - 1 && part == RV_SPLIT - 1 && tid == 0) rev_off[(size_t)B * N] = gbase + E;
     __syncthreads();
+    // fill + sort this slice's lists in LDS (ent), then one coalesced copy out: the sort never touches global memory
+    // (clouds whose N*k edge list does not fit next to the histogram sort in place in global memory instead)
+    const int s0 = off[d0], sn = off[d1] - s0;
+    int* ent = ent_in_lds ? off + N + 1          // [E] worst case: every edge of the cloud points into this slice
+                          : rev_ent + gbase + s0;
     for (int e = tid; e < E; e += nt) {
         int j = ib[e];
         if (j >= d0 && j < d1) {
             int pos = atomicAdd(&cnt[j], 1);
-            rev_ent[gbase + off[j] + pos] = ((e / k) << 8) | (e % k);
+            ent[off[j] - s0 + pos] = ((e / k) << 8) | (e % k);
         }
     }
     __syncthreads();
-    __threadfence_block();
+    if (!ent_in_lds) __threadfence_block();
     // per-destination insertion sort (lists are ~k long)
     for (int j = d0 + tid; j < d1; j += nt) {
-        int* a = rev_ent + gbase + off[j];
+        int* a = ent + off[j] - s0;
         int n = off[j + 1] - off[j];
         for (int u = 1; u < n; ++u) {
             int key = a[u];
@@ -1312,16 +1317,21 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
             a[w + 1] = key;
         }
     }
+    if (!ent_in_lds) return;
+    __syncthreads();
+    for (int i = tid; i < sn; i += nt) rev_ent[gbase + s0 + i] = ent[i];
 }
 
 int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent) {
     if (!idx || !rev_off || !rev_ent || B <= 0 || N <= 0 || k <= 0 || k > 256 || N > (1 << 22)) return MLSP_ERR_ARG;
     size_t lds = (size_t)(2 * N + 1) * sizeof(int);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
+    const int ent_in_lds = lds + (size_t)N * k * sizeof(int) <= 150 * 1024;
+    if (ent_in_lds) lds += (size_t)N * k * sizeof(int);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)knn_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B);
+    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, ent_in_lds);
     return mlsp_launch_status();
 }

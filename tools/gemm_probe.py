@@ -22,7 +22,8 @@ def build(flags, out):
 
 
 SHAPES = [("NT", 0, 1, 32768, 512, 512), ("NT", 0, 1, 32768, 1024, 512), ("NT", 0, 1, 32768, 256, 256), ("NT", 0, 1, 32768, 128, 256),
-          ("NN", 0, 0, 32768, 512, 512), ("NN", 0, 0, 32768, 256, 256), ("TN", 1, 0, 512, 512, 32768), ("TN", 1, 0, 256, 256, 32768)]
+          ("NN", 0, 0, 32768, 512, 512), ("NN", 0, 0, 32768, 256, 256), ("TN", 1, 0, 512, 512, 32768), ("TN", 1, 0, 256, 256, 32768),
+          ("NT", 0, 1, 32768, 512, 4096), ("NT", 0, 1, 8192, 8192, 1024)]
 
 
 def time_lib(path):
