@@ -36,7 +36,7 @@ struct SkinnyFwdArgs {
     float* Z; float* bn_save;          // Z [M][N]; bn_save = scale | shift | mean | invstd, N floats each
 };
 
-#define SK_WAVES 16          // waves per workgroup: the K range is cut 16 ways so that one round of loads covers K = 1024
+#define SK_WAVES 8           // waves per workgroup (2 per SIMD -> 256 VGPRs each): the K range is cut 8 ways
 #define SK_BATCH 8           // chunks (of 8 k) whose loads are all in flight before the first MFMA of the batch
 
 // sum of the SK_WAVES partial tiles in wave order; result in wave 0 (other waves return false)
