@@ -155,9 +155,12 @@ __global__ void colmax_dw_kernel(const float* __restrict__ S, const float* __res
 }
 
 // dX[b*N + p][:] += sum_{c : arg[b][c] == p} g[b][c] * W[c][:]
-// One workgroup per (row range, cloud): counting-sort the cloud's Cout (row, channel) pairs by row in LDS (ranks by
-// ascending channel -> fixed summation order), then one wave per touched row accumulates its few W rows.
-#define CSR_SPLIT 16     // workgroups per cloud: each repeats the (cheap) sort and accumulates N/16 rows (latency-bound loop)
+// CSR_SPLIT workgroups per cloud; each sorts the cloud's Cout (row, channel) pairs by row in LDS (lists ascending in
+// channel -> fixed summation order) and accumulates its slice of the rows.  The arg-max of many channels lands on the same
+// few "critical" points, so list lengths are heavily skewed: rows with up to CSR_LONG entries are handled one per wave,
+// longer ones by all waves of the workgroup together (entries strided over the waves, partial rows added in wave order).
+#define CSR_SPLIT 16
+#define CSR_LONG 8
 __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* __restrict__ g, const int* __restrict__ arg,
                                                                   const float* __restrict__ W, int ldw, int N, int Cout, int Cin,
                                                                   float* __restrict__ dX, int lddx) {
@@ -166,6 +169,8 @@ __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* 
     int* off = csm + N;             // [N+1]
     int* lst = off + N + 1;         // [Cout] channels sorted by (row, channel)
     int* ab = lst + Cout;           // [Cout] arg of this cloud
+    int* tmp = ab + Cout;           // [Cout] channels grouped by row, unsorted inside a row
+    float* red = (float*)(tmp + Cout);   // [16 waves][256] partial row slices of the cooperative path
     const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     for (int p = tid; p < N; p += nt) cnt[p] = 0;
@@ -184,19 +189,27 @@ __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* 
         if (tid == 63) off[N] = incl;
     }
     __syncthreads();
-    for (int c = tid; c < Cout; c += nt) {      // rank of c among the channels that share its row and precede it
+    for (int p = tid; p < N; p += nt) cnt[p] = 0;
+    __syncthreads();
+    for (int c = tid; c < Cout; c += nt) {      // group by row (arrival order), then rank inside the row by channel
         const int p = ab[c];
+        tmp[off[p] + atomicAdd(&cnt[p], 1)] = c;
+    }
+    __syncthreads();
+    for (int c = tid; c < Cout; c += nt) {
+        const int p = ab[c], e0 = off[p], e1 = off[p + 1];
         int rank = 0;
-        for (int c2 = 0; c2 < c; ++c2) rank += (ab[c2] == p);
-        lst[off[p] + rank] = c;
+        for (int e = e0; e < e1; ++e) rank += (tmp[e] < c);
+        lst[e0 + rank] = c;
     }
     __syncthreads();
     const int rows_per_part = (N + CSR_SPLIT - 1) / CSR_SPLIT;
     const int p0 = part * rows_per_part, p1 = min(N, p0 + rows_per_part);
     const float* gb = g + (size_t)b * Cout;
+    // short lists: one wave per row
     for (int p = p0 + wave; p < p1; p += nw) {
         const int e0 = off[p], e1 = off[p + 1];
-        if (e0 == e1) continue;
+        if (e0 == e1 || e1 - e0 > CSR_LONG) continue;
         float* o = dX + ((size_t)b * N + p) * lddx;
         for (int i0 = 0; i0 < Cin; i0 += 256) {
             float acc[4];
@@ -218,6 +231,33 @@ __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* 
             for (int u = 0; u < 4; ++u) {
                 int i = i0 + lane + 64 * u;
                 if (i < Cin) o[i] = acc[u];
+            }
+        }
+    }
+    // long lists: the whole workgroup per row (control flow is uniform: p and the list bounds come from LDS)
+    for (int p = p0; p < p1; ++p) {
+        const int e0 = off[p], e1 = off[p + 1];
+        if (e1 - e0 <= CSR_LONG) continue;
+        float* o = dX + ((size_t)b * N + p) * lddx;
+        for (int i0 = 0; i0 < Cin; i0 += 256) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int e = e0 + wave; e < e1; e += nw) {
+                const int c = lst[e];
+                const float gv = gb[c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int i = i0 + lane + 64 * u;
+                    if (i < Cin) acc[u] = fmaf(gv, W[(size_t)c * ldw + i], acc[u]);
+                }
+            }
+            __syncthreads();                               // previous slice's readers are done with red
+#pragma unroll
+            for (int u = 0; u < 4; ++u) red[wave * 256 + lane + 64 * u] = acc[u];
+            __syncthreads();
+            if (tid < 256 && i0 + tid < Cin) {
+                float s = o[i0 + tid];
+                for (int w = 0; w < nw; ++w) s += red[w * 256 + tid];
+                o[i0 + tid] = s;
             }
         }
     }
@@ -264,7 +304,7 @@ int launch_colmax_dw(hipStream_t st, const float* S, const float* WG, const floa
 }
 int launch_colmax_scatter_rows(hipStream_t st, const float* g, const int* arg, const float* W, int ldw, int B, int N, int Cout,
                                int Cin, float* dX, int lddx) {
-    size_t lds = ((size_t)2 * N + 1 + 2 * Cout) * sizeof(int);
+    size_t lds = ((size_t)2 * N + 1 + 3 * Cout + 16 * 256) * sizeof(int);
     if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)colmax_scatter_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
