@@ -29,6 +29,24 @@ PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA == f32 vector pe
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_gemm_traffic():
+    """HBM-side bytes per GEMM launch from the newest committed rocprofv3 --pmc summary (profiles/pmc_r1/summary_v*.csv,
+    produced by tools/prof/run_profiles.sh with FETCH_SIZE / WRITE_SIZE in separate passes): launch-weighted mean of
+    2*FETCH_SIZE + WRITE_SIZE (the gfx950 correction of MI355X_MICROARCH.md).  None when no summary is committed."""
+    import csv, glob, re
+    files = glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r1", "summary_v*.csv"))
+    if not files:
+        return None, None
+    f = max(files, key=lambda x: int(re.search(r"summary_v(\d+)", x).group(1)))
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(f)):
+        if "gemm_f32_kernel" in r["kernel"]:
+            l = int(r["launches"])
+            tot += l * (2 * float(r["fetch_KB_per_launch_raw"]) + float(r["write_KB_per_launch"])) * 1024
+            n += l
+    return (tot / n if n else None), os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))
+
+
 def synth_batch(B, N, device, seed=0):
     """x ~ U[-1,1), first-41-points mask, N(0,1) normals, counts U{0..30} -> soft 16-bin label."""
     g = torch.Generator().manual_seed(seed)
@@ -178,8 +196,10 @@ def main():
         if prof and prof[1] > 0:
             # prof = [total ms of the profiled kernel, launches, algorithmic FLOP summed over launches, 0]
             ach = prof[2] / (prof[0] * 1e-3) / 1e12
+            traffic, traffic_src = pmc_gemm_traffic()
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
+                               "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE), %s" % traffic_src,
                                "kernel": "gemm_f32_kernel<*> (every fp32 MFMA GEMM launch: fwd, dgrad, wgrad)",
                                "launches": int(prof[1]), "avg_us": 1e3 * prof[0] / prof[1],
                                "share_of_step": prof[0] / prof_steps / (1e3 * dt / a.steps),
