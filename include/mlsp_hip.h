@@ -167,6 +167,22 @@ int mlsp_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, 
 int mlsp_radius_count_f32(const float* x, int ldx, int B, int N, float radius, int max_nn, int32_t* count, mlsp_stream_t stream);
 int mlsp_knn_normals_f32(const float* x, int ldx, const int32_t* idx, int B, int N, int k, float* normals, mlsp_stream_t stream);
 
+/* PointNet++ set-abstraction front end (BASELINE.json configs[3]).  The reference states the semantics in
+ * PointDA/hengshuang_transformer/pointnet_util.py only: farthest_point_sample :53-73 (start index supplied by the caller --
+ * the reference draws it with torch.randint :65), query_ball_point :76-96 (first nsample indices with !(d2 > r2) in index
+ * order, padded with the first), sample_and_group :99-136 (rows [xyz_j - new_xyz_i | feat_j], edge-major (b, i, s)).
+ * xyz [B][N] rows of >= 3 floats (pitch ldx); new_xyz [B][S] rows (pitch ldq); feat [B*N][D] or NULL when D == 0;
+ * idx / fps_idx are int32 local to their cloud.  mlsp_group_reverse builds the reverse index of idx [B][S][ns] over the
+ * N source points (same format as mlsp_knn_reverse) for the deterministic backward of the grouping. */
+int mlsp_fps_f32(const float* xyz, int ldx, int B, int N, int S, const int32_t* start, int32_t* fps_idx, mlsp_stream_t stream);
+int mlsp_ball_query_f32(const float* xyz, int ldx, const float* new_xyz, int ldq, int B, int N, int S, float radius_sq, int nsample,
+                        int32_t* idx, mlsp_stream_t stream);
+int mlsp_group_reverse(const int32_t* idx, int B, int S, int N, int ns, int32_t* rev_off, int32_t* rev_ent, mlsp_stream_t stream);
+int mlsp_sa_group_fwd_f32(const float* xyz, int ldx, const float* feat, int D, const float* new_xyz, int ldq, const int32_t* idx, int B,
+                          int N, int S, int ns, float* G, mlsp_stream_t stream);
+int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
+                          float* dfeat, mlsp_stream_t stream);
+
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP
  * events on its launch stream.  mlsp_profile_end synchronises those events and fills
  * out[4] = {total ms in the kernel, launches, sum of algorithmic 2*M*N*K, 0}.  Not for production steps. */

@@ -53,6 +53,11 @@ SIGNATURES = {
     "mlsp_density_loss_bwd_f32": [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "mlsp_radius_count_f32": [_P, _I, _I, _I, _F, _I, _P, _P],
     "mlsp_knn_normals_f32": [_P, _I, _P, _I, _I, _I, _P, _P],
+    "mlsp_fps_f32": [_P, _I, _I, _I, _I, _P, _P, _P],
+    "mlsp_ball_query_f32": [_P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _P],
+    "mlsp_group_reverse": [_P, _I, _I, _I, _I, _P, _P, _P],
+    "mlsp_sa_group_fwd_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P],
+    "mlsp_sa_group_bwd_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_profile_begin": [],
     "mlsp_profile_end": [_P],
     "mlsp_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _SZ, _P],

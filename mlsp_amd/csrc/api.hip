@@ -23,6 +23,15 @@ int launch_skinny_linear_bn_act(hipStream_t st, const float* X, int ldx, int M, 
                                 float* Z, float* bn_save);
 int launch_skinny_bn_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* bn_save, int training,
                          int act, float slope, float p_drop, uint64_t seed, float* dgamma, float* dbeta);
+int launch_group_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent);
+int launch_fps(hipStream_t st, const float* xyz, int ldx, int B, int N, int S, const int* start, int* out);
+int launch_ball_query(hipStream_t st, const float* xyz, int ldx, const float* q, int ldq, int B, int N, int S, float r2, int nsample,
+                      int* idx);
+int launch_sa_group_fwd(hipStream_t st, const float* xyz, int ldx, const float* feat, int D, const float* q, int ldq, const int* idx,
+                        int B, int N, int S, int ns, float* G);
+int launch_sa_group_bwd(hipStream_t st, const float* dG, int D, const int* rev_off, const int* rev_ent, int B, int N, int S, int ns,
+                        float* dfeat);
+
 int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double* part);
 int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
@@ -157,6 +166,25 @@ int mlsp_knn_f32(const float* x, int ldx, int B, int N, int C, int k, int32_t* i
 
 int mlsp_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, int32_t* rev_ent, mlsp_stream_t st) {
     return launch_knn_reverse(st, idx, B, N, k, rev_off, rev_ent);
+}
+
+int mlsp_fps_f32(const float* xyz, int ldx, int B, int N, int S, const int32_t* start, int32_t* fps_idx, mlsp_stream_t st) {
+    return launch_fps(st, xyz, ldx, B, N, S, start, fps_idx);
+}
+int mlsp_ball_query_f32(const float* xyz, int ldx, const float* new_xyz, int ldq, int B, int N, int S, float radius_sq, int nsample,
+                        int32_t* idx, mlsp_stream_t st) {
+    return launch_ball_query(st, xyz, ldx, new_xyz, ldq, B, N, S, radius_sq, nsample, idx);
+}
+int mlsp_group_reverse(const int32_t* idx, int B, int S, int N, int ns, int32_t* rev_off, int32_t* rev_ent, mlsp_stream_t st) {
+    return launch_group_reverse(st, idx, B, S, N, ns, rev_off, rev_ent);
+}
+int mlsp_sa_group_fwd_f32(const float* xyz, int ldx, const float* feat, int D, const float* new_xyz, int ldq, const int32_t* idx, int B,
+                          int N, int S, int ns, float* G, mlsp_stream_t st) {
+    return launch_sa_group_fwd(st, xyz, ldx, feat, D, new_xyz, ldq, idx, B, N, S, ns, G);
+}
+int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
+                          float* dfeat, mlsp_stream_t st) {
+    return launch_sa_group_bwd(st, dG, D, rev_off, rev_ent, B, N, S, ns, dfeat);
 }
 
 int mlsp_graph_feature_fwd_f32(const float* x, const int32_t* idx, int B, int N, int C, int k, float* F, mlsp_stream_t st) {

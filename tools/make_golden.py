@@ -223,6 +223,69 @@ def seg_case(seg, seed, B, N):
     return out
 
 
+def import_sa_reference():
+    """PointDA/hengshuang_transformer/pointnet_util.py is pure torch + numpy: it imports with no stubs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_pointnet_util", os.path.join(ref_import.REF_ROOT, "PointDA", "hengshuang_transformer",
+                                                                                    "pointnet_util.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def sa_case(pu, seed, B, N, D, npoint, radius, nsample, mlp, group_all):
+    """One PointNetSetAbstraction layer of the reference: forward, a scalar loss, backward, BN buffers after the step."""
+    torch.manual_seed(seed)
+    layer = pu.PointNetSetAbstraction(npoint, radius, nsample, 3 + D, mlp, group_all)
+    layer.train()
+    with torch.no_grad():
+        gc.perturb_params(layer, seed)
+        g = torch.Generator().manual_seed(77 + seed)
+        for name, p in layer.named_parameters():               # BN affine terms off their init (names differ from DGCNN's)
+            if "mlp_bns" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.3 if name.endswith("bias") else 0.5) + (0.0 if name.endswith("bias") else 1.0))
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    points = (torch.randn(B, N, D, generator=g)).requires_grad_(True) if D else None
+    before = {k: npy(v).copy() for k, v in layer.state_dict().items()}
+    out = {"xyz": npy(xyz), "cfg": np.array([npoint or 0, nsample or 0, int(group_all), D] + list(mlp)), "radius": np.array(radius or 0.0)}
+    if D:
+        out["points"] = npy(points)
+    if not group_all:
+        torch.manual_seed(1234 + seed)                          # the first RNG draw of forward() is the FPS start (:65)
+        fps_idx = pu.farthest_point_sample(xyz, npoint)
+        new_xyz_ref = pu.index_points(xyz, fps_idx)
+        out["fps_idx"] = npy(fps_idx)
+        out["start"] = npy(fps_idx[:, 0])
+        out["group_idx"] = npy(pu.query_ball_point(radius, nsample, xyz, new_xyz_ref))
+    torch.manual_seed(1234 + seed)
+    new_xyz, new_points = layer(xyz, points)
+    wgt = torch.randn(new_points.shape, generator=g)
+    loss = (new_points * wgt).sum()
+    loss.backward()
+    out.update({"new_xyz": npy(new_xyz), "new_points": npy(new_points), "wgt": npy(wgt), "loss": npy(loss)})
+    if D:
+        out["d_points"] = npy(points.grad)
+    for k, v in before.items():
+        out["state_before/" + k] = v
+    for k, v in layer.state_dict().items():
+        out["state_after/" + k] = npy(v)
+    for k, p in layer.named_parameters():
+        out["grad/" + k] = npy(p.grad)
+    return out
+
+
+def sa_index_case(pu, seed, B, N, npoint, radius, nsample):
+    """Indices only, at BASELINE.json configs[3] scale (N = 2048): FPS + ball query of the reference."""
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    torch.manual_seed(99 + seed)
+    fps_idx = pu.farthest_point_sample(xyz, npoint)
+    gidx = pu.query_ball_point(radius, nsample, xyz, pu.index_points(xyz, fps_idx))
+    return {"xyz": npy(xyz), "start": npy(fps_idx[:, 0]), "fps_idx": fps_idx.numpy().astype(np.int16),
+            "group_idx": gidx.numpy().astype(np.int16), "radius": np.array(radius), "nsample": np.array(nsample)}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     RefModels, ref_mu, ref_mlsp = ref_import.import_reference()
@@ -242,5 +305,16 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def main_sa():
+    pu = import_sa_reference()
+    np.savez_compressed(os.path.join(OUT, "sa_s0_B4_N256.npz"), **sa_case(pu, 0, 4, 256, 6, 64, 0.4, 16, [32, 32, 64], False))
+    np.savez_compressed(os.path.join(OUT, "sa_s1_B3_N200_nofeat.npz"), **sa_case(pu, 1, 3, 200, 0, 50, 0.3, 8, [16, 24], False))
+    np.savez_compressed(os.path.join(OUT, "sa_s2_B4_N128_all.npz"), **sa_case(pu, 2, 4, 128, 16, None, None, None, [32, 64], True))
+    np.savez_compressed(os.path.join(OUT, "sa_idx_s3_B2_N2048.npz"), **sa_index_case(pu, 3, 2, 2048, 512, 0.2, 32))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sa":
+        main_sa()
+        sys.exit(0)
     main()
