@@ -54,7 +54,7 @@ int edge_bwd_reduce_parts(int P, int Cout, const void* a, const void* b, const v
 int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd);
 int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW);
 int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
-                       float* msel, uint8_t* argsel, float* s1, double* part);
+                       float* msel, uint8_t* argsel, float* s1, double* part, int* nparts_used);
 int launch_edge_select_act(hipStream_t st, const float* msel, const float* uv, int P, int Cout, const float* scale,
                            const float* shift, int act, float slope, float* out);
 int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, const float* msel, const float* uv, int P,
@@ -214,7 +214,7 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
     float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
     CHECK(launch_build_wd(st, W, Cout, C, Wd));
     CHECK(launch_gemm(st, false, true, P, 2 * Cout, C, x, ldx, Wd, C, uv, 2 * Cout, nullptr, nullptr, 0, slab, sf));
-    CHECK(launch_edge_reduce(st, uv, idx, gamma, P, N, Cout, k, msel, argsel, s1, part));
+    CHECK(launch_edge_reduce(st, uv, idx, gamma, P, N, Cout, k, msel, argsel, s1, part, &nparts));
     if (training) {
         CHECK(launch_bn_finalize(st, part, nparts, (double)P * k, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale,
                                  shift, mean, invstd));
@@ -286,7 +286,7 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     CHECK(launch_build_wd(st, W1, C1, C, Wd));
     CHECK(launch_gemm(st, false, true, P, 2 * C1, C, x, ldx, Wd, C, uv, 2 * C1, nullptr, nullptr, 0, slab, sf));
-    CHECK(launch_edge_reduce(st, uv, idx, gamma1, P, N, C1, k, msel, arg1, s1, part));
+    CHECK(launch_edge_reduce(st, uv, idx, gamma1, P, N, C1, k, msel, arg1, s1, part, &np1));
     if (training) {
         CHECK(launch_bn_finalize(st, part, np1, (double)P * k, C1, gamma1, beta1, run_mean1, run_var1, momentum, eps, bn1_save,
                                  bn1_save + C1, bn1_save + 2 * C1, bn1_save + 3 * C1));

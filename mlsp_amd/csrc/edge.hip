@@ -173,6 +173,83 @@ __global__ __launch_bounds__(256) void edge_reduce_vec_kernel(const float* __res
     }
 }
 
+// LDS-resident form (whole clouds, N <= 4096, k <= 32, Cout % 16 == 0): a workgroup owns one (cloud, 16-channel slice,
+// point chunk).  The slice of u for the WHOLE cloud (N x 16 floats, 64 KB at N = 1024) and the chunk's neighbour lists
+// (u16) are staged in LDS once; the k row gathers of every point then run at LDS rate instead of one L2 round trip per
+// neighbour row.  A thread owns (point, channel quad) and walks its k neighbours in slot order, so the first-occurrence
+// rule needs no cross-lane merge.  Partial BN statistics: one fp64 row per (cloud, chunk), each slice writes its columns.
+#define ELDS_CS 16
+template <int KMAX>
+__global__ __launch_bounds__(256) void edge_reduce_lds_kernel(const float* __restrict__ uv, const int* __restrict__ idx,
+                                                              const float* __restrict__ gamma, int B, int N, int k, int Cout, int psplit,
+                                                              float* __restrict__ msel, uint8_t* __restrict__ argsel,
+                                                              float* __restrict__ s1out, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float esm[];
+    constexpr int CS = ELDS_CS, QPP = CS / 4, PL = 256 / QPP;
+    float* Us = esm;                                           // [N][CS]
+    unsigned short* Is = (unsigned short*)(esm + (size_t)N * CS);   // [chunk points][k]
+    const int tid = threadIdx.x;
+    const int nsl = Cout / CS, bpc = nsl * psplit;
+    int b, r;
+    xcd_cloud_map(blockIdx.x, bpc, B, b, r);                   // all workgroups of a cloud on one XCD: uv rows come from its L2
+    const int sl = r % nsl, ch = r / nsl;
+    const int c0 = sl * CS, ld = 2 * Cout;
+    const int pper = (N + psplit - 1) / psplit, pbeg = ch * pper, pend = min(N, pbeg + pper);
+    const int q = tid % QPP, pl = tid / QPP;
+    const float* ub = uv + (size_t)b * N * ld;
+    for (int row = pl; row < N; row += PL)
+        *(f32x4*)(Us + row * CS + 4 * q) = *(const f32x4*)(ub + (size_t)row * ld + c0 + 4 * q);
+    const int* ib = idx + ((size_t)b * N + pbeg) * k;
+    for (int t = tid; t < (pend - pbeg) * k; t += 256) Is[t] = (unsigned short)ib[t];
+    __syncthreads();
+    const f32x4 g4 = *(const f32x4*)(gamma + c0 + 4 * q);
+    bool use_max[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) use_max[e] = g4[e] >= 0.f;
+    double ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+    for (int il = pl; il < pend - pbeg; il += PL) {
+        const unsigned short* irow = Is + il * k;
+        float best[4], s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+        int bs[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            if (s < k) {
+                const f32x4 u = *(const f32x4*)(Us + (int)irow[s] * CS + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] += u[e]; s2[e] = fmaf(u[e], u[e], s2[e]);
+                    const bool take = (s == 0) || (use_max[e] ? (u[e] > best[e]) : (u[e] < best[e]));
+                    best[e] = take ? u[e] : best[e]; bs[e] = take ? s : bs[e];
+                }
+            }
+        }
+        const size_t i = (size_t)b * N + pbeg + il;
+        const f32x4 v = *(const f32x4*)(uv + i * ld + Cout + c0 + 4 * q);
+        f32x4 b4, s4;
+        uint32_t a4 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b4[e] = best[e]; s4[e] = s1[e]; a4 |= (uint32_t)(bs[e] & 255) << (8 * e);
+            ps[e] += (double)s1[e] + (double)k * v[e];
+            pq[e] += (double)s2[e] + 2.0 * (double)v[e] * s1[e] + (double)k * v[e] * v[e];
+        }
+        *(f32x4*)(msel + i * Cout + c0 + 4 * q) = b4;
+        *(f32x4*)(s1out + i * Cout + c0 + 4 * q) = s4;
+        *(uint32_t*)(argsel + i * Cout + c0 + 4 * q) = a4;
+    }
+    __syncthreads();                                           // Us is dead: reuse it for the fp64 column reduction
+    double* red = (double*)esm;                                // [2][PL][CS]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[(0 * PL + pl) * CS + 4 * q + e] = ps[e]; red[(1 * PL + pl) * CS + 4 * q + e] = pq[e]; }
+    __syncthreads();
+    if (tid < 2 * CS) {
+        const int which = tid / CS, c = tid % CS;
+        double a = 0.0;
+        for (int u = 0; u < PL; ++u) a += red[(which * PL + u) * CS + c];
+        part[((size_t)(b * psplit + ch) * 2 + which) * Cout + c0 + c] = a;
+    }
+}
+
 // vectorised reverse gather (same lane layout): du_j over rev(j)
 template <int LR>
 __global__ __launch_bounds__(256) void edge_bwd_gather_vec_kernel(const float* __restrict__ gz, const uint8_t* __restrict__ argsel,
@@ -485,9 +562,29 @@ int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* 
     hipLaunchKernelGGL(unbuild_wd_kernel, dim3((Cout * C + 255) / 256), dim3(256), 0, st, dWd, Cout, C, dW);
     return mlsp_launch_status();
 }
+// *nparts_used (optional) receives the number of partial-statistics rows written (<= edge_reduce_parts(P))
 int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
-                       float* msel, uint8_t* argsel, float* s1, double* part) {
+                       float* msel, uint8_t* argsel, float* s1, double* part, int* nparts_used) {
     const bool al = (((uintptr_t)uv | (uintptr_t)msel | (uintptr_t)s1 | (uintptr_t)gamma) & 15) == 0 && (((uintptr_t)argsel) & 3) == 0;
+    if (nparts_used) *nparts_used = edge_reduce_parts(P);
+#ifndef EDGE_NO_LDS
+    if (al && Cout % ELDS_CS == 0 && P % N == 0 && N <= 4096 && k <= 32 && N % 4 == 0) {
+        const int B = P / N, nsl = Cout / ELDS_CS;
+        int psplit = 1;                                        // enough workgroups for two per CU, small neighbour-list stage
+        while (psplit < 8 && (B * nsl * psplit < 512 || (N / psplit) * k * 2 > 16 * 1024) && N % (psplit * 2) == 0) psplit *= 2;
+        const size_t lds = (size_t)N * ELDS_CS * sizeof(float) + align_up((size_t)((N + psplit - 1) / psplit) * k * 2, 16);
+        if (lds <= 150 * 1024 && B * psplit <= edge_reduce_parts(P) && lds >= (size_t)2 * (256 / (ELDS_CS / 4)) * ELDS_CS * sizeof(double)) {
+            auto kern = k <= 20 ? edge_reduce_lds_kernel<20> : edge_reduce_lds_kernel<32>;
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL(kern, dim3(B * nsl * psplit), dim3(256), lds, st, uv, idx, gamma, B, N, k, Cout, psplit, msel, argsel, s1, part);
+            if (nparts_used) *nparts_used = B * psplit;
+            return mlsp_launch_status();
+        }
+    }
+#endif
     if (al && (Cout == 64 || Cout == 128 || Cout == 256)) {
         dim3 g(edge_reduce_parts(P)), b(256);
         if (Cout == 64) hipLaunchKernelGGL((edge_reduce_vec_kernel<16>), g, b, 0, st, uv, idx, gamma, P, N, k, msel, argsel, s1, part);
