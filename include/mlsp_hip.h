@@ -183,6 +183,16 @@ int mlsp_sa_group_fwd_f32(const float* xyz, int ldx, const float* feat, int D, c
 int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
                           float* dfeat, mlsp_stream_t stream);
 
+/* Input corruption.  mlsp_region_assign_f32: utils/pc_utils.py:33-73 assign_region_to_point on X [B][C][N]
+ * (channel-major as the trainer holds it); thr[n+1] = fp32 voxel edges, clip = fp32(0.99999999); regions int32 [B][N].
+ * mlsp_deform_regions_f32: MLSP/mlsp.py:10-51 deform_input, DefRec_dist == 'volume_based_voxels': per cloud the first
+ * `groups` regions of `order` (np.random.permutation(n^3) in the reference, :27) holding >= min_pts points are replaced by
+ * lookup[region] + noise (noise [B][3][N], already scaled by sqrt(0.001): pc_utils.draw_from_gaussian :114-122);
+ * X is updated in place, mask [B][C][N] receives 1 on the first three channels of the replaced points, 0 elsewhere. */
+int mlsp_region_assign_f32(const float* X, int B, int C, int N, const float* thr, int n, float clip, int32_t* regions, mlsp_stream_t stream);
+int mlsp_deform_regions_f32(float* X, int B, int C, int N, const int32_t* regions, const int32_t* order, int nreg, const float* lookup,
+                            const float* noise, int min_pts, int groups, float* mask, mlsp_stream_t stream);
+
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP
  * events on its launch stream.  mlsp_profile_end synchronises those events and fills
  * out[4] = {total ms in the kernel, launches, sum of algorithmic 2*M*N*K, 0}.  Not for production steps. */

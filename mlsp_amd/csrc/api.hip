@@ -32,6 +32,9 @@ int launch_sa_group_fwd(hipStream_t st, const float* xyz, int ldx, const float* 
 int launch_sa_group_bwd(hipStream_t st, const float* dG, int D, const int* rev_off, const int* rev_ent, int B, int N, int S, int ns,
                         float* dfeat);
 
+int launch_region_assign(hipStream_t st, const float* X, int B, int C, int N, const float* thr, int n, float clip, int* Y);
+int launch_deform_regions(hipStream_t st, float* X, int B, int C, int N, const int* regions, const int* order, int nreg, const float* lookup,
+                          const float* noise, int min_pts, int groups, float* mask);
 int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double* part);
 int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
@@ -168,6 +171,13 @@ int mlsp_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, 
     return launch_knn_reverse(st, idx, B, N, k, rev_off, rev_ent);
 }
 
+int mlsp_region_assign_f32(const float* X, int B, int C, int N, const float* thr, int n, float clip, int32_t* regions, mlsp_stream_t st) {
+    return launch_region_assign(st, X, B, C, N, thr, n, clip, regions);
+}
+int mlsp_deform_regions_f32(float* X, int B, int C, int N, const int32_t* regions, const int32_t* order, int nreg, const float* lookup,
+                            const float* noise, int min_pts, int groups, float* mask, mlsp_stream_t st) {
+    return launch_deform_regions(st, X, B, C, N, regions, order, nreg, lookup, noise, min_pts, groups, mask);
+}
 int mlsp_fps_f32(const float* xyz, int ldx, int B, int N, int S, const int32_t* start, int32_t* fps_idx, mlsp_stream_t st) {
     return launch_fps(st, xyz, ldx, B, N, S, start, fps_idx);
 }

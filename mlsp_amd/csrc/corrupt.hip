@@ -1,0 +1,79 @@
+// Input corruption of the source/target branches: voxel-region assignment (utils/pc_utils.py:33-73) and
+// the "volume_based_voxels" deformation of MLSP/mlsp.py:10-51 -- in the reference a Python loop over the batch x 27 regions
+// with host round trips (1.16 s per batch on the CPU).  One kernel each; the random inputs (region visiting order, Gaussian
+// noise) are ARGUMENTS, so the result is a pure function that tests can compare with the reference's own arithmetic.
+#include "common.h"
+
+// Y[b][j] = id of the voxel (x*n*n + y*n + z) whose OPEN box contains the clamped point, 0 when none does (points on a
+// voxel face): the reference labels by overwriting inside three nested loops, which is the same thing because the boxes
+// are disjoint.  thr[0..n] are the fp32 box edges -1 + i*d exactly as torch rounds the Python scalars; clip = fp32(0.99999999).
+__global__ __launch_bounds__(256) void region_assign_kernel(const float* __restrict__ X, int C, int N, int total, const float* __restrict__ thr,
+                                                            int n, float clip, int* __restrict__ Y) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int b = t / N, j = t % N;
+    const float* xb = X + (size_t)b * C * N;
+    int id[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float v = xb[(size_t)a * N + j];
+        v = fminf(fmaxf(v, -clip), clip);
+        int r = -1;
+        for (int i = 0; i < n; ++i)
+            if (thr[i] < v && v < thr[i + 1]) r = i;
+        id[a] = r;
+    }
+    Y[t] = (id[0] < 0 || id[1] < 0 || id[2] < 0) ? 0 : (id[0] * n + id[1]) * n + id[2];
+}
+
+// One workgroup per cloud: histogram of the region ids, then the first `groups` regions of the visiting order that hold
+// >= min_pts points are collapsed: X[b][0:3][j] = centre + noise[b][0:3][j] (noise already scaled), mask[b][0:3][j] = 1.
+__global__ __launch_bounds__(256) void deform_regions_kernel(float* __restrict__ X, int C, int N, const int* __restrict__ regions,
+                                                             const int* __restrict__ order, int nreg, const float* __restrict__ lookup,
+                                                             const float* __restrict__ noise, int min_pts, int groups,
+                                                             float* __restrict__ mask) {
+    __shared__ int hist[512];
+    __shared__ int chosen[512];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int r = tid; r < nreg; r += 256) { hist[r] = 0; chosen[r] = 0; }
+    __syncthreads();
+    const int* rb = regions + (size_t)b * N;
+    for (int j = tid; j < N; j += 256) atomicAdd(&hist[rb[j]], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int it = 0;
+        for (int q = 0; q < nreg && it < groups; ++q) {
+            const int r = order[q];
+            if (hist[r] >= min_pts) { chosen[r] = 1; ++it; }
+        }
+    }
+    __syncthreads();
+    float* xb = X + (size_t)b * C * N;
+    float* mb = mask + (size_t)b * C * N;
+    const float* nb = noise + (size_t)b * 3 * N;
+    for (int j = tid; j < N; j += 256) {
+        const int r = rb[j];
+        const bool hit = chosen[r] != 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (hit) xb[(size_t)a * N + j] = lookup[r * 3 + a] + nb[(size_t)a * N + j];
+            mb[(size_t)a * N + j] = hit ? 1.f : 0.f;
+        }
+        for (int a = 3; a < C; ++a) mb[(size_t)a * N + j] = 0.f;
+    }
+}
+
+int launch_region_assign(hipStream_t st, const float* X, int B, int C, int N, const float* thr, int n, float clip, int* Y) {
+    if (!X || !thr || !Y || B <= 0 || C < 3 || N <= 0 || n <= 0 || n > 8) return MLSP_ERR_ARG;
+    const int total = B * N;
+    hipLaunchKernelGGL(region_assign_kernel, dim3((total + 255) / 256), dim3(256), 0, st, X, C, N, total, thr, n, clip, Y);
+    return mlsp_launch_status();
+}
+
+int launch_deform_regions(hipStream_t st, float* X, int B, int C, int N, const int* regions, const int* order, int nreg, const float* lookup,
+                          const float* noise, int min_pts, int groups, float* mask) {
+    if (!X || !regions || !order || !lookup || !noise || !mask || B <= 0 || C < 3 || N <= 0 || nreg <= 0 || nreg > 512 || groups <= 0)
+        return MLSP_ERR_ARG;
+    hipLaunchKernelGGL(deform_regions_kernel, dim3(B), dim3(256), 0, st, X, C, N, regions, order, nreg, lookup, noise, min_pts, groups, mask);
+    return mlsp_launch_status();
+}

@@ -1,16 +1,48 @@
 """Mirror of the tensor part of the reference's MLSP/mlsp.py (losses of the three heads) on the HIP path.
 
 Same function names, argument order and return conventions (0-dim tensors supporting .item() and
-.backward()) as MLSP/mlsp.py:115-238, 275-287, 430-454.  Host-side input corruption and the pcl-based
-corruption of that file (deform_input, scan_input) is out of this path's scope;
+.backward()) as MLSP/mlsp.py:115-238, 275-287, 430-454.  `deform_input` (MLSP/mlsp.py:10-51) runs
+on device for DefRec_dist == 'volume_based_voxels'; `scan_input` (a host numpy rasteriser) is not built.
 `cal_density` is provided on device by mlsp_amd/labels.py (f-1, parity unpinned: python-pcl is third-party).
 """
+import numpy as np
 import torch
+
+from . import _lib
+from . import pc_utils
 
 from . import functional as Fh
 from .labels import cal_density, cal_density_gpu, estimate_normals   # noqa: F401  (mlsp.py:240-272)
 
 DefRec_SCALER = 20.0   # MLSP/mlsp.py:7
+
+
+def deform_input(X, lookup, DefRec_dist='volume_based_voxels', device='cuda:0', groups=1, region_ids=None, noise=None):
+    """MLSP/mlsp.py:10-51.  X [B,C,N] is deformed IN PLACE (as in the reference) and returned with the 0/1 mask [B,C,N].
+    Per cloud the first `groups` voxels of a random visiting order that hold >= 40 points collapse to a Gaussian blob
+    (std sqrt(0.001), pc_utils.draw_from_gaussian) around the voxel centre `lookup[i]`.
+    The random inputs may be injected for reproducible runs: `region_ids` (a permutation of the 27 voxel ids; default
+    np.random.permutation like :27) and `noise` [B,3,N] standard normal (default torch.randn on the device)."""
+    if DefRec_dist != 'volume_based_voxels':
+        raise NotImplementedError("deform_input on MI355X implements DefRec_dist='volume_based_voxels' (the trainer's default)")
+    lib = _lib.load()
+    _lib.require_gpu(X)
+    if not X.is_contiguous():
+        raise ValueError("deform_input updates X in place: pass a contiguous [B,C,N] tensor")
+    B, C, N = X.shape
+    n = pc_utils.NREGIONS
+    regions = pc_utils.assign_region_to_point(X, device).to(torch.int32)
+    if region_ids is None:
+        region_ids = np.random.permutation(n ** 3)
+    order = torch.as_tensor(np.asarray(region_ids), dtype=torch.int32).to(X.device)
+    if noise is None:
+        noise = torch.randn(B, 3, N, device=X.device)
+    scaled = (noise.to(X.device, torch.float32) * float(np.sqrt(0.001))).contiguous()
+    look = lookup.to(X.device, torch.float32).contiguous()
+    mask = torch.empty_like(X)
+    _lib.check(lib.mlsp_deform_regions_f32(X.data_ptr(), B, C, N, regions.data_ptr(), order.data_ptr(), n ** 3, look.data_ptr(),
+                                           scaled.data_ptr(), 40, groups, mask.data_ptr(), _lib.stream()), "mlsp_deform_regions_f32")
+    return X, mask
 
 
 def chamfer_distance(p1, p2, mask):

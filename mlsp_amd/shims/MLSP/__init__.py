@@ -1,2 +1,2 @@
-"""Import shim: `from MLSP import PCM, mlsp` (PointDA/trainer.py:15).  `mlsp` is the HIP loss module with the
-host-side helpers of the reference attached when the reference package is importable; PCM is the reference's own."""
+"""Import shim: `from MLSP import PCM, mlsp` (PointDA/trainer.py:15): the HIP loss module, the on-device input corruption
+(mlsp.deform_input) and the mixup with on-device farthest point sampling (PCM.mix_shapes)."""

@@ -1,0 +1,73 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the input-corruption row: numpy restatement of
+utils/pc_utils.py:33-73 (assign_region_to_point), MLSP/mlsp.py:10-51 (deform_input, 'volume_based_voxels') and
+MLSP/PCM.py:6-38 (mix_shapes) / utils/pc_utils.py:137-161 (farthest_point_sample) with every random draw passed in.
+Pinned to the reference: tests/golden/deform_*.npz and pcm_*.npz were captured by running the reference functions with
+seeded / recorded random draws (tools/make_golden.py corrupt); tests/test_corrupt_oracle_cpu.py checks this file against them.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module.
+"""
+import numpy as np
+
+
+def assign_region(X, n=3):
+    """X [B,C,N] float32 -> [B,N] int64.  Open voxel boxes with fp32 edges; points on a face keep label 0 (:60-71)."""
+    d = 2 / n
+    thr = np.array([-1 + i * d for i in range(n + 1)], dtype=np.float64).astype(np.float32)
+    clip = np.float32(0.99999999)
+    Xc = np.clip(X[:, :3].astype(np.float32), -clip, clip)
+    Y = np.zeros((X.shape[0], X.shape[2]), dtype=np.int64)
+    rid = 0
+    for x in range(n):
+        for y in range(n):
+            for z in range(n):
+                inside = ((thr[x] < Xc[:, 0]) & (Xc[:, 0] < thr[x + 1]) & (thr[y] < Xc[:, 1]) & (Xc[:, 1] < thr[y + 1]) &
+                          (thr[z] < Xc[:, 2]) & (Xc[:, 2] < thr[z + 1]))
+                Y[inside] = rid
+                rid += 1
+    return Y
+
+
+def deform(X, lookup, region_ids, noise, groups=1, min_pts=40, n=3):
+    """X [B,C,N] -> (deformed copy, mask).  noise [B,3,N] standard normal; replaced value = centre + sqrt(0.001) * noise."""
+    X = X.copy()
+    regions = assign_region(X, n)
+    mask = np.zeros_like(X)
+    sig = np.float32(np.sqrt(0.001))
+    for b in range(X.shape[0]):
+        it = 0
+        for i in region_ids:
+            ind = regions[b] == i
+            if ind.sum() >= min_pts:
+                it += 1
+                mask[b, :3, ind] = 1
+                X[b, :3, ind] = (lookup[i].astype(np.float32)[None, :] + noise[b][:, ind].T.astype(np.float32) * sig)
+                if it >= groups:
+                    break
+    return X, mask
+
+
+def fps(xyz, npoint, start):
+    """utils/pc_utils.py:137-161 on [B,C,N]: indices [B,npoint] and the sampled columns [B,C,npoint]."""
+    B, C, N = xyz.shape
+    idx = np.zeros((B, npoint), dtype=np.int64)
+    dist = np.full((B, N), 1e10, dtype=np.float32)
+    far = np.asarray(start, dtype=np.int64).copy()
+    rows = np.arange(B)
+    for i in range(npoint):
+        idx[:, i] = far
+        c = xyz[rows, :, far][:, :, None]
+        diff = (xyz - c).astype(np.float32)
+        d = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+        dist = np.minimum(dist, d)
+        far = dist.argmax(-1)
+    vals = np.take_along_axis(xyz, idx[:, None, :].repeat(C, 1), 2)
+    return idx, vals
+
+
+def mix_shapes(X, index, lam, start_a, start_b, points_perm):
+    """MLSP/PCM.py:6-38 with the draws passed in."""
+    N = X.shape[2]
+    na = round(lam * N)
+    nb = N - round(lam * N)
+    _, va = fps(X, na, start_a) if na else (None, np.zeros((X.shape[0], X.shape[1], 0), np.float32))
+    _, vb = fps(X[index], nb, start_b) if nb else (None, np.zeros((X.shape[0], X.shape[1], 0), np.float32))
+    return np.concatenate([va, vb], 2)[:, :, points_perm]

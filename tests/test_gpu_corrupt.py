@@ -1,0 +1,69 @@
+"""On-device input corruption and PCM mixing against the reference's golden vectors and the numpy oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_corrupt_np as oc
+from test_corrupt_oracle_cpu import GOLD, check_deform_against_reference
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_region_assignment_bit_exact_vs_reference(dev):
+    from mlsp_amd import pc_utils
+    g = dict(np.load(os.path.join(GOLD, "deform_s5_B6_N1024.npz")))
+    got = pc_utils.assign_region_to_point(torch.from_numpy(g["X"]).to(dev), dev)
+    assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), g["regions"])
+    assert np.allclose(pc_utils.region_mean(3), g["lookup"])
+
+
+@pytest.mark.parametrize("groups", [1, 3])
+def test_deform_input_vs_reference_and_oracle(dev, groups):
+    from mlsp_amd import mlsp
+    g = dict(np.load(os.path.join(GOLD, "deform_s5_B6_N1024.npz")))
+    X = torch.from_numpy(g["X"]).to(dev)
+    noise = torch.randn(X.shape, generator=torch.Generator().manual_seed(groups))
+    Xd, mask = mlsp.deform_input(X, torch.from_numpy(g["lookup"]), 'volume_based_voxels', dev, groups,
+                                 region_ids=g["perm_g%d" % groups], noise=noise)
+    assert Xd.data_ptr() == X.data_ptr()                       # in place, like the reference
+    check_deform_against_reference(g["X"], Xd.cpu().numpy(), mask.cpu().numpy(), g, groups)
+    want, wmask = oc.deform(g["X"], g["lookup"], g["perm_g%d" % groups], noise.numpy(), groups)
+    assert np.array_equal(mask.cpu().numpy(), wmask)
+    np.testing.assert_allclose(Xd.cpu().numpy(), want, rtol=0, atol=1e-7)
+    # default random draws: still a valid deformation
+    X2 = torch.from_numpy(g["X"]).to(dev)
+    _, m2 = mlsp.deform_input(X2, torch.from_numpy(g["lookup"]), 'volume_based_voxels', dev)
+    assert (m2[:, 0].sum(1) >= 40).all() and (m2[:, :3].amax(1) == m2[:, :3].amin(1)).all()
+
+
+def test_pcm_mix_shapes_vs_reference(dev):
+    from mlsp_amd import PCM
+    g = dict(np.load(os.path.join(GOLD, "pcm_s3_B5_N256.npz")))
+    args = types.SimpleNamespace(cuda=True, mixup_params=1.0, DefRec_weight=0.5)
+    rng = {"index": torch.from_numpy(g["index"]), "lam": float(g["lam"]), "start_a": torch.from_numpy(g["start_a"]),
+           "start_b": torch.from_numpy(g["start_b"]), "points_perm": torch.from_numpy(g["points_perm"])}
+    mixed, (Ya, Yb, lam) = PCM.mix_shapes(args, torch.from_numpy(g["X"]).to(dev), torch.from_numpy(g["Y"]).to(dev), rng=rng)
+    assert np.array_equal(mixed.cpu().numpy(), g["mixed"])
+    assert np.array_equal(Ya.cpu().numpy(), g["Ya"]) and np.array_equal(Yb.cpu().numpy(), g["Yb"]) and lam == float(g["lam"])
+    # unseeded draws: a permutation of sampled columns of the two parents
+    mixed2, (_, _, lam2) = PCM.mix_shapes(args, torch.from_numpy(g["X"]).to(dev), torch.from_numpy(g["Y"]).to(dev))
+    assert mixed2.shape == mixed.shape and 0.0 <= lam2 <= 1.0
+
+
+def test_pc_utils_fps_vs_oracle(dev):
+    from mlsp_amd import pc_utils
+    gen = torch.Generator().manual_seed(2)
+    xyz = torch.rand(3, 3, 500, generator=gen) * 2 - 1
+    start = torch.tensor([0, 499, 123])
+    idx, vals = pc_utils.farthest_point_sample(None, xyz.to(dev), 77, start=start)
+    widx, wvals = oc.fps(xyz.numpy(), 77, start.numpy())
+    assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(vals.cpu().numpy(), wvals)

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 
 SRC = os.path.join(ROOT, "mlsp_amd", "csrc")
-FILES = ("api.hip", "gemm.hip", "knn.hip", "bn.hip", "edge.hip", "loss.hip", "tnet.hip", "colmax.hip", "labels.hip", "skinny.hip", "sa.hip")
+FILES = ("api.hip", "gemm.hip", "knn.hip", "bn.hip", "edge.hip", "loss.hip", "tnet.hip", "colmax.hip", "labels.hip", "skinny.hip", "sa.hip", "corrupt.hip")
 
 
 def build(flags, out):

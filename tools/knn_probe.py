@@ -8,7 +8,7 @@ def build(flags, out):
     src = os.path.join(ROOT, "mlsp_amd", "csrc")
     objs = []
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", out] + flags + \
-          [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "knn.hip", "bn.hip", "edge.hip", "loss.hip", "tnet.hip", "colmax.hip", "labels.hip", "skinny.hip", "sa.hip")]
+          [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "knn.hip", "bn.hip", "edge.hip", "loss.hip", "tnet.hip", "colmax.hip", "labels.hip", "skinny.hip", "sa.hip", "corrupt.hip")]
     subprocess.check_call(cmd)
 
 def time_lib(path, C, B=32, N=1024, k=20, reps=10):

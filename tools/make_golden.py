@@ -305,6 +305,64 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def corrupt_cases():
+    """deform_input / assign_region_to_point / PCM.mix_shapes of the reference with seeded (and recorded) random draws."""
+    import types
+    ref_import.install_stubs()
+    sys.path.insert(0, ref_import.REF_ROOT)
+    import utils.pc_utils as rpc                                   # noqa: E402  (reference, CPU)
+    from MLSP import mlsp as rmlsp, PCM as rpcm                      # noqa: E402
+    g = torch.Generator().manual_seed(5)
+    B, N = 6, 1024
+    X = torch.rand(B, 3, N, generator=g) * 2.2 - 1.1              # some points outside [-1,1] (clamped), all voxels populated
+    X[0, :, :8] = torch.tensor([[-1.0, -1 / 3, 1 / 3, 1.0, 0.0, -0.33333334, 0.33333334, 0.9999999]]).expand(3, 8)   # voxel faces
+    X[1, :, :600] = X[1, :, :600] * 0.3 + 0.6                      # a crowded voxel
+    X[2] = X[2] * 0.05                                             # everything in the centre voxel
+    regions = rpc.assign_region_to_point(X.clone(), "cpu")
+    lookup = torch.Tensor(rpc.region_mean(3))
+    out = {"X": npy(X), "regions": npy(regions), "lookup": npy(lookup)}
+    for groups in (1, 3):
+        np.random.seed(11 + groups)
+        perm = np.random.permutation(27)                            # first draw inside deform_input (:27)
+        np.random.seed(11 + groups)
+        Xd, mask = rmlsp.deform_input(X.clone(), lookup, 'volume_based_voxels', 'cpu', groups)
+        out["perm_g%d" % groups] = perm
+        out["X_out_g%d" % groups] = npy(Xd)
+        out["mask_g%d" % groups] = npy(mask)
+    np.savez_compressed(os.path.join(OUT, "deform_s5_B6_N1024.npz"), **out)
+
+    # PCM.mix_shapes: record the reference's random draws by wrapping the RNG entry points it calls
+    rec = {"randperm": [], "randint": []}
+    orig_randperm, orig_randint, orig_beta = torch.randperm, torch.randint, np.random.beta
+
+    def randperm(n, *a, **k):
+        r = orig_randperm(n, *a, **k)
+        rec["randperm"].append(r.clone())
+        return r
+
+    def randint(*a, **k):
+        r = orig_randint(*a, **k)
+        rec["randint"].append(r.clone())
+        return r
+
+    args = types.SimpleNamespace(cuda=False, mixup_params=1.0)
+    Xp = torch.rand(5, 3, 256, generator=g) * 2 - 1
+    Yp = torch.arange(5)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    lam = np.random.beta(1.0, 1.0)
+    np.random.seed(3)
+    torch.randperm, torch.randint = randperm, randint
+    try:
+        mixed, (Ya, Yb, lam2) = rpcm.mix_shapes(args, Xp.clone(), Yp)
+    finally:
+        torch.randperm, torch.randint = orig_randperm, orig_randint
+    assert lam == lam2
+    np.savez_compressed(os.path.join(OUT, "pcm_s3_B5_N256.npz"), X=npy(Xp), Y=npy(Yp), lam=np.array(lam), index=npy(rec["randperm"][0]),
+                        points_perm=npy(rec["randperm"][1]), start_a=npy(rec["randint"][0]), start_b=npy(rec["randint"][1]),
+                        mixed=npy(mixed), Ya=npy(Ya), Yb=npy(Yb))
+
+
 def main_sa():
     pu = import_sa_reference()
     np.savez_compressed(os.path.join(OUT, "sa_s0_B4_N256.npz"), **sa_case(pu, 0, 4, 256, 6, 64, 0.4, 16, [32, 32, 64], False))
@@ -316,5 +374,8 @@ def main_sa():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sa":
         main_sa()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "corrupt":
+        corrupt_cases()
         sys.exit(0)
     main()
