@@ -48,27 +48,40 @@ __device__ __forceinline__ bool tn_tile(int m, int B, int N, int TP, int& pt0, i
     return true;
 }
 
-// gather hpre = u_j + v_i for the rows of one tile into Hs (k-major); invalid rows are zero.  512 threads: 4 per row.
-__device__ __forceinline__ void tn_build_h(float* __restrict__ Hs, const float* __restrict__ uv, const int* __restrict__ idx,
-                                           int pt0, int npts, int k, int N, int tid) {
-    const int row = tid >> 2, qt = tid & 3;
+// Gather of hpre = u_j + v_i for the rows of one tile (512 threads: 4 per row), split so that it can run one tile AHEAD of
+// the MFMA work: the neighbour index of tile m+2 and the u/v rows of tile m+1 are in flight while tile m is computed (a
+// single workgroup per CU: nothing else would hide the two dependent L2 round trips of index -> row).
+struct TnRows { f32x4 u[4], v[4]; };
+
+// global source row of this thread's (point, slot) in a tile, -1 when the row is padding
+__device__ __forceinline__ int tn_row_index(const int* __restrict__ idx, int pt0, int npts, int k, int N, int tid) {
+    const int row = tid >> 2;
     const int pt = row / k, s = row - pt * k;
+    if (pt >= npts) return -1;
     const int i = pt0 + pt;
-    f32x4 hv[4];
-    if (pt < npts) {
-        const int j = (i / N) * N + idx[(size_t)i * k + s];
+    return (i / N) * N + idx[(size_t)i * k + s];
+}
+__device__ __forceinline__ void tn_load_rows(TnRows& r, const float* __restrict__ uv, int j, int pt0, int k, int tid) {
+    const int row = tid >> 2, qt = tid & 3;
+    if (j >= 0) {
+        const int i = pt0 + row / k;
         const f32x4* ur = (const f32x4*)(uv + (size_t)j * 2 * TN_C1 + 16 * qt);
         const f32x4* vr = (const f32x4*)(uv + (size_t)i * 2 * TN_C1 + TN_C1 + 16 * qt);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hv[q] = ur[q] + vr[q];
+        for (int q = 0; q < 4; ++q) { r.u[q] = ur[q]; r.v[q] = vr[q]; }
     } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) { r.u[q] = f32x4{0.f, 0.f, 0.f, 0.f}; r.v[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
+}
+__device__ __forceinline__ void tn_store_h(float* __restrict__ Hs, const TnRows& r, int tid) {
+    const int row = tid >> 2, qt = tid & 3;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 hv = r.u[q] + r.v[q];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Hs[(16 * qt + 4 * q + e) * TN_SH + row] = hv[q][e];
+        for (int e = 0; e < 4; ++e) Hs[(16 * qt + 4 * q + e) * TN_SH + row] = hv[e];
+    }
 }
 
 // Z tile = H W2^T  (H = LeakyReLU(scale1*hpre + shift1), zero on invalid rows) -> Zs[row][o].
@@ -121,11 +134,21 @@ __global__ __launch_bounds__(512) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
     const int o = tid & 127;
     const bool use_max = p.gamma2[o] >= 0.f;
     double ssum = 0.0, ssq = 0.0;
-    int pt0, npts;
-    for (int m = 0; tn_tile(m, p.P / p.N, p.N, p.TP, pt0, npts); ++m) {
+    int pt0 = 0, npts = 0, pt0n = 0, nptsn = 0, pt0nn = 0, nptsnn = 0;
+    const int Bc = p.P / p.N;
+    bool have = tn_tile(0, Bc, p.N, p.TP, pt0, npts);
+    TnRows rows;
+    if (have) tn_load_rows(rows, p.uv, tn_row_index(p.idx, pt0, npts, p.k, p.N, tid), pt0, p.k, tid);
+    bool haven = have && tn_tile(1, Bc, p.N, p.TP, pt0n, nptsn);
+    int jn = haven ? tn_row_index(p.idx, pt0n, nptsn, p.k, p.N, tid) : -1;
+    for (int m = 0; have; ++m) {
         __syncthreads();
-        tn_build_h(Hs, p.uv, p.idx, pt0, npts, p.k, p.N, tid);
+        tn_store_h(Hs, rows, tid);
         __syncthreads();
+        // tile m+1's rows and tile m+2's neighbour index travel under the MFMA + epilogue of tile m
+        if (haven) tn_load_rows(rows, p.uv, jn, pt0n, p.k, tid);
+        const bool havenn = haven && tn_tile(m + 2, Bc, p.N, p.TP, pt0nn, nptsnn);
+        const int jnn = havenn ? tn_row_index(p.idx, pt0nn, nptsnn, p.k, p.N, tid) : -1;
         tn_compute_z(Hs, Ws, S1, Zs, npts * p.k, p.slope, wm, wn, l31, h);
         __syncthreads();
         for (int item = tid; item < npts * TN_C2; item += 512) {
@@ -134,16 +157,25 @@ __global__ __launch_bounds__(512) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
             const float* z = Zs + (pt * p.k) * TN_SZ + o;
             float best = z[0], s1 = z[0], s2 = z[0] * z[0];
             int bs = 0;
-            for (int s = 1; s < p.k; ++s) {
-                float v = z[s * TN_SZ];
-                s1 += v; s2 = fmaf(v, v, s2);
-                bool take = use_max ? (v > best) : (v < best);
-                best = take ? v : best; bs = take ? s : bs;
+            for (int s0 = 1; s0 < p.k; s0 += 4) {            // four LDS reads in flight (one wave per SIMD pair: latency shows)
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = z[min(s0 + u, p.k - 1) * TN_SZ];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (s0 + u < p.k) {
+                        s1 += v[u]; s2 = fmaf(v[u], v[u], s2);
+                        const bool take = use_max ? (v[u] > best) : (v[u] < best);
+                        best = take ? v[u] : best; bs = take ? s0 + u : bs;
+                    }
+                }
             }
             p.zsel[i * TN_C2 + o] = best;
             p.argsel[i * TN_C2 + o] = (uint8_t)bs;
             ssum += s1; ssq += s2;
         }
+        have = haven; pt0 = pt0n; npts = nptsn;
+        haven = havenn; pt0n = pt0nn; nptsn = nptsnn; jn = jnn;
     }
     __syncthreads();
     double* red = (double*)Zs;                       // [2][512]
@@ -239,11 +271,21 @@ __global__ __launch_bounds__(512) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
     for (int r = 0; r < 16; ++r) accW[r] = 0.f;
     double sd = 0.0, sdh = 0.0;
 
-    int pt0, npts;
-    for (int m = 0; tn_tile(m, p.P / p.N, p.N, p.TP, pt0, npts); ++m) {
+    int pt0 = 0, npts = 0, pt0n = 0, nptsn = 0, pt0nn = 0, nptsnn = 0;
+    const int Bc = p.P / p.N;
+    bool have = tn_tile(0, Bc, p.N, p.TP, pt0, npts);
+    TnRows rows;
+    if (have) tn_load_rows(rows, p.uv, tn_row_index(p.idx, pt0, npts, p.k, p.N, tid), pt0, p.k, tid);
+    bool haven = have && tn_tile(1, Bc, p.N, p.TP, pt0n, nptsn);
+    int jn = haven ? tn_row_index(p.idx, pt0n, nptsn, p.k, p.N, tid) : -1;
+    for (int m = 0; have; ++m) {
         __syncthreads();
         const int nvalid = npts * p.k;
-        tn_build_h(Hs, p.uv, p.idx, pt0, npts, p.k, p.N, tid);
+        tn_store_h(Hs, rows, tid);
+        // tile m+1's rows and tile m+2's neighbour index travel under the three MFMA stages of tile m
+        if (haven) tn_load_rows(rows, p.uv, jn, pt0n, p.k, tid);
+        const bool havenn = haven && tn_tile(m + 2, Bc, p.N, p.TP, pt0nn, nptsnn);
+        const int jnn = havenn ? tn_row_index(p.idx, pt0nn, nptsnn, p.k, p.N, tid) : -1;
         if (tid < TN_ROWS) {
             int pt = tid / p.k, s = tid - pt * p.k;
             rowpt[tid] = tid < nvalid ? ((pt << 8) | s) : -1;
@@ -260,6 +302,7 @@ __global__ __launch_bounds__(512) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
         {
             const int o = tid & 127;
             const float A2 = C2[o], B2 = C2[TN_C2 + o], m2 = C2[2 * TN_C2 + o];
+#pragma unroll 8
             for (int row = tid >> 7; row < TN_ROWS; row += 4) {
                 const int rp = rowpt[row];
                 float dz = 0.f;
@@ -313,6 +356,8 @@ __global__ __launch_bounds__(512) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
             }
             sd += lsd; sdh += lsdh;
         }
+        have = haven; pt0 = pt0n; npts = nptsn;
+        haven = havenn; pt0n = pt0nn; nptsn = nptsnn; jn = jnn;
     }
     // per-block partials
 #pragma unroll
