@@ -145,6 +145,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     const int kbeg = split * p.ksplit;
     const int kend = min(p.K, kbeg + p.ksplit);
 
+#ifdef GP_TIMELINE
+    const long long tl0 = wall_clock64();
+    long long tl1 = 0;
+#endif
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -178,6 +182,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
         r2s<!TB, 4>(rb, Bs, tid);
         }
         __syncthreads();
+#ifdef GP_TIMELINE
+        if (k0 == kbeg) tl1 = wall_clock64();
+#endif
 #ifdef GP_NOGLOBAL
         if (false) {
 #else
@@ -244,6 +251,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 #endif
     }
 
+#ifdef GP_TIMELINE
+    const long long tl2 = wall_clock64();
+#endif
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
     const bool epi = (p.nsplit == 1);
@@ -329,6 +339,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
             p.stat_part[((size_t)tm * 2 + 1) * p.N + n0 + tid] = (double)red[1 * 128 + tid] + (double)red[3 * 128 + tid];
         }
     }
+#ifdef GP_TIMELINE
+    __syncthreads();
+    if (tid == 0) {                                    // 100 MHz ticks: start, first tile staged, loop end, epilogue end
+        const long long tl3 = wall_clock64();
+        float* dbg = p.C + (size_t)m0 * p.ldc + n0;
+        dbg[0] = (float)(tl0 & 0xffffff); dbg[1] = (float)(tl1 - tl0); dbg[2] = (float)(tl2 - tl1); dbg[3] = (float)(tl3 - tl2);
+    }
+#endif
 }
 
 // sum the split-K slabs (fixed order -> bitwise reproducible) and apply the epilogue

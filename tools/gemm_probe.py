@@ -50,7 +50,16 @@ def time_lib(path):
         for _ in range(10): run()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        out.append("%s %dx%dx%d %.0fus %.0fTF" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
+        extra = ""
+        if os.environ.get("GP_TIMELINE") and not ta:
+            torch.cuda.synchronize()
+            bm = 64 if (M // 128) * ((N + 127) // 128) < 1536 and M >= 256 else 128
+            d = C.view(M, N)[0::bm, 0::128, ].reshape(-1)            # first element of every tile row 0
+            T = C.view(M // bm, bm, N // 128, 128)[:, 0, :, :4].reshape(-1, 4).double().cpu()
+            t_start = T[:, 0]
+            extra = " | per-block (us): prologue %.1f loop %.1f epilogue %.1f ; starts span %.0f us" % (
+                T[:, 1].mean() / 100, T[:, 2].mean() / 100, T[:, 3].mean() / 100, (t_start.max() - t_start.min()) / 100)
+        out.append("%s %dx%dx%d %.0fus %.0fTF%s" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9, extra))
     return out
 
 
