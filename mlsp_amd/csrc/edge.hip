@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void edge_reduce_vec_kernel(const float* __res
 // neighbour row.  A thread owns (point, channel quad) and walks its k neighbours in slot order, so the first-occurrence
 // rule needs no cross-lane merge.  Partial BN statistics: one fp64 row per (cloud, chunk), each slice writes its columns.
 #define ELDS_CS 16
-template <int KMAX>
+template <int KMAX, bool EXACT>     // EXACT: k == KMAX, the neighbour loop is straight-line (all index / row reads of a point in flight)
 __global__ __launch_bounds__(256) void edge_reduce_lds_kernel(const float* __restrict__ uv, const int* __restrict__ idx,
                                                               const float* __restrict__ gamma, int B, int N, int k, int Cout, int psplit,
                                                               float* __restrict__ msel, uint8_t* __restrict__ argsel,
@@ -209,20 +209,27 @@ __global__ __launch_bounds__(256) void edge_reduce_lds_kernel(const float* __res
     double ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
     for (int il = pl; il < pend - pbeg; il += PL) {
         const unsigned short* irow = Is + il * k;
+        // min-channels (negative BN scale) are searched as the max of -u: one compare per value, strict > keeps the first slot
         float best[4], s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
         int bs[4] = {0, 0, 0, 0};
+        int jr[KMAX];
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) jr[s] = (EXACT || s < k) ? (int)irow[s] : 0;
 #pragma unroll
         for (int s = 0; s < KMAX; ++s) {
-            if (s < k) {
-                const f32x4 u = *(const f32x4*)(Us + (int)irow[s] * CS + 4 * q);
+            if (EXACT || s < k) {
+                const f32x4 u = *(const f32x4*)(Us + jr[s] * CS + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s1[e] += u[e]; s2[e] = fmaf(u[e], u[e], s2[e]);
-                    const bool take = (s == 0) || (use_max[e] ? (u[e] > best[e]) : (u[e] < best[e]));
-                    best[e] = take ? u[e] : best[e]; bs[e] = take ? s : bs[e];
+                    const float t = use_max[e] ? u[e] : -u[e];
+                    const bool take = (s == 0) || (t > best[e]);
+                    best[e] = take ? t : best[e]; bs[e] = take ? s : bs[e];
                 }
             }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) best[e] = use_max[e] ? best[e] : -best[e];
         const size_t i = (size_t)b * N + pbeg + il;
         const f32x4 v = *(const f32x4*)(uv + i * ld + Cout + c0 + 4 * q);
         f32x4 b4, s4;
@@ -574,7 +581,7 @@ int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const fl
         while (psplit < 8 && (B * nsl * psplit < 512 || (N / psplit) * k * 2 > 16 * 1024) && N % (psplit * 2) == 0) psplit *= 2;
         const size_t lds = (size_t)N * ELDS_CS * sizeof(float) + align_up((size_t)((N + psplit - 1) / psplit) * k * 2, 16);
         if (lds <= 150 * 1024 && B * psplit <= edge_reduce_parts(P) && lds >= (size_t)2 * (256 / (ELDS_CS / 4)) * ELDS_CS * sizeof(double)) {
-            auto kern = k <= 20 ? edge_reduce_lds_kernel<20> : edge_reduce_lds_kernel<32>;
+            auto kern = k == 20 ? edge_reduce_lds_kernel<20, true> : k <= 20 ? edge_reduce_lds_kernel<20, false> : edge_reduce_lds_kernel<32, false>;
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return (int)e;
