@@ -1,4 +1,4 @@
-"""Mirror of the reference's PointDA/Models.py:82-285 (DGCNN + the three MLSP heads) on the HIP path.
+"""Mirror of the reference's PointDA/Models.py:24-285 (PointNet, DGCNN + the three MLSP heads) on the HIP path.
 
 Same constructors, forward flags, output dict keys/shapes and state_dict keys (159 entries) as the
 reference, so PointDA/trainer.py and train_spst.py (strict load_state_dict) work unchanged.
@@ -119,6 +119,47 @@ class Density_prediction(nn.Module):
         X = x.transpose(2, 1).reshape(B * N, C)
         h = _bn_layer(X, self.conv1, self.bn1, self.training, Fh.ACT_RELU, p_drop=self.dp1.p)
         return self._tail(h)
+
+
+class PointNet(nn.Module):
+    """Models.py:24-79 -- the trainer's `--model pointnet` (PointDA/trainer.py:241-244): two T-Nets, five per-point
+    conv+BN+ReLU layers, global max, classifier and the DefRec head.  No neighbourhood graph: every layer is a row GEMM with
+    fused BN statistics; conv5 + max never writes its [B*N,1024] activation."""
+
+    def __init__(self, args):
+        super(PointNet, self).__init__()
+        num_class = int(args.num_class)
+        self.args = args
+        self.trans_net1 = transform_net(args, 3, 3)
+        self.trans_net2 = transform_net(args, 64, 64)
+        self.conv1 = conv_2d(3, 64, 1)
+        self.conv2 = conv_2d(64, 64, 1)
+        self.conv3 = conv_2d(64, 64, 1)
+        self.conv4 = conv_2d(64, 128, 1)
+        self.conv5 = conv_2d(128, 1024, 1)
+        num_f_prev = 64 + 64 + 64 + 128
+        self.C = classifier(args, num_class)
+        self.DefRec = RegionReconstruction(args, num_f_prev + 1024)
+
+    @flushing_forward
+    def forward(self, x, activate_DefRec=False):
+        B, _, N = x.shape
+        logits = {}
+        xp = x.float().transpose(2, 1).contiguous().view(B * N, 3)                  # point-major rows
+        T1 = self.trans_net1.rows(xp, B, N, 1)                                      # [B,3,3]   (Models.py:50-54)
+        h = torch.bmm(xp.view(B, N, 3), T1).view(B * N, 3)
+        x1 = self.conv1.rows(h)
+        x2 = self.conv2.rows(x1)
+        T2 = self.trans_net2.rows(x2, B, N, 1)                                      # [B,64,64] (:59-63)
+        h = torch.bmm(x2.view(B, N, 64), T2).view(B * N, 64)
+        x3 = self.conv3.rows(h)
+        x4 = self.conv4.rows(x3)
+        x_cat = torch.cat((x1, x2, x3, x4), dim=1)                                  # [P,320]
+        x5 = self.conv5.rows_colmax(x4, B, N)                                       # [B,1024]  (:68-70)
+        logits["cls"] = self.C(x5)
+        if activate_DefRec:
+            logits["DefRec"] = self.DefRec.rows(x_cat, x5, B, N)
+        return logits
 
 
 class DGCNN(nn.Module):

@@ -203,6 +203,48 @@ def dgcnn_forward(params, x, training=True, dropout_p=0.0, k=K_DEFAULT, knn_fn=k
     return out, c.new_buffers
 
 
+# --------------------------------------------------------------------------- PointNet (the trainer's other --model)
+def _conv2d_bn_relu(c, x, prefix):
+    """conv_2d with the pointnet defaults (model_utils.py:45-63): 1x1 Conv2d + bias + BN2d + ReLU.  x [B,C,N,1]."""
+    y = torch.einsum("oc,bcnk->bonk", c.p[prefix + ".conv.0.weight"][:, :, 0, 0], x) + c.p[prefix + ".conv.0.bias"].view(1, -1, 1, 1)
+    return F.relu(c.bn(y, prefix + ".conv.1", (0, 2, 3)))
+
+
+def _transform_net_pn(c, x, prefix, K):
+    """transform_net.forward (model_utils.py:108-127), non-dgcnn branch: ReLU, biases, no max over the last axis."""
+    for name in ("conv2d1", "conv2d2", "conv2d3"):
+        x = _conv2d_bn_relu(c, x, prefix + "." + name)
+    x = x.max(dim=2)[0].reshape(x.shape[0], -1)
+    x = _fc_bn_act(c, x, prefix + ".fc1", act="relu")
+    x = _fc_bn_act(c, x, prefix + ".fc2", act="relu")
+    x = x @ c.p[prefix + ".fc3.weight"].t() + c.p[prefix + ".fc3.bias"]
+    return (x + torch.eye(K).reshape(1, K * K)).view(-1, K, K)
+
+
+def pointnet_forward(params, x, training=True, dropout_p=0.0, activate_DefRec=False):
+    """PointNet.forward (PointDA/Models.py:43-79).  Returns (logits dict, new_buffers dict)."""
+    c = _Ctx(params, training, dropout_p, None)
+    B, _, N = x.shape
+    h = x.unsqueeze(3)
+    T1 = _transform_net_pn(c, h, "trans_net1", 3)
+    h = torch.bmm(x.transpose(2, 1), T1).transpose(2, 1).unsqueeze(3)
+    x1 = _conv2d_bn_relu(c, h, "conv1")
+    x2 = _conv2d_bn_relu(c, x1, "conv2")
+    T2 = _transform_net_pn(c, x2, "trans_net2", 64)
+    h = torch.bmm(x2.squeeze(3).transpose(2, 1), T2).transpose(2, 1).unsqueeze(3)
+    x3 = _conv2d_bn_relu(c, h, "conv3")
+    x4 = _conv2d_bn_relu(c, x3, "conv4")
+    x_cat = torch.cat((x1, x2, x3, x4), dim=1).squeeze(3)
+    x5 = _conv2d_bn_relu(c, x4, "conv5").max(dim=2)[0]            # [B,1024,1]
+    cls_in = x5.squeeze(2)
+    h1 = c.drop(_fc_bn_act(c, cls_in, "C.mlp1", act="relu"))
+    h2 = c.drop(_fc_bn_act(c, h1, "C.mlp2", act="relu"))
+    logits = {"cls": h2 @ c.p["C.mlp3.weight"].t() + c.p["C.mlp3.bias"]}
+    if activate_DefRec:
+        logits["DefRec"] = _region_head(c, torch.cat((x_cat, x5.expand(B, 1024, N)), dim=1), "DefRec")
+    return logits, c.new_buffers
+
+
 # --------------------------------------------------------------------------- losses
 def chamfer_distance(p1, p2, mask):
     """MLSP/mlsp.py:115-153.  p1,p2 [B,N,3]; mask [B,N,3] (0/1).  For each masked point of p1 the

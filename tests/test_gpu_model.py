@@ -272,3 +272,38 @@ def test_segda_free_running_and_full_size(dev):
     sum(v.float().mean() for v in out.values()).backward()
     assert all(torch.isfinite(v).all().item() for v in out.values())
     assert all(p.grad is None or torch.isfinite(p.grad).all().item() for p in m2.parameters())
+
+
+# ----------------------------------------------------------------------------- PointNet (the trainer's other --model)
+def test_pointnet_vs_reference_golden(dev, golden_dir):
+    """mlsp_amd.Models.PointNet on the GPU against the reference's PointNet (tests/golden/pointnet_*.npz): no dynamic graph,
+    so the whole network is compared directly -- outputs within the 1e-3 contract, gradients, BN buffers."""
+    from test_oracle_golden import _pointnet_from_golden
+    g = dict(np.load(os.path.join(golden_dir, "pointnet_s0_B4_N256.npz")))
+    m = _pointnet_from_golden(g).to(dev)
+    m.train()
+    logits = m(torch.from_numpy(g["x"]).to(dev), activate_DefRec=True)
+    np.testing.assert_allclose(logits["cls"].detach().cpu().numpy(), g["cls"], rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(logits["DefRec"].detach().cpu().numpy(), g["DefRec"], rtol=1e-3, atol=1e-3)
+    loss = (logits["cls"] * torch.from_numpy(g["w_cls"]).to(dev)).sum() + (logits["DefRec"] * torch.from_numpy(g["w_rec"]).to(dev)).sum()
+    loss.backward()
+    named = dict(m.named_parameters())
+    for key in [k[5:] for k in g if k.startswith("grad/")]:
+        want = g["grad/" + key]
+        got = named[key].grad.cpu().numpy()
+        err = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-12)
+        assert err < 5e-2, (key, err)
+    for k, v in gc.state_checksums(m).items():
+        if "running" in k or "num_batches" in k:
+            np.testing.assert_allclose(v, g["chk_after/" + k], rtol=5e-4, atol=1e-5, err_msg=k)
+    # full-size smoke: B=32, N=1024 through the drop-in import path
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mlsp_amd", "shims"))
+    from PointDA.Models import PointNet
+    args = gc.make_args(dropout=0.5, cuda=True)
+    args.model, args.encoder_type = "pointnet", "none"
+    big = PointNet(args).to(dev).train()
+    out = big(torch.rand(32, 3, 1024, device=dev) * 2 - 1, activate_DefRec=True)
+    assert out["cls"].shape == (32, 10) and out["DefRec"].shape == (32, 1024, 3)
+    (out["cls"].sum() + out["DefRec"].sum()).backward()
+    assert all(torch.isfinite(p.grad).all().item() for p in big.parameters() if p.grad is not None)

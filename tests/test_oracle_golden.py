@@ -207,3 +207,44 @@ def test_segda_oracle_vs_reference(golden_dir, fname, seed, B, N):
         assert rel < 5e-2, (key, rel)
     for key in [k[4:] for k in g if k.startswith("run/")]:
         np.testing.assert_allclose(newbuf[key].numpy(), g["run/" + key], rtol=1e-4, atol=1e-6, err_msg=key)
+
+
+def _pointnet_from_golden(g, seed=0):
+    """Rebuilds the reference's parameters from the seed: mlsp_amd.Models.PointNet creates its children in the reference's
+    order, so init + perturb_params give the identical state (checked against the golden checksums)."""
+    from mlsp_amd import Models
+    args = gc.make_args()
+    args.model, args.encoder_type = "pointnet", "none"
+    torch.manual_seed(seed)
+    m = Models.PointNet(args)
+    m.train()
+    gc.perturb_params(m, seed)
+    for k, v in gc.state_checksums(m).items():
+        np.testing.assert_allclose(v, g["chk_before/" + k], rtol=1e-6, atol=1e-9, err_msg=k)
+    return m
+
+
+def test_pointnet_oracle_vs_reference_golden(golden_dir):
+    """oracle/ref_cpu.py::pointnet_forward against the reference's PointNet (tests/golden/pointnet_*.npz)."""
+    g = dict(np.load(os.path.join(golden_dir, "pointnet_s0_B4_N256.npz")))
+    m = _pointnet_from_golden(g)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items() if v.dtype == torch.float32 and "running" not in k}
+    p2 = dict(params)
+    p2.update(leaves)
+    logits, nb = ref_cpu.pointnet_forward(p2, torch.from_numpy(g["x"]), training=True, activate_DefRec=True)
+    np.testing.assert_allclose(logits["cls"].detach().numpy(), g["cls"], rtol=2e-3, atol=5e-4)      # BN1d over 4 samples
+    np.testing.assert_allclose(logits["DefRec"].detach().numpy(), g["DefRec"], rtol=1e-3, atol=1e-4)
+    loss = (logits["cls"] * torch.from_numpy(g["w_cls"])).sum() + (logits["DefRec"] * torch.from_numpy(g["w_rec"])).sum()
+    loss.backward()
+    for key in [k[5:] for k in g if k.startswith("grad/")]:
+        want = g["grad/" + key]
+        got = leaves[key].grad.numpy()
+        err = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-12)        # BN over 4 samples amplifies fp32 noise
+        assert err < 5e-2, (key, err)
+    after = dict(params)
+    after.update(nb)
+    for k, v in after.items():
+        if "running" in k or "num_batches" in k:
+            v = v.double()
+            np.testing.assert_allclose([float(v.sum()), float(v.abs().sum())], g["chk_after/" + k], rtol=2e-4, atol=1e-6, err_msg=k)

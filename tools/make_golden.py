@@ -223,6 +223,45 @@ def seg_case(seg, seed, B, N):
     return out
 
 
+def pointnet_case(RefModels, seed, B, N):
+    """The reference's PointNet (PointDA/Models.py:24-79): forward with the DefRec head, a scalar loss, backward, BN buffers."""
+    args = gc.make_args()
+    args.model, args.encoder_type = "pointnet", "none"
+    torch.manual_seed(seed)
+    m = RefModels.PointNet(args)
+    m.train()
+    with torch.no_grad():
+        gc.perturb_params(m, seed)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, N, generator=g) * 2 - 1
+    before = gc.state_checksums(m)
+    logits = m(x, activate_DefRec=True)
+    w_cls = torch.randn(logits["cls"].shape, generator=g)
+    w_rec = torch.randn(logits["DefRec"].shape, generator=g)
+    loss = (logits["cls"] * w_cls).sum() + (logits["DefRec"] * w_rec).sum()
+    loss.backward()
+    out = {"x": npy(x), "cls": npy(logits["cls"]), "DefRec": npy(logits["DefRec"]), "w_cls": npy(w_cls), "w_rec": npy(w_rec),
+           "loss": npy(loss)}
+    for k, v in before.items():
+        out["chk_before/" + k] = v
+    for k, v in gc.state_checksums(m).items():
+        out["chk_after/" + k] = v
+    for k in POINTNET_GRAD_KEYS:                               # a spread of layers; the full gradient set would be 15 MB
+        out["grad/" + k] = npy(dict(m.named_parameters())[k].grad)
+    return out
+
+
+POINTNET_GRAD_KEYS = ["conv1.conv.0.weight", "conv2.conv.0.weight", "conv3.conv.1.weight", "conv4.conv.0.weight", "conv5.conv.1.bias",
+                      "trans_net1.fc3.weight", "trans_net1.conv2d1.conv.0.weight", "trans_net2.conv2d1.conv.0.weight", "trans_net2.fc3.bias",
+                      "trans_net2.fc2.fc.1.weight", "C.mlp1.fc.1.weight", "C.mlp3.weight", "DefRec.bn1.weight", "DefRec.conv4.weight"]
+
+
+def main_pointnet():
+    ref_import.install_stubs()
+    RefModels, _, _ = ref_import.import_reference()
+    np.savez_compressed(os.path.join(OUT, "pointnet_s0_B4_N256.npz"), **pointnet_case(RefModels, 0, 4, 256))
+
+
 def import_sa_reference():
     """PointDA/hengshuang_transformer/pointnet_util.py is pure torch + numpy: it imports with no stubs."""
     import importlib.util
@@ -374,6 +413,9 @@ def main_sa():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sa":
         main_sa()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pointnet":
+        main_pointnet()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "corrupt":
         corrupt_cases()
