@@ -192,6 +192,10 @@ int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const 
 int mlsp_region_assign_f32(const float* X, int B, int C, int N, const float* thr, int n, float clip, int32_t* regions, mlsp_stream_t stream);
 int mlsp_deform_regions_f32(float* X, int B, int C, int N, const int32_t* regions, const int32_t* order, int nreg, const float* lookup,
                             const float* noise, int min_pts, int groups, float* mask, mlsp_stream_t stream);
+/* MLSP/mlsp.py:54-89 scan_input / p_scan: X [B][N][C] point-major; R [B][9] float64 row-major rotation of every cloud
+ * (rotate_point_cloud_3d :91-112, drawn on the host); pixel = int(2 / pixel_size).  Xs [B][N][C] keeps only the visible points,
+ * mask [B][N][C] is 0 on their first three channels and 1 elsewhere. */
+int mlsp_scan_select_f32(const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask, mlsp_stream_t stream);
 
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP
  * events on its launch stream.  mlsp_profile_end synchronises those events and fills

@@ -33,6 +33,7 @@ int launch_sa_group_bwd(hipStream_t st, const float* dG, int D, const int* rev_o
                         float* dfeat);
 
 int launch_region_assign(hipStream_t st, const float* X, int B, int C, int N, const float* thr, int n, float clip, int* Y);
+int launch_scan_select(hipStream_t st, const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask);
 int launch_deform_regions(hipStream_t st, float* X, int B, int C, int N, const int* regions, const int* order, int nreg, const float* lookup,
                           const float* noise, int min_pts, int groups, float* mask);
 int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double* part);
@@ -177,6 +178,9 @@ int mlsp_region_assign_f32(const float* X, int B, int C, int N, const float* thr
 int mlsp_deform_regions_f32(float* X, int B, int C, int N, const int32_t* regions, const int32_t* order, int nreg, const float* lookup,
                             const float* noise, int min_pts, int groups, float* mask, mlsp_stream_t st) {
     return launch_deform_regions(st, X, B, C, N, regions, order, nreg, lookup, noise, min_pts, groups, mask);
+}
+int mlsp_scan_select_f32(const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask, mlsp_stream_t st) {
+    return launch_scan_select(st, X, B, N, C, R, pixel, Xs, mask);
 }
 int mlsp_fps_f32(const float* xyz, int ldx, int B, int N, int S, const int32_t* start, int32_t* fps_idx, mlsp_stream_t st) {
     return launch_fps(st, xyz, ldx, B, N, S, start, fps_idx);

@@ -63,6 +63,56 @@ __global__ __launch_bounds__(256) void deform_regions_kernel(float* __restrict__
     }
 }
 
+// scan_input / p_scan (MLSP/mlsp.py:54-89): every cloud is rotated by its own random matrix R (host float64, as the reference),
+// projected on a pixel grid along +x, and per occupied cell only the point with the largest rotated x survives ("visible"
+// from that side; ties -> lowest index, like the reference's sequential scan).  X [B][N][C] point-major (as the trainer holds it
+// here); Xs gets the survivors (all other points zero), mask is 1 everywhere except the first three channels of the survivors.
+// float64 like numpy: rot = ((p0*R0c + p1*R1c) + p2*R2c), cell = trunc(((z+1)/2*pixel)*pixel + ((y+1)/2)*pixel).
+__global__ __launch_bounds__(1024) void scan_select_kernel(const float* __restrict__ X, int N, int C, const double* __restrict__ R, int pixel,
+                                                           float* __restrict__ Xs, float* __restrict__ mask) {
+    extern __shared__ double ssm[];
+    double* xr = ssm;                      // [N] rotated x
+    int* cell = (int*)(ssm + N);           // [N]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xb = X + (size_t)b * N * C;
+    const double* Rb = R + (size_t)b * 9;
+    for (int j = tid; j < N; j += 1024) {
+        const double p0 = xb[(size_t)j * C], p1 = xb[(size_t)j * C + 1], p2 = xb[(size_t)j * C + 2];
+        const double rx = (p0 * Rb[0] + p1 * Rb[3]) + p2 * Rb[6];
+        const double ry = (p0 * Rb[1] + p1 * Rb[4]) + p2 * Rb[7];
+        const double rz = (p0 * Rb[2] + p1 * Rb[5]) + p2 * Rb[8];
+        xr[j] = rx;
+        cell[j] = (int)(((rz + 1.0) / 2.0 * pixel) * pixel + (ry + 1.0) / 2.0 * pixel);
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 1024) {
+        const int cj = cell[j];
+        const double xj = xr[j];
+        bool win = true;
+        for (int i = 0; i < N; ++i) {
+            const bool same = cell[i] == cj;
+            win = win && !(same && (xr[i] > xj || (xr[i] == xj && i < j)));
+        }
+        for (int c = 0; c < C; ++c) {
+            const size_t o = ((size_t)b * N + j) * C + c;
+            Xs[o] = win ? xb[(size_t)j * C + c] : 0.f;
+            mask[o] = (win && c < 3) ? 0.f : 1.f;
+        }
+    }
+}
+
+int launch_scan_select(hipStream_t st, const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask) {
+    if (!X || !R || !Xs || !mask || B <= 0 || N <= 0 || C < 3 || pixel <= 0) return MLSP_ERR_ARG;
+    const size_t lds = (size_t)N * (sizeof(double) + sizeof(int));
+    if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)scan_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(scan_select_kernel, dim3(B), dim3(1024), lds, st, X, N, C, R, pixel, Xs, mask);
+    return mlsp_launch_status();
+}
+
 int launch_region_assign(hipStream_t st, const float* X, int B, int C, int N, const float* thr, int n, float clip, int* Y) {
     if (!X || !thr || !Y || B <= 0 || C < 3 || N <= 0 || n <= 0 || n > 8) return MLSP_ERR_ARG;
     const int total = B * N;

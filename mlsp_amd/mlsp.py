@@ -2,7 +2,7 @@
 
 Same function names, argument order and return conventions (0-dim tensors supporting .item() and
 .backward()) as MLSP/mlsp.py:115-238, 275-287, 430-454.  `deform_input` (MLSP/mlsp.py:10-51) runs
-on device for DefRec_dist == 'volume_based_voxels'; `scan_input` (a host numpy rasteriser) is not built.
+on device for DefRec_dist == 'volume_based_voxels'; `scan_input` (:54-89) is one kernel per batch with the float64 arithmetic of the numpy original.
 `cal_density` is provided on device by mlsp_amd/labels.py (f-1, parity unpinned: python-pcl is third-party).
 """
 import numpy as np
@@ -43,6 +43,39 @@ def deform_input(X, lookup, DefRec_dist='volume_based_voxels', device='cuda:0', 
     _lib.check(lib.mlsp_deform_regions_f32(X.data_ptr(), B, C, N, regions.data_ptr(), order.data_ptr(), n ** 3, look.data_ptr(),
                                            scaled.data_ptr(), 40, groups, mask.data_ptr(), _lib.stream()), "mlsp_deform_regions_f32")
     return X, mask
+
+
+def rotation_matrix_3d(angles):
+    """rotate_point_cloud_3d (MLSP/mlsp.py:91-112): the float64 rotation matrix of three angles (host, numpy like the reference)."""
+    c, s_ = np.cos(angles), np.sin(angles)
+    r1 = np.array([[c[0], 0, s_[0]], [0, 1, 0], [-s_[0], 0, c[0]]])
+    r2 = np.array([[1, 0, 0], [0, c[1], -s_[1]], [0, s_[1], c[1]]])
+    r3 = np.array([[c[2], -s_[2], 0], [s_[2], c[2], 0], [0, 0, 1]])
+    return np.matmul(np.matmul(r1, r2), r3)
+
+
+def scan_input(X, device, pixel_size=0.07, angles=None):
+    """MLSP/mlsp.py:54-64 (+ p_scan :66-89).  X [B,N,C]: single-view "scan" of every cloud -- only the points visible along +x of
+    a random rotation survive (the rest become zero); mask [B,N,C] is 0 on the xyz of the survivors, 1 elsewhere.  As in the
+    reference the `pixel_size` argument is overwritten by random.uniform(0.045, 0.075) unless `angles` [B,3] is given, which
+    pins both random inputs (the rotation angles and the pixel size passed in) for reproducible runs."""
+    import random
+    lib = _lib.load()
+    _lib.require_gpu(X)
+    if angles is None:
+        pixel_size = random.uniform(0.045, 0.075)
+        angles = np.stack([np.random.rand(3) * 2 * np.pi for _ in range(X.shape[0])])
+    B, N, C = X.shape
+    R = np.stack([rotation_matrix_3d(np.asarray(a, dtype=np.float64)) for a in np.asarray(angles)]).reshape(B, 9)
+    Rd = torch.from_numpy(np.ascontiguousarray(R)).to(X.device)
+    xin = X.detach().float().contiguous()
+    Xs, mask = torch.empty_like(xin), torch.empty_like(xin)
+    _lib.check(lib.mlsp_scan_select_f32(xin.data_ptr(), B, N, C, Rd.data_ptr(), int(2 / pixel_size), Xs.data_ptr(), mask.data_ptr(),
+                                        _lib.stream()), "mlsp_scan_select_f32")
+    if X.dtype == torch.float32:
+        X.copy_(Xs)                                   # the reference overwrites its argument too (:61)
+        return X, mask
+    return Xs, mask
 
 
 def chamfer_distance(p1, p2, mask):

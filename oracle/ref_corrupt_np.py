@@ -71,3 +71,34 @@ def mix_shapes(X, index, lam, start_a, start_b, points_perm):
     _, va = fps(X, na, start_a) if na else (None, np.zeros((X.shape[0], X.shape[1], 0), np.float32))
     _, vb = fps(X[index], nb, start_b) if nb else (None, np.zeros((X.shape[0], X.shape[1], 0), np.float32))
     return np.concatenate([va, vb], 2)[:, :, points_perm]
+
+
+def rotation_matrix(angles):
+    """MLSP/mlsp.py:91-112 rotate_point_cloud_3d: R = R1(y) R2(x) R3(z), float64."""
+    c, s_ = np.cos(angles), np.sin(angles)
+    r1 = np.array([[c[0], 0, s_[0]], [0, 1, 0], [-s_[0], 0, c[0]]])
+    r2 = np.array([[1, 0, 0], [0, c[1], -s_[1]], [0, s_[1], c[1]]])
+    r3 = np.array([[c[2], -s_[2], 0], [s_[2], c[2], 0], [0, 0, 1]])
+    return r1 @ r2 @ r3
+
+
+def scan(X, pixel_size, angles):
+    """MLSP/mlsp.py:54-89 scan_input / p_scan with the random draws passed in.  X [B,N,C] -> (scanned copy, mask).
+    The rotation is evaluated as ((p0*R0c + p1*R1c) + p2*R2c) in float64 (the reference calls np.dot, whose BLAS may fuse)."""
+    X = X.astype(np.float32)
+    out, mask = np.zeros_like(X), np.ones_like(X)
+    pixel = int(2 / pixel_size)
+    for b in range(X.shape[0]):
+        pc = X[b].astype(np.float64)
+        R = rotation_matrix(np.asarray(angles[b], dtype=np.float64))
+        rot = (pc[:, 0:1] * R[0:1, :] + pc[:, 1:2] * R[1:2, :]) + pc[:, 2:3] * R[2:3, :]
+        cell = ((rot[:, 2] + 1) / 2 * pixel * pixel + (rot[:, 1] + 1) / 2 * pixel).astype(np.int64)
+        best = {}
+        for i in range(X.shape[1]):
+            c = int(cell[i])
+            if c not in best or rot[i, 0] > rot[best[c], 0]:
+                best[c] = i
+        keep = np.array(sorted(best.values()))
+        mask[b][keep, :3] = 0.0
+        out[b][keep] = X[b][keep]
+    return out, mask

@@ -45,3 +45,9 @@ def test_pcm_oracle_vs_reference():
     g = dict(np.load(os.path.join(GOLD, "pcm_s3_B5_N256.npz")))
     mixed = oc.mix_shapes(g["X"], g["index"], float(g["lam"]), g["start_a"], g["start_b"], g["points_perm"])
     assert np.array_equal(mixed, g["mixed"])
+
+
+def test_scan_oracle_vs_reference():
+    g = dict(np.load(os.path.join(GOLD, "scan_s21_B5_N512.npz")))
+    out, mask = oc.scan(g["X"], float(g["pixel_size"]), g["angles"])
+    assert np.array_equal(mask, g["mask"]) and np.array_equal(out, g["X_out"])

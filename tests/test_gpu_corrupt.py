@@ -67,3 +67,18 @@ def test_pc_utils_fps_vs_oracle(dev):
     idx, vals = pc_utils.farthest_point_sample(None, xyz.to(dev), 77, start=start)
     widx, wvals = oc.fps(xyz.numpy(), 77, start.numpy())
     assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(vals.cpu().numpy(), wvals)
+
+
+def test_scan_input_vs_reference(dev):
+    """mlsp.scan_input with the reference's own random draws (pixel size, rotation angles): identical survivors and mask."""
+    from mlsp_amd import mlsp
+    g = dict(np.load(os.path.join(GOLD, "scan_s21_B5_N512.npz")))
+    X = torch.from_numpy(g["X"]).to(dev)
+    Xs, mask = mlsp.scan_input(X, dev, pixel_size=float(g["pixel_size"]), angles=g["angles"])
+    assert Xs.data_ptr() == X.data_ptr()
+    assert np.array_equal(mask.cpu().numpy(), g["mask"]) and np.array_equal(Xs.cpu().numpy(), g["X_out"])
+    # unseeded: one survivor per occupied cell, everything else zeroed
+    X2 = torch.from_numpy(g["X"]).to(dev)
+    Xs2, m2 = mlsp.scan_input(X2, dev)
+    kept = (m2[:, :, 0] == 0)
+    assert (kept.sum(1) > 100).all() and (Xs2[~kept] == 0).all() and torch.equal(Xs2[kept], torch.from_numpy(g["X"]).to(dev)[kept])

@@ -370,6 +370,19 @@ def corrupt_cases():
         out["mask_g%d" % groups] = npy(mask)
     np.savez_compressed(os.path.join(OUT, "deform_s5_B6_N1024.npz"), **out)
 
+    # scan_input: python `random` draws the pixel size, numpy the three rotation angles of every cloud (replayed from the seeds)
+    import random
+    np.int = int                                                   # the reference still spells np.int (removed in numpy 1.24)
+    Xs = (torch.rand(5, 512, 3, generator=g) * 2 - 1) * 0.55        # inside the unit ball, as the datasets are normalised
+    random.seed(21)
+    np.random.seed(21)
+    px = random.uniform(0.045, 0.075)
+    angs = np.stack([np.random.rand(3) * 2 * np.pi for _ in range(5)])
+    random.seed(21)
+    np.random.seed(21)
+    Xo, mo = rmlsp.scan_input(Xs.clone(), "cpu")
+    np.savez_compressed(os.path.join(OUT, "scan_s21_B5_N512.npz"), X=npy(Xs), pixel_size=np.array(px), angles=angs, X_out=npy(Xo), mask=npy(mo))
+
     # PCM.mix_shapes: record the reference's random draws by wrapping the RNG entry points it calls
     rec = {"randperm": [], "randint": []}
     orig_randperm, orig_randint, orig_beta = torch.randperm, torch.randint, np.random.beta
