@@ -1254,7 +1254,7 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 #define RV_SPLIT 4
 __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict__ idx, int N, int k,
                                                            int* __restrict__ rev_off, int* __restrict__ rev_ent,
-                                                           int B, int ent_in_lds, int S) {
+                                                           int B, int ent_in_lds, int S, int rank_sort) {
     extern __shared__ int ism[];
     int* cnt = ism;            // [N]
     int* off = ism + N;        // [N+1]
@@ -1307,8 +1307,26 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
         }
     }
     __syncthreads();
+    if (ent_in_lds && rank_sort) {
+        // order every list by (i, slot): one thread per ENTRY ranks it inside its list.  In-degrees can be heavily skewed
+        // (ball-query groups are padded with copies of their first hit: a few points collect hundreds of edges), where a
+        // per-list insertion sort leaves one lane grinding through O(n^2) moves.
+        for (int i = tid; i < sn; i += nt) {
+            const int v = ent[i], target = s0 + i;
+            int lo = d0, hi = d1;                       // list j with off[j] <= target < off[j+1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (off[mid] <= target) lo = mid; else hi = mid;
+            }
+            const int e0 = off[lo] - s0, e1 = off[lo + 1] - s0;
+            int rank = 0;
+            for (int e = e0; e < e1; ++e) rank += (ent[e] < v);
+            rev_ent[gbase + s0 + e0 + rank] = v;
+        }
+        return;
+    }
     if (!ent_in_lds) __threadfence_block();
-    // per-destination insertion sort (lists are ~k long)
+    // per-destination insertion sort (kNN lists are ~k long: cheaper than ranking; also the in-place global-memory fallback)
     for (int j = d0 + tid; j < d1; j += nt) {
         int* a = ent + off[j] - s0;
         int n = off[j + 1] - off[j];
@@ -1324,7 +1342,7 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     for (int i = tid; i < sn; i += nt) rev_ent[gbase + s0 + i] = ent[i];
 }
 
-int launch_group_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent) {
+static int launch_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent, int rank_sort) {
     if (!idx || !rev_off || !rev_ent || B <= 0 || N <= 0 || S <= 0 || k <= 0 || k > 256 || N > (1 << 22) || S > (1 << 22)) return MLSP_ERR_ARG;
     size_t lds = (size_t)(2 * N + 1) * sizeof(int);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
@@ -1334,10 +1352,14 @@ int launch_group_reverse(hipStream_t st, const int* idx, int B, int S, int N, in
         hipError_t e = hipFuncSetAttribute((const void*)knn_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, ent_in_lds, S);
+    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, ent_in_lds, S, rank_sort);
     return mlsp_launch_status();
 }
 
+// ball-query groups (padded with copies of the first hit): skewed in-degrees -> rank-based ordering
+int launch_group_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent) {
+    return launch_reverse(st, idx, B, S, N, k, rev_off, rev_ent, 1);
+}
 int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent) {
-    return launch_group_reverse(st, idx, B, N, N, k, rev_off, rev_ent);
+    return launch_reverse(st, idx, B, N, N, k, rev_off, rev_ent, 0);
 }

@@ -126,7 +126,18 @@ __global__ __launch_bounds__(256) void sa_group_bwd_kernel(const float* __restri
     for (int c0 = 0; c0 < D; c0 += 64) {
         const int c = c0 + lane;
         float acc = 0.f;
-        for (int e = e0; e < e1; ++e) {
+        int e = e0;
+        for (; e + 4 <= e1; e += 4) {                    // four rows in flight (padded groups make some lists very long)
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ent = rev_ent[e + u];
+                const size_t row = ((size_t)b * S + (ent >> 8)) * ns + (ent & 255);
+                t[u] = c < D ? dG[row * C + 3 + c] : 0.f;
+            }
+            acc += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        for (; e < e1; ++e) {
             const int ent = rev_ent[e];
             const size_t row = ((size_t)b * S + (ent >> 8)) * ns + (ent & 255);
             if (c < D) acc += dG[row * C + 3 + c];
