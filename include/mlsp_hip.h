@@ -197,6 +197,11 @@ int mlsp_deform_regions_f32(float* X, int B, int C, int N, const int32_t* region
  * mask [B][N][C] is 0 on their first three channels and 1 elsewhere. */
 int mlsp_scan_select_f32(const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask, mlsp_stream_t stream);
 
+/* Operand precision of the GEMM family (process-wide switch, default 0).  0: fp32 MFMA, exact fp32 products -- the parity
+ * contract of the fp32 configs.  1: operands rounded to bf16, fp32 accumulation (v_mfma_f32_32x32x16_bf16) for the launches on
+ * the fast path (interior tiles, 16-byte aligned operands); BASELINE.json configs[4].  The kNN distances stay fp32 always. */
+int mlsp_set_gemm_precision(int mode);
+
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP
  * events on its launch stream.  mlsp_profile_end synchronises those events and fills
  * out[4] = {total ms in the kernel, launches, sum of algorithmic 2*M*N*K, 0}.  Not for production steps. */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mlsp_region_assign_f32": [_P, _I, _I, _I, _P, _I, _F, _P, _P],
     "mlsp_deform_regions_f32": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P],
     "mlsp_scan_select_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _P],
+    "mlsp_set_gemm_precision": [_I],
     "mlsp_profile_begin": [],
     "mlsp_profile_end": [_P],
     "mlsp_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _SZ, _P],

@@ -106,6 +106,98 @@ __device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, 
     }
 }
 
+// ---- epilogue shared by the fp32 and the bf16-operand kernels --------------------------------------------------------
+// acc: this wave's WM x 2 MFMA tiles of the block tile at (m0, n0); smem: the operand tiles, dead by now (scratch).
+template <int WM, bool FAST>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* smem, int tm, int m0, int n0, int split,
+                                              int tid, int l31, int h, int wm, int wn) {
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
+    const bool epi = (p.nsplit == 1);
+    float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int col = n0 + wn * 64 + j * 32 + l31;
+            if (!FAST && col >= p.N) continue;
+            float bv = (epi && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (FAST || row < p.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
+#ifdef GP_NOSTORE
+                    if (p.C && v == 12345.678f) Cout[(size_t)row * p.ldc + col] = v;
+#else
+                    if (p.C) Cout[(size_t)row * p.ldc + col] = v;
+#endif
+                    cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
+                    acc[i][j][r] = v;
+                }
+            }
+        }
+    if (p.sel_gamma) {       // fused column extreme (max over points follows this layer): per panel, per column
+        float bv[2]; int br[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            const bool use_max = col < p.N ? p.sel_gamma[col] >= 0.f : true;
+            float best = use_max ? -INFINITY : INFINITY;
+            int brow = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = acc[i][j][r];
+                    const bool take = row < p.M && (use_max ? (v > best) : (v < best));
+                    best = take ? v : best; brow = take ? row : brow;
+                }
+            const float ob = __shfl_xor(best, 32, 64);
+            const int orow = __shfl_xor(brow, 32, 64);
+            const bool better = use_max ? (ob > best) : (ob < best);
+            if (better || (ob == best && orow < brow)) { best = ob; brow = orow; }
+            bv[j] = best; br[j] = brow;
+        }
+        __syncthreads();                                  // smem is reused below (and by the statistics block)
+        float* sv = smem + 1024;                          // [wm][128] values, then rows
+        int* sr = (int*)(smem + 1024 + 256);
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { sv[wm * 128 + wn * 64 + j * 32 + l31] = bv[j]; sr[wm * 128 + wn * 64 + j * 32 + l31] = br[j]; }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const bool use_max = p.sel_gamma[n0 + tid] >= 0.f;
+            float a = sv[tid], b2 = sv[128 + tid];
+            int ra = sr[tid], rb = sr[128 + tid];
+            const bool better = use_max ? (b2 > a) : (b2 < a);
+            if (better || (b2 == a && rb < ra)) { a = b2; ra = rb; }
+            p.sel_val[(size_t)tm * p.N + n0 + tid] = a;
+            p.sel_row[(size_t)tm * p.N + n0 + tid] = ra;
+        }
+    }
+    if (p.stat_part) {       // fused BatchNorm statistics: one fp64 partial per 128-row panel and column
+        float* red = smem;   // [wm][sum|sq][128]  (the operand tiles are dead: the k-loop ended on a barrier)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cs[j] += __shfl_xor(cs[j], 32, 64);
+            cq[j] += __shfl_xor(cq[j], 32, 64);
+            if (h == 0) {
+                red[(wm * 2 + 0) * 128 + wn * 64 + j * 32 + l31] = cs[j];
+                red[(wm * 2 + 1) * 128 + wn * 64 + j * 32 + l31] = cq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            p.stat_part[((size_t)tm * 2 + 0) * p.N + n0 + tid] = (double)red[0 * 128 + tid] + (double)red[2 * 128 + tid];
+            p.stat_part[((size_t)tm * 2 + 1) * p.N + n0 + tid] = (double)red[1 * 128 + tid] + (double)red[3 * 128 + tid];
+        }
+    }
+}
+
 // WM = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile; 1 -> 64x128 (twice the workgroups, for launches whose
 // 128-row grid is too small to keep ~3 workgroups per CU in flight and out of phase)
 template <bool TA, bool TB, int WM, bool FAST>
@@ -254,91 +346,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 #ifdef GP_TIMELINE
     const long long tl2 = wall_clock64();
 #endif
-    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
-    const bool epi = (p.nsplit == 1);
-    float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int col = n0 + wn * 64 + j * 32 + l31;
-            if (!FAST && col >= p.N) continue;
-            float bv = (epi && p.bias) ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (FAST || row < p.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
-#ifdef GP_NOSTORE
-                    if (p.C && v == 12345.678f) Cout[(size_t)row * p.ldc + col] = v;
-#else
-                    if (p.C) Cout[(size_t)row * p.ldc + col] = v;
-#endif
-                    cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
-                    acc[i][j][r] = v;
-                }
-            }
-        }
-    if (p.sel_gamma) {       // fused column extreme (max over points follows this layer): per panel, per column
-        float bv[2]; int br[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l31;
-            const bool use_max = col < p.N ? p.sel_gamma[col] >= 0.f : true;
-            float best = use_max ? -INFINITY : INFINITY;
-            int brow = 0x7fffffff;
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float v = acc[i][j][r];
-                    const bool take = row < p.M && (use_max ? (v > best) : (v < best));
-                    best = take ? v : best; brow = take ? row : brow;
-                }
-            const float ob = __shfl_xor(best, 32, 64);
-            const int orow = __shfl_xor(brow, 32, 64);
-            const bool better = use_max ? (ob > best) : (ob < best);
-            if (better || (ob == best && orow < brow)) { best = ob; brow = orow; }
-            bv[j] = best; br[j] = brow;
-        }
-        __syncthreads();                                  // smem is reused below (and by the statistics block)
-        float* sv = smem + 1024;                          // [wm][128] values, then rows
-        int* sr = (int*)(smem + 1024 + 256);
-        if (h == 0) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { sv[wm * 128 + wn * 64 + j * 32 + l31] = bv[j]; sr[wm * 128 + wn * 64 + j * 32 + l31] = br[j]; }
-        }
-        __syncthreads();
-        if (tid < 128 && n0 + tid < p.N) {
-            const bool use_max = p.sel_gamma[n0 + tid] >= 0.f;
-            float a = sv[tid], b2 = sv[128 + tid];
-            int ra = sr[tid], rb = sr[128 + tid];
-            const bool better = use_max ? (b2 > a) : (b2 < a);
-            if (better || (b2 == a && rb < ra)) { a = b2; ra = rb; }
-            p.sel_val[(size_t)tm * p.N + n0 + tid] = a;
-            p.sel_row[(size_t)tm * p.N + n0 + tid] = ra;
-        }
-    }
-    if (p.stat_part) {       // fused BatchNorm statistics: one fp64 partial per 128-row panel and column
-        float* red = smem;   // [wm][sum|sq][128]  (the operand tiles are dead: the k-loop ended on a barrier)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            cs[j] += __shfl_xor(cs[j], 32, 64);
-            cq[j] += __shfl_xor(cq[j], 32, 64);
-            if (h == 0) {
-                red[(wm * 2 + 0) * 128 + wn * 64 + j * 32 + l31] = cs[j];
-                red[(wm * 2 + 1) * 128 + wn * 64 + j * 32 + l31] = cq[j];
-            }
-        }
-        __syncthreads();
-        if (tid < 128 && n0 + tid < p.N) {
-            p.stat_part[((size_t)tm * 2 + 0) * p.N + n0 + tid] = (double)red[0 * 128 + tid] + (double)red[2 * 128 + tid];
-            p.stat_part[((size_t)tm * 2 + 1) * p.N + n0 + tid] = (double)red[1 * 128 + tid] + (double)red[3 * 128 + tid];
-        }
-    }
+    gemm_epilogue<WM, FAST>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 #ifdef GP_TIMELINE
     __syncthreads();
     if (tid == 0) {                                    // 100 MHz ticks: start, first tile staged, loop end, epilogue end
@@ -347,6 +355,109 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
         dbg[0] = (float)(tl0 & 0xffffff); dbg[1] = (float)(tl1 - tl0); dbg[2] = (float)(tl2 - tl1); dbg[3] = (float)(tl3 - tl2);
     }
 #endif
+}
+
+// ---- bf16-operand variant (opt-in, mlsp_set_gemm_precision(1); BASELINE.json configs[4]) -------------------------------
+// Same tiling, epilogues and split-K protocol as gemm_f32_kernel<..., FAST>, but the fp32 operands are rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) on their way into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 8x fewer MFMA
+// issues per K-tile and half the LDS traffic.  Both LDS images are row-major [row][32 + 8] bf16 (80-byte pitch: every
+// fragment is one 16-byte read); k-major global sources are transposed on the LDS write (2-byte stores).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define BROW 40    // bf16 elements per LDS row
+
+template <bool SRC_KMAJOR, int NP>
+__device__ __forceinline__ void r2s_bf16(const f32x4 (&r)[4], __bf16* __restrict__ s, int tid) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (!SRC_KMAJOR) {
+            const int row = (tid >> 3) + 32 * p, k = (tid & 7) * 4;
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (__bf16)r[p][e];
+            *(bf16x4*)(s + row * BROW + k) = v;
+        } else {
+            const int k = NP == 4 ? (tid >> 5) + 8 * p : (tid >> 4) + 16 * p;
+            const int row = (NP == 4 ? (tid & 31) : (tid & 15)) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[(row + e) * BROW + k] = (__bf16)r[p][e];
+        }
+    }
+}
+
+template <bool TA, bool TB, int WM>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr int BMT = 64 * WM, NPA = 2 * WM;
+    __shared__ __attribute__((aligned(16))) float smem[BM * SROW * 2];      // same footprint as the fp32 kernel (epilogue scratch)
+    __bf16* As = (__bf16*)smem;
+    __bf16* Bs = As + BM * BROW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = blockIdx.x;
+    int tm, tn;
+    if (p.xcd_map) {
+        const int xcd = bid & 7, q = bid >> 3;
+        tn = q % p.ntn;
+        tm = (q / p.ntn) * 8 + xcd;
+        if (tm >= p.ntm) return;
+    } else {
+        tn = bid % p.ntn;
+        tm = bid / p.ntn;
+    }
+    const int split = blockIdx.y;
+    const int m0 = tm * BMT, n0 = tn * BN;
+    const int kbeg = split * p.ksplit;
+    const int kend = min(p.K, kbeg + p.ksplit);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[4], rb[4];
+    const float* pa = TA ? p.A + (size_t)(kbeg + (NPA == 4 ? (tid >> 5) : (tid >> 4))) * p.lda + m0 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 4
+                         : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
+    const float* pb = !TB ? p.B + (size_t)(kbeg + (tid >> 5)) * p.ldb + n0 + (tid & 31) * 4
+                          : p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + kbeg + (tid & 7) * 4;
+    g2r_fast<TA, NPA>(ra, pa, p.lda);
+    g2r_fast<!TB, 4>(rb, pb, p.ldb);
+    const int arow = wm * (32 * WM) + l31, bcol = wn * 64 + l31;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        r2s_bf16<TA, NPA>(ra, As, tid);
+        r2s_bf16<!TB, 4>(rb, Bs, tid);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            pa += TA ? (size_t)BK * p.lda : BK;
+            pb += !TB ? (size_t)BK * p.ldb : BK;
+            g2r_fast<TA, NPA>(ra, pa, p.lda);
+            g2r_fast<!TB, 4>(rb, pb, p.ldb);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 16; ++s2) {                      // MFMA step: k = 16*s2 + 8*h .. +7
+            const int kk = 16 * s2 + 8 * h;
+            const bf16x8 a0 = *(const bf16x8*)(As + arow * BROW + kk);
+            const bf16x8 b0 = *(const bf16x8*)(Bs + bcol * BROW + kk), b1 = *(const bf16x8*)(Bs + (bcol + 32) * BROW + kk);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            if (WM == 2) {
+                const bf16x8 a1 = *(const bf16x8*)(As + (arow + 32) * BROW + kk);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<WM, true>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
+}
+
+static int g_gemm_precision = 0;     // 0: fp32 MFMA (exact fp32 products); 1: bf16 operands, fp32 accumulation
+extern "C" int mlsp_set_gemm_precision(int mode) {
+    if (mode != 0 && mode != 1) return MLSP_ERR_ARG;
+    g_gemm_precision = mode;
+    return MLSP_OK;
 }
 
 // sum the split-K slabs (fixed order -> bitwise reproducible) and apply the epilogue
@@ -572,7 +683,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
     const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
-#define GEMM_GO(TA_, TB_, WM_) do { if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
+#define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
+                                     else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
     if (bm == 128) {
         if (!ta && tb) GEMM_GO(false, true, 2);

@@ -29,6 +29,33 @@ def _rows(t):
     return t
 
 
+class gemm_precision:
+    """Context manager / switch for the operand precision of the GEMM family (include/mlsp_hip.h mlsp_set_gemm_precision):
+    "fp32" (default: exact fp32 products, the parity contract of the fp32 configs) or "bf16" (operands rounded to bf16, fp32
+    accumulation; BASELINE.json configs[4]).  kNN distances, BatchNorm statistics, reductions and losses stay fp32."""
+    _MODES = {"fp32": 0, "bf16": 1}
+    current = "fp32"
+
+    def __init__(self, mode):
+        if mode not in self._MODES:
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.mode, self.prev = mode, None
+
+    @classmethod
+    def set(cls, mode):
+        _lib.check(_lib.load().mlsp_set_gemm_precision(cls._MODES[mode]), "mlsp_set_gemm_precision")
+        cls.current = mode
+
+    def __enter__(self):
+        self.prev = gemm_precision.current
+        gemm_precision.set(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        gemm_precision.set(self.prev)
+        return False
+
+
 class KnnGraph:
     """kNN indices of one graph stage plus the reverse index needed by the backward passes."""
     __slots__ = ("idx", "rev_off", "rev_ent", "B", "N", "k")

@@ -117,6 +117,31 @@ def test_gemm(dev, ta, tb, M, N, K):
     assert err < 2e-6 * K ** 0.5 * 4 + 1e-6, err
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 1024, 256, 512), (0, 0, 512, 384, 256), (1, 0, 256, 128, 8192), (0, 1, 4096, 128, 64),
+                                         (1, 1, 256, 256, 128), (0, 1, 300, 200, 64)])
+def test_gemm_bf16_operand_mode(dev, ta, tb, M, N, K):
+    """mlsp_set_gemm_precision(1): operands rounded to bf16 (RNE), fp32 accumulation -- compared with that exact model in
+    float64; shapes off the fast path (last case) keep using the fp32 kernel.  The switch is restored afterwards."""
+    Fh = _fh()
+    A = _rand((K, M) if ta else (M, K), 11)
+    B = _rand((N, K) if tb else (K, N), 12)
+    opA, opB = (A.t() if ta else A), (B.t() if tb else B)
+    with Fh.gemm_precision("bf16"):
+        got = Fh.gemm(A.to(dev), B.to(dev), ta=bool(ta), tb=bool(tb)).cpu().double()
+    assert Fh.gemm_precision.current == "fp32"
+    fast = M % 64 == 0 and N % 128 == 0 and K % 32 == 0
+    if fast:
+        want = opA.bfloat16().double() @ opB.bfloat16().double()
+        assert (got - want).abs().max().item() < 3e-6 * K ** 0.5 * 4 + 1e-6          # only the fp32 accumulation differs
+        exact = opA.double() @ opB.double()
+        assert (got - exact).abs().max().item() > 1e-5                                # and it really ran in bf16
+    else:
+        want = opA.double() @ opB.double()
+        assert (got - want).abs().max().item() < 2e-6 * K ** 0.5 * 4 + 1e-6
+    again = Fh.gemm(A.to(dev), B.to(dev), ta=bool(ta), tb=bool(tb)).cpu().double()
+    assert (again - opA.double() @ opB.double()).abs().max().item() < 2e-6 * K ** 0.5 * 4 + 1e-6
+
+
 def test_gemm_matches_fma_chain_bitwise(dev):
     """The f32 MFMA is a fmaf chain in issue order (what makes the MFMA kNN canonical).  The GEMM kernel feeds K in
     groups of four as (4m, 4m+2, 4m+1, 4m+3) -- see gemm.hip -- so emulate exactly that chain and compare bitwise."""
