@@ -36,6 +36,9 @@ int launch_region_assign(hipStream_t st, const float* X, int B, int C, int N, co
 int launch_scan_select(hipStream_t st, const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask);
 int launch_deform_regions(hipStream_t st, float* X, int B, int C, int N, const int* regions, const int* order, int nreg, const float* lookup,
                           const float* noise, int min_pts, int groups, float* mask);
+int launch_bn_act_bwd_partials_vec(hipStream_t st, const float* dZ, const float* Y, int M, int C, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, int act, float slope, double* part);
+int bn_vec_parts(int M);
 int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double* part);
 int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
@@ -344,7 +347,9 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
     float* dhp = w.take<float>(E * C1);
     float* dW2part = w.take<float>((size_t)nb * C2 * C1);
     int npr = (P + 511) / 512;
-    double* part = w.take<double>((size_t)(npr > nb ? npr : nb) * 2 * C2);
+    const int nprv = bn_vec_parts(P);                                  // rows of the vectorised BN2 partial pass
+    const int nrows_part = (npr > nb ? npr : nb) > nprv ? (npr > nb ? npr : nb) : nprv;
+    double* part = w.take<double>((size_t)nrows_part * 2 * C2);
     float* mean_dz = w.take<float>(C2);
     float* mean_dzy = w.take<float>(C2);
     float* m1 = w.take<float>(C1);
@@ -354,7 +359,15 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
     size_t sf = sf1 > sf2 ? sf1 : sf2;
     float* slab = sf ? w.take<float>(sf) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
-    CHECK(launch_tnet_bwd_reduce(st, dOut, out, zsel, bn2_save, P, slope, part));
+    // BN2 backward sums of dz = dOut * act'(out): the same computation as the first pass of the generic BN backward (out > 0 <=>
+    // scale2*zsel + shift2 > 0), so the vectorised column-stationary kernel is used when the operands allow it
+    {
+        const int rc = launch_bn_act_bwd_partials_vec(st, dOut, zsel, P, C2, bn2_save, bn2_save + C2, bn2_save + 2 * C2, bn2_save + 3 * C2,
+                                                      2, slope, part);
+        if (rc == MLSP_OK) npr = nprv;
+        else if (rc != MLSP_ERR_UNSUPPORTED) return rc;
+        else CHECK(launch_tnet_bwd_reduce(st, dOut, out, zsel, bn2_save, P, slope, part));
+    }
     CHECK(launch_bn_bwd_finalize(st, part, npr, (double)E, C2, dgamma2, dbeta2, mean_dz, mean_dzy));
     CHECK(launch_tnet_bwd_g(st, dOut, out, bn2_save, training ? mean_dz : nullptr, mean_dzy, P, slope, g, coef));
     CHECK(launch_tnet_edge_bwd(st, uv, idx, bn1_save, W2, bn2_save, g, argsel, coef, P, N, k, slope, dhp, dW2part, part));

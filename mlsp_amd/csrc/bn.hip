@@ -554,6 +554,17 @@ int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, fl
     return mlsp_launch_status();
 }
 
+// column partial sums of dz' = dZ * act'(Y*scale + shift) and dz' * yhat only (the first pass of launch_bn_act_bwd), vectorised form:
+// writes bn_vec_parts(M) rows of [2][C] doubles.  Requires C % 4 == 0, 256 % (C/4) == 0 and 16-byte aligned operands.
+int launch_bn_act_bwd_partials_vec(hipStream_t st, const float* dZ, const float* Y, int M, int C, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, int act, float slope, double* part) {
+    if (!(vec_ok(C, dZ, Y) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)))
+        return MLSP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel, dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, M, C, scale, shift, mean, invstd, act,
+                       slope, 0u, 1.f, (uint64_t)0, part);
+    return mlsp_launch_status();
+}
+
 int launch_colmax_fwd(hipStream_t st, const float* Z, int B, int N, int C, float* out, int* arg) {
     hipLaunchKernelGGL(colmax_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, Z, N, C, out, arg);
     return mlsp_launch_status();
