@@ -33,7 +33,6 @@ class FlatGradSync:
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self._use_avg = None
         self.views = []
         off = 0
         for p in self.params:
@@ -61,15 +60,6 @@ class FlatGradSync:
         ws = self.world_size
         if ws > 1:
             self.pack()
-            if self._use_avg is None:
-                self._use_avg = dist.get_backend(self.group) == "nccl"
-            if self._use_avg:
-                try:
-                    # RCCL averages inside the collective: no separate 18 MB divide pass
-                    dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
-                    return self.flat
-                except (RuntimeError, ValueError):
-                    self._use_avg = False                 # backend without AVG: sum, then divide
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(ws)
         return self.flat
