@@ -18,7 +18,7 @@ class FlatGradSync:
         sync = FlatGradSync(model)            # after model.to(device)
         opt = sync.wrap(torch.optim.Adam(model.parameters(), ...))
         ...  loss.backward() (any number of times) ...
-        opt.step()                            # flatten -> ONE all-reduce(sum) -> /world_size -> inner optimizer step
+        opt.step()                            # step pre-hook: flatten -> ONE all-reduce(sum) -> /world_size; then the step
         opt.zero_grad()                       # grads -> None (autograd then assigns instead of accumulating)
 
     Gradients are NOT pre-homed in the bucket during backward: autograd would then issue one `grad += new`
@@ -44,16 +44,23 @@ class FlatGradSync:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def pack(self):
-        """Copy the present gradients into the bucket (absent ones count as zero) and alias .grad to the bucket."""
-        present = [(v, p) for v, p in zip(self.views, self.params) if p.grad is not None]
-        if len(present) != len(self.params):
-            self.flat.zero_()
-        src = [p.grad for _, p in present if p.grad.data_ptr() != _.data_ptr()]
-        dst = [v for v, p in present if p.grad.data_ptr() != v.data_ptr()]
+        """Copy the present gradients into the bucket (absent ones count as zero) and alias .grad to the bucket.
+        Idempotent: a gradient that already lives in its bucket view is left alone, and only the views of ABSENT
+        parameters are zeroed (a head that did not run this step, e.g. DGCNN.Rec_scan in the default modes)."""
+        src, dst, absent = [], [], []
+        for v, p in zip(self.views, self.params):
+            if p.grad is None:
+                absent.append(v)
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if absent:
+            torch._foreach_zero_(absent)
         if src:
             torch._foreach_copy_(dst, src)
-        for v, p in present:
-            p.grad = v
+        for v, p in zip(self.views, self.params):
+            if p.grad is not None:
+                p.grad = v
         return self.flat
 
     def allreduce(self):
@@ -69,21 +76,11 @@ class FlatGradSync:
             p.grad = None
 
     def wrap(self, optimizer):
-        return _SyncedOptimizer(optimizer, self)
-
-
-class _SyncedOptimizer:
-    """Optimizer facade: step() = one flat all-reduce + inner step; zero_grad() drops the gradients."""
-
-    def __init__(self, inner, sync):
-        self.inner, self.sync = inner, sync
-
-    def step(self, *a, **kw):
-        self.sync.allreduce()
-        return self.inner.step(*a, **kw)
-
-    def zero_grad(self, set_to_none=True):
-        self.sync.zero_grad()
-
-    def __getattr__(self, name):
-        return getattr(self.inner, name)
+        """Install the exchange on `optimizer` itself (a step pre-hook) and return it: the object stays a real
+        torch.optim.Optimizer, so `CosineAnnealingLR(opt, ...)` (PointDA/trainer.py:260), `opt.state_dict()` and
+        `opt.param_groups` keep working.  `opt.zero_grad()` (set_to_none=True, torch's default) drops the bucket views
+        again so that autograd assigns fresh gradients instead of accumulating into the bucket."""
+        if not getattr(optimizer, "_mlsp_flat_sync", None):
+            optimizer.register_step_pre_hook(lambda *_a, **_k: (self.allreduce(), None)[1])
+            optimizer._mlsp_flat_sync = self
+        return optimizer

@@ -16,9 +16,18 @@ ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 _seed_counter = itertools.count(1)
 
 
+def _stream_id():
+    """What distinguishes this process' dropout stream from its peers': the data-parallel rank (the nn.DataParallel
+    replicas this replaces drew independent masks) -- ranks are seeded identically (bench.py), so without it
+    every rank would drop the same elements."""
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def _next_seed():
-    # counter-based dropout stream: (torch seed, call counter) -> 64-bit key hashed per element in-kernel
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    # counter-based dropout stream: (torch seed, rank, call counter) -> 64-bit key hashed per element in-kernel
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03
+            + _stream_id() * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
 
 
 def _rows(t):

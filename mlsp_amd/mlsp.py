@@ -27,8 +27,12 @@ def deform_input(X, lookup, DefRec_dist='volume_based_voxels', device='cuda:0', 
         raise NotImplementedError("deform_input on MI355X implements DefRec_dist='volume_based_voxels' (the trainer's default)")
     lib = _lib.load()
     _lib.require_gpu(X)
-    if not X.is_contiguous():
-        raise ValueError("deform_input updates X in place: pass a contiguous [B,C,N] tensor")
+    # every call site of the trainer passes `data.permute(0, 2, 1)` of a [B,N,3] loader tensor (PointDA/trainer.py:381-387,
+    # 428-431, 538-541): a non-contiguous view.  The kernels work on a dense [B,C,N] copy; the in-place contract of the
+    # reference (it writes into X and returns it) is kept by copying the result back through the view.
+    X_arg = X
+    if not X.is_contiguous() or X.dtype != torch.float32:
+        X = X.float().contiguous()
     B, C, N = X.shape
     n = pc_utils.NREGIONS
     regions = pc_utils.assign_region_to_point(X, device).to(torch.int32)
@@ -42,7 +46,10 @@ def deform_input(X, lookup, DefRec_dist='volume_based_voxels', device='cuda:0', 
     mask = torch.empty_like(X)
     _lib.check(lib.mlsp_deform_regions_f32(X.data_ptr(), B, C, N, regions.data_ptr(), order.data_ptr(), n ** 3, look.data_ptr(),
                                            scaled.data_ptr(), 40, groups, mask.data_ptr(), _lib.stream()), "mlsp_deform_regions_f32")
-    return X, mask
+    if X is not X_arg:
+        X_arg.copy_(X)
+        mask = mask.to(X_arg.dtype)
+    return X_arg, mask
 
 
 def rotation_matrix_3d(angles):

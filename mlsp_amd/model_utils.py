@@ -39,40 +39,49 @@ def get_graph_feature(x, args, k=20, idx=None):
     return F.view(B, N, k, 2 * C).permute(0, 3, 1, 2)
 
 
-_pending_nbt = []
+import functools
+import threading
+
+
+class _FwdState(threading.local):
+    """Per-THREAD bookkeeping of the forward in flight: nn.DataParallel (PointDA/trainer.py:251-252) runs one replica per
+    Python thread, so the queue of num_batches_tracked counters and the nesting depth must not be shared between threads."""
+
+    def __init__(self):
+        self.pending_nbt = []
+        self.depth = 0
+
+
+_state = _FwdState()
 
 
 def _bn_buffers(bn, training):
     """Running-stat buffers of a BatchNorm holder; in training mode its num_batches_tracked is queued for ONE
     multi-tensor increment per forward (flush_bn_counters) instead of one tiny kernel per layer."""
     if training:
-        _pending_nbt.append(bn.num_batches_tracked)
+        _state.pending_nbt.append(bn.num_batches_tracked)
     return bn.running_mean, bn.running_var
 
 
 def flush_bn_counters():
-    if _pending_nbt:
-        torch._foreach_add_(_pending_nbt, 1)
-        _pending_nbt.clear()
-
-
-_fwd_depth = 0
+    pend = _state.pending_nbt
+    if pend:
+        torch._foreach_add_(pend, 1)
+        pend.clear()
 
 
 def flushing_forward(fn):
-    """Decorator for the public forward() of every module here: the outermost call flushes the queued
+    """Decorator for the public forward() of every module here: the outermost call (of this thread) flushes the queued
     num_batches_tracked increments on exit, so state_dict() is exact after any forward."""
-    import functools
 
     @functools.wraps(fn)
     def wrapper(self, *a, **k):
-        global _fwd_depth
-        _fwd_depth += 1
+        _state.depth += 1
         try:
             return fn(self, *a, **k)
         finally:
-            _fwd_depth -= 1
-            if _fwd_depth == 0:
+            _state.depth -= 1
+            if _state.depth == 0:
                 flush_bn_counters()
     return wrapper
 

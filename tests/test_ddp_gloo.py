@@ -23,21 +23,28 @@ def _worker(rank, world, port, q):
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
     model[3].bias.requires_grad = False                       # a frozen parameter stays out of the bucket
+    model.add_module("unused", torch.nn.Linear(4, 4))         # a head that never runs: its grads stay None (DGCNN.Rec_scan)
     sync = FlatGradSync(model)
     opt = sync.wrap(torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.1))
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 10)      # PointDA/trainer.py:260 on the wrapped optimizer
     assert sync.numel == sum(p.numel() for p in model.parameters() if p.requires_grad)
+    model = model[:4]                                         # forward without the unused head
     g = torch.Generator().manual_seed(100 + rank)             # different shard per rank
     x, y = torch.randn(12, 8, generator=g), torch.randn(12, 4, generator=g)
     opt.zero_grad()
     ((model(x) - y) ** 2).mean().backward()
     ((model(x) - y) ** 2).mean().backward()                   # two backwards per step accumulate, ONE all-reduce
     local = sync.pack().clone()
+    assert torch.equal(sync.pack(), local) and local.abs().sum() > 0     # a second pack() must not wipe the aliased gradients
     opt.step()
+    sched.step()
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     want = sum(gathered) / world
     ok_avg = torch.allclose(sync.flat, want, atol=1e-6)
-    ok_views = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    ok_views = all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    ok_views = ok_views and sum(p.grad is None for p in sync.params) == 2
     w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     ws = [torch.zeros_like(w) for _ in range(world)]
     dist.all_gather(ws, w)
@@ -77,3 +84,24 @@ def test_single_process_is_identity():
     m.zero_grad(set_to_none=True)                             # a trainer doing this must not break the bucket
     m(torch.ones(4, 3)).sum().backward()
     assert torch.equal(s.pack(), flat)
+
+
+def test_pack_with_absent_gradients_is_idempotent():
+    """a parameter without a gradient must not make a second pack() zero the aliased gradients."""
+    from mlsp_amd.ddp import FlatGradSync
+    m = torch.nn.ModuleDict({"a": torch.nn.Linear(3, 2), "unused": torch.nn.Linear(2, 2)})
+    s = FlatGradSync(m)
+    opt = s.wrap(torch.optim.Adam(m.parameters(), lr=1e-2))
+    assert isinstance(opt, torch.optim.Optimizer) and s.wrap(opt) is opt
+    torch.optim.lr_scheduler.CosineAnnealingLR(opt, 5)
+    m["a"](torch.ones(4, 3)).sum().backward()
+    first = s.pack().clone()
+    assert first.abs().sum() > 0
+    assert torch.equal(s.pack(), first) and torch.equal(s.pack(), first)
+    assert all(p.grad is None for p in m["unused"].parameters())
+    s.flat[-1] = 7.0                                          # stale bytes in an absent view are cleared, present ones kept
+    assert torch.equal(s.pack(), first)
+    opt.step()
+    opt.step()
+    opt.zero_grad()
+    assert all(p.grad is None for p in m.parameters())

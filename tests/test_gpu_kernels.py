@@ -37,7 +37,12 @@ def _rand(shape, seed, scale=1.0):
                                      (3, 20, 3, 20), (2, 33, 64, 20), (2, 100, 5, 7), (1, 300, 3, 40), (2, 70, 16, 1),
                                      # v5 (two waves per query group) paths: LDS-resident / streamed, vector / scalar loads
                                      (2, 384, 16, 20), (2, 256, 5, 32), (1, 512, 100, 20), (1, 2048, 3, 20),
-                                     (1, 4096, 16, 8), (2, 640, 64, 32), (8, 128, 64, 20), (9, 256, 128, 20)])
+                                     (1, 4096, 16, 8), (2, 640, 64, 32), (8, 128, 64, 20), (9, 256, 128, 20),
+                                     # the benchmarked shapes themselves (BASELINE.json configs[1]: B = 32, N = 1024; XCD-mapped 8-wave path)
+                                     (32, 1024, 3, 20), (32, 1024, 64, 20), (32, 1024, 128, 20), (32, 2048, 64, 20),
+                                     # k > 32 (configs[4]: k = 40): the two-pass select with 128 chunk maxima per query
+                                     (2, 2048, 3, 40), (8, 2048, 64, 40), (3, 1024, 128, 40), (2, 512, 64, 33), (1, 256, 16, 48),
+                                     (1, 128, 64, 64), (2, 2048, 64, 64)])
 def test_knn_bit_exact_vs_oracle(dev, B, N, C, k):
     Fh = _fh()
     xp = _rand((B * N, C), 100 + N + C)

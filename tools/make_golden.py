@@ -42,7 +42,11 @@ def knn_case(ref_mu, seed, B, C, N, k=20):
     return dict(x=npy(x), idx=npy(idx).astype(np.int32), gap_k=npy(gap_k), gap_in=npy(gap_in))
 
 
-def model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep_feats):
+def model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep_feats, dtype=torch.float32):
+    """`dtype=torch.float64` evaluates the SAME reference modules in double precision (parameters and inputs are the fp32
+    values, cast): the rounding-free limit of the reference's arithmetic.  fp32 gradients of this network carry ~1e-2 of
+    summation noise at N = 1024 (both the reference's and any restatement's: tools/grad_conditioning.py), so the double
+    evaluation is the well-conditioned fixture that pins gradients tightly at full N."""
     torch.manual_seed(seed)
     args = gc.make_args(dropout=0.0)
     model = RefModels.DGCNN(args)
@@ -50,6 +54,9 @@ def model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep_feats):
     chk = gc.state_checksums(model)
     inp = gc.make_inputs(seed, B, N)
     out = {"x": npy(inp["x"])}
+    if dtype != torch.float32:
+        model = model.to(dtype)
+        inp = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in inp.items()}
     for k, v in chk.items():
         out["chk/" + k] = v
 
@@ -90,6 +97,11 @@ def model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep_feats):
         if gk.size > 70000:          # keep fixtures small: first 64 output rows
             gk = gk[:64]
         out["grad/" + k] = gk
+    if dtype != torch.float32:       # the double-precision fixture is a gradient/logit pin: no eval pass, compact storage
+        for k in list(out):
+            if k.startswith("train/") and out[k].ndim > 0:
+                out[k] = out[k].astype(np.float32)
+        return out
     st = model.state_dict()
     for k in ["conv1.conv.1.running_mean", "conv1.conv.1.running_var", "conv4.conv.1.running_var",
               "bn5.running_mean", "bn5.running_var", "DefRec.bn1.running_mean", "DefRec.bn1.running_var",
@@ -165,9 +177,12 @@ def import_seg_reference():
     return mod
 
 
-def seg_case(seg, seed, B, N):
+def seg_case(seg, seed, B, N, K=None):
     """DGCNN_DefRec (PointSegDA/Models.py:197-242): all heads, train mode (dropout 0) + eval mode, grads of a fixed
-    linear functional of the outputs, kNN indices of the four graph stages."""
+    linear functional of the outputs, kNN indices of the four graph stages.  `K` overrides the module constant
+    PointSegDA/Models.py:6 (read by the constructors at :150,:202) -- BASELINE.json configs[4] asks for k = 40."""
+    if K is not None:
+        seg.K = K
     torch.manual_seed(seed)
     args = gc.make_seg_args(dropout=0.0)
     model = seg.DGCNN_DefRec(args, in_size=3, num_classes=8)
@@ -415,6 +430,18 @@ def corrupt_cases():
                         mixed=npy(mixed), Ya=npy(Ya), Yb=npy(Yb))
 
 
+def main_round2():
+    """Round-2 fixtures: the reference in float64 at N = 1024 (gradient pin at full N) and PointSegDA with K = 40."""
+    RefModels, ref_mu, ref_mlsp = ref_import.import_reference()
+    torch.set_num_threads(8)
+    np.savez_compressed(os.path.join(OUT, "dgcnn_f64_s3_B4_N1024.npz"),
+                        **model_case(RefModels, ref_mu, ref_mlsp, 3, 4, 1024, False, dtype=torch.float64))
+    seg = import_seg_reference()
+    np.savez_compressed(os.path.join(OUT, "segda_k40_s2_B2_N512.npz"), **seg_case(seg, 2, 2, 512, K=40))
+    for f in ("dgcnn_f64_s3_B4_N1024.npz", "segda_k40_s2_B2_N512.npz"):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
 def main_sa():
     pu = import_sa_reference()
     np.savez_compressed(os.path.join(OUT, "sa_s0_B4_N256.npz"), **sa_case(pu, 0, 4, 256, 6, 64, 0.4, 16, [32, 32, 64], False))
@@ -432,5 +459,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "corrupt":
         corrupt_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        main_round2()
         sys.exit(0)
     main()
