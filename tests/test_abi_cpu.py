@@ -109,3 +109,49 @@ def test_no_register_spills_in_hot_kernels():
             if (int(s) or int(c)) and "knn_mfma_kernel" not in n:
                 bad.append((os.path.basename(f), n, int(s), int(c)))
     assert not bad, bad
+
+
+def test_forward_bookkeeping_is_per_thread():
+    """nn.DataParallel runs one replica per Python thread (PointDA/trainer.py:251-252): the queue of num_batches_tracked
+    increments and the forward nesting depth are thread-local, so interleaved forwards of two replicas lose no increment."""
+    import threading
+    from mlsp_amd import model_utils as mu
+
+    class Rep(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bn = torch.nn.BatchNorm1d(4)
+            self.inner = Inner()
+
+        @mu.flushing_forward
+        def forward(self, barrier):
+            mu._bn_buffers(self.bn, True)
+            barrier.wait()                    # both threads are inside a forward, each with a queued counter
+            self.inner(barrier)
+            return int(self.bn.num_batches_tracked)
+
+    class Inner(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bn = torch.nn.BatchNorm1d(4)
+
+        @mu.flushing_forward
+        def forward(self, barrier):
+            mu._bn_buffers(self.bn, True)
+            barrier.wait()
+
+    reps, barrier, errs = [Rep(), Rep()], threading.Barrier(2), []
+
+    def run(r):
+        try:
+            for it in range(50):
+                assert r(barrier) == it       # the nested forward must not flush; the outermost one flushes on exit
+        except Exception as e:                # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+    ts = [threading.Thread(target=run, args=(r,)) for r in reps]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for r in reps:
+        assert int(r.bn.num_batches_tracked) == 50 and int(r.inner.bn.num_batches_tracked) == 50

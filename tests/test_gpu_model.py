@@ -253,6 +253,34 @@ def test_module_api_surface(dev):
     assert pv.shape == (128, 16) and dn.shape == (128,)
 
 
+def test_dataparallel_and_replica_threads(dev):
+    """PointDA/trainer.py:251-253 wraps the model in nn.DataParallel: replicas run forward in one Python thread each.  (1) the
+    wrapper works end to end on this box's GPU; (2) two model copies driven concurrently by torch's own parallel_apply (two
+    threads, as DataParallel does) give the results of the serial runs and lose no num_batches_tracked increment."""
+    from torch.nn.parallel import parallel_apply
+    m = _model(7, dev).train()
+    x = (torch.rand(4, 3, 256, generator=torch.Generator().manual_seed(7)) * 2 - 1).to(dev)
+    dp = torch.nn.DataParallel(m, [0])
+    out = dp(x, activate_density_normal_ondef=True)
+    sum(v.float().sum() for v in out.values()).backward()
+    assert int(m.bn5.num_batches_tracked) == 1 and m.conv1.conv[0].weight.grad is not None
+    a, b = copy.deepcopy(m), copy.deepcopy(m)
+    xa, xb = x[:2].contiguous(), x[2:].contiguous()
+    with torch.no_grad():
+        want_a = copy.deepcopy(m)(xa, activate_density_normal_ondef=True)
+        want_b = copy.deepcopy(m)(xb, activate_density_normal_ondef=True)
+    for rep in range(5):
+        with torch.no_grad():
+            got = parallel_apply([a, b], [(xa,), (xb,)], [dict(activate_density_normal_ondef=True)] * 2, [0, 0])
+        if rep == 0:
+            for k in HEAD_KEYS:
+                assert torch.equal(got[0][k], want_a[k]) and torch.equal(got[1][k], want_b[k]), k
+    for r in (a, b):
+        st = r.state_dict()
+        assert all(int(v) == 1 + 5 for k, v in st.items() if k.endswith("num_batches_tracked") and not k.startswith("Rec_scan")), \
+            {k: int(v) for k, v in st.items() if k.endswith("num_batches_tracked")}
+
+
 def test_full_size_step_properties(dev):
     """BASELINE config (B=32, N=1024, k=20): one fwd+bwd; size-independent properties."""
     m = _model(5, dev, dropout=0.5)

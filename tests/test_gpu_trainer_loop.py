@@ -20,29 +20,45 @@ def test_trainer_shaped_loop():
         pytest.skip("needs a GPU")
     sys.path.insert(0, os.path.join(ROOT, "mlsp_amd", "shims"))
     try:
-        for mod in ("PointDA", "PointDA.Models", "MLSP", "MLSP.mlsp", "pcl"):
+        for mod in ("PointDA", "PointDA.Models", "MLSP", "MLSP.mlsp", "MLSP.PCM", "pcl"):
             sys.modules.pop(mod, None)
         from PointDA.Models import DGCNN                     # trainer.py:14
-        from MLSP import mlsp                                # trainer.py:15
+        from MLSP import PCM, mlsp                           # trainer.py:15
         import pcl                                           # trainer.py:18
+        from mlsp_amd import pc_utils
         device = torch.device("cuda:0")
         args = gc.make_args(dropout=0.5, cuda=True)
         args.radius, args.near = 0.135, 20
+        args.DefRec_dist, args.mixup_params = 'volume_based_voxels', 1.0             # trainer.py:112,119
         torch.manual_seed(1)
+        np.random.seed(1)
         model = DGCNN(args).to(device)                       # trainer.py:244-249
+        model = nn.DataParallel(model, [0])                  # :251-252 (the trainer's only multi-GPU mechanism)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)      # :258
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 3)              # :260
         criterion = nn.CrossEntropyLoss()
+        lookup = torch.Tensor(pc_utils.region_mean(3)).to(device)                    # :270
         B, N = 8, 256
         g = torch.Generator().manual_seed(0)
         losses = []
         for it in range(3):
             model.train()
             opt.zero_grad()
-            # ---- source branch (trainer.py:379-401, without PCM): CE on cls
+            # ---- source branch (trainer.py:376-401): DefRec on the deformed source, then PCM mixup on the original
             src = (torch.rand(B, N, 3, generator=g) * 2 - 1)
             src_label = torch.randint(0, 10, (B,), generator=g).to(device)
-            logits = model(src.to(device).permute(0, 2, 1), activate_DefRec=False)
-            loss = criterion(logits["cls"], src_label)
+            src_data = src.to(device).permute(0, 2, 1)       # a NON-contiguous [B,3,N] view, exactly as the trainer passes it
+            assert not src_data.is_contiguous()
+            src_data_orig = src_data.clone()
+            src_data, src_mask = mlsp.deform_input(src_data, lookup, args.DefRec_dist, device)       # :386
+            assert (src_mask[:, 0].sum(1) >= 40).all() and not torch.equal(src_data, src_data_orig)
+            src_logits = model(src_data, activate_DefRec=True)
+            loss = mlsp.calc_loss(args, src_logits, src_data_orig, src_mask)
+            loss.backward()
+            src_data = src_data_orig.clone()
+            src_data, mixup_vals = PCM.mix_shapes(args, src_data, src_label)                          # :396
+            assert src_data.shape == (B, 3, N)
+            loss = PCM.calc_loss(args, model(src_data, activate_DefRec=False), mixup_vals, criterion)
             loss.backward()
             # ---- target branch (trainer.py:522-566, Density_normal_viainput)
             trgt = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(device)
@@ -60,9 +76,9 @@ def test_trainer_shaped_loop():
             density_mse_label = torch.tensor(dml, dtype=torch.float).to(device).reshape(-1)
             trgt = trgt.permute(0, 2, 1)
             orig = trgt.clone()
-            mask = torch.zeros_like(trgt)
-            mask[:, :, :45] = 1                              # stands in for mlsp.deform_input's region mask
-            trgt = trgt + mask * 0.1 * torch.randn(trgt.shape, generator=g).to(device)
+            trgt, mask = mlsp.deform_input(trgt, lookup, args.DefRec_dist, device)                   # :541
+            moved = (trgt != orig).any(1)
+            assert torch.equal(moved, mask[:, 0] > 0) and (mask[:, 0].sum(1) >= 40).all()
             lp = model(trgt, activate_density_normal_ondef=True)
             loss = mlsp.calc_loss(args, lp, orig, mask)
             m2 = mask.permute(0, 2, 1)
@@ -76,6 +92,7 @@ def test_trainer_shaped_loop():
             losses.append(loss.item())
             loss.backward()
             opt.step()                                       # :571
+            scheduler.step()
         assert all(np.isfinite(losses))
         # ---- test() (trainer.py:298-331)
         model.eval()
@@ -83,11 +100,41 @@ def test_trainer_shaped_loop():
             data = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(device).permute(0, 2, 1)
             lg = model(data, activate_DefRec=False)
             assert lg["cls"].max(dim=1)[1].shape == (B,)
-        sd = model.state_dict()                              # io.save_model (utils/log.py:34) / strict reload (train_spst.py:141)
+        sd = model.module.state_dict()                       # io.save_model (utils/log.py:33-34) / strict reload (train_spst.py:141)
         m2 = DGCNN(args).to(device)
         m2.load_state_dict(sd, strict=True)
-        assert int(sd["bn5.num_batches_tracked"]) == 6       # 2 training forwards per step x 3 steps
+        assert int(sd["bn5.num_batches_tracked"]) == 9       # 3 training forwards per step x 3 steps
     finally:
         sys.path.remove(os.path.join(ROOT, "mlsp_amd", "shims"))
-        for mod in ("PointDA", "PointDA.Models", "MLSP", "MLSP.mlsp", "pcl"):
+        for mod in ("PointDA", "PointDA.Models", "MLSP", "MLSP.mlsp", "MLSP.PCM", "pcl"):
+            sys.modules.pop(mod, None)
+
+
+def test_segda_trainer_mixup_through_shim():
+    """PointSegDA/trainer.py:306: PCM.mix_shapes_segmentation through the shim -- labels follow their points."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(ROOT, "mlsp_amd", "shims"))
+    try:
+        for mod in ("MLSP", "MLSP.PCM"):
+            sys.modules.pop(mod, None)
+        from MLSP import PCM
+        import types
+        dev = torch.device("cuda:0")
+        g = torch.Generator().manual_seed(4)
+        B, N = 4, 256
+        X = (torch.rand(B, 3, N, generator=g) * 2 - 1).to(dev)
+        Y = (X[:, 0] * 1000).round().long()                  # a label that identifies its point
+        args = types.SimpleNamespace(gpus=[0], mixup_params=1.0)
+        mX, mY = PCM.mix_shapes_segmentation(args, X, Y)
+        assert mX.shape == (B, 3, N) and mY.shape == (B, N)
+        assert torch.equal((mX[:, 0] * 1000).round().long(), mY)
+        crit = nn.CrossEntropyLoss()
+        lg = torch.randn(B, 10, device=dev)
+        ya, yb = torch.randint(0, 10, (B,), device=dev), torch.randint(0, 10, (B,), device=dev)
+        want = 0.3 * crit(lg, ya) + 0.7 * crit(lg, yb)
+        assert torch.allclose(PCM.calc_loss_ptrans(args, lg, (ya, yb, 0.3), crit), want)
+    finally:
+        sys.path.remove(os.path.join(ROOT, "mlsp_amd", "shims"))
+        for mod in ("MLSP", "MLSP.PCM"):
             sys.modules.pop(mod, None)
