@@ -815,7 +815,19 @@ static int launch_knn_mfma4(hipStream_t st, const float* x, int ld, const float*
 //           publishes its exact top-k as keys; the same final merges the two halves.
 // RES (CT <= 16): the whole cloud's candidates stay in LDS for both passes, no per-tile barriers.
 // Requires N % 128 == 0 (full query chunks, an even number of 32-candidate tiles); everything else stays on v4.
+//
+// KB = 1 (24 < k <= 64; BASELINE.json configs[4] asks k = 40): the same two passes with a finer bound and a shared buffer:
+//   pass A  TWO running maxima per lane (first / second half of the wave's tiles): 128 chunk maxima per query; tau = k-th
+//           largest of the 128 = two 64-sorts (both halves of a wave: lane l sorts the maxima of candidate half 0, lane l+32
+//           those of half 1), one cross-half max layer (top 64 of the union, bitonic) and a 6-stage bitonic merge.
+//           k = 40 of 128 maxima leaves ~47 +- 7 survivors of 2048 candidates.
+//   pass B  survivors of BOTH halves go to ONE buffer of KNN5_CAPT keys per query (LDS atomic on the query's counter per
+//           ballot hit -- hits are rare, ~47 per query over the whole sweep), so the capacity covers the SUM of the halves.
+//   pass C  (overflow: massive ties) lane-distributed sorted lists with two entries per lane (positions l and 32 + l);
+//           the halves publish one after the other through the same buffer and rank their own keys against the other's.
+// The query fragments are re-read from global memory after the tau phase instead of staying live across it (registers).
 #define KNN5_CAP 32
+#define KNN5_CAPT 88               // KB = 1: keys per query, both halves together (16-byte aligned rows)
 #define KNN5_XS 68                 // row stride (floats) of the pass-A exchange image: 16 B aligned rows, 2-way banked
 typedef unsigned long long u64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -827,14 +839,14 @@ __device__ __forceinline__ u64 knn_key(float pd, int j) {
     return ((u64)u << 32) | (unsigned)(~j);                // larger key = (larger pd, then smaller index)
 }
 
-template <int CT, bool VEC, bool RES>
+template <int CT, bool VEC, bool RES, int KB>
 __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
                                                         int ld, int N, int C, int k, int* __restrict__ idx, int B) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TILE = CT * KM_STRIDE;
     constexpr int NSTEP = CT / 2;
     constexpr int SPR = NSTEP >= 16 ? NSTEP / 16 : 1;      // MFMA steps issued per query row of the select loop
-    constexpr int GS = NSTEP >= 16 ? 16 : NSTEP;           // B fragments fetched per group
+    constexpr int GS = (KB && CT == 128) ? 8 : NSTEP >= 16 ? 16 : NSTEP;   // B fragments fetched per group (the k > 24 variant at C = 128 is out of registers)
     constexpr int NG = NSTEP / GS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -847,21 +859,22 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
 
     float* tiles = sm;                                           // RES: [ntiles][CT][33]   else [2 halves][2][CT][33]
     float* cxx = tiles + (RES ? (size_t)ntiles * TILE : (size_t)4 * TILE);   // RES: [N]   else [2 halves][3][32]
-    u64* bufk = (u64*)(cxx + (RES ? N : 192));                   // [4 qg][2 ch][32 queries][CAP] survivor keys
-    float* xch = (float*)bufk;                                   // pass-A exchange [4][2][16][64], dead before pass B
-    float* tau = (float*)(bufk + 4 * 2 * 32 * KNN5_CAP);         // [4 qg][16 rows][2 h]
-    int* cnts = (int*)(tau + 128);                               // [4 qg][2 ch][32 queries]
+    u64* bufk = (u64*)(cxx + (RES ? N : 192));                   // KB=0: [4 qg][2 ch][32 queries][CAP] survivor keys; KB=1: [128 queries][CAPT]
+    float* xch = (float*)bufk;                                   // pass-A exchange [4][2][(2 parts)][16][XS], dead before pass B
+    float* tau = (float*)(bufk + (KB ? 128 * KNN5_CAPT : 4 * 2 * 32 * KNN5_CAP));   // [4 qg][16 rows][2 h]
+    int* cnts = (int*)(tau + 128);                               // KB=0: [4 qg][2 ch][32 queries]; KB=1: [4 qg][32 queries]
 
     const int q0 = chunk * 128 + qg * 32;
     float qa[NSTEP];
-    {
+    auto load_queries = [&]() {
         const int q = q0 + l31;
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             int c = 2 * s + h;
             qa[s] = (c < C) ? xb[(size_t)q * ld + c] : 0.f;
         }
-    }
+    };
+    load_queries();
     float xxq[16], thr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -944,8 +957,9 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
         return (RES ? tiles + (size_t)(ch * nt2 + tl) * TILE : htiles + (tl & 1) * TILE) + h * KM_STRIDE + l31;
     };
 
-    // one sweep over the wave's half; sel(r, pd, j) sees every (query row, candidate) distance once
-    auto sweep = [&](auto&& sel) {
+    // one sweep over the wave's half; sel(r, pd, j) sees every (query row, candidate) distance once; at_mid() runs between
+    // the first and the second half of the wave's tiles (KB = 1 pass A snapshots its running maxima there)
+    auto sweep = [&](auto&& sel, auto&& at_mid) {
         f32x16 accCur, accNext;
 #ifdef KNN5_PROBE_NOSEL
         float cmx = -INFINITY;
@@ -970,6 +984,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
         }
         for (int tl = 0; tl < nt2; ++tl) {
             if (!RES) __syncthreads();
+            if (KB && tl == (nt2 >> 1)) at_mid();
             const bool have_next = tl + 1 < nt2;
             if (!RES && tl + 2 < nt2) g2r_tile(tl + 2);
             const float* T = tile_ptr(tl + 1);
@@ -1022,29 +1037,50 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
         float cm[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
-        sweep([&](int r, float pd, int) { cm[r] = fmaxf(cm[r], pd); });
+        sweep([&](int r, float pd, int) { cm[r] = fmaxf(cm[r], pd); },
+              [&]() {          // KB: the first half's maxima go straight to the exchange image (bufk is dead during pass A)
+                  if (KB) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xch[((qg * 2 + ch) * 16 + r) * KNN5_XS + lane] = cm[r];
+                      for (int r = 0; r < 16; ++r) {
+                          xch[(((qg * 2 + ch) * 2 + 0) * 16 + r) * KNN5_XS + lane] = cm[r];
+                          cm[r] = -INFINITY;
+                      }
+                  }
+              });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(KB ? ((qg * 2 + ch) * 2 + 1) * 16 + r : (qg * 2 + ch) * 16 + r) * KNN5_XS + lane] = cm[r];
     }
     __syncthreads();
 #if defined(KNN5_PROBE) && KNN5_PROBE == 4
     if (xch[tid] == 12345.f) idx[0] = 1;
     return;
 #endif
-    // tau = k-th largest of a query's 64 chunk maxima.  One lane per query: the first 32 lanes of waves 0-3 (one per
+    // tau = k-th largest of a query's chunk maxima.  One lane per query: the first 32 lanes of waves 0-3 (one per
     // SIMD) pull the 64 values of "their" query into registers and run a bitonic sorting network (672 min/max pairs,
-    // no cross-lane traffic, no data-dependent control).
-    if (ch == 0 && lane < 32) {
-        const int r = (lane & 3) + 4 * (lane >> 3), hq = (lane >> 2) & 1;     // lane = query row of the group
+    // no cross-lane traffic, no data-dependent control).  KB = 1: lanes 32-63 sort the 64 maxima of the other candidate
+    // half at the same time, then the two sorted runs are merged (header comment).
+    if (ch == 0 && (KB || lane < 32)) {
+        const int r = (l31 & 3) + 4 * (l31 >> 3), hq = (l31 >> 2) & 1;     // l31 = query row of the group
         float v[64];
+        if (KB) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)                                    // c = part (first / second half of the tiles); h = candidate half
 #pragma unroll
-            for (int i4 = 0; i4 < 8; ++i4) {
-                const f32x4 t = *(const f32x4*)(xch + ((qg * 2 + c) * 16 + r) * KNN5_XS + hq * 32 + 4 * i4);
-                v[c * 32 + 4 * i4 + 0] = t[0]; v[c * 32 + 4 * i4 + 1] = t[1];
-                v[c * 32 + 4 * i4 + 2] = t[2]; v[c * 32 + 4 * i4 + 3] = t[3];
-            }
+                for (int i4 = 0; i4 < 8; ++i4) {
+                    const f32x4 t = *(const f32x4*)(xch + (((qg * 2 + h) * 2 + c) * 16 + r) * KNN5_XS + hq * 32 + 4 * i4);
+                    v[c * 32 + 4 * i4 + 0] = t[0]; v[c * 32 + 4 * i4 + 1] = t[1];
+                    v[c * 32 + 4 * i4 + 2] = t[2]; v[c * 32 + 4 * i4 + 3] = t[3];
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i4 = 0; i4 < 8; ++i4) {
+                    const f32x4 t = *(const f32x4*)(xch + ((qg * 2 + c) * 16 + r) * KNN5_XS + hq * 32 + 4 * i4);
+                    v[c * 32 + 4 * i4 + 0] = t[0]; v[c * 32 + 4 * i4 + 1] = t[1];
+                    v[c * 32 + 4 * i4 + 2] = t[2]; v[c * 32 + 4 * i4 + 3] = t[3];
+                }
+        }
 #pragma unroll
         for (int k2 = 2; k2 <= 64; k2 <<= 1)
 #pragma unroll
@@ -1058,50 +1094,168 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
                         else { v[i] = lo; v[l] = hi; }
                     }
                 }
+        if (KB) {
+            // top 64 of the two descending runs (mine and my partner lane's, lane ^ 32): t[i] = max(a[i], b[63-i]) is bitonic
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float pa = __shfl_xor(v[63 - i], 32, 64), pb = __shfl_xor(v[i], 32, 64);
+                v[i] = fmaxf(v[i], pa);
+                v[63 - i] = fmaxf(v[63 - i], pb);
+            }
+#pragma unroll
+            for (int j = 32; j > 0; j >>= 1)
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const float lo = fminf(v[i], v[l]), hi = fmaxf(v[i], v[l]);
+                        v[i] = hi; v[l] = lo;
+                    }
+                }
+        }
         float t = v[0];
 #pragma unroll
-        for (int i = 1; i < 32; ++i) t = (i == k - 1) ? v[i] : t;
-        tau[(qg * 16 + r) * 2 + hq] = t;
+        for (int i = 1; i < (KB ? 64 : 32); ++i) t = (i == k - 1) ? v[i] : t;
+        if (!KB || h == 0) tau[(qg * 16 + r) * 2 + hq] = t;
     }
+    if (KB && tid < 128) cnts[tid] = 0;
     __syncthreads();                           // tau complete; xch (aliases bufk) is dead from here on
 #pragma unroll
     for (int r = 0; r < 16; ++r) thr[r] = tau[(qg * 16 + r) * 2 + h];
+    if (KB) load_queries();                    // dead across the tau phase (register budget), re-read here
 
 #if defined(KNN5_PROBE) && KNN5_PROBE == 1
     if (thr[0] == 12345.f) idx[0] = 1;
     return;
 #endif
-    // ---- pass B: survivors of this half -> this wave's key buffers
-    u64* mybuf = bufk + (size_t)(qg * 2 + ch) * 32 * KNN5_CAP;
-    int cnt[16];
+    if (!KB) {
+        // ---- pass B: survivors of this half -> this wave's key buffers
+        u64* mybuf = bufk + (size_t)(qg * 2 + ch) * 32 * KNN5_CAP;
+        int cnt[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cnt[r] = 0;
+        for (int r = 0; r < 16; ++r) cnt[r] = 0;
+        sweep([&](int r, float pd, int j) {
+            const bool pass = pd >= thr[r];
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                const unsigned mine = h ? (unsigned)(m >> 32) : (unsigned)m;
+                const int pos = cnt[r] + __builtin_popcount(mine & ((1u << l31) - 1u));
+                if (pass && pos < KNN5_CAP) mybuf[((r & 3) + 8 * (r >> 2) + 4 * h) * KNN5_CAP + pos] = knn_key(pd, j);
+                cnt[r] += __builtin_popcount(mine);
+            }
+        }, []() {});
+        bool over = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) over |= cnt[r] > KNN5_CAP;
+
+#if defined(KNN5_PROBE) && KNN5_PROBE == 2
+        if (over) idx[0] = cnt[3];
+        return;
+#endif
+        if (__syncthreads_or(over ? 1 : 0)) {
+            // ---- pass C (exact for any input): sequential insertion over this half, lane-distributed sorted lists
+            float lv[16];
+            int li[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { lv[r] = -INFINITY; li[r] = 0x7fffffff; thr[r] = -INFINITY; }
+            sweep([&](int r, float pd, int j) {
+                unsigned long long m = __ballot(pd > thr[r]);
+                if (m) {
+                    unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+                    const int pdi = __float_as_int(pd);
+                    const int jbase = j - l31;
+                    while (lo | hi) {
+                        const int s0 = lo ? __builtin_ctz(lo) : 0, s1 = hi ? __builtin_ctz(hi) : 0;
+                        const float x0 = __int_as_float(__builtin_amdgcn_readlane(pdi, s0));
+                        const float x1 = __int_as_float(__builtin_amdgcn_readlane(pdi, 32 + s1));
+                        const bool active = h ? (hi != 0) : (lo != 0);
+                        const float xv = h ? x1 : x0;
+                        const int xj = jbase + (h ? s1 : s0);
+                        const float upv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv[r]), 0x138, 0xf, 0xf, false));
+                        const int upi = __builtin_amdgcn_update_dpp(0, li[r], 0x138, 0xf, 0xf, false);
+                        const bool lt = lv[r] < xv;
+                        const bool uplt = (l31 > 0) && (upv < xv);
+                        if (active && lt) { lv[r] = uplt ? upv : xv; li[r] = uplt ? upi : xj; }
+                        lo &= lo - 1; hi &= hi - 1;
+                    }
+                    const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), k - 1));
+                    const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), 32 + k - 1));
+                    thr[r] = h ? t1 : t0;
+                }
+            }, []() {});
+            // a half with fewer than k candidates (N/2 < k) leaves -inf/0x7fffffff fillers: they are not published
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool valid = l31 < k && li[r] != 0x7fffffff;
+                if (valid) mybuf[((r & 3) + 8 * (r >> 2) + 4 * h) * KNN5_CAP + l31] = knn_key(lv[r], li[r]);
+                const unsigned long long m = __ballot(valid);
+                cnt[r] = __builtin_popcount(h ? (unsigned)(m >> 32) : (unsigned)m);
+            }
+        }
+        if (l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnts[(qg * 2 + ch) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = cnt[r];
+        }
+        __syncthreads();
+
+        // ---- final: exact rank among the <= 64 keys of a query; this wave finishes 8 of the group's 16 rows
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = ch * 8 + rr;
+            const int qrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int n0 = cnts[(qg * 2 + 0) * 32 + qrow], n1 = cnts[(qg * 2 + 1) * 32 + qrow];
+            const u64* K0 = bufk + ((size_t)(qg * 2 + 0) * 32 + qrow) * KNN5_CAP;
+            const u64* K1 = bufk + ((size_t)(qg * 2 + 1) * 32 + qrow) * KNN5_CAP;
+            const u64 m0 = l31 < n0 ? K0[l31] : 0ull, m1 = l31 < n1 ? K1[l31] : 0ull;
+            int nm = max(n0, n1);
+            nm = max(__builtin_amdgcn_readlane(nm, 0), __builtin_amdgcn_readlane(nm, 32));
+            int rank0 = 0, rank1 = 0;
+            for (int i = 0; i < nm; i += 2) {
+                const u32x4 p0 = *(const u32x4*)(K0 + i), p1 = *(const u32x4*)(K1 + i);
+                const u64 a0 = i < n0 ? ((u64)p0[1] << 32 | p0[0]) : 0ull, a1 = i + 1 < n0 ? ((u64)p0[3] << 32 | p0[2]) : 0ull;
+                const u64 c0 = i < n1 ? ((u64)p1[1] << 32 | p1[0]) : 0ull, c1 = i + 1 < n1 ? ((u64)p1[3] << 32 | p1[2]) : 0ull;
+                rank0 += (a0 > m0) + (a1 > m0) + (c0 > m0) + (c1 > m0);
+                rank1 += (a0 > m1) + (a1 > m1) + (c0 > m1) + (c1 > m1);
+            }
+            int* out = idx + ((size_t)b * N + q0 + qrow) * k;
+            if (l31 < n0 && rank0 < k) out[rank0] = ~(int)(unsigned)m0;
+            if (l31 < n1 && rank1 < k) out[rank1] = ~(int)(unsigned)m1;
+        }
+    } else {
+    // ================= KB = 1: 32 < k <= 64 =================
+    // ---- pass B: survivors of BOTH halves -> the query's one key buffer (LDS counter per query)
     sweep([&](int r, float pd, int j) {
         const bool pass = pd >= thr[r];
         const unsigned long long m = __ballot(pass);
         if (m) {
-            const unsigned mine = h ? (unsigned)(m >> 32) : (unsigned)m;
-            const int pos = cnt[r] + __builtin_popcount(mine & ((1u << l31) - 1u));
-            if (pass && pos < KNN5_CAP) mybuf[((r & 3) + 8 * (r >> 2) + 4 * h) * KNN5_CAP + pos] = knn_key(pd, j);
-            cnt[r] += __builtin_popcount(mine);
+            const unsigned mine = h ? (unsigned)(m >> 32) : (unsigned)m;      // hits of my query row (uniform over the half-wave)
+            if (mine) {
+                const int qrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int leader = __builtin_ctz(mine);
+                int base = 0;
+                if (l31 == leader) base = atomicAdd(&cnts[qg * 32 + qrow], __builtin_popcount(mine));
+                base = __shfl(base, (h << 5) + leader, 64);
+                const int pos = base + __builtin_popcount(mine & ((1u << l31) - 1u));
+                if (pass && pos < KNN5_CAPT) bufk[(size_t)(qg * 32 + qrow) * KNN5_CAPT + pos] = knn_key(pd, j);
+            }
         }
-    });
-    bool over = false;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) over |= cnt[r] > KNN5_CAP;
-
-#if defined(KNN5_PROBE) && KNN5_PROBE == 2
-    if (over) idx[0] = cnt[3];
-    return;
-#endif
+    }, []() {});
+    __syncthreads();
+    const bool over = tid < 128 && cnts[tid] > KNN5_CAPT;
     if (__syncthreads_or(over ? 1 : 0)) {
-        // ---- pass C (exact for any input): sequential insertion over this half, lane-distributed sorted lists
-        float lv[16];
-        int li[16];
+        // ---- pass C (exact for any input): sequential insertion over this half; the sorted list of a query row lives in
+        // the 32 lanes of its half-wave with TWO entries per lane: positions l31 (lvA) and 32 + l31 (lvB).  An insertion into
+        // the first level pushes its last element (lane 31's) into the second.
+        float lvA[16], lvB[16];
+        int liA[16], liB[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { lv[r] = -INFINITY; li[r] = 0x7fffffff; thr[r] = -INFINITY; }
+        for (int r = 0; r < 16; ++r) { lvA[r] = lvB[r] = -INFINITY; liA[r] = liB[r] = 0x7fffffff; }
         sweep([&](int r, float pd, int j) {
-            unsigned long long m = __ballot(pd > thr[r]);
+            // current k-th best of my query row = list position k - 1 (first level: lane k - 1; second level: lane k - 33); read
+            // from the list itself instead of keeping 16 more live registers
+            const int tsrc = __float_as_int(k <= 32 ? lvA[r] : lvB[r]), tl = (k - 1) & 31;
+            const float t0 = __int_as_float(__builtin_amdgcn_readlane(tsrc, tl));
+            const float t1 = __int_as_float(__builtin_amdgcn_readlane(tsrc, 32 + tl));
+            unsigned long long m = __ballot(pd > (h ? t1 : t0));
             if (m) {
                 unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
                 const int pdi = __float_as_int(pd);
@@ -1113,88 +1267,131 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
                     const bool active = h ? (hi != 0) : (lo != 0);
                     const float xv = h ? x1 : x0;
                     const int xj = jbase + (h ? s1 : s0);
-                    const float upv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv[r]), 0x138, 0xf, 0xf, false));
-                    const int upi = __builtin_amdgcn_update_dpp(0, li[r], 0x138, 0xf, 0xf, false);
-                    const bool lt = lv[r] < xv;
-                    const bool uplt = (l31 > 0) && (upv < xv);
-                    if (active && lt) { lv[r] = uplt ? upv : xv; li[r] = uplt ? upi : xj; }
+                    // the element that leaves the first level if xv enters it: the current last one (lane 31 of my half)
+                    const float c0v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lvA[r]), 31));
+                    const float c1v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lvA[r]), 63));
+                    const int c0i = __builtin_amdgcn_readlane(liA[r], 31), c1i = __builtin_amdgcn_readlane(liA[r], 63);
+                    const float lastv = h ? c1v : c0v;
+                    const int lasti = h ? c1i : c0i;
+                    const bool intoA = lastv < xv;
+                    const float yv = intoA ? lastv : xv;               // what the second level receives
+                    const int yj = intoA ? lasti : xj;
+                    {
+                        const float upv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lvA[r]), 0x138, 0xf, 0xf, false));
+                        const int upi = __builtin_amdgcn_update_dpp(0, liA[r], 0x138, 0xf, 0xf, false);
+                        const bool lt = lvA[r] < xv;
+                        const bool uplt = (l31 > 0) && (upv < xv);
+                        if (active && lt) { lvA[r] = uplt ? upv : xv; liA[r] = uplt ? upi : xj; }
+                    }
+                    {
+                        const float upv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lvB[r]), 0x138, 0xf, 0xf, false));
+                        const int upi = __builtin_amdgcn_update_dpp(0, liB[r], 0x138, 0xf, 0xf, false);
+                        const bool lt = lvB[r] < yv;
+                        const bool uplt = (l31 > 0) && (upv < yv);
+                        if (active && lt) { lvB[r] = uplt ? upv : yv; liB[r] = uplt ? upi : yj; }
+                    }
                     lo &= lo - 1; hi &= hi - 1;
                 }
-                const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), k - 1));
-                const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), 32 + k - 1));
-                thr[r] = h ? t1 : t0;
             }
-        });
-        // a half with fewer than k candidates (N/2 < k) leaves -inf/0x7fffffff fillers: they are not published
+        }, []() {});
+        // Each half now holds its exact top-k per query (fewer when N/2 < k: fillers are not published).  The halves publish
+        // one after the other through the query's buffer; the other half ranks its own keys against what it reads.
+        // keys are rebuilt from (value, index) where they are used: 0 = no key (every real key is > 0)
+#define KNN5_KEYA(r) (liA[r] != 0x7fffffff ? knn_key(lvA[r], liA[r]) : 0ull)
+#define KNN5_KEYB(r) ((32 + l31 < k && liB[r] != 0x7fffffff) ? knn_key(lvB[r], liB[r]) : 0ull)
+        for (int turn = 0; turn < 2; ++turn) {
+            __syncthreads();                                   // everyone is done with the buffer's previous content
+            if (ch == turn) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool valid = l31 < k && li[r] != 0x7fffffff;
-            if (valid) mybuf[((r & 3) + 8 * (r >> 2) + 4 * h) * KNN5_CAP + l31] = knn_key(lv[r], li[r]);
-            const unsigned long long m = __ballot(valid);
-            cnt[r] = __builtin_popcount(h ? (unsigned)(m >> 32) : (unsigned)m);
+                for (int r = 0; r < 16; ++r) {
+                    u64* K = bufk + (size_t)(qg * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * KNN5_CAPT;
+                    K[l31] = KNN5_KEYA(r);
+                    K[32 + l31] = KNN5_KEYB(r);
+                }
+            }
+            __syncthreads();
+            if (ch != turn) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const u64* K = bufk + (size_t)(qg * 32 + qrow) * KNN5_CAPT;
+                    const u64 kA = KNN5_KEYA(r), kB = KNN5_KEYB(r);
+                    int ra = l31, rb = 32 + l31;               // rank inside my own sorted list
+                    for (int i = 0; i < 64; i += 2) {
+                        const u32x4 p = *(const u32x4*)(K + i);
+                        const u64 a0 = (u64)p[1] << 32 | p[0], a1 = (u64)p[3] << 32 | p[2];
+                        ra += (a0 > kA) + (a1 > kA);
+                        rb += (a0 > kB) + (a1 > kB);
+                    }
+                    int* out = idx + ((size_t)b * N + q0 + qrow) * k;
+                    if (kA != 0ull && ra < k) out[ra] = ~(int)(unsigned)kA;
+                    if (kB != 0ull && rb < k) out[rb] = ~(int)(unsigned)kB;
+                }
+            }
         }
+#undef KNN5_KEYA
+#undef KNN5_KEYB
+        return;
     }
-    if (l31 == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cnts[(qg * 2 + ch) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = cnt[r];
-    }
-    __syncthreads();
-
-    // ---- final: exact rank among the <= 64 keys of a query; this wave finishes 8 of the group's 16 rows
+    // ---- final: exact rank among the <= CAPT keys of a query; this wave finishes 8 of the group's 16 rows
     for (int rr = 0; rr < 8; ++rr) {
         const int r = ch * 8 + rr;
         const int qrow = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n0 = cnts[(qg * 2 + 0) * 32 + qrow], n1 = cnts[(qg * 2 + 1) * 32 + qrow];
-        const u64* K0 = bufk + ((size_t)(qg * 2 + 0) * 32 + qrow) * KNN5_CAP;
-        const u64* K1 = bufk + ((size_t)(qg * 2 + 1) * 32 + qrow) * KNN5_CAP;
-        const u64 m0 = l31 < n0 ? K0[l31] : 0ull, m1 = l31 < n1 ? K1[l31] : 0ull;
-        int nm = max(n0, n1);
-        nm = max(__builtin_amdgcn_readlane(nm, 0), __builtin_amdgcn_readlane(nm, 32));
-        int rank0 = 0, rank1 = 0;
+        const int n = cnts[qg * 32 + qrow];
+        const u64* K = bufk + (size_t)(qg * 32 + qrow) * KNN5_CAPT;
+        const u64 m0 = l31 < n ? K[l31] : 0ull, m1 = 32 + l31 < n ? K[32 + l31] : 0ull, m2 = 64 + l31 < n ? K[64 + l31] : 0ull;
+        int nm = max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 32));
+        int rank0 = 0, rank1 = 0, rank2 = 0;
         for (int i = 0; i < nm; i += 2) {
-            const u32x4 p0 = *(const u32x4*)(K0 + i), p1 = *(const u32x4*)(K1 + i);
-            const u64 a0 = i < n0 ? ((u64)p0[1] << 32 | p0[0]) : 0ull, a1 = i + 1 < n0 ? ((u64)p0[3] << 32 | p0[2]) : 0ull;
-            const u64 c0 = i < n1 ? ((u64)p1[1] << 32 | p1[0]) : 0ull, c1 = i + 1 < n1 ? ((u64)p1[3] << 32 | p1[2]) : 0ull;
-            rank0 += (a0 > m0) + (a1 > m0) + (c0 > m0) + (c1 > m0);
-            rank1 += (a0 > m1) + (a1 > m1) + (c0 > m1) + (c1 > m1);
+            const u32x4 p = *(const u32x4*)(K + i);
+            const u64 a0 = i < n ? ((u64)p[1] << 32 | p[0]) : 0ull, a1 = i + 1 < n ? ((u64)p[3] << 32 | p[2]) : 0ull;
+            rank0 += (a0 > m0) + (a1 > m0);
+            rank1 += (a0 > m1) + (a1 > m1);
+            rank2 += (a0 > m2) + (a1 > m2);
         }
         int* out = idx + ((size_t)b * N + q0 + qrow) * k;
-        if (l31 < n0 && rank0 < k) out[rank0] = ~(int)(unsigned)m0;
-        if (l31 < n1 && rank1 < k) out[rank1] = ~(int)(unsigned)m1;
+        if (l31 < n && rank0 < k) out[rank0] = ~(int)(unsigned)m0;
+        if (32 + l31 < n && rank1 < k) out[rank1] = ~(int)(unsigned)m1;
+        if (64 + l31 < n && rank2 < k) out[rank2] = ~(int)(unsigned)m2;
+    }
     }
 }
 
-template <int CT, bool VEC, bool RES>
+template <int CT, bool VEC, bool RES, int KB>
 static int launch_knn_mfma5_ct(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx,
                                size_t lds) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_mfma5_kernel<CT, VEC, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)knn_mfma5_kernel<CT, VEC, RES, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((knn_mfma5_kernel<CT, VEC, RES>), dim3((N / 128) * B), dim3(512), lds, st, x, xx, ld, N, C, k, idx, B);
+    hipLaunchKernelGGL((knn_mfma5_kernel<CT, VEC, RES, KB>), dim3((N / 128) * B), dim3(512), lds, st, x, xx, ld, N, C, k, idx, B);
     return mlsp_launch_status();
 }
 
-static size_t knn5_lds_bytes(int CT, int N, bool res) {
+static size_t knn5_lds_bytes(int CT, int N, bool res, bool kb) {
     const size_t tile = (size_t)CT * KM_STRIDE;
-    const size_t fl = (res ? (size_t)(N / 32) * tile + N : 4 * tile + 192) + (size_t)2 * 4 * 2 * 32 * KNN5_CAP + 128 + 256;
+    const size_t keys = kb ? (size_t)2 * 128 * KNN5_CAPT : (size_t)2 * 4 * 2 * 32 * KNN5_CAP;     // floats
+    const size_t fl = (res ? (size_t)(N / 32) * tile + N : 4 * tile + 192) + keys + 128 + 256;
     return fl * sizeof(float);
 }
 
-// returns MLSP_ERR_UNSUPPORTED when the shape is outside v5's fast path (caller falls back to v4)
+// returns MLSP_ERR_UNSUPPORTED when the shape is outside v5's fast path (caller falls back to v4 / the list-merge kernel)
 static int launch_knn_mfma5(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
-    if (N % 128 != 0 || k > 32 || C > 128) return MLSP_ERR_UNSUPPORTED;
+    if (N % 128 != 0 || k > 64 || C > 128) return MLSP_ERR_UNSUPPORTED;
+    const bool kb = k > 24;        // k = 25..32 on the 64-maxima bound overflow its 32-key buffers too often (734 us vs 290 at N = 2048)
     const int CT = C <= 4 ? 4 : C <= 16 ? 16 : C <= 64 ? 64 : 128;
     const bool vec = (C == CT) && (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
-    const bool res = CT <= 16 && knn5_lds_bytes(CT, N, true) <= 160 * 1024;
-    const size_t lds = knn5_lds_bytes(CT, N, res);
+    const bool res = CT <= 16 && knn5_lds_bytes(CT, N, true, kb) <= 160 * 1024;
+    const size_t lds = knn5_lds_bytes(CT, N, res, kb);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
-#define KNN5_GO(CTV, VECV, RESV) return launch_knn_mfma5_ct<CTV, VECV, RESV>(st, x, ld, xx, B, N, C, k, idx, lds)
+#define KNN5_GO(CTV, VECV, RESV) do { if (kb) return launch_knn_mfma5_ct<CTV, VECV, RESV, 1>(st, x, ld, xx, B, N, C, k, idx, lds); \
+                                      return launch_knn_mfma5_ct<CTV, VECV, RESV, 0>(st, x, ld, xx, B, N, C, k, idx, lds); } while (0)
     if (CT == 4) { if (res) { if (vec) KNN5_GO(4, true, true); KNN5_GO(4, false, true); } if (vec) KNN5_GO(4, true, false); KNN5_GO(4, false, false); }
     if (CT == 16) { if (res) { if (vec) KNN5_GO(16, true, true); KNN5_GO(16, false, true); } if (vec) KNN5_GO(16, true, false); KNN5_GO(16, false, false); }
     if (CT == 64) { if (vec) KNN5_GO(64, true, false); KNN5_GO(64, false, false); }
     if (vec) KNN5_GO(128, true, false);
-    KNN5_GO(128, false, false);
+    if (kb) return MLSP_ERR_UNSUPPORTED;       // k > 24 with 64 < C < 128 or unaligned rows: out of registers, stays on the list-merge kernel
+    return launch_knn_mfma5_ct<128, false, false, 0>(st, x, ld, xx, B, N, C, k, idx, lds);
 #undef KNN5_GO
 }
 
@@ -1235,6 +1432,10 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
             if (rc != MLSP_ERR_UNSUPPORTED) return rc;
 #endif
             return launch_knn_mfma4(st, x, ld, xx_ws, B, N, C, k, idx);
+        }
+        if (k > 24 && k <= 64 && C <= 128 && N >= 128) {       // 128 chunk maxima per query need N >= 128
+            const int rc = launch_knn_mfma5(st, x, ld, xx_ws, B, N, C, k, idx);
+            if (rc != MLSP_ERR_UNSUPPORTED) return rc;
         }
         if (k <= 32) return launch_knn_mfma3(st, x, ld, xx_ws, B, N, C, k, idx);      // lane-distributed lists
         if (k <= 20) return launch_knn_mfma<20>(st, x, ld, xx_ws, B, N, C, k, idx);

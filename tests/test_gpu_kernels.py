@@ -42,7 +42,7 @@ def _rand(shape, seed, scale=1.0):
                                      (32, 1024, 3, 20), (32, 1024, 64, 20), (32, 1024, 128, 20), (32, 2048, 64, 20),
                                      # k > 32 (configs[4]: k = 40): the two-pass select with 128 chunk maxima per query
                                      (2, 2048, 3, 40), (8, 2048, 64, 40), (3, 1024, 128, 40), (2, 512, 64, 33), (1, 256, 16, 48),
-                                     (1, 128, 64, 64), (2, 2048, 64, 64)])
+                                     (1, 128, 64, 64), (2, 2048, 64, 64), (2, 1024, 64, 25), (1, 384, 100, 40)])
 def test_knn_bit_exact_vs_oracle(dev, B, N, C, k):
     Fh = _fh()
     xp = _rand((B * N, C), 100 + N + C)
@@ -74,6 +74,24 @@ def test_knn_duplicates_and_strided_input(dev):
     sl = wide[:, 32:96]
     got = Fh.knn_graph(sl, 2, 128, 20).idx.view(2, 128, 20).cpu().numpy()
     want = knn_canon.knn_point_major(sl.cpu().contiguous().view(2, 128, 64), 20)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("k", [20, 28, 40, 64])
+def test_knn_massive_ties_overflow_path(dev, k):
+    """Every survivor buffer overflows (all / many candidates tie): the exact sequential-insertion pass decides, ties -> lower index.
+    k = 28..64 run the two-entries-per-lane lists of the k > 24 kernel."""
+    Fh = _fh()
+    N = 256
+    same = torch.zeros(2, N, 16)
+    same[1] = 0.5                                             # two clouds of N identical points
+    got = Fh.knn_graph(same.view(2 * N, 16).to(dev), 2, N, k).idx.view(2, N, k).cpu().numpy()
+    assert np.array_equal(got, np.broadcast_to(np.arange(k), (2, N, k)))
+    x = torch.zeros(1, N, 3)
+    x[0, :, 0] = (torch.arange(N) // 64).float()              # four clusters of 64 duplicates
+    x[0, :, 1] = (torch.arange(N) % 2).float() * 1e-3         # ... split in two interleaved sub-clusters
+    want = knn_canon.knn_point_major(x, k)
+    got = Fh.knn_graph(x.view(N, 3).to(dev), 1, N, k).idx.view(1, N, k).cpu().numpy()
     assert np.array_equal(got, want)
 
 

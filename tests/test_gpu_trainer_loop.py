@@ -38,14 +38,14 @@ def test_trainer_shaped_loop():
         scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 3)              # :260
         criterion = nn.CrossEntropyLoss()
         lookup = torch.Tensor(pc_utils.region_mean(3)).to(device)                    # :270
-        B, N = 8, 256
+        B, N = 8, 512       # clouds in [-0.66, 0.66]^3: the centre voxel of the 3x3x3 grid holds ~N/8 >= 40 points (deform_input's min_pts)
         g = torch.Generator().manual_seed(0)
         losses = []
         for it in range(3):
             model.train()
             opt.zero_grad()
             # ---- source branch (trainer.py:376-401): DefRec on the deformed source, then PCM mixup on the original
-            src = (torch.rand(B, N, 3, generator=g) * 2 - 1)
+            src = (torch.rand(B, N, 3, generator=g) * 2 - 1) * 0.66
             src_label = torch.randint(0, 10, (B,), generator=g).to(device)
             src_data = src.to(device).permute(0, 2, 1)       # a NON-contiguous [B,3,N] view, exactly as the trainer passes it
             assert not src_data.is_contiguous()
@@ -61,7 +61,7 @@ def test_trainer_shaped_loop():
             loss = PCM.calc_loss(args, model(src_data, activate_DefRec=False), mixup_vals, criterion)
             loss.backward()
             # ---- target branch (trainer.py:522-566, Density_normal_viainput)
-            trgt = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(device)
+            trgt = ((torch.rand(B, N, 3, generator=g) * 2 - 1) * 0.66).to(device)
             normal_gt = []
             for i in range(trgt.size(0)):                    # the trainer's per-cloud pcl loop, served by the shim
                 cloud = pcl.PointCloud()

@@ -42,7 +42,7 @@ def knn_case(ref_mu, seed, B, C, N, k=20):
     return dict(x=npy(x), idx=npy(idx).astype(np.int32), gap_k=npy(gap_k), gap_in=npy(gap_in))
 
 
-def model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep_feats, dtype=torch.float32):
+def model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep_feats, dtype=torch.float32, force_knn=None):
     """`dtype=torch.float64` evaluates the SAME reference modules in double precision (parameters and inputs are the fp32
     values, cast): the rounding-free limit of the reference's arithmetic.  fp32 gradients of this network carry ~1e-2 of
     summation noise at N = 1024 (both the reference's and any restatement's: tools/grad_conditioning.py), so the double
@@ -69,7 +69,7 @@ def model_case(RefModels, ref_mu, ref_mlsp, seed, B, N, keep_feats, dtype=torch.
     import model_utils as bare_mu   # Models.py:10 imported get_graph_feature from the bare module
 
     def logging_knn(x, k):
-        i = orig_knn(x, k)
+        i = orig_knn(x, k) if force_knn is None else force_knn[len(knn_log)].clone()
         knn_log.append(i)
         return i
     bare_mu.knn = logging_knn
@@ -434,8 +434,16 @@ def main_round2():
     """Round-2 fixtures: the reference in float64 at N = 1024 (gradient pin at full N) and PointSegDA with K = 40."""
     RefModels, ref_mu, ref_mlsp = ref_import.import_reference()
     torch.set_num_threads(8)
-    np.savez_compressed(os.path.join(OUT, "dgcnn_f64_s3_B4_N1024.npz"),
-                        **model_case(RefModels, ref_mu, ref_mlsp, 3, 4, 1024, False, dtype=torch.float64))
+    f64 = model_case(RefModels, ref_mu, ref_mlsp, 3, 4, 1024, False, dtype=torch.float64)
+    # the reference's OWN fp32 run on the same inputs and graphs: its distance from the double-precision gradients is the
+    # rounding noise of this step in fp32 -- the yardstick the HIP path's fp32 gradients are held to (no worse than that)
+    f32 = model_case(RefModels, ref_mu, ref_mlsp, 3, 4, 1024, False,
+                     force_knn=[torch.from_numpy(f64["knn%d" % i].astype(np.int64)) for i in range(5)])
+    for k in GRAD_KEYS:
+        a, b = f32["grad/" + k].astype(np.float64), f64["grad/" + k]
+        f64["ref32_rel/" + k] = np.array(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+        print("reference fp32 vs float64 %-45s %.2e" % (k, f64["ref32_rel/" + k]))
+    np.savez_compressed(os.path.join(OUT, "dgcnn_f64_s3_B4_N1024.npz"), **f64)
     seg = import_seg_reference()
     np.savez_compressed(os.path.join(OUT, "segda_k40_s2_B2_N512.npz"), **seg_case(seg, 2, 2, 512, K=40))
     for f in ("dgcnn_f64_s3_B4_N1024.npz", "segda_k40_s2_B2_N512.npz"):
