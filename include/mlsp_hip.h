@@ -30,7 +30,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 1
+#define MLSP_ABI_VERSION 2
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -62,13 +62,15 @@ int mlsp_graph_feature_bwd_f32(const float* dF, const int32_t* rev_off, const in
 /* Fused EdgeConv block = get_graph_feature + conv_2d (1x1 Conv2d bias=False + BatchNorm2d + act) + max over k:
  * PointDA/model_utils.py:18-63 with PointDA/Models.py:115-129.  Algebraically folded (edge.hip).
  * W [Cout][2C] in the reference's Conv2d layout.  Saved for backward: uv [P][2Cout], msel [P][Cout],
- * argsel [P][Cout] u8, s1 [P][Cout], bn_save [4][Cout]. */
+ * argsel [P][Cout] u8, s1 [P][Cout], bn_save [4][Cout].  out (row pitch ldo >= Cout) and dOut (row pitch lddo) may be column
+ * slices of a wider matrix: the four EdgeConv outputs are written straight into the [P][512] concatenation of
+ * PointDA/Models.py:131 (no torch.cat pass) and its gradient is read in place. */
 int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int act, float slope, int training,
-                          int B, int N, int C, int Cout, int k, float* out, float* uv, float* msel, uint8_t* argsel,
+                          int B, int N, int C, int Cout, int k, float* out, int ldo, float* uv, float* msel, uint8_t* argsel,
                           float* s1, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
-int mlsp_edgeconv_bwd_f32(const float* dOut, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
-                          const float* W, const float* out, const float* uv, const float* msel, const uint8_t* argsel,
+int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
+                          const float* W, const float* out, int ldo, const float* uv, const float* msel, const uint8_t* argsel,
                           const float* s1, const float* bn_save, int act, float slope, int training, int B, int N, int C,
                           int Cout, int k, float* dx, float* dW, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                           mlsp_stream_t stream);
@@ -93,14 +95,17 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
  * conv_2d / fc_layer (model_utils.py:45-87), conv5+bn5 (Models.py:132), head layers (Models.py:192-196,
  * 226-230, 272-279).  W [Cout][Cin] with row pitch ldw (a column slice of a wider weight is legal).  gbias [G][Cout] (nullable) is a per-row-group bias (row r uses group r / rows_per_group):
  * the x5-repeat half of the heads' 1536-channel input enters as a per-cloud bias (Models.py:156-160).
- * Y = pre-BN (saved), Z = output.  gamma == NULL: no BN (Y is not written, Z = act(linear)). */
+ * Y = pre-BN (saved), Z = output.  gamma == NULL: no BN (Y is not written, Z = act(linear)).
+ * Backward: dx_accumulate != 0 adds the input gradient to what dX already holds (beta = 1 in the dgrad epilogue): the four consumers
+ * of the concatenated encoder features (conv5 and the three heads, Models.py:132,156-160) sum their gradients in one buffer instead of
+ * three 67 MB element-wise adds. */
 int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                           const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                           float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
                           uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                           const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
-                          int n_groups, int rows_per_group, float* dX, int lddx, float* dW, float* dbias, float* dgbias,
+                          int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
                           float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* Fused per-point conv (bias-free) + BatchNorm + act + max over the N points of each cloud:
@@ -114,8 +119,8 @@ int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin,
                                  size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw,
                                  int Cout, const float* out, const float* ysel, const int32_t* arg, const float* bn_save,
-                                 int training, int act, float slope, float* dX, float* dW, float* dgamma, float* dbeta, void* ws,
-                                 size_t ws_bytes, mlsp_stream_t stream);
+                                 int training, int act, float slope, float* dX, int dx_accumulate, float* dW, float* dgamma, float* dbeta,
+                                 void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* max over the k edges of every point (`.max(dim=-1)`, model_utils.py:114) on an edge-major matrix */
 int mlsp_segmax_fwd_f32(const float* Z, int P, int k, int C, float* out, uint8_t* argk, mlsp_stream_t stream);

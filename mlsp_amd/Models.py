@@ -14,24 +14,25 @@ from .model_utils import transform_net, conv_2d, fc_layer, classifier, _bn_buffe
 K = 20   # Models.py:13
 
 
-def _bn_layer(X, conv, bn, training, act, p_drop=0.0, gbias=None, rows_per_group=0, W=None):
+def _bn_layer(X, conv, bn, training, act, p_drop=0.0, gbias=None, rows_per_group=0, W=None, grad_accum=None):
     """Conv1d(k=1, bias=False) + BatchNorm1d + act (+dropout) on a [rows, Cin] matrix."""
     rm, rv = _bn_buffers(bn, training)
     if W is None:
         W = conv.weight.view(conv.out_channels, conv.in_channels)
     return Fh.pointmlp(X, W, bias=conv.bias, gbias=gbias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
                        rows_per_group=rows_per_group, training=training, act=act, slope=0.2, p_drop=p_drop,
-                       momentum=bn.momentum, eps=bn.eps)
+                       momentum=bn.momentum, eps=bn.eps, grad_accum=grad_accum)
 
 
-def _first_head_layer(head, x_cat, x5, N, act, p_drop):
+def _first_head_layer(head, x_cat, x5, N, act, p_drop, grad_accum=None):
     """conv1 of a head on cat(x_cat, x5 repeated over N) (Models.py:156-160) without building the
     [B,1536,N] tensor: the x5 half of the weight acts on one row per cloud and enters as a per-cloud bias."""
     W = head.conv1.weight.view(head.conv1.out_channels, head.conv1.in_channels)
     Cc = x_cat.shape[1]
-    gb = Fh.pointmlp(x5, W[:, Cc:], training=head.training)            # [B, Cout]
+    Wc, W5 = Fh.split_columns(W, Cc)
+    gb = Fh.pointmlp(x5, W5, training=head.training)                   # [B, Cout]
     return _bn_layer(x_cat, head.conv1, head.bn1, head.training, act, p_drop=p_drop, gbias=gb, rows_per_group=N,
-                     W=W[:, :Cc])
+                     W=Wc, grad_accum=grad_accum)
 
 
 class _RegionHead(nn.Module):
@@ -57,8 +58,8 @@ class _RegionHead(nn.Module):
         h = Fh.pointmlp(h, self.conv4.weight.view(3, self.of3), training=self.training)
         return h.view(B, N, 3)                                       # == x.permute(0,2,1) of the reference
 
-    def rows(self, x_cat, x5, B, N):
-        h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p)
+    def rows(self, x_cat, x5, B, N, grad_accum=None):
+        h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p, grad_accum)
         return self._tail(h, B, N)
 
     @flushing_forward
@@ -108,8 +109,8 @@ class Density_prediction(nn.Module):
         logits = Fh.pointmlp(h, self.mlp3.weight, bias=self.mlp3.bias, training=self.training)
         return Fh.density_tail(logits, self.fc2.weight)
 
-    def rows(self, x_cat, x5, B, N):
-        h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p)
+    def rows(self, x_cat, x5, B, N, grad_accum=None):
+        h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p, grad_accum)
         return self._tail(h)
 
     @flushing_forward
@@ -199,31 +200,44 @@ class DGCNN(nn.Module):
         T = self.input_transform_net.points(xp0, g0, B, N, k)                    # [B,3,3]
         xp = torch.bmm(xp0.view(B, N, 3), T.transpose(1, 2)).view(B * N, 3)      # (T @ x)^T
 
-        feats = []
-        h = xp
-        for conv in (self.conv1, self.conv2, self.conv3, self.conv4):              # Models.py:115-129
+        # EdgeConv 1-4 (Models.py:115-129) write their outputs straight into the column slices of the [P,512] concatenation
+        # (:131): no torch.cat pass forward, no split copies backward
+        convs = (self.conv1, self.conv2, self.conv3, self.conv4)
+        x_cat_buf = torch.empty((B * N, sum(c.conv[0].out_channels for c in convs)), dtype=torch.float32, device=x.device)
+        feats, h, col = [], xp, 0
+        for conv in convs:
             g = Fh.knn_graph(h, B, N, k)
-            h = conv.edge(h, g)
+            w = conv.conv[0].out_channels
+            h = conv.edge(h, g, out=x_cat_buf[:, col:col + w])
             feats.append(h)
-        x_cat = torch.cat(feats, dim=1)                                            # [P,512]
+            col += w
+        x_cat = Fh.join_columns(x_cat_buf, feats)                                  # [P,512]
+
+        # conv5 and every active head read x_cat: their input gradients are summed in ONE buffer (functional.SharedInputGrad)
+        heads = []
+        if not visualization:
+            if activate_DefRec:
+                heads.append(("DefRec", self.DefRec))
+            if activate_normal:
+                heads.append(("Normal", self.Norm_pred))
+            if activate_scan:
+                heads.append(("Rec_scan", self.Rec_scan))
+            if activate_density:
+                heads.append(("density", self.Density_cls))
+            if activate_density_normal_ondef:
+                heads += [("DefRec", self.DefRec), ("density", self.Density_cls), ("Normal", self.Norm_pred)]
+        aliases, acc = Fh.fan_out(x_cat, 1 + len(heads))
         rm5, rv5 = _bn_buffers(self.bn5, self.training)                             # conv5+bn5+LReLU+max (Models.py:132-136)
-        x5 = Fh.pointmlp_colmax(x_cat, self.conv5.weight.view(1024, -1), self.bn5.weight, self.bn5.bias, rm5, rv5, B, N,
+        x5 = Fh.pointmlp_colmax(aliases[0], self.conv5.weight.view(1024, -1), self.bn5.weight, self.bn5.bias, rm5, rv5, B, N,
                                 training=self.training, act=Fh.ACT_LRELU, slope=0.2, momentum=self.bn5.momentum,
-                                eps=self.bn5.eps)                                  # [B,1024]
+                                eps=self.bn5.eps, grad_accum=acc)                  # [B,1024]
 
         logits["cls"] = self.C(x5)
         if visualization:
             return x5
-        if activate_DefRec:
-            logits["DefRec"] = self.DefRec.rows(x_cat, x5, B, N)
-        if activate_normal:
-            logits["Normal"] = self.Norm_pred.rows(x_cat, x5, B, N)
-        if activate_scan:
-            logits["Rec_scan"] = self.Rec_scan.rows(x_cat, x5, B, N)
-        if activate_density:
-            logits['density'], logits['density_mse'] = self.Density_cls.rows(x_cat, x5, B, N)
-        if activate_density_normal_ondef:
-            logits["DefRec"] = self.DefRec.rows(x_cat, x5, B, N)
-            logits['density'], logits['density_mse'] = self.Density_cls.rows(x_cat, x5, B, N)
-            logits["Normal"] = self.Norm_pred.rows(x_cat, x5, B, N)
+        for (key, head), xa in zip(heads, aliases[1:]):
+            if key == "density":
+                logits['density'], logits['density_mse'] = head.rows(xa, x5, B, N, grad_accum=acc)
+            else:
+                logits[key] = head.rows(xa, x5, B, N, grad_accum=acc)
         return logits

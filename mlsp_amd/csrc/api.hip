@@ -7,7 +7,8 @@
 // ---- launchers implemented in the other translation units -----------------------------------
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
-                double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr, int* sel_row = nullptr);
+                double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr, int* sel_row = nullptr,
+                bool accumulate = false);
 int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, int panel_rows,
                          float* ysel, int* arg);
 int gemm_panel_rows(int M, int N, int K);
@@ -57,18 +58,19 @@ int launch_colmax_bwd(hipStream_t st, const float* dOut, const int* arg, int B, 
 int launch_segmax_fwd(hipStream_t st, const float* Z, int P, int k, int C, float* out, uint8_t* argk);
 int launch_segmax_bwd(hipStream_t st, const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ);
 int edge_reduce_parts(int P);
-int edge_bwd_reduce_parts(int P, int Cout, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f);
+int edge_bwd_reduce_parts(int P, int Cout, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f,
+                          int lddo, int ldo);
 int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd);
 int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW);
 int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
                        float* msel, uint8_t* argsel, float* s1, double* part, int* nparts_used);
 int launch_edge_select_act(hipStream_t st, const float* msel, const float* uv, int P, int Cout, const float* scale,
-                           const float* shift, int act, float slope, float* out);
+                           const float* shift, int act, float slope, float* out, int ldo);
 int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, const float* msel, const float* uv, int P,
-                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part);
+                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part, int lddo, int ldo);
 int launch_edge_bwd_point(hipStream_t st, const float* dOut, const float* out, const float* uv, const float* s1, int P,
                           int Cout, int k, const float* scale, const float* mean, const float* invstd, const float* mean_dz,
-                          const float* mean_dzy, int act, float slope, float* gz, float* duv);
+                          const float* mean_dzy, int act, float slope, float* gz, float* duv, int lddo, int ldo);
 int launch_edge_bwd_gather(hipStream_t st, const float* gz, const uint8_t* argsel, const float* uv, const int* rev_off,
                            const int* rev_ent, int P, int N, int Cout, const float* scale, const float* mean,
                            const float* invstd, const float* mean_dz, const float* mean_dzy, float* duv);
@@ -216,10 +218,10 @@ int mlsp_graph_feature_bwd_f32(const float* dF, const int32_t* rev_off, const in
 
 int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int act, float slope, int training,
-                          int B, int N, int C, int Cout, int k, float* out, float* uv, float* msel, uint8_t* argsel,
+                          int B, int N, int C, int Cout, int k, float* out, int ldo, float* uv, float* msel, uint8_t* argsel,
                           float* s1, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     if (!x || !idx || !W || !gamma || !beta || !out || !uv || !msel || !argsel || !s1 || !bn_save) return MLSP_ERR_ARG;
-    if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || k > 255 || ldx < C) return MLSP_ERR_ARG;
+    if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || k > 255 || ldx < C || ldo < Cout) return MLSP_ERR_ARG;
     const int P = B * N;
     Workspace w(ws, ws_bytes);
     float* Wd = w.take<float>((size_t)2 * Cout * C);
@@ -239,19 +241,19 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
         if (!run_mean || !run_var) return MLSP_ERR_ARG;
         CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
     }
-    CHECK(launch_edge_select_act(st, msel, uv, P, Cout, scale, shift, act, slope, out));
+    CHECK(launch_edge_select_act(st, msel, uv, P, Cout, scale, shift, act, slope, out, ldo));
     return MLSP_OK;
 }
 
-int mlsp_edgeconv_bwd_f32(const float* dOut, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
-                          const float* W, const float* out, const float* uv, const float* msel, const uint8_t* argsel,
+int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
+                          const float* W, const float* out, int ldo, const float* uv, const float* msel, const uint8_t* argsel,
                           const float* s1, const float* bn_save, int act, float slope, int training, int B, int N, int C,
                           int Cout, int k, float* dx, float* dW, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                           mlsp_stream_t st) {
     if (!dOut || !x || !rev_off || !rev_ent || !W || !out || !uv || !msel || !argsel || !s1 || !bn_save || !dW || !dgamma ||
         !dbeta)
         return MLSP_ERR_ARG;
-    if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || ldx < C) return MLSP_ERR_ARG;
+    if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || ldx < C || lddo < Cout || ldo < Cout) return MLSP_ERR_ARG;
     const int P = B * N;
     Workspace w(ws, ws_bytes);
     float* Wd = w.take<float>((size_t)2 * Cout * C);
@@ -267,11 +269,11 @@ int mlsp_edgeconv_bwd_f32(const float* dOut, const float* x, int ldx, const int3
     float* slab = sf ? w.take<float>(sf) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float* scale = bn_save, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
-    CHECK(launch_edge_bwd_reduce(st, dOut, out, msel, uv, P, Cout, mean, invstd, act, slope, part));
-    CHECK(launch_bn_bwd_finalize(st, part, edge_bwd_reduce_parts(P, Cout, dOut, out, msel, uv, mean, invstd), (double)P * k, Cout,
+    CHECK(launch_edge_bwd_reduce(st, dOut, out, msel, uv, P, Cout, mean, invstd, act, slope, part, lddo, ldo));
+    CHECK(launch_bn_bwd_finalize(st, part, edge_bwd_reduce_parts(P, Cout, dOut, out, msel, uv, mean, invstd, lddo, ldo), (double)P * k, Cout,
                                  dgamma, dbeta, mean_dz, mean_dzy));
     const float* mdz = training ? mean_dz : nullptr;
-    CHECK(launch_edge_bwd_point(st, dOut, out, uv, s1, P, Cout, k, scale, mean, invstd, mdz, mean_dzy, act, slope, gz, duv));
+    CHECK(launch_edge_bwd_point(st, dOut, out, uv, s1, P, Cout, k, scale, mean, invstd, mdz, mean_dzy, act, slope, gz, duv, lddo, ldo));
     CHECK(launch_edge_bwd_gather(st, gz, argsel, uv, rev_off, rev_ent, P, N, Cout, scale, mean, invstd, mdz, mean_dzy, duv));
     CHECK(launch_build_wd(st, W, Cout, C, Wd));
     if (dx) CHECK(launch_gemm(st, false, false, P, C, 2 * Cout, duv, 2 * Cout, Wd, C, dx, C, nullptr, nullptr, 0, slab, sf));
@@ -422,7 +424,7 @@ int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* 
 
 int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                           const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
-                          int n_groups, int rows_per_group, float* dX, int lddx, float* dW, float* dbias, float* dgbias,
+                          int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
                           float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     if (!dZ || !X || !W || !dW || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
     if (has_bn && (!Y || !bn_save || !dgamma || !dbeta)) return MLSP_ERR_ARG;
@@ -448,7 +450,8 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
                                 training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy));
         g = dY;
     }
-    if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf));
+    if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf, nullptr, nullptr,
+                              nullptr, nullptr, dx_accumulate != 0));
     CHECK(launch_gemm(st, true, false, Cout, Cin, M, g, Cout, X, ldx, dW, Cin, nullptr, nullptr, 0, slab, sf));
     if (dbias) {
         if (has_bn && training) {
@@ -503,8 +506,8 @@ int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin,
 
 int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw,
                                  int Cout, const float* out, const float* ysel, const int32_t* arg, const float* bn_save,
-                                 int training, int act, float slope, float* dX, float* dW, float* dgamma, float* dbeta, void* ws,
-                                 size_t ws_bytes, mlsp_stream_t st) {
+                                 int training, int act, float slope, float* dX, int dx_accumulate, float* dW, float* dgamma, float* dbeta,
+                                 void* ws, size_t ws_bytes, mlsp_stream_t st) {
     if (!dOut || !X || !W || !out || !ysel || !arg || !bn_save || !dW || !dgamma || !dbeta) return MLSP_ERR_ARG;
     if (B <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || ldx != Cin || ldw < Cin) return MLSP_ERR_ARG;
     const int P = B * N;
@@ -542,8 +545,9 @@ int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int
             CHECK(launch_scale_rows(st, W, ldw, coef + 3 * Cout, Cout, Cin, Wb));                     // -Bc * W
             CHECK(launch_gemm(st, true, false, Cin, Cin, Cout, Wb, Cin, W, ldw, Mneg, Cin, nullptr, nullptr, 0, slab, sf));
             CHECK(launch_wt_vec_neg(st, W, ldw, coef + 2 * Cout, Cout, Cin, negr));
-            CHECK(launch_gemm(st, false, false, P, Cin, Cin, X, ldx, Mneg, Cin, dX, Cin, negr, nullptr, 0, slab, sf));
-        } else {
+            CHECK(launch_gemm(st, false, false, P, Cin, Cin, X, ldx, Mneg, Cin, dX, Cin, negr, nullptr, 0, slab, sf, nullptr, nullptr,
+                              nullptr, nullptr, dx_accumulate != 0));
+        } else if (!dx_accumulate) {
             hipError_t e = hipMemsetAsync(dX, 0, (size_t)P * Cin * sizeof(float), st);
             if (e != hipSuccess) return (int)e;
         }

@@ -321,12 +321,12 @@ __global__ __launch_bounds__(256) void edge_bwd_gather_vec_kernel(const float* _
 __global__ __launch_bounds__(256) void edge_select_act_kernel(const float* __restrict__ msel, const float* __restrict__ uv,
                                                               int P, int Cout, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int act, float slope,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int ldo) {
     size_t total = (size_t)P * Cout;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         size_t i = t / Cout; int c = (int)(t % Cout);
         float y = msel[t] + uv[i * 2 * Cout + Cout + c];
-        out[t] = lrelu_or_relu(fmaf(y, scale[c], shift[c]), act, slope);
+        out[i * ldo + c] = lrelu_or_relu(fmaf(y, scale[c], shift[c]), act, slope);
     }
 }
 
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __res
                                                               const float* __restrict__ msel, const float* __restrict__ uv,
                                                               int P, int Cout, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, int act, float slope,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, int lddo, int ldo) {
     __shared__ double sh[2][4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __res
         float mu = mean[c], is = invstd[c];
         for (int r = r0 + w; r < r1; r += 4) {
             size_t t = (size_t)r * Cout + c;
-            float d = dOut[t];
-            if (act && !(out[t] > 0.f)) d *= (act == 1 ? 0.f : slope);
+            float d = dOut[(size_t)r * lddo + c];
+            if (act && !(out[(size_t)r * ldo + c] > 0.f)) d *= (act == 1 ? 0.f : slope);
             float yh = (msel[t] + uv[(size_t)r * 2 * Cout + Cout + c] - mu) * is;
             s += d; q += (double)d * yh;
         }
@@ -368,12 +368,12 @@ __global__ __launch_bounds__(256) void edge_bwd_point_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ mean_dz,
                                                              const float* __restrict__ mean_dzy, int act, float slope,
-                                                             float* __restrict__ gz, float* __restrict__ duv) {
+                                                             float* __restrict__ gz, float* __restrict__ duv, int lddo, int ldo) {
     size_t total = (size_t)P * Cout;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         size_t i = t / Cout; int c = (int)(t % Cout);
-        float d = dOut[t];
-        if (act && !(out[t] > 0.f)) d *= (act == 1 ? 0.f : slope);
+        float d = dOut[i * lddo + c];
+        if (act && !(out[i * ldo + c] > 0.f)) d *= (act == 1 ? 0.f : slope);
         float sc = scale[c];
         float g = sc * d;
         gz[t] = g;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_vec_kernel(const float* _
                                                                   const float* __restrict__ msel, const float* __restrict__ uv,
                                                                   int P, int Cout, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, int act, float slope,
-                                                                  double* __restrict__ part) {
+                                                                  double* __restrict__ part, int lddo, int ldo) {
     __shared__ double shd[256 * 8];
     const int tid = threadIdx.x, tpr = Cout >> 2, nrg = 256 / tpr;
     const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
@@ -403,7 +403,8 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_vec_kernel(const float* _
     const int r0 = blockIdx.x * EVROWS, r1 = min(P, r0 + EVROWS);
     for (int r = r0 + rg; r < r1; r += nrg) {
         const size_t t = (size_t)r * Cout + c;
-        const f32x4 d4 = *(const f32x4*)(dOut + t), o4 = *(const f32x4*)(out + t), m4 = *(const f32x4*)(msel + t);
+        const f32x4 d4 = *(const f32x4*)(dOut + (size_t)r * lddo + c), o4 = *(const f32x4*)(out + (size_t)r * ldo + c);
+        const f32x4 m4 = *(const f32x4*)(msel + t);
         const f32x4 v4 = *(const f32x4*)(uv + (size_t)r * 2 * Cout + Cout + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_vec_kernel(const float* _
 __global__ __launch_bounds__(256) void edge_select_act_vec_kernel(const float* __restrict__ msel, const float* __restrict__ uv,
                                                                   size_t total4, int C4, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, int act, float slope,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, int ldo) {
     for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
         const size_t i = v / C4; const int c = (int)(v % C4) * 4;
         const f32x4 m = *(const f32x4*)(msel + v * 4), vv = *(const f32x4*)(uv + i * 8 * C4 + 4 * C4 + c);
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void edge_select_act_vec_kernel(const float* _
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = lrelu_or_relu(fmaf(m[e] + vv[e], sc[e], sh[e]), act, slope);
-        *(f32x4*)(out + v * 4) = o;
+        *(f32x4*)(out + i * ldo + c) = o;
     }
 }
 
@@ -449,11 +450,11 @@ __global__ __launch_bounds__(256) void edge_bwd_point_vec_kernel(const float* __
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  const float* __restrict__ mean_dz, const float* __restrict__ mean_dzy,
                                                                  int act, float slope, float* __restrict__ gz,
-                                                                 float* __restrict__ duv) {
+                                                                 float* __restrict__ duv, int lddo, int ldo) {
     const float fk = (float)k;
     for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
         const size_t i = v / C4; const int c = (int)(v % C4) * 4;
-        const f32x4 d4 = *(const f32x4*)(dOut + v * 4), o4 = *(const f32x4*)(out + v * 4);
+        const f32x4 d4 = *(const f32x4*)(dOut + i * lddo + c), o4 = *(const f32x4*)(out + i * ldo + c);
         const f32x4 sc = *(const f32x4*)(scale + c);
         f32x4 g, dv;
 #pragma unroll
@@ -554,8 +555,9 @@ static inline int ew_blocks2(size_t total) {
 }
 
 // number of partial rows launch_edge_bwd_reduce writes for this shape
-int edge_bwd_reduce_parts(int P, int Cout, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
-    bool vec = Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 &&
+int edge_bwd_reduce_parts(int P, int Cout, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f,
+                          int lddo, int ldo) {
+    bool vec = Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 && lddo % 4 == 0 && ldo % 4 == 0 &&
                ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f) & 15) == 0);
     return vec ? (P + EVROWS - 1) / EVROWS : (P + 511) / 512;
 }
@@ -606,42 +608,42 @@ int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const fl
     return mlsp_launch_status();
 }
 int launch_edge_select_act(hipStream_t st, const float* msel, const float* uv, int P, int Cout, const float* scale,
-                           const float* shift, int act, float slope, float* out) {
-    if (Cout % 4 == 0 && ((((uintptr_t)msel | (uintptr_t)uv | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0)) {
+                           const float* shift, int act, float slope, float* out, int ldo) {
+    if (Cout % 4 == 0 && ldo % 4 == 0 && ((((uintptr_t)msel | (uintptr_t)uv | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0)) {
         size_t t4 = (size_t)P * Cout / 4;
         hipLaunchKernelGGL(edge_select_act_vec_kernel, dim3(ew_blocks2(t4)), dim3(256), 0, st, msel, uv, t4, Cout / 4, scale, shift,
-                           act, slope, out);
+                           act, slope, out, ldo);
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(edge_select_act_kernel, dim3(ew_blocks2((size_t)P * Cout)), dim3(256), 0, st, msel, uv, P, Cout, scale,
-                       shift, act, slope, out);
+                       shift, act, slope, out, ldo);
     return mlsp_launch_status();
 }
 int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, const float* msel, const float* uv, int P,
-                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part) {
-    if (Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 &&
+                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part, int lddo, int ldo) {
+    if (Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 && lddo % 4 == 0 && ldo % 4 == 0 &&
         ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)msel | (uintptr_t)uv | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)) {
         // NOTE: writes (P+1023)/1024 partial rows -- callers size `part` for (P+511)/512 and pass the count below
         hipLaunchKernelGGL(edge_bwd_reduce_vec_kernel, dim3((P + EVROWS - 1) / EVROWS), dim3(256), 0, st, dOut, out, msel, uv, P, Cout,
-                           mean, invstd, act, slope, part);
+                           mean, invstd, act, slope, part, lddo, ldo);
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3((Cout + 63) / 64, (P + 511) / 512), dim3(256), 0, st, dOut, out, msel, uv,
-                       P, Cout, mean, invstd, act, slope, part);
+                       P, Cout, mean, invstd, act, slope, part, lddo, ldo);
     return mlsp_launch_status();
 }
 int launch_edge_bwd_point(hipStream_t st, const float* dOut, const float* out, const float* uv, const float* s1, int P,
                           int Cout, int k, const float* scale, const float* mean, const float* invstd, const float* mean_dz,
-                          const float* mean_dzy, int act, float slope, float* gz, float* duv) {
-    if (Cout % 4 == 0 && ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)uv | (uintptr_t)s1 | (uintptr_t)gz | (uintptr_t)duv |
+                          const float* mean_dzy, int act, float slope, float* gz, float* duv, int lddo, int ldo) {
+    if (Cout % 4 == 0 && lddo % 4 == 0 && ldo % 4 == 0 && ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)uv | (uintptr_t)s1 | (uintptr_t)gz | (uintptr_t)duv |
                             (uintptr_t)scale) & 15) == 0)) {
         size_t t4 = (size_t)P * Cout / 4;
         hipLaunchKernelGGL(edge_bwd_point_vec_kernel, dim3(ew_blocks2(t4)), dim3(256), 0, st, dOut, out, uv, s1, t4, Cout / 4, k, scale,
-                           mean, invstd, mean_dz, mean_dzy, act, slope, gz, duv);
+                           mean, invstd, mean_dz, mean_dzy, act, slope, gz, duv, lddo, ldo);
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(edge_bwd_point_kernel, dim3(ew_blocks2((size_t)P * Cout)), dim3(256), 0, st, dOut, out, uv, s1, P, Cout,
-                       k, scale, mean, invstd, mean_dz, mean_dzy, act, slope, gz, duv);
+                       k, scale, mean, invstd, mean_dz, mean_dzy, act, slope, gz, duv, lddo, ldo);
     return mlsp_launch_status();
 }
 int launch_edge_bwd_gather(hipStream_t st, const float* gz, const uint8_t* argsel, const float* uv, const int* rev_off,

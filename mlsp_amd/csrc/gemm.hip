@@ -33,6 +33,7 @@ struct GemmArgs {
     int ntm, ntn, nsplit, ksplit;   // tiles; split-K count; K range per split (multiple of BK)
     int a_vec, b_vec;               // 1 if float4 global loads are legal for that operand
     int xcd_map;                    // 1: XCD-grouped block->tile map (grid padded to a multiple of 8 panels)
+    int accumulate;                 // 1: C += result (beta = 1): several consumers of one activation sum their input gradients in place
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][N] (BN batch statistics)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
     float* sel_val; int* sel_row;   // [ntm][N] extreme of each 128-row panel and the global row attaining it (first occurrence)
@@ -128,6 +129,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
                 if (FAST || row < p.M) {
                     float v = acc[i][j][r] + bv;
                     if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
+                    if (epi && p.accumulate) v += Cout[(size_t)row * p.ldc + col];
 #ifdef GP_NOSTORE
                     if (p.C && v == 12345.678f) Cout[(size_t)row * p.ldc + col] = v;
 #else
@@ -593,9 +595,11 @@ int gemm_stat_parts(int M, int N, int K) {
 }
 int gemm_panel_rows(int M, int N, int K) { return gemm_pick_bm(M, N, K); }
 
+size_t thin_tn_slab_floats(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K) {
     int ns = gemm_pick_split(M, N, K);
-    return ns > 1 ? (size_t)ns * M * N : 0;
+    const size_t a = ns > 1 ? (size_t)ns * M * N : 0, b = thin_tn_slab_floats(M, N, K);      // thin.hip: A^T B with one side <= 16
+    return a > b ? a : b;
 }
 
 // ---- optional HIP-event profiling of the GEMM launches (bench.py roofline) -----------------------
@@ -647,14 +651,21 @@ extern "C" int mlsp_profile_end(double* out) {
 
 int launch_skinny_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                        float* C, int ldc, const float* bias);
+int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                     int ldc, const float* bias, float* slab, size_t slab_floats);
 
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                 size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
-                int* sel_row = nullptr) {
+                int* sel_row = nullptr, bool accumulate = false) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
+    // one tiny dimension (3 coordinates, 3 / 16 outputs): streaming VALU kernels priced against HBM, not MFMA tiles (thin.hip)
+    if (!gbias && !stat_part && !sel_gamma && !accumulate) {
+        const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats);
+        if (rc != MLSP_ERR_UNSUPPORTED) return rc;
+    }
     // per-cloud layers (<= 32 rows, or a 32-deep wgrad): one-pass skinny kernels, no split-K slab (skinny.hip)
-    if (!gbias && !stat_part && !sel_gamma && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
+    if (!gbias && !stat_part && !sel_gamma && !accumulate && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
         const int rc = launch_skinny_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
@@ -665,6 +676,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.rows_per_group = rows_per_group;
     int ns = gemm_pick_split(M, N, K);
     if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;   // no slab: fall back to one pass
+    if (accumulate) ns = 1;                                              // beta = 1 lives in the one-pass epilogue
+    p.accumulate = accumulate ? 1 : 0;
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
     p.stat_part = stat_part;
     p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;

@@ -846,7 +846,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
     constexpr int TILE = CT * KM_STRIDE;
     constexpr int NSTEP = CT / 2;
     constexpr int SPR = NSTEP >= 16 ? NSTEP / 16 : 1;      // MFMA steps issued per query row of the select loop
-    constexpr int GS = (KB && CT == 128) ? 8 : NSTEP >= 16 ? 16 : NSTEP;   // B fragments fetched per group (the k > 24 variant at C = 128 is out of registers)
+    constexpr int GS = (KB && CT == 128) ? 4 : NSTEP >= 16 ? 16 : NSTEP;   // B fragments fetched per group (the k > 24 variant at C = 128 is out of registers)
     constexpr int NG = NSTEP / GS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -1283,11 +1283,13 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
                         const bool uplt = (l31 > 0) && (upv < xv);
                         if (active && lt) { lvA[r] = uplt ? upv : xv; liA[r] = uplt ? upi : xj; }
                     }
-                    {
+                    {   // an element pushed out of the first level precedes EVERYTHING in the second (it was ahead of it in the total
+                        // order, ties included): it becomes position 32 and the whole level shifts; a fresh candidate is inserted
+                        // behind its equals like in the first level
                         const float upv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lvB[r]), 0x138, 0xf, 0xf, false));
                         const int upi = __builtin_amdgcn_update_dpp(0, liB[r], 0x138, 0xf, 0xf, false);
-                        const bool lt = lvB[r] < yv;
-                        const bool uplt = (l31 > 0) && (upv < yv);
+                        const bool lt = intoA || lvB[r] < yv;
+                        const bool uplt = (l31 > 0) && (intoA || upv < yv);
                         if (active && lt) { lvB[r] = uplt ? upv : yv; liB[r] = uplt ? upi : yj; }
                     }
                     lo &= lo - 1; hi &= hi - 1;

@@ -1,0 +1,191 @@
+// "Thin" GEMMs: one dimension of the contraction is tiny (3 coordinates, 3 / 16 outputs) while the row count is the point count.
+// On the 128x128 MFMA tiles these launches ran at 1-10 TFLOP/s (a 3-deep K or a 3-wide N wastes 97 % of every tile) and cost
+// 0.31 ms of the 7 ms step for 0.4 % of its FLOPs (round-1 verdict).  They are pure streaming: every byte of the big operand is
+// read or written exactly once, so they are priced against HBM bandwidth, not against the MFMA roof:
+//
+//   thin_smallk   C[M,N] = A[M,K] * op(B) (+bias),  K <= 16   first layer of the graph stages (x [P,3] -> [u|v] [P,128]), dgrad of
+//                                                              the heads' 128->3 / 256->16 output layers
+//   thin_smalln   C[M,N] = A[M,K] * op(B) (+bias),  N <= 16   the heads' output layers (128->3, 256->16), dgrad of the first layer
+//   thin_tn       C[M,N] = A[K,M]^T * B[K,N], min(M,N) <= 16  their weight gradients (K = point count): column reduction of a
+//                                                              [P, <=16] x [P, wide] outer product, partial slabs + fixed-order reduce
+//
+// fp32 VALU FMAs: the arithmetic is negligible (<= 16 FMAs per loaded or stored float).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------- small K
+// thread = (row, column quad); lanes of a wave cover consecutive quads of a row (16-byte coalesced stores), the K values of the row
+// are wave-broadcast loads.  B is staged once per workgroup as Bs[k][n].
+template <bool TB>
+__global__ __launch_bounds__(256) void thin_smallk_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
+                                                          int K, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];          // [K][N]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < K * N; i += 256) {
+        const int k = i / N, n = i - k * N;
+        Bs[i] = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
+    }
+    __syncthreads();
+    const int nq = N >> 2;
+    const int row0 = blockIdx.x * rows_per_block;
+    for (int i = tid; i < rows_per_block * nq; i += 256) {
+        const int r = row0 + i / nq, q = i % nq;
+        if (r >= M) break;
+        const float* a = A + (size_t)r * lda;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < K; ++k) {
+            const float av = a[k];
+            const f32x4 bv = *(const f32x4*)(Bs + k * N + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(av, bv[e], acc[e]);
+        }
+        if (bias) {
+            const f32x4 bb = *(const f32x4*)(bias + 4 * q);
+            acc = acc + bb;
+        }
+        *(f32x4*)(C + (size_t)r * ldc + 4 * q) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- small N
+// 16 lanes per row: lane g takes the k-quads g, g+16, ... of the row (16-byte coalesced loads), keeps N partial dot products, and the
+// 16 partials of a row are summed with xor-shuffles in a fixed order.  B is staged as Bs[n][k].
+template <bool TB, int NMAX>
+__global__ __launch_bounds__(256) void thin_smalln_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
+                                                          int K) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];          // [N][K]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < K * N; i += 256) {
+        const int n = i / K, k = i - n * K;
+        Bs[i] = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
+    }
+    __syncthreads();
+    const int g = tid & 15, sub = tid >> 4;                              // 16 row slots per workgroup pass
+    const int kq = K >> 2;
+    for (int r = blockIdx.x * 16 + sub; r < M; r += gridDim.x * 16) {
+        const float* a = A + (size_t)r * lda;
+        float acc[NMAX];
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+        for (int q = g; q < kq; q += 16) {
+            const f32x4 av = *(const f32x4*)(a + 4 * q);
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                if (n < N) {
+                    const f32x4 bv = *(const f32x4*)(Bs + n * K + 4 * q);
+                    acc[n] = fmaf(av[3], bv[3], fmaf(av[2], bv[2], fmaf(av[1], bv[1], fmaf(av[0], bv[0], acc[n]))));
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o, 64);
+        }
+        // lane g writes column g (N <= 16): a 4N-byte contiguous run per row
+        float out = 0.f;
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) out = (g == n) ? acc[n] : out;
+        if (g < N) C[(size_t)r * ldc + g] = out + (bias ? bias[g] : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- A^T B with one small side
+// D[s][l] = sum_k S[k][s] * L[k][l]  (S: [K, ns <= 16], L: [K, nl], nl % 4 == 0).  A workgroup owns a K chunk: thread = (column quad
+// of L, row group); it accumulates ns x 4 partials over its rows, the row groups are summed through LDS in a fixed order and the
+// chunk's partial goes to slab[chunk] in the layout of C (ds = stride of s, dl = stride of l), reduced afterwards in slab order.
+template <int NS>
+__global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ S, int lds_, const float* __restrict__ L, int ldl,
+                                                      float* __restrict__ slab, size_t slab_stride, int ds, int dl, int K, int ns, int nl,
+                                                      int rows_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float red[];         // [row groups][NS][nl]
+    const int tid = threadIdx.x;
+    const int nq = nl >> 2, ngr = 256 / nq;                              // nq in {32, 64, 128}: 8 / 4 / 2 row groups
+    const int q = tid % nq, gr = tid / nq;
+    const int k0 = blockIdx.x * rows_per_chunk, k1 = min(K, k0 + rows_per_chunk);
+    f32x4 acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (gr < ngr) {
+        for (int k = k0 + gr; k < k1; k += ngr) {
+            const f32x4 lv = *(const f32x4*)(L + (size_t)k * ldl + 4 * q);
+            const float* sp = S + (size_t)k * lds_;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s < ns) {
+                    const float sv = sp[s];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[s][e] = fmaf(sv, lv[e], acc[s][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (s < ns) *(f32x4*)(red + ((size_t)gr * NS + s) * nl + 4 * q) = acc[s];
+    }
+    __syncthreads();
+    float* out = slab + (size_t)blockIdx.x * slab_stride;
+    for (int i = tid; i < ns * nl; i += 256) {
+        const int s = i / nl, l = i - s * nl;
+        float v = 0.f;
+        for (int g2 = 0; g2 < ngr; ++g2) v += red[((size_t)g2 * NS + s) * nl + l];
+        out[(size_t)s * ds + (size_t)l * dl] = v;
+    }
+}
+
+int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int nsplit);
+
+// slab floats the thin TN path needs for (M, N, K) (0: shape not handled here)
+size_t thin_tn_slab_floats(int M, int N, int K) {
+    const bool small_m = M <= 16 && N % 4 == 0 && N >= 128 && N <= 512 && (N & (N - 1)) == 0;
+    const bool small_n = N <= 16 && M % 4 == 0 && M >= 128 && M <= 512 && (M & (M - 1)) == 0;
+    if (!(small_m || small_n) || K < 2048) return 0;
+    const int chunks = (K + 127) / 128;
+    return (size_t)chunks * M * N;
+}
+
+// Returns MLSP_ERR_UNSUPPORTED when the shape is not thin (the caller continues with the MFMA kernels).
+int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                     int ldc, const float* bias, float* slab, size_t slab_floats) {
+    auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    if (!ta && K <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && M >= 1024 && ldc % 4 == 0 && al16(C) && al16(bias)) {
+        const int nq = N / 4;
+        const int rpb = 4 * 256 / nq > 0 ? 4 * 256 / nq : 1;              // four passes of the workgroup per block
+        const size_t lds = (size_t)K * N * sizeof(float);
+        const dim3 grid((M + rpb - 1) / rpb);
+        if (tb) hipLaunchKernelGGL((thin_smallk_kernel<true>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb);
+        else hipLaunchKernelGGL((thin_smallk_kernel<false>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb);
+        return mlsp_launch_status();
+    }
+    if (!ta && N <= 16 && K % 4 == 0 && K >= 64 && K <= 1024 && M >= 1024 && lda % 4 == 0 && al16(A)) {
+        const size_t lds = (size_t)K * N * sizeof(float);
+        int blocks = (M + 15) / 16;
+        if (blocks > 2048) blocks = 2048;
+#define THIN_SN(TBV) do { if (N <= 4) hipLaunchKernelGGL((thin_smalln_kernel<TBV, 4>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K); \
+                          else hipLaunchKernelGGL((thin_smalln_kernel<TBV, 16>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K); } while (0)
+        if (tb) THIN_SN(true); else THIN_SN(false);
+#undef THIN_SN
+        return mlsp_launch_status();
+    }
+    if (ta && !tb && !bias) {
+        const size_t need = thin_tn_slab_floats(M, N, K);
+        if (!need || !slab || slab_floats < need) return MLSP_ERR_UNSUPPORTED;
+        const int chunks = (K + 127) / 128;
+        const bool small_m = M <= 16 && N % 4 == 0 && N >= 128;
+        if (small_m ? (ldb % 4 || !al16(B)) : (lda % 4 || !al16(A))) return MLSP_ERR_UNSUPPORTED;   // the wide operand is read 16 bytes per lane
+        // small side S, large side L; partial slabs are written in C's [M][N] layout
+        const float* S = small_m ? A : B; const int lds_ = small_m ? lda : ldb; const int ns = small_m ? M : N;
+        const float* L = small_m ? B : A; const int ldl = small_m ? ldb : lda; const int nl = small_m ? N : M;
+        const int ds = small_m ? N : 1, dl = small_m ? 1 : N;
+        const int ngr = 256 / (nl / 4);
+#define THIN_TN(NSV) hipLaunchKernelGGL((thin_tn_kernel<NSV>), dim3(chunks), dim3(256), (size_t)ngr * NSV * nl * sizeof(float), st, S, lds_, L, ldl, \
+                                        slab, (size_t)M * N, ds, dl, K, ns, nl, 128)
+        if (ns <= 4) THIN_TN(4); else THIN_TN(16);
+#undef THIN_TN
+        int rc = mlsp_launch_status();
+        if (rc != MLSP_OK) return rc;
+        return launch_slab_reduce(st, slab, C, M, N, ldc, chunks);
+    }
+    return MLSP_ERR_UNSUPPORTED;
+}

@@ -158,9 +158,97 @@ def graph_feature(xp, graph):
     return _GraphFeature.apply(xp, graph)
 
 
+class SharedInputGrad:
+    """Hand-off between the consumers of ONE activation matrix (conv5 and the three heads all read the concatenated encoder
+    features): the first consumer to run backward allocates the input-gradient buffer, the others add into it through the
+    beta = 1 epilogue of their dgrad GEMM and return the same tensor; `fan_out` then passes it upstream once.  Replaces three
+    67 MB element-wise adds of the autograd engine per step."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+    def claim(self, shape, device):
+        """-> (buffer, accumulate flag)"""
+        if self.buf is None:
+            self.buf = torch.empty(shape, dtype=torch.float32, device=device)
+            return self.buf, 0
+        return self.buf, 1
+
+
+class _FanOut(Function):
+    @staticmethod
+    def forward(ctx, X, acc, n):
+        ctx.acc = acc
+        acc.buf = None
+        return tuple(X.view_as(X) for _ in range(n))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        acc, total, seen = ctx.acc, None, False
+        for g in grads:
+            if g is None:
+                continue
+            if acc.buf is not None and g.data_ptr() == acc.buf.data_ptr():
+                if seen:
+                    continue                    # the shared buffer already holds the sum of every consumer that used it
+                seen = True
+            total = g if total is None else total + g
+        acc.buf = None
+        return total, None, None
+
+
+def fan_out(X, n):
+    """n aliases of X for n consumers that support `grad_accum=` (pointmlp, pointmlp_colmax): -> (aliases, SharedInputGrad)."""
+    acc = SharedInputGrad()
+    return _FanOut.apply(X, acc, n), acc
+
+
+class _JoinColumns(Function):
+    """The [P, sum C_i] matrix whose column slices the producers have ALREADY written (edgeconv(out=...)): forward is free,
+    backward hands each producer its column slice of the gradient as a strided view (no torch.cat, no split copies)."""
+
+    @staticmethod
+    def forward(ctx, base, *parts):
+        ctx.widths = [p.shape[1] for p in parts]
+        return base.view_as(base)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        outs, o = [], 0
+        for w in ctx.widths:
+            outs.append(g[:, o:o + w])
+            o += w
+        return (None,) + tuple(outs)
+
+
+def join_columns(base, parts):
+    return _JoinColumns.apply(base, *parts)
+
+
+class _SplitColumns(Function):
+    """(W[:, :c], W[:, c:]) with ONE concatenation in backward (plain slicing costs a zero-fill, a copy and an add per half)."""
+
+    @staticmethod
+    def forward(ctx, W, c):
+        ctx.c = c
+        return W[:, :c], W[:, c:]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ga, gb):
+        return torch.cat((ga, gb), dim=1), None
+
+
+def split_columns(W, c):
+    return _SplitColumns.apply(W, c)
+
+
 class _EdgeConv(Function):
     @staticmethod
-    def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps):
+    def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out_buf=None):
         lib = _lib.load()
         xp = _rows(xp)
         _lib.require_gpu(xp, W2d, gamma)
@@ -169,7 +257,11 @@ class _EdgeConv(Function):
         Cout = W2d.shape[0]
         assert W2d.shape[1] == 2 * C, (W2d.shape, C)
         dev = xp.device
-        out = torch.empty((P, Cout), dtype=torch.float32, device=dev)
+        if out_buf is None:
+            out = torch.empty((P, Cout), dtype=torch.float32, device=dev)
+        else:                                   # a column slice of the caller's concatenation buffer, written in place
+            assert out_buf.shape == (P, Cout) and out_buf.stride(1) == 1 and out_buf.dtype == torch.float32
+            out = out_buf
         uv = torch.empty((P, 2 * Cout), dtype=torch.float32, device=dev)
         msel = torch.empty((P, Cout), dtype=torch.float32, device=dev)
         s1 = torch.empty((P, Cout), dtype=torch.float32, device=dev)
@@ -179,8 +271,10 @@ class _EdgeConv(Function):
         _lib.check(lib.mlsp_edgeconv_fwd_f32(
             xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
             _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, act, slope, int(training), graph.B, graph.N, C, Cout,
-            graph.k, out.data_ptr(), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(), bn_save.data_ptr(),
-            ws, wsn, _lib.stream()), "mlsp_edgeconv_fwd_f32")
+            graph.k, out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
+            bn_save.data_ptr(), ws, wsn, _lib.stream()), "mlsp_edgeconv_fwd_f32")
+        if out_buf is not None:
+            out = out_buf.view_as(out_buf)      # a fresh alias: the Function's output, distinct from its (non-differentiable) input
         ctx.save_for_backward(xp, W2d, out, uv, msel, argsel, s1, bn_save)
         ctx.cfg = (graph, training, act, slope, C, Cout)
         return out
@@ -193,7 +287,7 @@ class _EdgeConv(Function):
         graph, training, act, slope, C, Cout = ctx.cfg
         if graph.rev_off is None:
             raise RuntimeError("EdgeConv backward needs the reverse neighbour index (knn_graph(need_reverse=True))")
-        dOut = dOut.contiguous()
+        dOut = _rows(dOut)                      # a column slice of the concatenation's gradient is read in place
         dev = dOut.device
         P = xp.shape[0]
         need_dx = ctx.needs_input_grad[0]
@@ -203,16 +297,17 @@ class _EdgeConv(Function):
         dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, P, C, 2 * Cout)
         _lib.check(lib.mlsp_edgeconv_bwd_f32(
-            dOut.data_ptr(), xp.data_ptr(), xp.stride(0), graph.rev_off.data_ptr(), graph.rev_ent.data_ptr(),
-            W2d.data_ptr(), out.data_ptr(), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
+            dOut.data_ptr(), dOut.stride(0), xp.data_ptr(), xp.stride(0), graph.rev_off.data_ptr(), graph.rev_ent.data_ptr(),
+            W2d.data_ptr(), out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
             bn_save.data_ptr(), act, slope, int(training), graph.B, graph.N, C, Cout, graph.k, _lib.ptr(dx), dW.data_ptr(),
             dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()), "mlsp_edgeconv_bwd_f32")
-        return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def edgeconv(xp, graph, W2d, gamma, beta, run_mean, run_var, training, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5):
-    """Fused get_graph_feature + conv_2d + max over k (Models.py:115-129).  xp [P,C] -> [P,Cout]."""
-    return _EdgeConv.apply(xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps)
+def edgeconv(xp, graph, W2d, gamma, beta, run_mean, run_var, training, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5, out=None):
+    """Fused get_graph_feature + conv_2d + max over k (Models.py:115-129).  xp [P,C] -> [P,Cout].  `out`: a [P,Cout] column
+    slice of a wider buffer to write the result into (see join_columns)."""
+    return _EdgeConv.apply(xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out)
 
 
 class _TnetEdge(Function):
@@ -280,7 +375,7 @@ def tnet_edge_supported(W1, W2, k):
 class _PointMLP(Function):
     @staticmethod
     def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,
-                momentum, eps):
+                momentum, eps, grad_accum=None):
         lib = _lib.load()
         X = _rows(X)
         _lib.require_gpu(X, W)
@@ -309,6 +404,7 @@ class _PointMLP(Function):
         ctx.save_for_backward(X, W, Y, bn_save)
         ctx.cfg = (has_bn, training, act, slope, p, seed, bias is not None, gbias.shape[0] if gbias is not None else 0,
                    int(rows_per_group))
+        ctx.grad_accum = grad_accum
         return Z
 
     @staticmethod
@@ -321,7 +417,12 @@ class _PointMLP(Function):
         dev = dZ.device
         M, Cin = X.shape
         Cout = W.shape[0]
-        dX = torch.empty((M, Cin), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dX, accumulate = None, 0
+        if ctx.needs_input_grad[0]:
+            if ctx.grad_accum is not None:
+                dX, accumulate = ctx.grad_accum.claim((M, Cin), dev)
+            else:
+                dX = torch.empty((M, Cin), dtype=torch.float32, device=dev)
         dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
         dbias = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bias else None
         dgbias = torch.empty((G, Cout), dtype=torch.float32, device=dev) if G else None
@@ -330,24 +431,26 @@ class _PointMLP(Function):
         ws, wsn = _lib.workspace(dev, M, Cin, Cout)
         _lib.check(lib.mlsp_pointmlp_bwd_f32(
             dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
-            _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, dW.data_ptr(),
+            _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate, dW.data_ptr(),
             _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
             "mlsp_pointmlp_bwd_f32")
-        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 10
+        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 11
 
 
 def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, run_var=None, rows_per_group=0,
-             training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5):
-    """Linear/1x1-conv (+bias, +per-group bias) [+ BatchNorm + act + dropout] on a [M,Cin] row matrix."""
+             training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5, grad_accum=None):
+    """Linear/1x1-conv (+bias, +per-group bias) [+ BatchNorm + act + dropout] on a [M,Cin] row matrix.
+    `grad_accum`: the SharedInputGrad of a fan_out(X, n) whose alias this X is."""
     seed = _next_seed() if (training and p_drop > 0) else 0
     return _PointMLP.apply(X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop,
-                           seed, momentum, eps)
+                           seed, momentum, eps, grad_accum)
 
 
 class _PointMLPColMax(Function):
     @staticmethod
-    def forward(ctx, X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps):
+    def forward(ctx, X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps, grad_accum=None):
         lib = _lib.load()
+        ctx.grad_accum = grad_accum
         X = X.contiguous()
         _lib.require_gpu(X, W)
         if W.stride(1) != 1:
@@ -379,22 +482,28 @@ class _PointMLPColMax(Function):
         dev = dOut.device
         P, Cin = X.shape
         Cout = W.shape[0]
-        dX = torch.empty((P, Cin), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dX, accumulate = None, 0
+        if ctx.needs_input_grad[0]:
+            if ctx.grad_accum is not None:
+                dX, accumulate = ctx.grad_accum.claim((P, Cin), dev)
+            else:
+                dX = torch.empty((P, Cin), dtype=torch.float32, device=dev)
         dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
         dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, max(P, Cout), Cin, max(Cout, Cin))
         _lib.check(lib.mlsp_pointmlp_colmax_bwd_f32(
             dOut.data_ptr(), X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, out.data_ptr(),
-            ysel.data_ptr(), arg.data_ptr(), bn_save.data_ptr(), int(training), act, slope, _lib.ptr(dX), dW.data_ptr(),
+            ysel.data_ptr(), arg.data_ptr(), bn_save.data_ptr(), int(training), act, slope, _lib.ptr(dX), accumulate, dW.data_ptr(),
             dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_bwd_f32")
-        return (dX, dW, dgamma, dbeta) + (None,) * 9
+        return (dX, dW, dgamma, dbeta) + (None,) * 10
 
 
-def pointmlp_colmax(X, W, gamma, beta, run_mean, run_var, B, N, training=True, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5):
+def pointmlp_colmax(X, W, gamma, beta, run_mean, run_var, B, N, training=True, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5,
+                    grad_accum=None):
     """conv (bias-free) + BN + act + max over the N rows of each of the B clouds: [B*N, Cin] -> [B, Cout]
     (Models.py:132-136; model_utils.py:116-117).  Closed-form backward through the Gram matrix (colmax.hip)."""
-    return _PointMLPColMax.apply(X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps)
+    return _PointMLPColMax.apply(X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps, grad_accum)
 
 
 class _SegMax(Function):

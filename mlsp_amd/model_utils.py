@@ -118,14 +118,15 @@ class conv_2d(nn.Module):
         return Fh.pointmlp_colmax(X, conv.weight.view(conv.out_channels, conv.in_channels), bn.weight, bn.bias, rm, rv, B, N,
                                   training=self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps)
 
-    def edge(self, xp, graph):
-        """Fused get_graph_feature + this conv + max over k.  xp [P,C] -> [P,Cout]."""
+    def edge(self, xp, graph, out=None):
+        """Fused get_graph_feature + this conv + max over k.  xp [P,C] -> [P,Cout] (written into `out` when given: a column
+        slice of the caller's concatenation buffer)."""
         conv, bn = self.conv[0], self.conv[1]
         if conv.bias is not None:
             raise NotImplementedError("fused EdgeConv expects bias=False (every DGCNN edge conv)")
         rm, rv = _bn_buffers(bn, self.training)
         return Fh.edgeconv(xp, graph, conv.weight.view(conv.out_channels, conv.in_channels), bn.weight, bn.bias, rm, rv,
-                           self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps)
+                           self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps, out=out)
 
     @flushing_forward
     def forward(self, x):

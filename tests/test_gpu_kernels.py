@@ -165,6 +165,26 @@ def test_gemm_bf16_operand_mode(dev, ta, tb, M, N, K):
     assert (again - opA.double() @ opB.double()).abs().max().item() < 2e-6 * K ** 0.5 * 4 + 1e-6
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K,bias", [(0, 1, 4096, 128, 3, 0), (0, 0, 4096, 128, 3, 0), (0, 0, 2048, 256, 16, 0), (0, 1, 4096, 3, 128, 0),
+                                              (0, 1, 4096, 16, 256, 1), (0, 0, 4096, 3, 128, 0), (1, 0, 3, 128, 4096, 0),
+                                              (1, 0, 16, 256, 8192, 0), (1, 0, 128, 3, 4096, 0), (1, 0, 256, 16, 2048, 0),
+                                              (0, 1, 32768, 128, 3, 1), (1, 0, 3, 128, 32768, 0)])
+def test_thin_gemms(dev, ta, tb, M, N, K, bias):
+    """One tiny dimension (3 coordinates, 3 / 16 outputs): the streaming VALU kernels of thin.hip behind mlsp_gemm_f32."""
+    Fh = _fh()
+    A = _rand((K, M) if ta else (M, K), 21)
+    B = _rand((N, K) if tb else (K, N), 22)
+    bv = _rand((N,), 23) if bias else None
+    want = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    if bias:
+        want = want + bv.double()
+    got = Fh.gemm(A.to(dev), B.to(dev), ta=bool(ta), tb=bool(tb), bias=bv.to(dev) if bias else None).cpu().double()
+    err = (got - want).abs().max().item()
+    assert err < 2e-6 * K ** 0.5 * 4 + 1e-6, err
+    again = Fh.gemm(A.to(dev), B.to(dev), ta=bool(ta), tb=bool(tb), bias=bv.to(dev) if bias else None).cpu().double()
+    assert torch.equal(got, again)                                     # fixed summation order: bitwise reproducible
+
+
 def test_gemm_matches_fma_chain_bitwise(dev):
     """The f32 MFMA is a fmaf chain in issue order (what makes the MFMA kNN canonical).  The GEMM kernel feeds K in
     groups of four as (4m, 4m+2, 4m+1, 4m+3) -- see gemm.hip -- so emulate exactly that chain and compare bitwise."""
