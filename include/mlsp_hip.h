@@ -108,6 +108,21 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
                           int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
                           float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
+/* The same layer with its ACTIVATIONS stored as bf16 in HBM (BASELINE.json configs[4]: PointSegDA N=2048 k=40 "bf16 with MFMA edge-MLP";
+ * PointSegDA/Models.py:245-385 head stacks).  x_bf16: X and dX are bf16 (else fp32); out_bf16: Y, Z, dZ and the internal dY are bf16.
+ * W, bias, gbias, BatchNorm parameters / statistics, dW and every reduction stay fp32; products are bf16 x bf16 with fp32 accumulation.
+ * BN layers on interior GEMM tiles only: mlsp_pointmlp_mx_supported() != 0, otherwise both entry points return MLSP_ERR_UNSUPPORTED and
+ * the caller runs that layer through mlsp_pointmlp_*_f32. */
+int mlsp_pointmlp_mx_supported(int M, int Cin, int Cout, int ldx, int x_bf16, int training);
+int mlsp_pointmlp_fwd_mx(const void* X, int x_bf16, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                         const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
+                         float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop, uint64_t seed,
+                         void* Y, void* Z, int out_bf16, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_pointmlp_bwd_mx(const void* dZ, const void* X, int x_bf16, int ldx, int M, int Cin, const float* W, int ldw, int Cout,
+                         const void* Y, int out_bf16, const float* bn_save, int training, int act, float slope, float p_drop,
+                         uint64_t seed, int n_groups, int rows_per_group, void* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
+                         float* dgbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+
 /* Fused per-point conv (bias-free) + BatchNorm + act + max over the N points of each cloud:
  * conv5/bn5/LeakyReLU/adaptive_max_pool1d (PointDA/Models.py:132-136) and the T-Net's conv2d3 + torch.max(dim=2)
  * (PointDA/model_utils.py:116-117).  out [B][Cout].  Backward is closed-form through the Gram matrix X^T X (colmax.hip):

@@ -14,14 +14,14 @@ from .model_utils import transform_net, conv_2d, fc_layer, classifier, _bn_buffe
 K = 20   # Models.py:13
 
 
-def _bn_layer(X, conv, bn, training, act, p_drop=0.0, gbias=None, rows_per_group=0, W=None, grad_accum=None):
+def _bn_layer(X, conv, bn, training, act, p_drop=0.0, gbias=None, rows_per_group=0, W=None, grad_accum=None, chain=False):
     """Conv1d(k=1, bias=False) + BatchNorm1d + act (+dropout) on a [rows, Cin] matrix."""
     rm, rv = _bn_buffers(bn, training)
     if W is None:
         W = conv.weight.view(conv.out_channels, conv.in_channels)
     return Fh.pointmlp(X, W, bias=conv.bias, gbias=gbias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
                        rows_per_group=rows_per_group, training=training, act=act, slope=0.2, p_drop=p_drop,
-                       momentum=bn.momentum, eps=bn.eps, grad_accum=grad_accum)
+                       momentum=bn.momentum, eps=bn.eps, grad_accum=grad_accum, chain=chain)
 
 
 def _first_head_layer(head, x_cat, x5, N, act, p_drop, grad_accum=None):
@@ -32,7 +32,7 @@ def _first_head_layer(head, x_cat, x5, N, act, p_drop, grad_accum=None):
     Wc, W5 = Fh.split_columns(W, Cc)
     gb = Fh.pointmlp(x5, W5, training=head.training)                   # [B, Cout]
     return _bn_layer(x_cat, head.conv1, head.bn1, head.training, act, p_drop=p_drop, gbias=gb, rows_per_group=N,
-                     W=Wc, grad_accum=grad_accum)
+                     W=Wc, grad_accum=grad_accum, chain=True)
 
 
 class _RegionHead(nn.Module):
@@ -53,7 +53,7 @@ class _RegionHead(nn.Module):
         self.conv4 = nn.Conv1d(self.of3, 3, kernel_size=1, bias=False)
 
     def _tail(self, h, B, N):
-        h = _bn_layer(h, self.conv2, self.bn2, self.training, Fh.ACT_RELU, p_drop=self.dp2.p)
+        h = _bn_layer(h, self.conv2, self.bn2, self.training, Fh.ACT_RELU, p_drop=self.dp2.p, chain=True)
         h = _bn_layer(h, self.conv3, self.bn3, self.training, Fh.ACT_RELU)
         h = Fh.pointmlp(h, self.conv4.weight.view(3, self.of3), training=self.training)
         return h.view(B, N, 3)                                       # == x.permute(0,2,1) of the reference
@@ -67,7 +67,7 @@ class _RegionHead(nn.Module):
         """Reference signature: x [B,input_size,N] -> [B,N,3]."""
         B, C, N = x.shape
         X = x.transpose(2, 1).reshape(B * N, C)
-        h = _bn_layer(X, self.conv1, self.bn1, self.training, Fh.ACT_RELU, p_drop=self.dp1.p)
+        h = _bn_layer(X, self.conv1, self.bn1, self.training, Fh.ACT_RELU, p_drop=self.dp1.p, chain=True)
         return self._tail(h, B, N)
 
 
@@ -104,7 +104,7 @@ class Density_prediction(nn.Module):
         self.fc2.weight.requires_grad = False
 
     def _tail(self, h):
-        h = self.mlp1(h, p_drop=self.dp1.p)                              # dp1 applied twice (:273,:278)
+        h = self.mlp1(h, p_drop=self.dp1.p, chain=True)                  # dp1 applied twice (:273,:278)
         h = self.mlp2(h, p_drop=self.dp2.p)
         logits = Fh.pointmlp(h, self.mlp3.weight, bias=self.mlp3.bias, training=self.training)
         return Fh.density_tail(logits, self.fc2.weight)
@@ -118,7 +118,7 @@ class Density_prediction(nn.Module):
         """Reference signature: x [B,input_size,N] -> (p_vec [B*N,nc], density [B*N])."""
         B, C, N = x.shape
         X = x.transpose(2, 1).reshape(B * N, C)
-        h = _bn_layer(X, self.conv1, self.bn1, self.training, Fh.ACT_RELU, p_drop=self.dp1.p)
+        h = _bn_layer(X, self.conv1, self.bn1, self.training, Fh.ACT_RELU, p_drop=self.dp1.p, chain=True)
         return self._tail(h)
 
 

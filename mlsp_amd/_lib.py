@@ -37,6 +37,11 @@ SIGNATURES = {
                               _P, _P, _P, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
                               _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_pointmlp_mx_supported": [_I, _I, _I, _I, _I, _I],
+    "mlsp_pointmlp_fwd_mx": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
+                             _P, _P, _I, _P, _P, _SZ, _P],
+    "mlsp_pointmlp_bwd_mx": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _F, _F, _U64, _I, _I,
+                             _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_pointmlp_colmax_fwd_f32": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_pointmlp_colmax_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _P, _I, _P, _P, _P, _P, _SZ, _P],
     "mlsp_segmax_fwd_f32": [_P, _I, _I, _I, _P, _P, _P],

@@ -9,6 +9,15 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
                 double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr, int* sel_row = nullptr,
                 bool accumulate = false);
+int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A, int a_bf16, int lda, const void* B, int b_bf16,
+                   int ldb, void* C, int c_bf16, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
+                   size_t slab_floats, double* stat_part, bool accumulate);
+int launch_bn_act_fwd_b16(hipStream_t st, const void* Y, void* Z, int rows, int C, const float* scale, const float* shift, int act,
+                          float slope, float p_drop, uint64_t seed);
+int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* dY, int M, int C, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, int training, int act, float slope, float p_drop, uint64_t seed,
+                          double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy);
+int launch_colsum_groups_b16(hipStream_t st, const void* X, int G, int rows_per_group, int C, float* out, float* scratch);
 int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, int panel_rows,
                          float* ysel, int* arg);
 int gemm_panel_rows(int M, int N, int K);
@@ -463,6 +472,84 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
         }
     }
     if (dgbias) CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias, gscratch));
+    return MLSP_OK;
+}
+
+// ---- bf16 activation storage (BASELINE.json configs[4]) ---------------------------------------------------------------------------
+// The Linear + BatchNorm + act (+dropout) layer with its activations held as bf16 in HBM: x_bf16 says how X (and dX) are stored,
+// out_bf16 how Y, Z (and dZ, dY) are.  Weights, biases, BN parameters / statistics and every weight gradient stay fp32; products are
+// bf16 x bf16 with fp32 accumulation (v_mfma_f32_32x32x16_bf16).  BN layers with fused statistics only (interior GEMM tiles):
+// MLSP_ERR_UNSUPPORTED otherwise -- mlsp_pointmlp_mx_supported() tells the caller beforehand, which then keeps that layer in fp32.
+int mlsp_pointmlp_mx_supported(int M, int Cin, int Cout, int ldx, int x_bf16, int training) {
+    if (M <= 32 || Cin % 32 || Cout % 128 || M % 128) return 0;
+    if (x_bf16 ? (ldx % 8) : (ldx % 4)) return 0;
+    if (Cout > 1024 || 256 % (Cout / 4)) return 0;
+    if (training && gemm_stat_parts(M, Cout, Cin) <= 0) return 0;
+    if (gemm_slab_floats(M, Cout, Cin) != 0 || gemm_slab_floats(M, Cin, Cout) != 0) return 0;      // forward / dgrad never split K here
+    return 1;
+}
+
+int mlsp_pointmlp_fwd_mx(const void* X, int x_bf16, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                         const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
+                         float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop, uint64_t seed,
+                         void* Y, void* Z, int out_bf16, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (!X || !W || !Y || !Z || !gamma || !beta || !bn_save || ldw < Cin || ldx < Cin) return MLSP_ERR_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
+    if (!mlsp_pointmlp_mx_supported(M, Cin, Cout, ldx, x_bf16, training)) return MLSP_ERR_UNSUPPORTED;
+    Workspace w(ws, ws_bytes);
+    const int fused_parts = training ? gemm_stat_parts(M, Cout, Cin) : 0;
+    double* part = w.take<double>((size_t)(fused_parts ? fused_parts : 1) * 2 * Cout);
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
+    CHECK(launch_gemm_mx(st, false, true, M, Cout, Cin, X, x_bf16, ldx, W, 0, ldw, Y, out_bf16, Cout, bias, gbias, rows_per_group, nullptr, 0,
+                         fused_parts ? part : nullptr, false));
+    if (training) {
+        CHECK(launch_bn_finalize(st, part, fused_parts, (double)M, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale, shift,
+                                 mean, invstd));
+    } else {
+        if (!run_mean || !run_var) return MLSP_ERR_ARG;
+        CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
+    }
+    if (out_bf16) return launch_bn_act_fwd_b16(st, Y, Z, M, Cout, scale, shift, act, slope, training ? p_drop : 0.f, seed);
+    return launch_bn_act_fwd(st, (const float*)Y, (float*)Z, (size_t)M, Cout, scale, shift, act, slope, training ? p_drop : 0.f, seed);
+}
+
+int mlsp_pointmlp_bwd_mx(const void* dZ, const void* X, int x_bf16, int ldx, int M, int Cin, const float* W, int ldw, int Cout,
+                         const void* Y, int out_bf16, const float* bn_save, int training, int act, float slope, float p_drop,
+                         uint64_t seed, int n_groups, int rows_per_group, void* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
+                         float* dgbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (!dZ || !X || !W || !Y || !bn_save || !dW || !dgamma || !dbeta || ldw < Cin || ldx < Cin) return MLSP_ERR_ARG;
+    if (dgbias && (n_groups <= 0 || rows_per_group <= 0 || (long)n_groups * rows_per_group != M)) return MLSP_ERR_ARG;
+    if (!mlsp_pointmlp_mx_supported(M, Cin, Cout, ldx, x_bf16, training)) return MLSP_ERR_UNSUPPORTED;
+    if (dbias && !training) return MLSP_ERR_UNSUPPORTED;
+    Workspace w(ws, ws_bytes);
+    void* dY = w.take<char>((size_t)M * Cout * (out_bf16 ? 2 : 4));
+    const int nparts = bn_parts_max(M);
+    double* part = w.take<double>((size_t)nparts * 2 * Cout);
+    float* mean_dz = w.take<float>(Cout);
+    float* mean_dzy = w.take<float>(Cout);
+    const size_t sf = gemm_slab_floats(Cout, Cin, M);
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    float* gscratch = dgbias ? w.take<float>((size_t)n_groups * 16 * Cout) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    const float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
+    if (out_bf16)
+        CHECK(launch_bn_act_bwd_b16(st, dZ, Y, dY, M, Cout, scale, shift, mean, invstd, training, act, slope, training ? p_drop : 0.f, seed,
+                                    part, dgamma, dbeta, mean_dz, mean_dzy));
+    else
+        CHECK(launch_bn_act_bwd(st, (const float*)dZ, (const float*)Y, (float*)dY, M, Cout, scale, shift, mean, invstd, training, act, slope,
+                                training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy));
+    if (dX) CHECK(launch_gemm_mx(st, false, false, M, Cin, Cout, dY, out_bf16, Cout, W, 0, ldw, dX, x_bf16, lddx, nullptr, nullptr, 0, nullptr, 0,
+                                 nullptr, dx_accumulate != 0));
+    CHECK(launch_gemm_mx(st, true, false, Cout, Cin, M, dY, out_bf16, Cout, X, x_bf16, ldx, dW, 0, Cin, nullptr, nullptr, 0, slab, sf, nullptr, false));
+    if (dbias) {     // a bias in front of a batch-stat BN has an analytically zero gradient (sum_rows dY == 0)
+        hipError_t e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (dgbias) {
+        if (out_bf16) CHECK(launch_colsum_groups_b16(st, dY, n_groups, rows_per_group, Cout, dgbias, gscratch));
+        else CHECK(launch_colsum_groups(st, (const float*)dY, n_groups, rows_per_group, Cout, dgbias, gscratch));
+    }
     return MLSP_OK;
 }
 

@@ -197,7 +197,25 @@ __device__ __forceinline__ void vec_block_reduce_write(double (&s)[4], double (&
     }
 }
 
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_vec_kernel(const float* __restrict__ dZ, const float* __restrict__ Y,
+// 4 consecutive elements of an activation matrix held as fp32 or bf16 (configs[4] activation storage) <-> four floats
+typedef __bf16 bn_bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* p) {
+    const bn_bf16x4 v = *(const bn_bf16x4*)p;
+    return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, f32x4 v) {
+    bn_bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    *(bn_bf16x4*)p = o;
+}
+
+template <typename TY>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_vec_kernel(const TY* __restrict__ dZ, const TY* __restrict__ Y,
                                                                     int M, int C, const float* __restrict__ scale,
                                                                     const float* __restrict__ shift,
                                                                     const float* __restrict__ mean,
@@ -214,7 +232,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_vec_kernel(const float*
         const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
         for (int r = r0 + rg; r < r1; r += nrg) {
             const size_t i = (size_t)r * C + c;
-            const f32x4 y = *(const f32x4*)(Y + i), dz = *(const f32x4*)(dZ + i);
+            const f32x4 y = ld4<TY>(Y + i), dz = ld4<TY>(dZ + i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float d = dz_prime(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, seed, i + e);
@@ -242,7 +260,8 @@ __global__ __launch_bounds__(256) void colstats_vec_kernel(const float* __restri
 }
 
 // column-stationary elementwise passes: a thread keeps its 4 columns' constants in registers and walks rows
-__global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __restrict__ Y, float* __restrict__ Z, int M, int C,
+template <typename TY>
+__global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const TY* __restrict__ Y, TY* __restrict__ Z, int M, int C,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int act, float slope, uint32_t thresh, float inv_keep,
                                                              uint64_t seed) {
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __rest
     const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
     for (int r = r0 + rg; r < r1; r += nrg) {
         const size_t i = (size_t)r * C + c;
-        const f32x4 y = *(const f32x4*)(Y + i);
+        const f32x4 y = ld4<TY>(Y + i);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -261,12 +280,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __rest
             if (thresh) a = dropout_keep(seed, i + e, thresh) ? a * inv_keep : 0.f;
             o[e] = a;
         }
-        *(f32x4*)(Z + i) = o;
+        st4<TY>(Z + i, o);
     }
 }
 
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const float* __restrict__ dZ, const float* __restrict__ Y,
-                                                                   float* __restrict__ dY, int M, int C,
+template <typename TY>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const TY* __restrict__ dZ, const TY* __restrict__ Y,
+                                                                   TY* __restrict__ dY, int M, int C,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    const float* __restrict__ mean_dz,
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const float* 
     const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
     for (int r = r0 + rg; r < r1; r += nrg) {
         const size_t i = (size_t)r * C + c;
-        const f32x4 y = *(const f32x4*)(Y + i), dz = *(const f32x4*)(dZ + i);
+        const f32x4 y = ld4<TY>(Y + i), dz = ld4<TY>(dZ + i);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -295,7 +315,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const float* 
             d = d - k1[e] - (y[e] - mu[e]) * k2[e];
             o[e] = sc[e] * d;
         }
-        *(f32x4*)(dY + i) = o;
+        st4<TY>(dY + i, o);
     }
 }
 
@@ -436,7 +456,7 @@ int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int
     size_t total = rows * C;
     float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     if (rows < (size_t)1 << 30 && vec_ok(C, Y, Z) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0)) {
-        hipLaunchKernelGGL(bn_act_fwd_vec_kernel, dim3(bn_vec_parts((int)rows)), dim3(256), 0, st, Y, Z, (int)rows, C, scale, shift,
+        hipLaunchKernelGGL((bn_act_fwd_vec_kernel<float>), dim3(bn_vec_parts((int)rows)), dim3(256), 0, st, Y, Z, (int)rows, C, scale, shift,
                            act, slope, drop_thresh(p_drop), inv_keep, seed);
         return mlsp_launch_status();
     }
@@ -455,7 +475,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
     const bool vec = vec_ok(C, dZ, Y, dY) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0);
     if (vec) {
         nparts = bn_vec_parts(M);
-        hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift, mean, invstd,
+        hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<float>), dim3(nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift, mean, invstd,
                            act, slope, th, inv_keep, seed, part);
     } else {
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift,
@@ -465,7 +485,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
                        dbeta, mean_dz, mean_dzy);
     size_t total = (size_t)M * C;
     if (vec) {
-        hipLaunchKernelGGL(bn_act_bwd_apply_vec_kernel, dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C,
+        hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C,
                            scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th,
                            inv_keep, seed);
         return mlsp_launch_status();
@@ -494,7 +514,8 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ part, int npar
 
 // column sums over all M rows of a [M][C] matrix (bias gradients); part: [bn_stat_parts(M)][2][C] doubles
 // vectorised per-group column sums: block = (64-row slab of a group); partial sums combined by a second tiny pass
-__global__ __launch_bounds__(256) void colsum_groups_vec_kernel(const float* __restrict__ X, int C, int rows_per_group, int slabs,
+template <typename TY>
+__global__ __launch_bounds__(256) void colsum_groups_vec_kernel(const TY* __restrict__ X, int C, int rows_per_group, int slabs,
                                                                 float* __restrict__ part) {
     __shared__ float shd[256 * 4];
     const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
@@ -504,7 +525,7 @@ __global__ __launch_bounds__(256) void colsum_groups_vec_kernel(const float* __r
     const int r0 = slab * rows_per_slab, r1 = min(rows_per_group, r0 + rows_per_slab);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (rg < nrg)
-        for (int r = r0 + rg; r < r1; r += nrg) s = s + *(const f32x4*)(X + ((size_t)g * rows_per_group + r) * C + c);
+        for (int r = r0 + rg; r < r1; r += nrg) s = s + ld4<TY>(X + ((size_t)g * rows_per_group + r) * C + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) shd[tid * 4 + e] = s[e];
     __syncthreads();
@@ -530,7 +551,7 @@ __global__ void colsum_groups_fin_kernel(const float* __restrict__ part, int G, 
 int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out, float* scratch = nullptr) {
     if (scratch && vec_ok(C, X) && 256 % (C / 4) == 0 && rows_per_group >= 256) {
         const int slabs = 16;                       // scratch: [G][16][C] floats
-        hipLaunchKernelGGL(colsum_groups_vec_kernel, dim3(slabs, G), dim3(256), 0, st, X, C, rows_per_group, slabs, scratch);
+        hipLaunchKernelGGL((colsum_groups_vec_kernel<float>), dim3(slabs, G), dim3(256), 0, st, X, C, rows_per_group, slabs, scratch);
         hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 255) / 256), dim3(256), 0, st, scratch, G, C, slabs, out);
         return mlsp_launch_status();
     }
@@ -545,7 +566,7 @@ int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, fl
         // streaming shape: 16-byte column-stationary partial sums over 4*nparts row slabs (the fp64 partial buffer reused as floats)
         const int slabs = 4 * nparts;
         float* scratch = (float*)part;
-        hipLaunchKernelGGL(colsum_groups_vec_kernel, dim3(slabs, 1), dim3(256), 0, st, X, C, M, slabs, scratch);
+        hipLaunchKernelGGL((colsum_groups_vec_kernel<float>), dim3(slabs, 1), dim3(256), 0, st, X, C, M, slabs, scratch);
         hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, 1, C, slabs, out);
         return mlsp_launch_status();
     }
@@ -560,7 +581,7 @@ int launch_bn_act_bwd_partials_vec(hipStream_t st, const float* dZ, const float*
                                    const float* mean, const float* invstd, int act, float slope, double* part) {
     if (!(vec_ok(C, dZ, Y) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)))
         return MLSP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bn_act_bwd_reduce_vec_kernel, dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, M, C, scale, shift, mean, invstd, act,
+    hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, M, C, scale, shift, mean, invstd, act,
                        slope, 0u, 1.f, (uint64_t)0, part);
     return mlsp_launch_status();
 }
@@ -584,5 +605,42 @@ int launch_segmax_fwd(hipStream_t st, const float* Z, int P, int k, int C, float
 
 int launch_segmax_bwd(hipStream_t st, const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ) {
     hipLaunchKernelGGL(segmax_bwd_kernel, dim3(ew_blocks((size_t)P * k * C)), dim3(256), 0, st, dOut, argk, P, k, C, dZ);
+    return mlsp_launch_status();
+}
+
+
+// ---- bf16 activation storage (BASELINE.json configs[4]): the same column-stationary passes on bf16 Y / Z / dZ / dY ------------
+// (fp32 arithmetic and fp64 partial sums as above; only the loads and stores are 2 bytes per element).  Vectorised shapes only.
+static inline bool vec_ok_b16(int C, const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 7) == 0);
+}
+int launch_bn_act_fwd_b16(hipStream_t st, const void* Y, void* Z, int rows, int C, const float* scale, const float* shift, int act,
+                          float slope, float p_drop, uint64_t seed) {
+    if (!vec_ok_b16(C, Y, Z) || ((((uintptr_t)scale | (uintptr_t)shift) & 15) != 0)) return MLSP_ERR_UNSUPPORTED;
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    hipLaunchKernelGGL((bn_act_fwd_vec_kernel<__bf16>), dim3(bn_vec_parts(rows)), dim3(256), 0, st, (const __bf16*)Y, (__bf16*)Z, rows, C,
+                       scale, shift, act, slope, drop_thresh(p_drop), inv_keep, seed);
+    return mlsp_launch_status();
+}
+int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* dY, int M, int C, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, int training, int act, float slope, float p_drop, uint64_t seed,
+                          double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy) {
+    if (!vec_ok_b16(C, dZ, Y, dY) || ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) != 0))
+        return MLSP_ERR_UNSUPPORTED;
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const uint32_t th = drop_thresh(p_drop);
+    const int nparts = bn_vec_parts(M);
+    hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, M, C, scale,
+                       shift, mean, invstd, act, slope, th, inv_keep, seed, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy);
+    hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, (__bf16*)dY,
+                       M, C, scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed);
+    return mlsp_launch_status();
+}
+int launch_colsum_groups_b16(hipStream_t st, const void* X, int G, int rows_per_group, int C, float* out, float* scratch) {
+    if (!scratch || !vec_ok_b16(C, X) || rows_per_group < 256) return MLSP_ERR_UNSUPPORTED;
+    const int slabs = 16;
+    hipLaunchKernelGGL((colsum_groups_vec_kernel<__bf16>), dim3(slabs, G), dim3(256), 0, st, (const __bf16*)X, C, rows_per_group, slabs, scratch);
+    hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 255) / 256), dim3(256), 0, st, scratch, G, C, slabs, out);
     return mlsp_launch_status();
 }

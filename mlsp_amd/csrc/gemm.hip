@@ -34,6 +34,7 @@ struct GemmArgs {
     int a_vec, b_vec;               // 1 if float4 global loads are legal for that operand
     int xcd_map;                    // 1: XCD-grouped block->tile map (grid padded to a multiple of 8 panels)
     int accumulate;                 // 1: C += result (beta = 1): several consumers of one activation sum their input gradients in place
+    int c_bf16;                     // 1: C holds bf16 (activation storage of BASELINE.json configs[4]); A / B element types are template arguments
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][N] (BN batch statistics)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
     float* sel_val; int* sel_row;   // [ntm][N] extreme of each 128-row panel and the global row attaining it (first occurrence)
@@ -109,11 +110,12 @@ __device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, 
 
 // ---- epilogue shared by the fp32 and the bf16-operand kernels --------------------------------------------------------
 // acc: this wave's WM x 2 MFMA tiles of the block tile at (m0, n0); smem: the operand tiles, dead by now (scratch).
-template <int WM, bool FAST>
+template <int WM, bool FAST, bool CBF = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* smem, int tm, int m0, int n0, int split,
                                               int tid, int l31, int h, int wm, int wn) {
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
+    __bf16* Cb = (__bf16*)p.C;                            // CBF: bf16 output (never split: the slab is fp32)
     const bool epi = (p.nsplit == 1);
     float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
 #pragma unroll
@@ -129,11 +131,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
                 if (FAST || row < p.M) {
                     float v = acc[i][j][r] + bv;
                     if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
-                    if (epi && p.accumulate) v += Cout[(size_t)row * p.ldc + col];
+                    if (epi && p.accumulate) v += CBF ? (float)Cb[(size_t)row * p.ldc + col] : Cout[(size_t)row * p.ldc + col];
 #ifdef GP_NOSTORE
                     if (p.C && v == 12345.678f) Cout[(size_t)row * p.ldc + col] = v;
 #else
-                    if (p.C) Cout[(size_t)row * p.ldc + col] = v;
+                    if (CBF) { if (p.C) Cb[(size_t)row * p.ldc + col] = (__bf16)v; }
+                    else if (p.C) Cout[(size_t)row * p.ldc + col] = v;
 #endif
                     cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
                     acc[i][j][r] = v;
@@ -387,7 +390,38 @@ __device__ __forceinline__ void r2s_bf16(const f32x4 (&r)[4], __bf16* __restrict
     }
 }
 
-template <bool TA, bool TB, int WM>
+// Operand staging of the bf16-MFMA kernel for a 128x32 (or 64x32) tile.  fp32 sources are rounded to bf16 on the LDS write
+// (operand mode); bf16 sources (activation storage) are copied: 16-byte global loads of 8 elements either way they lie.
+//   row-major bf16 source: thread t -> rows (t>>2) + 64p, k = (t&3)*8        one 16-byte LDS write
+//   k-major  bf16 source: thread t -> k = (t>>4) + 16p, rows (t&15)*8 ..+7    eight 2-byte LDS writes (transpose)
+struct BfStage { bf16x8 v[2]; };
+template <bool SRC_KMAJOR, int ROWS>
+__device__ __forceinline__ void g2r_b16(BfStage& r, const __bf16* __restrict__ base, int ld) {
+    constexpr int NPB = SRC_KMAJOR ? 2 : ROWS / 64;
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) r.v[p] = *(const bf16x8*)(base + (size_t)((SRC_KMAJOR ? 16 : 64) * p) * ld);
+}
+template <bool SRC_KMAJOR, int ROWS>
+__device__ __forceinline__ void r2s_b16(const BfStage& r, __bf16* __restrict__ s, int tid) {
+    constexpr int NPB = SRC_KMAJOR ? 2 : ROWS / 64;
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+        if (!SRC_KMAJOR) {
+            *(bf16x8*)(s + ((tid >> 2) + 64 * p) * BROW + (tid & 3) * 8) = r.v[p];
+        } else {
+            const int k = (tid >> 4) + 16 * p, row = (tid & 15) * 8;
+            if (ROWS == 128 || row < ROWS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[(row + e) * BROW + k] = r.v[p][e];
+            }
+        }
+    }
+}
+
+// AB16 / BB16: the A / B operand is stored as bf16 in HBM; CB16: C is written as bf16.
+// NEDGE (only with a k-major fp32 B, i.e. the dgrad dX = dY * W): N is a multiple of 4 but not of the 128-column tile (the 192-channel
+// input of the PointSegDA heads): B columns beyond N are zero-filled on the load and the epilogue predicates its stores.
+template <bool TA, bool TB, int WM, bool AB16, bool BB16, bool CB16, bool NEDGE = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int BMT = 64 * WM, NPA = 2 * WM;
     __shared__ __attribute__((aligned(16))) float smem[BM * SROW * 2];      // same footprint as the fp32 kernel (epilogue scratch)
@@ -420,22 +454,45 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f32x4 ra[4], rb[4];
-    const float* pa = TA ? p.A + (size_t)(kbeg + (NPA == 4 ? (tid >> 5) : (tid >> 4))) * p.lda + m0 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 4
-                         : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
-    const float* pb = !TB ? p.B + (size_t)(kbeg + (tid >> 5)) * p.ldb + n0 + (tid & 31) * 4
-                          : p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + kbeg + (tid & 7) * 4;
-    g2r_fast<TA, NPA>(ra, pa, p.lda);
-    g2r_fast<!TB, 4>(rb, pb, p.ldb);
+    BfStage sa, sb;
+    const float* pa = nullptr; const float* pb = nullptr;
+    const __bf16* qa = nullptr; const __bf16* qb = nullptr;
+    if (AB16) {
+        const __bf16* A16 = (const __bf16*)p.A;
+        qa = TA ? A16 + (size_t)(kbeg + (tid >> 4)) * p.lda + m0 + (tid & 15) * 8
+                : A16 + (size_t)(m0 + (tid >> 2)) * p.lda + kbeg + (tid & 3) * 8;
+        if (!TA || BMT == 128 || (tid & 15) * 8 < BMT) g2r_b16<TA, BMT>(sa, qa, p.lda);
+    } else {
+        pa = TA ? p.A + (size_t)(kbeg + (NPA == 4 ? (tid >> 5) : (tid >> 4))) * p.lda + m0 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 4
+                : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
+        g2r_fast<TA, NPA>(ra, pa, p.lda);
+    }
+    if (BB16) {
+        const __bf16* B16 = (const __bf16*)p.B;
+        qb = !TB ? B16 + (size_t)(kbeg + (tid >> 4)) * p.ldb + n0 + (tid & 15) * 8
+                 : B16 + (size_t)(n0 + (tid >> 2)) * p.ldb + kbeg + (tid & 3) * 8;
+        g2r_b16<!TB, 128>(sb, qb, p.ldb);
+    } else {
+        pb = !TB ? p.B + (size_t)(kbeg + (tid >> 5)) * p.ldb + n0 + (tid & 31) * 4
+                 : p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + kbeg + (tid & 7) * 4;
+        if (!NEDGE || n0 + (tid & 31) * 4 < p.N) g2r_fast<!TB, 4>(rb, pb, p.ldb);
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rb[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const bool b_lane_ok = !NEDGE || n0 + (tid & 31) * 4 < p.N;
+    const bool a_lane_ok = !AB16 || !TA || BMT == 128 || (tid & 15) * 8 < BMT;     // 64-row k-major bf16 tiles use half the lanes
     const int arow = wm * (32 * WM) + l31, bcol = wn * 64 + l31;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        r2s_bf16<TA, NPA>(ra, As, tid);
-        r2s_bf16<!TB, 4>(rb, Bs, tid);
+        if (AB16) r2s_b16<TA, BMT>(sa, As, tid); else r2s_bf16<TA, NPA>(ra, As, tid);
+        if (BB16) r2s_b16<!TB, 128>(sb, Bs, tid); else r2s_bf16<!TB, 4>(rb, Bs, tid);
         __syncthreads();
         if (k0 + BK < kend) {
-            pa += TA ? (size_t)BK * p.lda : BK;
-            pb += !TB ? (size_t)BK * p.ldb : BK;
-            g2r_fast<TA, NPA>(ra, pa, p.lda);
-            g2r_fast<!TB, 4>(rb, pb, p.ldb);
+            if (AB16) { qa += TA ? (size_t)BK * p.lda : BK; if (a_lane_ok) g2r_b16<TA, BMT>(sa, qa, p.lda); }
+            else { pa += TA ? (size_t)BK * p.lda : BK; g2r_fast<TA, NPA>(ra, pa, p.lda); }
+            if (BB16) { qb += !TB ? (size_t)BK * p.ldb : BK; g2r_b16<!TB, 128>(sb, qb, p.ldb); }
+            else { pb += !TB ? (size_t)BK * p.ldb : BK; if (b_lane_ok) g2r_fast<!TB, 4>(rb, pb, p.ldb); }
         }
 #pragma unroll
         for (int s2 = 0; s2 < BK / 16; ++s2) {                      // MFMA step: k = 16*s2 + 8*h .. +7
@@ -452,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         }
         __syncthreads();
     }
-    gemm_epilogue<WM, true>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
+    gemm_epilogue<WM, !NEDGE, CB16>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 }
 
 static int g_gemm_precision = 0;     // 0: fp32 MFMA (exact fp32 products); 1: bf16 operands, fp32 accumulation
@@ -696,7 +753,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
     const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
-#define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
+#define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
     if (bm == 128) {
@@ -718,5 +775,85 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         g_prof.flop += 2.0 * M * (double)N * K;
     }
     if (ns > 1) launch_splitk_reduce_any(st, slab, C, M, N, ldc, ns, bias, gbias, rows_per_group);
+    return mlsp_launch_status();
+}
+
+
+// ---- bf16 activation storage (BASELINE.json configs[4]) ---------------------------------------------------------------------
+// The same contraction with operands and/or the output held as bf16 in HBM: activations X / Y / Z and their gradients are bf16,
+// weights, biases, BatchNorm statistics and weight gradients stay fp32.  Runs on gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, fp32
+// accumulation); a bf16 operand is copied to LDS as it is (half the HBM bytes, no conversion), an fp32 one is rounded on the way.
+// Only interior-tile shapes (M % tile, N % 128, K % 32 == 0, 16-byte aligned rows): MLSP_ERR_UNSUPPORTED otherwise, and the caller keeps
+// that layer in fp32.  Same BN-statistics / bias / per-cloud-bias / beta = 1 epilogues; the statistics come from the fp32 accumulators.
+int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A, int a_bf16, int lda, const void* B, int b_bf16,
+                   int ldb, void* C, int c_bf16, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
+                   size_t slab_floats, double* stat_part, bool accumulate) {
+    if (!a_bf16 && !b_bf16 && !c_bf16)
+        return launch_gemm(st, ta, tb, M, N, K, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, bias, gbias, rows_per_group,
+                           slab, slab_floats, stat_part, nullptr, nullptr, nullptr, accumulate);
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return MLSP_ERR_ARG;
+    if (gbias && rows_per_group <= 0) return MLSP_ERR_ARG;
+    GemmArgs p;
+    p.A = (const float*)A; p.B = (const float*)B; p.C = (float*)C; p.bias = bias; p.gbias = gbias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.rows_per_group = rows_per_group;
+    int ns = gemm_pick_split(M, N, K);
+    if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;
+    if (accumulate) ns = 1;
+    if (ns > 1 && c_bf16) return MLSP_ERR_UNSUPPORTED;                   // a split result is reduced in fp32
+    if (stat_part && ns != 1) return MLSP_ERR_ARG;
+    p.accumulate = accumulate ? 1 : 0; p.c_bf16 = c_bf16;
+    p.stat_part = stat_part; p.sel_gamma = nullptr; p.sel_val = nullptr; p.sel_row = nullptr;
+    const int ktiles = (K + BK - 1) / BK;
+    const int kts = (ktiles + ns - 1) / ns;
+    ns = (ktiles + kts - 1) / kts;
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
+    p.ntm = (M + bm - 1) / bm; p.ntn = (N + BN - 1) / BN;
+    p.nsplit = ns; p.ksplit = kts * BK;
+    const bool a_ok = a_bf16 ? (lda % 8 == 0) : (lda % 4 == 0), b_ok = b_bf16 ? (ldb % 8 == 0) : (ldb % 4 == 0);
+    p.a_vec = a_ok && (((uintptr_t)A & 15) == 0);
+    p.b_vec = b_ok && (((uintptr_t)B & 15) == 0);
+    const bool nedge = (N % BN != 0);
+    if (nedge && !(!tb && !b_bf16 && N % 4 == 0 && !stat_part && !(c_bf16 && ns > 1))) return MLSP_ERR_UNSUPPORTED;   // k-major fp32 B only
+    if (!(p.a_vec && p.b_vec && M % bm == 0 && K % BK == 0)) return MLSP_ERR_UNSUPPORTED;
+    if (ns > 1) { p.C = slab; p.ldc = N; }
+    p.xcd_map = p.ntm >= 16 && p.ntn > 1;
+    dim3 grid(p.xcd_map ? ((p.ntm + 7) / 8) * 8 * p.ntn : p.ntm * p.ntn, ns);
+    const bool prof = g_prof.on && g_prof.used < PROF_MAX_PAIRS;
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
+    const int code = (a_bf16 ? 4 : 0) | (b_bf16 ? 2 : 0) | ((c_bf16 && ns == 1) ? 1 : 0);
+#define MX_GO(TA_, TB_, WM_, A_, B_, C_) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, A_, B_, C_>), grid, dim3(256), 0, st, p)
+#define MX_ACT_W(TA_, TB_, WM_) do { /* activation x weight: A in {f32, bf16}, B = fp32 weights, C in {f32, bf16} */ \
+        if (code == 0) MX_GO(TA_, TB_, WM_, false, false, false); else if (code == 1) MX_GO(TA_, TB_, WM_, false, false, true); \
+        else if (code == 4) MX_GO(TA_, TB_, WM_, true, false, false); else if (code == 5) MX_GO(TA_, TB_, WM_, true, false, true); \
+        else return MLSP_ERR_UNSUPPORTED; } while (0)
+#define MX_ACT_ACT(WM_) do { /* wgrad: A = dY, B = X in {f32, bf16}, C = fp32 */ \
+        if (code == 0) MX_GO(true, false, WM_, false, false, false); else if (code == 4) MX_GO(true, false, WM_, true, false, false); \
+        else if (code == 2) MX_GO(true, false, WM_, false, true, false); else if (code == 6) MX_GO(true, false, WM_, true, true, false); \
+        else return MLSP_ERR_UNSUPPORTED; } while (0)
+    if (ta && tb) return MLSP_ERR_UNSUPPORTED;
+    if (nedge) {            // ragged channel count on the N side (192-channel head input): dgrad dX = dY * W and wgrad dW = dY^T * X, B in fp32
+#define MX_NE(TA_, WM_) do { if (code == 0) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, false, WM_, false, false, false, true>), grid, dim3(256), 0, st, p); \
+        else if (code == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, false, WM_, false, false, true, true>), grid, dim3(256), 0, st, p); \
+        else if (code == 4) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, false, WM_, true, false, false, true>), grid, dim3(256), 0, st, p); \
+        else if (code == 5) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, false, WM_, true, false, true, true>), grid, dim3(256), 0, st, p); \
+        else return MLSP_ERR_UNSUPPORTED; } while (0)
+        if (ta) { if (bm == 128) MX_NE(true, 2); else MX_NE(true, 1); }
+        else { if (bm == 128) MX_NE(false, 2); else MX_NE(false, 1); }
+#undef MX_NE
+    } else if (bm == 128) {
+        if (!ta && tb) MX_ACT_W(false, true, 2); else if (!ta && !tb) MX_ACT_W(false, false, 2); else MX_ACT_ACT(2);
+    } else {
+        if (!ta && tb) MX_ACT_W(false, true, 1); else if (!ta && !tb) MX_ACT_W(false, false, 1); else MX_ACT_ACT(1);
+    }
+#undef MX_ACT_ACT
+#undef MX_ACT_W
+#undef MX_GO
+    if (prof) {
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
+        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + 4};
+        g_prof.used++;
+        g_prof.flop += 2.0 * M * (double)N * K;
+    }
+    if (ns > 1) launch_splitk_reduce_any(st, slab, (float*)C, M, N, ldc, ns, bias, gbias, rows_per_group);
     return mlsp_launch_status();
 }

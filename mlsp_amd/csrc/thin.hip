@@ -26,24 +26,38 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(const float* __restric
         Bs[i] = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
     }
     __syncthreads();
-    const int nq = N >> 2;
+    const int nq = N >> 2, rpp = 256 / nq;                              // rows per pass of the workgroup (nq divides 256)
+    const int q = tid % nq, rsub = tid / nq;
     const int row0 = blockIdx.x * rows_per_block;
-    for (int i = tid; i < rows_per_block * nq; i += 256) {
-        const int r = row0 + i / nq, q = i % nq;
-        if (r >= M) break;
-        const float* a = A + (size_t)r * lda;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < K; ++k) {
-            const float av = a[k];
-            const f32x4 bv = *(const f32x4*)(Bs + k * N + 4 * q);
+    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bb = *(const f32x4*)(bias + 4 * q);
+    // four rows per thread and iteration: their K-value loads are all in flight before the first FMA
+    for (int rb = rsub; rb < rows_per_block; rb += 4 * rpp) {
+        float av[4][16];
+        int rr[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(av, bv[e], acc[e]);
+        for (int u = 0; u < 4; ++u) {
+            rr[u] = row0 + rb + u * rpp;
+            const bool ok = rb + u * rpp < rows_per_block && rr[u] < M;
+            const float* a = A + (size_t)(ok ? rr[u] : 0) * lda;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) av[u][k] = (k < K) ? a[k] : 0.f;
+            if (!ok) rr[u] = -1;
         }
-        if (bias) {
-            const f32x4 bb = *(const f32x4*)(bias + 4 * q);
-            acc = acc + bb;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (rr[u] < 0) continue;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < K) {
+                    const f32x4 bv = *(const f32x4*)(Bs + k * N + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(av[u][k], bv[e], acc[e]);
+                }
+            }
+            *(f32x4*)(C + (size_t)rr[u] * ldc + 4 * q) = acc + bb;
         }
-        *(f32x4*)(C + (size_t)r * ldc + 4 * q) = acc;
     }
 }
 
@@ -63,31 +77,40 @@ __global__ __launch_bounds__(256) void thin_smalln_kernel(const float* __restric
     __syncthreads();
     const int g = tid & 15, sub = tid >> 4;                              // 16 row slots per workgroup pass
     const int kq = K >> 2;
-    for (int r = blockIdx.x * 16 + sub; r < M; r += gridDim.x * 16) {
-        const float* a = A + (size_t)r * lda;
-        float acc[NMAX];
+    const float bv_out = (bias && g < N) ? bias[g] : 0.f;
+    for (int r0 = blockIdx.x * 32 + sub; r0 < M; r0 += gridDim.x * 32) {     // two rows (r0, r0 + 16) per slot and iteration
+        const int r1 = r0 + 16;
+        const float* a0 = A + (size_t)r0 * lda;
+        const float* a1 = A + (size_t)(r1 < M ? r1 : r0) * lda;
+        float acc0[NMAX], acc1[NMAX];
 #pragma unroll
-        for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+        for (int n = 0; n < NMAX; ++n) { acc0[n] = 0.f; acc1[n] = 0.f; }
         for (int q = g; q < kq; q += 16) {
-            const f32x4 av = *(const f32x4*)(a + 4 * q);
+            const f32x4 x0 = *(const f32x4*)(a0 + 4 * q), x1 = *(const f32x4*)(a1 + 4 * q);
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
                     const f32x4 bv = *(const f32x4*)(Bs + n * K + 4 * q);
-                    acc[n] = fmaf(av[3], bv[3], fmaf(av[2], bv[2], fmaf(av[1], bv[1], fmaf(av[0], bv[0], acc[n]))));
+                    acc0[n] = fmaf(x0[3], bv[3], fmaf(x0[2], bv[2], fmaf(x0[1], bv[1], fmaf(x0[0], bv[0], acc0[n]))));
+                    acc1[n] = fmaf(x1[3], bv[3], fmaf(x1[2], bv[2], fmaf(x1[1], bv[1], fmaf(x1[0], bv[0], acc1[n]))));
                 }
             }
         }
+        float out0 = 0.f, out1 = 0.f;
 #pragma unroll
         for (int n = 0; n < NMAX; ++n) {
+            if (n < N) {
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o, 64);
+                for (int o = 8; o > 0; o >>= 1) { acc0[n] += __shfl_xor(acc0[n], o, 64); acc1[n] += __shfl_xor(acc1[n], o, 64); }
+            }
+            out0 = (g == n) ? acc0[n] : out0;
+            out1 = (g == n) ? acc1[n] : out1;
         }
         // lane g writes column g (N <= 16): a 4N-byte contiguous run per row
-        float out = 0.f;
-#pragma unroll
-        for (int n = 0; n < NMAX; ++n) out = (g == n) ? acc[n] : out;
-        if (g < N) C[(size_t)r * ldc + g] = out + (bias ? bias[g] : 0.f);
+        if (g < N) {
+            C[(size_t)r0 * ldc + g] = out0 + bv_out;
+            if (r1 < M) C[(size_t)r1 * ldc + g] = out1 + bv_out;
+        }
     }
 }
 
@@ -108,17 +131,24 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ 
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (gr < ngr) {
-        for (int k = k0 + gr; k < k1; k += ngr) {
-            const f32x4 lv = *(const f32x4*)(L + (size_t)k * ldl + 4 * q);
-            const float* sp = S + (size_t)k * lds_;
+        for (int kb = k0 + gr; kb < k1; kb += 4 * ngr) {                 // four rows per thread in flight
+            f32x4 lv[4];
+            float sv[4][NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (s < ns) {
-                    const float sv = sp[s];
+            for (int u = 0; u < 4; ++u) {
+                const int k = kb + u * ngr;
+                const bool ok = k < k1;
+                lv[u] = ok ? *(const f32x4*)(L + (size_t)k * ldl + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* sp = S + (size_t)(ok ? k : k0) * lds_;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[s][e] = fmaf(sv, lv[e], acc[s][e]);
-                }
+                for (int s = 0; s < NS; ++s) sv[u][s] = (s < ns) ? sp[s] : 0.f;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[s][e] = fmaf(sv[u][s], lv[u][e], acc[s][e]);
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -135,13 +165,14 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ 
 }
 
 int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int nsplit);
+#define THIN_TN_ROWS 64      // rows of the K dimension per workgroup (one partial slab each)
 
 // slab floats the thin TN path needs for (M, N, K) (0: shape not handled here)
 size_t thin_tn_slab_floats(int M, int N, int K) {
     const bool small_m = M <= 16 && N % 4 == 0 && N >= 128 && N <= 512 && (N & (N - 1)) == 0;
     const bool small_n = N <= 16 && M % 4 == 0 && M >= 128 && M <= 512 && (M & (M - 1)) == 0;
     if (!(small_m || small_n) || K < 2048) return 0;
-    const int chunks = (K + 127) / 128;
+    const int chunks = (K + THIN_TN_ROWS - 1) / THIN_TN_ROWS;
     return (size_t)chunks * M * N;
 }
 
@@ -151,7 +182,8 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
     auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
     if (!ta && K <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && M >= 1024 && ldc % 4 == 0 && al16(C) && al16(bias)) {
         const int nq = N / 4;
-        const int rpb = 4 * 256 / nq > 0 ? 4 * 256 / nq : 1;              // four passes of the workgroup per block
+        if (256 % nq) return MLSP_ERR_UNSUPPORTED;
+        const int rpb = 16 * (256 / nq);                                  // sixteen rows per thread (four iterations of four)
         const size_t lds = (size_t)K * N * sizeof(float);
         const dim3 grid((M + rpb - 1) / rpb);
         if (tb) hipLaunchKernelGGL((thin_smallk_kernel<true>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb);
@@ -160,8 +192,8 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
     }
     if (!ta && N <= 16 && K % 4 == 0 && K >= 64 && K <= 1024 && M >= 1024 && lda % 4 == 0 && al16(A)) {
         const size_t lds = (size_t)K * N * sizeof(float);
-        int blocks = (M + 15) / 16;
-        if (blocks > 2048) blocks = 2048;
+        int blocks = (M + 31) / 32;
+        if (blocks > 512) blocks = 512;                                      // B is staged once per workgroup: keep many rows per workgroup
 #define THIN_SN(TBV) do { if (N <= 4) hipLaunchKernelGGL((thin_smalln_kernel<TBV, 4>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K); \
                           else hipLaunchKernelGGL((thin_smalln_kernel<TBV, 16>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K); } while (0)
         if (tb) THIN_SN(true); else THIN_SN(false);
@@ -171,7 +203,7 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
     if (ta && !tb && !bias) {
         const size_t need = thin_tn_slab_floats(M, N, K);
         if (!need || !slab || slab_floats < need) return MLSP_ERR_UNSUPPORTED;
-        const int chunks = (K + 127) / 128;
+        const int chunks = (K + THIN_TN_ROWS - 1) / THIN_TN_ROWS;
         const bool small_m = M <= 16 && N % 4 == 0 && N >= 128;
         if (small_m ? (ldb % 4 || !al16(B)) : (lda % 4 || !al16(A))) return MLSP_ERR_UNSUPPORTED;   // the wide operand is read 16 bytes per lane
         // small side S, large side L; partial slabs are written in C's [M][N] layout
@@ -180,7 +212,7 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
         const int ds = small_m ? N : 1, dl = small_m ? 1 : N;
         const int ngr = 256 / (nl / 4);
 #define THIN_TN(NSV) hipLaunchKernelGGL((thin_tn_kernel<NSV>), dim3(chunks), dim3(256), (size_t)ngr * NSV * nl * sizeof(float), st, S, lds_, L, ldl, \
-                                        slab, (size_t)M * N, ds, dl, K, ns, nl, 128)
+                                        slab, (size_t)M * N, ds, dl, K, ns, nl, THIN_TN_ROWS)
         if (ns <= 4) THIN_TN(4); else THIN_TN(16);
 #undef THIN_TN
         int rc = mlsp_launch_status();

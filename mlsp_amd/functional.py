@@ -30,9 +30,9 @@ def _next_seed():
             + _stream_id() * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
 
 
-def _rows(t):
-    """[rows, C] fp32 matrix with unit channel stride (row pitch may exceed C)."""
-    assert t.dim() == 2 and t.dtype == torch.float32, (t.shape, t.dtype)
+def _rows(t, allow_bf16=False):
+    """[rows, C] fp32 (or, where the op takes bf16 activation storage, bf16) matrix with unit channel stride (row pitch may exceed C)."""
+    assert t.dim() == 2 and (t.dtype == torch.float32 or (allow_bf16 and t.dtype == torch.bfloat16)), (t.shape, t.dtype)
     if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
         t = t.contiguous()
     return t
@@ -62,6 +62,28 @@ class gemm_precision:
 
     def __exit__(self, *exc):
         gemm_precision.set(self.prev)
+        return False
+
+
+class activation_storage:
+    """Context manager / switch for how the per-point MLP stacks keep their activations in HBM: "fp32" (default; the parity contract
+    of the fp32 configs) or "bf16" (BASELINE.json configs[4]: Y / Z of chained Linear+BN+act layers and their gradients are stored as
+    bf16, bf16 x bf16 products with fp32 accumulation; weights, BN statistics, kNN distances, reductions, losses stay fp32).
+    Layers opt in with pointmlp(..., chain=True) (their consumer is another pointmlp); shapes the bf16 kernels do not cover stay fp32."""
+    current = "fp32"
+
+    def __init__(self, mode):
+        if mode not in ("fp32", "bf16"):
+            raise ValueError("storage must be 'fp32' or 'bf16'")
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        self.prev = activation_storage.current
+        activation_storage.current = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        activation_storage.current = self.prev
         return False
 
 
@@ -375,9 +397,9 @@ def tnet_edge_supported(W1, W2, k):
 class _PointMLP(Function):
     @staticmethod
     def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,
-                momentum, eps, grad_accum=None):
+                momentum, eps, grad_accum=None, out_bf16=False):
         lib = _lib.load()
-        X = _rows(X)
+        X = _rows(X, allow_bf16=True)
         _lib.require_gpu(X, W)
         if W.stride(1) != 1:
             W = W.contiguous()
@@ -386,8 +408,15 @@ class _PointMLP(Function):
         assert W.shape[1] == Cin, (W.shape, X.shape)
         dev = X.device
         has_bn = gamma is not None
-        Z = torch.empty((M, Cout), dtype=torch.float32, device=dev)
-        Y = torch.empty((M, Cout), dtype=torch.float32, device=dev) if has_bn else None
+        x_bf16 = X.dtype == torch.bfloat16
+        mx = x_bf16 or out_bf16            # bf16 activation storage on either side of this layer (mlsp_pointmlp_*_mx)
+        if mx and not (has_bn and lib.mlsp_pointmlp_mx_supported(M, Cin, Cout, X.stride(0), int(x_bf16), int(training))):
+            if x_bf16:
+                raise RuntimeError("pointmlp: bf16 input on a layer the bf16-storage kernels do not cover (M=%d Cin=%d Cout=%d)" % (M, Cin, Cout))
+            mx = out_bf16 = False
+        odt = torch.bfloat16 if out_bf16 else torch.float32
+        Z = torch.empty((M, Cout), dtype=odt, device=dev)
+        Y = torch.empty((M, Cout), dtype=odt, device=dev) if has_bn else None
         bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev) if has_bn else None
         if gbias is not None:
             gbias = gbias.contiguous()
@@ -396,15 +425,23 @@ class _PointMLP(Function):
             bias = bias.contiguous()
         p = float(p_drop) if training else 0.0
         ws, wsn = _lib.workspace(dev, M, Cin, Cout)
-        _lib.check(lib.mlsp_pointmlp_fwd_f32(
-            X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
-            int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
-            int(training), act, slope, p, seed, _lib.ptr(Y), Z.data_ptr(), _lib.ptr(bn_save), ws, wsn, _lib.stream()),
-            "mlsp_pointmlp_fwd_f32")
+        if mx:
+            _lib.check(lib.mlsp_pointmlp_fwd_mx(
+                X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
+                int(rows_per_group), gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
+                int(training), act, slope, p, seed, Y.data_ptr(), Z.data_ptr(), int(out_bf16), bn_save.data_ptr(), ws, wsn,
+                _lib.stream()), "mlsp_pointmlp_fwd_mx")
+        else:
+            _lib.check(lib.mlsp_pointmlp_fwd_f32(
+                X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
+                int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
+                int(training), act, slope, p, seed, _lib.ptr(Y), Z.data_ptr(), _lib.ptr(bn_save), ws, wsn, _lib.stream()),
+                "mlsp_pointmlp_fwd_f32")
         ctx.save_for_backward(X, W, Y, bn_save)
         ctx.cfg = (has_bn, training, act, slope, p, seed, bias is not None, gbias.shape[0] if gbias is not None else 0,
                    int(rows_per_group))
         ctx.grad_accum = grad_accum
+        ctx.mx = (mx, x_bf16, out_bf16)
         return Z
 
     @staticmethod
@@ -413,37 +450,49 @@ class _PointMLP(Function):
         lib = _lib.load()
         X, W, Y, bn_save = ctx.saved_tensors
         has_bn, training, act, slope, p, seed, has_bias, G, rpg = ctx.cfg
+        mx, x_bf16, out_bf16 = ctx.mx
         dZ = dZ.contiguous()
+        if dZ.dtype != (torch.bfloat16 if out_bf16 else torch.float32):
+            dZ = dZ.to(torch.bfloat16 if out_bf16 else torch.float32)
         dev = dZ.device
         M, Cin = X.shape
         Cout = W.shape[0]
         dX, accumulate = None, 0
         if ctx.needs_input_grad[0]:
-            if ctx.grad_accum is not None:
+            if ctx.grad_accum is not None and not x_bf16:
                 dX, accumulate = ctx.grad_accum.claim((M, Cin), dev)
             else:
-                dX = torch.empty((M, Cin), dtype=torch.float32, device=dev)
+                dX = torch.empty((M, Cin), dtype=X.dtype, device=dev)
         dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
         dbias = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bias else None
         dgbias = torch.empty((G, Cout), dtype=torch.float32, device=dev) if G else None
         dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bn else None
         dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bn else None
         ws, wsn = _lib.workspace(dev, M, Cin, Cout)
-        _lib.check(lib.mlsp_pointmlp_bwd_f32(
-            dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
-            _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate, dW.data_ptr(),
-            _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
-            "mlsp_pointmlp_bwd_f32")
-        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 11
+        if mx:
+            _lib.check(lib.mlsp_pointmlp_bwd_mx(
+                dZ.data_ptr(), X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, Y.data_ptr(),
+                int(out_bf16), bn_save.data_ptr(), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate,
+                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()),
+                "mlsp_pointmlp_bwd_mx")
+        else:
+            _lib.check(lib.mlsp_pointmlp_bwd_f32(
+                dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
+                _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate, dW.data_ptr(),
+                _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
+                "mlsp_pointmlp_bwd_f32")
+        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 12
 
 
 def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, run_var=None, rows_per_group=0,
-             training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5, grad_accum=None):
+             training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5, grad_accum=None, chain=False):
     """Linear/1x1-conv (+bias, +per-group bias) [+ BatchNorm + act + dropout] on a [M,Cin] row matrix.
-    `grad_accum`: the SharedInputGrad of a fan_out(X, n) whose alias this X is."""
+    `grad_accum`: the SharedInputGrad of a fan_out(X, n) whose alias this X is.  `chain=True`: the only consumer of the output is
+    another pointmlp BN layer, so under activation_storage("bf16") Y / Z may be stored as bf16."""
     seed = _next_seed() if (training and p_drop > 0) else 0
+    out_bf16 = bool(chain) and activation_storage.current == "bf16" and gamma is not None
     return _PointMLP.apply(X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop,
-                           seed, momentum, eps, grad_accum)
+                           seed, momentum, eps, grad_accum, out_bf16)
 
 
 class _PointMLPColMax(Function):

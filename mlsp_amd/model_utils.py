@@ -156,15 +156,17 @@ class fc_layer(nn.Module):
         self.act = _ACT[activation]
 
     @flushing_forward
-    def forward(self, x, p_drop=0.0):
-        """x [M,in] -> [M,out]; `p_drop` fuses the Dropout that follows this layer in the reference."""
+    def forward(self, x, p_drop=0.0, chain=False):
+        """x [M,in] -> [M,out]; `p_drop` fuses the Dropout that follows this layer in the reference; `chain`: the output only
+        feeds another Linear+BN layer (it may then be stored as bf16 under functional.activation_storage("bf16"))."""
         lin = self.fc[0]
         if not self.has_bn:
             raise NotImplementedError("fc_layer(bn=False) is not on the DGCNN hot path")
         bn = self.fc[1]
         rm, rv = _bn_buffers(bn, self.training)
         return Fh.pointmlp(x, lin.weight, bias=lin.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
-                           training=self.training, act=self.act, slope=0.2, p_drop=p_drop, momentum=bn.momentum, eps=bn.eps)
+                           training=self.training, act=self.act, slope=0.2, p_drop=p_drop, momentum=bn.momentum, eps=bn.eps,
+                           chain=chain)
 
 
 class transform_net(nn.Module):

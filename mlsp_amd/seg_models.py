@@ -94,14 +94,15 @@ class fc_layer_v2(nn.Module):
         self.act = Fh.ACT_RELU if activation == 'relu' else Fh.ACT_LRELU
 
     @flushing_forward
-    def forward(self, x, p_drop=0.0):
+    def forward(self, x, p_drop=0.0, chain=False):
         lin = self.fc[0]
         if not self.has_bn:
             return _linear_act(x, lin.weight, lin.bias, self.act)
         bn = self.fc[1]
         rm, rv = _bn_buffers(bn, self.training)
         return Fh.pointmlp(x, lin.weight, bias=lin.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
-                           training=self.training, act=self.act, slope=0.2, p_drop=p_drop, momentum=bn.momentum, eps=bn.eps)
+                           training=self.training, act=self.act, slope=0.2, p_drop=p_drop, momentum=bn.momentum, eps=bn.eps,
+                           chain=chain)
 
 
 class transform_net(nn.Module):
@@ -200,21 +201,22 @@ class shared_layers(nn.Module):
         return x123.view(B, N, -1).permute(0, 2, 1), x5.unsqueeze(2)
 
 
-def _head_bn_layer(X, conv, bn, training, p_drop=0.0, gbias=None, rows_per_group=0, W=None):
+def _head_bn_layer(X, conv, bn, training, p_drop=0.0, gbias=None, rows_per_group=0, W=None, chain=False):
     rm, rv = _bn_buffers(bn, training)
     if W is None:
         W = conv.weight.view(conv.out_channels, conv.in_channels)
     return Fh.pointmlp(X, W, bias=conv.bias, gbias=gbias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
                        rows_per_group=rows_per_group, training=training, act=Fh.ACT_RELU, slope=0.2, p_drop=p_drop,
-                       momentum=bn.momentum, eps=bn.eps)
+                       momentum=bn.momentum, eps=bn.eps, chain=chain)
 
 
 def _first_layer(head, x_cat, x5, N, p_drop):
     """conv1 on cat(x123, x5 repeated): the x5 half enters as a per-cloud bias (see mlsp_amd/Models.py)."""
     W = head.conv1.weight.view(head.conv1.out_channels, head.conv1.in_channels)
     Cc = x_cat.shape[1]
-    gb = Fh.pointmlp(x5, W[:, Cc:], training=head.training)
-    return _head_bn_layer(x_cat, head.conv1, head.bn1, head.training, p_drop=p_drop, gbias=gb, rows_per_group=N, W=W[:, :Cc])
+    Wc, W5 = Fh.split_columns(W, Cc)
+    gb = Fh.pointmlp(x5, W5, training=head.training)
+    return _head_bn_layer(x_cat, head.conv1, head.bn1, head.training, p_drop=p_drop, gbias=gb, rows_per_group=N, W=Wc, chain=True)
 
 
 class _BnHead(nn.Module):
@@ -234,7 +236,7 @@ class _BnHead(nn.Module):
         self.conv4 = nn.Conv1d(self.of3, out_size, kernel_size=1, bias=bias)
 
     def _tail(self, h, B, N):
-        h = _head_bn_layer(h, self.conv2, self.bn2, self.training, p_drop=self.dp2.p)
+        h = _head_bn_layer(h, self.conv2, self.bn2, self.training, p_drop=self.dp2.p, chain=True)
         h = _head_bn_layer(h, self.conv3, self.bn3, self.training)
         h = Fh.pointmlp(h, self.conv4.weight.view(self.conv4.out_channels, self.of3), bias=self.conv4.bias, training=self.training)
         return h.view(B, N, -1)
@@ -245,7 +247,7 @@ class _BnHead(nn.Module):
     @flushing_forward
     def forward(self, x):
         B, C, N = x.shape
-        h = _head_bn_layer(x.transpose(2, 1).reshape(B * N, C), self.conv1, self.bn1, self.training, p_drop=self.dp1.p)
+        h = _head_bn_layer(x.transpose(2, 1).reshape(B * N, C), self.conv1, self.bn1, self.training, p_drop=self.dp1.p, chain=True)
         return self._tail(h, B, N)
 
 
@@ -295,7 +297,7 @@ class Density_prediction(nn.Module):
         self.fc2.weight.requires_grad = False
 
     def _tail(self, h):
-        h = self.mlp1(h, p_drop=self.dp1.p)
+        h = self.mlp1(h, p_drop=self.dp1.p, chain=True)
         h = self.mlp2(h, p_drop=self.dp2.p)
         logits = Fh.pointmlp(h, self.mlp3.weight, bias=self.mlp3.bias, training=self.training)
         return Fh.density_tail(logits, self.fc2.weight)
@@ -306,7 +308,7 @@ class Density_prediction(nn.Module):
     @flushing_forward
     def forward(self, x):
         B, C, N = x.shape
-        h = _head_bn_layer(x.transpose(2, 1).reshape(B * N, C), self.conv1, self.bn1, self.training, p_drop=self.dp1.p)
+        h = _head_bn_layer(x.transpose(2, 1).reshape(B * N, C), self.conv1, self.bn1, self.training, p_drop=self.dp1.p, chain=True)
         return self._tail(h)
 
 

@@ -201,6 +201,90 @@ def test_gemm_matches_fma_chain_bitwise(dev):
     assert np.array_equal(got, want)
 
 
+# ----------------------------------------------------------------------------- bf16 activation storage (configs[4])
+class _RoundBF16(torch.autograd.Function):
+    """x -> bf16(x) with a straight-through gradient: where the storage-mode kernels round, the emulation rounds."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+@pytest.mark.parametrize("M,C0,training", [(32768, 192, True), (32768, 512, True), (32768, 192, False)])
+def test_pointmlp_bf16_activation_storage(dev, M, C0, training):
+    """functional.activation_storage("bf16"): a chain of Linear+BN+act layers keeps Y / Z (and dZ / dY / dX in backward) as bf16 in HBM
+    (mlsp_pointmlp_*_mx: bf16 x bf16 products, fp32 accumulation, fp32 BN statistics from the accumulators).
+    Oracle: the same chain in plain torch fp32 with a bf16 rounding (straight-through in backward) at every point where the kernels
+    round -- GEMM operands, stored Y, stored Z.  (Against the un-rounded fp32 chain the OUTPUT agrees to ~1 %, but its gradient
+    differs by ~9 %: rounding Y flips the ReLU mask of the ~0.3 % of activations that sit at the kink, i.e. it is the exact gradient
+    of a slightly different function.)"""
+    Fh = _fh()
+    dims = [C0, 256, 256, 128]
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(M, C0, generator=g)
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(3)]
+    gam = [torch.rand(dims[i + 1], generator=g) + 0.5 for i in range(3)]
+    bet = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(3)]
+    rms = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(3)]
+    rvs = [torch.rand(dims[i + 1], generator=g) + 0.5 for i in range(3)]
+    gb = torch.randn(M // 1024, 256, generator=g) * 0.3
+    wout = torch.randn(M, 128, generator=g)
+    rnd = _RoundBF16.apply
+
+    def leaves():
+        return ([X.to(dev).requires_grad_(True)] + [w.to(dev).requires_grad_(True) for w in Ws] + [t.to(dev).requires_grad_(True) for t in gam] +
+                [t.to(dev).requires_grad_(True) for t in bet] + [gb.to(dev).requires_grad_(True)])
+
+    def run(mode):
+        L = leaves()
+        x, ws, gs, bs, gbd = L[0], L[1:4], L[4:7], L[7:10], L[10]
+        seen = []
+        with Fh.activation_storage(mode):
+            h = x
+            for i in range(3):
+                h = Fh.pointmlp(h, ws[i], gbias=gbd if i == 0 else None, rows_per_group=1024 if i == 0 else 0, gamma=gs[i], beta=bs[i],
+                                run_mean=rms[i].to(dev), run_var=rvs[i].to(dev), training=training, act=Fh.ACT_RELU, chain=(i < 2))
+                seen.append(h.dtype)
+        (h.float() * wout.to(dev)).sum().backward()
+        return h.detach().float().cpu(), [t.grad.float().cpu() for t in L], seen
+
+    def emulate():
+        L = leaves()
+        x, ws, gs, bs, gbd = L[0], L[1:4], L[4:7], L[7:10], L[10]
+        h = x
+        for i in range(3):
+            store = i < 2                                              # layers 0, 1 store bf16; layer 2 reads bf16, writes fp32
+            y = rnd(h) @ rnd(ws[i]).t()                                # operands rounded, fp32 accumulation
+            if i == 0:
+                y = y + gbd.repeat_interleave(1024, dim=0)
+            if training:
+                mean, var = y.mean(0), y.var(0, unbiased=False)        # statistics from the fp32 accumulators
+            else:
+                mean, var = rms[i].to(dev), rvs[i].to(dev)
+            scale = gs[i] * torch.rsqrt(var + 1e-5)
+            yb = rnd(y) if store else y
+            z = torch.relu(yb * scale + (bs[i] - mean * scale))
+            h = rnd(z) if store else z
+        (h * wout.to(dev)).sum().backward()
+        return h.detach().cpu(), [t.grad.cpu() for t in L]
+
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-30)).item()
+    ref32, _, dref = run("fp32")
+    got, ggot, dgot = run("bf16")
+    want, gwant = emulate()
+    assert dref == [torch.float32] * 3 and dgot == [torch.bfloat16, torch.bfloat16, torch.float32]
+    assert Fh.activation_storage.current == "fp32"
+    assert rel(got, want) < 5e-3, rel(got, want)                       # same roundings at the same places
+    assert 1e-5 < rel(got, ref32) < 2e-2, rel(got, ref32)              # close to the fp32 chain, and it really stored bf16
+    errs = [rel(a, b) for a, b in zip(ggot, gwant)]
+    print("bf16-storage gradients vs rounded-forward emulation:", ["%.1e" % e for e in errs])
+    assert max(errs) < 3e-2, errs                                      # gradient tensors themselves are stored / multiplied in bf16
+
+
 # ----------------------------------------------------------------------------- pointmlp (Linear + BN + act)
 def _torch_pointmlp(X, W, bias, gbias, rpg, gamma, beta, rm, rv, training, act):
     Y = X @ W.t()

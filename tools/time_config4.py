@@ -1,0 +1,43 @@
+"""BASELINE.json configs[4] on one MI355X (run on the GPU box): PointSegDA DGCNN_DefRec, N = 2048, k = 40, all heads, fwd + bwd + Adam,
+B = 16 clouds per GPU (the reference trainer's default batch, PointSegDA/trainer.py:103), in three arithmetic modes:
+fp32 | bf16 GEMM operands (fp32 storage) | bf16 operands + bf16 activation storage (the configs[4] mode).  One JSON line per mode."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import golden_common as gc
+from mlsp_amd import seg_models, functional as Fh
+
+dev = torch.device("cuda:0")
+B, N, K = int(os.environ.get("C4_B", 16)), 2048, int(os.environ.get("C4_K", 40))
+seg = seg_models.DGCNN_DefRec(gc.make_seg_args(dropout=0.5, gpu=True), in_size=3, num_classes=8)
+seg.k = seg.shared_layers.k = K
+seg = seg.to(dev).train()
+opt = torch.optim.Adam(seg.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+x = torch.rand(B, 3, N, device=dev) * 2 - 1
+w = {k: torch.randn(s, device=dev) for k, s in (("seg", (B, N, 8)), ("DefRec", (B, N, 3)), ("Normal", (B, N, 3)), ("density", (B * N, 16)),
+                                                ("density_mse", (B * N,)))}
+
+
+def step():
+    opt.zero_grad()
+    out = seg(x, make_seg=True, activate_DefRec=True, activate_density_normal_ondef=True)
+    sum((out[k].float() * w[k]).mean() for k in w).backward()
+    opt.step()
+
+
+for name, prec, store in (("fp32", "fp32", "fp32"), ("bf16 operands", "bf16", "fp32"), ("bf16 operands + bf16 activation storage", "bf16", "bf16")):
+    with Fh.gemm_precision(prec), Fh.activation_storage(store):
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 10)
+    ms = sorted(ts)[2] * 1e3
+    print(json.dumps({"workload": "PointSegDA DGCNN_DefRec fwd+bwd+Adam, B=%d N=%d k=%d, all heads" % (B, N, K), "mode": name,
+                      "ms_per_step": round(ms, 3), "points_per_s": round(B * N / ms * 1e3)}))
