@@ -194,6 +194,18 @@ int mlsp_knn_normals_f32(const float* x, int ldx, const int32_t* idx, int B, int
  * xyz [B][N] rows of >= 3 floats (pitch ldx); new_xyz [B][S] rows (pitch ldq); feat [B*N][D] or NULL when D == 0;
  * idx / fps_idx are int32 local to their cloud.  mlsp_group_reverse builds the reverse index of idx [B][S][ns] over the
  * N source points (same format as mlsp_knn_reverse) for the deterministic backward of the grouping. */
+/* kNN of query points among DIFFERENT reference points: `square_distance` + argsort()[:, :, :k] (pointnet_util.py:26-38,116-118 knn=True
+ * grouping, :237-239 Msg, :287-289 the 3-NN of feature propagation; the KNN calls of PointDA/model_utils.py:175,188 have this shape).
+ * d = (-2 q.r + |q|^2) + |r|^2 in fp32 (dot = fmaf chain over the C <= 8 coordinates), ascending, ties -> lower reference index.
+ * ref [B][Nr] rows (pitch ldr), qry [B][Nq] rows (pitch ldq) -> idx [B][Nq][k] (local to the cloud), dist [B][Nq][k] (nullable). k <= 64. */
+int mlsp_knn_query_f32(const float* ref, int ldr, int Nr, const float* qry, int ldq, int Nq, int B, int C, int k, int32_t* idx, float* dist,
+                       mlsp_stream_t stream);
+/* PointNetFeaturePropagation interpolation (pointnet_util.py:287-294): out [B][N][D] = inverse-distance weighted mean of the features
+ * feat [B][S][D] of the three nearest sampled points (idx, dist [B][N][3] from mlsp_knn_query_f32); backward over the reverse index of idx
+ * (mlsp_group_reverse(idx, B, N, S, 3, ...)): dfeat [B][S][D], deterministic order. */
+int mlsp_interp3_fwd_f32(const float* feat, const int32_t* idx, const float* dist, int B, int N, int S, int D, float* out, mlsp_stream_t stream);
+int mlsp_interp3_bwd_f32(const float* dout, const float* dist, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int D,
+                         float* dfeat, mlsp_stream_t stream);
 int mlsp_fps_f32(const float* xyz, int ldx, int B, int N, int S, const int32_t* start, int32_t* fps_idx, mlsp_stream_t stream);
 int mlsp_ball_query_f32(const float* xyz, int ldx, const float* new_xyz, int ldq, int B, int N, int S, float radius_sq, int nsample,
                         int32_t* idx, mlsp_stream_t stream);
@@ -212,6 +224,14 @@ int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const 
 int mlsp_region_assign_f32(const float* X, int B, int C, int N, const float* thr, int n, float clip, int32_t* regions, mlsp_stream_t stream);
 int mlsp_deform_regions_f32(float* X, int B, int C, int N, const int32_t* regions, const int32_t* order, int nreg, const float* lookup,
                             const float* noise, int min_pts, int groups, float* mask, mlsp_stream_t stream);
+/* deform_input(..., 'volume_based_radius') = pc_utils.collapse_to_point (MLSP/mlsp.py:33-36, utils/pc_utils.py:76-111): per cloud one
+ * point with >= min_pts points within sqrt(radius2) is picked (uniformly by u[b] in [0,1) among the candidates in index order, or
+ * choice[b] >= 0 pins it) and all points within that radius of it become centre + noise (noise [B][3][N], already scaled by the
+ * Gaussian's std); mask [B][3][N] marks them; chosen[b] = the picked index or -1 when the cloud has no candidate (left untouched).
+ * X [B][3][N] is updated in place. */
+int mlsp_collapse_to_point_f32(float* X, int B, int N, const int32_t* choice, const float* u, const float* noise, float radius2,
+                               int min_pts, float* mask, int32_t* chosen, mlsp_stream_t stream);
+
 /* MLSP/mlsp.py:54-89 scan_input / p_scan: X [B][N][C] point-major; R [B][9] float64 row-major rotation of every cloud
  * (rotate_point_cloud_3d :91-112, drawn on the host); pixel = int(2 / pixel_size).  Xs [B][N][C] keeps only the visible points,
  * mask [B][N][C] is 0 on their first three channels and 1 elsewhere. */

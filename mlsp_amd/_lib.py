@@ -58,6 +58,9 @@ SIGNATURES = {
     "mlsp_density_loss_bwd_f32": [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "mlsp_radius_count_f32": [_P, _I, _I, _I, _F, _I, _P, _P],
     "mlsp_knn_normals_f32": [_P, _I, _P, _I, _I, _I, _P, _P],
+    "mlsp_knn_query_f32": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "mlsp_interp3_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mlsp_interp3_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_fps_f32": [_P, _I, _I, _I, _I, _P, _P, _P],
     "mlsp_ball_query_f32": [_P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _P],
     "mlsp_group_reverse": [_P, _I, _I, _I, _I, _P, _P, _P],
@@ -65,6 +68,7 @@ SIGNATURES = {
     "mlsp_sa_group_bwd_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_region_assign_f32": [_P, _I, _I, _I, _P, _I, _F, _P, _P],
     "mlsp_deform_regions_f32": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P],
+    "mlsp_collapse_to_point_f32": [_P, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P],
     "mlsp_scan_select_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _P],
     "mlsp_set_gemm_precision": [_I],
     "mlsp_profile_begin": [],

@@ -42,6 +42,13 @@ int launch_sa_group_fwd(hipStream_t st, const float* xyz, int ldx, const float* 
 int launch_sa_group_bwd(hipStream_t st, const float* dG, int D, const int* rev_off, const int* rev_ent, int B, int N, int S, int ns,
                         float* dfeat);
 
+int launch_collapse_to_point(hipStream_t st, float* X, int B, int N, const int* choice, const float* u, const float* noise, float r2,
+                             int min_pts, float* mask, int* chosen);
+int launch_knn_query(hipStream_t st, const float* ref, int ldr, int Nr, const float* qry, int ldq, int Nq, int B, int C, int k, int* idx,
+                     float* dist);
+int launch_interp3_fwd(hipStream_t st, const float* feat, const int* idx, const float* dist, int B, int N, int S, int D, float* out);
+int launch_interp3_bwd(hipStream_t st, const float* dout, const float* dist, const int* rev_off, const int* rev_ent, int B, int N, int S,
+                       int D, float* dfeat);
 int launch_region_assign(hipStream_t st, const float* X, int B, int C, int N, const float* thr, int n, float clip, int* Y);
 int launch_scan_select(hipStream_t st, const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask);
 int launch_deform_regions(hipStream_t st, float* X, int B, int C, int N, const int* regions, const int* order, int nreg, const float* lookup,
@@ -192,6 +199,21 @@ int mlsp_region_assign_f32(const float* X, int B, int C, int N, const float* thr
 int mlsp_deform_regions_f32(float* X, int B, int C, int N, const int32_t* regions, const int32_t* order, int nreg, const float* lookup,
                             const float* noise, int min_pts, int groups, float* mask, mlsp_stream_t st) {
     return launch_deform_regions(st, X, B, C, N, regions, order, nreg, lookup, noise, min_pts, groups, mask);
+}
+int mlsp_knn_query_f32(const float* ref, int ldr, int Nr, const float* qry, int ldq, int Nq, int B, int C, int k, int32_t* idx, float* dist,
+                       mlsp_stream_t st) {
+    return launch_knn_query(st, ref, ldr, Nr, qry, ldq, Nq, B, C, k, idx, dist);
+}
+int mlsp_interp3_fwd_f32(const float* feat, const int32_t* idx, const float* dist, int B, int N, int S, int D, float* out, mlsp_stream_t st) {
+    return launch_interp3_fwd(st, feat, idx, dist, B, N, S, D, out);
+}
+int mlsp_interp3_bwd_f32(const float* dout, const float* dist, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int D,
+                         float* dfeat, mlsp_stream_t st) {
+    return launch_interp3_bwd(st, dout, dist, rev_off, rev_ent, B, N, S, D, dfeat);
+}
+int mlsp_collapse_to_point_f32(float* X, int B, int N, const int32_t* choice, const float* u, const float* noise, float radius2,
+                               int min_pts, float* mask, int32_t* chosen, mlsp_stream_t st) {
+    return launch_collapse_to_point(st, X, B, N, choice, u, noise, radius2, min_pts, mask, chosen);
 }
 int mlsp_scan_select_f32(const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask, mlsp_stream_t st) {
     return launch_scan_select(st, X, B, N, C, R, pixel, Xs, mask);

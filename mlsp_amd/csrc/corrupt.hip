@@ -101,6 +101,88 @@ __global__ __launch_bounds__(1024) void scan_select_kernel(const float* __restri
     }
 }
 
+// deform_input(..., 'volume_based_radius') = pc_utils.collapse_to_point (utils/pc_utils.py:76-111), one workgroup per cloud:
+//   pd[i][j] = (xx_j + (-2 x_i.x_j)) + xx_i          (fp32, the reference's association; dot as an fmaf chain over the 3 coordinates)
+//   a point is a candidate when >= min_pts points lie within the radius (pd <= r2, itself included); one candidate is picked
+//   (uniformly by `u` in [0,1), or the given index `choice`), and every point within the radius of it is replaced by
+//   centre + noise (noise pre-scaled), mask = 1 on its three coordinates.  No candidate: the cloud is left untouched (the
+//   reference raises).  X [B][3][N]; chosen_out[b] = the picked point or -1.
+__global__ __launch_bounds__(1024) void collapse_to_point_kernel(float* __restrict__ X, int N, const int* __restrict__ choice,
+                                                                 const float* __restrict__ u, const float* __restrict__ noise, float r2,
+                                                                 int min_pts, float* __restrict__ mask, int* __restrict__ chosen_out) {
+    extern __shared__ float csm[];
+    float* px = csm; float* py = px + N; float* pz = py + N; float* xx = pz + N;      // [N] each
+    int* cand = (int*)(xx + N);                                                           // [N] candidate flags
+    __shared__ int s_ncand, s_pick;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* xb = X + (size_t)b * 3 * N;
+    for (int j = tid; j < N; j += 1024) {
+        const float a = xb[j], c = xb[N + j], d = xb[2 * N + j];
+        px[j] = a; py[j] = c; pz[j] = d;
+        xx[j] = (a * a + c * c) + d * d;
+    }
+    if (tid == 0) { s_ncand = 0; s_pick = -1; }
+    __syncthreads();
+    int my = 0;
+    for (int i = tid; i < N; i += 1024) {
+        const float a = px[i], c = py[i], d = pz[i], xi = xx[i];
+        int cnt = 0;
+        for (int j = 0; j < N; ++j) {
+            const float dot = fmaf(d, pz[j], fmaf(c, py[j], a * px[j]));
+            const float pd = (xx[j] + (-2.f * dot)) + xi;
+            cnt += pd <= r2;
+        }
+        const int f = cnt >= min_pts;
+        cand[i] = f; my += f;
+    }
+    atomicAdd(&s_ncand, my);
+    __syncthreads();
+    const int ncand = s_ncand;
+    if (ncand > 0) {
+        int want = (choice && choice[b] >= 0) ? -2 : (int)(u[b] * (float)ncand);
+        if (want >= ncand) want = ncand - 1;
+        if (want == -2) { if (tid == 0) s_pick = choice[b]; }
+        else {
+            for (int i = tid; i < N; i += 1024) {
+                if (!cand[i]) continue;
+                int rank = 0;
+                for (int j = 0; j < i; ++j) rank += cand[j];
+                if (rank == want) s_pick = i;
+            }
+        }
+    }
+    __syncthreads();
+    const int p = s_pick;
+    if (tid == 0) chosen_out[b] = p;
+    float* mb = mask + (size_t)b * 3 * N;
+    const float* nb = noise + (size_t)b * 3 * N;
+    float ca = 0.f, cc = 0.f, cd = 0.f, xp = 0.f;
+    if (p >= 0) { ca = px[p]; cc = py[p]; cd = pz[p]; xp = xx[p]; }
+    for (int j = tid; j < N; j += 1024) {
+        bool hit = false;
+        if (p >= 0) {
+            const float dot = fmaf(cd, pz[j], fmaf(cc, py[j], ca * px[j]));
+            hit = ((xx[j] + (-2.f * dot)) + xp) <= r2;
+        }
+        if (hit) { xb[j] = ca + nb[j]; xb[N + j] = cc + nb[N + j]; xb[2 * N + j] = cd + nb[2 * N + j]; }
+        const float m = hit ? 1.f : 0.f;
+        mb[j] = m; mb[N + j] = m; mb[2 * N + j] = m;
+    }
+}
+
+int launch_collapse_to_point(hipStream_t st, float* X, int B, int N, const int* choice, const float* u, const float* noise, float r2,
+                             int min_pts, float* mask, int* chosen) {
+    if (!X || !noise || !mask || !chosen || (!u && !choice) || B <= 0 || N <= 0 || min_pts <= 0) return MLSP_ERR_ARG;
+    const size_t lds = (size_t)N * 5 * sizeof(float);
+    if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)collapse_to_point_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(collapse_to_point_kernel, dim3(B), dim3(1024), lds, st, X, N, choice, u, noise, r2, min_pts, mask, chosen);
+    return mlsp_launch_status();
+}
+
 int launch_scan_select(hipStream_t st, const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask) {
     if (!X || !R || !Xs || !mask || B <= 0 || N <= 0 || C < 3 || pixel <= 0) return MLSP_ERR_ARG;
     const size_t lds = (size_t)N * (sizeof(double) + sizeof(int));

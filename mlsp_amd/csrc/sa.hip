@@ -183,3 +183,147 @@ int launch_sa_group_bwd(hipStream_t st, const float* dG, int D, const int* rev_o
     hipLaunchKernelGGL(sa_group_bwd_kernel, dim3((P + 3) / 4), dim3(256), 0, st, dG, D, rev_off, rev_ent, N, S, ns, P, dfeat);
     return mlsp_launch_status();
 }
+
+// ---- kNN of QUERY points among REFERENCE points (ref != query): `square_distance` + argsort()[:, :, :k] of
+// pointnet_util.py:26-38,116-118 (knn=True grouping, :237-239 Msg) and the 3-NN of PointNetFeaturePropagation (:287-289);
+// also the shape of knn_cuda.KNN / the KNN calls of PointDA/model_utils.py:175,188.
+//   d(q, r) = fl( fl(-2 * dot(q, r) + |q|^2) + |r|^2 ),  dot an fmaf chain over the C <= 8 coordinates, norms (x0^2 + x1^2) + ...
+//   order: d ascending, ties -> lower reference index; the k best, nearest first.
+// One thread per query with a sorted k-list in registers; the references stream through LDS in tiles of 256.
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_query_kernel(const float* __restrict__ ref, int ldr, int Nr, const float* __restrict__ qry,
+                                                        int ldq, int Nq, int C, int k, int* __restrict__ idx, float* __restrict__ dist) {
+    __shared__ float rs[256 * 8];
+    __shared__ float rn[256];
+    const int b = blockIdx.y, tid = threadIdx.x, q = blockIdx.x * 256 + tid;
+    const float* rb = ref + (size_t)b * Nr * ldr;
+    float qv[8], qn = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qv[c] = 0.f;
+    if (q < Nq) {
+        const float* qp = qry + ((size_t)b * Nq + q) * ldq;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) { qv[c] = qp[c]; qn = c == 0 ? qv[0] * qv[0] : qn + qv[c] * qv[c]; }
+    }
+    float bv[KMAX];
+    int bi[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { bv[s] = INFINITY; bi[s] = 0x7fffffff; }
+    for (int r0 = 0; r0 < Nr; r0 += 256) {
+        __syncthreads();
+        const int r = r0 + tid;
+        float nn = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = (r < Nr && c < C) ? rb[(size_t)r * ldr + c] : 0.f;
+            rs[tid * 8 + c] = v;
+            if (c < C) nn = c == 0 ? v * v : nn + v * v;
+        }
+        rn[tid] = nn;
+        __syncthreads();
+        const int lim = min(256, Nr - r0);
+        for (int j = 0; j < lim; ++j) {
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < C) dot = fmaf(qv[c], rs[j * 8 + c], dot);
+            const float d = (-2.f * dot + qn) + rn[j];
+            if (d < bv[KMAX - 1]) {                                     // strict: an equal distance with a higher index stays out
+                const int jj = r0 + j;
+#pragma unroll
+                for (int s = KMAX - 1; s >= 1; --s) {
+                    const bool up = d < bv[s - 1];
+                    const bool here = d < bv[s];
+                    const float nv = up ? bv[s - 1] : (here ? d : bv[s]);
+                    const int ni = up ? bi[s - 1] : (here ? jj : bi[s]);
+                    bv[s] = nv; bi[s] = ni;
+                }
+                if (d < bv[0]) { bv[0] = d; bi[0] = jj; }
+            }
+        }
+    }
+    if (q < Nq) {
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s)
+            if (s < k) {
+                idx[((size_t)b * Nq + q) * k + s] = bi[s];
+                if (dist) dist[((size_t)b * Nq + q) * k + s] = bv[s];
+            }
+    }
+}
+
+int launch_knn_query(hipStream_t st, const float* ref, int ldr, int Nr, const float* qry, int ldq, int Nq, int B, int C, int k, int* idx,
+                     float* dist) {
+    if (!ref || !qry || !idx || B <= 0 || Nr <= 0 || Nq <= 0 || C <= 0 || C > 8 || ldr < C || ldq < C || k <= 0 || k > Nr) return MLSP_ERR_ARG;
+    if (k > 64) return MLSP_ERR_UNSUPPORTED;
+    const dim3 grid((Nq + 255) / 256, B);
+    if (k <= 4) hipLaunchKernelGGL((knn_query_kernel<4>), grid, dim3(256), 0, st, ref, ldr, Nr, qry, ldq, Nq, C, k, idx, dist);
+    else if (k <= 16) hipLaunchKernelGGL((knn_query_kernel<16>), grid, dim3(256), 0, st, ref, ldr, Nr, qry, ldq, Nq, C, k, idx, dist);
+    else if (k <= 32) hipLaunchKernelGGL((knn_query_kernel<32>), grid, dim3(256), 0, st, ref, ldr, Nr, qry, ldq, Nq, C, k, idx, dist);
+    else hipLaunchKernelGGL((knn_query_kernel<64>), grid, dim3(256), 0, st, ref, ldr, Nr, qry, ldq, Nq, C, k, idx, dist);
+    return mlsp_launch_status();
+}
+
+// ---- PointNetFeaturePropagation interpolation (pointnet_util.py:287-294): out[b][n] = sum_t w_t * feat[b][idx[n][t]],
+// w_t = (1 / (d_t + 1e-8)) / sum_t' (1 / (d_t' + 1e-8)) over the three nearest sampled points.  Thread = (point, channel quad).
+__global__ __launch_bounds__(256) void interp3_fwd_kernel(const float* __restrict__ feat, const int* __restrict__ idx,
+                                                          const float* __restrict__ dist, int N, int S, int D, size_t total,
+                                                          float* __restrict__ out) {
+    const int dq = (D + 3) >> 2;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t pn = t / dq; const int c = (int)(t % dq) * 4;
+        const int b = (int)(pn / N);
+        float w[3], ws = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { w[u] = 1.0f / (dist[pn * 3 + u] + 1e-8f); ws += w[u]; }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const float wu = w[u] / ws;
+            const float* f = feat + ((size_t)b * S + idx[pn * 3 + u]) * D + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < D) acc[e] += f[e] * wu;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < D) out[pn * D + c + e] = acc[e];
+    }
+}
+// backward over the reverse index of idx [B][N][3] (mlsp_group_reverse with the roles S <- N, N <- S): wave per source point
+__global__ __launch_bounds__(256) void interp3_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ dist,
+                                                          const int* __restrict__ rev_off, const int* __restrict__ rev_ent, int N, int S,
+                                                          int D, int total_src, float* __restrict__ dfeat) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= total_src) return;
+    const int b = s / S;
+    const int e0 = rev_off[s], e1 = rev_off[s + 1];
+    for (int c = lane; c < D; c += 64) {
+        float acc = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const int ent = rev_ent[e];
+            const size_t pn = (size_t)b * N + (ent >> 8);
+            const int u = ent & 255;
+            float ws = 0.f, wu = 0.f;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { const float w = 1.0f / (dist[pn * 3 + v] + 1e-8f); ws += w; wu = v == u ? w : wu; }
+            acc += dout[pn * D + c] * (wu / ws);
+        }
+        dfeat[(size_t)s * D + c] = acc;
+    }
+}
+int launch_interp3_fwd(hipStream_t st, const float* feat, const int* idx, const float* dist, int B, int N, int S, int D, float* out) {
+    if (!feat || !idx || !dist || !out || B <= 0 || N <= 0 || S < 3 || D <= 0) return MLSP_ERR_ARG;
+    const size_t total = (size_t)B * N * ((D + 3) / 4);
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(interp3_fwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, feat, idx, dist, N, S, D, total, out);
+    return mlsp_launch_status();
+}
+int launch_interp3_bwd(hipStream_t st, const float* dout, const float* dist, const int* rev_off, const int* rev_ent, int B, int N, int S,
+                       int D, float* dfeat) {
+    if (!dout || !dist || !rev_off || !rev_ent || !dfeat || B <= 0 || N <= 0 || S <= 0 || D <= 0) return MLSP_ERR_ARG;
+    hipLaunchKernelGGL(interp3_bwd_kernel, dim3((B * S + 3) / 4), dim3(256), 0, st, dout, dist, rev_off, rev_ent, N, S, D, B * S, dfeat);
+    return mlsp_launch_status();
+}

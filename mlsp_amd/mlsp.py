@@ -17,14 +17,14 @@ from .labels import cal_density, cal_density_gpu, estimate_normals   # noqa: F40
 DefRec_SCALER = 20.0   # MLSP/mlsp.py:7
 
 
-def deform_input(X, lookup, DefRec_dist='volume_based_voxels', device='cuda:0', groups=1, region_ids=None, noise=None):
+def deform_input(X, lookup, DefRec_dist='volume_based_voxels', device='cuda:0', groups=1, region_ids=None, noise=None, choice=None):
     """MLSP/mlsp.py:10-51.  X [B,C,N] is deformed IN PLACE (as in the reference) and returned with the 0/1 mask [B,C,N].
     Per cloud the first `groups` voxels of a random visiting order that hold >= 40 points collapse to a Gaussian blob
     (std sqrt(0.001), pc_utils.draw_from_gaussian) around the voxel centre `lookup[i]`.
     The random inputs may be injected for reproducible runs: `region_ids` (a permutation of the 27 voxel ids; default
     np.random.permutation like :27) and `noise` [B,3,N] standard normal (default torch.randn on the device)."""
-    if DefRec_dist != 'volume_based_voxels':
-        raise NotImplementedError("deform_input on MI355X implements DefRec_dist='volume_based_voxels' (the trainer's default)")
+    if DefRec_dist not in ('volume_based_voxels', 'volume_based_radius'):
+        raise ValueError("DefRec_dist must be 'volume_based_voxels' or 'volume_based_radius'")
     lib = _lib.load()
     _lib.require_gpu(X)
     # every call site of the trainer passes `data.permute(0, 2, 1)` of a [B,N,3] loader tensor (PointDA/trainer.py:381-387,
@@ -34,6 +34,24 @@ def deform_input(X, lookup, DefRec_dist='volume_based_voxels', device='cuda:0', 
     if not X.is_contiguous() or X.dtype != torch.float32:
         X = X.float().contiguous()
     B, C, N = X.shape
+    if DefRec_dist == 'volume_based_radius':
+        # pc_utils.collapse_to_point per cloud (utils/pc_utils.py:76-111): a random point with >= MIN_POINTS points inside RADIUS
+        # attracts everything within RADIUS of it; `choice` [B] pins the picked points (default: uniform among the candidates)
+        if C != 3:
+            raise ValueError("'volume_based_radius' needs [B,3,N] clouds (the reference assigns a 3-row block)")
+        if noise is None:
+            noise = torch.randn(B, 3, N, device=X.device)
+        scaled = (noise.to(X.device, torch.float32) * float(np.sqrt(0.001))).contiguous()
+        ch = None if choice is None else torch.as_tensor(np.asarray(choice), dtype=torch.int32).to(X.device)
+        u = torch.rand(B, device=X.device)
+        mask = torch.empty_like(X)
+        chosen = torch.empty(B, dtype=torch.int32, device=X.device)
+        _lib.check(lib.mlsp_collapse_to_point_f32(X.data_ptr(), B, N, _lib.ptr(ch), u.data_ptr(), scaled.data_ptr(),
+                                                  float(np.float32(pc_utils.RADIUS ** 2)), pc_utils.MIN_POINTS, mask.data_ptr(),
+                                                  chosen.data_ptr(), _lib.stream()), "mlsp_collapse_to_point_f32")
+        if X is not X_arg:
+            X_arg.copy_(X)
+        return X_arg, mask
     n = pc_utils.NREGIONS
     regions = pc_utils.assign_region_to_point(X, device).to(torch.int32)
     if region_ids is None:

@@ -122,11 +122,23 @@ class conv_2d(nn.Module):
         """Fused get_graph_feature + this conv + max over k.  xp [P,C] -> [P,Cout] (written into `out` when given: a column
         slice of the caller's concatenation buffer)."""
         conv, bn = self.conv[0], self.conv[1]
-        if conv.bias is not None:
-            raise NotImplementedError("fused EdgeConv expects bias=False (every DGCNN edge conv)")
         rm, rv = _bn_buffers(bn, self.training)
-        return Fh.edgeconv(xp, graph, conv.weight.view(conv.out_channels, conv.in_channels), bn.weight, bn.bias, rm, rv,
-                           self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps, out=out)
+        W = conv.weight.view(conv.out_channels, conv.in_channels)
+        if conv.bias is None:
+            return Fh.edgeconv(xp, graph, W, bn.weight, bn.bias, rm, rv, self.training, act=self.act, slope=0.2,
+                               momentum=bn.momentum, eps=bn.eps, out=out)
+        # conv_2d(bias=True) (model_utils.py:45-63 default): a per-channel constant in front of the BatchNorm.  Training: the batch
+        # mean absorbs it (output unchanged, its gradient is exactly zero), only the running mean sees it.  Eval: it shifts the
+        # normalised value by scale * bias, i.e. it is the same as evaluating with running_mean - bias.
+        b = conv.bias
+        if self.training:
+            y = Fh.edgeconv(xp, graph, W, bn.weight, bn.bias, rm, rv, True, act=self.act, slope=0.2, momentum=bn.momentum,
+                            eps=bn.eps, out=out)
+            with torch.no_grad():
+                rm.add_(bn.momentum * b)
+            return y + 0.0 * b.sum()               # keeps bias in the graph with the zero gradient the reference gives it
+        return Fh.edgeconv(xp, graph, W, bn.weight, bn.bias, rm - b.detach(), rv, False, act=self.act, slope=0.2,
+                           momentum=bn.momentum, eps=bn.eps, out=out)
 
     @flushing_forward
     def forward(self, x):
@@ -161,7 +173,12 @@ class fc_layer(nn.Module):
         feeds another Linear+BN layer (it may then be stored as bf16 under functional.activation_storage("bf16"))."""
         lin = self.fc[0]
         if not self.has_bn:
-            raise NotImplementedError("fc_layer(bn=False) is not on the DGCNN hot path")
+            # fc_layer(bn=False) (model_utils.py:80-84): Linear + activation = the fused layer with an identity BatchNorm in eval
+            # mode (scale 1, shift = the bias, eps 0), which is exact
+            n = lin.out_features
+            one, zero = torch.ones(n, device=x.device), torch.zeros(n, device=x.device)
+            return Fh.pointmlp(x, lin.weight, gamma=one, beta=lin.bias if lin.bias is not None else zero, run_mean=zero, run_var=one,
+                               training=False, act=self.act, slope=0.2, eps=0.0)
         bn = self.fc[1]
         rm, rv = _bn_buffers(bn, self.training)
         return Fh.pointmlp(x, lin.weight, bias=lin.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,

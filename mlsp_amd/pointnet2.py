@@ -7,8 +7,9 @@ against that file runs unchanged.  Farthest point sampling, ball query and group
 bit-exact indices; the SA-MLP is the fused Linear+BN+ReLU kernel family over the B*S*nsample edge rows followed by the
 per-centre max.  No CPU fallback: every entry point raises MlspLibraryError without the HIP library.
 
-Not built (documented in DESIGN.md): `knn=True` grouping (argsort over a centre-to-point distance matrix),
-PointNetSetAbstractionMsg / FeaturePropagation, gradients with respect to the coordinates.
+`knn=True` grouping, PointNetSetAbstractionMsg and PointNetFeaturePropagation run on the query-kNN kernel (ref != query,
+mlsp_knn_query_f32) and the 3-NN interpolation kernels.  Not built: gradients with respect to the coordinates (the reference never
+asks for them: coordinates are inputs).
 """
 import torch
 import torch.nn as nn
@@ -67,6 +68,55 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
     return idx.long()
 
 
+def knn_point(k, xyz, new_xyz, return_dist=False):
+    """`square_distance(new_xyz, xyz).argsort()[:, :, :k]` (pointnet_util.py:26-38,116-118) without the [B,S,N] matrix:
+    xyz [B,N,3] reference points, new_xyz [B,S,3] queries -> idx [B,S,k] int64, nearest first (ties -> lower index)."""
+    lib = _lib.load()
+    x, q = _xyz_rows(xyz), _xyz_rows(new_xyz)
+    _lib.require_gpu(x, q)
+    B, N, C = x.shape
+    S = q.shape[1]
+    idx = torch.empty((B, S, k), dtype=torch.int32, device=x.device)
+    dist = torch.empty((B, S, k), dtype=torch.float32, device=x.device) if return_dist else None
+    _lib.check(lib.mlsp_knn_query_f32(x.data_ptr(), x.stride(1), N, q.data_ptr(), q.stride(1), S, B, min(C, 8), k, idx.data_ptr(),
+                                      _lib.ptr(dist), _lib.stream()), "mlsp_knn_query_f32")
+    return (idx.long(), dist) if return_dist else idx.long()
+
+
+class _Interp3(Function):
+    """Inverse-distance interpolation from the three nearest sampled points (pointnet_util.py:287-294)."""
+
+    @staticmethod
+    def forward(ctx, feat, idx32, dist):
+        lib = _lib.load()
+        feat = feat.contiguous()
+        B, S, D = feat.shape
+        N = idx32.shape[1]
+        out = torch.empty((B, N, D), dtype=torch.float32, device=feat.device)
+        _lib.check(lib.mlsp_interp3_fwd_f32(feat.data_ptr(), idx32.data_ptr(), dist.data_ptr(), B, N, S, D, out.data_ptr(), _lib.stream()),
+                   "mlsp_interp3_fwd_f32")
+        ctx.save_for_backward(idx32, dist)
+        ctx.dims = (B, N, S, D)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        lib = _lib.load()
+        idx32, dist = ctx.saved_tensors
+        B, N, S, D = ctx.dims
+        dout = dout.contiguous()
+        dev = dout.device
+        rev_off = torch.empty((B * S + 1,), dtype=torch.int32, device=dev)
+        rev_ent = torch.empty((B * N * 3,), dtype=torch.int32, device=dev)
+        _lib.check(lib.mlsp_group_reverse(idx32.data_ptr(), B, N, S, 3, rev_off.data_ptr(), rev_ent.data_ptr(), _lib.stream()),
+                   "mlsp_group_reverse")
+        dfeat = torch.empty((B, S, D), dtype=torch.float32, device=dev)
+        _lib.check(lib.mlsp_interp3_bwd_f32(dout.data_ptr(), dist.data_ptr(), rev_off.data_ptr(), rev_ent.data_ptr(), B, N, S, D,
+                                            dfeat.data_ptr(), _lib.stream()), "mlsp_interp3_bwd_f32")
+        return dfeat, None, None
+
+
 class _Group(Function):
     """[xyz_j - new_xyz_i | feat_j] edge rows (pointnet_util.py:120-129); gradient flows to the features only."""
 
@@ -110,14 +160,12 @@ class _Group(Function):
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, knn=False, fps_start=None):
     """pointnet_util.py:99-136: FPS centres, ball-query neighbourhoods, centred coordinates + features.
     Returns new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D] (+ grouped_xyz, fps_idx with returnfps)."""
-    if knn:
-        raise NotImplementedError("sample_and_group(knn=True) is not built on MI355X yet (DESIGN.md 6)")
     B, N, C = xyz.shape
     if xyz.requires_grad:
         raise NotImplementedError("gradients with respect to the coordinates are not built (the reference never needs them)")
     fps_idx = farthest_point_sample(xyz, npoint, start=fps_start)
     new_xyz = index_points(xyz, fps_idx)
-    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    idx = knn_point(nsample, xyz, new_xyz) if knn else query_ball_point(radius, nsample, xyz, new_xyz)      # :116-120
     G = _Group.apply(xyz, new_xyz, points, idx)
     new_points = G.view(B, npoint, nsample, -1)
     if returnfps:
@@ -165,10 +213,99 @@ class PointNetSetAbstraction(nn.Module):
                                                    fps_start=self.fps_start)
             S, ns = self.npoint, self.nsample
         X = new_points.reshape(B * S * ns, new_points.shape[-1])          # edge-major rows (b, centre, slot)
-        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            rm, rv = _bn_buffers(bn, self.training)
-            X = Fh.pointmlp(X, conv.weight.view(conv.out_channels, conv.in_channels), bias=conv.bias, gamma=bn.weight,
-                            beta=bn.bias, run_mean=rm, run_var=rv, training=self.training, act=Fh.ACT_RELU,
-                            momentum=bn.momentum, eps=bn.eps)
+        X = _sa_mlp(X, self.mlp_convs, self.mlp_bns, self.training)
         out = Fh.colmax(X, B, ns) if self.group_all else Fh.segmax(X, ns)  # max over the neighbourhood
         return new_xyz, out.view(B, S, -1)
+
+
+def _sa_mlp(X, convs, bns, training, first_weight=None):
+    """Conv2d(1x1)+BN2d+ReLU stack of a set-abstraction branch on edge-major rows [B*S*ns, Cin]."""
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
+        rm, rv = _bn_buffers(bn, training)
+        W = first_weight if (i == 0 and first_weight is not None) else conv.weight.view(conv.out_channels, conv.in_channels)
+        X = Fh.pointmlp(X, W, bias=conv.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv, training=training,
+                        act=Fh.ACT_RELU, momentum=bn.momentum, eps=bn.eps)
+    return X
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    """pointnet_util.py:199-258: multi-scale grouping -- one (radius, nsample, MLP) branch per scale around the same FPS centres,
+    outputs concatenated on the channel axis.  forward(xyz [B,N,3], points [B,N,D] | None, seed_idx=None) -> new_xyz [B,S,3],
+    new_points [B,S,sum(mlp[-1])].  The reference feeds its first conv [features | centred xyz] (:246) while the grouping kernel
+    emits [centred xyz | features]: the first layer's weight columns are permuted accordingly (same parameters, same result)."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list, knn=False):
+        super(PointNetSetAbstractionMsg, self).__init__()
+        self.npoint = npoint
+        self.radius_list = radius_list
+        self.nsample_list = nsample_list
+        self.knn = knn
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for i in range(len(mlp_list)):
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            last_channel = in_channel + 3
+            for out_channel in mlp_list[i]:
+                convs.append(nn.Conv2d(last_channel, out_channel, 1))
+                bns.append(nn.BatchNorm2d(out_channel))
+                last_channel = out_channel
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+        self.fps_start = None
+
+    @flushing_forward
+    def forward(self, xyz, points, seed_idx=None):
+        B, N, C = xyz.shape
+        S = self.npoint
+        fps_idx = farthest_point_sample(xyz, S, start=self.fps_start) if seed_idx is None else seed_idx
+        new_xyz = index_points(xyz, fps_idx)
+        outs = []
+        for i, radius in enumerate(self.radius_list):
+            K = self.nsample_list[i]
+            idx = knn_point(K, xyz, new_xyz) if self.knn else query_ball_point(radius, K, xyz, new_xyz)
+            G = _Group.apply(xyz, new_xyz, points, idx)                              # rows [xyz_j - c_i | feat_j]
+            c0 = self.conv_blocks[i][0]
+            W0 = c0.weight.view(c0.out_channels, c0.in_channels)
+            if points is not None:
+                D = points.shape[-1]
+                W0 = torch.cat((W0[:, D:], W0[:, :D]), dim=1)                        # reference column order: [feat | xyz]
+            X = _sa_mlp(G, self.conv_blocks[i], self.bn_blocks[i], self.training, first_weight=W0)
+            outs.append(Fh.segmax(X, K).view(B, S, -1))
+        return new_xyz, torch.cat(outs, dim=-1)
+
+
+class PointNetFeaturePropagation(nn.Module):
+    """pointnet_util.py:261-310.  forward(xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D1,N] | None, points2 [B,D2,S]) -> [B,mlp[-1],N]
+    (channel-major in and out, as the reference: "this function swaps N and C")."""
+
+    def __init__(self, in_channel, mlp):
+        super(PointNetFeaturePropagation, self).__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last_channel = out_channel
+
+    @flushing_forward
+    def forward(self, xyz1, xyz2, points1, points2):
+        x1 = xyz1.permute(0, 2, 1).contiguous()
+        x2 = xyz2.permute(0, 2, 1).contiguous()
+        p2 = points2.permute(0, 2, 1).contiguous()
+        B, N, _ = x1.shape
+        S = x2.shape[1]
+        if S == 1:
+            interp = p2.repeat(1, N, 1)
+        else:
+            if S < 3:
+                raise ValueError("feature propagation needs at least three sampled points (or exactly one)")
+            idx, dist = knn_point(3, x2, x1, return_dist=True)                       # three nearest sampled points of every point
+            interp = _Interp3.apply(p2, idx.to(torch.int32).contiguous(), dist)
+        new = torch.cat([points1.permute(0, 2, 1), interp], dim=-1) if points1 is not None else interp
+        X = new.reshape(B * N, -1)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            rm, rv = _bn_buffers(bn, self.training)
+            X = Fh.pointmlp(X, conv.weight.view(conv.out_channels, conv.in_channels), bias=conv.bias, gamma=bn.weight, beta=bn.bias,
+                            run_mean=rm, run_var=rv, training=self.training, act=Fh.ACT_RELU, momentum=bn.momentum, eps=bn.eps)
+        return X.view(B, N, -1).permute(0, 2, 1)

@@ -102,3 +102,31 @@ def scan(X, pixel_size, angles):
         mask[b][keep, :3] = 0.0
         out[b][keep] = X[b][keep]
     return out, mask
+
+
+def collapse_to_point(X, choice, noise, radius=0.5, min_pts=20):
+    """deform_input(..., 'volume_based_radius') = utils/pc_utils.py:76-111 collapse_to_point per cloud, with the random draws passed in:
+    `choice` [B] the picked candidate of every cloud, `noise` [B,3,N] standard normal (scaled by sqrt(0.001) like draw_from_gaussian).
+    X [B,3,N] -> (deformed copy, mask [B,3,N], candidate flags [B,N]).  fp32 arithmetic in the reference's association:
+    pd = (xx_j + (-2 x_i.x_j)) + xx_i, in-radius iff pd <= radius^2, candidate iff >= min_pts points in radius."""
+    X = X.astype(np.float32).copy()
+    B, _, N = X.shape
+    mask = np.zeros_like(X)
+    cand = np.zeros((B, N), bool)
+    r2 = np.float32(radius ** 2)
+    std = np.float32(np.sqrt(0.001))
+    for b in range(B):
+        x = X[b]
+        xx = (x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]
+        dot = (x[0][:, None] * x[0][None, :] + x[1][:, None] * x[1][None, :]) + x[2][:, None] * x[2][None, :]
+        pd = (xx[None, :] + np.float32(-2.0) * dot) + xx[:, None]
+        inr = pd <= r2
+        cand[b] = inr.sum(1) >= min_pts
+        p = int(choice[b])
+        if p < 0:
+            continue
+        hit = inr[p]
+        centre = x[:, p].copy()
+        X[b][:, hit] = centre[:, None] + noise[b][:, hit].astype(np.float32) * std
+        mask[b][:, hit] = 1.0
+    return X, mask, cand

@@ -77,3 +77,67 @@ def sa_forward(params, buffers, cfg, xyz, points, start, training=True, momentum
         h = F.relu(h)
     out = h.max(2)[0].transpose(1, 2)
     return new_xyz, out, fps_idx, gidx, new_buffers
+
+
+# --------------------------------------------------------------------------- round 2: knn grouping, multi-scale grouping, feature propagation
+def square_distance(src, dst):
+    """pointnet_util.py:22-38: -2 src.dst^T + |src|^2 + |dst|^2, in that association."""
+    d = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    d = d + torch.sum(src ** 2, -1).unsqueeze(-1)
+    return d + torch.sum(dst ** 2, -1).unsqueeze(1)
+
+
+def knn_group(k, xyz, new_xyz):
+    """pointnet_util.py:116-118 (knn=True): the k nearest points of every centre, nearest first (ties -> lower index)."""
+    d = square_distance(new_xyz, xyz)
+    return torch.sort(d, dim=-1, stable=True)[1][:, :, :k]
+
+
+def _conv_bn_relu(h, params, new_buffers, conv_key, bn_key, training, momentum, eps, conv):
+    h = conv(h, params[conv_key + ".weight"], params[conv_key + ".bias"])
+    rm, rv = new_buffers[bn_key + ".running_mean"].clone(), new_buffers[bn_key + ".running_var"].clone()
+    h = F.batch_norm(h, rm, rv, params[bn_key + ".weight"], params[bn_key + ".bias"], training, momentum, eps)
+    new_buffers[bn_key + ".running_mean"], new_buffers[bn_key + ".running_var"] = rm, rv
+    return F.relu(h)
+
+
+def sa_msg_forward(params, buffers, cfg, xyz, points, fps_idx, training=True, momentum=0.1, eps=1e-5):
+    """PointNetSetAbstractionMsg.forward (pointnet_util.py:220-258) with the FPS indices passed in (`seed_idx`).
+    cfg: {"radius_list", "nsample_list", "mlp_list", "knn"}.  Returns new_xyz, new_points [B,S,sum], group indices, new_buffers."""
+    B, N, C = xyz.shape
+    S = fps_idx.shape[1]
+    new_buffers = dict(buffers)
+    new_xyz = gather_rows(xyz, fps_idx)
+    outs, gidxs = [], []
+    for i, radius in enumerate(cfg["radius_list"]):
+        K = cfg["nsample_list"][i]
+        gidx = knn_group(K, xyz, new_xyz) if cfg.get("knn") else ball_query(radius, K, xyz, new_xyz)
+        gidxs.append(gidx)
+        gx = gather_rows(xyz, gidx) - new_xyz.view(B, S, 1, C)
+        g = torch.cat([gather_rows(points, gidx), gx], -1) if points is not None else gx       # features first (:246)
+        h = g.permute(0, 3, 2, 1)
+        for j in range(len(cfg["mlp_list"][i])):
+            h = _conv_bn_relu(h, params, new_buffers, "conv_blocks.%d.%d" % (i, j), "bn_blocks.%d.%d" % (i, j), training, momentum, eps, F.conv2d)
+        outs.append(h.max(2)[0])
+    return new_xyz, torch.cat(outs, 1).transpose(1, 2), gidxs, new_buffers
+
+
+def fp_forward(params, buffers, mlp, xyz1, xyz2, points1, points2, training=True, momentum=0.1, eps=1e-5):
+    """PointNetFeaturePropagation.forward (pointnet_util.py:272-310); channel-major inputs/outputs like the reference."""
+    x1, x2, p2 = xyz1.permute(0, 2, 1), xyz2.permute(0, 2, 1), points2.permute(0, 2, 1)
+    B, N, _ = x1.shape
+    S = x2.shape[1]
+    new_buffers = dict(buffers)
+    if S == 1:
+        interp = p2.repeat(1, N, 1)
+    else:
+        d, idx = torch.sort(square_distance(x1, x2), dim=-1, stable=True)
+        d, idx = d[:, :, :3], idx[:, :, :3]
+        recip = 1.0 / (d + 1e-8)
+        w = recip / recip.sum(2, keepdim=True)
+        interp = (gather_rows(p2, idx) * w.view(B, N, 3, 1)).sum(2)
+    h = torch.cat([points1.permute(0, 2, 1), interp], -1) if points1 is not None else interp
+    h = h.permute(0, 2, 1)
+    for i in range(len(mlp)):
+        h = _conv_bn_relu(h, params, new_buffers, "mlp_convs.%d" % i, "mlp_bns.%d" % i, training, momentum, eps, F.conv1d)
+    return h, new_buffers

@@ -51,3 +51,15 @@ def test_scan_oracle_vs_reference():
     g = dict(np.load(os.path.join(GOLD, "scan_s21_B5_N512.npz")))
     out, mask = oc.scan(g["X"], float(g["pixel_size"]), g["angles"])
     assert np.array_equal(mask, g["mask"]) and np.array_equal(out, g["X_out"])
+
+
+def test_collapse_to_point_oracle_vs_reference():
+    """deform_input(..., 'volume_based_radius'): oracle/ref_corrupt_np.collapse_to_point with the reference's recorded draws reproduces
+    the reference's mask exactly and its deformed cloud to fp32 rounding (tests/golden/collapse_*.npz, tools/make_golden.py radius)."""
+    g = dict(np.load(os.path.join(GOLD, "collapse_s9_B5_N512.npz")))
+    X, mask, cand = oc.collapse_to_point(g["X"], g["choice"], g["noise"])
+    assert np.array_equal(mask, g["mask"])
+    np.testing.assert_allclose(X, g["X_out"], rtol=0, atol=2e-7)
+    assert all(cand[b, g["choice"][b]] for b in range(len(g["choice"])))       # the reference only picks candidates
+    keep = g["mask"] == 0
+    assert np.array_equal(X[keep], g["X"][keep])

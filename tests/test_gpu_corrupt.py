@@ -82,3 +82,30 @@ def test_scan_input_vs_reference(dev):
     Xs2, m2 = mlsp.scan_input(X2, dev)
     kept = (m2[:, :, 0] == 0)
     assert (kept.sum(1) > 100).all() and (Xs2[~kept] == 0).all() and torch.equal(Xs2[kept], torch.from_numpy(g["X"]).to(dev)[kept])
+
+
+def test_deform_input_volume_based_radius(dev):
+    """mlsp.deform_input(..., 'volume_based_radius') (MLSP/mlsp.py:33-36 -> pc_utils.collapse_to_point) on device: with the reference's
+    recorded picks and Gaussian draws the mask is identical and the deformed cloud equal to fp32 rounding; with its own draws the
+    picked point is a candidate (>= 20 points within 0.5) and exactly the points within 0.5 of it move."""
+    from mlsp_amd import mlsp
+    g = dict(np.load(os.path.join(GOLD, "collapse_s9_B5_N512.npz")))
+    X = torch.from_numpy(g["X"]).to(dev)
+    Xd, mask = mlsp.deform_input(X.clone(), None, 'volume_based_radius', dev, choice=g["choice"], noise=torch.from_numpy(g["noise"]))
+    assert np.array_equal(mask.cpu().numpy(), g["mask"])
+    np.testing.assert_allclose(Xd.cpu().numpy(), g["X_out"], rtol=0, atol=3e-7)
+    # the trainer's calling convention: a permuted (non-contiguous) view, default draws
+    Xv = torch.from_numpy(g["X"]).to(dev).permute(0, 2, 1).contiguous().permute(0, 2, 1)
+    assert not Xv.is_contiguous()
+    orig = Xv.clone()
+    X2, m2 = mlsp.deform_input(Xv, None, 'volume_based_radius', dev)
+    assert X2.data_ptr() == Xv.data_ptr()
+    moved = (X2 != orig).any(1)
+    assert torch.equal(moved, m2[:, 0] > 0) and (m2[:, 0].sum(1) >= 20).all()
+    _, _, cand = oc.collapse_to_point(g["X"], -np.ones(5, np.int32), g["noise"])
+    for b in range(5):                                   # the moved set is the 0.5-ball of ONE candidate point of the original cloud
+        o = orig[b].cpu().numpy()
+        d2 = ((o[:, :, None] - o[:, None, :]) ** 2).sum(0)
+        sets = {tuple(np.nonzero(d2[p] <= 0.25 + 1e-6)[0]) for p in np.nonzero(cand[b])[0]} | \
+               {tuple(np.nonzero(d2[p] <= 0.25 - 1e-6)[0]) for p in np.nonzero(cand[b])[0]}
+        assert tuple(np.nonzero(moved[b].cpu().numpy())[0]) in sets

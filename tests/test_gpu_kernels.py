@@ -649,3 +649,45 @@ def test_knn_two_pass_overflow_fallback(dev):
     want = knn_canon.knn_point_major(xf.view(2, 1024, 64), k)
     got = Fh.knn_graph(xf.to(dev), 2, 1024, k).idx.view(2, 1024, k).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------- API parity of the op layer's optional arguments
+@pytest.mark.parametrize("training", [True, False])
+def test_conv2d_edge_with_bias_and_fc_without_bn(dev, training):
+    """model_utils.conv_2d(bias=True) on the fused EdgeConv path and fc_layer(bn=False) (PointDA/model_utils.py:45-87 accept both):
+    compared with the same modules' materialised reference-shaped forward (graph feature -> conv+BN+act -> max over k) / plain torch."""
+    from mlsp_amd import model_utils as mu
+    Fh = _fh()
+    torch.manual_seed(3)
+    B, N, C, k = 2, 128, 8, 20
+    conv = mu.conv_2d(2 * C, 32, 1, activation='leakyrelu', bias=True).to(dev)
+    with torch.no_grad():
+        conv.conv[0].bias.normal_(0, 0.5)
+        conv.conv[1].weight.uniform_(0.5, 1.5)
+        conv.conv[1].bias.normal_(0, 0.2)
+        conv.conv[1].running_mean.normal_(0, 0.3)
+        conv.conv[1].running_var.uniform_(0.5, 1.5)
+    conv.train(training)
+    ref = __import__("copy").deepcopy(conv)
+    x = _rand((B, C, N), 9).to(dev)
+    xp = x.transpose(2, 1).contiguous().view(B * N, C).requires_grad_(True)
+    g = Fh.knn_graph(xp, B, N, k)
+    got = conv.edge(xp, g)
+    got.square().sum().backward()
+    xr = x.clone().requires_grad_(True)
+    feat = mu.get_graph_feature(xr, None, k=k, idx=g.idx.view(B, N, k).long())            # [B,2C,N,k]
+    want = ref(feat).max(dim=-1)[0].permute(0, 2, 1).reshape(B * N, 32)
+    want.square().sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(xp.grad.cpu().numpy(), xr.grad.transpose(2, 1).reshape(B * N, C).cpu().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(conv.conv[0].weight.grad.cpu().numpy(), ref.conv[0].weight.grad.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(conv.conv[1].running_mean.cpu().numpy(), ref.conv[1].running_mean.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    if training:
+        assert conv.conv[0].bias.grad is not None and conv.conv[0].bias.grad.abs().max().item() == 0.0
+    fc = mu.fc_layer(64, 48, bn=False, activation='leakyrelu').to(dev).train(training)
+    xin = _rand((40, 64), 4).to(dev).requires_grad_(True)
+    out = fc(xin)
+    out.sum().backward()
+    w, b = fc.fc[0].weight.detach(), fc.fc[0].bias.detach()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), F.leaky_relu(xin.detach() @ w.t() + b, 0.2).cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert fc.fc[0].weight.grad is not None and xin.grad is not None

@@ -96,3 +96,91 @@ def test_set_abstraction_stack_config3_shape(dev):
     # every sampled centre is its own first in-radius neighbour candidate; FPS indices are unique
     fps_idx = p2.farthest_point_sample(xyz, 512, start=torch.zeros(B, dtype=torch.long))
     assert all(len(set(r.tolist())) == 512 for r in fps_idx.cpu()[:4])
+
+
+# ----------------------------------------------------------------------------- round 2: knn grouping, multi-scale grouping, feature propagation
+from test_sa_oracle_cpu import split_state
+
+
+def _load_into(layer, g, dev):
+    params, buffers = split_state(g)
+    sd = dict(params)
+    sd.update(buffers)
+    for k in layer.state_dict():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+    layer.load_state_dict(sd, strict=True)                 # the reference's state_dict keys
+    return layer.to(dev).train()
+
+
+def _check_layer(g, layer, tol_grad=5e-3):
+    for k, p in layer.named_parameters():
+        want = g["grad/" + k]
+        err = np.linalg.norm(p.grad.cpu().numpy() - want) / (np.linalg.norm(want) + 1e-12)
+        assert err < tol_grad, (k, err)
+    st = layer.state_dict()
+    for k in st:
+        if "running" in k:
+            np.testing.assert_allclose(st[k].cpu().numpy(), g["state_after/" + k], rtol=1e-3, atol=1e-5, err_msg=k)
+
+
+def test_knn_point_bit_exact_vs_oracle(dev):
+    from mlsp_amd import pointnet2 as p2
+    g = torch.Generator().manual_seed(21)
+    for B, N, S, k in [(2, 300, 48, 12), (1, 2048, 512, 32), (3, 64, 64, 40), (2, 500, 7, 3)]:
+        xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+        q = xyz[:, torch.randperm(N, generator=g)[:S]] + (0.0 if k == 12 else 0.05) * torch.randn(B, S, 3, generator=g)
+        want = sa.knn_group(k, xyz, q)
+        got, dist = p2.knn_point(k, xyz.to(dev), q.to(dev), return_dist=True)
+        d = sa.square_distance(q, xyz)
+        gap = torch.sort(d, dim=-1)[0]
+        safe = ((gap[:, :, 1:k + 1] - gap[:, :, :k]).min(-1)[0] > 5e-6) if N > k else torch.ones(B, S, dtype=torch.bool)
+        assert torch.equal(got.cpu()[safe], want[safe]) and safe.float().mean() > 0.8     # rows whose rank gaps exceed fp32 rounding
+        np.testing.assert_allclose(dist.cpu().numpy(), torch.gather(d, 2, got.cpu()).numpy(), rtol=0, atol=2e-6)
+
+
+def test_sa_knn_grouping_vs_reference_golden(dev):
+    from mlsp_amd import pointnet2 as p2
+    g = dict(np.load(os.path.join(GOLD, "sa_knn_s11_B3_N300.npz")))
+    layer = _load_into(p2.PointNetSetAbstraction(48, 0.3, 12, 3 + 5, [16, 32], False, knn=True), g, dev)
+    layer.fps_start = torch.from_numpy(g["start"])
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    pts = torch.from_numpy(g["points"]).to(dev).requires_grad_(True)
+    assert np.array_equal(p2.knn_point(12, xyz, p2.index_points(xyz, torch.from_numpy(g["fps_idx"]).to(dev))).cpu().numpy(), g["group_idx"])
+    new_xyz, out = layer(xyz, pts)
+    np.testing.assert_allclose(new_xyz.cpu().numpy(), g["new_xyz"], rtol=0, atol=0)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["new_points"], rtol=1e-3, atol=2e-4)
+    (out * torch.from_numpy(g["wgt"]).to(dev)).sum().backward()
+    np.testing.assert_allclose(pts.grad.cpu().numpy(), g["d_points"], rtol=1e-3, atol=1e-4)
+    _check_layer(g, layer)
+
+
+@pytest.mark.parametrize("name,knn,D", [("sa_msg_s12_B2_N256.npz", False, 6), ("sa_msgknn_s12_B2_N256.npz", True, 0)])
+def test_sa_msg_vs_reference_golden(dev, name, knn, D):
+    from mlsp_amd import pointnet2 as p2
+    g = dict(np.load(os.path.join(GOLD, name)))
+    layer = _load_into(p2.PointNetSetAbstractionMsg(32, [0.2, 0.45], [8, 16], D, [[16, 24], [16, 32]], knn=knn), g, dev)
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    pts = torch.from_numpy(g["points"]).to(dev).requires_grad_(True) if D else None
+    new_xyz, out = layer(xyz, pts, seed_idx=torch.from_numpy(g["fps_idx"]).to(dev))
+    np.testing.assert_allclose(new_xyz.cpu().numpy(), g["new_xyz"], rtol=0, atol=0)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["new_points"], rtol=1e-3, atol=2e-4)
+    (out * torch.from_numpy(g["wgt"]).to(dev)).sum().backward()
+    if D:
+        np.testing.assert_allclose(pts.grad.cpu().numpy(), g["d_points"], rtol=1e-3, atol=1e-4)
+    _check_layer(g, layer)
+
+
+@pytest.mark.parametrize("name", ["sa_fp_s13_B2_N200.npz", "sa_fp1_s13_B2_N200.npz"])
+def test_feature_propagation_vs_reference_golden(dev, name):
+    from mlsp_amd import pointnet2 as p2
+    g = dict(np.load(os.path.join(GOLD, name)))
+    layer = _load_into(p2.PointNetFeaturePropagation(4 + 7, [16, 12]), g, dev)
+    p1 = torch.from_numpy(g["points1"]).to(dev).requires_grad_(True)
+    pp2 = torch.from_numpy(g["points2"]).to(dev).requires_grad_(True)
+    out = layer(torch.from_numpy(g["xyz1"]).to(dev), torch.from_numpy(g["xyz2"]).to(dev), p1, pp2)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-3, atol=1e-3)
+    (out * torch.from_numpy(g["wgt"]).to(dev)).sum().backward()
+    np.testing.assert_allclose(p1.grad.cpu().numpy(), g["d_points1"], rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(pp2.grad.cpu().numpy(), g["d_points2"], rtol=2e-3, atol=1e-3)
+    _check_layer(g, layer, tol_grad=1e-2)

@@ -430,6 +430,45 @@ def corrupt_cases():
                         mixed=npy(mixed), Ya=npy(Ya), Yb=npy(Yb))
 
 
+def radius_case():
+    """deform_input(..., 'volume_based_radius') of the reference (pc_utils.collapse_to_point): the picked points (np.random.choice)
+    and the Gaussian draws (draw_from_gaussian) are recorded by wrapping the two entry points."""
+    ref_import.install_stubs()
+    sys.path.insert(0, ref_import.REF_ROOT)
+    import utils.pc_utils as rpc                                   # noqa: E402
+    from MLSP import mlsp as rmlsp                                   # noqa: E402
+    g = torch.Generator().manual_seed(9)
+    B, N = 5, 512
+    X = (torch.rand(B, 3, N, generator=g) * 2 - 1) * torch.tensor([1.0, 0.8, 0.6, 0.9, 0.3]).view(B, 1, 1)
+    rec = {"choice": [], "gauss": []}
+    orig_choice, orig_gauss = np.random.choice, rpc.draw_from_gaussian
+
+    def choice(a, *aa, **kk):
+        r = orig_choice(a, *aa, **kk)
+        rec["choice"].append(int(r))
+        return r
+
+    def gauss(mean, n):
+        r = orig_gauss(mean, n)
+        rec["gauss"].append((np.array(mean, dtype=np.float64), r.copy()))
+        return r
+    np.random.seed(17)
+    np.random.choice, rpc.draw_from_gaussian = choice, gauss
+    try:
+        Xd, mask = rmlsp.deform_input(X.clone(), torch.Tensor(rpc.region_mean(3)), 'volume_based_radius', 'cpu')
+    finally:
+        np.random.choice, rpc.draw_from_gaussian = orig_choice, orig_gauss
+    noise = np.zeros((B, 3, N), np.float64)
+    for b in range(B):
+        mean, draw = rec["gauss"][b]
+        hit = npy(mask)[b, 0] > 0
+        noise[b][:, hit] = (draw - mean[:, None]) / np.sqrt(0.001)       # the standard-normal draws behind the reference's samples
+    np.savez_compressed(os.path.join(OUT, "collapse_s9_B5_N512.npz"), X=npy(X), X_out=npy(Xd), mask=npy(mask),
+                        choice=np.array(rec["choice"], np.int32), noise=noise.astype(np.float32))
+    print("collapse_s9_B5_N512.npz", os.path.getsize(os.path.join(OUT, "collapse_s9_B5_N512.npz")), "picked", rec["choice"],
+          "moved per cloud", npy(mask)[:, 0].sum(1))
+
+
 def main_round2():
     """Round-2 fixtures: the reference in float64 at N = 1024 (gradient pin at full N) and PointSegDA with K = 40."""
     RefModels, ref_mu, ref_mlsp = ref_import.import_reference()
@@ -450,6 +489,89 @@ def main_round2():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def _perturb_sa(layer, seed):
+    with torch.no_grad():
+        gc.perturb_params(layer, seed)
+        g = torch.Generator().manual_seed(77 + seed)
+        for name, p in layer.named_parameters():               # BN affine terms off their init
+            if "bn" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.3 if name.endswith("bias") else 0.5) + (0.0 if name.endswith("bias") else 1.0))
+
+
+def sa_round2_cases(pu):
+    """Round-2 set-abstraction fixtures from the reference file itself: knn=True grouping, PointNetSetAbstractionMsg (ball query and
+    knn branches), PointNetFeaturePropagation (3-NN interpolation and the S == 1 broadcast)."""
+    out = {}
+    # (1) sample_and_group(knn=True) inside PointNetSetAbstraction
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(11)
+    B, N, D = 3, 300, 5
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    pts = torch.randn(B, N, D, generator=g).requires_grad_(True)
+    layer = pu.PointNetSetAbstraction(48, 0.3, 12, 3 + D, [16, 32], False, knn=True).train()
+    _perturb_sa(layer, 11)
+    torch.manual_seed(2024)
+    fps_idx = pu.farthest_point_sample(xyz, 48)
+    torch.manual_seed(2024)
+    new_xyz, new_points = layer(xyz, pts)
+    w = torch.randn(new_points.shape, generator=g)
+    (new_points * w).sum().backward()
+    c = {"xyz": npy(xyz), "points": npy(pts), "start": npy(fps_idx[:, 0]), "fps_idx": npy(fps_idx), "new_xyz": npy(new_xyz),
+         "new_points": npy(new_points), "wgt": npy(w), "d_points": npy(pts.grad),
+         "group_idx": npy(pu.square_distance(pu.index_points(xyz, fps_idx), xyz).argsort()[:, :, :12])}
+    for k, v in layer.state_dict().items():
+        c["state_after/" + k] = npy(v)
+    for k, p in layer.named_parameters():
+        c["grad/" + k] = npy(p.grad)
+    np.savez_compressed(os.path.join(OUT, "sa_knn_s11_B3_N300.npz"), **c)
+    # (2) PointNetSetAbstractionMsg, ball-query branches with features, and a knn variant without features
+    for tag, knn, D in (("msg", False, 6), ("msgknn", True, 0)):
+        g = torch.Generator().manual_seed(12)
+        B, N = 2, 256
+        xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+        pts = torch.randn(B, N, D, generator=g).requires_grad_(True) if D else None
+        torch.manual_seed(12)
+        layer = pu.PointNetSetAbstractionMsg(32, [0.2, 0.45], [8, 16], D, [[16, 24], [16, 32]], knn=knn).train()
+        _perturb_sa(layer, 12)
+        torch.manual_seed(7)
+        fps_idx = pu.farthest_point_sample(xyz, 32)
+        new_xyz, new_points = layer(xyz, pts, seed_idx=fps_idx)
+        w = torch.randn(new_points.shape, generator=g)
+        (new_points * w).sum().backward()
+        c = {"xyz": npy(xyz), "fps_idx": npy(fps_idx), "new_xyz": npy(new_xyz), "new_points": npy(new_points), "wgt": npy(w)}
+        if D:
+            c["points"], c["d_points"] = npy(pts), npy(pts.grad)
+        for k, v in layer.state_dict().items():
+            c["state_after/" + k] = npy(v)
+        for k, p in layer.named_parameters():
+            c["grad/" + k] = npy(p.grad)
+        np.savez_compressed(os.path.join(OUT, "sa_%s_s12_B2_N256.npz" % tag), **c)
+    # (3) PointNetFeaturePropagation: S = 40 (3-NN interpolation) and S = 1 (broadcast)
+    for tag, S in (("fp", 40), ("fp1", 1)):
+        g = torch.Generator().manual_seed(13)
+        B, N, D1, D2 = 2, 200, 4, 7
+        xyz1 = (torch.rand(B, 3, N, generator=g) * 2 - 1)
+        xyz2 = xyz1[:, :, :S].clone() + 0.01 * torch.randn(B, 3, S, generator=g)
+        p1 = torch.randn(B, D1, N, generator=g).requires_grad_(True)
+        p2 = torch.randn(B, D2, S, generator=g).requires_grad_(True)
+        torch.manual_seed(13)
+        layer = pu.PointNetFeaturePropagation(D1 + D2, [16, 12]).train()
+        _perturb_sa(layer, 13)
+        outp = layer(xyz1, xyz2, p1, p2)
+        w = torch.randn(outp.shape, generator=g)
+        (outp * w).sum().backward()
+        c = {"xyz1": npy(xyz1), "xyz2": npy(xyz2), "points1": npy(p1), "points2": npy(p2), "out": npy(outp), "wgt": npy(w),
+             "d_points1": npy(p1.grad), "d_points2": npy(p2.grad)}
+        for k, v in layer.state_dict().items():
+            c["state_after/" + k] = npy(v)
+        for k, p in layer.named_parameters():
+            c["grad/" + k] = npy(p.grad)
+        np.savez_compressed(os.path.join(OUT, "sa_%s_s13_B2_N200.npz" % tag), **c)
+    for f in sorted(os.listdir(OUT)):
+        if f.startswith(("sa_knn", "sa_msg", "sa_fp")):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
 def main_sa():
     pu = import_sa_reference()
     np.savez_compressed(os.path.join(OUT, "sa_s0_B4_N256.npz"), **sa_case(pu, 0, 4, 256, 6, 64, 0.4, 16, [32, 32, 64], False))
@@ -467,6 +589,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "corrupt":
         corrupt_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sa2":
+        sa_round2_cases(import_sa_reference())
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "radius":
+        radius_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
         main_round2()
