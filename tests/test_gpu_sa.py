@@ -116,6 +116,9 @@ def _load_into(layer, g, dev):
 def _check_layer(g, layer, tol_grad=5e-3):
     for k, p in layer.named_parameters():
         want = g["grad/" + k]
+        if "conv" in k and k.endswith(".bias"):    # a bias in front of a batch-statistics BatchNorm: analytically zero (the reference holds rounding noise)
+            assert np.abs(want).max() < 1e-3 and p.grad.abs().max().item() < 1e-3, k
+            continue
         err = np.linalg.norm(p.grad.cpu().numpy() - want) / (np.linalg.norm(want) + 1e-12)
         assert err < tol_grad, (k, err)
     st = layer.state_dict()
