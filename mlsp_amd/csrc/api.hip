@@ -115,6 +115,7 @@ int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, doubl
 int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int nsplit);
 int tnet_grid(int ntiles);
 int tnet_points_per_tile(int k);
+int tnet_fwd_parts(int B, int N, int k);
 int launch_tnet_edge_fwd(hipStream_t st, const float* uv, const int* idx, const float* bn1, const float* W2, const float* gamma2,
                          int P, int N, int k, float slope, float* zsel, uint8_t* argsel, double* part);
 int launch_tnet_out(hipStream_t st, const float* zsel, const float* bn2, int P, float slope, float* out);
@@ -329,7 +330,7 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
     float* Wd = w.take<float>((size_t)2 * C1 * C);
     float* msel = w.take<float>((size_t)P * C1);
     uint8_t* arg1 = w.take<uint8_t>((size_t)P * C1);
-    int np1 = edge_reduce_parts(P), np2 = tnet_grid(ntiles);
+    int np1 = edge_reduce_parts(P), np2 = tnet_fwd_parts(B, N, k);
     double* part = w.take<double>((size_t)(np1 > np2 ? np1 : np2) * 2 * C2);
     size_t sf = gemm_slab_floats(P, 2 * C1, C);
     float* slab = sf ? w.take<float>(sf) : nullptr;

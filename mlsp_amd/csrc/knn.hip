@@ -22,7 +22,27 @@ __global__ void sqnorm_kernel(const float* __restrict__ x, int ld, int P, int C,
     if (i >= P) return;
     const float* r = x + (size_t)i * ld;
     float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc = fmaf(r[c], r[c], acc);
+    if ((C & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)x) & 15) == 0) {      // same chain (c ascending), 16-byte loads, four in flight
+        int c = 0;
+        for (; c + 16 <= C; c += 16) {
+            const f32x4 a = *(const f32x4*)(r + c), b = *(const f32x4*)(r + c + 4), d = *(const f32x4*)(r + c + 8), e = *(const f32x4*)(r + c + 12);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(a[u], a[u], acc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(b[u], b[u], acc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(d[u], d[u], acc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(e[u], e[u], acc);
+        }
+        for (; c < C; c += 4) {
+            const f32x4 a = *(const f32x4*)(r + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(a[u], a[u], acc);
+        }
+    } else {
+        for (int c = 0; c < C; ++c) acc = fmaf(r[c], r[c], acc);
+    }
     xx[i] = acc;
 }
 

@@ -26,38 +26,24 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(const float* __restric
         Bs[i] = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
     }
     __syncthreads();
-    const int nq = N >> 2, rpp = 256 / nq;                              // rows per pass of the workgroup (nq divides 256)
-    const int q = tid % nq, rsub = tid / nq;
+    const int nq = N >> 2;
     const int row0 = blockIdx.x * rows_per_block;
-    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bb = *(const f32x4*)(bias + 4 * q);
-    // four rows per thread and iteration: their K-value loads are all in flight before the first FMA
-    for (int rb = rsub; rb < rows_per_block; rb += 4 * rpp) {
-        float av[4][16];
-        int rr[4];
+    for (int i = tid; i < rows_per_block * nq; i += 256) {
+        const int r = row0 + i / nq, q = i % nq;
+        if (r >= M) break;
+        const float* a = A + (size_t)r * lda;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < K; ++k) {
+            const float av = a[k];
+            const f32x4 bv = *(const f32x4*)(Bs + k * N + 4 * q);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            rr[u] = row0 + rb + u * rpp;
-            const bool ok = rb + u * rpp < rows_per_block && rr[u] < M;
-            const float* a = A + (size_t)(ok ? rr[u] : 0) * lda;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) av[u][k] = (k < K) ? a[k] : 0.f;
-            if (!ok) rr[u] = -1;
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(av, bv[e], acc[e]);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (rr[u] < 0) continue;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k < K) {
-                    const f32x4 bv = *(const f32x4*)(Bs + k * N + 4 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(av[u][k], bv[e], acc[e]);
-                }
-            }
-            *(f32x4*)(C + (size_t)rr[u] * ldc + 4 * q) = acc + bb;
+        if (bias) {
+            const f32x4 bb = *(const f32x4*)(bias + 4 * q);
+            acc = acc + bb;
         }
+        *(f32x4*)(C + (size_t)r * ldc + 4 * q) = acc;
     }
 }
 
@@ -183,7 +169,7 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
     if (!ta && K <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && M >= 1024 && ldc % 4 == 0 && al16(C) && al16(bias)) {
         const int nq = N / 4;
         if (256 % nq) return MLSP_ERR_UNSUPPORTED;
-        const int rpb = 16 * (256 / nq);                                  // sixteen rows per thread (four iterations of four)
+        const int rpb = 4 * 256 / nq;                                     // four passes of the workgroup per block
         const size_t lds = (size_t)K * N * sizeof(float);
         const dim3 grid((M + rpb - 1) / rpb);
         if (tb) hipLaunchKernelGGL((thin_smallk_kernel<true>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb);

@@ -187,6 +187,169 @@ __global__ __launch_bounds__(512) void tnet_edge_fwd_kernel(TnetFwdArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Forward, register-resident (round 2).  The Z tile never touches LDS: a point's K edge rows are laid out so that the per-point
+// max / arg-max and the BN2 sums come straight out of the MFMA accumulators.
+//   workgroup = 4 waves, tile = 160 rows = 5 MFMA row blocks = 160 / K points (K = 20: 8 points, K = 40: 4 points); K % 4 == 0 puts
+//   every aligned group of 4 rows inside ONE point, and a 32x32 accumulator holds its rows in exactly such groups
+//   (register 4q..4q+3 of lane half h <-> rows 8q + 4h .. +3), so "which point / which slot" is a compile-time function of
+//   (block, q) and the lane half.  160 rows is the smallest row count that is a multiple of both 32 and K in {20, 40}.
+//   wave w owns output columns 32w..32w+31 for all 5 row blocks: 80 accumulator registers, its W2 fragment (32 registers) stays in
+//   registers for the whole kernel.  LDS holds only the ACTIVATED H tile [160][64] (row-major, pitch 66 floats: the gathered rows
+//   are stored as they arrive and one ds_read_b64 feeds two MFMA steps, conflict-free): 42 KB -> three workgroups per CU, whose
+//   gather / MFMA / epilogue phases overlap each other (the 141 KB, one-workgroup-per-CU kernel above had nothing to overlap with).
+#define TF_ROWS 160
+#define TF_PITCH 66
+template <int K>
+__global__ __launch_bounds__(256, 2) void tnet_edge_fwd2_kernel(TnetFwdArgs p) {
+    constexpr int PT = TF_ROWS / K;                  // points per tile
+    constexpr int GP = K / 4;                        // aligned 4-row groups per point
+    __shared__ __attribute__((aligned(16))) float Hs[TF_ROWS * TF_PITCH];
+    __shared__ float S1[2 * TN_C1];
+    __shared__ __attribute__((aligned(16))) float Vs[PT * TN_C1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int o = 32 * wave + l31;
+    if (tid < 2 * TN_C1) S1[tid] = p.bn1[tid];
+    float2 w2[16];                                    // B fragments: W2[o][4m + 2h], W2[o][4m + 2h + 1]
+#pragma unroll
+    for (int m = 0; m < 16; ++m) w2[m] = *(const float2*)(p.W2 + (size_t)o * TN_C1 + 4 * m + 2 * h);
+    const bool use_max = p.gamma2[o] >= 0.f;
+    double ssum = 0.0, ssq = 0.0;
+    const int Bc = p.P / p.N;
+    int pt0 = 0, npts = 0, pt0n = 0, nptsn = 0;
+    __syncthreads();
+    // neighbour indices of the rows this thread gathers in a tile (-1: padding); tile m+1's are fetched under tile m's MFMA phase so
+    // that only ONE dependent global round trip (the rows themselves) sits on a tile's critical path
+    auto tile_rows = [&](int t0, int np, int (&jr)[3]) {
+        const int base = (t0 / p.N) * p.N;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int item = tid + 256 * u, row = item >> 2;
+            const int pt = row / K, s = row - pt * K;
+            const bool ok = item < TF_ROWS * 4 && pt < np;
+            jr[u] = ok ? base + p.idx[(size_t)(t0 + pt) * K + s] : -1;
+        }
+    };
+    bool have = tn_tile(0, Bc, p.N, PT, pt0, npts);
+    int jrow[3] = {-1, -1, -1}, jnext[3] = {-1, -1, -1};
+    if (have) tile_rows(pt0, npts, jrow);
+    for (int m = 0; have; ++m) {
+        // ---- gather: 160 rows x 4 quarter rows (16 channels) of u_j over 256 threads, everything in flight before the first use;
+        //      the centre term v_i is the same for the K rows of a point: PT rows staged through LDS (Vs) instead of 160
+        f32x4 ur[3][4];
+        f32x4 vstage = {0.f, 0.f, 0.f, 0.f};
+        if (tid < PT * 16 && (tid >> 4) < npts) vstage = *(const f32x4*)(p.uv + (size_t)(pt0 + (tid >> 4)) * 2 * TN_C1 + TN_C1 + 4 * (tid & 15));
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int qt = (tid + 256 * u) & 3;
+            if (jrow[u] >= 0) {
+                const f32x4* up = (const f32x4*)(p.uv + (size_t)jrow[u] * 2 * TN_C1 + 16 * qt);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ur[u][e] = up[e];
+            }
+        }
+        const bool haven = tn_tile(m + 1, Bc, p.N, PT, pt0n, nptsn);
+        if (haven) tile_rows(pt0n, nptsn, jnext);
+        __syncthreads();                              // every wave is done reading the previous tile's H (and Vs)
+        if (tid < PT * 16) *(f32x4*)(Vs + 4 * tid) = vstage;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int item = tid + 256 * u, row = item >> 2, qt = item & 3;
+            if (item < TF_ROWS * 4) {
+                float* dst = Hs + row * TF_PITCH + 16 * qt;
+                const float* vs = Vs + (row / K) * TN_C1 + 16 * qt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 vv = *(const f32x4*)(vs + 4 * e);
+                    float hv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int ch = 16 * qt + 4 * e + c;
+                        hv[c] = jrow[u] >= 0 ? lrelu(fmaf(ur[u][e][c] + vv[c], S1[ch], S1[TN_C1 + ch]), p.slope) : 0.f;
+                    }
+                    *(float2*)(dst + 4 * e) = make_float2(hv[0], hv[1]);
+                    *(float2*)(dst + 4 * e + 2) = make_float2(hv[2], hv[3]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Z = H W2^T for this wave's 32 columns, all 5 row blocks
+        f32x16 acc[5];
+#pragma unroll
+        for (int b = 0; b < 5; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) {
+            float2 a[5];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) a[b] = *(const float2*)(Hs + (32 * b + l31) * TF_PITCH + 4 * mm + 2 * h);
+#pragma unroll
+            for (int b = 0; b < 5; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b].x, w2[mm].x, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 5; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b].y, w2[mm].y, acc[b], 0, 0, 0);
+        }
+        // ---- epilogue in registers: per point max (or min) over its K rows with the first arg-max, BN2 sums over all rows
+        float best[PT];
+        int bslot[PT];
+#pragma unroll
+        for (int q = 0; q < PT; ++q) { best[q] = use_max ? -INFINITY : INFINITY; bslot[q] = 0; }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < 5; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                constexpr int dummy = 0; (void)dummy;
+                const int G0 = 8 * b + 2 * q;                          // 4-row group index of lane half 0 (half 1: G0 + 1)
+                const int p0 = G0 / GP, r0 = G0 % GP;
+                const bool cross = (r0 == GP - 1);                     // half 1's group belongs to the next point
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[b][4 * q + e];
+                    s1 += v; s2 = fmaf(v, v, s2);
+                    if (!cross) {
+                        const int slot = 4 * (r0 + h) + e;
+                        const bool take = use_max ? (v > best[p0]) : (v < best[p0]);
+                        best[p0] = take ? v : best[p0]; bslot[p0] = take ? slot : bslot[p0];
+                    } else {
+                        {
+                            const bool take = h == 0 && (use_max ? (v > best[p0]) : (v < best[p0]));
+                            best[p0] = take ? v : best[p0]; bslot[p0] = take ? 4 * (GP - 1) + e : bslot[p0];
+                        }
+                        if (p0 + 1 < PT) {
+                            const bool take = h == 1 && (use_max ? (v > best[p0 + 1]) : (v < best[p0 + 1]));
+                            best[p0 + 1] = take ? v : best[p0 + 1]; bslot[p0 + 1] = take ? e : bslot[p0 + 1];
+                        }
+                    }
+                }
+            }
+        ssum += s1; ssq += s2;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            const float ob = __shfl_xor(best[q], 32, 64);
+            const int os = __shfl_xor(bslot[q], 32, 64);
+            const bool better = use_max ? (ob > best[q]) : (ob < best[q]);
+            if (better || (ob == best[q] && os < bslot[q])) { best[q] = ob; bslot[q] = os; }
+            if (h == 0 && q < npts) {
+                p.zsel[(size_t)(pt0 + q) * TN_C2 + o] = best[q];
+                p.argsel[(size_t)(pt0 + q) * TN_C2 + o] = (uint8_t)bslot[q];
+            }
+        }
+        have = haven; pt0 = pt0n; npts = nptsn;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) jrow[u] = jnext[u];
+    }
+    // per-workgroup BN2 partials: the two lane halves hold different rows of the same column
+    ssum += __shfl_xor(ssum, 32, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (h == 0) {
+        p.part[((size_t)blockIdx.x * 2 + 0) * TN_C2 + o] = ssum;
+        p.part[((size_t)blockIdx.x * 2 + 1) * TN_C2 + o] = ssq;
+    }
+}
+
 // t = act(scale2 * zsel + shift2)        [P][128]
 __global__ __launch_bounds__(256) void tnet_out_kernel(const float* __restrict__ zsel, const float* __restrict__ bn2, size_t total,
                                                        float slope, float* __restrict__ out) {
@@ -430,12 +593,30 @@ static int tnet_set_lds(const void* fn) {
     return e == hipSuccess ? MLSP_OK : (int)e;
 }
 
+// number of BN2 partial rows launch_tnet_edge_fwd writes (= its grid size)
+int tnet_fwd_parts(int B, int N, int k) {
+    if (k == 20 || k == 40) {
+        const int pt = TF_ROWS / k, ntiles = B * ((N + pt - 1) / pt);
+        return ntiles < 512 ? ((ntiles + 7) / 8) * 8 : 512;          // two 4-wave workgroups per CU (237 VGPRs), a multiple of 8 (XCD-aware walk)
+    }
+    const int tp = tnet_points_per_tile(k);
+    return tp > 0 ? tnet_grid(B * ((N + tp - 1) / tp)) : 0;
+}
+
 int launch_tnet_edge_fwd(hipStream_t st, const float* uv, const int* idx, const float* bn1, const float* W2, const float* gamma2,
                          int P, int N, int k, float slope, float* zsel, uint8_t* argsel, double* part) {
     TnetFwdArgs a;
     a.uv = uv; a.idx = idx; a.bn1 = bn1; a.W2 = W2; a.gamma2 = gamma2; a.zsel = zsel; a.argsel = argsel; a.part = part;
     a.P = P; a.N = N; a.k = k; a.TP = tnet_points_per_tile(k); a.slope = slope;
     if (a.TP <= 0) return MLSP_ERR_UNSUPPORTED;
+    if (k == 20 || k == 40) {
+        const int grid = tnet_fwd_parts(P / N, N, k);
+        a.TP = TF_ROWS / k;
+        a.ntiles = (P / N) * ((N + a.TP - 1) / a.TP);
+        if (k == 20) hipLaunchKernelGGL((tnet_edge_fwd2_kernel<20>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((tnet_edge_fwd2_kernel<40>), dim3(grid), dim3(256), 0, st, a);
+        return mlsp_launch_status();
+    }
     a.ntiles = (P / N) * ((N + a.TP - 1) / a.TP);
     int rc = tnet_set_lds((const void*)tnet_edge_fwd_kernel);
     if (rc) return rc;
