@@ -228,7 +228,11 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd2_kernel(TnetFwdArgs p) {
             const int item = tid + 256 * u, row = item >> 2;
             const int pt = row / K, s = row - pt * K;
             const bool ok = item < TF_ROWS * 4 && pt < np;
+#ifdef TF_PROBE_NOGATHER
+            jr[u] = ok ? t0 + pt : -1;
+#else
             jr[u] = ok ? base + p.idx[(size_t)(t0 + pt) * K + s] : -1;
+#endif
         }
     };
     bool have = tn_tile(0, Bc, p.N, PT, pt0, npts);
@@ -281,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd2_kernel(TnetFwdArgs p) {
         for (int b = 0; b < 5; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#ifndef TF_PROBE_NOMFMA
 #pragma unroll
         for (int mm = 0; mm < 16; ++mm) {
             float2 a[5];
@@ -291,6 +296,10 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd2_kernel(TnetFwdArgs p) {
 #pragma unroll
             for (int b = 0; b < 5; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b].y, w2[mm].y, acc[b], 0, 0, 0);
         }
+#else
+#pragma unroll
+        for (int b = 0; b < 5; ++b) acc[b][0] = Hs[(32 * b + l31) * TF_PITCH + h] * w2[b].x;
+#endif
         // ---- epilogue in registers: per point max (or min) over its K rows with the first arg-max, BN2 sums over all rows
         float best[PT];
         int bslot[PT];
