@@ -30,21 +30,27 @@ PEAK_HBM_GBS = 8000.0
 
 
 def pmc_gemm_traffic():
-    """HBM-side bytes per GEMM launch from the newest committed rocprofv3 --pmc summary (profiles/pmc_r1/summary_v*.csv,
+    """HBM-side bytes per GEMM launch from the newest committed rocprofv3 --pmc summary (profiles/pmc_r<round>/summary*.csv,
     produced by tools/prof/run_profiles.sh with FETCH_SIZE / WRITE_SIZE in separate passes): launch-weighted mean of
     2*FETCH_SIZE + WRITE_SIZE (the gfx950 correction of MI355X_MICROARCH.md).  None when no summary is committed."""
     import csv, glob, re
-    files = glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r1", "summary_v*.csv"))
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = glob.glob(os.path.join(root, "profiles", "pmc_r*", "summary*.csv"))
     if not files:
         return None, None
-    f = max(files, key=lambda x: int(re.search(r"summary_v(\d+)", x).group(1)))
+
+    def order(path):
+        rnd = int(re.search(r"pmc_r(\d+)", path).group(1))
+        ver = re.search(r"summary_v(\d+)", path)
+        return (rnd, int(ver.group(1)) if ver else 0)
+    f = max(files, key=order)
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
         if "gemm_f32_kernel" in r["kernel"]:
             l = int(r["launches"])
             tot += l * (2 * float(r["fetch_KB_per_launch_raw"]) + float(r["write_KB_per_launch"])) * 1024
             n += l
-    return (tot / n if n else None), os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))
+    return (tot / n if n else None), os.path.relpath(f, root)
 
 
 def synth_batch(B, N, device, seed=0):

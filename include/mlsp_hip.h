@@ -10,9 +10,12 @@
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors); the library never
  *     allocates or frees caller-visible memory.  Scratch is passed in (`ws`, `ws_bytes`; size it
  *     with mlsp_workspace_bytes).
- *   - every call is asynchronous on `stream`, re-entrant, keeps no global mutable state, never
- *     throws, and returns 0 on success, a negative MLSP_ERR_* code for bad arguments, or a
- *     positive hipError_t.
+ *   - every compute call is asynchronous on `stream`, re-entrant, never throws, and returns 0 on
+ *     success, a negative MLSP_ERR_* code for bad arguments, or a positive hipError_t.  The compute
+ *     entry points keep no mutable state of their own; the library has exactly two process-wide
+ *     switches, both off by default and both set from the host thread that owns the training loop:
+ *     mlsp_set_gemm_precision (operand rounding of the GEMM family) and mlsp_profile_begin/_end
+ *     (HIP events around the GEMM launches).  Neither is touched by any compute call.
  *   - activations are POINT-major fp32 row matrices: [rows][C] with rows = B*N points (or
  *     B*N*k edges), channels contiguous.  The reference itself moves to this layout before its
  *     gather (model_utils.py:35).  Indices are int32, local to their cloud (0..N-1).

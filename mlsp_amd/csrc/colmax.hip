@@ -117,8 +117,17 @@ __global__ __launch_bounds__(1024) void wt_vec_neg_kernel(const float* __restric
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     float acc = 0.f;
-    if (i < Cin)
-        for (int c = w; c < Cout; c += 16) acc = fmaf(v[c], W[(size_t)c * ldw + i], acc);
+    if (i < Cin) {
+        int c = w;
+        for (; c + 16 * 7 < Cout; c += 16 * 8) {          // eight independent loads in flight per lane (the chain itself is fixed-order)
+            float wv[8], vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { wv[u] = W[(size_t)(c + 16 * u) * ldw + i]; vv[u] = v[c + 16 * u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(vv[u], wv[u], acc);
+        }
+        for (; c < Cout; c += 16) acc = fmaf(v[c], W[(size_t)c * ldw + i], acc);
+    }
     red[w][lane] = acc;
     __syncthreads();
     if (w == 0 && i < Cin) {
