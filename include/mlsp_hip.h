@@ -227,6 +227,11 @@ int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const 
 int mlsp_region_assign_f32(const float* X, int B, int C, int N, const float* thr, int n, float clip, int32_t* regions, mlsp_stream_t stream);
 int mlsp_deform_regions_f32(float* X, int B, int C, int N, const int32_t* regions, const int32_t* order, int nreg, const float* lookup,
                             const float* noise, int min_pts, int groups, float* mask, mlsp_stream_t stream);
+/* Input transform (PointDA/Models.py:113 `x = torch.matmul(transformd_x0, x)`, PointSegDA/Models.py:218): out [B*N][3], out[p] = T[b] x[p] for the
+ * points of cloud b; x [B*N][3] point-major, T [B][3][3].  Backward: dx (nullable) [B*N][3] and dT [B][3][3] (fixed reduction order). */
+int mlsp_transform3_fwd_f32(const float* x, const float* T, int B, int N, float* out, mlsp_stream_t stream);
+int mlsp_transform3_bwd_f32(const float* x, const float* T, const float* dout, int B, int N, float* dx, float* dT, mlsp_stream_t stream);
+
 /* deform_input(..., 'volume_based_radius') = pc_utils.collapse_to_point (MLSP/mlsp.py:33-36, utils/pc_utils.py:76-111): per cloud one
  * point with >= min_pts points within sqrt(radius2) is picked (uniformly by u[b] in [0,1) among the candidates in index order, or
  * choice[b] >= 0 pins it) and all points within that radius of it become centre + noise (noise [B][3][N], already scaled by the

@@ -198,7 +198,7 @@ class DGCNN(nn.Module):
         # T-Net on the graph feature of the raw cloud (Models.py:111-113)
         g0 = Fh.knn_graph(xp0, B, N, k)
         T = self.input_transform_net.points(xp0, g0, B, N, k)                    # [B,3,3]
-        xp = torch.bmm(xp0.view(B, N, 3), T.transpose(1, 2)).view(B * N, 3)      # (T @ x)^T
+        xp = Fh.apply_transform(xp0, T)                                          # (T @ x)^T, point-major
 
         # EdgeConv 1-4 (Models.py:115-129) write their outputs straight into the column slices of the [P,512] concatenation
         # (:131): no torch.cat pass forward, no split copies backward

@@ -68,6 +68,8 @@ SIGNATURES = {
     "mlsp_sa_group_bwd_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_region_assign_f32": [_P, _I, _I, _I, _P, _I, _F, _P, _P],
     "mlsp_deform_regions_f32": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P],
+    "mlsp_transform3_fwd_f32": [_P, _P, _I, _I, _P, _P],
+    "mlsp_transform3_bwd_f32": [_P, _P, _P, _I, _I, _P, _P, _P],
     "mlsp_collapse_to_point_f32": [_P, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P],
     "mlsp_scan_select_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _P],
     "mlsp_set_gemm_precision": [_I],

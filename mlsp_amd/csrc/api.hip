@@ -49,6 +49,8 @@ int launch_knn_query(hipStream_t st, const float* ref, int ldr, int Nr, const fl
 int launch_interp3_fwd(hipStream_t st, const float* feat, const int* idx, const float* dist, int B, int N, int S, int D, float* out);
 int launch_interp3_bwd(hipStream_t st, const float* dout, const float* dist, const int* rev_off, const int* rev_ent, int B, int N, int S,
                        int D, float* dfeat);
+int launch_transform3_fwd(hipStream_t st, const float* x, const float* T, int B, int N, float* out);
+int launch_transform3_bwd(hipStream_t st, const float* x, const float* T, const float* dout, int B, int N, float* dx, float* dT);
 int launch_region_assign(hipStream_t st, const float* X, int B, int C, int N, const float* thr, int n, float clip, int* Y);
 int launch_scan_select(hipStream_t st, const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask);
 int launch_deform_regions(hipStream_t st, float* X, int B, int C, int N, const int* regions, const int* order, int nreg, const float* lookup,
@@ -212,6 +214,12 @@ int mlsp_interp3_bwd_f32(const float* dout, const float* dist, const int32_t* re
                          float* dfeat, mlsp_stream_t st) {
     return launch_interp3_bwd(st, dout, dist, rev_off, rev_ent, B, N, S, D, dfeat);
 }
+int mlsp_transform3_fwd_f32(const float* x, const float* T, int B, int N, float* out, mlsp_stream_t st) {
+    return launch_transform3_fwd(st, x, T, B, N, out);
+}
+int mlsp_transform3_bwd_f32(const float* x, const float* T, const float* dout, int B, int N, float* dx, float* dT, mlsp_stream_t st) {
+    return launch_transform3_bwd(st, x, T, dout, B, N, dx, dT);
+}
 int mlsp_collapse_to_point_f32(float* X, int B, int N, const int32_t* choice, const float* u, const float* noise, float radius2,
                                int min_pts, float* mask, int32_t* chosen, mlsp_stream_t st) {
     return launch_collapse_to_point(st, X, B, N, choice, u, noise, radius2, min_pts, mask, chosen);
@@ -325,7 +333,6 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
     if (B <= 0 || N <= 0 || C <= 0 || k <= 0 || ldx < C) return MLSP_ERR_ARG;
     if (C1 != 64 || C2 != 128 || tnet_points_per_tile(k) <= 0) return MLSP_ERR_UNSUPPORTED;
     const int P = B * N;
-    const int ntiles = B * ((N + tnet_points_per_tile(k) - 1) / tnet_points_per_tile(k));
     Workspace w(ws, ws_bytes);
     float* Wd = w.take<float>((size_t)2 * C1 * C);
     float* msel = w.take<float>((size_t)P * C1);

@@ -209,3 +209,59 @@ int launch_deform_regions(hipStream_t st, float* X, int B, int C, int N, const i
     hipLaunchKernelGGL(deform_regions_kernel, dim3(B), dim3(256), 0, st, X, C, N, regions, order, nreg, lookup, noise, min_pts, groups, mask);
     return mlsp_launch_status();
 }
+
+// Input transform of DGCNN (PointDA/Models.py:113, x = matmul(T, x)): out[p][i] = sum_j T[b][i][j] * x[p][j] on point-major
+// [P][3] rows, T [B][3][3].  A 3x3 batched matmul through the vendor GEMM is three launches of transposes and tiles; here one
+// streaming pass each way.  Backward: dx[p][j] = sum_i dout[p][i] T[b][i][j];  dT[b][i][j] = sum_p dout[p][i] x[p][j] (one workgroup
+// per cloud, fixed reduction order).
+__global__ __launch_bounds__(256) void transform3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ T, int N, int P,
+                                                             float* __restrict__ out) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float* t = T + (size_t)(p / N) * 9;
+    const float a = x[(size_t)p * 3], b = x[(size_t)p * 3 + 1], c = x[(size_t)p * 3 + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[(size_t)p * 3 + i] = fmaf(t[3 * i + 2], c, fmaf(t[3 * i + 1], b, t[3 * i] * a));
+}
+__global__ __launch_bounds__(256) void transform3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ T,
+                                                             const float* __restrict__ dout, int N, float* __restrict__ dx,
+                                                             float* __restrict__ dT) {
+    __shared__ float red[4][9];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* t = T + (size_t)b * 9;
+    float acc[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) acc[e] = 0.f;
+    for (int n = tid; n < N; n += 256) {
+        const size_t p = (size_t)b * N + n;
+        const float g0 = dout[p * 3], g1 = dout[p * 3 + 1], g2 = dout[p * 3 + 2];
+        const float x0 = x[p * 3], x1 = x[p * 3 + 1], x2 = x[p * 3 + 2];
+        if (dx) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dx[p * 3 + j] = fmaf(g2, t[6 + j], fmaf(g1, t[3 + j], g0 * t[j]));
+        }
+        acc[0] = fmaf(g0, x0, acc[0]); acc[1] = fmaf(g0, x1, acc[1]); acc[2] = fmaf(g0, x2, acc[2]);
+        acc[3] = fmaf(g1, x0, acc[3]); acc[4] = fmaf(g1, x1, acc[4]); acc[5] = fmaf(g1, x2, acc[5]);
+        acc[6] = fmaf(g2, x0, acc[6]); acc[7] = fmaf(g2, x1, acc[7]); acc[8] = fmaf(g2, x2, acc[8]);
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+        float v = acc[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[w][e] = v;
+    }
+    __syncthreads();
+    if (tid < 9) dT[(size_t)b * 9 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+int launch_transform3_fwd(hipStream_t st, const float* x, const float* T, int B, int N, float* out) {
+    if (!x || !T || !out || B <= 0 || N <= 0) return MLSP_ERR_ARG;
+    const int P = B * N;
+    hipLaunchKernelGGL(transform3_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, T, N, P, out);
+    return mlsp_launch_status();
+}
+int launch_transform3_bwd(hipStream_t st, const float* x, const float* T, const float* dout, int B, int N, float* dx, float* dT) {
+    if (!x || !T || !dout || !dT || B <= 0 || N <= 0) return MLSP_ERR_ARG;
+    hipLaunchKernelGGL(transform3_bwd_kernel, dim3(B), dim3(256), 0, st, x, T, dout, N, dx, dT);
+    return mlsp_launch_status();
+}

@@ -622,6 +622,40 @@ def colmax(Z, B, N):
     return _ColMax.apply(Z, B, N)
 
 
+class _Transform3(Function):
+    @staticmethod
+    def forward(ctx, xp, T):
+        lib = _lib.load()
+        xp, T = xp.contiguous(), T.contiguous()
+        _lib.require_gpu(xp, T)
+        B = T.shape[0]
+        N = xp.shape[0] // B
+        out = torch.empty_like(xp)
+        _lib.check(lib.mlsp_transform3_fwd_f32(xp.data_ptr(), T.data_ptr(), B, N, out.data_ptr(), _lib.stream()), "mlsp_transform3_fwd_f32")
+        ctx.save_for_backward(xp, T)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        lib = _lib.load()
+        xp, T = ctx.saved_tensors
+        B = T.shape[0]
+        N = xp.shape[0] // B
+        dout = dout.contiguous()
+        dx = torch.empty_like(xp) if ctx.needs_input_grad[0] else None
+        dT = torch.empty_like(T)
+        _lib.check(lib.mlsp_transform3_bwd_f32(xp.data_ptr(), T.data_ptr(), dout.data_ptr(), B, N, _lib.ptr(dx), dT.data_ptr(),
+                                               _lib.stream()), "mlsp_transform3_bwd_f32")
+        return dx, dT
+
+
+def apply_transform(xp, T):
+    """Models.py:113 `x = torch.matmul(T, x)` on point-major rows: xp [B*N,3], T [B,3,3] -> [B*N,3] with row p = T[b] @ x_p."""
+    assert xp.shape[1] == 3 and tuple(T.shape[1:]) == (3, 3) and xp.dtype == torch.float32
+    return _Transform3.apply(xp, T)
+
+
 class _Chamfer(Function):
     @staticmethod
     def forward(ctx, pred, gold, mask, scale):

@@ -336,7 +336,7 @@ class DGCNN_DefRec(nn.Module):
         xp0 = x.transpose(2, 1).contiguous().view(B * N, C)
         g0 = Fh.knn_graph(xp0, B, N, self.k)
         T = self.input_transform_net.points(xp0, g0, B, N, self.k)                 # [B,3,3]
-        xp = torch.bmm(xp0.view(B, N, C), T.transpose(1, 2)).view(B * N, C)        # (T @ x)^T
+        xp = Fh.apply_transform(xp0, T) if C == 3 else torch.bmm(xp0.view(B, N, C), T.transpose(1, 2)).view(B * N, C)   # (T @ x)^T
         x123, x5 = self.shared_layers.points(xp, B, N)
         if make_seg:
             logits["seg"] = self.seg.rows(x123, x5, B, N)

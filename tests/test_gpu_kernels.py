@@ -691,3 +691,21 @@ def test_conv2d_edge_with_bias_and_fc_without_bn(dev, training):
     w, b = fc.fc[0].weight.detach(), fc.fc[0].bias.detach()
     np.testing.assert_allclose(out.detach().cpu().numpy(), F.leaky_relu(xin.detach() @ w.t() + b, 0.2).cpu().numpy(), rtol=1e-4, atol=1e-5)
     assert fc.fc[0].weight.grad is not None and xin.grad is not None
+
+
+def test_apply_transform_vs_bmm(dev):
+    """functional.apply_transform (the 3x3 input transform of Models.py:113 on point-major rows) against torch.bmm, forward and backward."""
+    Fh = _fh()
+    B, N = 5, 333
+    x = _rand((B * N, 3), 31).to(dev).requires_grad_(True)
+    T = (_rand((B, 3, 3), 32) + torch.eye(3)).to(dev).requires_grad_(True)
+    w = _rand((B * N, 3), 33).to(dev)
+    out = Fh.apply_transform(x, T)
+    (out * w).sum().backward()
+    gx, gT = x.grad.clone(), T.grad.clone()
+    x.grad = T.grad = None
+    ref = torch.bmm(x.view(B, N, 3), T.transpose(1, 2)).view(B * N, 3)
+    (ref * w).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(gx.cpu().numpy(), x.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gT.cpu().numpy(), T.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
