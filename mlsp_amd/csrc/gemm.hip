@@ -362,6 +362,78 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 #endif
 }
 
+// ---- N = 64 variant: 128 x 64 x 32 tiles, the four waves stacked along M (32 rows x 64 columns each) -----------------------------
+// The dgrads into a 64-channel input (dx = duv * Wd of EdgeConv 2 / 3) and their wgrads have N = 64: on the 128-column tile half of
+// every B stage and half of the MFMA columns are padding (17-31 TF).  Interior shapes only (M % 128 == 0, K-range % 32 == 0, 16-byte
+// aligned operands), plain / split-K output, no fused epilogue.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f32_n64_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[BM * SROW + 64 * SROW + 32 * 64];
+    float* As = smem;                              // row-major image [128][36] or k-major [32][128]
+    float* Bs = smem + BM * SROW;                  // row-major image [64][36]  or k-major [32][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tm = blockIdx.x, split = blockIdx.y;
+    const int m0 = tm * 128;
+    const int kbeg = split * p.ksplit, kend = min(p.K, kbeg + p.ksplit);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    f32x4 ra[4], rb[4];
+    const float* pa = TA ? p.A + (size_t)(kbeg + (tid >> 5)) * p.lda + m0 + (tid & 31) * 4
+                         : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
+    const float* pb = !TB ? p.B + (size_t)(kbeg + (tid >> 4)) * p.ldb + (tid & 15) * 4
+                          : p.B + (size_t)(tid >> 3) * p.ldb + kbeg + (tid & 7) * 4;
+    g2r_fast<TA, 4>(ra, pa, p.lda);
+    g2r_fast<!TB, 2>(rb, pb, p.ldb);
+    constexpr int BSK = 64;                        // k-major B image stride
+    const int arow = wave * 32 + l31;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        r2s<TA, 4>(ra, As, tid);
+        if (TB) r2s<false, 2>(rb, Bs, tid);
+        else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *(f32x4*)(Bs + ((tid >> 4) + 16 * q) * BSK + (tid & 15) * 4) = rb[q];
+        }
+        __syncthreads();
+        if (k0 + BK < kend) {
+            pa += TA ? (size_t)BK * p.lda : BK;
+            pb += !TB ? (size_t)BK * p.ldb : BK;
+            g2r_fast<TA, 4>(ra, pa, p.lda);
+            g2r_fast<!TB, 2>(rb, pb, p.ldb);
+        }
+#pragma unroll
+        for (int m = 0; m < BK / 4; ++m) {
+            const int kq = 4 * m + 2 * h;
+            float a0, a1, b00, b01, b10, b11;
+            if (!TA) { const float2 t = *(const float2*)(As + arow * SROW + kq); a0 = t.x; a1 = t.y; }
+            else { a0 = As[kq * SKMJ + arow]; a1 = As[(kq + 1) * SKMJ + arow]; }
+            if (TB) {
+                const float2 t0 = *(const float2*)(Bs + l31 * SROW + kq), t1 = *(const float2*)(Bs + (l31 + 32) * SROW + kq);
+                b00 = t0.x; b01 = t0.y; b10 = t1.x; b11 = t1.y;
+            } else {
+                b00 = Bs[kq * BSK + l31]; b01 = Bs[(kq + 1) * BSK + l31];
+                b10 = Bs[kq * BSK + l31 + 32]; b11 = Bs[(kq + 1) * BSK + l31 + 32];
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b00, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b10, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b01, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b11, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            Cout[(size_t)row * p.ldc + j * 32 + l31] = acc[j][r];
+        }
+}
+
 // ---- bf16-operand variant (opt-in, mlsp_set_gemm_precision(1); BASELINE.json configs[4]) -------------------------------
 // Same tiling, epilogues and split-K protocol as gemm_f32_kernel<..., FAST>, but the fp32 operands are rounded to bf16 (RNE,
 // v_cvt_pk_bf16_f32) on their way into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 8x fewer MFMA
@@ -753,6 +825,14 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
     const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+    const bool n64 = N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !bias && !gbias && !stat_part && !sel_gamma &&
+                     !accumulate && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
+    if (n64) {
+        dim3 g64(M / 128, ns);
+        if (!ta && tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, true>), g64, dim3(256), 0, st, p);
+        else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, false>), g64, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_f32_n64_kernel<true, false>), g64, dim3(256), 0, st, p);
+    } else
 #define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
