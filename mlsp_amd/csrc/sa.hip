@@ -66,6 +66,67 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
     }
 }
 
+// ---- FPS, round 2: the per-sample critical path is one arg-max over the cloud.  The kernel above spends it in ~20 dependent
+// ds_bpermute shuffles and two workgroup barriers (1.6 us per sample).  Here: 4 waves, <= 8 points per lane in registers, the arg-max
+// as a max over ONE 64-bit key (distance bits << 32 | ~index: distances are >= 0 so their bit patterns order like the floats, and the
+// larger ~index is the smaller index = the reference's first maximum) reduced inside a wave by DPP row / bank shifts (no LDS
+// crossbar), across the 4 waves through a double-buffered LDS slot and ONE barrier.  Same distance expression, same running
+// minimum, same tie rule: identical indices.  N <= 2048.
+__device__ __forceinline__ unsigned long long fps_key_max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long fps_dpp64(unsigned long long v) {        // lanes without a source keep their own value
+    const unsigned lo = __builtin_amdgcn_update_dpp((int)(unsigned)v, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__global__ __launch_bounds__(256) void fps_kernel2(const float* __restrict__ xyz, int ldx, int N, int S, const int* __restrict__ start,
+                                                   int* __restrict__ out) {
+    extern __shared__ float fsm[];
+    float* cx = fsm;                                             // [N][3]
+    unsigned long long* slot = (unsigned long long*)(fsm + 3 * ((N + 1) & ~1));   // [2][4] wave maxima, double-buffered
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xb = xyz + (size_t)b * N * ldx;
+    float px[8], py[8], pz[8], dmin[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = tid + 256 * u;
+        px[u] = py[u] = pz[u] = 0.f; dmin[u] = 1e10f;
+        if (j < N) {
+            px[u] = xb[(size_t)j * ldx]; py[u] = xb[(size_t)j * ldx + 1]; pz[u] = xb[(size_t)j * ldx + 2];
+            cx[3 * j] = px[u]; cx[3 * j + 1] = py[u]; cx[3 * j + 2] = pz[u];
+        }
+    }
+    __syncthreads();
+    int far = start[b];
+    for (int i = 0; i < S; ++i) {
+        if (tid == 0) out[(size_t)b * S + i] = far;
+        const float fx = cx[3 * far], fy = cx[3 * far + 1], fz = cx[3 * far + 2];
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = tid + 256 * u;
+            if (j < N) {
+                const float dx = px[u] - fx, dy = py[u] - fy, dz = pz[u] - fz;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                dmin[u] = fminf(dmin[u], d);
+                key = fps_key_max(key, ((unsigned long long)__float_as_uint(dmin[u]) << 32) | (unsigned)(~j));
+            }
+        }
+        // wave max by DPP: within rows of 16 (shr 1, 2, 3 + combine), then row broadcasts 15 and 31 -> lane 63 holds the wave's maximum
+        key = fps_key_max(key, fps_dpp64<0x111>(key));           // row_shr:1
+        key = fps_key_max(key, fps_dpp64<0x112>(key));           // row_shr:2
+        key = fps_key_max(key, fps_dpp64<0x114>(key));           // row_shr:4
+        key = fps_key_max(key, fps_dpp64<0x118>(key));           // row_shr:8   -> lane 15 of every row: row maximum
+        key = fps_key_max(key, fps_dpp64<0x142>(key));           // row_bcast:15 -> rows 1..3 see the previous row's maximum
+        key = fps_key_max(key, fps_dpp64<0x143>(key));           // row_bcast:31 -> lane 63: maximum of all four rows
+        if (lane == 63) slot[(i & 1) * 4 + wave] = key;
+        __syncthreads();
+        const unsigned long long* sl = slot + (i & 1) * 4;
+        const unsigned long long best = fps_key_max(fps_key_max(sl[0], sl[1]), fps_key_max(sl[2], sl[3]));
+        far = (int)(~(unsigned)best);
+    }
+}
+
 // ---- ball query: one wave per query; candidates scanned in index order, 64 at a time.
 // idx[b][i][0..nsample): the first nsample j with !(|q_i - x_j|^2 > r2), padded with the first hit.
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz, int ldx, const float* __restrict__ q, int ldq, int N,
@@ -154,6 +215,11 @@ int launch_fps(hipStream_t st, const float* xyz, int ldx, int B, int N, int S, c
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+    }
+    if (N <= 2048 && N >= 64) {
+        const size_t lds2 = ((size_t)3 * ((N + 1) & ~1)) * sizeof(float) + 8 * sizeof(unsigned long long);
+        hipLaunchKernelGGL(fps_kernel2, dim3(B), dim3(256), lds2, st, xyz, ldx, N, S, start, out);
+        return mlsp_launch_status();
     }
     hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(FPS_T), lds, st, xyz, ldx, N, S, start, out);
     return mlsp_launch_status();
