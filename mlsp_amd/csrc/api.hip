@@ -125,9 +125,10 @@ int launch_tnet_bwd_reduce(hipStream_t st, const float* dT, const float* T, cons
                            float slope, double* part);
 int launch_tnet_bwd_g(hipStream_t st, const float* dT, const float* T, const float* bn2, const float* mean_dz,
                       const float* mean_dzy, int P, float slope, float* g, float* coef);
+size_t tnet_bwd_scratch_floats(int ntiles);
 int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const float* bn1, const float* W2, const float* bn2,
                          const float* g, const uint8_t* argsel, const float* coef, int P, int N, int k, float slope, float* dhp,
-                         float* dW2part, double* part1);
+                         float* scratch, double* part1, float* dW2, int* nparts);
 int launch_tnet_edge_bwd2(hipStream_t st, const float* dhp, const float* uv, const float* s1, const float* bn1, const float* m1,
                           const float* m2, const int* rev_off, const int* rev_ent, int P, int N, int k, float* duv);
 
@@ -169,7 +170,7 @@ size_t mlsp_workspace_bytes(int rows, int cin, int cout) {
     size_t act = 3 * r * co * sizeof(float) + r * sizeof(float);            // gz + duv (edgeconv bwd) / dY (mlp bwd) / xx
     size_t parts = (r / 64 + 2) * 2 * co * sizeof(double);                  // stat partials
     size_t wts = 4 * co * ci * sizeof(float) * 2 + 8 * co * sizeof(float);  // Wd, dWd, coefficient vectors
-    return act + parts + wts + SLAB_BOUND_FLOATS * sizeof(float) + (1 << 20);
+    return act + parts + wts + SLAB_BOUND_FLOATS * sizeof(float) + (32 << 20);       // + fixed-size per-workgroup partial slabs
 }
 
 int mlsp_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
@@ -386,7 +387,7 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
     float* g = w.take<float>((size_t)P * C2);
     float* coef = w.take<float>(2 * C2);
     float* dhp = w.take<float>(E * C1);
-    float* dW2part = w.take<float>((size_t)nb * C2 * C1);
+    float* dW2part = w.take<float>(tnet_bwd_scratch_floats(ntiles));
     int npr = (P + 511) / 512;
     const int nprv = bn_vec_parts(P);                                  // rows of the vectorised BN2 partial pass
     const int nrows_part = (npr > nb ? npr : nb) > nprv ? (npr > nb ? npr : nb) : nprv;
@@ -411,9 +412,9 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
     }
     CHECK(launch_bn_bwd_finalize(st, part, npr, (double)E, C2, dgamma2, dbeta2, mean_dz, mean_dzy));
     CHECK(launch_tnet_bwd_g(st, dOut, out, bn2_save, training ? mean_dz : nullptr, mean_dzy, P, slope, g, coef));
-    CHECK(launch_tnet_edge_bwd(st, uv, idx, bn1_save, W2, bn2_save, g, argsel, coef, P, N, k, slope, dhp, dW2part, part));
-    CHECK(launch_slab_reduce(st, dW2part, dW2, C2, C1, C1, nb));
-    CHECK(launch_bn_bwd_finalize(st, part, nb, (double)E, C1, dgamma1, dbeta1, m1, m2));
+    int nparts = 0;
+    CHECK(launch_tnet_edge_bwd(st, uv, idx, bn1_save, W2, bn2_save, g, argsel, coef, P, N, k, slope, dhp, dW2part, part, dW2, &nparts));
+    CHECK(launch_bn_bwd_finalize(st, part, nparts, (double)E, C1, dgamma1, dbeta1, m1, m2));
     CHECK(launch_tnet_edge_bwd2(st, dhp, uv, s1, bn1_save, training ? m1 : nullptr, m2, rev_off, rev_ent, P, N, k, duv));
     CHECK(launch_build_wd(st, W1, C1, C, Wd));
     if (dx) CHECK(launch_gemm(st, false, false, P, C, 2 * C1, duv, 2 * C1, Wd, C, dx, C, nullptr, nullptr, 0, slab, sf));

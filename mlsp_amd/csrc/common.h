@@ -11,6 +11,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 static inline int mlsp_launch_status() {
     hipError_t e = hipGetLastError();

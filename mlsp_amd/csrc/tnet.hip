@@ -15,6 +15,7 @@
 // folded onto the points (tnet_edge_bwd2_kernel, a gather over the reverse neighbour index).
 #include "common.h"
 #include <math.h>
+#include <cstdlib>
 
 #define TN_C1 64
 #define TN_C2 128
@@ -554,6 +555,380 @@ __global__ __launch_bounds__(512) void tnet_edge_bwd_kernel(TnetBwdArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Backward, round 2: the per-edge tile dZ is never formed.  With BN2's backward in closed form the tile is AFFINE in Z = H' W2^T,
+//     dZ[row][o] = gsel[row][o] - B2[o] Z[row][o] - K2[o],     gsel[row][o] = g[pt][o] if row is the arg-max slot of (pt, o) else 0,
+// so both products that consume it split into a SPARSE part (one non-zero per point and channel) and a part through 64 x 64 matrices:
+//     dH  = dZ W2    = gsel W2  -  H' M  -  cv          M = W2^T diag(B2) W2 (64 x 64),  cv = K2^T W2       (tnet_bwd_prep_kernel)
+//     dW2 = dZ^T H'  = gsel^T H'  -  diag(B2) W2 (H'^T H')  -  K2 (1^T H')                                   (tnet_bwd_finish_kernel)
+// Per 128-row tile that is 2 x 32 MFMAs per wave (P = H' M, and the tile's share of the Gram matrix H'^T H') instead of three
+// 128 x 128 x 64 products (1/3 of the round-1 MFMA work, 1/6 of its flops), plus 2 x 128 fused multiply-adds per point and channel lane:
+//     G1[o][c] += g[pt][o] H'[row(pt, arg)][c]        wave = 16 output channels (registers), lane = c
+//     S[row(pt, arg)][c] += g[pt][o] W2[o][c]         wave = point, lane = c, the point's rows in registers indexed by the uniform slot
+// g / arg-max slots are wave-uniform and come through the scalar cache.  LDS: H' double-buffered (the next tile is gathered while
+// this one is computed), S, M, W2 = 147 KB, one workgroup of 8 waves per CU.  The epilogue (dh' = dH act'(a), BN1-backward sums)
+// runs in the MFMA layout on P still in registers; a is recovered from the activated value (LeakyReLU is a bijection for slope != 0).
+#define TG_HP 66
+#define TG_SLAB (TN_C2 * TN_C1 + TN_C1 * TN_C1 + TN_C1)          // per-workgroup partials: G1 [128][64], Gram [64][64], colsum(H') [64]
+struct TnetBwdGLds {
+    float Hs[2][TN_ROWS * TG_HP];
+    float Ss[TN_ROWS * TN_C1];
+    float Ms[TN_C1 * TN_C1];
+    float Ws[TN_C2 * TN_C1];
+    float S1[4 * TN_C1];                 // scale1, shift1, mean1, invstd1
+    float cv[TN_C1];
+    float gT[2][TN_MAXTP * TN_C2];       // g of the tile's points, staged one tile ahead
+    uint32_t aT[2][TN_MAXTP * TN_C2 / 4];   // their arg-max slots, 4 per word
+};
+
+__global__ void tnet_bwd_prep_kernel(const float* __restrict__ W2, const float* __restrict__ coef, const float* __restrict__ bn2,
+                                     float* __restrict__ Mc) {
+    const int c1 = blockIdx.x, c2 = threadIdx.x;
+    float acc = 0.f;
+    if (c1 < TN_C1) {
+        for (int o = 0; o < TN_C2; ++o) acc = fmaf(W2[o * TN_C1 + c1] * coef[TN_C2 + o], W2[o * TN_C1 + c2], acc);
+        Mc[c1 * TN_C1 + c2] = acc;
+    } else {
+        for (int o = 0; o < TN_C2; ++o) acc = fmaf(coef[o] - coef[TN_C2 + o] * bn2[2 * TN_C2 + o], W2[o * TN_C1 + c2], acc);
+        Mc[TN_C1 * TN_C1 + c2] = acc;
+    }
+}
+
+// R = the workgroup partials summed in a fixed order: dW2 = G1 - diag(B2) W2 Gram - K2 colsum
+__global__ void tnet_bwd_finish_kernel(const float* __restrict__ R, const float* __restrict__ W2, const float* __restrict__ coef,
+                                       const float* __restrict__ bn2, float* __restrict__ dW2) {
+    const int o = blockIdx.x, c = threadIdx.x;
+    const float B2 = coef[TN_C2 + o], K2 = coef[o] - B2 * bn2[2 * TN_C2 + o];
+    float zh = 0.f;
+    for (int c1 = 0; c1 < TN_C1; ++c1) zh = fmaf(W2[o * TN_C1 + c1], R[TN_C2 * TN_C1 + c1 * TN_C1 + c], zh);
+    dW2[o * TN_C1 + c] = (R[o * TN_C1 + c] - B2 * zh) - K2 * R[TN_C2 * TN_C1 + TN_C1 * TN_C1 + c];
+}
+
+// Register-indexed FMAs (VGPR index mode, M0 = a wave-uniform index): two SALU + one VALU instruction per sparse entry.  The indexed
+// 32-register block is pinned (v[224:255], shared: the two uses never overlap) because the instruction text has to name its first register.
+//   tg_fma_dst8: acc[slot_i - s0] += g_i * w_i        (destination and addend indexed)
+//   tg_fma_src8: c_i += g_i * rows[slot_i - s0]       (second factor indexed)
+// for the 8 entries whose slots are the bytes of (a0, a1); g_i are float bit patterns in SGPRs.  The slot is masked to [0, 32); RANGED
+// (k > 32): entries whose slot lies outside [s0, s0 + 32) add an exact zero.
+template <bool RANGED> __device__ __forceinline__ void tg_fma_dst8(f32x32& acc, uint32_t a0, uint32_t a1, const uint32_t (&g)[8], int s0,
+                                                                 const float* w) {
+    uint32_t t, u;
+    if (RANGED) {
+        asm volatile(
+            "s_and_b32 %[t], %[a0], 0xff\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g0], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_on %[t], gpr_idx(SRC2,DST)\n\ts_nop 0\n\tv_fma_f32 v224, %[u], %[w0], v224\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x80008\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g1], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[u], %[w1], v224\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x80010\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g2], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[u], %[w2], v224\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x80018\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g3], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[u], %[w3], v224\n\t"
+            "s_and_b32 %[t], %[a1], 0xff\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g4], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[u], %[w4], v224\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x80008\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g5], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[u], %[w5], v224\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x80010\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g6], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[u], %[w6], v224\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x80018\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g7], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[u], %[w7], v224\n\t"
+            "s_set_gpr_idx_off"
+            : "+{v[224:255]}"(acc), [t] "=&s"(t), [u] "=&s"(u)
+            : [a0] "s"(a0), [a1] "s"(a1), [s0] "s"(s0), [g0] "s"(g[0]), [g1] "s"(g[1]), [g2] "s"(g[2]), [g3] "s"(g[3]), [g4] "s"(g[4]), [g5] "s"(g[5]), [g6] "s"(g[6]), [g7] "s"(g[7]),
+              [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]), [w7] "v"(w[7])
+            : "scc");
+    } else {
+        asm volatile(
+            "s_and_b32 %[t], %[a0], 31\n\ts_set_gpr_idx_on %[t], gpr_idx(SRC2,DST)\n\ts_nop 0\n\tv_fma_f32 v224, %[g0], %[w0], v224\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x50008\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[g1], %[w1], v224\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x50010\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[g2], %[w2], v224\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x50018\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[g3], %[w3], v224\n\t"
+            "s_and_b32 %[t], %[a1], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[g4], %[w4], v224\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x50008\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[g5], %[w5], v224\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x50010\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[g6], %[w6], v224\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x50018\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v224, %[g7], %[w7], v224\n\t"
+            "s_set_gpr_idx_off"
+            : "+{v[224:255]}"(acc), [t] "=&s"(t)
+            : [a0] "s"(a0), [a1] "s"(a1), [g0] "s"(g[0]), [g1] "s"(g[1]), [g2] "s"(g[2]), [g3] "s"(g[3]), [g4] "s"(g[4]), [g5] "s"(g[5]), [g6] "s"(g[6]), [g7] "s"(g[7]),
+              [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]), [w7] "v"(w[7])
+            : "scc");
+    }
+}
+template <bool RANGED> __device__ __forceinline__ void tg_fma_src8(float* c, const f32x32& rows, uint32_t a0, uint32_t a1, const uint32_t (&g)[8],
+                                                                 int s0) {
+    uint32_t t, u;
+    if (RANGED) {
+        asm volatile(
+            "s_and_b32 %[t], %[a0], 0xff\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g0], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_on %[t], gpr_idx(SRC1)\n\ts_nop 0\n\tv_fma_f32 %[c0], %[u], v224, %[c0]\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x80008\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g1], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c1], %[u], v224, %[c1]\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x80010\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g2], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c2], %[u], v224, %[c2]\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x80018\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g3], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c3], %[u], v224, %[c3]\n\t"
+            "s_and_b32 %[t], %[a1], 0xff\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g4], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c4], %[u], v224, %[c4]\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x80008\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g5], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c5], %[u], v224, %[c5]\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x80010\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g6], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c6], %[u], v224, %[c6]\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x80018\n\ts_sub_u32 %[t], %[t], %[s0]\n\ts_cmp_lt_u32 %[t], 32\n\ts_cselect_b32 %[u], %[g7], 0\n\ts_and_b32 %[t], %[t], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c7], %[u], v224, %[c7]\n\t"
+            "s_set_gpr_idx_off"
+            : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [t] "=&s"(t), [u] "=&s"(u)
+            : "{v[224:255]}"(rows), [a0] "s"(a0), [a1] "s"(a1), [s0] "s"(s0), [g0] "s"(g[0]), [g1] "s"(g[1]), [g2] "s"(g[2]), [g3] "s"(g[3]), [g4] "s"(g[4]), [g5] "s"(g[5]), [g6] "s"(g[6]), [g7] "s"(g[7])
+            : "scc");
+    } else {
+        asm volatile(
+            "s_and_b32 %[t], %[a0], 31\n\ts_set_gpr_idx_on %[t], gpr_idx(SRC1)\n\ts_nop 0\n\tv_fma_f32 %[c0], %[g0], v224, %[c0]\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x50008\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c1], %[g1], v224, %[c1]\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x50010\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c2], %[g2], v224, %[c2]\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x50018\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c3], %[g3], v224, %[c3]\n\t"
+            "s_and_b32 %[t], %[a1], 31\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c4], %[g4], v224, %[c4]\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x50008\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c5], %[g5], v224, %[c5]\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x50010\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c6], %[g6], v224, %[c6]\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x50018\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c7], %[g7], v224, %[c7]\n\t"
+            "s_set_gpr_idx_off"
+            : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [t] "=&s"(t)
+            : "{v[224:255]}"(rows), [a0] "s"(a0), [a1] "s"(a1), [g0] "s"(g[0]), [g1] "s"(g[1]), [g2] "s"(g[2]), [g3] "s"(g[3]), [g4] "s"(g[4]), [g5] "s"(g[5]), [g6] "s"(g[6]), [g7] "s"(g[7])
+            : "scc");
+    }
+}
+
+template <bool RANGED, int KR> __global__ __launch_bounds__(512) void tnet_edge_bwdg_kernel(
+    const float* __restrict__ uv, const int* __restrict__ idx, const float* __restrict__ bn1, const float* __restrict__ W2,
+    const float* __restrict__ Mc, const float* __restrict__ g, const uint8_t* __restrict__ argsel, float* __restrict__ dhp,
+    float* __restrict__ slabs, double* __restrict__ part1, int P, int N, int k, int TP, float slope) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    TnetBwdGLds& L = *reinterpret_cast<TnetBwdGLds*>(smraw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    for (int e = tid; e < (int)(sizeof(TnetBwdGLds) / 16); e += 512) ((f32x4*)smraw)[e] = f32x4{0.f, 0.f, 0.f, 0.f};   // no NaN patterns anywhere
+    __syncthreads();
+    for (int e = tid; e < TN_C2 * TN_C1 / 4; e += 512) ((f32x4*)L.Ws)[e] = ((const f32x4*)W2)[e];
+    for (int e = tid; e < TN_C1 * TN_C1 / 4; e += 512) ((f32x4*)L.Ms)[e] = ((const f32x4*)Mc)[e];
+    if (tid < 4 * TN_C1) L.S1[tid] = bn1[tid];
+    if (tid < TN_C1) L.cv[tid] = Mc[TN_C1 * TN_C1 + tid];
+    // gather role: 4 threads per tile row, 16 channels each
+    const int grow = tid >> 2, gq = tid & 3;
+    const int gpt = grow / k, gslot = grow - gpt * k;
+    // MFMA roles: P tile (row block rb, channel tile ct); Gram tile (gi, gj) over the row half gh
+    const int rb = wave & 3, ct = wave >> 2;
+    const int gi = wave & 1, gj = (wave >> 1) & 1, gh = wave >> 2;
+    f32x16 accG;
+    float accO[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accG[r] = 0.f; accO[r] = 0.f; }
+    double sd = 0.0, sdh = 0.0, shs = 0.0;
+    const int Bc = P / N;
+    const int nsw = RANGED ? (k + 31) >> 5 : 1;                // 32-slot ranges per point (S rows live in registers); !RANGED: k <= 32
+    const float rslope = 1.0f / slope;
+
+    auto row_index = [&](int pt0_, int npts_) -> int {        // uv row of this thread's neighbour, -1 = padding row
+        return gpt < npts_ ? (pt0_ / N) * N + idx[(size_t)(pt0_ + gpt) * k + gslot] : -1;
+    };
+    auto load_rows = [&](int j, int pt0_, f32x4 (&u)[4], f32x4 (&v)[4]) {
+        if (j >= 0) {
+            const f32x4* up = (const f32x4*)(uv + (size_t)j * 2 * TN_C1 + 16 * gq);
+            const f32x4* vp = (const f32x4*)(uv + (size_t)(pt0_ + gpt) * 2 * TN_C1 + TN_C1 + 16 * gq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { u[e] = up[e]; v[e] = vp[e]; }
+        }
+    };
+    // g / arg-max slots of a tile's points: loaded with the rows, stored to the LDS tables with them
+    auto load_scal = [&](int pt0_, int npts_, float (&gq)[2], uint32_t& aq) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) gq[e] = tid + 512 * e < npts_ * TN_C2 ? g[(size_t)pt0_ * TN_C2 + tid + 512 * e] : 0.f;
+        aq = tid < npts_ * (TN_C2 / 4) ? ((const uint32_t*)argsel)[(size_t)pt0_ * (TN_C2 / 4) + tid] : 0u;
+    };
+    auto store_scal = [&](int buf, const float (&gq)[2], uint32_t aq) {
+        L.gT[buf][tid] = gq[0]; L.gT[buf][tid + 512] = gq[1];
+        if (tid < TN_MAXTP * TN_C2 / 4) L.aT[buf][tid] = aq;
+    };
+    auto store_rows = [&](float* Hd, int j, const f32x4 (&u)[4], const f32x4 (&v)[4]) {
+        float* dst = Hd + grow * TG_HP + 16 * gq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float hv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ch = 16 * gq + 4 * e + c;
+                hv[c] = j >= 0 ? lrelu(fmaf(u[e][c] + v[e][c], L.S1[ch], L.S1[TN_C1 + ch]), slope) : 0.f;
+            }
+            *(float2*)(dst + 4 * e) = make_float2(hv[0], hv[1]);
+            *(float2*)(dst + 4 * e + 2) = make_float2(hv[2], hv[3]);
+        }
+    };
+
+    int pt0 = 0, npts = 0, pt0n = 0, nptsn = 0;
+    bool have = tn_tile(0, Bc, N, TP, pt0, npts);
+    bool haven = have && tn_tile(1, Bc, N, TP, pt0n, nptsn);
+    __syncthreads();                                           // S1 is read by store_rows
+    {
+        f32x4 u[4], v[4];
+        const int j0 = have ? row_index(pt0, npts) : -1;
+        float gq[2]; uint32_t aq;
+        load_rows(j0, pt0, u, v);
+        load_scal(pt0, have ? npts : 0, gq, aq);
+        store_rows(L.Hs[0], j0, u, v);
+        store_scal(0, gq, aq);
+    }
+    int jn = haven ? row_index(pt0n, nptsn) : -1;
+    __syncthreads();
+    for (int m = 0; have; ++m) {
+        const float* Hc = L.Hs[m & 1];
+        const int nvalid = npts * k;
+        f32x4 u[4], v[4];
+        float gq[2]; uint32_t aq;
+        load_rows(jn, pt0n, u, v);                             // next tile's rows and scalars in flight during this tile's work
+        load_scal(pt0n, haven ? nptsn : 0, gq, aq);
+        int pt0nn = 0, nptsnn = 0;
+        const bool havenn = haven && tn_tile(m + 2, Bc, N, TP, pt0nn, nptsnn);
+        const int jnn = havenn ? row_index(pt0nn, nptsnn) : -1;
+        // ---- two independent halves per tile and wave: the 64 MFMAs (P = H' M for rows 32 rb.., channels 32 ct..; Gram tile (gi, gj)
+        // += H'^T H' over rows 64 gh..) and the sparse work (S rows, G1).  Waves 0-3 run the MFMA half first, waves 4-7 the sparse
+        // half first: each SIMD holds one wave of either kind, so its matrix pipe and its scalar/vector issue are busy at the same time.
+        f32x16 accP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accP[r] = 0.f;
+        const float* gt = L.gT[m & 1];
+        const uint32_t* at = L.aT[m & 1];
+        for (int half = 0; half < 2; ++half) {
+            if ((half == 0) == (wave < 4)) {
+#ifndef TG_PROBE_NOMFMA
+                // the two accumulation chains alternate: a wave alone keeps the matrix pipe full (a chain by itself waits for each result)
+#pragma unroll 4
+                for (int kk = 0; kk < 16; ++kk) {
+                    const float2 a = *(const float2*)(Hc + (32 * rb + l31) * TG_HP + 4 * kk + 2 * h);
+                    const float b0 = L.Ms[(4 * kk + 2 * h) * TN_C1 + 32 * ct + l31], b1 = L.Ms[(4 * kk + 2 * h + 1) * TN_C1 + 32 * ct + l31];
+                    const float* hr = Hc + (64 * gh + 4 * kk + h) * TG_HP + l31;
+                    const float ga0 = hr[32 * gi], gb0 = hr[32 * gj], ga1 = hr[2 * TG_HP + 32 * gi], gb1 = hr[2 * TG_HP + 32 * gj];
+                    accP = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, accP, 0, 0, 0);
+                    accG = __builtin_amdgcn_mfma_f32_32x32x2f32(ga0, gb0, accG, 0, 0, 0);
+                    accP = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, accP, 0, 0, 0);
+                    accG = __builtin_amdgcn_mfma_f32_32x32x2f32(ga1, gb1, accG, 0, 0, 0);
+                }
+#endif
+            } else {
+                // ---- S[row(pt, arg)][lane] = sum_o g[pt][o] W2[o][lane] over the channels whose arg-max is that row: one wave per
+                // (point, 32-slot range) keeps its rows in the indexed register block, adds in ascending o, then stores the rows
+#ifndef TG_PROBE_NOSCATTER
+                if (wave < npts * nsw) {
+                    const int spt = wave / nsw, s0 = (wave - spt * nsw) * 32;
+                    const int gv0 = __float_as_int(gt[spt * TN_C2 + lane]), gv1 = __float_as_int(gt[spt * TN_C2 + 64 + lane]);
+                    const uint32_t av = at[spt * (TN_C2 / 4) + l31];
+                    const float* wb = L.Ws + lane;
+                    f32x32 acc;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+                    float w[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) w[i] = wb[i * TN_C1];
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        const int chn = ch < 7 ? ch + 1 : ch;
+                        float wn[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) wn[i] = wb[(16 * chn + i) * TN_C1];     // the next chunk's W2 values are requested first
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int o = 16 * ch + 8 * q;
+                            const int gsrc = o < 64 ? gv0 : gv1;                          // g values travel as bit patterns in SGPRs
+                            uint32_t ge[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) ge[e] = __builtin_amdgcn_readlane(gsrc, (o + e) & 63);
+                            tg_fma_dst8<RANGED>(acc, __builtin_amdgcn_readlane(av, o >> 2), __builtin_amdgcn_readlane(av, (o >> 2) + 1), ge, s0,
+                                                w + 8 * q);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) w[i] = wn[i];
+                    }
+                    float* sb = L.Ss + (spt * k + s0) * TN_C1 + lane;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i)
+                        if (s0 + i < k) sb[i * TN_C1] = acc[i];
+                }
+#endif
+                // ---- G1[16 wave + i][lane] += g[pt][o] H'[row(pt, arg)][lane]: KR (>= k, or 32 when RANGED) of the point's H' rows are
+                // loaded into the indexed register block, the 16 entries then cost one indexed FMA each.  Rows past k are the next
+                // points' rows (or, past the tile, whatever follows in LDS, zeroed at kernel start): finite, and only ever multiplied
+                // by an exact zero.
+#ifndef TG_PROBE_NOG1
+                for (int pt = 0; pt < npts; ++pt) {
+                    const int gvi = __float_as_int(gt[pt * TN_C2 + 16 * wave + (lane & 15)]);
+                    const uint32_t av = at[pt * (TN_C2 / 4) + 4 * wave + (lane & 3)];
+                    uint32_t ge[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ge[e] = __builtin_amdgcn_readlane(gvi, e);
+                    uint32_t ae[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ae[e] = __builtin_amdgcn_readlane(av, e);
+                    for (int rg = 0; rg < nsw; ++rg) {
+                        const int s0 = 32 * rg;
+                        const float* hr = Hc + (pt * k + s0) * TG_HP + lane;
+                        f32x32 rows;
+#pragma unroll
+                        for (int sl = 0; sl < KR; ++sl) rows[sl] = hr[sl * TG_HP];
+#pragma unroll
+                        for (int sl = KR; sl < 32; ++sl) rows[sl] = 0.f;
+                        tg_fma_src8<RANGED>(accO, rows, ae[0], ae[1], (const uint32_t(&)[8])ge[0], s0);
+                        tg_fma_src8<RANGED>(accO + 8, rows, ae[2], ae[3], (const uint32_t(&)[8])ge[8], s0);
+                    }
+                }
+#endif
+            }
+        }
+        if (haven) { store_rows(L.Hs[(m & 1) ^ 1], jn, u, v); store_scal((m & 1) ^ 1, gq, aq); }
+        __syncthreads();
+        // ---- dH = S - P - cv in the MFMA layout: channel c = 32 ct + l31, rows 32 rb + map(r, h)
+        {
+            const int c = 32 * ct + l31;
+            const float sc = L.S1[c], sh = L.S1[TN_C1 + c], mu = L.S1[2 * TN_C1 + c], is = L.S1[3 * TN_C1 + c], cvc = L.cv[c];
+            const float rsc = sc != 0.f ? 1.0f / sc : 0.f;
+            float lsd = 0.f, lsdh = 0.f, lhs = 0.f;
+            const int row0 = 32 * rb + 4 * h;                  // one base per array + compile-time offsets (LDS / global immediates)
+            const float* sp = L.Ss + row0 * TN_C1 + c;
+            const float* hp = Hc + row0 * TG_HP + c;
+            float* dp = dhp + ((size_t)pt0 * k + row0) * TN_C1 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                const float sv = sp[dr * TN_C1];
+                const float hv = hp[dr * TG_HP];
+#ifdef TG_PROBE_NOEPI
+                if (row0 + dr < nvalid && sv == 123.456f) {
+#else
+                if (row0 + dr < nvalid) {
+#endif
+                    const float dH = (sv - accP[r]) - cvc;
+                    const float a = hv > 0.f ? hv : hv * rslope;
+                    const float d = dH * (hv > 0.f ? 1.f : slope);
+                    dp[dr * TN_C1] = d;
+                    lsd += d; lsdh = fmaf(d, ((a - sh) * rsc - mu) * is, lsdh); lhs += hv;
+                }
+            }
+            sd += lsd; sdh += lsdh; shs += lhs;
+        }
+        __syncthreads();
+        pt0 = pt0n; npts = nptsn; have = haven;
+        pt0n = pt0nn; nptsn = nptsnn; haven = havenn; jn = jnn;
+    }
+    // ---- per-workgroup partials
+    float* slab = slabs + (size_t)blockIdx.x * TG_SLAB;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) slab[(16 * wave + i) * TN_C1 + lane] = accO[i];
+    float* gred = L.Ss;                                        // 4 Gram tiles of the upper row half [4][16][64]
+    if (gh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gred[((wave & 3) * 16 + r) * 64 + lane] = accG[r];
+    }
+    double* red = reinterpret_cast<double*>(L.Hs[0]);          // [3 kinds][4 row blocks][64 channels]
+    {
+        const double a = sd + __shfl_xor(sd, 32, 64), b = sdh + __shfl_xor(sdh, 32, 64), c3 = shs + __shfl_xor(shs, 32, 64);
+        if (h == 0) {
+            const int c = 32 * ct + l31;
+            red[(0 * 4 + rb) * 64 + c] = a; red[(1 * 4 + rb) * 64 + c] = b; red[(2 * 4 + rb) * 64 + c] = c3;
+        }
+    }
+    __syncthreads();
+    if (gh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            slab[TN_C2 * TN_C1 + (32 * gi + (r & 3) + 8 * (r >> 2) + 4 * h) * TN_C1 + 32 * gj + l31] =
+                accG[r] + gred[((wave & 3) * 16 + r) * 64 + lane];
+    }
+    if (tid < 3 * TN_C1) {
+        const int kind = tid >> 6, c = tid & 63;
+        const double t = (red[(kind * 4 + 0) * 64 + c] + red[(kind * 4 + 1) * 64 + c]) + (red[(kind * 4 + 2) * 64 + c] + red[(kind * 4 + 3) * 64 + c]);
+        if (kind < 2) part1[((size_t)blockIdx.x * 2 + kind) * TN_C1 + c] = t;
+        else slab[TN_C2 * TN_C1 + TN_C1 * TN_C1 + c] = (float)t;
+    }
+}
+
 // Fold dh' onto the points (BN1 backward in closed form), wave per point, lane = channel (64):
 //   g_e = scale1*(dh'_e - m1 - hhat_e*m2);  dv_i = sum_s g_(i,s);  du_j = sum_{e in rev(j)} g_e
 __global__ __launch_bounds__(256) void tnet_edge_bwd2_kernel(const float* __restrict__ dhp, const float* __restrict__ uv,
@@ -655,19 +1030,54 @@ int launch_tnet_bwd_g(hipStream_t st, const float* dT, const float* T, const flo
     return mlsp_launch_status();
 }
 
+int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int nsplit);
+int tnet_bwd_grid(int ntiles) { return ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256; }
+// floats of scratch the backward needs: workgroup partial slabs + M/cv + the reduced slab (Gram path), or the round-1 kernel's dW2 slabs
+size_t tnet_bwd_scratch_floats(int ntiles) {
+    const size_t a = (size_t)tnet_bwd_grid(ntiles) * TG_SLAB + TN_C1 * TN_C1 + TN_C1 + TG_SLAB;
+    const size_t b = (size_t)tnet_grid(ntiles) * TN_C2 * TN_C1;
+    return a > b ? a : b;
+}
+// Per-edge backward: dh' [E][64], dW2, and the BN1-backward partial sums part1 [*nparts][2][64].
 int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const float* bn1, const float* W2, const float* bn2,
                          const float* g, const uint8_t* argsel, const float* coef, int P, int N, int k, float slope, float* dhp,
-                         float* dW2part, double* part1) {
+                         float* scratch, double* part1, float* dW2, int* nparts) {
+    const int TP = tnet_points_per_tile(k);
+    if (TP <= 0) return MLSP_ERR_UNSUPPORTED;
+    const int ntiles = (P / N) * ((N + TP - 1) / TP);
+    static const bool use_old = getenv("MLSP_TNET_BWD_OLD") != nullptr;       // A/B switch (tools/time_tnet.py): the round-1 kernel
+    if (!use_old && slope != 0.f) {
+        const int nb = tnet_bwd_grid(ntiles);
+        float* slabs = scratch;
+        float* Mc = slabs + (size_t)nb * TG_SLAB;
+        float* R = Mc + TN_C1 * TN_C1 + TN_C1;
+        hipLaunchKernelGGL(tnet_bwd_prep_kernel, dim3(TN_C1 + 1), dim3(TN_C1), 0, st, W2, coef, bn2, Mc);
+        const size_t lds = sizeof(TnetBwdGLds);
+        auto kern = k <= 20 ? tnet_edge_bwdg_kernel<false, 20> : k <= 24 ? tnet_edge_bwdg_kernel<false, 24> : k <= 32 ? tnet_edge_bwdg_kernel<false, 32> : tnet_edge_bwdg_kernel<true, 32>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, st, uv, idx, bn1, W2, Mc, g, argsel, dhp, slabs, part1, P, N, k, TP, slope);
+        int rc = mlsp_launch_status();
+        if (rc) return rc;
+        rc = launch_slab_reduce(st, slabs, R, TG_SLAB / TN_C1, TN_C1, TN_C1, nb);
+        if (rc) return rc;
+        hipLaunchKernelGGL(tnet_bwd_finish_kernel, dim3(TN_C2), dim3(TN_C1), 0, st, R, W2, coef, bn2, dW2);
+        *nparts = nb;
+        return mlsp_launch_status();
+    }
     TnetBwdArgs a;
     a.uv = uv; a.idx = idx; a.bn1 = bn1; a.W2 = W2; a.bn2 = bn2; a.g = g; a.argsel = argsel; a.coef = coef;
-    a.dhp = dhp; a.dW2part = dW2part; a.part1 = part1;
-    a.P = P; a.N = N; a.k = k; a.TP = tnet_points_per_tile(k); a.slope = slope;
-    if (a.TP <= 0) return MLSP_ERR_UNSUPPORTED;
-    a.ntiles = (P / N) * ((N + a.TP - 1) / a.TP);
+    a.dhp = dhp; a.dW2part = scratch; a.part1 = part1;
+    a.P = P; a.N = N; a.k = k; a.TP = TP; a.slope = slope;
+    a.ntiles = ntiles;
     int rc = tnet_set_lds((const void*)tnet_edge_bwd_kernel);
     if (rc) return rc;
-    hipLaunchKernelGGL(tnet_edge_bwd_kernel, dim3(tnet_grid(a.ntiles)), dim3(512), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
-    return mlsp_launch_status();
+    const int nb = tnet_grid(ntiles);
+    hipLaunchKernelGGL(tnet_edge_bwd_kernel, dim3(nb), dim3(512), (size_t)TN_LDS_FLOATS * sizeof(float), st, a);
+    rc = mlsp_launch_status();
+    if (rc) return rc;
+    *nparts = nb;
+    return launch_slab_reduce(st, scratch, dW2, TN_C2, TN_C1, TN_C1, nb);
 }
 
 int launch_tnet_edge_bwd2(hipStream_t st, const float* dhp, const float* uv, const float* s1, const float* bn1, const float* m1,
