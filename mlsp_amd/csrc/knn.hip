@@ -1474,108 +1474,165 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 // For every point j: the list of (i, slot) with idx[i][slot] == j, sorted by i*256+slot so that the
 // backward gather-reduce that walks it sums in a fixed order (bitwise reproducible gradients).
 //   rev_off [B*N+1]  global edge offsets;  rev_ent [B*N*k]  packed (i_local << 8 | slot)
-#define RV_SPLIT 4
+#define RV_SPLIT 8
+#define RV_CAP (16 * 1024)                // LDS entries of a slice's lists, twice: filled / ordered (a slice past that sorts in place in global memory)
+// RV_SPLIT workgroups per cloud, each owns a contiguous slice of the destinations: it counts only the edges that point into its
+// slice (LDS atomics are the expensive instruction here: ~3 clocks per lane), gets the slice's base offset by counting the edges
+// that point BELOW it (plain adds + one block reduction), fills its lists and orders every list.
 __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict__ idx, int N, int k,
                                                            int* __restrict__ rev_off, int* __restrict__ rev_ent,
-                                                           int B, int ent_in_lds, int S, int rank_sort) {
+                                                           int B, int S, int rank_sort) {
     extern __shared__ int ism[];
-    int* cnt = ism;            // [N]
-    int* off = ism + N;        // [N+1]
-    // RV_SPLIT workgroups per cloud: each builds the (cheap) histogram + scan of the whole cloud, then fills and sorts
-    // only its own slice of destinations
+    __shared__ int wsum[16];
+    __shared__ int nbig;                  // lists of more than 64 entries: queued (cnt is free by then) for the whole-workgroup loop
     int b, part;
     xcd_cloud_map(blockIdx.x, RV_SPLIT, B, b, part);      // the RV_SPLIT workgroups of a cloud share an XCD (they read the same idx)
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int dper = (N + RV_SPLIT - 1) / RV_SPLIT, d0 = part * dper, d1 = min(N, d0 + dper);
+    const int dper = (N + RV_SPLIT - 1) / RV_SPLIT, d0 = min(N, part * dper), d1 = min(N, d0 + dper), nd = d1 - d0;
+    int* cnt = ism;            // [dper]
+    int* off = ism + dper;     // [dper + 1]  offsets inside the slice
+    int* lent = off + dper + 1;   // [RV_CAP] as filled
+    int* lord = lent + RV_CAP;    // [RV_CAP] ordered
     // S source rows of k slots per cloud point at N destinations (S == N for the kNN graph; the set-abstraction grouping has
     // S sampled centres gathering from N points)
     const int* ib = idx + (size_t)b * S * k;
     const int E = S * k;
-    for (int j = tid; j < N; j += nt) cnt[j] = 0;
+    for (int j = tid; j < nd; j += nt) cnt[j] = 0;
+    if (tid == 0) nbig = 0;
     __syncthreads();
-    for (int e = tid; e < E; e += nt) atomicAdd(&cnt[ib[e]], 1);
+    int below = 0;
+    for (int eb = tid; eb < E; eb += nt * 8) {           // 8 index loads in flight per thread (the atomics would serialise them)
+        int jv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) jv[u] = eb + u * nt < E ? ib[eb + u * nt] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = jv[u];
+            below += j >= 0 && j < d0;
+            if (j >= d0 && j < d1) atomicAdd(&cnt[j - d0], 1);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = below;
     __syncthreads();
-    // exclusive scan by one wave (N is a few thousand at most)
+#if defined(RV_PROBE) && RV_PROBE == 1
+    if (below == -12345) rev_off[0] = 1;
+    return;
+#endif
+    int s0 = 0;
+    for (int w = 0; w < (nt >> 6); ++w) s0 += wsum[w];   // edges into the slices before this one
+    // exclusive scan of the slice's counts by one wave
     if (tid < 64) {
-        int chunk = (N + 63) / 64;
-        int beg = tid * chunk, end = min(N, beg + chunk);
-        int s = 0;
-        for (int j = beg; j < end; ++j) s += cnt[j];
-        int incl = s;
+        const int chunk = (nd + 63) / 64;
+        const int beg = min(nd, tid * chunk), end = min(nd, beg + chunk);
+        int sm = 0;
+        for (int j = beg; j < end; ++j) sm += cnt[j];
+        int incl = sm;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            int t = __shfl_up(incl, o, 64);
+            const int t = __shfl_up(incl, o, 64);
             if (tid >= o) incl += t;
         }
-        int run = incl - s;
+        int run = incl - sm;
         for (int j = beg; j < end; ++j) { off[j] = run; run += cnt[j]; }
-        if (tid == 63) off[N] = incl;
+        if (tid == 63) off[nd] = incl;
     }
     __syncthreads();
     const int gbase = b * E;
-    for (int j = d0 + tid; j < d1; j += nt) rev_off[(size_t)b * N + j] = gbase + off[j];
-    for (int j = tid; j < N; j += nt) cnt[j] = 0;
+    for (int j = tid; j < nd; j += nt) { rev_off[(size_t)b * N + d0 + j] = gbase + s0 + off[j]; cnt[j] = 0; }
     if (b == B - 1 && part == RV_SPLIT - 1 && tid == 0) rev_off[(size_t)B * N] = gbase + E;
+    const int sn = off[nd];
     __syncthreads();
-    // fill + sort this slice's lists in LDS (ent), then one coalesced copy out: the sort never touches global memory
-    // (clouds whose N*k edge list does not fit next to the histogram sort in place in global memory instead)
-    const int s0 = off[d0], sn = off[d1] - s0;
-    int* ent = ent_in_lds ? off + N + 1          // [E] worst case: every edge of the cloud points into this slice
-                          : rev_ent + gbase + s0;
-    for (int e = tid; e < E; e += nt) {
-        int j = ib[e];
-        if (j >= d0 && j < d1) {
-            int pos = atomicAdd(&cnt[j], 1);
-            ent[off[j] - s0 + pos] = ((e / k) << 8) | (e % k);
+#if defined(RV_PROBE) && RV_PROBE == 2
+    return;
+#endif
+    // fill + order this slice's lists in LDS, then one coalesced copy out: the ordering never touches global memory
+    // (a slice with more than RV_CAP entries orders in place in global memory instead)
+    const bool in_lds = sn <= RV_CAP;
+    int* ent = in_lds ? lent : rev_ent + gbase + s0;
+    for (int eb = tid; eb < E; eb += nt * 8) {
+        int jv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) jv[u] = eb + u * nt < E ? ib[eb + u * nt] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = jv[u], e = eb + u * nt;
+            if (j >= d0 && j < d1) {
+                const int pos = atomicAdd(&cnt[j - d0], 1);
+                ent[off[j - d0] + pos] = ((e / k) << 8) | (e % k);
+            }
         }
     }
     __syncthreads();
-    if (ent_in_lds && rank_sort) {
-        // order every list by (i, slot): one thread per ENTRY ranks it inside its list.  In-degrees can be heavily skewed
-        // (ball-query groups are padded with copies of their first hit: a few points collect hundreds of edges), where a
-        // per-list insertion sort leaves one lane grinding through O(n^2) moves.
-        for (int i = tid; i < sn; i += nt) {
-            const int v = ent[i], target = s0 + i;
-            int lo = d0, hi = d1;                       // list j with off[j] <= target < off[j+1]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (off[mid] <= target) lo = mid; else hi = mid;
+#if defined(RV_PROBE) && RV_PROBE == 3
+    return;
+#endif
+    if (in_lds) {
+        // order every list by (i, slot) by RANK: 16 lanes per list, every lane ranks its entries against the whole list (the 16 lanes
+        // read the same LDS words: broadcasts) and writes them straight to their final place.  Lists of more than 64 entries
+        // (ball-query groups are padded with copies of their first hit: a few points collect hundreds of edges) are left to the
+        // second loop, where the whole workgroup shares one list.
+        int* out = lord;
+        const int lg = tid >> 4, ll = tid & 15;
+        for (int j = lg; j < nd; j += nt >> 4) {
+            const int e0 = off[j], n = off[j + 1] - e0;
+            if (n > 64) {
+                if (ll == 0) cnt[atomicAdd(&nbig, 1)] = j;
+                continue;
             }
-            const int e0 = off[lo] - s0, e1 = off[lo + 1] - s0;
-            int rank = 0;
-            for (int e = e0; e < e1; ++e) rank += (ent[e] < v);
-            rev_ent[gbase + s0 + e0 + rank] = v;
+            const int* a = ent + e0;
+            for (int q = ll; q < n; q += 16) {
+                const int v = a[q];
+                int rank = 0, e = 0;
+                for (; e + 4 <= n; e += 4) {
+                    const int a0 = a[e], a1 = a[e + 1], a2 = a[e + 2], a3 = a[e + 3];
+                    rank += (a0 < v) + (a1 < v) + (a2 < v) + (a3 < v);
+                }
+                for (; e < n; ++e) rank += a[e] < v;
+                out[e0 + rank] = v;
+            }
         }
+        __syncthreads();
+        for (int bi = 0; bi < nbig; ++bi) {
+            const int j = cnt[bi];
+            const int e0 = off[j], n = off[j + 1] - e0;
+            const int* a = ent + e0;
+            for (int q = tid; q < n; q += nt) {
+                const int v = a[q];
+                int rank = 0;
+                for (int e = 0; e < n; ++e) rank += a[e] < v;
+                out[e0 + rank] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < sn; i += nt) rev_ent[gbase + s0 + i] = lord[i];      // one coalesced copy out
         return;
     }
-    if (!ent_in_lds) __threadfence_block();
-    // per-destination insertion sort (kNN lists are ~k long: cheaper than ranking; also the in-place global-memory fallback)
-    for (int j = d0 + tid; j < d1; j += nt) {
-        int* a = ent + off[j] - s0;
-        int n = off[j + 1] - off[j];
+    __threadfence_block();
+    // a slice too large for LDS: per-destination insertion sort in place in global memory
+    for (int j = tid; j < nd; j += nt) {
+        int* a = ent + off[j];
+        const int n = off[j + 1] - off[j];
         for (int u = 1; u < n; ++u) {
-            int key = a[u];
+            const int key = a[u];
             int w = u - 1;
             while (w >= 0 && a[w] > key) { a[w + 1] = a[w]; --w; }
             a[w + 1] = key;
         }
     }
-    if (!ent_in_lds) return;
-    __syncthreads();
-    for (int i = tid; i < sn; i += nt) rev_ent[gbase + s0 + i] = ent[i];
 }
 
 static int launch_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent, int rank_sort) {
     if (!idx || !rev_off || !rev_ent || B <= 0 || N <= 0 || S <= 0 || k <= 0 || k > 256 || N > (1 << 22) || S > (1 << 22)) return MLSP_ERR_ARG;
-    size_t lds = (size_t)(2 * N + 1) * sizeof(int);
+    const int dper = (N + RV_SPLIT - 1) / RV_SPLIT;
+    const size_t lds = (size_t)(2 * dper + 1 + 2 * RV_CAP) * sizeof(int);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
-    const int ent_in_lds = lds + (size_t)S * k * sizeof(int) <= 150 * 1024;
-    if (ent_in_lds) lds += (size_t)S * k * sizeof(int);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)knn_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, ent_in_lds, S, rank_sort);
+    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, S, rank_sort);
     return mlsp_launch_status();
 }
 
