@@ -1046,7 +1046,7 @@ int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const 
     if (TP <= 0) return MLSP_ERR_UNSUPPORTED;
     const int ntiles = (P / N) * ((N + TP - 1) / TP);
     static const bool use_old = getenv("MLSP_TNET_BWD_OLD") != nullptr;       // A/B switch (tools/time_tnet.py): the round-1 kernel
-    if (!use_old && slope != 0.f) {
+    if (!use_old && slope > 0.f) {                             // the pre-activation is recovered from the activated value: needs a bijection
         const int nb = tnet_bwd_grid(ntiles);
         float* slabs = scratch;
         float* Mc = slabs + (size_t)nb * TG_SLAB;

@@ -557,7 +557,9 @@ def test_chamfer_edge_cases(dev):
 
 
 # ----------------------------------------------------------------------------- fused T-Net per-edge stage
-@pytest.mark.parametrize("B,N,k,training", [(2, 128, 20, True), (3, 50, 20, True), (1, 77, 7, True), (2, 64, 20, False)])
+@pytest.mark.parametrize("B,N,k,training", [(2, 128, 20, True), (3, 50, 20, True), (1, 77, 7, True), (2, 64, 20, False),
+                                            (2, 96, 24, True), (2, 80, 32, True), (2, 100, 40, True), (1, 130, 48, True),
+                                            (8, 70, 16, True)])
 def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
     """tnet.hip (LDS-resident gather + MFMA) against the reference's op sequence in torch on the CPU:
     graph feature -> conv 6->64 + BN + LReLU -> conv 64->128 + BN + LReLU -> max over k."""
@@ -587,8 +589,11 @@ def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
     leaves = [xp, W1, g1, b1, W2, g2, b2]
     gl = [t.detach().to(dev).requires_grad_(True) for t in leaves]
     rg = [t.to(dev) for t in rms]
-    graph = Fh.knn_graph(gl[0], B, N, k)
-    assert np.array_equal(graph.idx.view(B, N, k).cpu().numpy(), idx.numpy())
+    if k <= 40:
+        graph = Fh.knn_graph(gl[0], B, N, k)
+        assert np.array_equal(graph.idx.view(B, N, k).cpu().numpy(), idx.numpy())
+    else:                       # the kNN kernels stop at k = 40 for 3 channels; the fused stage itself takes any k <= 128
+        graph = Fh.graph_from_indices(idx.to(dev), B, N, k)
     og = Fh.tnet_edge(gl[0], graph, gl[1], gl[2], gl[3], rg[0], rg[1], gl[4], gl[5], gl[6], rg[2], rg[3], training)
     og.backward(dOut.to(dev))
     np.testing.assert_allclose(og.detach().cpu().numpy(), oc.detach().numpy(), rtol=3e-4, atol=3e-4)
