@@ -581,15 +581,21 @@ struct TnetBwdGLds {
     uint32_t aT[2][TN_MAXTP * TN_C2 / 4];   // their arg-max slots, 4 per word
 };
 
-__global__ void tnet_bwd_prep_kernel(const float* __restrict__ W2, const float* __restrict__ coef, const float* __restrict__ bn2,
-                                     float* __restrict__ Mc) {
-    const int c1 = blockIdx.x, c2 = threadIdx.x;
+__global__ __launch_bounds__(256) void tnet_bwd_prep_kernel(const float* __restrict__ W2, const float* __restrict__ coef,
+                                                            const float* __restrict__ bn2, float* __restrict__ Mc) {
+    __shared__ __attribute__((aligned(16))) float Ws[TN_C2 * TN_C1];
+    __shared__ float B2s[TN_C2], K2s[TN_C2];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < TN_C2 * TN_C1 / 4; e += 256) ((f32x4*)Ws)[e] = ((const f32x4*)W2)[e];
+    if (tid < TN_C2) { B2s[tid] = coef[TN_C2 + tid]; K2s[tid] = coef[tid] - coef[TN_C2 + tid] * bn2[2 * TN_C2 + tid]; }
+    __syncthreads();
+    const int c1 = blockIdx.x * 4 + (tid >> 6), c2 = tid & 63;     // 17 workgroups: rows 0..63 of M, row 64 = cv
     float acc = 0.f;
     if (c1 < TN_C1) {
-        for (int o = 0; o < TN_C2; ++o) acc = fmaf(W2[o * TN_C1 + c1] * coef[TN_C2 + o], W2[o * TN_C1 + c2], acc);
+        for (int o = 0; o < TN_C2; ++o) acc = fmaf(Ws[o * TN_C1 + c1] * B2s[o], Ws[o * TN_C1 + c2], acc);
         Mc[c1 * TN_C1 + c2] = acc;
-    } else {
-        for (int o = 0; o < TN_C2; ++o) acc = fmaf(coef[o] - coef[TN_C2 + o] * bn2[2 * TN_C2 + o], W2[o * TN_C1 + c2], acc);
+    } else if (c1 == TN_C1) {
+        for (int o = 0; o < TN_C2; ++o) acc = fmaf(K2s[o], Ws[o * TN_C1 + c2], acc);
         Mc[TN_C1 * TN_C1 + c2] = acc;
     }
 }
@@ -1051,7 +1057,7 @@ int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const 
         float* slabs = scratch;
         float* Mc = slabs + (size_t)nb * TG_SLAB;
         float* R = Mc + TN_C1 * TN_C1 + TN_C1;
-        hipLaunchKernelGGL(tnet_bwd_prep_kernel, dim3(TN_C1 + 1), dim3(TN_C1), 0, st, W2, coef, bn2, Mc);
+        hipLaunchKernelGGL(tnet_bwd_prep_kernel, dim3(TN_C1 / 4 + 1), dim3(256), 0, st, W2, coef, bn2, Mc);
         const size_t lds = sizeof(TnetBwdGLds);
         auto kern = k <= 20 ? tnet_edge_bwdg_kernel<false, 20> : k <= 24 ? tnet_edge_bwdg_kernel<false, 24> : k <= 32 ? tnet_edge_bwdg_kernel<false, 32> : tnet_edge_bwdg_kernel<true, 32>;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
