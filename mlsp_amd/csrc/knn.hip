@@ -1474,21 +1474,21 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 // For every point j: the list of (i, slot) with idx[i][slot] == j, sorted by i*256+slot so that the
 // backward gather-reduce that walks it sums in a fixed order (bitwise reproducible gradients).
 //   rev_off [B*N+1]  global edge offsets;  rev_ent [B*N*k]  packed (i_local << 8 | slot)
-#define RV_SPLIT 8
+#define RV_SPLIT_MAX 16                   // workgroups per cloud: 8, or 16 when 8 would leave CUs idle (chosen by the launcher)
 #define RV_CAP (16 * 1024)                // LDS entries of a slice's lists, twice: filled / ordered (a slice past that sorts in place in global memory)
-// RV_SPLIT workgroups per cloud, each owns a contiguous slice of the destinations: it counts only the edges that point into its
+// `nsplit` workgroups per cloud, each owns a contiguous slice of the destinations: it counts only the edges that point into its
 // slice (LDS atomics are the expensive instruction here: ~3 clocks per lane), gets the slice's base offset by counting the edges
 // that point BELOW it (plain adds + one block reduction), fills its lists and orders every list.
 __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict__ idx, int N, int k,
                                                            int* __restrict__ rev_off, int* __restrict__ rev_ent,
-                                                           int B, int S, int rank_sort) {
+                                                           int B, int S, int nsplit) {
     extern __shared__ int ism[];
     __shared__ int wsum[16];
     __shared__ int nbig;                  // lists of more than 64 entries: queued (cnt is free by then) for the whole-workgroup loop
     int b, part;
-    xcd_cloud_map(blockIdx.x, RV_SPLIT, B, b, part);      // the RV_SPLIT workgroups of a cloud share an XCD (they read the same idx)
+    xcd_cloud_map(blockIdx.x, nsplit, B, b, part);        // the workgroups of a cloud share an XCD (they read the same idx)
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int dper = (N + RV_SPLIT - 1) / RV_SPLIT, d0 = min(N, part * dper), d1 = min(N, d0 + dper), nd = d1 - d0;
+    const int dper = (N + nsplit - 1) / nsplit, d0 = min(N, part * dper), d1 = min(N, d0 + dper), nd = d1 - d0;
     int* cnt = ism;            // [dper]
     int* off = ism + dper;     // [dper + 1]  offsets inside the slice
     int* lent = off + dper + 1;   // [RV_CAP] as filled
@@ -1541,7 +1541,7 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     __syncthreads();
     const int gbase = b * E;
     for (int j = tid; j < nd; j += nt) { rev_off[(size_t)b * N + d0 + j] = gbase + s0 + off[j]; cnt[j] = 0; }
-    if (b == B - 1 && part == RV_SPLIT - 1 && tid == 0) rev_off[(size_t)B * N] = gbase + E;
+    if (b == B - 1 && part == nsplit - 1 && tid == 0) rev_off[(size_t)B * N] = gbase + E;
     const int sn = off[nd];
     __syncthreads();
 #if defined(RV_PROBE) && RV_PROBE == 2
@@ -1625,14 +1625,15 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
 
 static int launch_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent, int rank_sort) {
     if (!idx || !rev_off || !rev_ent || B <= 0 || N <= 0 || S <= 0 || k <= 0 || k > 256 || N > (1 << 22) || S > (1 << 22)) return MLSP_ERR_ARG;
-    const int dper = (N + RV_SPLIT - 1) / RV_SPLIT;
+    const int nsplit = B * 8 >= 256 || N < 1024 ? 8 : RV_SPLIT_MAX;
+    const int dper = (N + nsplit - 1) / nsplit;
     const size_t lds = (size_t)(2 * dper + 1 + 2 * RV_CAP) * sizeof(int);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)knn_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * RV_SPLIT), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, S, rank_sort);
+    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * nsplit), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, S, nsplit);
     return mlsp_launch_status();
 }
 
