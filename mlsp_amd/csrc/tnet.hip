@@ -611,14 +611,14 @@ __global__ void tnet_bwd_finish_kernel(const float* __restrict__ R, const float*
 }
 
 // Register-indexed FMAs (VGPR index mode, M0 = a wave-uniform index): two SALU + one VALU instruction per sparse entry.  The indexed
-// register block is pinned because the instruction text has to name its first register: v[224:255] (32 rows), or v[192:255] as two
-// 32-register operands (64 rows); the two uses (S rows / H' rows) never overlap.
+// register block is pinned because the instruction text has to name its first register: v[224:255] (32 rows), or v[216:255] as an
+// 8- and a 32-register operand (40 rows); the two uses (S rows / H' rows) never overlap.
 //   tg_fma_dst8: acc[slot_i - s0] += g_i * w_i        (destination and addend indexed)
 //   tg_fma_src8: c_i += g_i * rows[slot_i - s0]       (second factor indexed)
 // for the 8 entries whose slots are the bytes of (a0, a1); g_i are float bit patterns in SGPRs.
-// MODE 0: k <= 32, slot masked to [0, 32).  MODE 1: k <= 64, 64-row block, slot masked to [0, 64).  MODE 2 (k > 64): 32-slot ranges,
+// MODE 0: k <= 32, slot masked to [0, 32).  MODE 1: k <= 40 (configs[4]), 40-row block, slot clamped to [0, 40).  MODE 2 (k > 40): 32-slot ranges,
 // entries whose slot lies outside [s0, s0 + 32) add an exact zero.
-template <int MODE> __device__ __forceinline__ void tg_fma_dst8(f32x32& lo, f32x32& hi, uint32_t a0, uint32_t a1, const uint32_t (&g)[8], int s0,
+template <int MODE> __device__ __forceinline__ void tg_fma_dst8(f32x8& lo, f32x32& hi, uint32_t a0, uint32_t a1, const uint32_t (&g)[8], int s0,
                                                               const float* w) {
     uint32_t t, u;
     if (MODE == 2) {
@@ -638,16 +638,16 @@ template <int MODE> __device__ __forceinline__ void tg_fma_dst8(f32x32& lo, f32x
             : "scc");
     } else if (MODE == 1) {
         asm volatile(
-            "s_and_b32 %[t], %[a0], 63\n\ts_set_gpr_idx_on %[t], gpr_idx(SRC2,DST)\n\ts_nop 0\n\tv_fma_f32 v192, %[g0], %[w0], v192\n\t"
-            "s_bfe_u32 %[t], %[a0], 0x60008\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v192, %[g1], %[w1], v192\n\t"
-            "s_bfe_u32 %[t], %[a0], 0x60010\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v192, %[g2], %[w2], v192\n\t"
-            "s_bfe_u32 %[t], %[a0], 0x60018\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v192, %[g3], %[w3], v192\n\t"
-            "s_and_b32 %[t], %[a1], 63\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v192, %[g4], %[w4], v192\n\t"
-            "s_bfe_u32 %[t], %[a1], 0x60008\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v192, %[g5], %[w5], v192\n\t"
-            "s_bfe_u32 %[t], %[a1], 0x60010\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v192, %[g6], %[w6], v192\n\t"
-            "s_bfe_u32 %[t], %[a1], 0x60018\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v192, %[g7], %[w7], v192\n\t"
+            "s_and_b32 %[t], %[a0], 63\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_on %[t], gpr_idx(SRC2,DST)\n\ts_nop 0\n\tv_fma_f32 v216, %[g0], %[w0], v216\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x60008\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v216, %[g1], %[w1], v216\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x60010\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v216, %[g2], %[w2], v216\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x60018\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v216, %[g3], %[w3], v216\n\t"
+            "s_and_b32 %[t], %[a1], 63\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v216, %[g4], %[w4], v216\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x60008\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v216, %[g5], %[w5], v216\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x60010\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v216, %[g6], %[w6], v216\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x60018\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 v216, %[g7], %[w7], v216\n\t"
             "s_set_gpr_idx_off"
-            : "+{v[192:223]}"(lo), "+{v[224:255]}"(hi), [t] "=&s"(t)
+            : "+{v[216:223]}"(lo), "+{v[224:255]}"(hi), [t] "=&s"(t)
             : [a0] "s"(a0), [a1] "s"(a1), [g0] "s"(g[0]), [g1] "s"(g[1]), [g2] "s"(g[2]), [g3] "s"(g[3]), [g4] "s"(g[4]), [g5] "s"(g[5]), [g6] "s"(g[6]), [g7] "s"(g[7]),
               [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]), [w7] "v"(w[7])
             : "scc");
@@ -668,7 +668,7 @@ template <int MODE> __device__ __forceinline__ void tg_fma_dst8(f32x32& lo, f32x
             : "scc");
     }
 }
-template <int MODE> __device__ __forceinline__ void tg_fma_src8(float* c, const f32x32& lo, const f32x32& hi, uint32_t a0, uint32_t a1,
+template <int MODE> __device__ __forceinline__ void tg_fma_src8(float* c, const f32x8& lo, const f32x32& hi, uint32_t a0, uint32_t a1,
                                                               const uint32_t (&g)[8], int s0) {
     uint32_t t, u;
     if (MODE == 2) {
@@ -687,17 +687,17 @@ template <int MODE> __device__ __forceinline__ void tg_fma_src8(float* c, const 
             : "scc");
     } else if (MODE == 1) {
         asm volatile(
-            "s_and_b32 %[t], %[a0], 63\n\ts_set_gpr_idx_on %[t], gpr_idx(SRC1)\n\ts_nop 0\n\tv_fma_f32 %[c0], %[g0], v192, %[c0]\n\t"
-            "s_bfe_u32 %[t], %[a0], 0x60008\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c1], %[g1], v192, %[c1]\n\t"
-            "s_bfe_u32 %[t], %[a0], 0x60010\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c2], %[g2], v192, %[c2]\n\t"
-            "s_bfe_u32 %[t], %[a0], 0x60018\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c3], %[g3], v192, %[c3]\n\t"
-            "s_and_b32 %[t], %[a1], 63\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c4], %[g4], v192, %[c4]\n\t"
-            "s_bfe_u32 %[t], %[a1], 0x60008\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c5], %[g5], v192, %[c5]\n\t"
-            "s_bfe_u32 %[t], %[a1], 0x60010\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c6], %[g6], v192, %[c6]\n\t"
-            "s_bfe_u32 %[t], %[a1], 0x60018\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c7], %[g7], v192, %[c7]\n\t"
+            "s_and_b32 %[t], %[a0], 63\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_on %[t], gpr_idx(SRC1)\n\ts_nop 0\n\tv_fma_f32 %[c0], %[g0], v216, %[c0]\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x60008\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c1], %[g1], v216, %[c1]\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x60010\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c2], %[g2], v216, %[c2]\n\t"
+            "s_bfe_u32 %[t], %[a0], 0x60018\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c3], %[g3], v216, %[c3]\n\t"
+            "s_and_b32 %[t], %[a1], 63\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c4], %[g4], v216, %[c4]\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x60008\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c5], %[g5], v216, %[c5]\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x60010\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c6], %[g6], v216, %[c6]\n\t"
+            "s_bfe_u32 %[t], %[a1], 0x60018\n\ts_min_u32 %[t], %[t], 39\n\ts_set_gpr_idx_idx %[t]\n\ts_nop 0\n\tv_fma_f32 %[c7], %[g7], v216, %[c7]\n\t"
             "s_set_gpr_idx_off"
             : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [t] "=&s"(t)
-            : "{v[192:223]}"(lo), "{v[224:255]}"(hi), [a0] "s"(a0), [a1] "s"(a1), [g0] "s"(g[0]), [g1] "s"(g[1]), [g2] "s"(g[2]), [g3] "s"(g[3]), [g4] "s"(g[4]), [g5] "s"(g[5]), [g6] "s"(g[6]), [g7] "s"(g[7])
+            : "{v[216:223]}"(lo), "{v[224:255]}"(hi), [a0] "s"(a0), [a1] "s"(a1), [g0] "s"(g[0]), [g1] "s"(g[1]), [g2] "s"(g[2]), [g3] "s"(g[3]), [g4] "s"(g[4]), [g5] "s"(g[5]), [g6] "s"(g[6]), [g7] "s"(g[7])
             : "scc");
     } else {
         asm volatile(
@@ -742,8 +742,8 @@ template <int MODE, int KR> __global__ __launch_bounds__(512) void tnet_edge_bwd
     for (int r = 0; r < 16; ++r) { accG[r] = 0.f; accO[r] = 0.f; }
     double sd = 0.0, sdh = 0.0, shs = 0.0;
     const int Bc = P / N;
-    constexpr int NB = MODE == 1 ? 64 : 32;                    // rows of the indexed register block
-    const int nsw = MODE == 2 ? (k + 31) >> 5 : 1;             // 32-slot ranges per point (MODE 2 only: k > 64)
+    constexpr int NB = MODE == 1 ? 40 : 32;                    // rows of the indexed register block
+    const int nsw = MODE == 2 ? (k + 31) >> 5 : 1;             // 32-slot ranges per point (MODE 2 only: k > 40)
     const float rslope = 1.0f / slope;
 
     auto row_index = [&](int pt0_, int npts_) -> int {        // uv row of this thread's neighbour, -1 = padding row
@@ -840,9 +840,12 @@ template <int MODE, int KR> __global__ __launch_bounds__(512) void tnet_edge_bwd
                     const int gv0 = __float_as_int(gt[spt * TN_C2 + lane]), gv1 = __float_as_int(gt[spt * TN_C2 + 64 + lane]);
                     const uint32_t av = at[spt * (TN_C2 / 4) + l31];
                     const float* wb = L.Ws + lane;
-                    f32x32 acc, acc2;                                 // acc2: rows 0..31 of the 64-row block (MODE 1), acc: the last 32
+                    f32x32 acc;
+                    f32x8 acc2;                                       // rows 0..7 of the 40-row block (MODE 1); acc: the last 32
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+                    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc2[i] = 0.f;
                     float w[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) w[i] = wb[i * TN_C1];
@@ -868,7 +871,7 @@ template <int MODE, int KR> __global__ __launch_bounds__(512) void tnet_edge_bwd
                     float* sb = L.Ss + (spt * k + s0) * TN_C1 + lane;
 #pragma unroll
                     for (int i = 0; i < NB; ++i)
-                        if (s0 + i < k) sb[i * TN_C1] = MODE == 1 ? (i < 32 ? acc2[i & 31] : acc[i & 31]) : acc[i & 31];
+                        if (s0 + i < k) sb[i * TN_C1] = MODE == 1 ? (i < 8 ? acc2[i & 7] : acc[(i - 8) & 31]) : acc[i & 31];
                 }
 #endif
                 // ---- G1[16 wave + i][lane] += g[pt][o] H'[row(pt, arg)][lane]: KR (>= k, or 32 when RANGED) of the point's H' rows are
@@ -888,15 +891,14 @@ template <int MODE, int KR> __global__ __launch_bounds__(512) void tnet_edge_bwd
                     for (int rg = 0; rg < nsw; ++rg) {
                         const int s0 = 32 * rg;
                         const float* hr = Hc + (pt * k + s0) * TG_HP + lane;
-                        f32x32 rows, rows2;                           // rows2: rows 0..31 of the 64-row block (MODE 1), rows: the last 32
+                        f32x32 rows;
+                        f32x8 rows2;                                  // rows 0..7 of the 40-row block (MODE 1); rows: the last 32
 #pragma unroll
-                        for (int sl = 0; sl < NB; ++sl) {
-                            const float hv = sl < KR ? hr[sl * TG_HP] : 0.f;
-                            if (MODE == 1 && sl < 32) rows2[sl & 31] = hv; else rows[sl & 31] = hv;
-                        }
-                        if (MODE != 1) {
+                        for (int sl = 0; sl < 8; ++sl) rows2[sl] = MODE == 1 ? hr[sl * TG_HP] : 0.f;
 #pragma unroll
-                            for (int sl = 0; sl < 32; ++sl) rows2[sl] = 0.f;
+                        for (int sl = 0; sl < 32; ++sl) {
+                            const int r = MODE == 1 ? sl + 8 : sl;
+                            rows[sl] = r < KR ? hr[r * TG_HP] : 0.f;
                         }
                         tg_fma_src8<MODE>(accO, rows2, rows, ae[0], ae[1], (const uint32_t(&)[8])ge[0], s0);
                         tg_fma_src8<MODE>(accO + 8, rows2, rows, ae[2], ae[3], (const uint32_t(&)[8])ge[8], s0);
@@ -1097,7 +1099,7 @@ int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const 
         hipLaunchKernelGGL(tnet_bwd_prep_kernel, dim3(TN_C1 / 4 + 1), dim3(256), 0, st, W2, coef, bn2, Mc);
         const size_t lds = sizeof(TnetBwdGLds);
         auto kern = k <= 20 ? tnet_edge_bwdg_kernel<0, 20> : k <= 24 ? tnet_edge_bwdg_kernel<0, 24> : k <= 32 ? tnet_edge_bwdg_kernel<0, 32>
-                  : k <= 40 ? tnet_edge_bwdg_kernel<1, 40> : k <= 64 ? tnet_edge_bwdg_kernel<1, 64> : tnet_edge_bwdg_kernel<2, 32>;
+                  : k <= 40 ? tnet_edge_bwdg_kernel<1, 40> : tnet_edge_bwdg_kernel<2, 32>;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, st, uv, idx, bn1, W2, Mc, g, argsel, dhp, slabs, part1, P, N, k, TP, slope);
