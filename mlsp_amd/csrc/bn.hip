@@ -37,6 +37,32 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     }
 }
 
+// Column c of the partial planes [nparts][2][C] summed by a 256-thread workgroup: every thread strides over the partial rows with four
+// loads of each plane in flight (one wave per channel left 8+ dependent round trips on the critical path of every BN layer), then a
+// fixed-order butterfly inside the wave and a fixed-order sum of the four waves -> reproducible.  Result valid in thread 0.
+#define FIN_THREADS 256
+__device__ __forceinline__ void fin_part_sums(const double* __restrict__ part, int nparts, int C, int c, double& s, double& q) {
+    __shared__ double fred[2][FIN_THREADS / 64];
+    const int tid = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    int i = tid;
+    for (; i + 3 * FIN_THREADS < nparts; i += 4 * FIN_THREADS) {
+        const double a0 = part[((size_t)i * 2) * C + c], b0 = part[((size_t)i * 2 + 1) * C + c];
+        const double a1 = part[((size_t)(i + FIN_THREADS) * 2) * C + c], b1 = part[((size_t)(i + FIN_THREADS) * 2 + 1) * C + c];
+        const double a2 = part[((size_t)(i + 2 * FIN_THREADS) * 2) * C + c], b2 = part[((size_t)(i + 2 * FIN_THREADS) * 2 + 1) * C + c];
+        const double a3 = part[((size_t)(i + 3 * FIN_THREADS) * 2) * C + c], b3 = part[((size_t)(i + 3 * FIN_THREADS) * 2 + 1) * C + c];
+        s0 += a0; s1 += a1; s2 += a2; s3 += a3; q0 += b0; q1 += b1; q2 += b2; q3 += b3;
+    }
+    for (; i < nparts; i += FIN_THREADS) { s0 += part[((size_t)i * 2) * C + c]; q0 += part[((size_t)i * 2 + 1) * C + c]; }
+    s = (s0 + s1) + (s2 + s3); q = (q0 + q1) + (q2 + q3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if ((tid & 63) == 0) { fred[0][tid >> 6] = s; fred[1][tid >> 6] = q; }
+    __syncthreads();
+    s = (fred[0][0] + fred[0][1]) + (fred[0][2] + fred[0][3]);
+    q = (fred[1][0] + fred[1][1]) + (fred[1][2] + fred[1][3]);
+}
+
 // partials -> mean / biased var -> scale, shift, saved stats, running-stat update (torch semantics:
 // running_var uses the unbiased estimate, momentum 0.1; model_utils.py:56-58 defaults)
 __global__ void bn_finalize_kernel(const double* __restrict__ part, int nparts, double count, int C,
@@ -44,12 +70,9 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int nparts, 
                                    float* __restrict__ run_mean, float* __restrict__ run_var, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd) {
-    // one wave per channel: lanes stride over the partial blocks, fixed-order butterfly -> reproducible
     const int c = blockIdx.x;
-    double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 64) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    double s, q;
+    fin_part_sums(part, nparts, C, c, s, q);
     if (threadIdx.x != 0) return;
     double mean = s / count;
     double var = q / count - mean * mean;
@@ -141,10 +164,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int npar
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ mean_dz, float* __restrict__ mean_dzy) {
     const int c = blockIdx.x;
-    double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 64) { s += part[((size_t)i * 2) * C + c]; q += part[((size_t)i * 2 + 1) * C + c]; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    double s, q;
+    fin_part_sums(part, nparts, C, c, s, q);
     if (threadIdx.x != 0) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
@@ -438,7 +459,7 @@ int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double
 int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
                        float* shift, float* save_mean, float* save_invstd) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, count, C, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, gamma, beta,
                        run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
     return mlsp_launch_status();
 }
@@ -481,7 +502,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift,
                            mean, invstd, act, slope, th, inv_keep, seed, part);
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, (double)M, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma,
                        dbeta, mean_dz, mean_dzy);
     size_t total = (size_t)M * C;
     if (vec) {
@@ -497,7 +518,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
 
 int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
                            float* mean_dz, float* mean_dzy) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, count, C, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, dgamma, dbeta,
                        mean_dz, mean_dzy);
     return mlsp_launch_status();
 }
@@ -632,7 +653,7 @@ int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* d
     const int nparts = bn_vec_parts(M);
     hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, M, C, scale,
                        shift, mean, invstd, act, slope, th, inv_keep, seed, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy);
     hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, (__bf16*)dY,
                        M, C, scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed);
     return mlsp_launch_status();
