@@ -15,7 +15,8 @@
  *     entry points keep no mutable state of their own; the library has exactly two process-wide
  *     switches, both off by default and both set from the host thread that owns the training loop:
  *     mlsp_set_gemm_precision (operand rounding of the GEMM family) and mlsp_profile_begin/_end
- *     (HIP events around the GEMM launches).  Neither is touched by any compute call.
+ *     (HIP events around the GEMM launches).  Neither is touched by any compute call.  One environment variable is read once per
+ *     process: MLSP_TNET_BWD_OLD=1 selects the round-1 T-Net backward kernel (A/B measurements, tools/time_tnet.py).
  *   - activations are POINT-major fp32 row matrices: [rows][C] with rows = B*N points (or
  *     B*N*k edges), channels contiguous.  The reference itself moves to this layout before its
  *     gather (model_utils.py:35).  Indices are int32, local to their cloud (0..N-1).
