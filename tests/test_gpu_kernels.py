@@ -606,6 +606,18 @@ def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
             np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,N,k", [(8, 512, 20), (4, 512, 40)])
+def test_tnet_backward_gram_form_vs_round1_kernel(dev, B, N, k):
+    """Two independent backward kernels of the fused stage: the Gram form (dZ never formed, register-indexed sparse part) and the
+    round-1 kernel (three MFMA products on the dZ tile, MLSP_TNET_BWD_OLD=1; read once per process, hence the subprocesses)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cmp_tnet_bwd", os.path.join(os.path.dirname(__file__), "..", "tools", "cmp_tnet_bwd.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name, err in mod.compare(B, N, k).items():
+        assert err < 1e-4, (name, err)
+
+
 # ----------------------------------------------------------------------------- conv + BN + act + max over N (Gram backward)
 @pytest.mark.parametrize("B,N,Cin,Cout,training", [(4, 100, 64, 96, True), (3, 128, 128, 256, True), (2, 64, 512, 1024, True),
                                                    (3, 50, 40, 70, False)])
