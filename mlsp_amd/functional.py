@@ -117,6 +117,19 @@ class forced_graphs:
         return False
 
 
+_identity_rows = {}
+
+
+def identity_row(K, device, dtype=torch.float32):
+    """flattened K x K identity [1, K*K] on `device`, built once per (K, device, dtype): the T-Nets add it to their output every
+    forward (PointDA/model_utils.py:122-125 builds it with torch.eye each time: three launches)"""
+    key = (K, device, dtype)
+    t = _identity_rows.get(key)
+    if t is None:
+        t = _identity_rows[key] = torch.eye(K, device=device, dtype=dtype).view(1, K * K)
+    return t
+
+
 def knn_graph(xp, B, N, k, need_reverse=True):
     """xp [B*N, C] point-major (detached use only: indices are not differentiable,
     PointDA/model_utils.py:15).  Returns KnnGraph with int32 idx [B*N, k] (local indices)."""

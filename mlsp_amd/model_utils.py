@@ -237,7 +237,7 @@ class transform_net(nn.Module):
         h = self.fc1(h)
         h = self.fc2(h)
         h = Fh.pointmlp(h, self.fc3.weight, bias=self.fc3.bias, training=self.training)
-        iden = torch.eye(self.K, device=h.device, dtype=h.dtype).view(1, self.K * self.K)
+        iden = Fh.identity_row(self.K, h.device, h.dtype)
         return (h + iden).view(B, self.K, self.K)
 
     @flushing_forward

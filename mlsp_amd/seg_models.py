@@ -135,7 +135,7 @@ class transform_net(nn.Module):
                                act=Fh.ACT_LRELU, slope=0.2, eps=0.0)
         h = self.fc2(self.fc1(h))
         h = Fh.pointmlp(h, self.fc3.weight, bias=self.fc3.bias, training=self.training)
-        iden = torch.eye(self.K, device=h.device, dtype=h.dtype).view(1, self.K * self.K)
+        iden = Fh.identity_row(self.K, h.device, h.dtype)
         return (h + iden).view(B, self.K, self.K)
 
     @flushing_forward
@@ -146,7 +146,7 @@ class transform_net(nn.Module):
         h = Fh.colmax(self.conv2d3.rows(Fh.segmax(h, k)), B, N)
         h = self.fc2(self.fc1(h))
         h = Fh.pointmlp(h, self.fc3.weight, bias=self.fc3.bias, training=self.training)
-        iden = torch.eye(self.K, device=h.device, dtype=h.dtype).view(1, self.K * self.K)
+        iden = Fh.identity_row(self.K, h.device, h.dtype)
         return (h + iden).view(B, self.K, self.K)
 
 
