@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 2
+#define MLSP_ABI_VERSION 3
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -102,11 +102,28 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
  * Y = pre-BN (saved), Z = output.  gamma == NULL: no BN (Y is not written, Z = act(linear)).
  * Backward: dx_accumulate != 0 adds the input gradient to what dX already holds (beta = 1 in the dgrad epilogue): the four consumers
  * of the concatenated encoder features (conv5 and the three heads, Models.py:132,156-160) sum their gradients in one buffer instead of
- * three 67 MB element-wise adds. */
+ * three 67 MB element-wise adds.
+ * Chained layers (the output of one Linear+BN+act layer feeds exactly one other such layer: conv1 -> conv2 -> conv3 of the heads,
+ * Models.py:192-196): the producer is called with Z == NULL (only Y, the pre-BN output, and bn_save are written: the streaming
+ * BN+act pass is skipped), the consumer through mlsp_pointmlp_fwd_chain_f32 / mlsp_pointmlp_bwd_chain_f32 with Xpre = the producer's
+ * Y [M][Cin], in_bn_save = its bn_save [4][Cin] and its act / slope / dropout (p already 0 in eval mode) / seed: act(Xpre * scale +
+ * shift) and the dropout mask are applied while the GEMM stages the operand (forward: A rows; wgrad: the k-major B operand), or by one
+ * streaming pass into the workspace for shapes outside the interior-tile path.  The gradients the consumer returns in dX are with
+ * respect to the ACTIVATED input, i.e. exactly the dZ the producer's mlsp_pointmlp_bwd_f32 expects. */
 int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                           const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                           float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
                           uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope, float in_p_drop,
+                                uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                                const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
+                                float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
+                                uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope,
+                                float in_p_drop, uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+                                const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
+                                int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
+                                float* dgbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                           const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                           int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,

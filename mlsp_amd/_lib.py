@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLSP_HIP_LIB") or os.path.join(_HERE, "libmlsp_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c = ctypes
 _P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
@@ -37,6 +37,10 @@ SIGNATURES = {
                               _P, _P, _P, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
                               _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_pointmlp_fwd_chain_f32": [_P, _I, _P, _I, _F, _F, _U64, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
+                                    _P, _P, _P, _P, _SZ, _P],
+    "mlsp_pointmlp_bwd_chain_f32": [_P, _P, _I, _P, _I, _F, _F, _U64, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
+                                    _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_pointmlp_mx_supported": [_I, _I, _I, _I, _I, _I],
     "mlsp_pointmlp_fwd_mx": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
                              _P, _P, _I, _P, _P, _SZ, _P],

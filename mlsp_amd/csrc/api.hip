@@ -8,7 +8,8 @@
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
                 double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr, int* sel_row = nullptr,
-                bool accumulate = false);
+                bool accumulate = false, const GemmXf* xf = nullptr);
+bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which);
 int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A, int a_bf16, int lda, const void* B, int b_bf16,
                    int ldb, void* C, int c_bf16, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                    size_t slab_floats, double* stat_part, bool accumulate);
@@ -167,7 +168,8 @@ const char* mlsp_strerror(int code) {
 
 size_t mlsp_workspace_bytes(int rows, int cin, int cout) {
     size_t r = rows > 0 ? rows : 1, ci = cin > 0 ? cin : 1, co = cout > 0 ? cout : 1;
-    size_t act = 3 * r * co * sizeof(float) + r * sizeof(float);            // gz + duv (edgeconv bwd) / dY (mlp bwd) / xx
+    size_t act = 3 * r * co * sizeof(float) + r * sizeof(float)             // gz + duv (edgeconv bwd) / dY (mlp bwd) / xx
+               + r * ci * sizeof(float);                                    // a chained layer's activated input, shapes outside the fused path
     size_t parts = (r / 64 + 2) * 2 * co * sizeof(double);                  // stat partials
     size_t wts = 4 * co * ci * sizeof(float) * 2 + 8 * co * sizeof(float);  // Wd, dWd, coefficient vectors
     return act + parts + wts + SLAB_BOUND_FLOATS * sizeof(float) + (32 << 20);       // + fixed-size per-workgroup partial slabs
@@ -423,15 +425,27 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
     return MLSP_OK;
 }
 
-int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
-                          const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
-                          float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
-                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
-    if (!X || !W || !Z || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
+// The input of a chained layer: X holds the PRE-BatchNorm output of the previous layer; its BN scale / shift, activation and dropout
+// are applied while the GEMM stages the operand (GemmXf), or by one streaming pass into the workspace when the shape is not covered.
+struct ChainIn { const float* bn_save; int act; float slope; float p_drop; uint64_t seed; };
+static GemmXf chain_xf(const ChainIn& in, int Cin, int which) {
+    GemmXf x;
+    x.scale = in.bn_save; x.shift = in.bn_save + Cin; x.act = in.act; x.slope = in.slope; x.thresh = dropout_thresh8(in.p_drop);
+    x.inv_keep = dropout_inv_keep8(in.p_drop); x.seed = in.seed; x.ld = Cin; x.which = which;
+    return x;
+}
+
+static int pointmlp_fwd_impl(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                             const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
+                             float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
+                             uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st,
+                             const ChainIn* in) {
+    if (!X || !W || (!Z && !gamma) || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
     if (gamma && (!beta || !Y || !bn_save)) return MLSP_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
+    if (in && (!in->bn_save || in->p_drop < 0.f || in->p_drop >= 1.f)) return MLSP_ERR_ARG;
     // per-cloud layers (batch <= 32 rows): Linear + BatchNorm1d + activation + dropout in ONE kernel (skinny.hip)
-    if (gamma && !gbias && M <= 32)
+    if (gamma && !gbias && M <= 32 && !in && Z)
         return launch_skinny_linear_bn_act(st, X, ldx, M, Cin, W, ldw, Cout, bias, gamma, beta, run_mean, run_var, momentum, eps,
                                            training, act, slope, p_drop, seed, Y, Z, bn_save);
     Workspace w(ws, ws_bytes);
@@ -441,15 +455,27 @@ int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* 
     double* part = gamma ? w.take<double>((size_t)nparts * 2 * Cout) : nullptr;
     size_t sf = gemm_slab_floats(M, Cout, Cin);
     float* slab = sf ? w.take<float>(sf) : nullptr;
+    GemmXf xf_s; const GemmXf* xf = nullptr;
+    if (in) {
+        if (gemm_xf_supported(false, true, M, Cout, Cin, X, ldx, W, ldw, 1)) { xf_s = chain_xf(*in, Cin, 1); xf = &xf_s; }
+        else {                                             // shape outside the fused path: materialise the activated input once
+            if (ldx != Cin) return MLSP_ERR_UNSUPPORTED;
+            float* Xa = w.take<float>((size_t)M * Cin);
+            if (!w.ok()) return MLSP_ERR_WORKSPACE;
+            CHECK(launch_bn_act_fwd(st, X, Xa, (size_t)M, Cin, in->bn_save, in->bn_save + Cin, in->act, in->slope, in->p_drop, in->seed));
+            X = Xa;
+        }
+    }
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     if (!gamma) {
         // plain Linear: the GEMM writes Z directly.  Every activated layer of the hot path has a BN.
         if (act || p_drop > 0.f) return MLSP_ERR_UNSUPPORTED;
-        return launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Z, Cout, bias, gbias, rows_per_group, slab, sf);
+        return launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Z, Cout, bias, gbias, rows_per_group, slab, sf, nullptr, nullptr,
+                           nullptr, nullptr, false, xf);
     }
     float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
     CHECK(launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Y, Cout, bias, gbias, rows_per_group, slab, sf,
-                      fused_parts ? part : nullptr));
+                      fused_parts ? part : nullptr, nullptr, nullptr, nullptr, false, xf));
     if (training) {
         if (!fused_parts) CHECK(launch_colstats(st, Y, M, Cout, Cout, part));
         CHECK(launch_bn_finalize(st, part, nparts, (double)M, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale, shift,
@@ -458,14 +484,33 @@ int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* 
         if (!run_mean || !run_var) return MLSP_ERR_ARG;
         CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
     }
-    CHECK(launch_bn_act_fwd(st, Y, Z, (size_t)M, Cout, scale, shift, act, slope, training ? p_drop : 0.f, seed));
+    // Z == NULL: the activation is deferred to the consumer (mlsp_pointmlp_*_chain_f32 apply it in their operand loads)
+    if (Z) CHECK(launch_bn_act_fwd(st, Y, Z, (size_t)M, Cout, scale, shift, act, slope, training ? p_drop : 0.f, seed));
     return MLSP_OK;
 }
 
-int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
-                          const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
-                          int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
-                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                          const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
+                          float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
+                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    return pointmlp_fwd_impl(X, ldx, M, Cin, W, ldw, Cout, bias, gbias, rows_per_group, gamma, beta, run_mean, run_var, momentum, eps,
+                             training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, nullptr);
+}
+
+int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope, float in_p_drop,
+                                uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                                const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
+                                float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
+                                uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    const ChainIn in = {in_bn_save, in_act, in_slope, in_p_drop, in_seed};
+    return pointmlp_fwd_impl(Xpre, ldx, M, Cin, W, ldw, Cout, bias, gbias, rows_per_group, gamma, beta, run_mean, run_var, momentum, eps,
+                             training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, &in);
+}
+
+static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+                             const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
+                             int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
+                             float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st, const ChainIn* in) {
     if (!dZ || !X || !W || !dW || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
     if (has_bn && (!Y || !bn_save || !dgamma || !dbeta)) return MLSP_ERR_ARG;
     if (dgbias && (n_groups <= 0 || rows_per_group <= 0 || (long)n_groups * rows_per_group != M)) return MLSP_ERR_ARG;
@@ -479,6 +524,18 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
     size_t sf = sf1 > sf2 ? sf1 : sf2;
     float* slab = sf ? w.take<float>(sf) : nullptr;
     float* gscratch = dgbias ? w.take<float>((size_t)n_groups * 16 * Cout) : nullptr;
+    GemmXf xf_s; const GemmXf* xf = nullptr;            // chained input: the wgrad reads the previous layer's pre-BN output
+    if (in) {
+        if (!in->bn_save || M <= 32) return MLSP_ERR_ARG;
+        if (gemm_xf_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx, 2)) { xf_s = chain_xf(*in, Cin, 2); xf = &xf_s; }
+        else {
+            if (ldx != Cin) return MLSP_ERR_UNSUPPORTED;
+            float* Xa = w.take<float>((size_t)M * Cin);
+            if (!w.ok()) return MLSP_ERR_WORKSPACE;
+            CHECK(launch_bn_act_fwd(st, X, Xa, (size_t)M, Cin, in->bn_save, in->bn_save + Cin, in->act, in->slope, in->p_drop, in->seed));
+            X = Xa;
+        }
+    }
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float* g = dZ;   // gradient wrt the linear output
     if (has_bn && M <= 32) {
@@ -492,7 +549,8 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
     }
     if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf, nullptr, nullptr,
                               nullptr, nullptr, dx_accumulate != 0));
-    CHECK(launch_gemm(st, true, false, Cout, Cin, M, g, Cout, X, ldx, dW, Cin, nullptr, nullptr, 0, slab, sf));
+    CHECK(launch_gemm(st, true, false, Cout, Cin, M, g, Cout, X, ldx, dW, Cin, nullptr, nullptr, 0, slab, sf, nullptr, nullptr, nullptr,
+                      nullptr, false, xf));
     if (dbias) {
         if (has_bn && training) {
             // a bias in front of a batch-stat BN has an analytically zero gradient (sum_rows dY == 0)
@@ -504,6 +562,24 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
     }
     if (dgbias) CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias, gscratch));
     return MLSP_OK;
+}
+
+int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+                          const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
+                          int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
+                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    return pointmlp_bwd_impl(dZ, X, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
+                             rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, nullptr);
+}
+
+int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope,
+                                float in_p_drop, uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+                                const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
+                                int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
+                                float* dgbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    const ChainIn in = {in_bn_save, in_act, in_slope, in_p_drop, in_seed};
+    return pointmlp_bwd_impl(dZ, Xpre, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
+                             rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, &in);
 }
 
 // ---- bf16 activation storage (BASELINE.json configs[4]) ---------------------------------------------------------------------------

@@ -105,7 +105,7 @@ __global__ void bn_eval_prepare_kernel(int C, const float* __restrict__ gamma, c
     save_invstd[c] = invstd;
 }
 
-// Z = dropout(act(Y*scale + shift)).  thresh = p * 2^32, inv_keep = 1/(1-p)
+// Z = dropout(act(Y*scale + shift)).  thresh = round(256 p), inv_keep = 256 / (256 - thresh)  (common.h)
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Y, float* __restrict__ Z, size_t total,
                                                          int C, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int act, float slope,
@@ -295,10 +295,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const TY* __restric
         const size_t i = (size_t)r * C + c;
         const f32x4 y = ld4<TY>(Y + i);
         f32x4 o;
+        const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;      // i is a multiple of 4: one hash for the quad
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a = lrelu_or_relu(fmaf(y[e], sc[e], sh[e]), act, slope);
-            if (thresh) a = dropout_keep(seed, i + e, thresh) ? a * inv_keep : 0.f;
+            if (thresh) a = ((hq >> (8 * e)) & 255u) >= thresh ? a * inv_keep : 0.f;
             o[e] = a;
         }
         st4<TY>(Z + i, o);
@@ -429,11 +430,7 @@ static inline int ew_blocks(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b < 4096 ? (b ? b : 1) : 4096);
 }
-static inline uint32_t drop_thresh(float p) {
-    if (p <= 0.f) return 0u;
-    double t = (double)p * 4294967296.0;
-    return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
-}
+static inline uint32_t drop_thresh(float p) { return dropout_thresh8(p); }
 
 int bn_stat_parts(int M) { return (M + STAT_ROWS - 1) / STAT_ROWS; }
 // upper bound on the partial rows any BN reduction over M rows writes (vectorised form uses 64-row blocks)
@@ -475,7 +472,7 @@ int launch_bn_eval_prepare(hipStream_t st, int C, const float* gamma, const floa
 int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int C, const float* scale,
                       const float* shift, int act, float slope, float p_drop, uint64_t seed) {
     size_t total = rows * C;
-    float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    float inv_keep = dropout_inv_keep8(p_drop);
     if (rows < (size_t)1 << 30 && vec_ok(C, Y, Z) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0)) {
         hipLaunchKernelGGL((bn_act_fwd_vec_kernel<float>), dim3(bn_vec_parts((int)rows)), dim3(256), 0, st, Y, Z, (int)rows, C, scale, shift,
                            act, slope, drop_thresh(p_drop), inv_keep, seed);
@@ -490,7 +487,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
                       const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
                       float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz,
                       float* mean_dzy) {
-    float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    float inv_keep = dropout_inv_keep8(p_drop);
     uint32_t th = drop_thresh(p_drop);
     int nparts = bn_stat_parts(M);
     const bool vec = vec_ok(C, dZ, Y, dY) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0);
@@ -638,7 +635,7 @@ static inline bool vec_ok_b16(int C, const void* a, const void* b = nullptr, con
 int launch_bn_act_fwd_b16(hipStream_t st, const void* Y, void* Z, int rows, int C, const float* scale, const float* shift, int act,
                           float slope, float p_drop, uint64_t seed) {
     if (!vec_ok_b16(C, Y, Z) || ((((uintptr_t)scale | (uintptr_t)shift) & 15) != 0)) return MLSP_ERR_UNSUPPORTED;
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const float inv_keep = dropout_inv_keep8(p_drop);
     hipLaunchKernelGGL((bn_act_fwd_vec_kernel<__bf16>), dim3(bn_vec_parts(rows)), dim3(256), 0, st, (const __bf16*)Y, (__bf16*)Z, rows, C,
                        scale, shift, act, slope, drop_thresh(p_drop), inv_keep, seed);
     return mlsp_launch_status();
@@ -648,7 +645,7 @@ int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* d
                           double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy) {
     if (!vec_ok_b16(C, dZ, Y, dY) || ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) != 0))
         return MLSP_ERR_UNSUPPORTED;
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const float inv_keep = dropout_inv_keep8(p_drop);
     const uint32_t th = drop_thresh(p_drop);
     const int nparts = bn_vec_parts(M);
     hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, M, C, scale,

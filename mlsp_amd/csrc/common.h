@@ -49,6 +49,12 @@ __device__ __forceinline__ void xcd_cloud_map(int bid, int bpc, int B, int& clou
     }
 }
 
+// Operand transform of a GEMM (gemm.hip): the operand holds the PRE-BatchNorm output of the previous layer; act(x * scale[c] + shift[c])
+// and that layer's dropout are applied while the tile is staged.  which: 1 = A ([M][K] row-major, c = k), 2 = B ([K][N] k-major, c = n).
+struct GemmXf {
+    const float* scale; const float* shift; int act; float slope; uint32_t thresh; float inv_keep; uint64_t seed; int ld; int which;
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -61,12 +67,27 @@ __device__ __forceinline__ float lrelu_or_relu(float x, int act, float slope) {
     return x > 0.f ? x : (act == 1 ? 0.f : x * slope);
 }
 
-// counter-based dropout bit: keep iff hash(seed, i) >= p * 2^32   (lowbias32 mix)
+// Counter-based dropout: ONE 32-bit hash (lowbias32 mix) per aligned quad of elements, one byte of it per element: element i is kept
+// iff byte (i & 3) of hash(seed, i >> 2) >= thresh, thresh = round(256 p) in [0, 255] (p = 0.5 is exact; other rates are quantised to
+// 1/256 and inv_keep = 256 / (256 - thresh) keeps the expectation exact).  The two 32-bit multiplies of the mix are quarter-rate
+// instructions: per quad instead of per element they are cheap enough to regenerate the mask inside a GEMM operand load (gemm.hip XF).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
+__device__ __forceinline__ uint32_t dropout_hash4(uint64_t seed, uint64_t quad) {
+    return mix32((uint32_t)quad ^ mix32((uint32_t)(quad >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9e3779b9U);
+}
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t i, uint32_t thresh) {
-    uint32_t h = mix32((uint32_t)i ^ mix32((uint32_t)(i >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9e3779b9U);
-    return h >= thresh;
+    return ((dropout_hash4(seed, i >> 2) >> (8 * ((uint32_t)i & 3))) & 255u) >= thresh;
+}
+// host side: the byte threshold of a rate and the matching rescale
+static inline uint32_t dropout_thresh8(float p) {
+    if (!(p > 0.f)) return 0u;
+    const int t = (int)(p * 256.0f + 0.5f);
+    return (uint32_t)(t > 255 ? 255 : t);
+}
+static inline float dropout_inv_keep8(float p) {
+    const uint32_t t = dropout_thresh8(p);
+    return t ? 256.0f / (float)(256u - t) : 1.0f;
 }

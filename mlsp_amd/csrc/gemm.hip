@@ -35,6 +35,10 @@ struct GemmArgs {
     int xcd_map;                    // 1: XCD-grouped block->tile map (grid padded to a multiple of 8 panels)
     int accumulate;                 // 1: C += result (beta = 1): several consumers of one activation sum their input gradients in place
     int c_bf16;                     // 1: C holds bf16 (activation storage of BASELINE.json configs[4]); A / B element types are template arguments
+    // operand transform (XF != 0): the operand is the PRE-BatchNorm output of the previous layer and is turned into that layer's
+    // activated output while it is staged: act(x * scale[c] + shift[c]), dropout by the counter hash of element row * x_ld + c.
+    // XF == 1: A is [M][K] row-major, c = k.  XF == 2: B is [K][N] k-major (the wgrad's X), c = n.
+    const float* x_scale; const float* x_shift; int x_act; float x_slope; uint32_t x_thresh; float x_inv_keep; uint64_t x_seed; int x_ld;
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][N] (BN batch statistics)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
     float* sel_val; int* sel_row;   // [ntm][N] extreme of each 128-row panel and the global row attaining it (first occurrence)
@@ -205,7 +209,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
 
 // WM = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile; 1 -> 64x128 (twice the workgroups, for launches whose
 // 128-row grid is too small to keep ~3 workgroups per CU in flight and out of phase)
-template <bool TA, bool TB, int WM, bool FAST>
+// one staged f32x4 of an operand under the transform: c0 = first channel of the quad (channels contiguous when XF == 1 / 2 alike),
+// e0 = element index (row * x_ld + c0) of its first value
+__device__ __forceinline__ f32x4 xf_quad(const GemmArgs& p, f32x4 v, const f32x4& xs, const f32x4& xh, uint64_t e0) {
+    const uint32_t hq = p.x_thresh ? dropout_hash4(p.x_seed, e0 >> 2) : 0u;  // e0 is a multiple of 4: one hash for the quad
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = lrelu_or_relu(fmaf(v[e], xs[e], xh[e]), p.x_act, p.x_slope);
+        if (p.x_thresh) a = ((hq >> (8 * e)) & 255u) >= p.x_thresh ? a * p.x_inv_keep : 0.f;
+        v[e] = a;
+    }
+    return v;
+}
+
+template <bool TA, bool TB, int WM, bool FAST, int XF = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     constexpr int BMT = 64 * WM, NPA = 2 * WM;
     // A tile is k-major in LDS either way; its GLOBAL source is k-major iff TA.  B's source is
@@ -258,6 +275,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     // FAST: this thread's source pointers (advance by one K-tile per iteration)
     const float* pa = nullptr;
     const float* pb = nullptr;
+    // XF (FAST, fp32 only): scale / shift of this thread's channel quad.  XF == 1: the k-quad of the A tile held in ra (reloaded with
+    // every tile); XF == 2: the n-quad of B (fixed).
+    f32x4 xs = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
+    static_assert(XF == 0 || FAST, "operand transform: interior tiles only");
+    static_assert(XF != 1 || !TA, "XF == 1: A row-major");
+    static_assert(XF != 2 || !TB, "XF == 2: B k-major");
     if (FAST) {
         pa = TA ? p.A + (size_t)(kbeg + (NPA == 4 ? (tid >> 5) : (tid >> 4))) * p.lda + m0 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 4
                 : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
@@ -265,11 +288,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                  : p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + kbeg + (tid & 7) * 4;
         g2r_fast<TA, NPA>(ra, pa, p.lda);
         g2r_fast<!TB, 4>(rb, pb, p.ldb);
+        if (XF == 1) { xs = *(const f32x4*)(p.x_scale + kbeg + (tid & 7) * 4); xh = *(const f32x4*)(p.x_shift + kbeg + (tid & 7) * 4); }
+        if (XF == 2) { xs = *(const f32x4*)(p.x_scale + n0 + (tid & 31) * 4); xh = *(const f32x4*)(p.x_shift + n0 + (tid & 31) * 4); }
     } else {
         g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid);
         g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid);
     }
 
+    // XF: the staged registers of the tile at kt become the previous layer's activated output.  The first tile is transformed here;
+    // every later one in the MIDDLE of the MFMA loop of the tile before it (its loads have landed by then and the vector work runs
+    // under the matrix pipe instead of in front of the LDS writes, where all four waves would wait on it).
+    auto xf_tile = [&](int kt) {
+        if (XF == 1) {                                    // rows m0 + (tid >> 3) + 32 q, channels kt + 4 (tid & 7) ..
+#pragma unroll
+            for (int q = 0; q < NPA; ++q)
+                ra[q] = xf_quad(p, ra[q], xs, xh, (uint64_t)(m0 + (tid >> 3) + 32 * q) * p.x_ld + kt + (tid & 7) * 4);
+        }
+        if (XF == 2) {                                    // rows (points) kt + (tid >> 5) + 8 q, channels n0 + 4 (tid & 31) ..
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                rb[q] = xf_quad(p, rb[q], xs, xh, (uint64_t)(kt + (tid >> 5) + 8 * q) * p.x_ld + n0 + (tid & 31) * 4);
+        }
+    };
+    if (XF) xf_tile(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #ifdef GP_NOR2S
         if (k0 == kbeg)
@@ -292,6 +333,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                 pb += !TB ? (size_t)BK * p.ldb : BK;
                 g2r_fast<TA, NPA>(ra, pa, p.lda);
                 g2r_fast<!TB, 4>(rb, pb, p.ldb);
+                if (XF == 1) {
+                    xs = *(const f32x4*)(p.x_scale + k0 + BK + (tid & 7) * 4); xh = *(const f32x4*)(p.x_shift + k0 + BK + (tid & 7) * 4);
+                }
             } else {
                 g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid);
                 g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid);
@@ -309,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 #ifdef GP_IGLP
             __builtin_amdgcn_iglp_opt(GP_IGLP);
 #endif
+            if (XF && m == BK / 8 && k0 + BK < kend) xf_tile(k0 + BK);
             const int kq = 4 * m + 2 * h;
             float a0s0, a0s1, a1s0, a1s1, b0s0, b0s1, b1s0, b1s1;
             a1s0 = 0.f; a1s1 = 0.f;
@@ -783,18 +828,31 @@ int launch_skinny_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, co
 int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                      int ldc, const float* bias, float* slab, size_t slab_floats);
 
+// Can this contraction stage `which` (1: A [M][K] row-major, 2: B [K][N] k-major) through the operand transform?  Interior tiles,
+// 16-byte loads, fp32 operands, the MFMA tile kernels (not the thin / skinny / N = 64 ones).
+bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which) {
+    if (g_gemm_precision != 0) return false;
+    if (which == 1 ? ta : !(ta && !tb)) return false;
+    if (M <= 32 || N < 32 || K < 32 || (ta && !tb && K <= 32)) return false;
+    const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    int ns = gemm_pick_split(M, N, K);
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
+    return vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+}
+
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                 size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
-                int* sel_row = nullptr, bool accumulate = false) {
+                int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
+    if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
     // one tiny dimension (3 coordinates, 3 / 16 outputs): streaming VALU kernels priced against HBM, not MFMA tiles (thin.hip)
-    if (!gbias && !stat_part && !sel_gamma && !accumulate) {
+    if (!gbias && !stat_part && !sel_gamma && !accumulate && !xf) {
         const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
     // per-cloud layers (<= 32 rows, or a 32-deep wgrad): one-pass skinny kernels, no split-K slab (skinny.hip)
-    if (!gbias && !stat_part && !sel_gamma && !accumulate && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
+    if (!gbias && !stat_part && !sel_gamma && !accumulate && !xf && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
         const int rc = launch_skinny_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
@@ -810,6 +868,11 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
     p.stat_part = stat_part;
     p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
+    p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0;
+    if (xf) {
+        p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_slope = xf->slope; p.x_thresh = xf->thresh;
+        p.x_inv_keep = xf->inv_keep; p.x_seed = xf->seed; p.x_ld = xf->ld;
+    }
     int ktiles = (K + BK - 1) / BK;
     int kts = (ktiles + ns - 1) / ns;
     ns = (ktiles + kts - 1) / kts;
@@ -825,7 +888,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
     const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
-    const bool n64 = N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !bias && !gbias && !stat_part && !sel_gamma &&
+    const bool n64 = !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !bias && !gbias && !stat_part && !sel_gamma &&
                      !accumulate && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
     if (n64) {
         dim3 g64(M / 128, ns);
@@ -836,7 +899,18 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
 #define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
-    if (bm == 128) {
+    if (xf) {                                             // operand transform: FAST fp32 instantiations only (gemm_xf_supported)
+        if (xf->which == 1 && tb) {
+            if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, true, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, true, 1>), grid, dim3(256), 0, st, p);
+        } else if (xf->which == 1) {
+            if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, true, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1, true, 1>), grid, dim3(256), 0, st, p);
+        } else {
+            if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2, true, 2>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1, true, 2>), grid, dim3(256), 0, st, p);
+        }
+    } else if (bm == 128) {
         if (!ta && tb) GEMM_GO(false, true, 2);
         else if (!ta && !tb) GEMM_GO(false, false, 2);
         else if (ta && !tb) GEMM_GO(true, false, 2);

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const float* __restrict_
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-static inline uint32_t sk_drop_thresh(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+static inline uint32_t sk_drop_thresh(float p) { return dropout_thresh8(p); }
 
 // plain skinny GEMMs behind launch_gemm (no split-K, no slab).  Returns MLSP_ERR_UNSUPPORTED when the shape is not skinny.
 int launch_skinny_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -294,7 +294,7 @@ int launch_skinny_linear_bn_act(hipStream_t st, const float* X, int ldx, int M, 
     p.gamma = gamma; p.beta = beta; p.run_mean = run_mean; p.run_var = run_var; p.momentum = momentum; p.eps = eps;
     p.training = training; p.act = act; p.slope = slope;
     const float pd = training ? p_drop : 0.f;
-    p.thresh = sk_drop_thresh(pd); p.inv_keep = pd > 0.f ? 1.f / (1.f - pd) : 1.f; p.seed = seed;
+    p.thresh = sk_drop_thresh(pd); p.inv_keep = dropout_inv_keep8(pd); p.seed = seed;
     p.Z = Z; p.bn_save = bn_save;
     hipLaunchKernelGGL(skinny_fwd_kernel, dim3((Cout + 31) / 32), dim3(64 * SK_WAVES), 0, st, p);
     return mlsp_launch_status();
@@ -305,6 +305,6 @@ int launch_skinny_bn_bwd(hipStream_t st, const float* dZ, const float* Y, float*
     if (M > 32) return MLSP_ERR_ARG;
     const float pd = training ? p_drop : 0.f;
     hipLaunchKernelGGL(skinny_bn_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, st, dZ, Y, dY, M, C, bn_save, training, act, slope,
-                       sk_drop_thresh(pd), pd > 0.f ? 1.f / (1.f - pd) : 1.f, seed, dgamma, dbeta);
+                       sk_drop_thresh(pd), dropout_inv_keep8(pd), seed, dgamma, dbeta);
     return mlsp_launch_status();
 }

@@ -5,6 +5,7 @@ or B*N*k edges).  The module layer (Models.py / model_utils.py) converts from an
 reference's channel-major [B, C, N] at its boundary only.
 """
 import itertools
+import os
 
 import torch
 from torch.autograd import Function
@@ -407,10 +408,37 @@ def tnet_edge_supported(W1, W2, k):
     return W1.shape[0] == 64 and tuple(W2.shape) == (128, 64) and 1 <= k <= 128
 
 
+_DEFER_CHAINS = os.environ.get("MLSP_NO_DEFERRED_ACT") is None     # A/B switch: keep every activated tensor materialised
+
+
+class DeferredAct:
+    """Output of a chained Linear+BN+act layer (pointmlp(..., chain=True), fp32 storage) whose BatchNorm scale / shift, activation
+    and dropout have NOT been applied yet: `y` is the pre-BN GEMM output, an autograd tensor that stands for the activated output
+    (gradients flowing into it are gradients w.r.t. the activated value), `bn_save` [4, C] the layer's scale | shift | mean | invstd.
+    The only legal consumer is another pointmlp, which applies the transform in its GEMM operand loads (include/mlsp_hip.h
+    mlsp_pointmlp_*_chain_f32): the streaming BN+act pass and the activated tensor disappear."""
+    __slots__ = ("y", "bn_save", "act", "slope", "p", "seed")
+
+    def __init__(self, y, bn_save, act, slope, p, seed):
+        self.y, self.bn_save, self.act, self.slope, self.p, self.seed = y, bn_save, int(act), float(slope), float(p), int(seed)
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+    @property
+    def device(self):
+        return self.y.device
+
+    @property
+    def dtype(self):
+        return self.y.dtype
+
+
 class _PointMLP(Function):
     @staticmethod
     def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,
-                momentum, eps, grad_accum=None, out_bf16=False):
+                momentum, eps, grad_accum=None, out_bf16=False, in_bn=None, in_cfg=None, defer_out=False):
         lib = _lib.load()
         X = _rows(X, allow_bf16=True)
         _lib.require_gpu(X, W)
@@ -427,8 +455,10 @@ class _PointMLP(Function):
             if x_bf16:
                 raise RuntimeError("pointmlp: bf16 input on a layer the bf16-storage kernels do not cover (M=%d Cin=%d Cout=%d)" % (M, Cin, Cout))
             mx = out_bf16 = False
+        assert not (mx and (in_bn is not None or defer_out)), "bf16 activation storage and deferred activations are exclusive"
+        assert not defer_out or has_bn
         odt = torch.bfloat16 if out_bf16 else torch.float32
-        Z = torch.empty((M, Cout), dtype=odt, device=dev)
+        Z = None if defer_out else torch.empty((M, Cout), dtype=odt, device=dev)
         Y = torch.empty((M, Cout), dtype=odt, device=dev) if has_bn else None
         bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev) if has_bn else None
         if gbias is not None:
@@ -444,22 +474,33 @@ class _PointMLP(Function):
                 int(rows_per_group), gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
                 int(training), act, slope, p, seed, Y.data_ptr(), Z.data_ptr(), int(out_bf16), bn_save.data_ptr(), ws, wsn,
                 _lib.stream()), "mlsp_pointmlp_fwd_mx")
+        elif in_bn is not None:
+            iact, islope, ip, iseed = in_cfg
+            _lib.check(lib.mlsp_pointmlp_fwd_chain_f32(
+                X.data_ptr(), X.stride(0), in_bn.data_ptr(), iact, islope, ip, iseed, M, Cin, W.data_ptr(), W.stride(0), Cout,
+                _lib.ptr(bias), _lib.ptr(gbias), int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean),
+                _lib.ptr(run_var), momentum, eps, int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), ws, wsn,
+                _lib.stream()), "mlsp_pointmlp_fwd_chain_f32")
         else:
             _lib.check(lib.mlsp_pointmlp_fwd_f32(
                 X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
                 int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
-                int(training), act, slope, p, seed, _lib.ptr(Y), Z.data_ptr(), _lib.ptr(bn_save), ws, wsn, _lib.stream()),
+                int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_fwd_f32")
+        ctx.in_bn, ctx.in_cfg = in_bn, in_cfg
         ctx.save_for_backward(X, W, Y, bn_save)
         ctx.cfg = (has_bn, training, act, slope, p, seed, bias is not None, gbias.shape[0] if gbias is not None else 0,
                    int(rows_per_group))
         ctx.grad_accum = grad_accum
         ctx.mx = (mx, x_bf16, out_bf16)
-        return Z
+        if bn_save is not None:
+            ctx.mark_non_differentiable(bn_save)
+        # a deferred layer hands out its pre-BN output: Y is both saved and returned (same storage, nobody writes to it)
+        return (Y.view_as(Y) if defer_out else Z), bn_save
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dZ):
+    def backward(ctx, dZ, _dbn=None):
         lib = _lib.load()
         X, W, Y, bn_save = ctx.saved_tensors
         has_bn, training, act, slope, p, seed, has_bias, G, rpg = ctx.cfg
@@ -488,13 +529,20 @@ class _PointMLP(Function):
                 int(out_bf16), bn_save.data_ptr(), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate,
                 dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_mx")
+        elif ctx.in_bn is not None:
+            iact, islope, ip, iseed = ctx.in_cfg
+            _lib.check(lib.mlsp_pointmlp_bwd_chain_f32(
+                dZ.data_ptr(), X.data_ptr(), X.stride(0), ctx.in_bn.data_ptr(), iact, islope, ip, iseed, M, Cin, W.data_ptr(), W.stride(0),
+                Cout, _lib.ptr(Y), _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate,
+                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
+                "mlsp_pointmlp_bwd_chain_f32")
         else:
             _lib.check(lib.mlsp_pointmlp_bwd_f32(
                 dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
                 _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate, dW.data_ptr(),
                 _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_f32")
-        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 12
+        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 15
 
 
 def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, run_var=None, rows_per_group=0,
@@ -504,8 +552,17 @@ def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, 
     another pointmlp BN layer, so under activation_storage("bf16") Y / Z may be stored as bf16."""
     seed = _next_seed() if (training and p_drop > 0) else 0
     out_bf16 = bool(chain) and activation_storage.current == "bf16" and gamma is not None
-    return _PointMLP.apply(X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop,
-                           seed, momentum, eps, grad_accum, out_bf16)
+    in_bn = in_cfg = None
+    if isinstance(X, DeferredAct):
+        in_bn, in_cfg, X = X.bn_save, (X.act, X.slope, X.p, X.seed), X.y
+    # fp32 storage: a chained layer leaves its BN + activation (+ dropout) to its consumer's GEMM operand loads
+    defer_out = (bool(chain) and gamma is not None and activation_storage.current == "fp32" and gemm_precision.current == "fp32"
+                 and X.shape[0] > 32 and X.dtype == torch.float32 and _DEFER_CHAINS)
+    out, bn_save = _PointMLP.apply(X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop,
+                                   seed, momentum, eps, grad_accum, out_bf16, in_bn, in_cfg, defer_out)
+    if defer_out:
+        return DeferredAct(out, bn_save, act, slope, float(p_drop) if training else 0.0, seed)
+    return out
 
 
 class _PointMLPColMax(Function):

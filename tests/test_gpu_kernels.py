@@ -618,6 +618,37 @@ def test_tnet_backward_gram_form_vs_round1_kernel(dev, B, N, k):
         assert err < 1e-4, (name, err)
 
 
+@pytest.mark.parametrize("M,C0,C1,C2,training", [(4096, 128, 256, 128, True), (8192, 512, 256, 256, True), (1000, 96, 80, 64, True),
+                                                 (4096, 128, 256, 128, False)])
+def test_pointmlp_deferred_activation_chain(dev, M, C0, C1, C2, training, monkeypatch):
+    """pointmlp(..., chain=True) under fp32 storage hands its PRE-BN output to the next layer, which applies BN + ReLU + dropout in
+    its GEMM operand loads (forward: A rows, wgrad: the k-major B operand) -- bit-identical to the materialised path: the staged
+    values are computed by the same expressions.  The third case is outside the interior-tile path (one streaming pass instead)."""
+    Fh = _fh()
+    import itertools as it
+
+    def run(defer):
+        monkeypatch.setattr(Fh, "_DEFER_CHAINS", defer)
+        monkeypatch.setattr(Fh, "_seed_counter", it.count(1234), raising=False)
+        ts = [(_rand((M, C0), 1)), _rand((C1, C0), 2, 0.2), _rand((C2, C1), 3, 0.2), _rand((3, C2), 4, 0.2)]
+        gb = [(_rand((C1,), 5) + 0.3), _rand((C1,), 6), (_rand((C2,), 7) + 0.3), _rand((C2,), 8)]
+        leaves = [t.to(dev).requires_grad_(True) for t in ts + gb]
+        X, W1, W2, W3, g1, b1, g2, b2 = leaves
+        rs = [torch.zeros(C1, device=dev), torch.ones(C1, device=dev), torch.zeros(C2, device=dev), torch.ones(C2, device=dev)]
+        h = Fh.pointmlp(X, W1, gamma=g1, beta=b1, run_mean=rs[0], run_var=rs[1], training=training, act=Fh.ACT_RELU, p_drop=0.5, chain=True)
+        assert isinstance(h, Fh.DeferredAct) == bool(defer)
+        h = Fh.pointmlp(h, W2, gamma=g2, beta=b2, run_mean=rs[2], run_var=rs[3], training=training, act=Fh.ACT_LRELU, slope=0.2, p_drop=0.3,
+                        chain=True)
+        out = Fh.pointmlp(h, W3, training=training)
+        out.backward(_rand((M, 3), 9).to(dev))
+        return [out.detach().cpu()] + [t.grad.cpu() for t in leaves] + [r.cpu() for r in rs]
+
+    a, b = run(True), run(False)
+    names = ["out", "dX", "dW1", "dW2", "dW3", "dg1", "db1", "dg2", "db2", "rm1", "rv1", "rm2", "rv2"]
+    for n, x, y in zip(names, a, b):
+        assert torch.equal(x, y), (n, (x - y).abs().max().item())
+
+
 # ----------------------------------------------------------------------------- conv + BN + act + max over N (Gram backward)
 @pytest.mark.parametrize("B,N,Cin,Cout,training", [(4, 100, 64, 96, True), (3, 128, 128, 256, True), (2, 64, 512, 1024, True),
                                                    (3, 50, 40, 70, False)])
