@@ -129,6 +129,17 @@ __device__ __forceinline__ float dz_prime(float dz, float y, float sc, float sh,
     return dz;
 }
 
+// the same for element e of an aligned quad whose hash hq = dropout_hash4(seed, i >> 2) the caller computed once
+__device__ __forceinline__ float dz_prime_q(float dz, float y, float sc, float sh, int act, float slope, uint32_t thresh,
+                                            float inv_keep, uint32_t hq, int e) {
+    if (thresh) dz = ((hq >> (8 * e)) & 255u) >= thresh ? dz * inv_keep : 0.f;
+    if (act) {
+        float a = fmaf(y, sc, sh);
+        if (!(a > 0.f)) dz *= (act == 1 ? 0.f : slope);
+    }
+    return dz;
+}
+
 // partial column sums of dz' and dz'*yhat  (fp64 partials [nparts][2][C])
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dZ, const float* __restrict__ Y,
                                                                 int M, int C, const float* __restrict__ scale,
@@ -254,9 +265,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_vec_kernel(const TY* __
         for (int r = r0 + rg; r < r1; r += nrg) {
             const size_t i = (size_t)r * C + c;
             const f32x4 y = ld4<TY>(Y + i), dz = ld4<TY>(dZ + i);
+            const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float d = dz_prime(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, seed, i + e);
+                float d = dz_prime_q(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
                 s[e] += d; q[e] += (double)d * ((y[e] - mu[e]) * is[e]);
             }
         }
@@ -330,10 +342,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const TY* __r
     for (int r = r0 + rg; r < r1; r += nrg) {
         const size_t i = (size_t)r * C + c;
         const f32x4 y = ld4<TY>(Y + i), dz = ld4<TY>(dZ + i);
+        const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float d = dz_prime(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, seed, i + e);
+            float d = dz_prime_q(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
             d = d - k1[e] - (y[e] - mu[e]) * k2[e];
             o[e] = sc[e] * d;
         }
