@@ -457,7 +457,10 @@ static int pointmlp_fwd_impl(const float* X, int ldx, int M, int Cin, const floa
     float* slab = sf ? w.take<float>(sf) : nullptr;
     GemmXf xf_s; const GemmXf* xf = nullptr;
     if (in) {
-        if (gemm_xf_supported(false, true, M, Cout, Cin, X, ldx, W, ldw, 1)) { xf_s = chain_xf(*in, Cin, 1); xf = &xf_s; }
+        // (a LeakyReLU slope outside [0, 1] takes the streaming pass: the fused transform writes the activation as one max)
+        if (!(in->act == 2 && !(in->slope >= 0.f && in->slope <= 1.f)) && gemm_xf_supported(false, true, M, Cout, Cin, X, ldx, W, ldw, 1)) {
+            xf_s = chain_xf(*in, Cin, 1); xf = &xf_s;
+        }
         else {                                             // shape outside the fused path: materialise the activated input once
             if (ldx != Cin) return MLSP_ERR_UNSUPPORTED;
             float* Xa = w.take<float>((size_t)M * Cin);
@@ -527,7 +530,9 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     GemmXf xf_s; const GemmXf* xf = nullptr;            // chained input: the wgrad reads the previous layer's pre-BN output
     if (in) {
         if (!in->bn_save || M <= 32) return MLSP_ERR_ARG;
-        if (gemm_xf_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx, 2)) { xf_s = chain_xf(*in, Cin, 2); xf = &xf_s; }
+        if (!(in->act == 2 && !(in->slope >= 0.f && in->slope <= 1.f)) && gemm_xf_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx, 2)) {
+            xf_s = chain_xf(*in, Cin, 2); xf = &xf_s;
+        }
         else {
             if (ldx != Cin) return MLSP_ERR_UNSUPPORTED;
             float* Xa = w.take<float>((size_t)M * Cin);

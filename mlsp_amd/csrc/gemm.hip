@@ -212,10 +212,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
 // one staged f32x4 of an operand under the transform: c0 = first channel of the quad (channels contiguous when XF == 1 / 2 alike),
 // e0 = element index (row * x_ld + c0) of its first value
 __device__ __forceinline__ f32x4 xf_quad(const GemmArgs& p, f32x4 v, const f32x4& xs, const f32x4& xh, uint64_t e0) {
+    // x_slope here is the EFFECTIVE negative-side factor in [0, 1] (0 for ReLU, 1 for no activation: launch_gemm), so the activation
+    // is one max: max(a, a * s) == (a > 0 ? a : a * s).  The dropout rescale is applied exactly as bn_act_fwd does (a * inv_keep).
     const uint32_t hq = p.x_thresh ? dropout_hash4(p.x_seed, e0 >> 2) : 0u;  // e0 is a multiple of 4: one hash for the quad
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float a = lrelu_or_relu(fmaf(v[e], xs[e], xh[e]), p.x_act, p.x_slope);
+        float a = fmaf(v[e], xs[e], xh[e]);
+        a = fmaxf(a, a * p.x_slope);
         if (p.x_thresh) a = ((hq >> (8 * e)) & 255u) >= p.x_thresh ? a * p.x_inv_keep : 0.f;
         v[e] = a;
     }
@@ -870,7 +873,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
     p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0;
     if (xf) {
-        p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_slope = xf->slope; p.x_thresh = xf->thresh;
+        p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_thresh = xf->thresh;
+        p.x_slope = xf->act == 0 ? 1.f : xf->act == 1 ? 0.f : xf->slope;          // effective negative-side factor (xf_quad)
         p.x_inv_keep = xf->inv_keep; p.x_seed = xf->seed; p.x_ld = xf->ld;
     }
     int ktiles = (K + BK - 1) / BK;

@@ -408,7 +408,11 @@ def tnet_edge_supported(W1, W2, k):
     return W1.shape[0] == 64 and tuple(W2.shape) == (128, 64) and 1 <= k <= 128
 
 
-_DEFER_CHAINS = os.environ.get("MLSP_NO_DEFERRED_ACT") is None     # A/B switch: keep every activated tensor materialised
+# Deferred activations of chained layers (DeferredAct below) are opt-in: MLSP_DEFERRED_ACT=1.  Measured on the DGCNN step they remove
+# six streaming passes (-98 us) and cost +66 us in the twelve consumer GEMMs (vector work does not hide under the matrix pipe on
+# gfx950), i.e. -0.5 % step time for a GEMM family that runs 4 % slower -- not worth it by default; profitable where the consumer has
+# <= 128 output channels.
+_DEFER_CHAINS = os.environ.get("MLSP_DEFERRED_ACT") is not None
 
 
 class DeferredAct:

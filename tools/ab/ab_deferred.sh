@@ -1,7 +1,7 @@
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for v in on off; do
   rm -rf /tmp/pf_$v
-  if [ $v = off ]; then export MLSP_NO_DEFERRED_ACT=1; else unset MLSP_NO_DEFERRED_ACT; fi
+  if [ $v = on ]; then export MLSP_DEFERRED_ACT=1; else unset MLSP_DEFERRED_ACT; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$v -o run -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 done
 python3 - <<'PY'
