@@ -34,6 +34,7 @@ struct GemmArgs {
     int a_vec, b_vec;               // 1 if float4 global loads are legal for that operand
     int xcd_map;                    // 1: XCD-grouped block->tile map (grid padded to a multiple of 8 panels)
     int accumulate;                 // 1: C += result (beta = 1): several consumers of one activation sum their input gradients in place
+    int fast_out;                   // 1: interior fp32 tiles may use the lean output pass (gemm_out_fast): set by launch_gemm
     int c_bf16;                     // 1: C holds bf16 (activation storage of BASELINE.json configs[4]); A / B element types are template arguments
     // operand transform (XF != 0): the operand is the PRE-BatchNorm output of the previous layer and is turned into that layer's
     // activated output while it is staged: act(x * scale[c] + shift[c]), dropout by the counter hash of element row * x_ld + c.
@@ -112,6 +113,51 @@ __device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, 
     }
 }
 
+// ---- lean output pass of the interior-tile fp32 kernels -------------------------------------------------------------------------
+// Measured (tools/gemm_probe.py, GP_TIMELINE): while the other workgroups of a CU keep the matrix pipe full, every vector instruction
+// of a workgroup that has left its K loop waits about one MFMA issue slot (64+ clocks).  The generic epilogue below spends 10+ vector
+// and branch instructions per output element (64-bit address arithmetic, per-element predicates): 6-21 us per workgroup in which its
+// slot does no matrix work (1.5 us when it runs alone).  Here an element costs ONE buffer store (+ one add per bias term, two FMAs for
+// the BatchNorm sums): the wave's 32 x 64 (64 x 64) region gets a buffer descriptor whose base is the region's first element (scalar
+// arithmetic), the lane's offset inside it is one register, the row of accumulator register r is a scalar offset.
+// C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#define MLSP_BUF_FLAGS 0x00020000          // raw dword buffer, gfx94x / gfx950 (DATA_FORMAT = 32 bit)
+template <int WM, bool GB, bool ACC, bool ST>
+__device__ __forceinline__ void gemm_out_fast(const GemmArgs& p, f32x16 (&acc)[2][2], float* Cw, const float (&bv)[2], const float (&gv)[2],
+                                              int l31, int h, float (&cs)[2], float (&cq)[2]) {
+    const int ldc4 = p.ldc * 4;                                            // bytes per row (scalar)
+    const int voff = 4 * h * ldc4 + 4 * l31;                               // this lane inside the wave's region
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cw, 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+    const bool store = Cw != nullptr;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float old[16];
+            if (ACC) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4 + j * 128, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + bv[j];
+                if (GB) v += gv[j];
+                if (ACC) v += old[r];
+                if (ST) { cs[j] += v; cq[j] = fmaf(v, v, cq[j]); }
+                acc[i][j][r] = v;
+            }
+            if (store) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                {   // (a __builtin_bit_cast of the vector ELEMENT is miscompiled by this clang: every store took element 0)
+                    const float vv = acc[i][j][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv), rs, voff, (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4 + j * 128, 0);
+                }
+            }
+        }
+}
+
 // ---- epilogue shared by the fp32 and the bf16-operand kernels --------------------------------------------------------
 // acc: this wave's WM x 2 MFMA tiles of the block tile at (m0, n0); smem: the operand tiles, dead by now (scratch).
 template <int WM, bool FAST, bool CBF = false>
@@ -122,6 +168,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
     __bf16* Cb = (__bf16*)p.C;                            // CBF: bf16 output (never split: the slab is fp32)
     const bool epi = (p.nsplit == 1);
     float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
+    // interior fp32 tiles whose rows share one per-cloud bias row: the lean output pass (launch_gemm sets p.fast_out)
+    if (FAST && !CBF && p.fast_out) {
+        float bv[2] = {0.f, 0.f}, gv[2] = {0.f, 0.f};
+        if (epi && p.bias) { bv[0] = p.bias[n0 + wn * 64 + l31]; bv[1] = p.bias[n0 + wn * 64 + 32 + l31]; }
+        const bool gb = epi && p.gbias;
+        if (gb) {
+            const float* g = p.gbias + (size_t)(m0 / p.rows_per_group) * p.N + n0 + wn * 64 + l31;
+            gv[0] = g[0]; gv[1] = g[32];
+        }
+        float* Cw = p.C ? Cout + (size_t)(m0 + wm * (32 * WM)) * p.ldc + n0 + wn * 64 : nullptr;
+        if (epi && p.accumulate) gemm_out_fast<WM, false, true, false>(p, acc, Cw, bv, gv, l31, h, cs, cq);
+        else if (gb) gemm_out_fast<WM, true, false, true>(p, acc, Cw, bv, gv, l31, h, cs, cq);
+        else if (p.stat_part) gemm_out_fast<WM, false, false, true>(p, acc, Cw, bv, gv, l31, h, cs, cq);
+        else gemm_out_fast<WM, false, false, false>(p, acc, Cw, bv, gv, l31, h, cs, cq);
+    } else
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -239,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     float* Bs = smem + BM * SROW;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the output pass addresses with it
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -265,6 +326,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 #ifdef GP_TIMELINE
     const long long tl0 = wall_clock64();
     long long tl1 = 0;
+#endif
+#ifdef GP_DEPHASE
+    {   // co-resident workgroups get distinct issue priorities: they drift out of phase, one's C stores run under another's MFMAs
+#if GP_DEPHASE == 1
+        const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 3u;        // HW_ID.wave_id[3:0] & 3
+#elif GP_DEPHASE == 2
+        const unsigned slot = ((unsigned)bid >> 3) & 3u;
+#else
+        const unsigned slot = ((unsigned)bid >> 8) & 3u;
+#endif
+        if (slot == 0) __builtin_amdgcn_s_setprio(0);
+        else if (slot == 1) __builtin_amdgcn_s_setprio(1);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
 #endif
     f32x16 acc[2][2];
 #pragma unroll
@@ -406,6 +482,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
         const long long tl3 = wall_clock64();
         float* dbg = p.C + (size_t)m0 * p.ldc + n0;
         dbg[0] = (float)(tl0 & 0xffffff); dbg[1] = (float)(tl1 - tl0); dbg[2] = (float)(tl2 - tl1); dbg[3] = (float)(tl3 - tl2);
+        dbg[4] = (float)(__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4));      // HW_ID[15:0]: wave, simd, pipe, cu, sh, se
+        dbg[5] = (float)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20));      // XCC_ID
     }
 #endif
 }
@@ -868,6 +946,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;   // no slab: fall back to one pass
     if (accumulate) ns = 1;                                              // beta = 1 lives in the one-pass epilogue
     p.accumulate = accumulate ? 1 : 0;
+    p.fast_out = 0;
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
     p.stat_part = stat_part;
     p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
@@ -892,6 +971,9 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
     const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+    static const bool old_epilogue = getenv("MLSP_GEMM_OLD_EPILOGUE") != nullptr;       // read-once A/B switch (tools/ab)
+    // lean output pass: every row of a tile takes the same per-cloud bias row, byte offsets inside a wave's region fit 31 bits
+    p.fast_out = (fast && (!gbias || rows_per_group % bm == 0) && (long)p.ldc * 4 * 64 < (1L << 30) && !old_epilogue) ? 1 : 0;
     const bool n64 = !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !bias && !gbias && !stat_part && !sel_gamma &&
                      !accumulate && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
     if (n64) {
@@ -959,7 +1041,7 @@ int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const 
     if (accumulate) ns = 1;
     if (ns > 1 && c_bf16) return MLSP_ERR_UNSUPPORTED;                   // a split result is reduced in fp32
     if (stat_part && ns != 1) return MLSP_ERR_ARG;
-    p.accumulate = accumulate ? 1 : 0; p.c_bf16 = c_bf16;
+    p.accumulate = accumulate ? 1 : 0; p.c_bf16 = c_bf16; p.fast_out = 0;
     p.stat_part = stat_part; p.sel_gamma = nullptr; p.sel_val = nullptr; p.sel_row = nullptr;
     const int ktiles = (K + BK - 1) / BK;
     const int kts = (ktiles + ns - 1) / ns;

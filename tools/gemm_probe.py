@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 
 SRC = os.path.join(ROOT, "mlsp_amd", "csrc")
-FILES = ("api.hip", "gemm.hip", "knn.hip", "bn.hip", "edge.hip", "loss.hip", "tnet.hip", "colmax.hip", "labels.hip", "skinny.hip", "sa.hip", "corrupt.hip")
+FILES = ("api.hip", "gemm.hip", "knn.hip", "bn.hip", "edge.hip", "loss.hip", "tnet.hip", "colmax.hip", "labels.hip", "skinny.hip", "sa.hip", "corrupt.hip", "thin.hip")
 
 
 def build(flags, out):
@@ -21,7 +21,7 @@ def build(flags, out):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + objs)
 
 
-SHAPES = [("NT", 0, 1, 32768, 512, 512), ("NT", 0, 1, 32768, 1024, 512), ("NT", 0, 1, 32768, 256, 256), ("NT", 0, 1, 32768, 128, 256),
+SHAPES = [("NT", 0, 1, 32768, 256, 256), ("NN", 0, 0, 32768, 256, 256), ("NT", 0, 1, 32768, 128, 256)] if os.environ.get("GP_SHORT") else [("NT", 0, 1, 32768, 512, 512), ("NT", 0, 1, 32768, 1024, 512), ("NT", 0, 1, 32768, 256, 256), ("NT", 0, 1, 32768, 128, 256),
           ("NN", 0, 0, 32768, 512, 512), ("NN", 0, 0, 32768, 256, 256), ("TN", 1, 0, 512, 512, 32768), ("TN", 1, 0, 256, 256, 32768),
           ("NT", 0, 1, 32768, 512, 4096), ("NT", 0, 1, 8192, 8192, 1024)]
 
@@ -57,8 +57,33 @@ def time_lib(path):
             d = C.view(M, N)[0::bm, 0::128, ].reshape(-1)            # first element of every tile row 0
             T = C.view(M // bm, bm, N // 128, 128)[:, 0, :, :4].reshape(-1, 4).double().cpu()
             t_start = T[:, 0]
-            extra = " | per-block (us): prologue %.1f loop %.1f epilogue %.1f ; starts span %.0f us" % (
-                T[:, 1].mean() / 100, T[:, 2].mean() / 100, T[:, 3].mean() / 100, (t_start.max() - t_start.min()) / 100)
+            T = C.view(M // bm, bm, N // 128, 128)[:, 0, :, :6].reshape(-1, 6).double().cpu()
+            t_start = T[:, 0]
+            dur = T[:, 1] + T[:, 2] + T[:, 3]
+            if os.environ.get("GP_PERCU"):
+                hw = T[:, 4].long(); xcc = T[:, 5].long()
+                cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+                key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+                t0 = t_start.min()
+                print("  %s %dx%dx%d: %d distinct CUs" % (name, M, N, K, key.unique().numel()))
+                for x in range(8):
+                    m = xcc == x
+                    if m.sum() == 0: continue
+                    print("   xcc %d: blocks %d  CUs %d  loop mean %.1f min %.1f max %.1f  last end %.1f us" % (
+                        x, int(m.sum()), key[m].unique().numel(), T[m, 2].mean() / 100, T[m, 2].min() / 100, T[m, 2].max() / 100,
+                        ((t_start + dur)[m].max() - t0) / 100))
+                cnt = torch.bincount(key - key.min())
+                cnt = cnt[cnt > 0]
+                print("   blocks per CU: min %d max %d ; histogram %s" % (int(cnt.min()), int(cnt.max()), torch.bincount(cnt).tolist()))
+                # the blocks of the first few CUs: end of loop / end of block, relative to the kernel start
+                for k in key.unique()[:6].tolist():
+                    m = key == k
+                    print("   cu %d: start %s loop_end %s end %s" % (k, ((t_start[m] - t0) / 100).tolist(), ((t_start + T[:, 1] + T[:, 2] - t0)[m] / 100).tolist(),
+                                                                    ((t_start + dur - t0)[m] / 100).tolist()))
+            end = t_start + dur
+            extra = " | per-block (us): prologue %.1f loop %.1f (min %.1f max %.1f) epilogue %.1f (max %.1f); block total mean %.1f max %.1f; starts span %.0f us, kernel span (first start .. last end) %.1f us" % (
+                T[:, 1].mean() / 100, T[:, 2].mean() / 100, T[:, 2].min() / 100, T[:, 2].max() / 100, T[:, 3].mean() / 100, T[:, 3].max() / 100,
+                dur.mean() / 100, dur.max() / 100, (t_start.max() - t_start.min()) / 100, (end.max() - t_start.min()) / 100)
         out.append("%s %dx%dx%d %.0fus %.0fTF%s" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9, extra))
     return out
 
