@@ -34,7 +34,12 @@ struct GemmArgs {
     int a_vec, b_vec;               // 1 if float4 global loads are legal for that operand
     int xcd_map;                    // 1: XCD-grouped block->tile map (grid padded to a multiple of 8 panels)
     int accumulate;                 // 1: C += result (beta = 1): several consumers of one activation sum their input gradients in place
+    int fast_out;                   // 1: interior fp32 tiles may use the lean output pass (gemm_out_fast): set by launch_gemm
     int c_bf16;                     // 1: C holds bf16 (activation storage of BASELINE.json configs[4]); A / B element types are template arguments
+    // operand transform (XF != 0): the operand is the PRE-BatchNorm output of the previous layer and is turned into that layer's
+    // activated output while it is staged: act(x * scale[c] + shift[c]), dropout by the counter hash of element row * x_ld + c.
+    // XF == 1: A is [M][K] row-major, c = k.  XF == 2: B is [K][N] k-major (the wgrad's X), c = n.
+    const float* x_scale; const float* x_shift; int x_act; float x_slope; uint32_t x_thresh; float x_inv_keep; uint64_t x_seed; int x_ld;
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][N] (BN batch statistics)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
     float* sel_val; int* sel_row;   // [ntm][N] extreme of each 128-row panel and the global row attaining it (first occurrence)
@@ -108,6 +113,51 @@ __device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, 
     }
 }
 
+// ---- lean output pass of the interior-tile fp32 kernels -------------------------------------------------------------------------
+// Measured (tools/gemm_probe.py, GP_TIMELINE): while the other workgroups of a CU keep the matrix pipe full, every vector instruction
+// of a workgroup that has left its K loop waits about one MFMA issue slot (64+ clocks).  The generic epilogue below spends 10+ vector
+// and branch instructions per output element (64-bit address arithmetic, per-element predicates): 6-21 us per workgroup in which its
+// slot does no matrix work (1.5 us when it runs alone).  Here an element costs ONE buffer store (+ one add per bias term, two FMAs for
+// the BatchNorm sums): the wave's 32 x 64 (64 x 64) region gets a buffer descriptor whose base is the region's first element (scalar
+// arithmetic), the lane's offset inside it is one register, the row of accumulator register r is a scalar offset.
+// C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#define MLSP_BUF_FLAGS 0x00020000          // raw dword buffer, gfx94x / gfx950 (DATA_FORMAT = 32 bit)
+template <int WM, bool GB, bool ACC, bool ST>
+__device__ __forceinline__ void gemm_out_fast(const GemmArgs& p, f32x16 (&acc)[2][2], float* Cw, const float (&bv)[2], const float (&gv)[2],
+                                              int l31, int h, float (&cs)[2], float (&cq)[2]) {
+    const int ldc4 = p.ldc * 4;                                            // bytes per row (scalar)
+    const int voff = 4 * h * ldc4 + 4 * l31;                               // this lane inside the wave's region
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cw, 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+    const bool store = Cw != nullptr;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float old[16];
+            if (ACC) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4 + j * 128, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + bv[j];
+                if (GB) v += gv[j];
+                if (ACC) v += old[r];
+                if (ST) { cs[j] += v; cq[j] = fmaf(v, v, cq[j]); }
+                acc[i][j][r] = v;
+            }
+            if (store) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                {   // (a __builtin_bit_cast of the vector ELEMENT is miscompiled by this clang: every store took element 0)
+                    const float vv = acc[i][j][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv), rs, voff, (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4 + j * 128, 0);
+                }
+            }
+        }
+}
+
 // ---- epilogue shared by the fp32 and the bf16-operand kernels --------------------------------------------------------
 // acc: this wave's WM x 2 MFMA tiles of the block tile at (m0, n0); smem: the operand tiles, dead by now (scratch).
 template <int WM, bool FAST, bool CBF = false>
@@ -118,6 +168,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
     __bf16* Cb = (__bf16*)p.C;                            // CBF: bf16 output (never split: the slab is fp32)
     const bool epi = (p.nsplit == 1);
     float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
+    // interior fp32 tiles whose rows share one per-cloud bias row: the lean output pass (launch_gemm sets p.fast_out)
+    if (FAST && !CBF && p.fast_out) {
+        float bv[2] = {0.f, 0.f}, gv[2] = {0.f, 0.f};
+        if (epi && p.bias) { bv[0] = p.bias[n0 + wn * 64 + l31]; bv[1] = p.bias[n0 + wn * 64 + 32 + l31]; }
+        const bool gb = epi && p.gbias;
+        if (gb) {
+            const float* g = p.gbias + (size_t)(m0 / p.rows_per_group) * p.N + n0 + wn * 64 + l31;
+            gv[0] = g[0]; gv[1] = g[32];
+        }
+        float* Cw = p.C ? Cout + (size_t)(m0 + wm * (32 * WM)) * p.ldc + n0 + wn * 64 : nullptr;
+        if (epi && p.accumulate) gemm_out_fast<WM, false, true, false>(p, acc, Cw, bv, gv, l31, h, cs, cq);
+        else if (gb) gemm_out_fast<WM, true, false, true>(p, acc, Cw, bv, gv, l31, h, cs, cq);
+        else if (p.stat_part) gemm_out_fast<WM, false, false, true>(p, acc, Cw, bv, gv, l31, h, cs, cq);
+        else gemm_out_fast<WM, false, false, false>(p, acc, Cw, bv, gv, l31, h, cs, cq);
+    } else
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -131,10 +196,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
                 if (FAST || row < p.M) {
                     float v = acc[i][j][r] + bv;
                     if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
+                    if (epi && p.accumulate) v += CBF ? (float)Cb[(size_t)row * p.ldc + col] : Cout[(size_t)row * p.ldc + col];
 #ifdef GP_NOSTORE
                     if (p.C && v == 12345.678f) Cout[(size_t)row * p.ldc + col] = v;
 #else
-                    if (p.C) Cout[(size_t)row * p.ldc + col] = v;
+                    if (CBF) { if (p.C) Cb[(size_t)row * p.ldc + col] = (__bf16)v; }
+                    else if (p.C) Cout[(size_t)row * p.ldc + col] = v;
 #endif
                     cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
                     acc[i][j][r] = v;
@@ -203,7 +270,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
 
 // WM = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile; 1 -> 64x128 (twice the workgroups, for launches whose
 // 128-row grid is too small to keep ~3 workgroups per CU in flight and out of phase)
-template <bool TA, bool TB, int WM, bool FAST>
+// one staged f32x4 of an operand under the transform: c0 = first channel of the quad (channels contiguous when XF == 1 / 2 alike),
+// e0 = element index (row * x_ld + c0) of its first value
+__device__ __forceinline__ f32x4 xf_quad(const GemmArgs& p, f32x4 v, const f32x4& xs, const f32x4& xh, uint64_t e0) {
+    // x_slope here is the EFFECTIVE negative-side factor in [0, 1] (0 for ReLU, 1 for no activation: launch_gemm), so the activation
+    // is one max: max(a, a * s) == (a > 0 ? a : a * s).  The dropout rescale is applied exactly as bn_act_fwd does (a * inv_keep).
+    const uint32_t hq = p.x_thresh ? dropout_hash4(p.x_seed, e0 >> 2) : 0u;  // e0 is a multiple of 4: one hash for the quad
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = fmaf(v[e], xs[e], xh[e]);
+        a = fmaxf(a, a * p.x_slope);
+        if (p.x_thresh) a = ((hq >> (8 * e)) & 255u) >= p.x_thresh ? a * p.x_inv_keep : 0.f;
+        v[e] = a;
+    }
+    return v;
+}
+
+template <bool TA, bool TB, int WM, bool FAST, int XF = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     constexpr int BMT = 64 * WM, NPA = 2 * WM;
     // A tile is k-major in LDS either way; its GLOBAL source is k-major iff TA.  B's source is
@@ -217,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     float* Bs = smem + BM * SROW;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the output pass addresses with it
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -244,6 +327,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     const long long tl0 = wall_clock64();
     long long tl1 = 0;
 #endif
+#ifdef GP_DEPHASE
+    {   // co-resident workgroups get distinct issue priorities: they drift out of phase, one's C stores run under another's MFMAs
+#if GP_DEPHASE == 1
+        const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 3u;        // HW_ID.wave_id[3:0] & 3
+#elif GP_DEPHASE == 2
+        const unsigned slot = ((unsigned)bid >> 3) & 3u;
+#else
+        const unsigned slot = ((unsigned)bid >> 8) & 3u;
+#endif
+        if (slot == 0) __builtin_amdgcn_s_setprio(0);
+        else if (slot == 1) __builtin_amdgcn_s_setprio(1);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -256,6 +354,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     // FAST: this thread's source pointers (advance by one K-tile per iteration)
     const float* pa = nullptr;
     const float* pb = nullptr;
+    // XF (FAST, fp32 only): scale / shift of this thread's channel quad.  XF == 1: the k-quad of the A tile held in ra (reloaded with
+    // every tile); XF == 2: the n-quad of B (fixed).
+    f32x4 xs = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
+    static_assert(XF == 0 || FAST, "operand transform: interior tiles only");
+    static_assert(XF != 1 || !TA, "XF == 1: A row-major");
+    static_assert(XF != 2 || !TB, "XF == 2: B k-major");
     if (FAST) {
         pa = TA ? p.A + (size_t)(kbeg + (NPA == 4 ? (tid >> 5) : (tid >> 4))) * p.lda + m0 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 4
                 : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
@@ -263,11 +367,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                  : p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + kbeg + (tid & 7) * 4;
         g2r_fast<TA, NPA>(ra, pa, p.lda);
         g2r_fast<!TB, 4>(rb, pb, p.ldb);
+        if (XF == 1) { xs = *(const f32x4*)(p.x_scale + kbeg + (tid & 7) * 4); xh = *(const f32x4*)(p.x_shift + kbeg + (tid & 7) * 4); }
+        if (XF == 2) { xs = *(const f32x4*)(p.x_scale + n0 + (tid & 31) * 4); xh = *(const f32x4*)(p.x_shift + n0 + (tid & 31) * 4); }
     } else {
         g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid);
         g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid);
     }
 
+    // XF: the staged registers of the tile at kt become the previous layer's activated output.  The first tile is transformed here;
+    // every later one in the MIDDLE of the MFMA loop of the tile before it (its loads have landed by then and the vector work runs
+    // under the matrix pipe instead of in front of the LDS writes, where all four waves would wait on it).
+    auto xf_tile = [&](int kt) {
+        if (XF == 1) {                                    // rows m0 + (tid >> 3) + 32 q, channels kt + 4 (tid & 7) ..
+#pragma unroll
+            for (int q = 0; q < NPA; ++q)
+                ra[q] = xf_quad(p, ra[q], xs, xh, (uint64_t)(m0 + (tid >> 3) + 32 * q) * p.x_ld + kt + (tid & 7) * 4);
+        }
+        if (XF == 2) {                                    // rows (points) kt + (tid >> 5) + 8 q, channels n0 + 4 (tid & 31) ..
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                rb[q] = xf_quad(p, rb[q], xs, xh, (uint64_t)(kt + (tid >> 5) + 8 * q) * p.x_ld + n0 + (tid & 31) * 4);
+        }
+    };
+    if (XF) xf_tile(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #ifdef GP_NOR2S
         if (k0 == kbeg)
@@ -290,6 +412,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                 pb += !TB ? (size_t)BK * p.ldb : BK;
                 g2r_fast<TA, NPA>(ra, pa, p.lda);
                 g2r_fast<!TB, 4>(rb, pb, p.ldb);
+                if (XF == 1) {
+                    xs = *(const f32x4*)(p.x_scale + k0 + BK + (tid & 7) * 4); xh = *(const f32x4*)(p.x_shift + k0 + BK + (tid & 7) * 4);
+                }
             } else {
                 g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid);
                 g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid);
@@ -307,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 #ifdef GP_IGLP
             __builtin_amdgcn_iglp_opt(GP_IGLP);
 #endif
+            if (XF && m == BK / 8 && k0 + BK < kend) xf_tile(k0 + BK);
             const int kq = 4 * m + 2 * h;
             float a0s0, a0s1, a1s0, a1s1, b0s0, b0s1, b1s0, b1s1;
             a1s0 = 0.f; a1s1 = 0.f;
@@ -356,8 +482,82 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
         const long long tl3 = wall_clock64();
         float* dbg = p.C + (size_t)m0 * p.ldc + n0;
         dbg[0] = (float)(tl0 & 0xffffff); dbg[1] = (float)(tl1 - tl0); dbg[2] = (float)(tl2 - tl1); dbg[3] = (float)(tl3 - tl2);
+        dbg[4] = (float)(__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4));      // HW_ID[15:0]: wave, simd, pipe, cu, sh, se
+        dbg[5] = (float)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20));      // XCC_ID
     }
 #endif
+}
+
+// ---- N = 64 variant: 128 x 64 x 32 tiles, the four waves stacked along M (32 rows x 64 columns each) -----------------------------
+// The dgrads into a 64-channel input (dx = duv * Wd of EdgeConv 2 / 3) and their wgrads have N = 64: on the 128-column tile half of
+// every B stage and half of the MFMA columns are padding (17-31 TF).  Interior shapes only (M % 128 == 0, K-range % 32 == 0, 16-byte
+// aligned operands), plain / split-K output, no fused epilogue.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f32_n64_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[BM * SROW + 64 * SROW + 32 * 64];
+    float* As = smem;                              // row-major image [128][36] or k-major [32][128]
+    float* Bs = smem + BM * SROW;                  // row-major image [64][36]  or k-major [32][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tm = blockIdx.x, split = blockIdx.y;
+    const int m0 = tm * 128;
+    const int kbeg = split * p.ksplit, kend = min(p.K, kbeg + p.ksplit);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    f32x4 ra[4], rb[4];
+    const float* pa = TA ? p.A + (size_t)(kbeg + (tid >> 5)) * p.lda + m0 + (tid & 31) * 4
+                         : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
+    const float* pb = !TB ? p.B + (size_t)(kbeg + (tid >> 4)) * p.ldb + (tid & 15) * 4
+                          : p.B + (size_t)(tid >> 3) * p.ldb + kbeg + (tid & 7) * 4;
+    g2r_fast<TA, 4>(ra, pa, p.lda);
+    g2r_fast<!TB, 2>(rb, pb, p.ldb);
+    constexpr int BSK = 64;                        // k-major B image stride
+    const int arow = wave * 32 + l31;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        r2s<TA, 4>(ra, As, tid);
+        if (TB) r2s<false, 2>(rb, Bs, tid);
+        else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *(f32x4*)(Bs + ((tid >> 4) + 16 * q) * BSK + (tid & 15) * 4) = rb[q];
+        }
+        __syncthreads();
+        if (k0 + BK < kend) {
+            pa += TA ? (size_t)BK * p.lda : BK;
+            pb += !TB ? (size_t)BK * p.ldb : BK;
+            g2r_fast<TA, 4>(ra, pa, p.lda);
+            g2r_fast<!TB, 2>(rb, pb, p.ldb);
+        }
+#pragma unroll
+        for (int m = 0; m < BK / 4; ++m) {
+            const int kq = 4 * m + 2 * h;
+            float a0, a1, b00, b01, b10, b11;
+            if (!TA) { const float2 t = *(const float2*)(As + arow * SROW + kq); a0 = t.x; a1 = t.y; }
+            else { a0 = As[kq * SKMJ + arow]; a1 = As[(kq + 1) * SKMJ + arow]; }
+            if (TB) {
+                const float2 t0 = *(const float2*)(Bs + l31 * SROW + kq), t1 = *(const float2*)(Bs + (l31 + 32) * SROW + kq);
+                b00 = t0.x; b01 = t0.y; b10 = t1.x; b11 = t1.y;
+            } else {
+                b00 = Bs[kq * BSK + l31]; b01 = Bs[(kq + 1) * BSK + l31];
+                b10 = Bs[kq * BSK + l31 + 32]; b11 = Bs[(kq + 1) * BSK + l31 + 32];
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b00, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b10, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b01, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b11, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            Cout[(size_t)row * p.ldc + j * 32 + l31] = acc[j][r];
+        }
 }
 
 // ---- bf16-operand variant (opt-in, mlsp_set_gemm_precision(1); BASELINE.json configs[4]) -------------------------------
@@ -709,18 +909,31 @@ int launch_skinny_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, co
 int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                      int ldc, const float* bias, float* slab, size_t slab_floats);
 
+// Can this contraction stage `which` (1: A [M][K] row-major, 2: B [K][N] k-major) through the operand transform?  Interior tiles,
+// 16-byte loads, fp32 operands, the MFMA tile kernels (not the thin / skinny / N = 64 ones).
+bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which) {
+    if (g_gemm_precision != 0) return false;
+    if (which == 1 ? ta : !(ta && !tb)) return false;
+    if (M <= 32 || N < 32 || K < 32 || (ta && !tb && K <= 32)) return false;
+    const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    int ns = gemm_pick_split(M, N, K);
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
+    return vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+}
+
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                 size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
-                int* sel_row = nullptr, bool accumulate = false) {
+                int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
+    if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
     // one tiny dimension (3 coordinates, 3 / 16 outputs): streaming VALU kernels priced against HBM, not MFMA tiles (thin.hip)
-    if (!gbias && !stat_part && !sel_gamma && !accumulate) {
+    if (!gbias && !stat_part && !sel_gamma && !accumulate && !xf) {
         const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
     // per-cloud layers (<= 32 rows, or a 32-deep wgrad): one-pass skinny kernels, no split-K slab (skinny.hip)
-    if (!gbias && !stat_part && !sel_gamma && !accumulate && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
+    if (!gbias && !stat_part && !sel_gamma && !accumulate && !xf && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
         const int rc = launch_skinny_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
@@ -733,9 +946,16 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;   // no slab: fall back to one pass
     if (accumulate) ns = 1;                                              // beta = 1 lives in the one-pass epilogue
     p.accumulate = accumulate ? 1 : 0;
+    p.fast_out = 0;
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
     p.stat_part = stat_part;
     p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
+    p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0;
+    if (xf) {
+        p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_thresh = xf->thresh;
+        p.x_slope = xf->act == 0 ? 1.f : xf->act == 1 ? 0.f : xf->slope;          // effective negative-side factor (xf_quad)
+        p.x_inv_keep = xf->inv_keep; p.x_seed = xf->seed; p.x_ld = xf->ld;
+    }
     int ktiles = (K + BK - 1) / BK;
     int kts = (ktiles + ns - 1) / ns;
     ns = (ktiles + kts - 1) / kts;
@@ -751,10 +971,32 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
     const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+    static const bool old_epilogue = getenv("MLSP_GEMM_OLD_EPILOGUE") != nullptr;       // read-once A/B switch (tools/ab)
+    // lean output pass: every row of a tile takes the same per-cloud bias row, byte offsets inside a wave's region fit 31 bits
+    p.fast_out = (fast && (!gbias || rows_per_group % bm == 0) && (long)p.ldc * 4 * 64 < (1L << 30) && !old_epilogue) ? 1 : 0;
+    const bool n64 = !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !bias && !gbias && !stat_part && !sel_gamma &&
+                     !accumulate && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
+    if (n64) {
+        dim3 g64(M / 128, ns);
+        if (!ta && tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, true>), g64, dim3(256), 0, st, p);
+        else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, false>), g64, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_f32_n64_kernel<true, false>), g64, dim3(256), 0, st, p);
+    } else
 #define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
-    if (bm == 128) {
+    if (xf) {                                             // operand transform: FAST fp32 instantiations only (gemm_xf_supported)
+        if (xf->which == 1 && tb) {
+            if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, true, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, true, 1>), grid, dim3(256), 0, st, p);
+        } else if (xf->which == 1) {
+            if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, true, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1, true, 1>), grid, dim3(256), 0, st, p);
+        } else {
+            if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2, true, 2>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1, true, 2>), grid, dim3(256), 0, st, p);
+        }
+    } else if (bm == 128) {
         if (!ta && tb) GEMM_GO(false, true, 2);
         else if (!ta && !tb) GEMM_GO(false, false, 2);
         else if (ta && !tb) GEMM_GO(true, false, 2);
@@ -799,7 +1041,7 @@ int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const 
     if (accumulate) ns = 1;
     if (ns > 1 && c_bf16) return MLSP_ERR_UNSUPPORTED;                   // a split result is reduced in fp32
     if (stat_part && ns != 1) return MLSP_ERR_ARG;
-    p.accumulate = accumulate ? 1 : 0; p.c_bf16 = c_bf16;
+    p.accumulate = accumulate ? 1 : 0; p.c_bf16 = c_bf16; p.fast_out = 0;
     p.stat_part = stat_part; p.sel_gamma = nullptr; p.sel_val = nullptr; p.sel_row = nullptr;
     const int ktiles = (K + BK - 1) / BK;
     const int kts = (ktiles + ns - 1) / ns;
