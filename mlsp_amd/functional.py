@@ -499,12 +499,15 @@ class _PointMLP(Function):
         ctx.mx = (mx, x_bf16, out_bf16)
         if bn_save is not None:
             ctx.mark_non_differentiable(bn_save)
+        ctx.set_materialize_grads(False)       # (autograd would zero-fill a [4, Cout] gradient for bn_save on every backward: 11 fills a step)
         # a deferred layer hands out its pre-BN output: Y is both saved and returned (same storage, nobody writes to it)
         return (Y.view_as(Y) if defer_out else Z), bn_save
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dZ, _dbn=None):
+        if dZ is None:
+            return (None,) * 21
         lib = _lib.load()
         X, W, Y, bn_save = ctx.saved_tensors
         has_bn, training, act, slope, p, seed, has_bias, G, rpg = ctx.cfg

@@ -97,6 +97,20 @@ __device__ __forceinline__ void g2r_fast(f32x4 (&r)[4], const float* __restrict_
     }
 }
 
+// The same loads through a buffer descriptor: the tile origin is the descriptor's base (scalar), the thread's place inside the tile
+// one register that never changes, the K-tile / pass advance a scalar offset -- no vector instruction in the K loop computes an address
+// (a vector instruction of a wave whose neighbours keep the matrix pipe full waits for an MFMA slot: see gemm_out_fast).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <bool SRC_KMAJOR, int NP>
+__device__ __forceinline__ void g2r_buf(f32x4 (&r)[4], __amdgpu_buffer_rsrc_t rs, int voff, int soff, int ld4) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int step = (!SRC_KMAJOR ? 32 : (NP == 4 ? 8 : 16)) * p * ld4;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + step, 0);
+        r[p][0] = __uint_as_float(v[0]); r[p][1] = __uint_as_float(v[1]); r[p][2] = __uint_as_float(v[2]); r[p][3] = __uint_as_float(v[3]);
+    }
+}
+
 template <bool SRC_KMAJOR, int NP>
 __device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, int tid) {
 #pragma unroll
@@ -351,22 +365,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[4], rb[4];
-    // FAST: this thread's source pointers (advance by one K-tile per iteration)
-    const float* pa = nullptr;
-    const float* pb = nullptr;
     // XF (FAST, fp32 only): scale / shift of this thread's channel quad.  XF == 1: the k-quad of the A tile held in ra (reloaded with
     // every tile); XF == 2: the n-quad of B (fixed).
     f32x4 xs = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
     static_assert(XF == 0 || FAST, "operand transform: interior tiles only");
     static_assert(XF != 1 || !TA, "XF == 1: A row-major");
     static_assert(XF != 2 || !TB, "XF == 2: B k-major");
+    // FAST: buffer descriptors based at the tile's first element of this K range; voa / vob = this thread's byte offset inside the tile
+    __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, MLSP_BUF_FLAGS), rsb = rsa;
+    int voa = 0, vob = 0, soa = 0, sob = 0;
+    const int lda4 = p.lda * 4, ldb4 = p.ldb * 4;
     if (FAST) {
-        pa = TA ? p.A + (size_t)(kbeg + (NPA == 4 ? (tid >> 5) : (tid >> 4))) * p.lda + m0 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 4
-                : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
-        pb = !TB ? p.B + (size_t)(kbeg + (tid >> 5)) * p.ldb + n0 + (tid & 31) * 4
-                 : p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + kbeg + (tid & 7) * 4;
-        g2r_fast<TA, NPA>(ra, pa, p.lda);
-        g2r_fast<!TB, 4>(rb, pb, p.ldb);
+        rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(TA ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg), 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+        rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(!TB ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg), 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+        voa = TA ? (NPA == 4 ? (tid >> 5) : (tid >> 4)) * lda4 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 16 : (tid >> 3) * lda4 + (tid & 7) * 16;
+        vob = !TB ? (tid >> 5) * ldb4 + (tid & 31) * 16 : (tid >> 3) * ldb4 + (tid & 7) * 16;
+        g2r_buf<TA, NPA>(ra, rsa, voa, soa, lda4);
+        g2r_buf<!TB, 4>(rb, rsb, vob, sob, ldb4);
         if (XF == 1) { xs = *(const f32x4*)(p.x_scale + kbeg + (tid & 7) * 4); xh = *(const f32x4*)(p.x_shift + kbeg + (tid & 7) * 4); }
         if (XF == 2) { xs = *(const f32x4*)(p.x_scale + n0 + (tid & 31) * 4); xh = *(const f32x4*)(p.x_shift + n0 + (tid & 31) * 4); }
     } else {
@@ -408,10 +423,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
         if (k0 + BK < kend) {
 #endif
             if (FAST) {
-                pa += TA ? (size_t)BK * p.lda : BK;
-                pb += !TB ? (size_t)BK * p.ldb : BK;
-                g2r_fast<TA, NPA>(ra, pa, p.lda);
-                g2r_fast<!TB, 4>(rb, pb, p.ldb);
+                soa += TA ? BK * lda4 : BK * 4;
+                sob += !TB ? BK * ldb4 : BK * 4;
+                g2r_buf<TA, NPA>(ra, rsa, voa, soa, lda4);
+                g2r_buf<!TB, 4>(rb, rsb, vob, sob, ldb4);
                 if (XF == 1) {
                     xs = *(const f32x4*)(p.x_scale + k0 + BK + (tid & 7) * 4); xh = *(const f32x4*)(p.x_shift + k0 + BK + (tid & 7) * 4);
                 }
@@ -918,7 +933,7 @@ bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, in
     const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
     int ns = gemm_pick_split(M, N, K);
     const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
-    return vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+    return vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0) && (long)(ta ? M : K) * lda * 4 < (1L << 30) && (long)K * ldb * 4 < (1L << 30);
 }
 
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
@@ -970,7 +985,10 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     const bool prof = g_prof.on && g_prof.used < PROF_MAX_PAIRS;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
-    const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+    // (byte offsets inside an operand tile's K range are 32-bit buffer offsets)
+    const long a_span = ta ? (long)p.ksplit * lda * 4 : 128L * lda * 4 + (long)p.ksplit * 4;
+    const long b_span = !tb ? (long)p.ksplit * ldb * 4 : 128L * ldb * 4 + (long)p.ksplit * 4;
+    const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0) && a_span < (1L << 31) - 4096 && b_span < (1L << 31) - 4096;
     static const bool old_epilogue = getenv("MLSP_GEMM_OLD_EPILOGUE") != nullptr;       // read-once A/B switch (tools/ab)
     // lean output pass: every row of a tile takes the same per-cloud bias row, byte offsets inside a wave's region fit 31 bits
     p.fast_out = (fast && (!gbias || rows_per_group % bm == 0) && (long)p.ldc * 4 * 64 < (1L << 30) && !old_epilogue) ? 1 : 0;
