@@ -19,7 +19,6 @@
 // Block -> tile mapping keeps all column tiles of one 128-row panel on one XCD (blockIdx % 8 is the
 // XCD label under round-robin dispatch), so the activation panel is fetched into one L2 only.
 #include "common.h"
-#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -846,8 +845,7 @@ int gemm_pick_split(int M, int N, int K) {
     long tiles = (long)ntm * ntn;
     int ktiles = (K + BK - 1) / BK;
     if (tiles >= 256 || ktiles < 4) return 1;
-    static const int want_blocks = getenv("MLSP_GEMM_SPLIT_WANT") ? atoi(getenv("MLSP_GEMM_SPLIT_WANT")) : 512;     // (experiment switch)
-    long want = (want_blocks + tiles - 1) / tiles;          // aim at ~2 blocks per CU (measured: 320 is 35 % slower on the wgrad shapes)
+    long want = (512 + tiles - 1) / tiles;          // aim at ~2 blocks per CU (measured: 320 is 35 % slower on the wgrad shapes; 768 / 1024 and 64-row tiles for the split launches: no gain)
     int ns = (int)(want < ktiles / 2 ? want : ktiles / 2);
     if (ns < 1) ns = 1;
     if (ns > 256) ns = 256;
@@ -976,8 +974,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     int ktiles = (K + BK - 1) / BK;
     int kts = (ktiles + ns - 1) / ns;
     ns = (ktiles + kts - 1) / kts;
-    static const int split_bm = getenv("MLSP_GEMM_SPLIT_BM") ? atoi(getenv("MLSP_GEMM_SPLIT_BM")) : 128;               // (experiment switch)
-    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : (M % 64 == 0 && M >= 128 ? split_bm : 128);
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
     p.ntm = (M + bm - 1) / bm; p.ntn = (N + BN - 1) / BN;
     p.nsplit = ns; p.ksplit = kts * BK;
     p.a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
@@ -1067,8 +1064,7 @@ int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const 
     const int ktiles = (K + BK - 1) / BK;
     const int kts = (ktiles + ns - 1) / ns;
     ns = (ktiles + kts - 1) / kts;
-    static const int split_bm = getenv("MLSP_GEMM_SPLIT_BM") ? atoi(getenv("MLSP_GEMM_SPLIT_BM")) : 128;               // (experiment switch)
-    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : (M % 64 == 0 && M >= 128 ? split_bm : 128);
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
     p.ntm = (M + bm - 1) / bm; p.ntn = (N + BN - 1) / BN;
     p.nsplit = ns; p.ksplit = kts * BK;
     const bool a_ok = a_bf16 ? (lda % 8 == 0) : (lda % 4 == 0), b_ok = b_bf16 ? (ldb % 8 == 0) : (ldb % 4 == 0);
