@@ -69,9 +69,7 @@ int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int
                       int act, float slope, float p_drop, uint64_t seed);
 int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* scale,
                       const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
-                      float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy,
-                      float* gpart = nullptr, int rows_per_group = 0, int* gpart_slabs = nullptr);
-int launch_colsum_groups_fin(hipStream_t st, const float* scratch, int G, int C, int slabs, float* out);
+                      float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy);
 int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out, float* scratch = nullptr);
 int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out);
 int launch_colmax_fwd(hipStream_t st, const float* Z, int B, int N, int C, float* out, int* arg);
@@ -545,16 +543,13 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     }
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float* g = dZ;   // gradient wrt the linear output
-    int g_slabs = 0;       // > 0: launch_bn_act_bwd already left the per-group partial sums of dY in gscratch
     if (has_bn && M <= 32) {
         CHECK(launch_skinny_bn_bwd(st, dZ, Y, dY, M, Cout, bn_save, training, act, slope, p_drop, seed, dgamma, dbeta));
         g = dY;
     } else if (has_bn) {
         const float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
-        // (the per-cloud bias gradient -- column sums of dY per cloud -- comes out of the same pass when the shape allows)
         CHECK(launch_bn_act_bwd(st, dZ, Y, dY, M, Cout, scale, shift, mean, invstd, training, act, slope,
-                                training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy, dgbias ? gscratch : nullptr,
-                                rows_per_group, &g_slabs));
+                                training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy));
         g = dY;
     }
     if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf, nullptr, nullptr,
@@ -570,10 +565,7 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
             CHECK(launch_colsum(st, g, M, Cout, part, dbias));
         }
     }
-    if (dgbias) {
-        if (g_slabs > 0) CHECK(launch_colsum_groups_fin(st, gscratch, n_groups, Cout, g_slabs, dgbias));
-        else CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias, gscratch));
-    }
+    if (dgbias) CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias, gscratch));
     return MLSP_OK;
 }
 

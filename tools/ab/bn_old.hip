@@ -325,17 +325,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const TY* __r
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    const float* __restrict__ mean_dz,
                                                                    const float* __restrict__ mean_dzy, int act, float slope,
-                                                                   uint32_t thresh, float inv_keep, uint64_t seed,
-                                                                   float* __restrict__ gpart) {
-    // gpart (fp32 storage, 256 % (C / 4) == 0, a block's VROWS rows inside one group): this block's column sums of dY, laid out and
-    // summed exactly as colsum_groups_vec_kernel does with one slab per block -- the per-cloud bias gradient of the heads' first
-    // layer without reading dY again (colsum_groups_fin_kernel finishes it)
-    __shared__ float shd[256 * 4];
+                                                                   uint32_t thresh, float inv_keep, uint64_t seed) {
     const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
     const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
-    if (rg >= nrg) return;                                              // (never with gpart: nrg * tpr == 256)
+    if (rg >= nrg) return;
     const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
-    f32x4 gs = {0.f, 0.f, 0.f, 0.f};
     f32x4 mu = {0, 0, 0, 0}, k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0};      // d - k1 - (y - mu)*k2
     if (mean_dz) {
         mu = *(const f32x4*)(mean + c);
@@ -357,20 +351,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const TY* __r
             o[e] = sc[e] * d;
         }
         st4<TY>(dY + i, o);
-        gs = gs + o;
-    }
-    if (gpart) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) shd[tid * 4 + e] = gs[e];
-        __syncthreads();
-        if (tid < tpr) {
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int q = 0; q < nrg; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] += shd[(q * tpr + tid) * 4 + e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gpart[(size_t)blockIdx.x * C + tid * 4 + e] = a[e];
-        }
     }
 }
 
@@ -519,16 +499,11 @@ int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int
 int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* scale,
                       const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
                       float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz,
-                      float* mean_dzy, float* gpart, int rows_per_group, int* gpart_slabs) {
-    // gpart / gpart_slabs (nullable): ask for the per-group column sums of dY as a by-product; *gpart_slabs is set to the slab count
-    // written per group ([G][slabs][C] floats, finish with launch_colsum_groups_fin) or to 0 when this shape does not fuse them
-    if (gpart_slabs) *gpart_slabs = 0;
+                      float* mean_dzy) {
     float inv_keep = dropout_inv_keep8(p_drop);
     uint32_t th = drop_thresh(p_drop);
     int nparts = bn_stat_parts(M);
     const bool vec = vec_ok(C, dZ, Y, dY) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0);
-    const bool fuse_g = vec && gpart && gpart_slabs && rows_per_group > 0 && rows_per_group % VROWS == 0 && rows_per_group / VROWS <= 16 &&
-                        M % rows_per_group == 0;
     if (vec) {
         nparts = bn_vec_parts(M);
         hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<float>), dim3(nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift, mean, invstd,
@@ -543,8 +518,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
     if (vec) {
         hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C,
                            scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th,
-                           inv_keep, seed, fuse_g ? gpart : (float*)nullptr);
-        if (fuse_g) *gpart_slabs = rows_per_group / VROWS;
+                           inv_keep, seed);
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dZ, Y, dY, total, C, scale, shift,
@@ -613,12 +587,6 @@ int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_gro
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(colsum_groups_kernel, dim3((C + 63) / 64, G), dim3(256), 0, st, X, C, rows_per_group, out);
-    return mlsp_launch_status();
-}
-
-// second half of launch_colsum_groups alone: scratch [G][slabs][C] written by bn_act_bwd_apply_vec_kernel (launch_bn_act_bwd, gpart)
-int launch_colsum_groups_fin(hipStream_t st, const float* scratch, int G, int C, int slabs, float* out) {
-    hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 255) / 256), dim3(256), 0, st, scratch, G, C, slabs, out);
     return mlsp_launch_status();
 }
 
@@ -697,7 +665,7 @@ int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* d
                        shift, mean, invstd, act, slope, th, inv_keep, seed, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy);
     hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, (__bf16*)dY,
-                       M, C, scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed, (float*)nullptr);
+                       M, C, scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed);
     return mlsp_launch_status();
 }
 int launch_colsum_groups_b16(hipStream_t st, const void* X, int G, int rows_per_group, int C, float* out, float* scratch) {
