@@ -280,61 +280,74 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd2_kernel(TnetFwdArgs p) {
             }
         }
         __syncthreads();
-        // ---- Z = H W2^T for this wave's 32 columns, all 5 row blocks
+        // ---- Z = H W2^T for this wave's 32 columns, one row block after the other; the register epilogue of block b - 1 (per point
+        //      max / min over its K rows with the first arg-max, BN2 sums: ~6 vector instructions per element) is issued BETWEEN the
+        //      MFMAs of block b.  A vector instruction that has to squeeze in between another wave's back-to-back MFMAs waits about one
+        //      MFMA slot (gemm.hip, gemm_out_fast); inside the issuing wave's own MFMA stream it is free: the matrix pipe is busy for 64
+        //      clocks per MFMA and the wave's next instructions issue meanwhile.  Only the last block's epilogue stays exposed.
+        //      (Accumulation order per block and the order of the sums are those of the all-blocks-at-once form: bitwise the same.)
+        //      Measured: forward op 228 -> 219 us.  Also moving BN1 + activation from the staging pass to the fragment reads (6 more
+        //      vector instructions and three more LDS reads per MFMA pair) loses that again: 233 us.
         f32x16 acc[5];
-#pragma unroll
-        for (int b = 0; b < 5; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-#ifndef TF_PROBE_NOMFMA
-#pragma unroll
-        for (int mm = 0; mm < 16; ++mm) {
-            float2 a[5];
-#pragma unroll
-            for (int b = 0; b < 5; ++b) a[b] = *(const float2*)(Hs + (32 * b + l31) * TF_PITCH + 4 * mm + 2 * h);
-#pragma unroll
-            for (int b = 0; b < 5; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b].x, w2[mm].x, acc[b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < 5; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b].y, w2[mm].y, acc[b], 0, 0, 0);
-        }
-#else
-#pragma unroll
-        for (int b = 0; b < 5; ++b) acc[b][0] = Hs[(32 * b + l31) * TF_PITCH + h] * w2[b].x;
-#endif
-        // ---- epilogue in registers: per point max (or min) over its K rows with the first arg-max, BN2 sums over all rows
         float best[PT];
         int bslot[PT];
 #pragma unroll
         for (int q = 0; q < PT; ++q) { best[q] = use_max ? -INFINITY : INFINITY; bslot[q] = 0; }
         float s1 = 0.f, s2 = 0.f;
+        auto epi = [&](int b, int r) {                                 // (b, r) are compile-time after unrolling
+            const int q = r >> 2, e = r & 3;
+            const int G0 = 8 * b + 2 * q;                              // 4-row group index of lane half 0 (half 1: G0 + 1)
+            const int p0 = G0 / GP, r0 = G0 % GP;
+            const bool cross = (r0 == GP - 1);                         // half 1's group belongs to the next point
+            const float v = acc[b][r];
+            s1 += v; s2 = fmaf(v, v, s2);
+            if (!cross) {
+                const int slot = 4 * (r0 + h) + e;
+                const bool take = use_max ? (v > best[p0]) : (v < best[p0]);
+                best[p0] = take ? v : best[p0]; bslot[p0] = take ? slot : bslot[p0];
+            } else {
+                {
+                    const bool take = h == 0 && (use_max ? (v > best[p0]) : (v < best[p0]));
+                    best[p0] = take ? v : best[p0]; bslot[p0] = take ? 4 * (GP - 1) + e : bslot[p0];
+                }
+                if (p0 + 1 < PT) {
+                    const bool take = h == 1 && (use_max ? (v > best[p0 + 1]) : (v < best[p0 + 1]));
+                    best[p0 + 1] = take ? v : best[p0 + 1]; bslot[p0 + 1] = take ? e : bslot[p0 + 1];
+                }
+            }
+        };
+#ifndef TF_PROBE_NOMFMA
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+            const float* hrow = Hs + (32 * b + l31) * TF_PITCH + 2 * h;
+            float2 a_cur = *(const float2*)hrow;
+#pragma unroll
+            for (int mm = 0; mm < 16; ++mm) {
+                float2 a_nxt = a_cur;
+                if (mm + 1 < 16) a_nxt = *(const float2*)(hrow + 4 * (mm + 1));
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, w2[mm].x, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, w2[mm].y, acc[b], 0, 0, 0);
+                if (b > 0) epi(b - 1, mm);
+                __builtin_amdgcn_sched_barrier(0);
+                a_cur = a_nxt;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) epi(4, r);
+#else
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+            acc[b][0] = Hs[(32 * b + l31) * TF_PITCH + h] * w2[b].x;
+        }
 #pragma unroll
         for (int b = 0; b < 5; ++b)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                constexpr int dummy = 0; (void)dummy;
-                const int G0 = 8 * b + 2 * q;                          // 4-row group index of lane half 0 (half 1: G0 + 1)
-                const int p0 = G0 / GP, r0 = G0 % GP;
-                const bool cross = (r0 == GP - 1);                     // half 1's group belongs to the next point
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = acc[b][4 * q + e];
-                    s1 += v; s2 = fmaf(v, v, s2);
-                    if (!cross) {
-                        const int slot = 4 * (r0 + h) + e;
-                        const bool take = use_max ? (v > best[p0]) : (v < best[p0]);
-                        best[p0] = take ? v : best[p0]; bslot[p0] = take ? slot : bslot[p0];
-                    } else {
-                        {
-                            const bool take = h == 0 && (use_max ? (v > best[p0]) : (v < best[p0]));
-                            best[p0] = take ? v : best[p0]; bslot[p0] = take ? 4 * (GP - 1) + e : bslot[p0];
-                        }
-                        if (p0 + 1 < PT) {
-                            const bool take = h == 1 && (use_max ? (v > best[p0 + 1]) : (v < best[p0 + 1]));
-                            best[p0 + 1] = take ? v : best[p0 + 1]; bslot[p0 + 1] = take ? e : bslot[p0 + 1];
-                        }
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r) epi(b, r);
+#endif
         ssum += s1; ssq += s2;
 #pragma unroll
         for (int q = 0; q < PT; ++q) {

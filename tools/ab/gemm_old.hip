@@ -1,0 +1,1017 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, exact f32,
+// 157 TFLOP/s dense peak == the fp32 roof of the chip).  Every dense contraction of the hot path
+// (1x1 convs, Linears, their dgrad and wgrad) goes through this one kernel family.
+//
+//   C[M,N] = opA(A) * opB(B) (+ bias[N]) (+ gbias[row / rows_per_group][N])
+//   opA(A)[m][k] = TA ? A[k*lda + m] : A[m*lda + k]
+//   opB(B)[k][n] = TB ? B[n*ldb + k] : B[k*ldb + n]
+//
+//   forward  Y  = X  * W^T : TA=0 TB=1        (X [P,Cin] point-major, W [Cout,Cin] as torch stores it)
+//   dgrad    dX = dY * W   : TA=0 TB=0
+//   wgrad    dW = dY^T * X : TA=1 TB=0, K = P (split-K over the grid, slab + reduce: deterministic)
+//
+// Tiling: 128x128x32 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.
+// LDS images follow the global layout of each operand, so staging is 16-byte loads and 16-byte LDS writes only:
+// row-major sources -> [row][32+4] (an operand fragment is ONE ds_read_b64 per two MFMA steps), k-major sources ->
+// [k][128] (ds_read_b32 per value).  K is consumed in groups of four (k = 4m+2h, then 4m+2h+1) so that both images
+// feed the same k to the A and the B side.
+// Global loads of tile t+1 are issued before the MFMA loop of tile t (register prefetch).
+// Block -> tile mapping keeps all column tiles of one 128-row panel on one XCD (blockIdx % 8 is the
+// XCD label under round-robin dispatch), so the activation panel is fetched into one L2 only.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define SROW 36    // LDS row pitch (floats) for operands whose global source is row-major: image [rows][BK+4]
+#define SKMJ 128   // LDS stride for operands whose global source is k-major    [K][rows]
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* gbias;
+    int M, N, K, lda, ldb, ldc, rows_per_group;
+    int ntm, ntn, nsplit, ksplit;   // tiles; split-K count; K range per split (multiple of BK)
+    int a_vec, b_vec;               // 1 if float4 global loads are legal for that operand
+    int xcd_map;                    // 1: XCD-grouped block->tile map (grid padded to a multiple of 8 panels)
+    int accumulate;                 // 1: C += result (beta = 1): several consumers of one activation sum their input gradients in place
+    int c_bf16;                     // 1: C holds bf16 (activation storage of BASELINE.json configs[4]); A / B element types are template arguments
+    // operand transform (XF != 0): the operand is the PRE-BatchNorm output of the previous layer and is turned into that layer's
+    // activated output while it is staged: act(x * scale[c] + shift[c]), dropout by the counter hash of element row * x_ld + c.
+    // XF == 1: A is [M][K] row-major, c = k.  XF == 2: B is [K][N] k-major (the wgrad's X), c = n.
+    const float* x_scale; const float* x_shift; int x_act; float x_slope; uint32_t x_thresh; float x_inv_keep; uint64_t x_seed; int x_ld;
+    double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][N] (BN batch statistics)
+    const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
+    float* sel_val; int* sel_row;   // [ntm][N] extreme of each 128-row panel and the global row attaining it (first occurrence)
+};
+
+// ---- global -> registers for one 128x32 operand tile -----------------------------------------
+// SRC_KMAJOR = false: source [rows][K] (ld = row pitch). thread t: k-quad (t&7)*4, rows (t>>3)+32p.
+// SRC_KMAJOR = true : source [K][rows] (ld = k pitch).   thread t: row-quad (t&31)*4, k (t>>5)+8p.
+template <bool SRC_KMAJOR, int NP>
+__device__ __forceinline__ void g2r(f32x4 (&r)[4], const float* __restrict__ src, int ld, int row0, int nrows,
+                                    int k0, int kend, int vec_ok, int tid) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!SRC_KMAJOR) {
+            int row = row0 + (tid >> 3) + 32 * p;
+            int k = k0 + (tid & 7) * 4;
+            if (row < nrows) {
+                const float* g = src + (size_t)row * ld + k;
+                if (vec_ok && k + 3 < kend) {
+                    v = *(const f32x4*)g;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < kend) v[e] = g[e];
+                }
+            }
+        } else {
+            // NP == 4: 128 rows (32 threads per k-row, 8 k-rows per pass); NP == 2: 64 rows (16 threads per k-row, 16 per pass)
+            int k = k0 + (NP == 4 ? (tid >> 5) + 8 * p : (tid >> 4) + 16 * p);
+            int row = row0 + (NP == 4 ? (tid & 31) : (tid & 15)) * 4;
+            if (k < kend) {
+                const float* g = src + (size_t)k * ld + row;
+                if (vec_ok && row + 3 < nrows) {
+                    v = *(const f32x4*)g;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row + e < nrows) v[e] = g[e];
+                }
+            }
+        }
+        r[p] = v;
+    }
+}
+
+// FAST path (every tile interior, 16-byte loads legal): no predicates, the per-thread source pointer just advances by one
+// K-tile per iteration.  `base` already points at this thread's first element of the tile at k0.
+template <bool SRC_KMAJOR, int NP>
+__device__ __forceinline__ void g2r_fast(f32x4 (&r)[4], const float* __restrict__ base, int ld) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (!SRC_KMAJOR) r[p] = *(const f32x4*)(base + (size_t)(32 * p) * ld);
+        else r[p] = *(const f32x4*)(base + (size_t)((NP == 4 ? 8 : 16) * p) * ld);
+    }
+}
+
+template <bool SRC_KMAJOR, int NP>
+__device__ __forceinline__ void r2s(const f32x4 (&r)[4], float* __restrict__ s, int tid) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (!SRC_KMAJOR) {
+            int row = (tid >> 3) + 32 * p;
+            int k = (tid & 7) * 4;
+            *(f32x4*)(s + row * SROW + k) = r[p];
+        } else {
+            int k = NP == 4 ? (tid >> 5) + 8 * p : (tid >> 4) + 16 * p;
+            int row = (NP == 4 ? (tid & 31) : (tid & 15)) * 4;
+            *(f32x4*)(s + k * SKMJ + row) = r[p];
+        }
+    }
+}
+
+// ---- epilogue shared by the fp32 and the bf16-operand kernels --------------------------------------------------------
+// acc: this wave's WM x 2 MFMA tiles of the block tile at (m0, n0); smem: the operand tiles, dead by now (scratch).
+template <int WM, bool FAST, bool CBF = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* smem, int tm, int m0, int n0, int split,
+                                              int tid, int l31, int h, int wm, int wn) {
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
+    __bf16* Cb = (__bf16*)p.C;                            // CBF: bf16 output (never split: the slab is fp32)
+    const bool epi = (p.nsplit == 1);
+    float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int col = n0 + wn * 64 + j * 32 + l31;
+            if (!FAST && col >= p.N) continue;
+            float bv = (epi && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (FAST || row < p.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (epi && p.gbias) v += p.gbias[(size_t)(row / p.rows_per_group) * p.N + col];
+                    if (epi && p.accumulate) v += CBF ? (float)Cb[(size_t)row * p.ldc + col] : Cout[(size_t)row * p.ldc + col];
+#ifdef GP_NOSTORE
+                    if (p.C && v == 12345.678f) Cout[(size_t)row * p.ldc + col] = v;
+#else
+                    if (CBF) { if (p.C) Cb[(size_t)row * p.ldc + col] = (__bf16)v; }
+                    else if (p.C) Cout[(size_t)row * p.ldc + col] = v;
+#endif
+                    cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
+                    acc[i][j][r] = v;
+                }
+            }
+        }
+    if (p.sel_gamma) {       // fused column extreme (max over points follows this layer): per panel, per column
+        float bv[2]; int br[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            const bool use_max = col < p.N ? p.sel_gamma[col] >= 0.f : true;
+            float best = use_max ? -INFINITY : INFINITY;
+            int brow = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = acc[i][j][r];
+                    const bool take = row < p.M && (use_max ? (v > best) : (v < best));
+                    best = take ? v : best; brow = take ? row : brow;
+                }
+            const float ob = __shfl_xor(best, 32, 64);
+            const int orow = __shfl_xor(brow, 32, 64);
+            const bool better = use_max ? (ob > best) : (ob < best);
+            if (better || (ob == best && orow < brow)) { best = ob; brow = orow; }
+            bv[j] = best; br[j] = brow;
+        }
+        __syncthreads();                                  // smem is reused below (and by the statistics block)
+        float* sv = smem + 1024;                          // [wm][128] values, then rows
+        int* sr = (int*)(smem + 1024 + 256);
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { sv[wm * 128 + wn * 64 + j * 32 + l31] = bv[j]; sr[wm * 128 + wn * 64 + j * 32 + l31] = br[j]; }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const bool use_max = p.sel_gamma[n0 + tid] >= 0.f;
+            float a = sv[tid], b2 = sv[128 + tid];
+            int ra = sr[tid], rb = sr[128 + tid];
+            const bool better = use_max ? (b2 > a) : (b2 < a);
+            if (better || (b2 == a && rb < ra)) { a = b2; ra = rb; }
+            p.sel_val[(size_t)tm * p.N + n0 + tid] = a;
+            p.sel_row[(size_t)tm * p.N + n0 + tid] = ra;
+        }
+    }
+    if (p.stat_part) {       // fused BatchNorm statistics: one fp64 partial per 128-row panel and column
+        float* red = smem;   // [wm][sum|sq][128]  (the operand tiles are dead: the k-loop ended on a barrier)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cs[j] += __shfl_xor(cs[j], 32, 64);
+            cq[j] += __shfl_xor(cq[j], 32, 64);
+            if (h == 0) {
+                red[(wm * 2 + 0) * 128 + wn * 64 + j * 32 + l31] = cs[j];
+                red[(wm * 2 + 1) * 128 + wn * 64 + j * 32 + l31] = cq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            p.stat_part[((size_t)tm * 2 + 0) * p.N + n0 + tid] = (double)red[0 * 128 + tid] + (double)red[2 * 128 + tid];
+            p.stat_part[((size_t)tm * 2 + 1) * p.N + n0 + tid] = (double)red[1 * 128 + tid] + (double)red[3 * 128 + tid];
+        }
+    }
+}
+
+// WM = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile; 1 -> 64x128 (twice the workgroups, for launches whose
+// 128-row grid is too small to keep ~3 workgroups per CU in flight and out of phase)
+// one staged f32x4 of an operand under the transform: c0 = first channel of the quad (channels contiguous when XF == 1 / 2 alike),
+// e0 = element index (row * x_ld + c0) of its first value
+__device__ __forceinline__ f32x4 xf_quad(const GemmArgs& p, f32x4 v, const f32x4& xs, const f32x4& xh, uint64_t e0) {
+    // x_slope here is the EFFECTIVE negative-side factor in [0, 1] (0 for ReLU, 1 for no activation: launch_gemm), so the activation
+    // is one max: max(a, a * s) == (a > 0 ? a : a * s).  The dropout rescale is applied exactly as bn_act_fwd does (a * inv_keep).
+    const uint32_t hq = p.x_thresh ? dropout_hash4(p.x_seed, e0 >> 2) : 0u;  // e0 is a multiple of 4: one hash for the quad
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = fmaf(v[e], xs[e], xh[e]);
+        a = fmaxf(a, a * p.x_slope);
+        if (p.x_thresh) a = ((hq >> (8 * e)) & 255u) >= p.x_thresh ? a * p.x_inv_keep : 0.f;
+        v[e] = a;
+    }
+    return v;
+}
+
+template <bool TA, bool TB, int WM, bool FAST, int XF = 0>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
+    constexpr int BMT = 64 * WM, NPA = 2 * WM;
+    // A tile is k-major in LDS either way; its GLOBAL source is k-major iff TA.  B's source is
+    // k-major iff !TB.
+#ifdef GP_LDSPAD
+    __shared__ __attribute__((aligned(16))) float smem[BM * SROW * 2 + GP_LDSPAD];
+#else
+    __shared__ __attribute__((aligned(16))) float smem[BM * SROW * 2];
+#endif
+    float* As = smem;
+    float* Bs = smem + BM * SROW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile mapping (only when there are >= 8 row panels): all ntn column tiles of a row
+    // panel share blockIdx.x % 8, i.e. one XCD's L2 under round-robin dispatch.  With fewer panels
+    // (wgrad, skinny GEMMs) plain order keeps every XCD busy.
+    const int bid = blockIdx.x;
+    int tm, tn;
+    if (p.xcd_map) {
+        const int xcd = bid & 7, q = bid >> 3;
+        tn = q % p.ntn;
+        tm = (q / p.ntn) * 8 + xcd;
+        if (tm >= p.ntm) return;
+    } else {
+        tn = bid % p.ntn;
+        tm = bid / p.ntn;
+    }
+    const int split = blockIdx.y;
+    const int m0 = tm * BMT, n0 = tn * BN;
+    const int kbeg = split * p.ksplit;
+    const int kend = min(p.K, kbeg + p.ksplit);
+
+#ifdef GP_TIMELINE
+    const long long tl0 = wall_clock64();
+    long long tl1 = 0;
+#endif
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    // FAST: this thread's source pointers (advance by one K-tile per iteration)
+    const float* pa = nullptr;
+    const float* pb = nullptr;
+    // XF (FAST, fp32 only): scale / shift of this thread's channel quad.  XF == 1: the k-quad of the A tile held in ra (reloaded with
+    // every tile); XF == 2: the n-quad of B (fixed).
+    f32x4 xs = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
+    static_assert(XF == 0 || FAST, "operand transform: interior tiles only");
+    static_assert(XF != 1 || !TA, "XF == 1: A row-major");
+    static_assert(XF != 2 || !TB, "XF == 2: B k-major");
+    if (FAST) {
+        pa = TA ? p.A + (size_t)(kbeg + (NPA == 4 ? (tid >> 5) : (tid >> 4))) * p.lda + m0 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 4
+                : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
+        pb = !TB ? p.B + (size_t)(kbeg + (tid >> 5)) * p.ldb + n0 + (tid & 31) * 4
+                 : p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + kbeg + (tid & 7) * 4;
+        g2r_fast<TA, NPA>(ra, pa, p.lda);
+        g2r_fast<!TB, 4>(rb, pb, p.ldb);
+        if (XF == 1) { xs = *(const f32x4*)(p.x_scale + kbeg + (tid & 7) * 4); xh = *(const f32x4*)(p.x_shift + kbeg + (tid & 7) * 4); }
+        if (XF == 2) { xs = *(const f32x4*)(p.x_scale + n0 + (tid & 31) * 4); xh = *(const f32x4*)(p.x_shift + n0 + (tid & 31) * 4); }
+    } else {
+        g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid);
+        g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid);
+    }
+
+    // XF: the staged registers of the tile at kt become the previous layer's activated output.  The first tile is transformed here;
+    // every later one in the MIDDLE of the MFMA loop of the tile before it (its loads have landed by then and the vector work runs
+    // under the matrix pipe instead of in front of the LDS writes, where all four waves would wait on it).
+    auto xf_tile = [&](int kt) {
+        if (XF == 1) {                                    // rows m0 + (tid >> 3) + 32 q, channels kt + 4 (tid & 7) ..
+#pragma unroll
+            for (int q = 0; q < NPA; ++q)
+                ra[q] = xf_quad(p, ra[q], xs, xh, (uint64_t)(m0 + (tid >> 3) + 32 * q) * p.x_ld + kt + (tid & 7) * 4);
+        }
+        if (XF == 2) {                                    // rows (points) kt + (tid >> 5) + 8 q, channels n0 + 4 (tid & 31) ..
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                rb[q] = xf_quad(p, rb[q], xs, xh, (uint64_t)(kt + (tid >> 5) + 8 * q) * p.x_ld + n0 + (tid & 31) * 4);
+        }
+    };
+    if (XF) xf_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#ifdef GP_NOR2S
+        if (k0 == kbeg)
+#endif
+        {
+        r2s<TA, NPA>(ra, As, tid);
+        r2s<!TB, 4>(rb, Bs, tid);
+        }
+        __syncthreads();
+#ifdef GP_TIMELINE
+        if (k0 == kbeg) tl1 = wall_clock64();
+#endif
+#ifdef GP_NOGLOBAL
+        if (false) {
+#else
+        if (k0 + BK < kend) {
+#endif
+            if (FAST) {
+                pa += TA ? (size_t)BK * p.lda : BK;
+                pb += !TB ? (size_t)BK * p.ldb : BK;
+                g2r_fast<TA, NPA>(ra, pa, p.lda);
+                g2r_fast<!TB, 4>(rb, pb, p.ldb);
+                if (XF == 1) {
+                    xs = *(const f32x4*)(p.x_scale + k0 + BK + (tid & 7) * 4); xh = *(const f32x4*)(p.x_shift + k0 + BK + (tid & 7) * 4);
+                }
+            } else {
+                g2r<TA, NPA>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid);
+                g2r<!TB, 4>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid);
+            }
+        }
+        // Fragment reads.  K is consumed in groups of 4: MFMA step 2m takes k = 4m + 2h, step 2m+1 takes k = 4m + 2h + 1
+        // (h = lane >> 5), so a row-major image gives each lane its two values with ONE 8-byte read; a k-major image is
+        // read per value.  Both operands use the same k assignment, so every (TA, TB) combination is consistent.
+        const int arow = wm * (32 * WM) + l31, bcol = wn * 64 + l31;
+#ifdef GP_PRIO
+        __builtin_amdgcn_s_setprio(GP_PRIO);
+#endif
+#pragma unroll
+        for (int m = 0; m < BK / 4; ++m) {
+#ifdef GP_IGLP
+            __builtin_amdgcn_iglp_opt(GP_IGLP);
+#endif
+            if (XF && m == BK / 8 && k0 + BK < kend) xf_tile(k0 + BK);
+            const int kq = 4 * m + 2 * h;
+            float a0s0, a0s1, a1s0, a1s1, b0s0, b0s1, b1s0, b1s1;
+            a1s0 = 0.f; a1s1 = 0.f;
+            if (!TA) {
+                const float2 t0 = *(const float2*)(As + arow * SROW + kq);
+                a0s0 = t0.x; a0s1 = t0.y;
+                if (WM == 2) { const float2 t1 = *(const float2*)(As + (arow + 32) * SROW + kq); a1s0 = t1.x; a1s1 = t1.y; }
+            } else {
+                a0s0 = As[kq * SKMJ + arow]; a0s1 = As[(kq + 1) * SKMJ + arow];
+                if (WM == 2) { a1s0 = As[kq * SKMJ + arow + 32]; a1s1 = As[(kq + 1) * SKMJ + arow + 32]; }
+            }
+            if (TB) {
+                const float2 t0 = *(const float2*)(Bs + bcol * SROW + kq), t1 = *(const float2*)(Bs + (bcol + 32) * SROW + kq);
+                b0s0 = t0.x; b0s1 = t0.y; b1s0 = t1.x; b1s1 = t1.y;
+            } else {
+                b0s0 = Bs[kq * SKMJ + bcol]; b0s1 = Bs[(kq + 1) * SKMJ + bcol];
+                b1s0 = Bs[kq * SKMJ + bcol + 32]; b1s1 = Bs[(kq + 1) * SKMJ + bcol + 32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s0, b0s0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s0, b1s0, acc[0][1], 0, 0, 0);
+            if (WM == 2) {
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s0, b0s0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s0, b1s0, acc[1][1], 0, 0, 0);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s1, b0s1, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0s1, b1s1, acc[0][1], 0, 0, 0);
+            if (WM == 2) {
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s1, b0s1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1s1, b1s1, acc[1][1], 0, 0, 0);
+            }
+        }
+#ifdef GP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#ifndef GP_NOBAR
+        __syncthreads();
+#endif
+    }
+
+#ifdef GP_TIMELINE
+    const long long tl2 = wall_clock64();
+#endif
+    gemm_epilogue<WM, FAST>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
+#ifdef GP_TIMELINE
+    __syncthreads();
+    if (tid == 0) {                                    // 100 MHz ticks: start, first tile staged, loop end, epilogue end
+        const long long tl3 = wall_clock64();
+        float* dbg = p.C + (size_t)m0 * p.ldc + n0;
+        dbg[0] = (float)(tl0 & 0xffffff); dbg[1] = (float)(tl1 - tl0); dbg[2] = (float)(tl2 - tl1); dbg[3] = (float)(tl3 - tl2);
+    }
+#endif
+}
+
+// ---- N = 64 variant: 128 x 64 x 32 tiles, the four waves stacked along M (32 rows x 64 columns each) -----------------------------
+// The dgrads into a 64-channel input (dx = duv * Wd of EdgeConv 2 / 3) and their wgrads have N = 64: on the 128-column tile half of
+// every B stage and half of the MFMA columns are padding (17-31 TF).  Interior shapes only (M % 128 == 0, K-range % 32 == 0, 16-byte
+// aligned operands), plain / split-K output, no fused epilogue.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f32_n64_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[BM * SROW + 64 * SROW + 32 * 64];
+    float* As = smem;                              // row-major image [128][36] or k-major [32][128]
+    float* Bs = smem + BM * SROW;                  // row-major image [64][36]  or k-major [32][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tm = blockIdx.x, split = blockIdx.y;
+    const int m0 = tm * 128;
+    const int kbeg = split * p.ksplit, kend = min(p.K, kbeg + p.ksplit);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    f32x4 ra[4], rb[4];
+    const float* pa = TA ? p.A + (size_t)(kbeg + (tid >> 5)) * p.lda + m0 + (tid & 31) * 4
+                         : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
+    const float* pb = !TB ? p.B + (size_t)(kbeg + (tid >> 4)) * p.ldb + (tid & 15) * 4
+                          : p.B + (size_t)(tid >> 3) * p.ldb + kbeg + (tid & 7) * 4;
+    g2r_fast<TA, 4>(ra, pa, p.lda);
+    g2r_fast<!TB, 2>(rb, pb, p.ldb);
+    constexpr int BSK = 64;                        // k-major B image stride
+    const int arow = wave * 32 + l31;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        r2s<TA, 4>(ra, As, tid);
+        if (TB) r2s<false, 2>(rb, Bs, tid);
+        else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *(f32x4*)(Bs + ((tid >> 4) + 16 * q) * BSK + (tid & 15) * 4) = rb[q];
+        }
+        __syncthreads();
+        if (k0 + BK < kend) {
+            pa += TA ? (size_t)BK * p.lda : BK;
+            pb += !TB ? (size_t)BK * p.ldb : BK;
+            g2r_fast<TA, 4>(ra, pa, p.lda);
+            g2r_fast<!TB, 2>(rb, pb, p.ldb);
+        }
+#pragma unroll
+        for (int m = 0; m < BK / 4; ++m) {
+            const int kq = 4 * m + 2 * h;
+            float a0, a1, b00, b01, b10, b11;
+            if (!TA) { const float2 t = *(const float2*)(As + arow * SROW + kq); a0 = t.x; a1 = t.y; }
+            else { a0 = As[kq * SKMJ + arow]; a1 = As[(kq + 1) * SKMJ + arow]; }
+            if (TB) {
+                const float2 t0 = *(const float2*)(Bs + l31 * SROW + kq), t1 = *(const float2*)(Bs + (l31 + 32) * SROW + kq);
+                b00 = t0.x; b01 = t0.y; b10 = t1.x; b11 = t1.y;
+            } else {
+                b00 = Bs[kq * BSK + l31]; b01 = Bs[(kq + 1) * BSK + l31];
+                b10 = Bs[kq * BSK + l31 + 32]; b11 = Bs[(kq + 1) * BSK + l31 + 32];
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b00, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b10, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b01, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b11, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            Cout[(size_t)row * p.ldc + j * 32 + l31] = acc[j][r];
+        }
+}
+
+// ---- bf16-operand variant (opt-in, mlsp_set_gemm_precision(1); BASELINE.json configs[4]) -------------------------------
+// Same tiling, epilogues and split-K protocol as gemm_f32_kernel<..., FAST>, but the fp32 operands are rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) on their way into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 8x fewer MFMA
+// issues per K-tile and half the LDS traffic.  Both LDS images are row-major [row][32 + 8] bf16 (80-byte pitch: every
+// fragment is one 16-byte read); k-major global sources are transposed on the LDS write (2-byte stores).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define BROW 40    // bf16 elements per LDS row
+
+template <bool SRC_KMAJOR, int NP>
+__device__ __forceinline__ void r2s_bf16(const f32x4 (&r)[4], __bf16* __restrict__ s, int tid) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (!SRC_KMAJOR) {
+            const int row = (tid >> 3) + 32 * p, k = (tid & 7) * 4;
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (__bf16)r[p][e];
+            *(bf16x4*)(s + row * BROW + k) = v;
+        } else {
+            const int k = NP == 4 ? (tid >> 5) + 8 * p : (tid >> 4) + 16 * p;
+            const int row = (NP == 4 ? (tid & 31) : (tid & 15)) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[(row + e) * BROW + k] = (__bf16)r[p][e];
+        }
+    }
+}
+
+// Operand staging of the bf16-MFMA kernel for a 128x32 (or 64x32) tile.  fp32 sources are rounded to bf16 on the LDS write
+// (operand mode); bf16 sources (activation storage) are copied: 16-byte global loads of 8 elements either way they lie.
+//   row-major bf16 source: thread t -> rows (t>>2) + 64p, k = (t&3)*8        one 16-byte LDS write
+//   k-major  bf16 source: thread t -> k = (t>>4) + 16p, rows (t&15)*8 ..+7    eight 2-byte LDS writes (transpose)
+struct BfStage { bf16x8 v[2]; };
+template <bool SRC_KMAJOR, int ROWS>
+__device__ __forceinline__ void g2r_b16(BfStage& r, const __bf16* __restrict__ base, int ld) {
+    constexpr int NPB = SRC_KMAJOR ? 2 : ROWS / 64;
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) r.v[p] = *(const bf16x8*)(base + (size_t)((SRC_KMAJOR ? 16 : 64) * p) * ld);
+}
+template <bool SRC_KMAJOR, int ROWS>
+__device__ __forceinline__ void r2s_b16(const BfStage& r, __bf16* __restrict__ s, int tid) {
+    constexpr int NPB = SRC_KMAJOR ? 2 : ROWS / 64;
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+        if (!SRC_KMAJOR) {
+            *(bf16x8*)(s + ((tid >> 2) + 64 * p) * BROW + (tid & 3) * 8) = r.v[p];
+        } else {
+            const int k = (tid >> 4) + 16 * p, row = (tid & 15) * 8;
+            if (ROWS == 128 || row < ROWS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[(row + e) * BROW + k] = r.v[p][e];
+            }
+        }
+    }
+}
+
+// AB16 / BB16: the A / B operand is stored as bf16 in HBM; CB16: C is written as bf16.
+// NEDGE (only with a k-major fp32 B, i.e. the dgrad dX = dY * W): N is a multiple of 4 but not of the 128-column tile (the 192-channel
+// input of the PointSegDA heads): B columns beyond N are zero-filled on the load and the epilogue predicates its stores.
+template <bool TA, bool TB, int WM, bool AB16, bool BB16, bool CB16, bool NEDGE = false>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr int BMT = 64 * WM, NPA = 2 * WM;
+    __shared__ __attribute__((aligned(16))) float smem[BM * SROW * 2];      // same footprint as the fp32 kernel (epilogue scratch)
+    __bf16* As = (__bf16*)smem;
+    __bf16* Bs = As + BM * BROW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = blockIdx.x;
+    int tm, tn;
+    if (p.xcd_map) {
+        const int xcd = bid & 7, q = bid >> 3;
+        tn = q % p.ntn;
+        tm = (q / p.ntn) * 8 + xcd;
+        if (tm >= p.ntm) return;
+    } else {
+        tn = bid % p.ntn;
+        tm = bid / p.ntn;
+    }
+    const int split = blockIdx.y;
+    const int m0 = tm * BMT, n0 = tn * BN;
+    const int kbeg = split * p.ksplit;
+    const int kend = min(p.K, kbeg + p.ksplit);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[4], rb[4];
+    BfStage sa, sb;
+    const float* pa = nullptr; const float* pb = nullptr;
+    const __bf16* qa = nullptr; const __bf16* qb = nullptr;
+    if (AB16) {
+        const __bf16* A16 = (const __bf16*)p.A;
+        qa = TA ? A16 + (size_t)(kbeg + (tid >> 4)) * p.lda + m0 + (tid & 15) * 8
+                : A16 + (size_t)(m0 + (tid >> 2)) * p.lda + kbeg + (tid & 3) * 8;
+        if (!TA || BMT == 128 || (tid & 15) * 8 < BMT) g2r_b16<TA, BMT>(sa, qa, p.lda);
+    } else {
+        pa = TA ? p.A + (size_t)(kbeg + (NPA == 4 ? (tid >> 5) : (tid >> 4))) * p.lda + m0 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 4
+                : p.A + (size_t)(m0 + (tid >> 3)) * p.lda + kbeg + (tid & 7) * 4;
+        g2r_fast<TA, NPA>(ra, pa, p.lda);
+    }
+    if (BB16) {
+        const __bf16* B16 = (const __bf16*)p.B;
+        qb = !TB ? B16 + (size_t)(kbeg + (tid >> 4)) * p.ldb + n0 + (tid & 15) * 8
+                 : B16 + (size_t)(n0 + (tid >> 2)) * p.ldb + kbeg + (tid & 3) * 8;
+        g2r_b16<!TB, 128>(sb, qb, p.ldb);
+    } else {
+        pb = !TB ? p.B + (size_t)(kbeg + (tid >> 5)) * p.ldb + n0 + (tid & 31) * 4
+                 : p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + kbeg + (tid & 7) * 4;
+        if (!NEDGE || n0 + (tid & 31) * 4 < p.N) g2r_fast<!TB, 4>(rb, pb, p.ldb);
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rb[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const bool b_lane_ok = !NEDGE || n0 + (tid & 31) * 4 < p.N;
+    const bool a_lane_ok = !AB16 || !TA || BMT == 128 || (tid & 15) * 8 < BMT;     // 64-row k-major bf16 tiles use half the lanes
+    const int arow = wm * (32 * WM) + l31, bcol = wn * 64 + l31;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        if (AB16) r2s_b16<TA, BMT>(sa, As, tid); else r2s_bf16<TA, NPA>(ra, As, tid);
+        if (BB16) r2s_b16<!TB, 128>(sb, Bs, tid); else r2s_bf16<!TB, 4>(rb, Bs, tid);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            if (AB16) { qa += TA ? (size_t)BK * p.lda : BK; if (a_lane_ok) g2r_b16<TA, BMT>(sa, qa, p.lda); }
+            else { pa += TA ? (size_t)BK * p.lda : BK; g2r_fast<TA, NPA>(ra, pa, p.lda); }
+            if (BB16) { qb += !TB ? (size_t)BK * p.ldb : BK; g2r_b16<!TB, 128>(sb, qb, p.ldb); }
+            else { pb += !TB ? (size_t)BK * p.ldb : BK; if (b_lane_ok) g2r_fast<!TB, 4>(rb, pb, p.ldb); }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 16; ++s2) {                      // MFMA step: k = 16*s2 + 8*h .. +7
+            const int kk = 16 * s2 + 8 * h;
+            const bf16x8 a0 = *(const bf16x8*)(As + arow * BROW + kk);
+            const bf16x8 b0 = *(const bf16x8*)(Bs + bcol * BROW + kk), b1 = *(const bf16x8*)(Bs + (bcol + 32) * BROW + kk);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            if (WM == 2) {
+                const bf16x8 a1 = *(const bf16x8*)(As + (arow + 32) * BROW + kk);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<WM, !NEDGE, CB16>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
+}
+
+static int g_gemm_precision = 0;     // 0: fp32 MFMA (exact fp32 products); 1: bf16 operands, fp32 accumulation
+extern "C" int mlsp_set_gemm_precision(int mode) {
+    if (mode != 0 && mode != 1) return MLSP_ERR_ARG;
+    g_gemm_precision = mode;
+    return MLSP_OK;
+}
+
+// sum the split-K slabs (fixed order -> bitwise reproducible) and apply the epilogue
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N, int ldc,
+                                     int nsplit, const float* __restrict__ bias, const float* __restrict__ gbias,
+                                     int rows_per_group) {
+    size_t total = (size_t)M * N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int row = (int)(i / N), col = (int)(i % N);
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += slab[(size_t)z * M * N + i];
+        if (bias) s += bias[col];
+        if (gbias) s += gbias[(size_t)(row / rows_per_group) * N + col];
+        C[(size_t)row * ldc + col] = s;
+    }
+}
+
+static void launch_splitk_reduce_any(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int ns, const float* bias,
+                                     const float* gbias, int rows_per_group);
+
+int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int nsplit) {
+    launch_splitk_reduce_any(st, slab, C, M, N, ldc, nsplit, nullptr, nullptr, 0);
+    return mlsp_launch_status();
+}
+
+// vectorised slab reduce (contiguous C only): 16 bytes per lane.  A workgroup covers 256/ZG consecutive float4 outputs;
+// its ZG thread groups each sum the slabs z = g, g+ZG, ... (8 loads in flight), then the groups are added in order through
+// LDS.  The order is fixed by (nsplit, ZG) alone -> bitwise reproducible.
+template <int ZG>
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ slab, float* __restrict__ C, size_t total4,
+                                                                int N4, int nsplit, const float* __restrict__ bias,
+                                                                const float* __restrict__ gbias, int rows_per_group) {
+    constexpr int EPB = 256 / ZG;                 // float4 outputs per workgroup
+    __shared__ f32x4 part[ZG > 1 ? 256 : 1];
+    const int e = threadIdx.x % EPB, g = threadIdx.x / EPB;
+    const size_t v = (size_t)blockIdx.x * EPB + e;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (v < total4) {
+        const f32x4* p = (const f32x4*)slab + v;
+        int z = g;
+        for (; z + 7 * ZG < nsplit; z += 8 * ZG) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(z + u * ZG) * total4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = s + t[u];
+        }
+        for (; z < nsplit; z += ZG) s = s + p[(size_t)z * total4];
+    }
+    if (ZG > 1) {
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (g != 0) return;
+#pragma unroll
+        for (int q = 1; q < ZG; ++q) s = s + part[q * EPB + e];
+    }
+    if (v >= total4) return;
+    const int col = (int)(v % N4) * 4;
+    if (bias) { const f32x4 bv = *(const f32x4*)(bias + col); s = s + bv; }
+    if (gbias) {
+        const size_t row = v / N4;
+        const f32x4 gv = *(const f32x4*)(gbias + (row / rows_per_group) * (size_t)N4 * 4 + col);
+        s = s + gv;
+    }
+    ((f32x4*)C)[v] = s;
+}
+
+// scalar outputs with many slabs (N = 3 wgrads ...): one wave per output element, lanes stride the slabs, fixed shuffle tree
+__global__ __launch_bounds__(256) void splitk_reduce_wave_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N,
+                                                                 int ldc, int nsplit, const float* __restrict__ bias,
+                                                                 const float* __restrict__ gbias, int rows_per_group) {
+    const size_t total = (size_t)M * N;
+    const int lane = threadIdx.x & 63;
+    for (size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (size_t)gridDim.x * 4) {
+        float s = 0.f;
+        for (int z = lane; z < nsplit; z += 64) s += slab[(size_t)z * total + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            const int row = (int)(i / N), col = (int)(i % N);
+            if (bias) s += bias[col];
+            if (gbias) s += gbias[(size_t)(row / rows_per_group) * N + col];
+            C[(size_t)row * ldc + col] = s;
+        }
+    }
+}
+
+static void launch_splitk_reduce_any(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int ns, const float* bias,
+                                     const float* gbias, int rows_per_group) {
+    size_t total = (size_t)M * N;
+    const bool vec = (N % 4 == 0) && ldc == N && ((((uintptr_t)slab | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)gbias) & 15) == 0);
+    if (vec) {
+        size_t t4 = total / 4;
+        // enough workgroups to fill the chip: more slab groups per workgroup when the output is small
+        if (ns >= 32 && t4 <= 64 * 1024)
+            hipLaunchKernelGGL((splitk_reduce_vec_kernel<8>), dim3((unsigned)((t4 + 31) / 32)), dim3(256), 0, st, slab, C, t4, N / 4, ns, bias, gbias, rows_per_group);
+        else if (ns >= 8)
+            hipLaunchKernelGGL((splitk_reduce_vec_kernel<4>), dim3((unsigned)((t4 + 63) / 64)), dim3(256), 0, st, slab, C, t4, N / 4, ns, bias, gbias, rows_per_group);
+        else
+            hipLaunchKernelGGL((splitk_reduce_vec_kernel<1>), dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, st, slab, C, t4, N / 4, ns, bias, gbias, rows_per_group);
+    } else if (ns >= 32 && total <= 256 * 1024) {
+        int blocks = (int)((total + 3) / 4 < 4096 ? (total + 3) / 4 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_wave_kernel, dim3(blocks), dim3(256), 0, st, slab, C, M, N, ldc, ns, bias, gbias, rows_per_group);
+    } else {
+        int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, C, M, N, ldc, ns, bias, gbias, rows_per_group);
+    }
+}
+
+// How many K splits a launch will use (shared by the launcher and mlsp_workspace_bytes).
+int gemm_pick_split(int M, int N, int K) {
+    int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    long tiles = (long)ntm * ntn;
+    int ktiles = (K + BK - 1) / BK;
+    if (tiles >= 256 || ktiles < 4) return 1;
+    long want = (512 + tiles - 1) / tiles;          // aim at ~2 blocks per CU (measured: 320 is 35 % slower on the wgrad shapes)
+    int ns = (int)(want < ktiles / 2 ? want : ktiles / 2);
+    if (ns < 1) ns = 1;
+    if (ns > 256) ns = 256;
+    return ns;
+}
+
+// number of BN-statistic partial rows a stats-fused launch writes (0: the launch would split K, use colstats)
+// 64-row tiles when the 128-row grid is too small to keep ~3 workgroups per CU busy (and K is not split)
+static int gemm_pick_bm(int M, int N, int K) {
+    long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN);
+    return (gemm_pick_split(M, N, K) == 1 && tiles128 < 1536 && M >= 256) ? 64 : 128;
+}
+int gemm_stat_parts(int M, int N, int K) {
+    if (gemm_pick_split(M, N, K) != 1) return 0;
+    int bm = gemm_pick_bm(M, N, K);
+    return (M + bm - 1) / bm;
+}
+int gemm_panel_rows(int M, int N, int K) { return gemm_pick_bm(M, N, K); }
+
+size_t thin_tn_slab_floats(int M, int N, int K);
+size_t gemm_slab_floats(int M, int N, int K) {
+    int ns = gemm_pick_split(M, N, K);
+    const size_t a = ns > 1 ? (size_t)ns * M * N : 0, b = thin_tn_slab_floats(M, N, K);      // thin.hip: A^T B with one side <= 16
+    return a > b ? a : b;
+}
+
+// ---- optional HIP-event profiling of the GEMM launches (bench.py roofline) -----------------------
+// Off by default.  mlsp_profile_begin() arms it; every gemm_f32_kernel launch is then bracketed by two
+// events recorded on the launch stream; mlsp_profile_end() returns {ms, launches, algorithmic FLOP}.
+#include <vector>
+#include <cstdlib>
+#include <cstdio>
+static struct GemmProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev;     // pairs
+    size_t used = 0;
+    double flop = 0.0;
+    struct Rec { int M, N, K, ta, tb, ns, bm, fused; };
+    std::vector<Rec> rec;           // one per pair, for the MLSP_PROF_DUMP listing
+} g_prof;
+#define PROF_MAX_PAIRS 4096
+
+extern "C" int mlsp_profile_begin(void) {
+    if (g_prof.ev.empty()) {
+        g_prof.ev.resize(2 * PROF_MAX_PAIRS);
+        g_prof.rec.resize(PROF_MAX_PAIRS);
+        for (auto& e : g_prof.ev)
+            if (hipEventCreate(&e) != hipSuccess) { g_prof.ev.clear(); return MLSP_ERR_UNSUPPORTED; }
+    }
+    g_prof.used = 0; g_prof.flop = 0.0; g_prof.on = true;
+    return MLSP_OK;
+}
+
+// out[0] = total milliseconds inside gemm_f32_kernel, out[1] = launches, out[2] = sum of 2*M*N*K, out[3] = dropped launches
+extern "C" int mlsp_profile_end(double* out) {
+    g_prof.on = false;
+    double ms = 0.0;
+    const bool dump = getenv("MLSP_PROF_DUMP") != nullptr;    // debug listing: one line per profiled launch
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
+        ms += t;
+        if (dump) {
+            const auto& r = g_prof.rec[i];
+            fprintf(stderr, "gemm %c%c M=%d N=%d K=%d split=%d bm=%d epi=%d  %.1f us  %.1f TF\n", r.ta ? 'T' : 'N', r.tb ? 'T' : 'N',
+                    r.M, r.N, r.K, r.ns, r.bm, r.fused, t * 1e3, 2.0 * r.M * r.N * r.K / (t * 1e-3) / 1e12);
+        }
+    }
+    if (out) { out[0] = ms; out[1] = (double)g_prof.used; out[2] = g_prof.flop; out[3] = 0.0; }
+    return MLSP_OK;
+}
+
+int launch_skinny_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                       float* C, int ldc, const float* bias);
+int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                     int ldc, const float* bias, float* slab, size_t slab_floats);
+
+// Can this contraction stage `which` (1: A [M][K] row-major, 2: B [K][N] k-major) through the operand transform?  Interior tiles,
+// 16-byte loads, fp32 operands, the MFMA tile kernels (not the thin / skinny / N = 64 ones).
+bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which) {
+    if (g_gemm_precision != 0) return false;
+    if (which == 1 ? ta : !(ta && !tb)) return false;
+    if (M <= 32 || N < 32 || K < 32 || (ta && !tb && K <= 32)) return false;
+    const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    int ns = gemm_pick_split(M, N, K);
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
+    return vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+}
+
+int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
+                int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
+                size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
+                int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
+    if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
+    // one tiny dimension (3 coordinates, 3 / 16 outputs): streaming VALU kernels priced against HBM, not MFMA tiles (thin.hip)
+    if (!gbias && !stat_part && !sel_gamma && !accumulate && !xf) {
+        const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats);
+        if (rc != MLSP_ERR_UNSUPPORTED) return rc;
+    }
+    // per-cloud layers (<= 32 rows, or a 32-deep wgrad): one-pass skinny kernels, no split-K slab (skinny.hip)
+    if (!gbias && !stat_part && !sel_gamma && !accumulate && !xf && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
+        const int rc = launch_skinny_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias);
+        if (rc != MLSP_ERR_UNSUPPORTED) return rc;
+    }
+    if (sel_gamma && (!sel_val || !sel_row || gemm_pick_split(M, N, K) != 1)) return MLSP_ERR_ARG;
+    if (gbias && rows_per_group <= 0) return MLSP_ERR_ARG;
+    GemmArgs p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.gbias = gbias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.rows_per_group = rows_per_group;
+    int ns = gemm_pick_split(M, N, K);
+    if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;   // no slab: fall back to one pass
+    if (accumulate) ns = 1;                                              // beta = 1 lives in the one-pass epilogue
+    p.accumulate = accumulate ? 1 : 0;
+    if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
+    p.stat_part = stat_part;
+    p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
+    p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0;
+    if (xf) {
+        p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_thresh = xf->thresh;
+        p.x_slope = xf->act == 0 ? 1.f : xf->act == 1 ? 0.f : xf->slope;          // effective negative-side factor (xf_quad)
+        p.x_inv_keep = xf->inv_keep; p.x_seed = xf->seed; p.x_ld = xf->ld;
+    }
+    int ktiles = (K + BK - 1) / BK;
+    int kts = (ktiles + ns - 1) / ns;
+    ns = (ktiles + kts - 1) / kts;
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
+    p.ntm = (M + bm - 1) / bm; p.ntn = (N + BN - 1) / BN;
+    p.nsplit = ns; p.ksplit = kts * BK;
+    p.a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
+    p.b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    if (ns > 1) { p.C = slab; p.ldc = N; }
+    p.xcd_map = p.ntm >= 16 && p.ntn > 1;
+    dim3 grid(p.xcd_map ? ((p.ntm + 7) / 8) * 8 * p.ntn : p.ntm * p.ntn, ns);
+    const bool prof = g_prof.on && g_prof.used < PROF_MAX_PAIRS;
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
+    // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
+    const bool fast = p.a_vec && p.b_vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0);
+    const bool n64 = !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !bias && !gbias && !stat_part && !sel_gamma &&
+                     !accumulate && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
+    if (n64) {
+        dim3 g64(M / 128, ns);
+        if (!ta && tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, true>), g64, dim3(256), 0, st, p);
+        else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, false>), g64, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_f32_n64_kernel<true, false>), g64, dim3(256), 0, st, p);
+    } else
+#define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
+                                     else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
+                                     else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
+    if (xf) {                                             // operand transform: FAST fp32 instantiations only (gemm_xf_supported)
+        if (xf->which == 1 && tb) {
+            if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, true, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, true, 1>), grid, dim3(256), 0, st, p);
+        } else if (xf->which == 1) {
+            if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, true, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1, true, 1>), grid, dim3(256), 0, st, p);
+        } else {
+            if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2, true, 2>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1, true, 2>), grid, dim3(256), 0, st, p);
+        }
+    } else if (bm == 128) {
+        if (!ta && tb) GEMM_GO(false, true, 2);
+        else if (!ta && !tb) GEMM_GO(false, false, 2);
+        else if (ta && !tb) GEMM_GO(true, false, 2);
+        else GEMM_GO(true, true, 2);
+    } else {
+        if (!ta && tb) GEMM_GO(false, true, 1);
+        else if (!ta && !tb) GEMM_GO(false, false, 1);
+        else if (ta && !tb) GEMM_GO(true, false, 1);
+        else GEMM_GO(true, true, 1);
+    }
+#undef GEMM_GO
+    if (prof) {
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
+        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0)};
+        g_prof.used++;
+        g_prof.flop += 2.0 * M * (double)N * K;
+    }
+    if (ns > 1) launch_splitk_reduce_any(st, slab, C, M, N, ldc, ns, bias, gbias, rows_per_group);
+    return mlsp_launch_status();
+}
+
+
+// ---- bf16 activation storage (BASELINE.json configs[4]) ---------------------------------------------------------------------
+// The same contraction with operands and/or the output held as bf16 in HBM: activations X / Y / Z and their gradients are bf16,
+// weights, biases, BatchNorm statistics and weight gradients stay fp32.  Runs on gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, fp32
+// accumulation); a bf16 operand is copied to LDS as it is (half the HBM bytes, no conversion), an fp32 one is rounded on the way.
+// Only interior-tile shapes (M % tile, N % 128, K % 32 == 0, 16-byte aligned rows): MLSP_ERR_UNSUPPORTED otherwise, and the caller keeps
+// that layer in fp32.  Same BN-statistics / bias / per-cloud-bias / beta = 1 epilogues; the statistics come from the fp32 accumulators.
+int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A, int a_bf16, int lda, const void* B, int b_bf16,
+                   int ldb, void* C, int c_bf16, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
+                   size_t slab_floats, double* stat_part, bool accumulate) {
+    if (!a_bf16 && !b_bf16 && !c_bf16)
+        return launch_gemm(st, ta, tb, M, N, K, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, bias, gbias, rows_per_group,
+                           slab, slab_floats, stat_part, nullptr, nullptr, nullptr, accumulate);
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return MLSP_ERR_ARG;
+    if (gbias && rows_per_group <= 0) return MLSP_ERR_ARG;
+    GemmArgs p;
+    p.A = (const float*)A; p.B = (const float*)B; p.C = (float*)C; p.bias = bias; p.gbias = gbias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.rows_per_group = rows_per_group;
+    int ns = gemm_pick_split(M, N, K);
+    if (ns > 1 && (!slab || slab_floats < (size_t)ns * M * N)) ns = 1;
+    if (accumulate) ns = 1;
+    if (ns > 1 && c_bf16) return MLSP_ERR_UNSUPPORTED;                   // a split result is reduced in fp32
+    if (stat_part && ns != 1) return MLSP_ERR_ARG;
+    p.accumulate = accumulate ? 1 : 0; p.c_bf16 = c_bf16;
+    p.stat_part = stat_part; p.sel_gamma = nullptr; p.sel_val = nullptr; p.sel_row = nullptr;
+    const int ktiles = (K + BK - 1) / BK;
+    const int kts = (ktiles + ns - 1) / ns;
+    ns = (ktiles + kts - 1) / kts;
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
+    p.ntm = (M + bm - 1) / bm; p.ntn = (N + BN - 1) / BN;
+    p.nsplit = ns; p.ksplit = kts * BK;
+    const bool a_ok = a_bf16 ? (lda % 8 == 0) : (lda % 4 == 0), b_ok = b_bf16 ? (ldb % 8 == 0) : (ldb % 4 == 0);
+    p.a_vec = a_ok && (((uintptr_t)A & 15) == 0);
+    p.b_vec = b_ok && (((uintptr_t)B & 15) == 0);
+    const bool nedge = (N % BN != 0);
+    if (nedge && !(!tb && !b_bf16 && N % 4 == 0 && !stat_part && !(c_bf16 && ns > 1))) return MLSP_ERR_UNSUPPORTED;   // k-major fp32 B only
+    if (!(p.a_vec && p.b_vec && M % bm == 0 && K % BK == 0)) return MLSP_ERR_UNSUPPORTED;
+    if (ns > 1) { p.C = slab; p.ldc = N; }
+    p.xcd_map = p.ntm >= 16 && p.ntn > 1;
+    dim3 grid(p.xcd_map ? ((p.ntm + 7) / 8) * 8 * p.ntn : p.ntm * p.ntn, ns);
+    const bool prof = g_prof.on && g_prof.used < PROF_MAX_PAIRS;
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
+    const int code = (a_bf16 ? 4 : 0) | (b_bf16 ? 2 : 0) | ((c_bf16 && ns == 1) ? 1 : 0);
+#define MX_GO(TA_, TB_, WM_, A_, B_, C_) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, A_, B_, C_>), grid, dim3(256), 0, st, p)
+#define MX_ACT_W(TA_, TB_, WM_) do { /* activation x weight: A in {f32, bf16}, B = fp32 weights, C in {f32, bf16} */ \
+        if (code == 0) MX_GO(TA_, TB_, WM_, false, false, false); else if (code == 1) MX_GO(TA_, TB_, WM_, false, false, true); \
+        else if (code == 4) MX_GO(TA_, TB_, WM_, true, false, false); else if (code == 5) MX_GO(TA_, TB_, WM_, true, false, true); \
+        else return MLSP_ERR_UNSUPPORTED; } while (0)
+#define MX_ACT_ACT(WM_) do { /* wgrad: A = dY, B = X in {f32, bf16}, C = fp32 */ \
+        if (code == 0) MX_GO(true, false, WM_, false, false, false); else if (code == 4) MX_GO(true, false, WM_, true, false, false); \
+        else if (code == 2) MX_GO(true, false, WM_, false, true, false); else if (code == 6) MX_GO(true, false, WM_, true, true, false); \
+        else return MLSP_ERR_UNSUPPORTED; } while (0)
+    if (ta && tb) return MLSP_ERR_UNSUPPORTED;
+    if (nedge) {            // ragged channel count on the N side (192-channel head input): dgrad dX = dY * W and wgrad dW = dY^T * X, B in fp32
+#define MX_NE(TA_, WM_) do { if (code == 0) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, false, WM_, false, false, false, true>), grid, dim3(256), 0, st, p); \
+        else if (code == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, false, WM_, false, false, true, true>), grid, dim3(256), 0, st, p); \
+        else if (code == 4) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, false, WM_, true, false, false, true>), grid, dim3(256), 0, st, p); \
+        else if (code == 5) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, false, WM_, true, false, true, true>), grid, dim3(256), 0, st, p); \
+        else return MLSP_ERR_UNSUPPORTED; } while (0)
+        if (ta) { if (bm == 128) MX_NE(true, 2); else MX_NE(true, 1); }
+        else { if (bm == 128) MX_NE(false, 2); else MX_NE(false, 1); }
+#undef MX_NE
+    } else if (bm == 128) {
+        if (!ta && tb) MX_ACT_W(false, true, 2); else if (!ta && !tb) MX_ACT_W(false, false, 2); else MX_ACT_ACT(2);
+    } else {
+        if (!ta && tb) MX_ACT_W(false, true, 1); else if (!ta && !tb) MX_ACT_W(false, false, 1); else MX_ACT_ACT(1);
+    }
+#undef MX_ACT_ACT
+#undef MX_ACT_W
+#undef MX_GO
+    if (prof) {
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
+        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + 4};
+        g_prof.used++;
+        g_prof.flop += 2.0 * M * (double)N * K;
+    }
+    if (ns > 1) launch_splitk_reduce_any(st, slab, (float*)C, M, N, ldc, ns, bias, gbias, rows_per_group);
+    return mlsp_launch_status();
+}
