@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 3
+#define MLSP_ABI_VERSION 4
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -235,6 +235,22 @@ int mlsp_sa_group_fwd_f32(const float* xyz, int ldx, const float* feat, int D, c
                           int N, int S, int ns, float* G, mlsp_stream_t stream);
 int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
                           float* dfeat, mlsp_stream_t stream);
+
+/* Folded first layer of a set-abstraction MLP (pointnet_util.py:120-129 grouping + :185-190 first Conv2d + BatchNorm2d + ReLU): the
+ * conv over the edge rows [x_j - c_i | f_j] equals u_j - w_i with u [B*N][C] = [x | f] W^T + b per source point and w [B*S][C] = c Wx^T
+ * per centre (two per-point GEMMs the caller runs with mlsp_pointmlp_fwd_f32 / mlsp_gemm_f32); neither the grouped tensor nor the
+ * pre-BN output is materialised.  idx [B][S][ns] int32 (indices local to the cloud, as mlsp_ball_query_f32 / mlsp_knn_query_f32
+ * return them).  fwd: BatchNorm over the E = B*S*ns edges (training: batch statistics, running buffers updated; eval: running
+ * buffers), Z [E][C] = relu(scale * (u_j - w_i) + shift), bn_save [4][C] = scale | shift | mean | invstd.
+ * bwd: dZ [E][C] -> du [B*N][C], dw [B*S][C] (closed-form BN backward; du over the reverse index of idx from
+ * mlsp_group_reverse(idx, B, S, N, ns, ...): fixed summation order), dgamma, dbeta [C].
+ * C in {16, 32, 64, 128, 256}, ns <= 256; MLSP_ERR_UNSUPPORTED otherwise (the caller keeps the grouped path). */
+int mlsp_sa_fold_fwd_f32(const float* u, const float* w, const int32_t* idx, int B, int N, int S, int ns, int C, const float* gamma,
+                         const float* beta, float* run_mean, float* run_var, float momentum, float eps, int training, float* Z,
+                         float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_sa_fold_bwd_f32(const float* dZ, const float* u, const float* w, const int32_t* idx, const int32_t* rev_off, const int32_t* rev_ent,
+                         int B, int N, int S, int ns, int C, const float* bn_save, int training, float* du, float* dw, float* dgamma,
+                         float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* Input corruption.  mlsp_region_assign_f32: utils/pc_utils.py:33-73 assign_region_to_point on X [B][C][N]
  * (channel-major as the trainer holds it); thr[n+1] = fp32 voxel edges, clip = fp32(0.99999999); regions int32 [B][N].

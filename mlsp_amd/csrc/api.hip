@@ -81,6 +81,13 @@ int launch_segmax_bwd(hipStream_t st, const float* dOut, const uint8_t* argk, in
 int edge_reduce_parts(int P);
 int edge_bwd_reduce_parts(int P, int Cout, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f,
                           int lddo, int ldo);
+int launch_sa_fold_fwd(hipStream_t st, const float* u, const float* w, const int* idx, int B, int N, int S, int ns, int C, const float* gamma,
+                       const float* beta, float* run_mean, float* run_var, float momentum, float eps, int training, float* Z, float* bn_save,
+                       double* part);
+int launch_sa_fold_bwd(hipStream_t st, const float* dZ, const float* u, const float* w, const int* idx, const int* rev_off, const int* rev_ent,
+                       int B, int N, int S, int ns, int C, const float* bn_save, int training, float* du, float* dw, float* dgamma,
+                       float* dbeta, double* part, float* mean_dz, float* mean_dzy);
+int sa_fold_parts(long E);
 int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd);
 int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW);
 int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
@@ -249,6 +256,30 @@ int mlsp_sa_group_fwd_f32(const float* xyz, int ldx, const float* feat, int D, c
 int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
                           float* dfeat, mlsp_stream_t st) {
     return launch_sa_group_bwd(st, dG, D, rev_off, rev_ent, B, N, S, ns, dfeat);
+}
+
+
+int mlsp_sa_fold_fwd_f32(const float* u, const float* w, const int32_t* idx, int B, int N, int S, int ns, int C, const float* gamma,
+                         const float* beta, float* run_mean, float* run_var, float momentum, float eps, int training, float* Z,
+                         float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (B <= 0 || S <= 0 || ns <= 0 || C <= 0) return MLSP_ERR_ARG;
+    Workspace wk(ws, ws_bytes);
+    double* part = training ? wk.take<double>((size_t)sa_fold_parts((long)B * S * ns) * 2 * C) : nullptr;
+    if (!wk.ok()) return MLSP_ERR_WORKSPACE;
+    return launch_sa_fold_fwd(st, u, w, idx, B, N, S, ns, C, gamma, beta, run_mean, run_var, momentum, eps, training, Z, bn_save, part);
+}
+
+int mlsp_sa_fold_bwd_f32(const float* dZ, const float* u, const float* w, const int32_t* idx, const int32_t* rev_off, const int32_t* rev_ent,
+                         int B, int N, int S, int ns, int C, const float* bn_save, int training, float* du, float* dw, float* dgamma,
+                         float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (B <= 0 || S <= 0 || ns <= 0 || C <= 0) return MLSP_ERR_ARG;
+    Workspace wk(ws, ws_bytes);
+    double* part = wk.take<double>((size_t)sa_fold_parts((long)B * S * ns) * 2 * C);
+    float* mean_dz = wk.take<float>(C);
+    float* mean_dzy = wk.take<float>(C);
+    if (!wk.ok()) return MLSP_ERR_WORKSPACE;
+    return launch_sa_fold_bwd(st, dZ, u, w, idx, rev_off, rev_ent, B, N, S, ns, C, bn_save, training, du, dw, dgamma, dbeta, part, mean_dz,
+                              mean_dzy);
 }
 
 int mlsp_graph_feature_fwd_f32(const float* x, const int32_t* idx, int B, int N, int C, int k, float* F, mlsp_stream_t st) {

@@ -393,3 +393,220 @@ int launch_interp3_bwd(hipStream_t st, const float* dout, const float* dist, con
     hipLaunchKernelGGL(interp3_bwd_kernel, dim3((B * S + 3) / 4), dim3(256), 0, st, dout, dist, rev_off, rev_ent, N, S, D, B * S, dfeat);
     return mlsp_launch_status();
 }
+
+// ---- folded first layer of a set-abstraction MLP (pointnet_util.py:120-129,185-190) ---------------------------------
+// The first 1x1 conv acts on the edge rows [x_j - c_i | f_j]:  W [x_j - c_i ; f_j] + b = u_j - w_i  with  u = [x | f] W^T + b  per
+// SOURCE point (B*N rows) and  w = c Wx^T  per CENTRE (B*S rows): two small per-point GEMMs instead of one over the B*S*ns edge rows,
+// and neither the grouped tensor [E, 3+D] nor the pre-BN output [E, C] is written.  BatchNorm batch statistics run over the E edges
+// (pass 1: gather u_j - w_i and reduce), pass 2 gathers again (the u rows stay in L2) and writes z = relu(scale*y + shift) [E, C], the
+// operand of the second conv.  Backward recomputes y the same way: dz' = dz*[scale*y + shift > 0], closed-form BN backward
+// dy = scale*(dz' - mean(dz') - yhat*mean(dz'*yhat)), then  dw_i = -sum_s dy_(i,s)  (a centre's edges are consecutive rows) and
+// du_j = sum over the edges that point at j (reverse index, fixed order: bitwise reproducible, no float atomics).
+// Thread = (channel quad, edge lane); C % 4 == 0, 256 % (C / 4) == 0.
+#define SAF_EPB 256          // edges per workgroup of the edge passes
+template <int MODE>          // 0: statistics of y | 1: z = relu(scale*y + shift) | 2: sums of dz' and dz'*yhat
+__global__ __launch_bounds__(256) void sa_fold_edge_kernel(const float* __restrict__ u, const float* __restrict__ w, const int* __restrict__ idx,
+                                                           int N, int S, int ns, int C, long E, const float* __restrict__ bn /* scale|shift|mean|invstd */,
+                                                           const float* __restrict__ dZ, float* __restrict__ Z, double* __restrict__ part) {
+    __shared__ float shd[2][256 * 4];
+    const int tid = threadIdx.x, tpr = C >> 2, nel = 256 / tpr;
+    const int cq = tid % tpr, el = tid / tpr, c = 4 * cq;
+    f32x4 sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0}, mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+    if (MODE != 0) { sc = *(const f32x4*)(bn + c); sh = *(const f32x4*)(bn + C + c); }
+    if (MODE == 2) { mu = *(const f32x4*)(bn + 2 * C + c); is = *(const f32x4*)(bn + 3 * C + c); }
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const long e0 = (long)blockIdx.x * SAF_EPB;
+    const long e1 = e0 + SAF_EPB < E ? e0 + SAF_EPB : E;
+    for (long eb = e0 + el; eb < e1; eb += 4L * nel) {                     // four edges per thread in flight
+        f32x4 uv[4], wv[4], dz[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long e = eb + (long)t * nel;
+            const bool ok = e < e1;
+            const long ee = ok ? e : e0;
+            const long ctr = ee / ns;                                       // global centre row b*S + i
+            const long cloud = ctr / S;
+            const int j = idx[ee];
+            uv[t] = *(const f32x4*)(u + ((size_t)cloud * N + j) * C + c);
+            wv[t] = *(const f32x4*)(w + (size_t)ctr * C + c);
+            if (MODE == 2) dz[t] = *(const f32x4*)(dZ + (size_t)ee * C + c);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long e = eb + (long)t * nel;
+            if (e >= e1) continue;
+            f32x4 y = uv[t] - wv[t];
+            if (MODE == 0) {
+                a0 = a0 + y;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a1[q] = fmaf(y[q], y[q], a1[q]);
+            } else if (MODE == 1) {
+                f32x4 z;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[q] = fmaxf(fmaf(y[q], sc[q], sh[q]), 0.f);
+                *(f32x4*)(Z + (size_t)e * C + c) = z;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float d = fmaf(y[q], sc[q], sh[q]) > 0.f ? dz[t][q] : 0.f;
+                    a0[q] += d;
+                    a1[q] = fmaf(d, (y[q] - mu[q]) * is[q], a1[q]);
+                }
+            }
+        }
+    }
+    if (MODE == 1) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { shd[0][tid * 4 + q] = a0[q]; shd[1][tid * 4 + q] = a1[q]; }
+    __syncthreads();
+    if (tid < tpr) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int g = 0; g < nel; ++g) { s0 += (double)shd[0][(g * tpr + tid) * 4 + q]; s1 += (double)shd[1][(g * tpr + tid) * 4 + q]; }
+            part[((size_t)blockIdx.x * 2 + 0) * C + 4 * tid + q] = s0;
+            part[((size_t)blockIdx.x * 2 + 1) * C + 4 * tid + q] = s1;
+        }
+    }
+}
+
+// dy of one edge, channel quad: scale * (dz' - m1 - yhat * m2)   (eval mode: m1 = m2 = 0)
+__device__ __forceinline__ f32x4 saf_dy(const f32x4& uq, const f32x4& wq, const f32x4& dz, const f32x4& sc, const f32x4& sh, const f32x4& mu,
+                                        const f32x4& is, const f32x4& m1, const f32x4& m2) {
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float y = uq[q] - wq[q];
+        const float d = fmaf(y, sc[q], sh[q]) > 0.f ? dz[q] : 0.f;
+        r[q] = sc[q] * (d - m1[q] - (y - mu[q]) * is[q] * m2[q]);
+    }
+    return r;
+}
+
+// dw_i = -sum over the ns edges of centre i.  Workgroup = 256 / (C/4) centres' worth of edge lanes: thread (cq, el) sums the slots
+// el, el + nel, ... of ONE centre per pass; the nel partials are added through LDS in lane order.
+__global__ __launch_bounds__(256) void sa_fold_bwd_centre_kernel(const float* __restrict__ dZ, const float* __restrict__ u, const float* __restrict__ w,
+                                                                 const int* __restrict__ idx, int N, int S, int ns, int C, long ncentres,
+                                                                 const float* __restrict__ bn, const float* __restrict__ m1v,
+                                                                 const float* __restrict__ m2v, float* __restrict__ dw) {
+    __shared__ float shd[256 * 4];
+    const int tid = threadIdx.x, tpr = C >> 2, nel = 256 / tpr;
+    const int cq = tid % tpr, el = tid / tpr, c = 4 * cq;
+    const f32x4 sc = *(const f32x4*)(bn + c), sh = *(const f32x4*)(bn + C + c), mu = *(const f32x4*)(bn + 2 * C + c), is = *(const f32x4*)(bn + 3 * C + c);
+    f32x4 m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+    if (m1v) { m1 = *(const f32x4*)(m1v + c); m2 = *(const f32x4*)(m2v + c); }
+    const long ctr = blockIdx.x;
+    if (ctr >= ncentres) return;
+    const long cloud = ctr / S;
+    const f32x4 wq = *(const f32x4*)(w + (size_t)ctr * C + c);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = el; s < ns; s += nel) {
+        const long e = ctr * ns + s;
+        const int j = idx[e];
+        const f32x4 uq = *(const f32x4*)(u + ((size_t)cloud * N + j) * C + c);
+        const f32x4 dz = *(const f32x4*)(dZ + (size_t)e * C + c);
+        acc = acc + saf_dy(uq, wq, dz, sc, sh, mu, is, m1, m2);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) shd[tid * 4 + q] = acc[q];
+    __syncthreads();
+    if (tid < tpr) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < nel; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] += shd[(g * tpr + tid) * 4 + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = -s[q];
+        *(f32x4*)(dw + (size_t)ctr * C + 4 * tid) = s;
+    }
+}
+
+// du_j = sum over the edges (i, s) with idx[i][s] == j, in the order of the reverse index.  One wave per point, lane = channel quad
+// group: 64 lanes = (C/4 quads) x (64 / (C/4) entry lanes); entry lanes are combined with xor-shuffles in a fixed order.
+__global__ __launch_bounds__(256) void sa_fold_bwd_point_kernel(const float* __restrict__ dZ, const float* __restrict__ u, const float* __restrict__ w,
+                                                                const int* __restrict__ rev_off, const int* __restrict__ rev_ent, int N, int S,
+                                                                int ns, int C, long P, const float* __restrict__ bn, const float* __restrict__ m1v,
+                                                                const float* __restrict__ m2v, float* __restrict__ du) {
+    const int lane = threadIdx.x & 63;
+    const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= P) return;
+    const int tpr = C >> 2;                      // 16 (C = 64): 4 entry lanes; 32 (C = 128): 2; 64 (C = 256): 1
+    const int nen = 64 / tpr;
+    const int cq = lane % tpr, en = lane / tpr, c = 4 * cq;
+    const long b = j / N;
+    const f32x4 sc = *(const f32x4*)(bn + c), sh = *(const f32x4*)(bn + C + c), mu = *(const f32x4*)(bn + 2 * C + c), is = *(const f32x4*)(bn + 3 * C + c);
+    f32x4 m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+    if (m1v) { m1 = *(const f32x4*)(m1v + c); m2 = *(const f32x4*)(m2v + c); }
+    const f32x4 uq = *(const f32x4*)(u + (size_t)j * C + c);
+    const int e0 = rev_off[j], e1 = rev_off[j + 1];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = e0 + en; t < e1; t += 2 * nen) {                          // two entries per lane in flight
+        const int t2 = t + nen;
+        const int ent = rev_ent[t], ent2 = t2 < e1 ? rev_ent[t2] : ent;
+        const size_t ctr = (size_t)b * S + (ent >> 8), ctr2 = (size_t)b * S + (ent2 >> 8);
+        const size_t row = ctr * ns + (ent & 255), row2 = ctr2 * ns + (ent2 & 255);
+        const f32x4 dz = *(const f32x4*)(dZ + row * C + c), wq = *(const f32x4*)(w + ctr * C + c);
+        const f32x4 dzb = *(const f32x4*)(dZ + row2 * C + c), wqb = *(const f32x4*)(w + ctr2 * C + c);
+        acc = acc + saf_dy(uq, wq, dz, sc, sh, mu, is, m1, m2);
+        if (t2 < e1) acc = acc + saf_dy(uq, wqb, dzb, sc, sh, mu, is, m1, m2);
+    }
+    for (int o = tpr; o < 64; o <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], o, 64);
+    }
+    if (en == 0) *(f32x4*)(du + (size_t)j * C + c) = acc;
+}
+
+int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma, const float* beta,
+                       float* run_mean, float* run_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
+                       float* save_invstd);
+int launch_bn_eval_prepare(hipStream_t st, int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
+                           float eps, float* scale, float* shift, float* save_mean, float* save_invstd);
+int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta, float* mean_dz,
+                           float* mean_dzy);
+
+static bool saf_shape_ok(int C, int ns) { return (C == 16 || C == 32 || C == 64 || C == 128 || C == 256) && ns <= 256; }
+int sa_fold_parts(long E) { return (int)((E + SAF_EPB - 1) / SAF_EPB); }
+
+int launch_sa_fold_fwd(hipStream_t st, const float* u, const float* w, const int* idx, int B, int N, int S, int ns, int C, const float* gamma,
+                       const float* beta, float* run_mean, float* run_var, float momentum, float eps, int training, float* Z, float* bn_save,
+                       double* part) {
+    if (!u || !w || !idx || !gamma || !beta || !Z || !bn_save || B <= 0 || N <= 0 || S <= 0 || ns <= 0) return MLSP_ERR_ARG;
+    if (!saf_shape_ok(C, ns)) return MLSP_ERR_UNSUPPORTED;
+    const long E = (long)B * S * ns;
+    const int nparts = sa_fold_parts(E);
+    float* scale = bn_save, *shift = bn_save + C, *mean = bn_save + 2 * C, *invstd = bn_save + 3 * C;
+    if (training) {
+        if (!part) return MLSP_ERR_WORKSPACE;
+        hipLaunchKernelGGL((sa_fold_edge_kernel<0>), dim3(nparts), dim3(256), 0, st, u, w, idx, N, S, ns, C, E, (const float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, part);
+        int rc = launch_bn_finalize(st, part, nparts, (double)E, C, gamma, beta, run_mean, run_var, momentum, eps, scale, shift, mean, invstd);
+        if (rc != MLSP_OK) return rc;
+    } else {
+        if (!run_mean || !run_var) return MLSP_ERR_ARG;
+        int rc = launch_bn_eval_prepare(st, C, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd);
+        if (rc != MLSP_OK) return rc;
+    }
+    hipLaunchKernelGGL((sa_fold_edge_kernel<1>), dim3(nparts), dim3(256), 0, st, u, w, idx, N, S, ns, C, E, (const float*)bn_save,
+                       (const float*)nullptr, Z, (double*)nullptr);
+    return mlsp_launch_status();
+}
+
+int launch_sa_fold_bwd(hipStream_t st, const float* dZ, const float* u, const float* w, const int* idx, const int* rev_off, const int* rev_ent,
+                       int B, int N, int S, int ns, int C, const float* bn_save, int training, float* du, float* dw, float* dgamma,
+                       float* dbeta, double* part, float* mean_dz, float* mean_dzy) {
+    if (!dZ || !u || !w || !idx || !rev_off || !rev_ent || !bn_save || !du || !dw || !dgamma || !dbeta || !part || !mean_dz || !mean_dzy)
+        return MLSP_ERR_ARG;
+    if (!saf_shape_ok(C, ns)) return MLSP_ERR_UNSUPPORTED;
+    const long E = (long)B * S * ns, P = (long)B * N, NC = (long)B * S;
+    const int nparts = sa_fold_parts(E);
+    hipLaunchKernelGGL((sa_fold_edge_kernel<2>), dim3(nparts), dim3(256), 0, st, u, w, idx, N, S, ns, C, E, bn_save, dZ, (float*)nullptr, part);
+    int rc = launch_bn_bwd_finalize(st, part, nparts, (double)E, C, dgamma, dbeta, mean_dz, mean_dzy);
+    if (rc != MLSP_OK) return rc;
+    const float* m1 = training ? mean_dz : nullptr;
+    hipLaunchKernelGGL(sa_fold_bwd_centre_kernel, dim3((unsigned)NC), dim3(256), 0, st, dZ, u, w, idx, N, S, ns, C, NC, bn_save, m1,
+                       (const float*)mean_dzy, dw);
+    hipLaunchKernelGGL(sa_fold_bwd_point_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, dZ, u, w, rev_off, rev_ent, N, S, ns, C, P,
+                       bn_save, m1, (const float*)mean_dzy, du);
+    return mlsp_launch_status();
+}

@@ -157,6 +157,72 @@ class _Group(Function):
         return None, None, dfeat, None
 
 
+class _SAFold(Function):
+    """BatchNorm + ReLU of the folded first SA layer on the edges: Z[(b,i,s)] = relu(BN(u[b, idx[b,i,s]] - w[b,i]))  (mlsp_sa_fold_*_f32);
+    u [B*N,C] per source point, w [B*S,C] per centre, idx int32 [B,S,ns].  Gradients: du, dw, dgamma, dbeta."""
+
+    @staticmethod
+    def forward(ctx, u, w, idx32, gamma, beta, run_mean, run_var, training, momentum, eps, dims):
+        lib = _lib.load()
+        B, N, S, ns = dims
+        u, w = u.contiguous(), w.contiguous()
+        _lib.require_gpu(u, w, idx32)
+        C = u.shape[1]
+        dev = u.device
+        Z = torch.empty((B * S * ns, C), dtype=torch.float32, device=dev)
+        bn_save = torch.empty((4, C), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, B * S * ns, C, C)
+        _lib.check(lib.mlsp_sa_fold_fwd_f32(u.data_ptr(), w.data_ptr(), idx32.data_ptr(), B, N, S, ns, C, gamma.data_ptr(), beta.data_ptr(),
+                                            _lib.ptr(run_mean), _lib.ptr(run_var), float(momentum), float(eps), int(training), Z.data_ptr(),
+                                            bn_save.data_ptr(), ws, wsn, _lib.stream()), "mlsp_sa_fold_fwd_f32")
+        ctx.save_for_backward(u, w, idx32, bn_save)
+        ctx.dims, ctx.training = dims, bool(training)
+        return Z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dZ):
+        lib = _lib.load()
+        u, w, idx32, bn_save = ctx.saved_tensors
+        B, N, S, ns = ctx.dims
+        C = u.shape[1]
+        dev = dZ.device
+        dZ = dZ.contiguous()
+        rev_off = torch.empty((B * N + 1,), dtype=torch.int32, device=dev)
+        rev_ent = torch.empty((B * S * ns,), dtype=torch.int32, device=dev)
+        _lib.check(lib.mlsp_group_reverse(idx32.data_ptr(), B, S, N, ns, rev_off.data_ptr(), rev_ent.data_ptr(), _lib.stream()),
+                   "mlsp_group_reverse")
+        du, dw = torch.empty_like(u), torch.empty_like(w)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, B * S * ns, C, C)
+        _lib.check(lib.mlsp_sa_fold_bwd_f32(dZ.data_ptr(), u.data_ptr(), w.data_ptr(), idx32.data_ptr(), rev_off.data_ptr(), rev_ent.data_ptr(),
+                                            B, N, S, ns, C, bn_save.data_ptr(), int(ctx.training), du.data_ptr(), dw.data_ptr(),
+                                            dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()), "mlsp_sa_fold_bwd_f32")
+        return du, dw, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+_FOLD_CHANNELS = (16, 32, 64, 128, 256)
+
+
+def _fold_supported(conv, nsample):
+    return conv.out_channels in _FOLD_CHANNELS and nsample <= 256
+
+
+def _fold_first_layer(xyz, new_xyz, points, idx, W0, conv, bn, training):
+    """First Conv2d(1x1) + BatchNorm2d + ReLU of a set-abstraction branch WITHOUT the grouped tensor:
+    W0 [x_j - c_i ; f_j] + b = u_j - w_i,  u = [x | f] W0^T + b per source point, w = c W0[:, :3]^T per centre (W0 columns ordered
+    [xyz | features], pointnet_util.py:124-129).  -> activated edge rows [B*S*ns, C]."""
+    B, N, _ = xyz.shape
+    S, ns = idx.shape[1], idx.shape[2]
+    rows = xyz.reshape(B * N, 3) if points is None else torch.cat([xyz, points], dim=-1).reshape(B * N, -1)
+    u = Fh.pointmlp(rows, W0, bias=conv.bias)
+    w = Fh.pointmlp(new_xyz.reshape(B * S, 3).contiguous(), W0[:, :3])
+    rm, rv = _bn_buffers(bn, training)
+    idx32 = idx.to(torch.int32).contiguous()
+    return _SAFold.apply(u, w, idx32, bn.weight, bn.bias, rm, rv, training, bn.momentum, bn.eps, (B, N, S, ns))
+
+
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, knn=False, fps_start=None):
     """pointnet_util.py:99-136: FPS centres, ball-query neighbourhoods, centred coordinates + features.
     Returns new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D] (+ grouped_xyz, fps_idx with returnfps)."""
@@ -201,6 +267,7 @@ class PointNetSetAbstraction(nn.Module):
             last_channel = out_channel
         self.group_all = group_all
         self.fps_start = None
+        self.fold_first = True          # fold the first conv onto the points (no grouped tensor); False: the materialised path
 
     @flushing_forward
     def forward(self, xyz, points):
@@ -208,6 +275,19 @@ class PointNetSetAbstraction(nn.Module):
         if self.group_all:
             new_xyz, new_points = sample_and_group_all(xyz, points)
             S, ns = 1, xyz.shape[1]
+        elif self.fold_first and _fold_supported(self.mlp_convs[0], self.nsample) and len(self.mlp_convs) > 1:
+            # sample_and_group (pointnet_util.py:99-136) without its output tensor: the first conv is folded onto the points
+            if xyz.requires_grad:
+                raise NotImplementedError("gradients with respect to the coordinates are not built (the reference never needs them)")
+            S, ns = self.npoint, self.nsample
+            fps_idx = farthest_point_sample(xyz, S, start=self.fps_start)
+            new_xyz = index_points(xyz, fps_idx)
+            idx = knn_point(ns, xyz, new_xyz) if self.knn else query_ball_point(self.radius, ns, xyz, new_xyz)
+            c0 = self.mlp_convs[0]
+            X = _fold_first_layer(xyz, new_xyz, points, idx, c0.weight.view(c0.out_channels, c0.in_channels), c0, self.mlp_bns[0],
+                                  self.training)
+            X = _sa_mlp(X, self.mlp_convs[1:], self.mlp_bns[1:], self.training)
+            return new_xyz, Fh.segmax(X, ns).view(B, S, -1)
         else:
             new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, knn=self.knn,
                                                    fps_start=self.fps_start)
@@ -252,6 +332,7 @@ class PointNetSetAbstractionMsg(nn.Module):
             self.conv_blocks.append(convs)
             self.bn_blocks.append(bns)
         self.fps_start = None
+        self.fold_first = True
 
     @flushing_forward
     def forward(self, xyz, points, seed_idx=None):
@@ -263,13 +344,17 @@ class PointNetSetAbstractionMsg(nn.Module):
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
             idx = knn_point(K, xyz, new_xyz) if self.knn else query_ball_point(radius, K, xyz, new_xyz)
-            G = _Group.apply(xyz, new_xyz, points, idx)                              # rows [xyz_j - c_i | feat_j]
             c0 = self.conv_blocks[i][0]
             W0 = c0.weight.view(c0.out_channels, c0.in_channels)
             if points is not None:
                 D = points.shape[-1]
                 W0 = torch.cat((W0[:, D:], W0[:, :D]), dim=1)                        # reference column order: [feat | xyz]
-            X = _sa_mlp(G, self.conv_blocks[i], self.bn_blocks[i], self.training, first_weight=W0)
+            if self.fold_first and _fold_supported(c0, K) and len(self.conv_blocks[i]) > 1:
+                X = _fold_first_layer(xyz, new_xyz, points, idx, W0, c0, self.bn_blocks[i][0], self.training)
+                X = _sa_mlp(X, self.conv_blocks[i][1:], self.bn_blocks[i][1:], self.training)
+            else:
+                G = _Group.apply(xyz, new_xyz, points, idx)                          # rows [xyz_j - c_i | feat_j]
+                X = _sa_mlp(G, self.conv_blocks[i], self.bn_blocks[i], self.training, first_weight=W0)
             outs.append(Fh.segmax(X, K).view(B, S, -1))
         return new_xyz, torch.cat(outs, dim=-1)
 

@@ -187,3 +187,47 @@ def test_feature_propagation_vs_reference_golden(dev, name):
     np.testing.assert_allclose(p1.grad.cpu().numpy(), g["d_points1"], rtol=2e-3, atol=1e-3)
     np.testing.assert_allclose(pp2.grad.cpu().numpy(), g["d_points2"], rtol=2e-3, atol=1e-3)
     _check_layer(g, layer, tol_grad=1e-2)
+
+
+# ----------------------------------------------------------------------------- folded first layer (no grouped tensor)
+@pytest.mark.parametrize("B,N,S,radius,ns,D,mlp,knn,train", [(4, 256, 64, 0.4, 16, 0, [64, 64, 128], False, True),
+                                                              (3, 300, 50, 0.5, 24, 13, [128, 64], False, True),
+                                                              (2, 200, 40, 0.5, 8, 5, [32, 48], True, True),
+                                                              (2, 256, 64, 0.4, 16, 6, [64, 32], False, False)])
+def test_folded_first_sa_layer_equals_grouped_path(dev, B, N, S, radius, ns, D, mlp, knn, train):
+    """W [x_j - c_i ; f_j] + b = u_j - w_i on the points (mlsp_sa_fold_*_f32, `fold_first`) against the materialised grouped tensor +
+    edge GEMM of the same module: outputs, feature / parameter gradients and BatchNorm buffers (training and eval mode)."""
+    from mlsp_amd import pointnet2 as p2
+    import copy
+    torch.manual_seed(7)
+    xyz = (torch.rand(B, N, 3) * 2 - 1).to(dev)
+    feat = torch.randn(B, N, D).to(dev) if D else None
+    a = p2.PointNetSetAbstraction(S, radius, ns, 3 + D, mlp, False, knn=knn).to(dev)
+    for bn in a.mlp_bns:                                   # non-trivial affine parameters and buffers (negative scales included)
+        bn.weight.data.uniform_(-1.0, 1.5); bn.bias.data.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    b = copy.deepcopy(a)
+    a.fold_first, b.fold_first = True, False
+    start = torch.arange(B) % N
+    a.fps_start = b.fps_start = start
+    a.train(train); b.train(train)
+    fa = feat.clone().requires_grad_(True) if D else None
+    fb = feat.clone().requires_grad_(True) if D else None
+    xa, oa = a(xyz, fa)
+    xb, ob = b(xyz, fb)
+    assert torch.equal(xa, xb)
+    scale = ob.abs().max().item() + 1e-9
+    assert (oa - ob).abs().max().item() / scale < 2e-5, (oa - ob).abs().max().item() / scale
+    wgt = torch.randn_like(oa)
+    (oa * wgt).sum().backward()
+    (ob * wgt).sum().backward()
+    if D:
+        err = (fa.grad - fb.grad).abs().max().item() / (fb.grad.abs().max().item() + 1e-9)
+        assert err < 2e-4, err
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if k.startswith("mlp_convs") and k.endswith("bias") and train:
+            continue                                       # analytically zero in front of a batch-statistics BatchNorm
+        err = (pa.grad - pb.grad).abs().max().item() / (pb.grad.abs().max().item() + 1e-9)
+        assert err < 5e-4, (k, err)
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        np.testing.assert_allclose(va.cpu().numpy(), vb.cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
