@@ -139,6 +139,9 @@ size_t tnet_bwd_scratch_floats(int ntiles);
 int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const float* bn1, const float* W2, const float* bn2,
                          const float* g, const uint8_t* argsel, const float* coef, int P, int N, int k, float slope, float* dhp,
                          float* scratch, double* part1, float* dW2, int* nparts);
+size_t tnet_w1_moment_doubles(int P, int k);
+int launch_tnet_bwd_w1_moments(hipStream_t st, const float* dhp, const int* idx, const int* rev_off, const float* x, int ldx, const float* W1,
+                               const float* bn1, const float* m1, const float* m2, int P, int N, int k, int C, double* scratch, float* dW1);
 int launch_tnet_edge_bwd2(hipStream_t st, const float* dhp, const float* uv, const float* s1, const float* bn1, const float* m1,
                           const float* m2, const int* rev_off, const int* rev_ent, int P, int N, int k, float* duv);
 
@@ -450,6 +453,13 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
     int nparts = 0;
     CHECK(launch_tnet_edge_bwd(st, uv, idx, bn1_save, W2, bn2_save, g, argsel, coef, P, N, k, slope, dhp, dW2part, part, dW2, &nparts));
     CHECK(launch_bn_bwd_finalize(st, part, nparts, (double)E, C1, dgamma1, dbeta1, m1, m2));
+    if (!dx && C <= 4) {
+        // the input cloud needs no gradient (DGCNN's T-Net reads the raw coordinates): dW1 straight from one sequential pass over dh'
+        // and the coordinate moments -- no fold onto the points, no [P,128]^T [P,C] GEMM (tnet.hip, tnet_bwd_tmom_kernel)
+        double* mom = w.take<double>(tnet_w1_moment_doubles(P, k));
+        if (!w.ok()) return MLSP_ERR_WORKSPACE;
+        return launch_tnet_bwd_w1_moments(st, dhp, idx, rev_off, x, ldx, W1, bn1_save, training ? m1 : nullptr, m2, P, N, k, C, mom, dW1);
+    }
     CHECK(launch_tnet_edge_bwd2(st, dhp, uv, s1, bn1_save, training ? m1 : nullptr, m2, rev_off, rev_ent, P, N, k, duv));
     CHECK(launch_build_wd(st, W1, C1, C, Wd));
     if (dx) CHECK(launch_gemm(st, false, false, P, C, 2 * C1, duv, 2 * C1, Wd, C, dx, C, nullptr, nullptr, 0, slab, sf));

@@ -1145,3 +1145,199 @@ int launch_tnet_edge_bwd2(hipStream_t st, const float* dhp, const float* uv, con
                        k, duv);
     return mlsp_launch_status();
 }
+
+// ---- first T-Net conv, weight gradient WITHOUT folding dh' onto the points (the input cloud needs no gradient) ---------------------
+// With hpre_e = Wa x_j + Wv x_i (Wa = W1[:, :C], Wv = W1[:, C:] - Wa; edge e = (i, s), j its neighbour) and the closed-form BN1
+// backward g_e = scale (dh'_e - m1 - hhat_e m2), the gradients dA = sum_e g_e x_j^T and dD = sum_e g_e x_i^T need from the E-sized data
+// only  T1 = sum_e dh'_e x_j^T  and  T2 = sum_e dh'_e x_i^T  (64 x C each): ONE sequential pass over dh' instead of the reverse-index
+// gather of tnet_edge_bwd2_kernel (random 256-byte rows) + the [P,128]^T [P,C] GEMM.  Everything else is a function of the
+// coordinate moments  A = sum_e x_j x_j^T = sum_j deg_j x_j x_j^T,  Bm = sum_e x_i x_j^T = sum_i x_i (sum_s x_j(i,s))^T,
+// Cm = k sum_i x_i x_i^T,  sj = sum_j deg_j x_j,  si = k sum_i x_i  (a P-sized pass):
+//   dA[c] = sc_c ( T1[c] - m1_c sj - m2_c is_c ( Wa[c] A + Wv[c] Bm - mu_c sj ) )
+//   dD[c] = sc_c ( T2[c] - m1_c si - m2_c is_c ( Wa[c] Bm^T + Wv[c] Cm - mu_c si ) )        dW1 = [dA - dD | dD]
+// (eval mode: m1 = m2 = 0).  C <= 4 coordinates.
+#define TW_ROWS 512          // edge rows per workgroup of the T pass (two chunks of 256)
+#define TW_XM 56             // moments per block: A[16] Bm[16] Cm[16] sj[4] si[4]
+// T pass: a workgroup owns TW_ROWS consecutive edge rows.  Per chunk of 256 rows every thread first fetches ONE row's coordinates
+// (idx -> x_j, and x_i: the only dependent loads, 256 of them in parallel) into LDS; then the four waves stream the dh' rows
+// (lane = channel, 256-byte coalesced loads, eight rows in flight) against the staged coordinates.
+__global__ __launch_bounds__(256) void tnet_bwd_tmom_kernel(const float* __restrict__ dhp, const int* __restrict__ idx, const float* __restrict__ x,
+                                                            int ldx, long E, int N, int k, int C, double* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float xs[256][8];            // [row of the chunk][x_j (4) | x_i (4)]
+    __shared__ float red[4][TN_C1][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long e0 = (long)blockIdx.x * TW_ROWS, e1 = e0 + TW_ROWS < E ? e0 + TW_ROWS : E;
+    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long r0 = e0; r0 < e1; r0 += 256) {
+        const long e = r0 + tid;
+        f32x4 vj = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
+        if (e < e1) {
+            const long i = e / k;
+            const long j = (i / N) * N + idx[e];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < C) { vj[c] = x[j * ldx + c]; vi[c] = x[i * ldx + c]; }
+        }
+        __syncthreads();                                                 // the previous chunk's readers are done
+        *(f32x4*)&xs[tid][0] = vj;
+        *(f32x4*)&xs[tid][4] = vi;
+        __syncthreads();
+        const int nrow = (int)(e1 - r0 < 256 ? e1 - r0 : 256);
+        for (int rb = wave; rb < nrow; rb += 32) {                       // rows rb, rb + 4, ... rb + 28 of this wave in flight
+            float d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + 4 * u;
+                d[u] = r < nrow ? dhp[(size_t)(r0 + r) * TN_C1 + lane] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + 4 * u;
+                const int rr = r < nrow ? r : 0;
+                const f32x4 cj = *(const f32x4*)&xs[rr][0], ci = *(const f32x4*)&xs[rr][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { t1[c] = fmaf(d[u], cj[c], t1[c]); t2[c] = fmaf(d[u], ci[c], t2[c]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { red[wave][lane][c] = t1[c]; red[wave][lane][4 + c] = t2[c]; }
+    __syncthreads();
+    for (int t = tid; t < TN_C1 * 8; t += 256) {
+        const int ch = t >> 3, q = t & 7;
+        part[((size_t)ch * gridDim.x + blockIdx.x) * 8 + q] = ((double)red[0][ch][q] + (double)red[1][ch][q]) + ((double)red[2][ch][q] + (double)red[3][ch][q]);
+    }
+}
+
+// coordinate moments: one wave per 64 points (many small workgroups: the pass is a chain of two dependent gathers, not bandwidth)
+__global__ __launch_bounds__(64) void tnet_bwd_xmom_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ idx,
+                                                           const int* __restrict__ rev_off, int P, int N, int k, int C, double* __restrict__ part) {
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    float m[TW_XM];
+#pragma unroll
+    for (int q = 0; q < TW_XM; ++q) m[q] = 0.f;
+    if (i < P) {
+        float xi[4] = {0.f, 0.f, 0.f, 0.f}, xb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) xi[c] = x[(size_t)i * ldx + c];
+        const int base = (i / N) * N;
+        for (int s0 = 0; s0 < k; s0 += 16) {                              // sixteen neighbours' coordinates in flight
+            int j[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) j[u] = s0 + u < k ? base + idx[(size_t)i * k + s0 + u] : -1;
+            float v[16][3];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[u][c] = (j[u] >= 0 && c < C) ? x[(size_t)j[u] * ldx + c] : 0.f;
+            float v3[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v3[u] = (j[u] >= 0 && C > 3) ? x[(size_t)j[u] * ldx + 3] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) xb[c] += v[u][c];
+                xb[3] += v3[u];
+            }
+        }
+        const float deg = (float)(rev_off[i + 1] - rev_off[i]), fk = (float)k;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                m[4 * a + b] = deg * xi[a] * xi[b];           // A
+                m[16 + 4 * a + b] = xi[a] * xb[b];            // Bm[a][b] = sum_e x_i[a] x_j[b]
+                m[32 + 4 * a + b] = fk * xi[a] * xi[b];       // Cm
+            }
+            m[48 + a] = deg * xi[a];                          // sj
+            m[52 + a] = fk * xi[a];                           // si
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TW_XM; ++q) {
+        float v = m[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) part[(size_t)blockIdx.x * TW_XM + q] = (double)v;
+    }
+}
+
+// one workgroup per conv1 output channel c: sums the partials (parallel over the partial blocks, fixed order), evaluates the closed
+// form, writes row c of dW1 [C1][2C]
+__global__ __launch_bounds__(256) void tnet_bwd_w1_finish_kernel(const double* __restrict__ tpart, int ntb, const double* __restrict__ xpart, int nxb,
+                                                                 const float* __restrict__ W1, const float* __restrict__ bn1,
+                                                                 const float* __restrict__ m1v, const float* __restrict__ m2v, int C,
+                                                                 float* __restrict__ dW1) {
+    __shared__ double sh[4][8];
+    __shared__ double shx[4][TW_XM];
+    __shared__ double xm[TW_XM];
+    __shared__ double T[8];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // T1 | T2 of channel c: thread (group g = tid >> 3, value q = tid & 7) sums the partial blocks g, g + 32, ...
+        const int q = tid & 7, g = tid >> 3;
+        double a = 0.0;
+        const double* tp = tpart + (size_t)c * ntb * 8 + q;               // [c][block][8]: this channel's partials are contiguous
+        for (int b0 = g; b0 < ntb; b0 += 32 * 8) {                        // eight loads in flight, added in block order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = b0 + 32 * u < ntb ? tp[(size_t)(b0 + 32 * u) * 8] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+        if (lane < 8) sh[wave][lane] = a;
+    }
+    {   // coordinate moments: thread (group g = tid / 56 < 4, value q = tid % 56)
+        const int q = tid % TW_XM, g = tid / TW_XM;
+        double a = 0.0;
+        if (g < 4)
+            for (int b0 = g; b0 < nxb; b0 += 4 * 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = b0 + 4 * u < nxb ? xpart[(size_t)(b0 + 4 * u) * TW_XM + q] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+        if (g < 4) shx[g][q] = a;
+    }
+    __syncthreads();
+    if (tid < 8) T[tid] = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
+    if (tid < TW_XM) xm[tid] = (shx[0][tid] + shx[1][tid]) + (shx[2][tid] + shx[3][tid]);
+    __syncthreads();
+    if (tid < C) {
+        const int d = tid;
+        const double sc = bn1[c], mu = bn1[2 * TN_C1 + c], is = bn1[3 * TN_C1 + c];
+        const double m1 = m1v ? (double)m1v[c] : 0.0, m2 = m1v ? (double)m2v[c] : 0.0;
+        double hxj = 0.0, hxi = 0.0;                          // sum_e hpre_e[c] x_j[d], sum_e hpre_e[c] x_i[d]
+        for (int q = 0; q < C; ++q) {
+            const double wa = W1[(size_t)c * 2 * C + q], wv = (double)W1[(size_t)c * 2 * C + C + q] - wa;
+            hxj += wa * xm[4 * q + d] + wv * xm[16 + 4 * q + d];
+            hxi += wa * xm[16 + 4 * d + q] + wv * xm[32 + 4 * q + d];
+        }
+        const double sj = xm[48 + d], si = xm[52 + d];
+        const double dA = sc * (T[d] - m1 * sj - m2 * is * (hxj - mu * sj));
+        const double dD = sc * (T[4 + d] - m1 * si - m2 * is * (hxi - mu * si));
+        dW1[(size_t)c * 2 * C + d] = (float)(dA - dD);
+        dW1[(size_t)c * 2 * C + C + d] = (float)dD;
+    }
+}
+
+static int tw_blocks(long E) { return (int)((E + TW_ROWS - 1) / TW_ROWS); }
+size_t tnet_w1_moment_doubles(int P, int k) { return (size_t)tw_blocks((long)P * k) * TN_C1 * 8 + (size_t)((P + 63) / 64) * TW_XM; }
+int launch_tnet_bwd_w1_moments(hipStream_t st, const float* dhp, const int* idx, const int* rev_off, const float* x, int ldx, const float* W1,
+                               const float* bn1, const float* m1, const float* m2, int P, int N, int k, int C, double* scratch, float* dW1) {
+    if (C < 1 || C > 4) return MLSP_ERR_UNSUPPORTED;
+    const long E = (long)P * k;
+    const int nxb = (P + 63) / 64;
+    const int ntb = tw_blocks(E);
+    double* tpart = scratch;
+    double* xpart = scratch + (size_t)ntb * TN_C1 * 8;
+    hipLaunchKernelGGL(tnet_bwd_tmom_kernel, dim3(ntb), dim3(256), 0, st, dhp, idx, x, ldx, E, N, k, C, tpart);
+    hipLaunchKernelGGL(tnet_bwd_xmom_kernel, dim3(nxb), dim3(64), 0, st, x, ldx, idx, rev_off, P, N, k, C, xpart);
+    hipLaunchKernelGGL(tnet_bwd_w1_finish_kernel, dim3(TN_C1), dim3(256), 0, st, (const double*)tpart, ntb, (const double*)xpart, nxb, W1, bn1, m1,
+                       m2, C, dW1);
+    return mlsp_launch_status();
+}

@@ -606,6 +606,17 @@ def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
     if training:
         for a, b in zip(rg, rc):
             np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
+    # the input cloud without a gradient (how DGCNN calls it): dW1 comes from the sequential moment pass (tnet_bwd_tmom_kernel) instead of
+    # the fold onto the points + GEMM -- same gradients
+    g2l = [t.detach().to(dev).requires_grad_(i > 0) for i, t in enumerate(leaves)]
+    rg2 = [t.to(dev) for t in rms]
+    og2 = Fh.tnet_edge(g2l[0], graph, g2l[1], g2l[2], g2l[3], rg2[0], rg2[1], g2l[4], g2l[5], g2l[6], rg2[2], rg2[3], training)
+    og2.backward(dOut.to(dev))
+    assert torch.equal(og2, og) and g2l[0].grad is None
+    for a, b, want, name in zip([t.grad for t in g2l[1:]], [t.grad for t in gl[1:]], [t.grad for t in leaves[1:]], ["dW1", "dg1", "db1", "dW2", "dg2", "db2"]):
+        scale = want.abs().max().item() + 1e-6
+        assert (a.cpu() - want).abs().max().item() / scale < 3e-3, name
+        assert (a - b).abs().max().item() / scale < (2e-4 if name == "dW1" else 1e-7), (name, (a - b).abs().max().item() / scale)
 
 
 @pytest.mark.parametrize("B,N,k", [(8, 512, 20), (4, 512, 40)])
