@@ -11,6 +11,7 @@
 // top-K list in registers; the 4 partial lists are merged through LDS under the same total order,
 // so the result does not depend on the partition.
 #include "common.h"
+#include <type_traits>
 #include <math.h>
 
 #define KNN_QB 64      // queries per workgroup
@@ -859,11 +860,38 @@ __device__ __forceinline__ u64 knn_key(float pd, int j) {
     return ((u64)u << 32) | (unsigned)(~j);                // larger key = (larger pd, then smaller index)
 }
 
+// ---- pass A on the bf16 matrix cores (streaming variants, C = 64 and C = 128 with k <= 24) ------------------------------------------------
+// Pass A only has to produce a LOWER BOUND tau of a query's k-th best distance; pass B (exact fp32, canonical arithmetic) decides the
+// result.  So pass A may use approximate distances: x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-17 |x|),
+//   dot' = sum hi_q hi_j + hi_q lo_j + lo_q hi_j      (3 x C/16 v_mfma_f32_32x32x16_bf16 per 32x32 tile instead of C/2 fp32 MFMAs)
+// |2 dot' - 2 dot| <= 2^-15 |x_q| |x_j| (dropped lo lo term, the two residuals) + fp32 accumulation (C 2^-24), so with the final
+// roundings  |pd' - pd| < 2^-15.3 (xx_q + max_j xx_j).  tau' = k-th largest of the approximate chunk maxima; at least k candidates have
+// pd' >= tau', hence pd >= tau' - eps: tau = tau' - eps_q with eps_q = 2^-14 (xx_q + max_j xx_j) is still a proven bound (a NaN bound
+// becomes -inf: everything survives, the exact fallback sweep takes over).  A few more survivors reach pass B; the indices stay bit-exact.
+typedef __bf16 kbf16x8 __attribute__((ext_vector_type(8)));
+#define KNN5_EPS 6.103515625e-05f          // 2^-14
+__device__ __forceinline__ void knn_split8(const float (&b)[8], kbf16x8& hi, kbf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hv = (__bf16)b[e];
+        hi[e] = hv;
+        lo[e] = (__bf16)(b[e] - (float)hv);
+    }
+}
+
 template <int CT, bool VEC, bool RES, int KB>
 __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
                                                         int ld, int N, int C, int k, int* __restrict__ idx, int B) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TILE = CT * KM_STRIDE;
+#ifndef KNN5_NO_BF16A
+    constexpr bool AP = (CT == 64 || (CT == 128 && KB == 0)) && !RES && VEC;     // pass A on the bf16 matrix cores (header comment above the kernel; C = 128 with k > 24 is out of registers)
+#else
+    constexpr bool AP = false;
+#endif
+    constexpr int PA = CT + 8;                              // bf16 elements per candidate row of a pass-A image (16-byte aligned rows)
+    constexpr int TILEA = 32 * PA;                          // floats of one pass-A tile image: hi rows [32][PA] bf16, then lo rows
+    constexpr int TILE_ALLOC = (AP && TILEA > TILE) ? TILEA : TILE;
     constexpr int NSTEP = CT / 2;
     constexpr int SPR = NSTEP >= 16 ? NSTEP / 16 : 1;      // MFMA steps issued per query row of the select loop
     constexpr int GS = (KB && CT == 128) ? 4 : NSTEP >= 16 ? 16 : NSTEP;   // B fragments fetched per group (the k > 24 variant at C = 128 is out of registers)
@@ -878,7 +906,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
     const int ntiles = N / 32, nt2 = ntiles / 2;
 
     float* tiles = sm;                                           // RES: [ntiles][CT][33]   else [2 halves][2][CT][33]
-    float* cxx = tiles + (RES ? (size_t)ntiles * TILE : (size_t)4 * TILE);   // RES: [N]   else [2 halves][3][32]
+    float* cxx = tiles + (RES ? (size_t)ntiles * TILE : (size_t)4 * TILE_ALLOC);   // RES: [N]   else [2 halves][3][32]
     u64* bufk = (u64*)(cxx + (RES ? N : 192));                   // KB=0: [4 qg][2 ch][32 queries][CAP] survivor keys; KB=1: [128 queries][CAPT]
     float* xch = (float*)bufk;                                   // pass-A exchange [4][2][(2 parts)][16][XS], dead before pass B
     float* tau = (float*)(bufk + (KB ? 128 * KNN5_CAPT : 4 * 2 * 32 * KNN5_CAP));   // [4 qg][16 rows][2 h]
@@ -894,7 +922,31 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
             qa[s] = (c < C) ? xb[(size_t)q * ld + c] : 0.f;
         }
     };
-    load_queries();
+    constexpr int NKB = CT / 16;
+    kbf16x8 qhi[AP ? NKB : 1], qlo[AP ? NKB : 1];          // the query row's hi / lo halves, channels 16 kb + 8 h .. + 7
+    float xxmax = 0.f;
+    if (AP) {
+        const int q = q0 + l31;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = 16 * kb + 8 * h + e; t[e] = c < C ? xb[(size_t)q * ld + c] : 0.f; }
+            knn_split8(t, qhi[kb], qlo[kb]);
+        }
+        // largest squared norm of the cloud (the error bound of a distance scales with xx_q + xx_j)
+        __shared__ float xxm_s[8];
+        float m = 0.f;
+        for (int j = tid; j < N; j += 512) m = fmaxf(m, xxb[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) xxm_s[wave] = m;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 8; ++w) xxmax = fmaxf(xxmax, xxm_s[w]);
+    } else {
+        load_queries();
+    }
     float xxq[16], thr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -931,7 +983,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
     f32x4 stagev[VEC ? NLD : 1];
     float stages[VEC ? 1 : NLD];
     float xxstage = 0.f;
-    float* htiles = tiles + ch * 2 * TILE;
+    float* htiles = tiles + ch * 2 * TILE_ALLOC;
     float* hcxx = cxx + ch * 96;
     auto g2r_tile = [&](int tl) {                          // tl: tile index inside the half, < nt2
         const int j0 = (ch * nt2 + tl) * 32;
@@ -952,8 +1004,32 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
             }
         }
     };
+    // pass-A image of a tile: every candidate row split into bf16 hi / lo ONCE, by the thread that staged it (the four query-group
+    // waves of the half then read ready-made 16-byte fragments)
+    auto r2s_tileA = [&](int buf, int tl) {
+        __bf16* Ih = (__bf16*)(htiles + buf * TILE_ALLOC);
+        __bf16* Il = Ih + 32 * PA;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int f = ht + 256 * p;
+            if (32 * CT / 4 >= 256 * (p + 1) || f < 32 * CT / 4) {
+                const int cand = f / (CT / 4), c = (f % (CT / 4)) * 4;
+                typedef __bf16 kbf16x4 __attribute__((ext_vector_type(4)));
+                kbf16x4 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = VEC ? stagev[p][e] : 0.f;
+                    const __bf16 hh = (__bf16)v;
+                    hv[e] = hh; lv[e] = (__bf16)(v - (float)hh);
+                }
+                *(kbf16x4*)(Ih + cand * PA + c) = hv;
+                *(kbf16x4*)(Il + cand * PA + c) = lv;
+            }
+        }
+        if (ht < 32) hcxx[(tl % 3) * 32 + ht] = xxstage;
+    };
     auto r2s_tile = [&](int buf, int tl) {
-        float* T = htiles + buf * TILE;
+        float* T = htiles + buf * TILE_ALLOC;
         if (VEC) {
 #pragma unroll
             for (int p = 0; p < NLD; ++p) {
@@ -974,12 +1050,13 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
         if (ht < 32) hcxx[(tl % 3) * 32 + ht] = xxstage;
     };
     auto tile_ptr = [&](int tl) -> const float* {          // B-fragment base of tile tl of this wave's half
-        return (RES ? tiles + (size_t)(ch * nt2 + tl) * TILE : htiles + (tl & 1) * TILE) + h * KM_STRIDE + l31;
+        return (RES ? tiles + (size_t)(ch * nt2 + tl) * TILE : htiles + (tl & 1) * TILE_ALLOC) + h * KM_STRIDE + l31;
     };
 
     // one sweep over the wave's half; sel(r, pd, j) sees every (query row, candidate) distance once; at_mid() runs between
     // the first and the second half of the wave's tiles (KB = 1 pass A snapshots its running maxima there)
-    auto sweep = [&](auto&& sel, auto&& at_mid) {
+    auto sweep = [&](auto&& sel, auto&& at_mid, auto approx_tag) {
+        constexpr bool APX = AP && decltype(approx_tag)::value;        // this sweep computes its tiles with the split-bf16 products
         f32x16 accCur, accNext;
 #ifdef KNN5_PROBE_NOSEL
         float cmx = -INFINITY;
@@ -987,12 +1064,27 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accCur[r] = 0.f; accNext[r] = 0.f; }
         __syncthreads();                       // previous sweep is done with the tile buffers / RES image is complete
+        // fragment of block kb of the pass-A image in buffer `buf`: candidate row l31, channels 16 kb + 8 h .. + 7 (one 16-byte read each)
+        auto fragA = [&](int buf, int kb, kbf16x8& bh, kbf16x8& bl) {
+            const __bf16* Ih = (const __bf16*)(htiles + buf * TILE_ALLOC) + l31 * PA + 16 * kb + 8 * h;
+            bh = *(const kbf16x8*)Ih;
+            bl = *(const kbf16x8*)(Ih + 32 * PA);
+        };
         if (!RES) {
             g2r_tile(0);
-            r2s_tile(0, 0);
+            if (APX) r2s_tileA(0, 0); else r2s_tile(0, 0);
             __syncthreads();
         }
-        {
+        if (APX) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                kbf16x8 bh, bl;
+                fragA(0, kb, bh, bl);
+                accCur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qhi[kb], bh, accCur, 0, 0, 0);
+                accCur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qhi[kb], bl, accCur, 0, 0, 0);
+                accCur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qlo[kb], bh, accCur, 0, 0, 0);
+            }
+        } else {
             const float* T = tile_ptr(0);
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s)
@@ -1000,7 +1092,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
         }
         if (!RES) {
             g2r_tile(1);                       // nt2 >= 2 (N >= 128)
-            r2s_tile(1, 1);
+            if (APX) r2s_tileA(1, 1); else r2s_tile(1, 1);
         }
         for (int tl = 0; tl < nt2; ++tl) {
             if (!RES) __syncthreads();
@@ -1010,15 +1102,36 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
             const float* T = tile_ptr(tl + 1);
             const int j = (ch * nt2 + tl) * 32 + l31;
             const float xxc = RES ? cxx[j] : hcxx[(tl % 3) * 32 + l31];
-            float bf[2][GS];
+            float bf[2][APX ? 1 : GS];
+            kbf16x8 bh, bl, bhn, bln;                       // APX: fragments of the current / the next channel block of the next tile
             if (have_next) {
+                if (APX) {
+                    fragA((tl + 1) & 1, 0, bhn, bln);
+                } else {
 #pragma unroll
-                for (int s = 0; s < GS; ++s) bf[0][s] = T[(2 * s) * KM_STRIDE];
+                    for (int s = 0; s < GS; ++s) bf[0][s] = T[(2 * s) * KM_STRIDE];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) accNext[r] = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                if (APX) {
+                    // the 3 NKB bf16 MFMAs of the next tile spread over the 16 query rows of the select loop: MFMA m = block m / 3,
+                    // product m % 3 (hi hi, hi lo, lo hi); a block's fragments are read one block ahead
+                    if (have_next) {
+                        constexpr int M = 3 * NKB;
+#pragma unroll
+                        for (int m = (r * M) / 16; m < ((r + 1) * M) / 16; ++m) {
+                            const int kb = m / 3, w = m % 3;
+                            if (w == 0) {
+                                bh = bhn; bl = bln;
+                                if (kb + 1 < NKB) fragA((tl + 1) & 1, kb + 1, bhn, bln);
+                            }
+                            accNext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w == 2 ? qlo[kb] : qhi[kb], w == 1 ? bl : bh, accNext, 0, 0, 0);
+                        }
+                    }
+                } else
                 if (have_next) {
                     if (NSTEP >= 16) {
                         const int s0 = r * SPR, g = s0 / GS;
@@ -1043,7 +1156,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             }
-            if (!RES && tl + 2 < nt2) r2s_tile(tl & 1, tl + 2);
+            if (!RES && tl + 2 < nt2) { if (APX) r2s_tileA(tl & 1, tl + 2); else r2s_tile(tl & 1, tl + 2); }
 #pragma unroll
             for (int r = 0; r < 16; ++r) accCur[r] = accNext[r];
         }
@@ -1066,7 +1179,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
                           cm[r] = -INFINITY;
                       }
                   }
-              });
+              }, std::true_type{});
 #pragma unroll
         for (int r = 0; r < 16; ++r) xch[(KB ? ((qg * 2 + ch) * 2 + 1) * 16 + r : (qg * 2 + ch) * 16 + r) * KNN5_XS + lane] = cm[r];
     }
@@ -1141,8 +1254,14 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
     if (KB && tid < 128) cnts[tid] = 0;
     __syncthreads();                           // tau complete; xch (aliases bufk) is dead from here on
 #pragma unroll
-    for (int r = 0; r < 16; ++r) thr[r] = tau[(qg * 16 + r) * 2 + h];
-    if (KB) load_queries();                    // dead across the tau phase (register budget), re-read here
+    for (int r = 0; r < 16; ++r) {
+        thr[r] = tau[(qg * 16 + r) * 2 + h];
+        if (AP) {                              // approximate pass A: lower the bound by the distance error of this query (header comment)
+            const float t = thr[r] - KNN5_EPS * (xxq[r] + xxmax);
+            thr[r] = t == t ? t : -INFINITY;
+        }
+    }
+    if (KB || AP) load_queries();              // dead across pass A / the tau phase (register budget), read here
 
 #if defined(KNN5_PROBE) && KNN5_PROBE == 1
     if (thr[0] == 12345.f) idx[0] = 1;
@@ -1163,7 +1282,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
                 if (pass && pos < KNN5_CAP) mybuf[((r & 3) + 8 * (r >> 2) + 4 * h) * KNN5_CAP + pos] = knn_key(pd, j);
                 cnt[r] += __builtin_popcount(mine);
             }
-        }, []() {});
+        }, []() {}, std::false_type{});
         bool over = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) over |= cnt[r] > KNN5_CAP;
@@ -1202,7 +1321,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
                     const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[r]), 32 + k - 1));
                     thr[r] = h ? t1 : t0;
                 }
-            }, []() {});
+            }, []() {}, std::false_type{});
             // a half with fewer than k candidates (N/2 < k) leaves -inf/0x7fffffff fillers: they are not published
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1258,7 +1377,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
                 if (pass && pos < KNN5_CAPT) bufk[(size_t)(qg * 32 + qrow) * KNN5_CAPT + pos] = knn_key(pd, j);
             }
         }
-    }, []() {});
+    }, []() {}, std::false_type{});
     __syncthreads();
     const bool over = tid < 128 && cnts[tid] > KNN5_CAPT;
     if (__syncthreads_or(over ? 1 : 0)) {
@@ -1315,7 +1434,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
                     lo &= lo - 1; hi &= hi - 1;
                 }
             }
-        }, []() {});
+        }, []() {}, std::false_type{});
         // Each half now holds its exact top-k per query (fewer when N/2 < k: fillers are not published).  The halves publish
         // one after the other through the query's buffer; the other half ranks its own keys against what it reads.
         // keys are rebuilt from (value, index) where they are used: 0 = no key (every real key is > 0)
@@ -1390,8 +1509,11 @@ static int launch_knn_mfma5_ct(hipStream_t st, const float* x, int ld, const flo
     return mlsp_launch_status();
 }
 
-static size_t knn5_lds_bytes(int CT, int N, bool res, bool kb) {
-    const size_t tile = (size_t)CT * KM_STRIDE;
+static size_t knn5_lds_bytes(int CT, int N, bool res, bool kb, bool vec = false) {
+    size_t tile = (size_t)CT * KM_STRIDE;
+#ifndef KNN5_NO_BF16A
+    if ((CT == 64 || (CT == 128 && !kb)) && !res && vec && (size_t)32 * (CT + 8) > tile) tile = (size_t)32 * (CT + 8);     // pass-A images (kernel: TILE_ALLOC)
+#endif
     const size_t keys = kb ? (size_t)2 * 128 * KNN5_CAPT : (size_t)2 * 4 * 2 * 32 * KNN5_CAP;     // floats
     const size_t fl = (res ? (size_t)(N / 32) * tile + N : 4 * tile + 192) + keys + 128 + 256;
     return fl * sizeof(float);
@@ -1404,7 +1526,7 @@ static int launch_knn_mfma5(hipStream_t st, const float* x, int ld, const float*
     const int CT = C <= 4 ? 4 : C <= 16 ? 16 : C <= 64 ? 64 : 128;
     const bool vec = (C == CT) && (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
     const bool res = CT <= 16 && knn5_lds_bytes(CT, N, true, kb) <= 160 * 1024;
-    const size_t lds = knn5_lds_bytes(CT, N, res, kb);
+    const size_t lds = knn5_lds_bytes(CT, N, res, kb, vec);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
 #define KNN5_GO(CTV, VECV, RESV) do { if (kb) return launch_knn_mfma5_ct<CTV, VECV, RESV, 1>(st, x, ld, xx, B, N, C, k, idx, lds); \
                                       return launch_knn_mfma5_ct<CTV, VECV, RESV, 0>(st, x, ld, xx, B, N, C, k, idx, lds); } while (0)

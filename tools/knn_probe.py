@@ -8,7 +8,7 @@ def build(flags, out):
     src = os.path.join(ROOT, "mlsp_amd", "csrc")
     objs = []
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", out] + flags + \
-          [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "knn.hip", "bn.hip", "edge.hip", "loss.hip", "tnet.hip", "colmax.hip", "labels.hip", "skinny.hip", "sa.hip", "corrupt.hip")]
+          [os.path.join(src, f) for f in ("api.hip", "gemm.hip", "knn.hip", "bn.hip", "edge.hip", "loss.hip", "tnet.hip", "colmax.hip", "labels.hip", "skinny.hip", "sa.hip", "corrupt.hip", "thin.hip")]
     subprocess.check_call(cmd)
 
 def time_lib(path, C, B=32, N=1024, k=20, reps=10):
@@ -32,7 +32,8 @@ def time_lib(path, C, B=32, N=1024, k=20, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 if __name__ == "__main__":
-    variants = {"v5": [], "sweepA": ["-DKNN5_PROBE=4"], "passA": ["-DKNN5_PROBE=1"]}
+    variants = {"v5": [], "sweepA": ["-DKNN5_PROBE=4"], "passA": ["-DKNN5_PROBE=1"],
+                "v5 fp32 pass A": ["-DKNN5_NO_BF16A"], "sweepA fp32": ["-DKNN5_PROBE=4", "-DKNN5_NO_BF16A"]}
     for name, fl in variants.items():
         out = "/tmp/libknn_%s.so" % name
         build(fl, out)
