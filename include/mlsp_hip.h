@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 4
+#define MLSP_ABI_VERSION 5
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -249,8 +249,14 @@ int mlsp_sa_fold_fwd_f32(const float* u, const float* w, const int32_t* idx, int
                          const float* beta, float* run_mean, float* run_var, float momentum, float eps, int training, float* Z,
                          float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_sa_fold_bwd_f32(const float* dZ, const float* u, const float* w, const int32_t* idx, const int32_t* rev_off, const int32_t* rev_ent,
-                         int B, int N, int S, int ns, int C, const float* bn_save, int training, float* du, float* dw, float* dgamma,
-                         float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                         const int32_t* rev_cnt, const int32_t* pad_cnt, int B, int N, int S, int ns, int C, const float* bn_save, int training,
+                         float* du, float* dw, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+/* Reverse index of padded groups WITHOUT their padding slots (ball-query groups repeat their first hit: slot s > 0 with idx[i][s] ==
+ * idx[i][0]): rev_off [B*N+1] list starts, rev_cnt [B*N] list lengths (the lists of a cloud no longer fill its S*ns entries), rev_ent as
+ * mlsp_group_reverse, pad_cnt [B*S] padding slots per group.  mlsp_sa_fold_bwd_f32 takes rev_cnt / pad_cnt (both or neither, NULL = the
+ * full index of mlsp_group_reverse) and adds a group's identical padding rows as a multiple of one row. */
+int mlsp_group_reverse_compact(const int32_t* idx, int B, int S, int N, int ns, int32_t* rev_off, int32_t* rev_cnt, int32_t* rev_ent,
+                               int32_t* pad_cnt, mlsp_stream_t stream);
 
 /* Input corruption.  mlsp_region_assign_f32: utils/pc_utils.py:33-73 assign_region_to_point on X [B][C][N]
  * (channel-major as the trainer holds it); thr[n+1] = fp32 voxel edges, clip = fp32(0.99999999); regions int32 [B][N].

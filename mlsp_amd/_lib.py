@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLSP_HIP_LIB") or os.path.join(_HERE, "libmlsp_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c = ctypes
 _P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
@@ -71,7 +71,8 @@ SIGNATURES = {
     "mlsp_sa_group_fwd_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_sa_group_bwd_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_sa_fold_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _SZ, _P],
-    "mlsp_sa_fold_bwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_sa_fold_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_group_reverse_compact": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mlsp_region_assign_f32": [_P, _I, _I, _I, _P, _I, _F, _P, _P],
     "mlsp_deform_regions_f32": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P],
     "mlsp_transform3_fwd_f32": [_P, _P, _I, _I, _P, _P],

@@ -86,7 +86,9 @@ int launch_sa_fold_fwd(hipStream_t st, const float* u, const float* w, const int
                        double* part);
 int launch_sa_fold_bwd(hipStream_t st, const float* dZ, const float* u, const float* w, const int* idx, const int* rev_off, const int* rev_ent,
                        int B, int N, int S, int ns, int C, const float* bn_save, int training, float* du, float* dw, float* dgamma,
-                       float* dbeta, double* part, float* mean_dz, float* mean_dzy);
+                       float* dbeta, double* part, float* mean_dz, float* mean_dzy, const int* rev_cnt, const int* pad_cnt);
+int launch_group_reverse_compact(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_cnt, int* rev_ent,
+                                 int* pad_cnt);
 int sa_fold_parts(long E);
 int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd);
 int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW);
@@ -273,8 +275,8 @@ int mlsp_sa_fold_fwd_f32(const float* u, const float* w, const int32_t* idx, int
 }
 
 int mlsp_sa_fold_bwd_f32(const float* dZ, const float* u, const float* w, const int32_t* idx, const int32_t* rev_off, const int32_t* rev_ent,
-                         int B, int N, int S, int ns, int C, const float* bn_save, int training, float* du, float* dw, float* dgamma,
-                         float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                         const int32_t* rev_cnt, const int32_t* pad_cnt, int B, int N, int S, int ns, int C, const float* bn_save, int training,
+                         float* du, float* dw, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     if (B <= 0 || S <= 0 || ns <= 0 || C <= 0) return MLSP_ERR_ARG;
     Workspace wk(ws, ws_bytes);
     double* part = wk.take<double>((size_t)sa_fold_parts((long)B * S * ns) * 2 * C);
@@ -282,7 +284,12 @@ int mlsp_sa_fold_bwd_f32(const float* dZ, const float* u, const float* w, const 
     float* mean_dzy = wk.take<float>(C);
     if (!wk.ok()) return MLSP_ERR_WORKSPACE;
     return launch_sa_fold_bwd(st, dZ, u, w, idx, rev_off, rev_ent, B, N, S, ns, C, bn_save, training, du, dw, dgamma, dbeta, part, mean_dz,
-                              mean_dzy);
+                              mean_dzy, rev_cnt, pad_cnt);
+}
+
+int mlsp_group_reverse_compact(const int32_t* idx, int B, int S, int N, int ns, int32_t* rev_off, int32_t* rev_cnt, int32_t* rev_ent,
+                               int32_t* pad_cnt, mlsp_stream_t st) {
+    return launch_group_reverse_compact(st, idx, B, S, N, ns, rev_off, rev_cnt, rev_ent, pad_cnt);
 }
 
 int mlsp_graph_feature_fwd_f32(const float* x, const int32_t* idx, int B, int N, int C, int k, float* F, mlsp_stream_t st) {

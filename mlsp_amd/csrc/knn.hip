@@ -1601,9 +1601,12 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 // `nsplit` workgroups per cloud, each owns a contiguous slice of the destinations: it counts only the edges that point into its
 // slice (LDS atomics are the expensive instruction here: ~3 clocks per lane), gets the slice's base offset by counting the edges
 // that point BELOW it (plain adds + one block reduction), fills its lists and orders every list.
+// skip_pad: the padding slots of a ball-query group (copies of its first hit: slot s > 0 with idx[i][s] == idx[i][0]) are left out of the
+// lists -- their rows are identical, the consumer adds them as a multiple of one row (sa.hip, sa_fold_bwd_point_kernel).  The lists of a
+// cloud then no longer fill its E entries, so the list LENGTHS are returned as well (rev_cnt, nullable otherwise).
 __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict__ idx, int N, int k,
                                                            int* __restrict__ rev_off, int* __restrict__ rev_ent,
-                                                           int B, int S, int nsplit) {
+                                                           int B, int S, int nsplit, int skip_pad, int* __restrict__ rev_cnt) {
     extern __shared__ int ism[];
     __shared__ int wsum[16];
     __shared__ int nbig;                  // lists of more than 64 entries: queued (cnt is free by then) for the whole-workgroup loop
@@ -1629,7 +1632,8 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
         for (int u = 0; u < 8; ++u) jv[u] = eb + u * nt < E ? ib[eb + u * nt] : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int j = jv[u];
+            int j = jv[u];
+            if (skip_pad && j >= 0) { const int e = eb + u * nt, sl = e % k; if (sl != 0 && j == ib[e - sl]) j = -1; }
             below += j >= 0 && j < d0;
             if (j >= d0 && j < d1) atomicAdd(&cnt[j - d0], 1);
         }
@@ -1662,7 +1666,11 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     }
     __syncthreads();
     const int gbase = b * E;
-    for (int j = tid; j < nd; j += nt) { rev_off[(size_t)b * N + d0 + j] = gbase + s0 + off[j]; cnt[j] = 0; }
+    for (int j = tid; j < nd; j += nt) {
+        rev_off[(size_t)b * N + d0 + j] = gbase + s0 + off[j];
+        if (rev_cnt) rev_cnt[(size_t)b * N + d0 + j] = off[j + 1] - off[j];
+        cnt[j] = 0;
+    }
     if (b == B - 1 && part == nsplit - 1 && tid == 0) rev_off[(size_t)B * N] = gbase + E;
     const int sn = off[nd];
     __syncthreads();
@@ -1679,7 +1687,9 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
         for (int u = 0; u < 8; ++u) jv[u] = eb + u * nt < E ? ib[eb + u * nt] : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int j = jv[u], e = eb + u * nt;
+            int j = jv[u];
+            const int e = eb + u * nt;
+            if (skip_pad && j >= 0) { const int sl = e % k; if (sl != 0 && j == ib[e - sl]) j = -1; }
             if (j >= d0 && j < d1) {
                 const int pos = atomicAdd(&cnt[j - d0], 1);
                 ent[off[j - d0] + pos] = ((e / k) << 8) | (e % k);
@@ -1745,7 +1755,8 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     }
 }
 
-static int launch_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent, int rank_sort) {
+static int launch_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent, int rank_sort,
+                          int skip_pad = 0, int* rev_cnt = nullptr) {
     if (!idx || !rev_off || !rev_ent || B <= 0 || N <= 0 || S <= 0 || k <= 0 || k > 256 || N > (1 << 22) || S > (1 << 22)) return MLSP_ERR_ARG;
     const int nsplit = B * 8 >= 256 || N < 1024 ? 8 : RV_SPLIT_MAX;
     const int dper = (N + nsplit - 1) / nsplit;
@@ -1755,13 +1766,31 @@ static int launch_reverse(hipStream_t st, const int* idx, int B, int S, int N, i
         hipError_t e = hipFuncSetAttribute((const void*)knn_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * nsplit), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, S, nsplit);
+    hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * nsplit), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, S, nsplit, skip_pad, rev_cnt);
     return mlsp_launch_status();
 }
 
 // ball-query groups (padded with copies of the first hit): skewed in-degrees -> rank-based ordering
 int launch_group_reverse(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_ent) {
     return launch_reverse(st, idx, B, S, N, k, rev_off, rev_ent, 1);
+}
+// the same without the padding slots; pad_cnt [B*S] = number of padding slots of every group (s > 0 with idx[i][s] == idx[i][0])
+__global__ __launch_bounds__(256) void group_pad_count_kernel(const int* __restrict__ idx, int G, int k, int* __restrict__ pad_cnt) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    const int* r = idx + (size_t)g * k;
+    const int first = r[0];
+    int c = 0;
+    for (int s = 1; s < k; ++s) c += r[s] == first;
+    pad_cnt[g] = c;
+}
+int launch_group_reverse_compact(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_cnt, int* rev_ent,
+                                 int* pad_cnt) {
+    if (!rev_cnt || !pad_cnt) return MLSP_ERR_ARG;
+    const int rc = launch_reverse(st, idx, B, S, N, k, rev_off, rev_ent, 1, 1, rev_cnt);
+    if (rc != MLSP_OK) return rc;
+    hipLaunchKernelGGL(group_pad_count_kernel, dim3((B * S + 255) / 256), dim3(256), 0, st, idx, B * S, k, pad_cnt);
+    return mlsp_launch_status();
 }
 int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent) {
     return launch_reverse(st, idx, B, N, N, k, rev_off, rev_ent, 0);

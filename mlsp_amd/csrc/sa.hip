@@ -526,7 +526,8 @@ __global__ __launch_bounds__(256) void sa_fold_bwd_centre_kernel(const float* __
 __global__ __launch_bounds__(256) void sa_fold_bwd_point_kernel(const float* __restrict__ dZ, const float* __restrict__ u, const float* __restrict__ w,
                                                                 const int* __restrict__ rev_off, const int* __restrict__ rev_ent, int N, int S,
                                                                 int ns, int C, long P, const float* __restrict__ bn, const float* __restrict__ m1v,
-                                                                const float* __restrict__ m2v, float* __restrict__ du) {
+                                                                const float* __restrict__ m2v, float* __restrict__ du,
+                                                                const int* __restrict__ rev_cnt, const int* __restrict__ pad_cnt) {
     const int lane = threadIdx.x & 63;
     const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= P) return;
@@ -538,8 +539,30 @@ __global__ __launch_bounds__(256) void sa_fold_bwd_point_kernel(const float* __r
     f32x4 m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
     if (m1v) { m1 = *(const f32x4*)(m1v + c); m2 = *(const f32x4*)(m2v + c); }
     const f32x4 uq = *(const f32x4*)(u + (size_t)j * C + c);
-    const int e0 = rev_off[j], e1 = rev_off[j + 1];
+    // compact lists (rev_cnt / pad_cnt, mlsp_group_reverse_compact): the padding slots of a ball-query group are not listed; their
+    // rows are identical (same u_j, same w_i, same incoming gradient), so a group's slot-0 entry also adds pad_cnt times the row of its
+    // LAST slot -- without this a point that pads many groups collects hundreds of entries
+    const int e0 = rev_off[j], e1 = rev_cnt ? e0 + rev_cnt[j] : rev_off[j + 1];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (pad_cnt) {
+        for (int t = e0 + en; t < e1; t += nen) {
+            const int ent = rev_ent[t];
+            const size_t ctr = (size_t)b * S + (ent >> 8);
+            const int slot = ent & 255;
+            const size_t row = ctr * ns + slot;
+            const f32x4 wq = *(const f32x4*)(w + ctr * C + c);
+            const f32x4 dz = *(const f32x4*)(dZ + row * C + c);
+            acc = acc + saf_dy(uq, wq, dz, sc, sh, mu, is, m1, m2);
+            const int pc = slot == 0 ? pad_cnt[ctr] : 0;
+            if (pc > 0) {
+                const f32x4 dzp = *(const f32x4*)(dZ + (ctr * ns + ns - 1) * C + c);
+                const f32x4 d = saf_dy(uq, wq, dzp, sc, sh, mu, is, m1, m2);
+                const float fp = (float)pc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(fp, d[q], acc[q]);
+            }
+        }
+    } else
     for (int t = e0 + en; t < e1; t += 2 * nen) {                          // two entries per lane in flight
         const int t2 = t + nen;
         const int ent = rev_ent[t], ent2 = t2 < e1 ? rev_ent[t2] : ent;
@@ -594,7 +617,8 @@ int launch_sa_fold_fwd(hipStream_t st, const float* u, const float* w, const int
 
 int launch_sa_fold_bwd(hipStream_t st, const float* dZ, const float* u, const float* w, const int* idx, const int* rev_off, const int* rev_ent,
                        int B, int N, int S, int ns, int C, const float* bn_save, int training, float* du, float* dw, float* dgamma,
-                       float* dbeta, double* part, float* mean_dz, float* mean_dzy) {
+                       float* dbeta, double* part, float* mean_dz, float* mean_dzy, const int* rev_cnt, const int* pad_cnt) {
+    if ((rev_cnt == nullptr) != (pad_cnt == nullptr)) return MLSP_ERR_ARG;
     if (!dZ || !u || !w || !idx || !rev_off || !rev_ent || !bn_save || !du || !dw || !dgamma || !dbeta || !part || !mean_dz || !mean_dzy)
         return MLSP_ERR_ARG;
     if (!saf_shape_ok(C, ns)) return MLSP_ERR_UNSUPPORTED;
@@ -607,6 +631,6 @@ int launch_sa_fold_bwd(hipStream_t st, const float* dZ, const float* u, const fl
     hipLaunchKernelGGL(sa_fold_bwd_centre_kernel, dim3((unsigned)NC), dim3(256), 0, st, dZ, u, w, idx, N, S, ns, C, NC, bn_save, m1,
                        (const float*)mean_dzy, dw);
     hipLaunchKernelGGL(sa_fold_bwd_point_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, dZ, u, w, rev_off, rev_ent, N, S, ns, C, P,
-                       bn_save, m1, (const float*)mean_dzy, du);
+                       bn_save, m1, (const float*)mean_dzy, du, rev_cnt, pad_cnt);
     return mlsp_launch_status();
 }

@@ -189,15 +189,18 @@ class _SAFold(Function):
         dev = dZ.device
         dZ = dZ.contiguous()
         rev_off = torch.empty((B * N + 1,), dtype=torch.int32, device=dev)
+        rev_cnt = torch.empty((B * N,), dtype=torch.int32, device=dev)
         rev_ent = torch.empty((B * S * ns,), dtype=torch.int32, device=dev)
-        _lib.check(lib.mlsp_group_reverse(idx32.data_ptr(), B, S, N, ns, rev_off.data_ptr(), rev_ent.data_ptr(), _lib.stream()),
-                   "mlsp_group_reverse")
+        pad_cnt = torch.empty((B * S,), dtype=torch.int32, device=dev)
+        # the padding slots of the ball-query groups (copies of the first hit, most of the slots at these radii) stay out of the lists
+        _lib.check(lib.mlsp_group_reverse_compact(idx32.data_ptr(), B, S, N, ns, rev_off.data_ptr(), rev_cnt.data_ptr(), rev_ent.data_ptr(),
+                                                  pad_cnt.data_ptr(), _lib.stream()), "mlsp_group_reverse_compact")
         du, dw = torch.empty_like(u), torch.empty_like(w)
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, B * S * ns, C, C)
         _lib.check(lib.mlsp_sa_fold_bwd_f32(dZ.data_ptr(), u.data_ptr(), w.data_ptr(), idx32.data_ptr(), rev_off.data_ptr(), rev_ent.data_ptr(),
-                                            B, N, S, ns, C, bn_save.data_ptr(), int(ctx.training), du.data_ptr(), dw.data_ptr(),
+                                            rev_cnt.data_ptr(), pad_cnt.data_ptr(), B, N, S, ns, C, bn_save.data_ptr(), int(ctx.training), du.data_ptr(), dw.data_ptr(),
                                             dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()), "mlsp_sa_fold_bwd_f32")
         return du, dw, None, dgamma, dbeta, None, None, None, None, None, None
 
