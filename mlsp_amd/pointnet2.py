@@ -218,9 +218,14 @@ def _fold_first_layer(xyz, new_xyz, points, idx, W0, conv, bn, training):
     [xyz | features], pointnet_util.py:124-129).  -> activated edge rows [B*S*ns, C]."""
     B, N, _ = xyz.shape
     S, ns = idx.shape[1], idx.shape[2]
-    rows = xyz.reshape(B * N, 3) if points is None else torch.cat([xyz, points], dim=-1).reshape(B * N, -1)
-    u = Fh.pointmlp(rows, W0, bias=conv.bias)
-    w = Fh.pointmlp(new_xyz.reshape(B * S, 3).contiguous(), W0[:, :3])
+    Wx = W0[:, :3]
+    u = Fh.pointmlp(xyz.reshape(B * N, 3), Wx, bias=conv.bias)            # K = 3: the streaming thin-GEMM kernels
+    if points is not None:
+        # the feature half as its own GEMM with an aligned, interior-tile shape (K = D) instead of one ragged K = 3 + D product on the
+        # predicated kernel: [x | f] W0^T = x Wx^T + f Wf^T
+        D = points.shape[-1]
+        u = u + Fh.pointmlp(points.reshape(B * N, D), W0[:, 3:].contiguous())
+    w = Fh.pointmlp(new_xyz.reshape(B * S, 3).contiguous(), Wx)
     rm, rv = _bn_buffers(bn, training)
     idx32 = idx.to(torch.int32).contiguous()
     return _SAFold.apply(u, w, idx32, bn.weight, bn.bias, rm, rv, training, bn.momentum, bn.eps, (B, N, S, ns))
@@ -296,7 +301,16 @@ class PointNetSetAbstraction(nn.Module):
                                                    fps_start=self.fps_start)
             S, ns = self.npoint, self.nsample
         X = new_points.reshape(B * S * ns, new_points.shape[-1])          # edge-major rows (b, centre, slot)
-        X = _sa_mlp(X, self.mlp_convs, self.mlp_bns, self.training)
+        first_weight = None
+        Kin = X.shape[1]
+        if self.group_all and Kin % 128 != 0 and Kin > 32 and X.shape[0] % 128 == 0:
+            # a ragged channel count (3 + D = 259) keeps the first layer's three GEMMs on the predicated kernel: zero-pad the input rows
+            # and the weight columns to the next multiple of 128 (exact: the padding multiplies zeros)
+            Kp = (Kin + 127) // 128 * 128
+            X = torch.nn.functional.pad(X, (0, Kp - Kin))
+            c0 = self.mlp_convs[0]
+            first_weight = torch.nn.functional.pad(c0.weight.view(c0.out_channels, c0.in_channels), (0, Kp - Kin))
+        X = _sa_mlp(X, self.mlp_convs, self.mlp_bns, self.training, first_weight=first_weight)
         out = Fh.colmax(X, B, ns) if self.group_all else Fh.segmax(X, ns)  # max over the neighbourhood
         return new_xyz, out.view(B, S, -1)
 
