@@ -236,6 +236,21 @@ int mlsp_sa_group_fwd_f32(const float* xyz, int ldx, const float* feat, int D, c
 int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
                           float* dfeat, mlsp_stream_t stream);
 
+/* Linear + BatchNorm + activation + max over the k consecutive rows of every group, fused (pointnet_util.py:188-195: the last conv of a
+ * set-abstraction MLP and `torch.max(new_points, 2)[0]`; also sample_and_group_all with k = N <= 255).  X [M][Cin] edge rows, M = G*k.
+ * fwd: Y [M][Cout] pre-BN output (kept for the backward), out [G][Cout] = max_s act(BN(y)), ysel [G][Cout] the selected pre-BN value
+ * (max for scale >= 0, min otherwise), argk [G][Cout] uint8 its first slot, bn_save [4][Cout].  The activated tensor is never written.
+ * bwd: dOut [G][Cout] -> dX (nullable) [M][Cin], dW [Cout][Cin], dbias (nullable), dgamma, dbeta; the BatchNorm sums come from the
+ * G*Cout selected entries, the gradient of the activated tensor is never materialised.  k <= 255, Cout % 4 == 0, 256 % (Cout/4) == 0. */
+int mlsp_pointmlp_segmax_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                                 const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                                 int training, int act, float slope, int k, float* Y, float* out, float* ysel, uint8_t* argk, float* bn_save,
+                                 void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_pointmlp_segmax_bwd_f32(const float* dOut, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+                                 const float* ysel, const uint8_t* argk, const float* bn_save, int training, int act, float slope, int k,
+                                 float* dX, int lddx, float* dW, float* dbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                 mlsp_stream_t stream);
+
 /* Folded first layer of a set-abstraction MLP (pointnet_util.py:120-129 grouping + :185-190 first Conv2d + BatchNorm2d + ReLU): the
  * conv over the edge rows [x_j - c_i | f_j] equals u_j - w_i with u [B*N][C] = [x | f] W^T + b per source point and w [B*S][C] = c Wx^T
  * per centre (two per-point GEMMs the caller runs with mlsp_pointmlp_fwd_f32 / mlsp_gemm_f32); neither the grouped tensor nor the

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mlsp_group_reverse": [_P, _I, _I, _I, _I, _P, _P, _P],
     "mlsp_sa_group_fwd_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_sa_group_bwd_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mlsp_pointmlp_segmax_fwd_f32": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_pointmlp_segmax_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_sa_fold_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _SZ, _P],
     "mlsp_sa_fold_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_group_reverse_compact": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P],

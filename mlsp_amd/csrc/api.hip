@@ -90,6 +90,10 @@ int launch_sa_fold_bwd(hipStream_t st, const float* dZ, const float* u, const fl
 int launch_group_reverse_compact(hipStream_t st, const int* idx, int B, int S, int N, int k, int* rev_off, int* rev_cnt, int* rev_ent,
                                  int* pad_cnt);
 int sa_fold_parts(long E);
+int launch_segsel_act_fwd(hipStream_t st, const float* Y, int G, int k, int C, const float* scale, const float* shift, int act, float slope,
+                          float* out, float* ysel, uint8_t* argk);
+int launch_segsel_bwd_apply(hipStream_t st, const float* dOut, const float* Y, const float* ysel, const uint8_t* argk, size_t M, int k, int C,
+                            const float* bn, const float* m1, const float* m2, int act, float slope, float* dY);
 int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd);
 int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW);
 int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
@@ -641,6 +645,75 @@ int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, con
     const ChainIn in = {in_bn_save, in_act, in_slope, in_p_drop, in_seed};
     return pointmlp_bwd_impl(dZ, Xpre, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
                              rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, &in);
+}
+
+// ---- Linear + BatchNorm + act + max over the k rows of every group (last conv of a set-abstraction MLP + the neighbourhood max) ------
+// The activated [M, Cout] tensor and its gradient are never materialised: forward keeps the pre-BN output Y (needed by the backward
+// anyway), the group extreme ysel [G, Cout] and its slot; backward gets the BatchNorm sums from the G x Cout selected values (the
+// gradient of the max is non-zero at one row per group and channel) and writes dY in one pass.
+int mlsp_pointmlp_segmax_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+                                 const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                                 int training, int act, float slope, int k, float* Y, float* out, float* ysel, uint8_t* argk, float* bn_save,
+                                 void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    if (!X || !W || !gamma || !beta || !Y || !out || !ysel || !argk || !bn_save || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin)
+        return MLSP_ERR_ARG;
+    if (k < 1 || k > 255 || M % k || Cout % 4) return MLSP_ERR_UNSUPPORTED;
+    Workspace w(ws, ws_bytes);
+    const int fused_parts = training ? gemm_stat_parts(M, Cout, Cin) : 0;
+    int nparts = fused_parts ? fused_parts : bn_stat_parts(M);
+    double* part = w.take<double>((size_t)nparts * 2 * Cout);
+    size_t sf = gemm_slab_floats(M, Cout, Cin);
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
+    CHECK(launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Y, Cout, bias, nullptr, 0, slab, sf, fused_parts ? part : nullptr));
+    if (training) {
+        if (!fused_parts) CHECK(launch_colstats(st, Y, M, Cout, Cout, part));
+        CHECK(launch_bn_finalize(st, part, nparts, (double)M, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale, shift, mean, invstd));
+    } else {
+        if (!run_mean || !run_var) return MLSP_ERR_ARG;
+        CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
+    }
+    return launch_segsel_act_fwd(st, Y, M / k, k, Cout, scale, shift, act, slope, out, ysel, argk);
+}
+
+int mlsp_pointmlp_segmax_bwd_f32(const float* dOut, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+                                 const float* ysel, const uint8_t* argk, const float* bn_save, int training, int act, float slope, int k,
+                                 float* dX, int lddx, float* dW, float* dbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                 mlsp_stream_t st) {
+    if (!dOut || !X || !W || !Y || !ysel || !argk || !bn_save || !dW || !dgamma || !dbeta || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin ||
+        ldw < Cin) return MLSP_ERR_ARG;
+    if (k < 1 || k > 255 || M % k || Cout % 4) return MLSP_ERR_UNSUPPORTED;
+    const int G = M / k;
+    Workspace w(ws, ws_bytes);
+    float* dY = w.take<float>((size_t)M * Cout);
+    const int npr = bn_vec_parts(G);
+    double* part = w.take<double>((size_t)npr * 2 * Cout);
+    float* mean_dz = w.take<float>(Cout);
+    float* mean_dzy = w.take<float>(Cout);
+    size_t sf1 = dX ? gemm_slab_floats(M, Cin, Cout) : 0, sf2 = gemm_slab_floats(Cout, Cin, M);
+    size_t sf = sf1 > sf2 ? sf1 : sf2;
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    const float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
+    // sums of dz' and dz'*yhat over ALL M rows == over the G x Cout selected entries (every other row's dz is zero)
+    {
+        const int rc = launch_bn_act_bwd_partials_vec(st, dOut, ysel, G, Cout, scale, shift, mean, invstd, act, slope, part);
+        if (rc != MLSP_OK) return rc;                          // (vectorised shapes only: Cout % 4 == 0, 256 % (Cout / 4) == 0)
+    }
+    CHECK(launch_bn_bwd_finalize(st, part, npr, (double)M, Cout, dgamma, dbeta, mean_dz, mean_dzy));
+    CHECK(launch_segsel_bwd_apply(st, dOut, Y, ysel, argk, (size_t)M, k, Cout, bn_save, training ? mean_dz : nullptr, mean_dzy, act, slope, dY));
+    if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, dY, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf));
+    CHECK(launch_gemm(st, true, false, Cout, Cin, M, dY, Cout, X, ldx, dW, Cin, nullptr, nullptr, 0, slab, sf));
+    if (dbias) {
+        if (training) {                                        // a bias in front of a batch-statistics BatchNorm: analytically zero gradient
+            hipError_t e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        } else {
+            CHECK(launch_colsum(st, dY, M, Cout, part, dbias));
+        }
+    }
+    return MLSP_OK;
 }
 
 // ---- bf16 activation storage (BASELINE.json configs[4]) ---------------------------------------------------------------------------

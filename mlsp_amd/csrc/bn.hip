@@ -666,6 +666,99 @@ int launch_segmax_fwd(hipStream_t st, const float* Z, int P, int k, int C, float
     return mlsp_launch_status();
 }
 
+// ---- BatchNorm + activation + max over the k rows of every group, fused (the last conv of a set-abstraction MLP, pointnet_util.py:
+// 188-195) -- the activated [G*k, C] tensor is never written.  act(scale*y + shift) is monotone in y with the sign of scale, so the group
+// extreme of the PRE-BN values (max for scale >= 0, min otherwise; first slot attaining it) decides:  out = act(scale*ysel + shift).
+// thread = (group, channel quad); a group's k rows are read as coalesced 16-byte quads.
+__global__ __launch_bounds__(256) void segsel_act_fwd_kernel(const float* __restrict__ Y, int G, int k, int C, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int act, float slope, float* __restrict__ out,
+                                                             float* __restrict__ ysel, uint8_t* __restrict__ argk) {
+    const int tpr = C >> 2;
+    const size_t total = (size_t)G * tpr;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = t / tpr;
+        const int c = (int)(t % tpr) * 4;
+        const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+        const float* y0 = Y + (g * k) * C + c;
+        f32x4 best = *(const f32x4*)y0;
+        int bs[4] = {0, 0, 0, 0};
+        for (int s0 = 1; s0 < k; s0 += 4) {                                // four rows in flight
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(y0 + (size_t)(s0 + u < k ? s0 + u : 0) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u < k) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool take = sc[e] >= 0.f ? v[u][e] > best[e] : v[u][e] < best[e];
+                        best[e] = take ? v[u][e] : best[e]; bs[e] = take ? s0 + u : bs[e];
+                    }
+                }
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = lrelu_or_relu(fmaf(best[e], sc[e], sh[e]), act, slope);
+        *(f32x4*)(out + g * C + c) = o;
+        *(f32x4*)(ysel + g * C + c) = best;
+        *(uint32_t*)(argk + g * C + c) = (uint32_t)bs[0] | ((uint32_t)bs[1] << 8) | ((uint32_t)bs[2] << 16) | ((uint32_t)bs[3] << 24);
+    }
+}
+
+// dY[(g,s)][c] = scale * ( [s == arg] * dOut[g][c] * act'(scale*ysel + shift) - m1 - (y - mean) * invstd * m2 )     (eval: m1 = m2 = 0)
+// thread = (row, channel quad): reads Y, the group's arg / dOut / ysel quads, writes dY.
+__global__ __launch_bounds__(256) void segsel_bwd_apply_kernel(const float* __restrict__ dOut, const float* __restrict__ Y, const float* __restrict__ ysel,
+                                                               const uint8_t* __restrict__ argk, size_t M, int k, int C,
+                                                               const float* __restrict__ bn, const float* __restrict__ m1v,
+                                                               const float* __restrict__ m2v, int act, float slope, float* __restrict__ dY) {
+    const int tpr = C >> 2;
+    const size_t total = M * tpr;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = t / tpr;
+        const int c = (int)(t % tpr) * 4;
+        const size_t g = r / k;
+        const int s = (int)(r % k);
+        const f32x4 sc = *(const f32x4*)(bn + c), sh = *(const f32x4*)(bn + C + c);
+        const f32x4 y = *(const f32x4*)(Y + r * C + c);
+        const uint32_t a4 = *(const uint32_t*)(argk + g * C + c);
+        f32x4 o;
+        if (m1v) {
+            const f32x4 mu = *(const f32x4*)(bn + 2 * C + c), is = *(const f32x4*)(bn + 3 * C + c);
+            const f32x4 m1 = *(const f32x4*)(m1v + c), m2 = *(const f32x4*)(m2v + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = -m1[e] - (y[e] - mu[e]) * is[e] * m2[e];
+        } else {
+            o = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (((a4 & 255u) == (uint32_t)s) | (((a4 >> 8) & 255u) == (uint32_t)s) | (((a4 >> 16) & 255u) == (uint32_t)s) | ((a4 >> 24) == (uint32_t)s)) {
+            const f32x4 d = *(const f32x4*)(dOut + g * C + c), ys = *(const f32x4*)(ysel + g * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (((a4 >> (8 * e)) & 255u) == (uint32_t)s) {
+                    const float a = fmaf(ys[e], sc[e], sh[e]);
+                    const float dp = act == 0 ? 1.f : (a > 0.f ? 1.f : (act == 2 ? slope : 0.f));
+                    o[e] += d[e] * dp;
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] *= sc[e];
+        *(f32x4*)(dY + r * C + c) = o;
+    }
+}
+
+int launch_segsel_act_fwd(hipStream_t st, const float* Y, int G, int k, int C, const float* scale, const float* shift, int act, float slope,
+                          float* out, float* ysel, uint8_t* argk) {
+    if (C % 4 || k < 1 || k > 255 || ((((uintptr_t)Y | (uintptr_t)out | (uintptr_t)ysel | (uintptr_t)scale | (uintptr_t)shift) & 15) != 0) ||
+        (((uintptr_t)argk) & 3)) return MLSP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(segsel_act_fwd_kernel, dim3(ew_blocks((size_t)G * (C / 4))), dim3(256), 0, st, Y, G, k, C, scale, shift, act, slope, out, ysel, argk);
+    return mlsp_launch_status();
+}
+int launch_segsel_bwd_apply(hipStream_t st, const float* dOut, const float* Y, const float* ysel, const uint8_t* argk, size_t M, int k, int C,
+                            const float* bn, const float* m1, const float* m2, int act, float slope, float* dY) {
+    hipLaunchKernelGGL(segsel_bwd_apply_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, st, dOut, Y, ysel, argk, M, k, C, bn, m1, m2, act, slope, dY);
+    return mlsp_launch_status();
+}
+
 int launch_segmax_bwd(hipStream_t st, const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ) {
     hipLaunchKernelGGL(segmax_bwd_kernel, dim3(ew_blocks((size_t)P * k * C)), dim3(256), 0, st, dOut, argk, P, k, C, dZ);
     return mlsp_launch_status();

@@ -666,6 +666,69 @@ def segmax(Z, k):
     return _SegMax.apply(Z, k)
 
 
+class _PointMLPSegMax(Function):
+    """Linear + BatchNorm + act + max over every k consecutive rows (mlsp_pointmlp_segmax_*_f32): the activated [M, Cout] tensor and its
+    gradient are never materialised."""
+
+    @staticmethod
+    def forward(ctx, X, W, bias, gamma, beta, run_mean, run_var, k, training, act, slope, momentum, eps):
+        lib = _lib.load()
+        X = _rows(X)
+        _lib.require_gpu(X, W)
+        if W.stride(1) != 1:
+            W = W.contiguous()
+        M, Cin = X.shape
+        Cout = W.shape[0]
+        dev = X.device
+        G = M // k
+        Y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+        out = torch.empty((G, Cout), dtype=torch.float32, device=dev)
+        ysel = torch.empty((G, Cout), dtype=torch.float32, device=dev)
+        argk = torch.empty((G, Cout), dtype=torch.uint8, device=dev)
+        bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, M, Cin, Cout)
+        _lib.check(lib.mlsp_pointmlp_segmax_fwd_f32(X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias),
+                                                    gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean), _lib.ptr(run_var), float(momentum),
+                                                    float(eps), int(training), int(act), float(slope), int(k), Y.data_ptr(), out.data_ptr(),
+                                                    ysel.data_ptr(), argk.data_ptr(), bn_save.data_ptr(), ws, wsn, _lib.stream()),
+                   "mlsp_pointmlp_segmax_fwd_f32")
+        ctx.save_for_backward(X, W, Y, ysel, argk, bn_save)
+        ctx.cfg = (int(k), bool(training), int(act), float(slope), bias is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dOut):
+        lib = _lib.load()
+        X, W, Y, ysel, argk, bn_save = ctx.saved_tensors
+        k, training, act, slope, has_bias = ctx.cfg
+        dOut = dOut.contiguous()
+        M, Cin = X.shape
+        Cout = W.shape[0]
+        dev = dOut.device
+        dX = torch.empty((M, Cin), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+        dbias = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bias else None
+        dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, M, Cin, Cout)
+        _lib.check(lib.mlsp_pointmlp_segmax_bwd_f32(dOut.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout,
+                                                    Y.data_ptr(), ysel.data_ptr(), argk.data_ptr(), bn_save.data_ptr(), int(training), act, slope,
+                                                    k, _lib.ptr(dX), Cin, dW.data_ptr(), _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                    ws, wsn, _lib.stream()), "mlsp_pointmlp_segmax_bwd_f32")
+        return dX, dW, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def pointmlp_segmax_supported(M, Cout, k):
+    return 1 <= k <= 255 and M % k == 0 and Cout % 4 == 0 and 256 % (Cout // 4) == 0 and Cout <= 1024
+
+
+def pointmlp_segmax(X, W, k, bias=None, gamma=None, beta=None, run_mean=None, run_var=None, training=True, act=ACT_RELU, slope=0.2,
+                    momentum=0.1, eps=1e-5):
+    """max over every k consecutive rows of act(BN(X W^T + b)): [M, Cin] -> [M // k, Cout] without the activated [M, Cout] tensor."""
+    return _PointMLPSegMax.apply(X, W, bias, gamma, beta, run_mean, run_var, k, training, act, slope, momentum, eps)
+
+
 class _ColMax(Function):
     @staticmethod
     def forward(ctx, Z, B, N):

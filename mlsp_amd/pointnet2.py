@@ -276,6 +276,7 @@ class PointNetSetAbstraction(nn.Module):
         self.group_all = group_all
         self.fps_start = None
         self.fold_first = True          # fold the first conv onto the points (no grouped tensor); False: the materialised path
+        self.fuse_max = True            # last conv + BN + ReLU + neighbourhood max in one op (no activated edge tensor); False: separate max
 
     @flushing_forward
     def forward(self, xyz, points):
@@ -294,8 +295,8 @@ class PointNetSetAbstraction(nn.Module):
             c0 = self.mlp_convs[0]
             X = _fold_first_layer(xyz, new_xyz, points, idx, c0.weight.view(c0.out_channels, c0.in_channels), c0, self.mlp_bns[0],
                                   self.training)
-            X = _sa_mlp(X, self.mlp_convs[1:], self.mlp_bns[1:], self.training)
-            return new_xyz, Fh.segmax(X, ns).view(B, S, -1)
+            out = _sa_mlp(X, self.mlp_convs[1:], self.mlp_bns[1:], self.training, max_over=ns if self.fuse_max else 0)
+            return new_xyz, (out if self.fuse_max else Fh.segmax(out, ns)).view(B, S, -1)
         else:
             new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, knn=self.knn,
                                                    fps_start=self.fps_start)
@@ -310,19 +311,28 @@ class PointNetSetAbstraction(nn.Module):
             X = torch.nn.functional.pad(X, (0, Kp - Kin))
             c0 = self.mlp_convs[0]
             first_weight = torch.nn.functional.pad(c0.weight.view(c0.out_channels, c0.in_channels), (0, Kp - Kin))
-        X = _sa_mlp(X, self.mlp_convs, self.mlp_bns, self.training, first_weight=first_weight)
-        out = Fh.colmax(X, B, ns) if self.group_all else Fh.segmax(X, ns)  # max over the neighbourhood
+        if self.fuse_max and ns <= 255:
+            out = _sa_mlp(X, self.mlp_convs, self.mlp_bns, self.training, first_weight=first_weight, max_over=ns)
+        else:
+            X = _sa_mlp(X, self.mlp_convs, self.mlp_bns, self.training, first_weight=first_weight)
+            out = Fh.colmax(X, B, ns) if self.group_all else Fh.segmax(X, ns)  # max over the neighbourhood
         return new_xyz, out.view(B, S, -1)
 
 
-def _sa_mlp(X, convs, bns, training, first_weight=None):
-    """Conv2d(1x1)+BN2d+ReLU stack of a set-abstraction branch on edge-major rows [B*S*ns, Cin]."""
+def _sa_mlp(X, convs, bns, training, first_weight=None, max_over=0):
+    """Conv2d(1x1)+BN2d+ReLU stack of a set-abstraction branch on edge-major rows [B*S*ns, Cin].  max_over = k > 0: followed by the max
+    over every k consecutive rows (the neighbourhood max, pointnet_util.py:195), fused into the last layer where the shape allows --
+    returns [rows // k, C]."""
+    n = len(convs)
     for i, (conv, bn) in enumerate(zip(convs, bns)):
         rm, rv = _bn_buffers(bn, training)
         W = first_weight if (i == 0 and first_weight is not None) else conv.weight.view(conv.out_channels, conv.in_channels)
+        if max_over and i == n - 1 and Fh.pointmlp_segmax_supported(X.shape[0], conv.out_channels, max_over):
+            return Fh.pointmlp_segmax(X, W, max_over, bias=conv.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
+                                      training=training, act=Fh.ACT_RELU, momentum=bn.momentum, eps=bn.eps)
         X = Fh.pointmlp(X, W, bias=conv.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv, training=training,
                         act=Fh.ACT_RELU, momentum=bn.momentum, eps=bn.eps)
-    return X
+    return Fh.segmax(X, max_over) if max_over else X
 
 
 class PointNetSetAbstractionMsg(nn.Module):
@@ -368,11 +378,11 @@ class PointNetSetAbstractionMsg(nn.Module):
                 W0 = torch.cat((W0[:, D:], W0[:, :D]), dim=1)                        # reference column order: [feat | xyz]
             if self.fold_first and _fold_supported(c0, K) and len(self.conv_blocks[i]) > 1:
                 X = _fold_first_layer(xyz, new_xyz, points, idx, W0, c0, self.bn_blocks[i][0], self.training)
-                X = _sa_mlp(X, self.conv_blocks[i][1:], self.bn_blocks[i][1:], self.training)
+                X = _sa_mlp(X, self.conv_blocks[i][1:], self.bn_blocks[i][1:], self.training, max_over=K)
             else:
                 G = _Group.apply(xyz, new_xyz, points, idx)                          # rows [xyz_j - c_i | feat_j]
-                X = _sa_mlp(G, self.conv_blocks[i], self.bn_blocks[i], self.training, first_weight=W0)
-            outs.append(Fh.segmax(X, K).view(B, S, -1))
+                X = _sa_mlp(G, self.conv_blocks[i], self.bn_blocks[i], self.training, first_weight=W0, max_over=K)
+            outs.append(X.view(B, S, -1))
         return new_xyz, torch.cat(outs, dim=-1)
 
 

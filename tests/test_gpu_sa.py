@@ -208,6 +208,7 @@ def test_folded_first_sa_layer_equals_grouped_path(dev, B, N, S, radius, ns, D, 
         bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
     b = copy.deepcopy(a)
     a.fold_first, b.fold_first = True, False
+    b.fuse_max = False                                     # path b: grouped tensor, edge GEMMs, activated tensor, separate max
     start = torch.arange(B) % N
     a.fps_start = b.fps_start = start
     a.train(train); b.train(train)
