@@ -155,8 +155,8 @@ int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N
 
 // slab floats the thin TN path needs for (M, N, K) (0: shape not handled here)
 size_t thin_tn_slab_floats(int M, int N, int K) {
-    const bool small_m = M <= 16 && N % 4 == 0 && N >= 128 && N <= 512 && (N & (N - 1)) == 0;
-    const bool small_n = N <= 16 && M % 4 == 0 && M >= 128 && M <= 512 && (M & (M - 1)) == 0;
+    const bool small_m = M <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && (N & (N - 1)) == 0;
+    const bool small_n = N <= 16 && M % 4 == 0 && M >= 64 && M <= 512 && (M & (M - 1)) == 0;
     if (!(small_m || small_n) || K < 2048) return 0;
     const int chunks = (K + THIN_TN_ROWS - 1) / THIN_TN_ROWS;
     return (size_t)chunks * M * N;
@@ -190,7 +190,7 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
         const size_t need = thin_tn_slab_floats(M, N, K);
         if (!need || !slab || slab_floats < need) return MLSP_ERR_UNSUPPORTED;
         const int chunks = (K + THIN_TN_ROWS - 1) / THIN_TN_ROWS;
-        const bool small_m = M <= 16 && N % 4 == 0 && N >= 128;
+        const bool small_m = M <= 16 && N % 4 == 0 && N >= 64;
         if (small_m ? (ldb % 4 || !al16(B)) : (lda % 4 || !al16(A))) return MLSP_ERR_UNSUPPORTED;   // the wide operand is read 16 bytes per lane
         // small side S, large side L; partial slabs are written in C's [M][N] layout
         const float* S = small_m ? A : B; const int lds_ = small_m ? lda : ldb; const int ns = small_m ? M : N;

@@ -167,7 +167,7 @@ def test_gemm_bf16_operand_mode(dev, ta, tb, M, N, K):
 
 @pytest.mark.parametrize("ta,tb,M,N,K,bias", [(0, 1, 4096, 128, 3, 0), (0, 0, 4096, 128, 3, 0), (0, 0, 2048, 256, 16, 0), (0, 1, 4096, 3, 128, 0),
                                               (0, 1, 4096, 16, 256, 1), (0, 0, 4096, 3, 128, 0), (1, 0, 3, 128, 4096, 0),
-                                              (1, 0, 16, 256, 8192, 0), (1, 0, 128, 3, 4096, 0), (1, 0, 256, 16, 2048, 0),
+                                              (1, 0, 16, 256, 8192, 0), (1, 0, 128, 3, 4096, 0), (1, 0, 256, 16, 2048, 0), (1, 0, 64, 3, 8192, 0), (1, 0, 3, 64, 8192, 0),
                                               (0, 1, 32768, 128, 3, 1), (1, 0, 3, 128, 32768, 0)])
 def test_thin_gemms(dev, ta, tb, M, N, K, bias):
     """One tiny dimension (3 coordinates, 3 / 16 outputs): the streaming VALU kernels of thin.hip behind mlsp_gemm_f32."""
