@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 // ---- N = 64 variant: 128 x 64 x 32 tiles, the four waves stacked along M (32 rows x 64 columns each) -----------------------------
 // The dgrads into a 64-channel input (dx = duv * Wd of EdgeConv 2 / 3) and their wgrads have N = 64: on the 128-column tile half of
 // every B stage and half of the MFMA columns are padding (17-31 TF).  Interior shapes only (M % 128 == 0, K-range % 32 == 0, 16-byte
-// aligned operands), plain / split-K output, no fused epilogue.
+// aligned operands), plain / split-K output; epilogue options: bias, BatchNorm statistics per 128-row panel.
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_f32_n64_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[BM * SROW + 64 * SROW + 32 * 64];
@@ -566,13 +566,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_n64_kernel(GemmArgs p) {
         __syncthreads();
     }
     float* Cout = p.C + (p.nsplit > 1 ? (size_t)split * p.M * p.ldc : 0);
+    const bool epi = p.nsplit == 1;
+    float bv[2] = {0.f, 0.f};
+    if (epi && p.bias) { bv[0] = p.bias[l31]; bv[1] = p.bias[32 + l31]; }
+    float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            Cout[(size_t)row * p.ldc + j * 32 + l31] = acc[j][r];
+            const float v = acc[j][r] + bv[j];
+            Cout[(size_t)row * p.ldc + j * 32 + l31] = v;
+            cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
         }
+    if (p.stat_part) {       // fused BatchNorm statistics of the 128-row panel (the 64-channel layers with a bias: PointNet / set abstraction)
+        float* red = smem;   // [4 waves][sum | sq][64]  (the operand tiles are dead: the K loop ended on a barrier)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cs[j] += __shfl_xor(cs[j], 32, 64);
+            cq[j] += __shfl_xor(cq[j], 32, 64);
+            if (h == 0) { red[(wave * 2 + 0) * 64 + j * 32 + l31] = cs[j]; red[(wave * 2 + 1) * 64 + j * 32 + l31] = cq[j]; }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            p.stat_part[((size_t)tm * 2 + 0) * p.N + tid] = ((double)red[0 * 64 + tid] + (double)red[2 * 64 + tid]) + ((double)red[4 * 64 + tid] + (double)red[6 * 64 + tid]);
+            p.stat_part[((size_t)tm * 2 + 1) * p.N + tid] = ((double)red[1 * 64 + tid] + (double)red[3 * 64 + tid]) + ((double)red[5 * 64 + tid] + (double)red[7 * 64 + tid]);
+        }
+    }
 }
 
 // ---- bf16-operand variant (opt-in, mlsp_set_gemm_precision(1); BASELINE.json configs[4]) -------------------------------
@@ -992,8 +1012,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     static const bool old_epilogue = getenv("MLSP_GEMM_OLD_EPILOGUE") != nullptr;       // read-once A/B switch (tools/ab)
     // lean output pass: every row of a tile takes the same per-cloud bias row, byte offsets inside a wave's region fit 31 bits
     p.fast_out = (fast && (!gbias || rows_per_group % bm == 0) && (long)p.ldc * 4 * 64 < (1L << 30) && !old_epilogue) ? 1 : 0;
-    const bool n64 = !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !bias && !gbias && !stat_part && !sel_gamma &&
-                     !accumulate && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
+    const bool n64 = !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
+                     (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && !accumulate && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
     if (n64) {
         dim3 g64(M / 128, ns);
         if (!ta && tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, true>), g64, dim3(256), 0, st, p);

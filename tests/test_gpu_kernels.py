@@ -306,6 +306,8 @@ def _torch_pointmlp(X, W, bias, gbias, rpg, gamma, beta, rm, rv, training, act):
     (2048, 512, 256, 1, False, 4, True), (777, 100, 33, 1, True, 0, False), (640, 128, 3, 0, True, 0, True),
     # per-cloud bias gradient out of the BN-backward pass (1024-row clouds: 16 slabs) and its separate-kernel fallback (ragged clouds)
     (2048, 128, 256, 2, False, 2, True), (1200, 64, 128, 2, False, 4, True),
+    # 64 output channels with a bias and fused statistics on the 128 x 64-tile kernel (needs >= 1536 row panels)
+    (196608, 64, 64, 1, True, 0, True),
     # per-cloud layers (skinny.hip): fused Linear + BN1d + act over <= 32 rows; eval mode; ragged sizes; plain Linear
     (32, 512, 256, 2, False, 0, True), (20, 300, 70, 1, True, 0, False), (5, 64, 40, 2, True, 0, True),
     (32, 256, 9, 0, True, 0, True), (32, 256, 10, 0, True, 0, False)])
