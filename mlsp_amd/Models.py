@@ -196,7 +196,7 @@ class DGCNN(nn.Module):
         xp0 = x.transpose(2, 1).contiguous().view(B * N, 3)                 # point-major [P,3]
 
         # T-Net on the graph feature of the raw cloud (Models.py:111-113)
-        g0 = Fh.knn_graph(xp0, B, N, k)
+        g0 = Fh.knn_graph(xp0, B, N, k, need_reverse=xp0.requires_grad)    # (the T-Net of a cloud without a gradient needs no reverse index)
         T = self.input_transform_net.points(xp0, g0, B, N, k)                    # [B,3,3]
         xp = Fh.apply_transform(xp0, T)                                          # (T @ x)^T, point-major
 

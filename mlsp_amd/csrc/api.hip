@@ -421,9 +421,10 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
                            float slope, int training, int B, int N, int C, int C1, int C2, int k, float* dx, float* dW1,
                            float* dgamma1, float* dbeta1, float* dW2, float* dgamma2, float* dbeta2, void* ws, size_t ws_bytes,
                            mlsp_stream_t st) {
-    if (!dOut || !x || !idx || !rev_off || !rev_ent || !W1 || !W2 || !out || !uv || !s1 || !bn1_save || !zsel || !argsel || !bn2_save ||
+    if (!dOut || !x || !idx || !W1 || !W2 || !out || !uv || !s1 || !bn1_save || !zsel || !argsel || !bn2_save ||
         !dW1 || !dgamma1 || !dbeta1 || !dW2 || !dgamma2 || !dbeta2)
         return MLSP_ERR_ARG;
+    if ((!rev_off || !rev_ent) && (dx || C > 4)) return MLSP_ERR_ARG;      // only the moment path (no input gradient, C <= 4) works without it
     if (B <= 0 || N <= 0 || C <= 0 || k <= 0 || ldx < C) return MLSP_ERR_ARG;
     if (C1 != 64 || C2 != 128 || tnet_points_per_tile(k) <= 0) return MLSP_ERR_UNSUPPORTED;
     const int P = B * N;

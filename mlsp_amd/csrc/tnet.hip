@@ -1223,6 +1223,11 @@ __global__ __launch_bounds__(64) void tnet_bwd_xmom_kernel(const float* __restri
         for (int c = 0; c < 4; ++c)
             if (c < C) xi[c] = x[(size_t)i * ldx + c];
         const int base = (i / N) * N;
+        float aj[4][4];                                                   // sum over this point's neighbours of x_j x_j^T
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) aj[a][b] = 0.f;
         for (int s0 = 0; s0 < k; s0 += 16) {                              // sixteen neighbours' coordinates in flight
             int j[16];
 #pragma unroll
@@ -1237,21 +1242,25 @@ __global__ __launch_bounds__(64) void tnet_bwd_xmom_kernel(const float* __restri
             for (int u = 0; u < 16; ++u) v3[u] = (j[u] >= 0 && C > 3) ? x[(size_t)j[u] * ldx + 3] : 0.f;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
+                const float vv[4] = {v[u][0], v[u][1], v[u][2], v3[u]};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) xb[c] += v[u][c];
-                xb[3] += v3[u];
+                for (int a = 0; a < 4; ++a) {
+                    xb[a] += vv[a];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) aj[a][b] = fmaf(vv[a], vv[b], aj[a][b]);
+                }
             }
         }
-        const float deg = (float)(rev_off[i + 1] - rev_off[i]), fk = (float)k;
+        const float fk = (float)k;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                m[4 * a + b] = deg * xi[a] * xi[b];           // A
+                m[4 * a + b] = aj[a][b];                      // A  = sum_e x_j x_j^T (per edge: no in-degrees, no reverse index)
                 m[16 + 4 * a + b] = xi[a] * xb[b];            // Bm[a][b] = sum_e x_i[a] x_j[b]
                 m[32 + 4 * a + b] = fk * xi[a] * xi[b];       // Cm
             }
-            m[48 + a] = deg * xi[a];                          // sj
+            m[48 + a] = xb[a];                                // sj = sum_e x_j
             m[52 + a] = fk * xi[a];                           // si
         }
     }

@@ -384,6 +384,8 @@ class _TnetEdge(Function):
         dev = dOut.device
         P = xp.shape[0]
         dx = torch.empty((P, C), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        if graph.rev_off is None and (dx is not None or C > 4):
+            raise RuntimeError("tnet_edge backward with an input gradient needs the reverse neighbour index (knn_graph(need_reverse=True))")
         dW1, dW2 = torch.empty_like(W1), torch.empty_like(W2)
         dg1 = torch.empty((C1,), dtype=torch.float32, device=dev)
         db1 = torch.empty((C1,), dtype=torch.float32, device=dev)
@@ -391,8 +393,8 @@ class _TnetEdge(Function):
         db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, P * graph.k, C1, C1)
         _lib.check(lib.mlsp_tnet_edge_bwd_f32(
-            dOut.data_ptr(), xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), graph.rev_off.data_ptr(),
-            graph.rev_ent.data_ptr(), W1.data_ptr(), W2.data_ptr(), out.data_ptr(), uv.data_ptr(), s1.data_ptr(), bn1.data_ptr(),
+            dOut.data_ptr(), xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), _lib.ptr(graph.rev_off),
+            _lib.ptr(graph.rev_ent), W1.data_ptr(), W2.data_ptr(), out.data_ptr(), uv.data_ptr(), s1.data_ptr(), bn1.data_ptr(),
             zsel.data_ptr(), argsel.data_ptr(), bn2.data_ptr(), slope, int(training), graph.B, graph.N, C, C1, C2, graph.k,
             _lib.ptr(dx), dW1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
             ws, wsn, _lib.stream()), "mlsp_tnet_edge_bwd_f32")
