@@ -772,3 +772,46 @@ def test_apply_transform_vs_bmm(dev):
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(gx.cpu().numpy(), x.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(gT.cpu().numpy(), T.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- Linear + BN + act + max over every k rows, fused
+@pytest.mark.parametrize("G,k,Cin,Cout,act,training,use_bias", [(64, 32, 64, 128, 1, True, True), (48, 20, 96, 256, 2, True, False),
+                                                                (16, 128, 131, 64, 1, False, True), (200, 7, 32, 1024, 0, True, True)])
+def test_pointmlp_segmax_vs_torch(dev, G, k, Cin, Cout, act, training, use_bias):
+    """mlsp_pointmlp_segmax_*_f32 (the activated [G*k, Cout] tensor is never written; BN-backward sums from the selected entries only)
+    against Linear -> BatchNorm1d -> activation -> max over every k consecutive rows in torch on the CPU; negative BN scales included
+    (min-select path), eval mode, first-occurrence ties irrelevant for random data."""
+    Fh = _fh()
+    M = G * k
+    X = _rand((M, Cin), 1).requires_grad_(True)
+    W = _rand((Cout, Cin), 2, 0.2).requires_grad_(True)
+    b = _rand((Cout,), 3).requires_grad_(True) if use_bias else None
+    g = (_rand((Cout,), 4) * 0.8 + 0.1).requires_grad_(True)            # both signs
+    be = _rand((Cout,), 5).requires_grad_(True)
+    rm, rv = _rand((Cout,), 6) * 0.1, _rand((Cout,), 7).abs() + 0.5
+    dOut = _rand((G, Cout), 8)
+    rmc, rvc = rm.clone(), rv.clone()
+    Y = X @ W.t() + (b if use_bias else 0.0)
+    Z = F.batch_norm(Y, rmc, rvc, g, be, training, 0.1, 1e-5)
+    Z = F.relu(Z) if act == 1 else F.leaky_relu(Z, 0.2) if act == 2 else Z
+    oc = Z.view(G, k, Cout).max(dim=1)[0]
+    oc.backward(dOut)
+    leaves = [t for t in (X, W, b, g, be) if t is not None]
+    gl = [t.detach().to(dev).requires_grad_(True) for t in leaves]
+    it = iter(gl)
+    Xg, Wg = next(it), next(it)
+    bg = next(it) if use_bias else None
+    gg, beg = next(it), next(it)
+    rmg, rvg = rm.to(dev), rv.to(dev)
+    og = Fh.pointmlp_segmax(Xg, Wg, k, bias=bg, gamma=gg, beta=beg, run_mean=rmg, run_var=rvg, training=training, act=act, slope=0.2)
+    og.backward(dOut.to(dev))
+    np.testing.assert_allclose(og.detach().cpu().numpy(), oc.detach().numpy(), rtol=2e-4, atol=2e-4)
+    for got, want, name in zip([t.grad for t in gl], [t.grad for t in leaves], [n for n, t in zip(["dX", "dW", "db", "dg", "dbe"], (X, W, b, g, be)) if t is not None]):
+        if name == "db" and training:
+            assert got.abs().max().item() == 0.0                       # a bias in front of batch statistics: analytically zero
+            continue
+        scale = want.abs().max().item() + 1e-6
+        assert (got.cpu() - want).abs().max().item() / scale < 2e-3, (name, (got.cpu() - want).abs().max().item() / scale)
+    if training:
+        np.testing.assert_allclose(rmg.cpu().numpy(), rmc.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rvg.cpu().numpy(), rvc.numpy(), rtol=1e-4, atol=1e-5)
