@@ -271,11 +271,13 @@ def main():
                                "kernel": "whole step (algorithmic 28.19 MFLOP/pt)"}
         # Whole-step figures.  The kernels do NOT execute the reference's 28.19 MFLOP/pt: the folded EdgeConv, the per-cloud
         # head bias and the Gram-matrix backward remove ~60 % of them.  Executed MFMA work per step = the GEMM launches (HIP
-        # events above) + the fused T-Net per-edge stage (64x128 MACs per edge, forward + two backward products) + the two
-        # distance sweeps of each of the five kNN stages (channel counts padded to the MFMA tile).
+        # events above) + the fused T-Net per-edge stage (64x128 MACs per edge, forward + two backward products) + the fp32
+        # distance sweeps of the five kNN stages (channel counts padded to the MFMA tile): both passes of the two 3-channel
+        # stages, the exact pass B only of the 64 / 64 / 128-channel stages (their pass A runs on the bf16 matrix cores and is
+        # not counted as fp32 work).
         P = B_PER_GPU * NPTS
         exec_flop = (prof[2] / prof_steps if prof and prof[1] > 0 else 0.0) + 3 * 2.0 * P * K_NN * 64 * 128 \
-            + 2 * 2.0 * P * NPTS * (4 + 4 + 64 + 64 + 128)
+            + 2.0 * P * NPTS * (2 * (4 + 4) + (64 + 64 + 128))
         step_s = dt / a.steps
         out["executed_tflops"] = exec_flop / step_s / 1e12
         out["executed_mfma_frac"] = out["executed_tflops"] / PEAK_FP32_TFLOPS
