@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 5
+#define MLSP_ABI_VERSION 6
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -174,6 +174,15 @@ int mlsp_chamfer_masked_fwd_f32(const float* pred, const float* gold, const floa
 int mlsp_chamfer_masked_bwd_f32(const float* pred, const float* gold, const float* mask, int B, int N, float scale,
                                 const float* per_cloud, const int32_t* argA, const int32_t* argB, const float* grad_loss,
                                 float* dpred, mlsp_stream_t stream);
+
+/* ONE direction of the masked Chamfer distance = the reference's chamfer_distance(p1, p2, mask) (MLSP/mlsp.py:115-153):
+ * loss = sum_b (sum over the masked rows i of p1 of min_j (|p1_i - p2_j|^2 + 100 [mask_j == 0])) / cnt_b.
+ * p1, p2 [B][N][3]; mask_cord [B][N] = mask[:, :, 0]; per_cloud [B][2] = {sum, cnt} and arg [B][N] (arg-min column of every
+ * masked row) are saved for the backward, which writes dp1 and / or dp2 [B][N][3] (either may be NULL). */
+int mlsp_chamfer_dir_fwd_f32(const float* p1, const float* p2, const float* mask_cord, int B, int N, float* per_cloud, int32_t* arg,
+                             float* loss, mlsp_stream_t stream);
+int mlsp_chamfer_dir_bwd_f32(const float* p1, const float* p2, const float* mask_cord, int B, int N, const float* per_cloud,
+                             const int32_t* arg, const float* grad_loss, float* dp1, float* dp2, mlsp_stream_t stream);
 
 /* normal loss (MLSP/mlsp.py:275-287; weighted form PointDA/trainer.py:551-556):
  * out[0] = -weight * sum_i w_i |cos(pred_i, gt_i)| / sum_i w_i ; out[1] = sum w.  w nullable (=1). */

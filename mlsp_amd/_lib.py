@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLSP_HIP_LIB") or os.path.join(_HERE, "libmlsp_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c = ctypes
 _P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
@@ -54,6 +54,8 @@ SIGNATURES = {
     "mlsp_colmax_bwd_f32": [_P, _P, _I, _I, _I, _P, _P],
     "mlsp_chamfer_masked_fwd_f32": [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P],
     "mlsp_chamfer_masked_bwd_f32": [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
+    "mlsp_chamfer_dir_fwd_f32": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "mlsp_chamfer_dir_bwd_f32": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "mlsp_normal_loss_fwd_f32": [_P, _P, _P, _I, _F, _P, _P, _SZ, _P],
     "mlsp_normal_loss_bwd_f32": [_P, _P, _P, _I, _F, _P, _P, _P, _P],
     "mlsp_density_tail_fwd_f32": [_P, _P, _I, _I, _P, _P, _P],

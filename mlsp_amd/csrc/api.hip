@@ -115,6 +115,10 @@ int launch_chamfer_fwd(hipStream_t st, const float* pred, const float* gold, con
                        float* per_cloud, int* argA, int* argB, float* loss);
 int launch_chamfer_bwd(hipStream_t st, const float* pred, const float* gold, const float* mask, int B, int N, float scale,
                        const float* per_cloud, const int* argA, const int* argB, const float* gout, float* dpred);
+int launch_chamfer_dir_fwd(hipStream_t st, const float* p1, const float* p2, const float* mc, int B, int N, float* per_cloud, int* arg,
+                           float* loss);
+int launch_chamfer_dir_bwd(hipStream_t st, const float* p1, const float* p2, const float* mc, int B, int N, const float* per_cloud,
+                           const int* arg, const float* gout, float* dp1, float* dp2);
 int launch_normal_loss_fwd(hipStream_t st, const float* pred, const float* gt, const float* w, int P, float weight,
                            double* part, float* out);
 int launch_normal_loss_bwd(hipStream_t st, const float* pred, const float* gt, const float* w, int P, float weight,
@@ -921,6 +925,17 @@ int mlsp_chamfer_masked_bwd_f32(const float* pred, const float* gold, const floa
                                 float* dpred, mlsp_stream_t st) {
     if (!pred || !gold || !mask || !per_cloud || !argA || !argB || !grad_loss || !dpred || B <= 0 || N <= 0) return MLSP_ERR_ARG;
     return launch_chamfer_bwd(st, pred, gold, mask, B, N, scale, per_cloud, argA, argB, grad_loss, dpred);
+}
+
+int mlsp_chamfer_dir_fwd_f32(const float* p1, const float* p2, const float* mask_cord, int B, int N, float* per_cloud, int32_t* arg,
+                             float* loss, mlsp_stream_t st) {
+    if (!p1 || !p2 || !mask_cord || !per_cloud || !arg || !loss || B <= 0 || N <= 0) return MLSP_ERR_ARG;
+    return launch_chamfer_dir_fwd(st, p1, p2, mask_cord, B, N, per_cloud, arg, loss);
+}
+int mlsp_chamfer_dir_bwd_f32(const float* p1, const float* p2, const float* mask_cord, int B, int N, const float* per_cloud,
+                             const int32_t* arg, const float* grad_loss, float* dp1, float* dp2, mlsp_stream_t st) {
+    if (!p1 || !p2 || !mask_cord || !per_cloud || !arg || !grad_loss || (!dp1 && !dp2) || B <= 0 || N <= 0) return MLSP_ERR_ARG;
+    return launch_chamfer_dir_bwd(st, p1, p2, mask_cord, B, N, per_cloud, arg, grad_loss, dp1, dp2);
 }
 
 int mlsp_normal_loss_fwd_f32(const float* pred, const float* gt, const float* wgt, int P, float weight, float* out, void* ws,

@@ -143,6 +143,129 @@ __global__ __launch_bounds__(1024) void chamfer_bwd_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// ONE direction of the masked Chamfer distance, as the reference's chamfer_distance(p1, p2, mask) (MLSP/mlsp.py:115-153):
+// p1, p2 [B][N][3] point-major, mc [B][N] = mask[:, :, 0].  Rows = the masked points of p1, columns = all points of p2 with a
+// +100 penalty on the unmasked ones.  per_cloud[b] = {sum of the row minima, number of masked rows}; arg [B][N] the arg-min column
+// of every masked row.
+__global__ __launch_bounds__(1024) void chamfer_dir_fwd_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                               const float* __restrict__ mc, int N, float* __restrict__ per_cloud,
+                                                               int* __restrict__ arg) {
+    extern __shared__ float dsm[];
+    float* cx = dsm;                  // p2 (columns) [3][N]
+    float* pen = dsm + 3 * N;         // [N]
+    int* rows = (int*)(dsm + 4 * N);  // [N]
+    float* rowv = dsm + 5 * N;        // [N]
+    __shared__ int nrows;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const float* a = p1 + (size_t)b * N * 3;
+    const float* c = p2 + (size_t)b * N * 3;
+    const float* mb = mc + (size_t)b * N;
+    for (int n = tid; n < N; n += nt) {
+        cx[n] = c[n * 3]; cx[N + n] = c[n * 3 + 1]; cx[2 * N + n] = c[n * 3 + 2];
+        pen[n] = mb[n] == 0.f ? 100.f : 0.f;
+    }
+    if (wave == 0) {
+        int base = 0;
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            int n = n0 + lane;
+            bool m = n < N && mb[n] != 0.f;
+            unsigned long long bal = __ballot(m);
+            int pos = __popcll(bal & ((1ull << lane) - 1ull));
+            if (m) rows[base + pos] = n;
+            base += __popcll(bal);
+        }
+        if (lane == 0) nrows = base;
+    }
+    __syncthreads();
+    const int nr = nrows;
+    for (int r = wave; r < nr; r += nw) {
+        const int i = rows[r];
+        const float ax = a[i * 3], ay = a[i * 3 + 1], az = a[i * 3 + 2];
+        float best = INFINITY;
+        int bj = 0x7fffffff;
+        for (int j = lane; j < N; j += 64) {
+            float dx = ax - cx[j], dy = ay - cx[N + j], dz = az - cx[2 * N + j];
+            float nrm = sqrtf(dx * dx + dy * dy + dz * dz);     // norm(...)**2 (mlsp.py:138)
+            float d = nrm * nrm + pen[j];
+            if (d < best) { best = d; bj = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(best, o, 64);
+            int oj = __shfl_xor(bj, o, 64);
+            if (ov < best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+        }
+        if (lane == 0) { rowv[r] = best; arg[(size_t)b * N + i] = bj; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int r = 0; r < nr; ++r) s += rowv[r];
+        per_cloud[b * 2] = s; per_cloud[b * 2 + 1] = (float)nr;
+    }
+}
+
+__global__ void chamfer_dir_finalize_kernel(const float* __restrict__ per_cloud, int B, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += per_cloud[b * 2] / per_cloud[b * 2 + 1];
+        loss[0] = s;
+    }
+}
+
+// dp1_i = coef (p1_i - p2_t(i)) on masked rows (0 elsewhere); dp2_j = -coef sum_{i masked, t(i) = j} (p1_i - p2_j); coef = 2 g / cnt_b
+__global__ __launch_bounds__(1024) void chamfer_dir_bwd_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                               const float* __restrict__ mc, int N, const float* __restrict__ per_cloud,
+                                                               const int* __restrict__ arg, const float* __restrict__ gout,
+                                                               float* __restrict__ dp1, float* __restrict__ dp2) {
+    extern __shared__ int esm[];
+    int* rows = esm;
+    int* tgt = esm + N;
+    __shared__ int nrows;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const float* a = p1 + (size_t)b * N * 3;
+    const float* c = p2 + (size_t)b * N * 3;
+    const float* mb = mc + (size_t)b * N;
+    if (wave == 0) {
+        int base = 0;
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            int n = n0 + lane;
+            bool m = n < N && mb[n] != 0.f;
+            unsigned long long bal = __ballot(m);
+            int pos = __popcll(bal & ((1ull << lane) - 1ull));
+            if (m) { rows[base + pos] = n; tgt[base + pos] = arg[(size_t)b * N + n]; }
+            base += __popcll(bal);
+        }
+        if (lane == 0) nrows = base;
+    }
+    __syncthreads();
+    const int nr = nrows;
+    const float coef = gout[0] * 2.0f / per_cloud[b * 2 + 1];
+    for (int j = tid; j < N; j += nt) {
+        if (dp1) {
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+            if (mb[j] != 0.f) {
+                const int t = arg[(size_t)b * N + j];
+                gx = a[j * 3] - c[t * 3]; gy = a[j * 3 + 1] - c[t * 3 + 1]; gz = a[j * 3 + 2] - c[t * 3 + 2];
+            }
+            float* o = dp1 + ((size_t)b * N + j) * 3;
+            o[0] = coef * gx; o[1] = coef * gy; o[2] = coef * gz;
+        }
+        if (dp2) {
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+            const float cxj = c[j * 3], cyj = c[j * 3 + 1], czj = c[j * 3 + 2];
+            for (int r = 0; r < nr; ++r)          // fixed order
+                if (tgt[r] == j) {
+                    const int i = rows[r];
+                    gx += cxj - a[i * 3]; gy += cyj - a[i * 3 + 1]; gz += czj - a[i * 3 + 2];
+                }
+            float* o = dp2 + ((size_t)b * N + j) * 3;
+            o[0] = coef * gx; o[1] = coef * gy; o[2] = coef * gz;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // normal loss:  loss = -weight * sum_i w_i |cos_i| / sum_i w_i     (w == null: w_i = 1)
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -327,6 +450,25 @@ int launch_chamfer_bwd(hipStream_t st, const float* pred, const float* gold, con
     size_t lds = (size_t)2 * N * sizeof(int);
     hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(B), dim3(1024), lds, st, pred, gold, mask, N, per_cloud, argA, argB, gout, scale,
                        dpred);
+    return mlsp_launch_status();
+}
+int launch_chamfer_dir_fwd(hipStream_t st, const float* p1, const float* p2, const float* mc, int B, int N, float* per_cloud, int* arg,
+                           float* loss) {
+    size_t lds = (size_t)6 * N * sizeof(float);
+    if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)chamfer_dir_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(chamfer_dir_fwd_kernel, dim3(B), dim3(1024), lds, st, p1, p2, mc, N, per_cloud, arg);
+    hipLaunchKernelGGL(chamfer_dir_finalize_kernel, dim3(1), dim3(64), 0, st, per_cloud, B, loss);
+    return mlsp_launch_status();
+}
+int launch_chamfer_dir_bwd(hipStream_t st, const float* p1, const float* p2, const float* mc, int B, int N, const float* per_cloud,
+                           const int* arg, const float* gout, float* dp1, float* dp2) {
+    size_t lds = (size_t)2 * N * sizeof(int);
+    if (lds > 64 * 1024) return MLSP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(chamfer_dir_bwd_kernel, dim3(B), dim3(1024), lds, st, p1, p2, mc, N, per_cloud, arg, gout, dp1, dp2);
     return mlsp_launch_status();
 }
 int launch_normal_loss_fwd(hipStream_t st, const float* pred, const float* gt, const float* w, int P, float weight,

@@ -837,6 +837,47 @@ def chamfer_masked(pred, gold, mask, scale):
     return _Chamfer.apply(pred, gold, mask, float(scale))
 
 
+class _ChamferDir(Function):
+    @staticmethod
+    def forward(ctx, p1, p2, mask_cord):
+        lib = _lib.load()
+        p1, p2 = p1.contiguous().float(), p2.contiguous().float()
+        mask_cord = mask_cord.contiguous().float()
+        _lib.require_gpu(p1, p2, mask_cord)
+        B, N, C = p1.shape
+        assert C == 3 and p2.shape == (B, N, 3) and mask_cord.shape == (B, N), (p1.shape, p2.shape, mask_cord.shape)
+        dev = p1.device
+        per_cloud = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, N), dtype=torch.int32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(lib.mlsp_chamfer_dir_fwd_f32(p1.data_ptr(), p2.data_ptr(), mask_cord.data_ptr(), B, N, per_cloud.data_ptr(),
+                                                arg.data_ptr(), loss.data_ptr(), _lib.stream()), "mlsp_chamfer_dir_fwd_f32")
+        ctx.save_for_backward(p1, p2, mask_cord, per_cloud, arg)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        p1, p2, mask_cord, per_cloud, arg = ctx.saved_tensors
+        B, N, _ = p1.shape
+        g = g.contiguous().float()
+        dp1 = torch.empty_like(p1) if ctx.needs_input_grad[0] else None
+        dp2 = torch.empty_like(p2) if ctx.needs_input_grad[1] else None
+        if dp1 is None and dp2 is None:
+            return None, None, None
+        _lib.check(lib.mlsp_chamfer_dir_bwd_f32(p1.data_ptr(), p2.data_ptr(), mask_cord.data_ptr(), B, N, per_cloud.data_ptr(),
+                                                arg.data_ptr(), g.data_ptr(), _lib.ptr(dp1), _lib.ptr(dp2), _lib.stream()),
+                   "mlsp_chamfer_dir_bwd_f32")
+        return dp1, dp2, None
+
+
+def chamfer_dir(p1, p2, mask_cord):
+    """ONE direction of the masked Chamfer distance (MLSP/mlsp.py:115-153): p1, p2 [B,N,3], mask_cord [B,N] -> 0-dim loss;
+    gradients flow to both point sets."""
+    return _ChamferDir.apply(p1, p2, mask_cord)
+
+
 class _NormalLoss(Function):
     @staticmethod
     def forward(ctx, pred, gt, w, weight):

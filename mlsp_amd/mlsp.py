@@ -104,9 +104,12 @@ def scan_input(X, device, pixel_size=0.07, angles=None):
 
 
 def chamfer_distance(p1, p2, mask):
-    """MLSP/mlsp.py:115-153 is only ever called in symmetric pairs by reconstruction_loss; the fused
-    kernel computes both directions at once, so the one-directional entry is not provided."""
-    raise NotImplementedError("use reconstruction_loss(pred, gold, mask): both directions are fused in one kernel")
+    """MLSP/mlsp.py:115-153.  p1, p2, mask [B,N,3] (reconstruction_loss passes the permuted clouds): for every MASKED point of p1
+    the squared distance to its nearest masked point of p2 (unmasked columns carry a +100 penalty), averaged over the masked
+    points of each cloud and summed over the batch.  One direction of the fused kernel behind reconstruction_loss; differentiable
+    in p1 and p2."""
+    assert p1.size(0) == p2.size(0) and p1.size(1) == p2.size(1)
+    return Fh.chamfer_dir(p1, p2, mask[:, :, 0])
 
 
 def reconstruction_loss(pred, gold, mask):

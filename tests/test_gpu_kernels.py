@@ -542,6 +542,30 @@ def test_losses_vs_golden(dev, golden_dir, fname):
         np.testing.assert_allclose(mae_u.item(), g["mae_unmasked"], rtol=1e-4)
 
 
+@pytest.mark.parametrize("fname", ["chamfer_dir_s4_B3_N256.npz", "chamfer_dir_s5_B2_N1024.npz"])
+def test_chamfer_distance_one_direction_vs_golden(dev, golden_dir, fname):
+    """mlsp.chamfer_distance(p1, p2, mask) (MLSP/mlsp.py:115-153) against the reference's value and BOTH gradients; the two
+    directions add up to reconstruction_loss."""
+    from mlsp_amd import mlsp
+    g = dict(np.load(os.path.join(golden_dir, fname)))
+    p1 = torch.from_numpy(g["p1"]).to(dev).requires_grad_(True)
+    p2 = torch.from_numpy(g["p2"]).to(dev).requires_grad_(True)
+    mask = torch.from_numpy(g["mask"]).to(dev)
+    d = mlsp.chamfer_distance(p1, p2, mask)
+    d.backward()
+    np.testing.assert_allclose(d.item(), g["dist"], rtol=1e-5)
+    np.testing.assert_allclose(p1.grad.cpu().numpy(), g["g_p1"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(p2.grad.cpu().numpy(), g["g_p2"], rtol=1e-4, atol=1e-7)
+    with torch.no_grad():
+        both = mlsp.chamfer_distance(p1, p2, mask) + mlsp.chamfer_distance(p2, p1, mask)
+        fused = mlsp.reconstruction_loss(p2, p1.permute(0, 2, 1).contiguous(), mask.permute(0, 2, 1).contiguous())
+    np.testing.assert_allclose(both.item() / p1.shape[0], fused.item(), rtol=1e-6)
+    # only one side needs a gradient
+    q = torch.from_numpy(g["p2"]).to(dev).requires_grad_(True)
+    mlsp.chamfer_distance(p1.detach(), q, mask).backward()
+    np.testing.assert_allclose(q.grad.cpu().numpy(), g["g_p2"], rtol=1e-4, atol=1e-7)
+
+
 def test_chamfer_edge_cases(dev):
     """Empty mask -> NaN like the reference (0/0, mlsp.py:152); all-masked cloud; pred == gold -> 0."""
     from mlsp_amd import mlsp

@@ -93,6 +93,19 @@ def test_losses(golden_dir, fname):
         np.testing.assert_allclose(mae.item(), g["mae_unmasked"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("fname", ["chamfer_dir_s4_B3_N256.npz", "chamfer_dir_s5_B2_N1024.npz"])
+def test_chamfer_distance_one_direction(golden_dir, fname):
+    """oracle chamfer_distance vs the reference's own MLSP/mlsp.py:115-153 output and gradients (tools/make_golden.py round3)"""
+    g = _load(golden_dir, fname)
+    p1 = torch.from_numpy(g["p1"]).requires_grad_(True)
+    p2 = torch.from_numpy(g["p2"]).requires_grad_(True)
+    d = ref_cpu.chamfer_distance(p1, p2, torch.from_numpy(g["mask"]))
+    d.backward()
+    np.testing.assert_allclose(d.item(), g["dist"], rtol=1e-5)
+    np.testing.assert_allclose(p1.grad.numpy(), g["g_p1"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(p2.grad.numpy(), g["g_p2"], rtol=1e-4, atol=1e-7)
+
+
 # ----------------------------------------------------------------------------- DGCNN + heads
 def _build_params(seed):
     """Parameters identical to the reference model of the fixture (checked via checksums)."""

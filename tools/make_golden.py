@@ -159,6 +159,27 @@ def loss_case(ref_mlsp, seed, B, N):
     return out
 
 
+def chamfer_dir_case(ref_mlsp, seed, B, N):
+    """MLSP/mlsp.py:115-153 chamfer_distance(p1, p2, mask) on its own (one direction), gradients w.r.t. both clouds."""
+    inp = gc.make_inputs(seed, B, N)
+    g = torch.Generator().manual_seed(91 + seed)
+    p1 = inp["gold"].permute(0, 2, 1).contiguous().requires_grad_(True)
+    p2 = (inp["gold"].permute(0, 2, 1) + 0.1 * torch.randn(B, N, 3, generator=g)).requires_grad_(True)
+    mask = inp["mask"].permute(0, 2, 1).contiguous()
+    d = ref_mlsp.chamfer_distance(p1, p2, mask)
+    d.backward()
+    return dict(p1=npy(p1), p2=npy(p2), mask=npy(mask), dist=npy(d), g_p1=npy(p1.grad), g_p2=npy(p2.grad))
+
+
+def main_round3():
+    """Round-3 fixtures: the one-directional chamfer_distance entry."""
+    _, _, ref_mlsp = ref_import.import_reference()
+    for seed, B, N in [(4, 3, 256), (5, 2, 1024)]:
+        f = os.path.join(OUT, "chamfer_dir_s%d_B%d_N%d.npz" % (seed, B, N))
+        np.savez_compressed(f, **chamfer_dir_case(ref_mlsp, seed, B, N))
+        print(f, os.path.getsize(f))
+
+
 def graph_feature_case(ref_mu, seed):
     g = torch.Generator().manual_seed(seed)
     x = torch.rand(2, 5, 64, generator=g) * 2 - 1
@@ -595,6 +616,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "radius":
         radius_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round3":
+        main_round3()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
         main_round2()
