@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
         import ctypes
         for kind, ct in zip(kinds, _lib.SIGNATURES[name]):
             assert (ct is ctypes.c_void_p) == (kind == "p"), (name, args)
-    assert lib.mlsp_abi_version() == 5
+    assert lib.mlsp_abi_version() == _lib.ABI_VERSION == 6
     assert b"workspace" in lib.mlsp_strerror(-2)
     assert lib.mlsp_workspace_bytes(32768, 512, 1024) > 32768 * 1024 * 4
 
@@ -50,7 +50,7 @@ def test_reference_api_surface_cpu():
     for name in ("DGCNN", "RegionReconstruction", "Normal_prediction", "Density_prediction"):
         assert hasattr(Models, name)
     for name in ("calc_loss", "calc_scan_loss", "reconstruction_loss", "calc_normal_loss", "normal_prediction_loss",
-                 "densityloss", "DefRec_SCALER"):
+                 "densityloss", "chamfer_distance", "DefRec_SCALER"):
         assert hasattr(mlsp, name)
     assert mlsp.DefRec_SCALER == 20.0
     sig = inspect.signature(Models.DGCNN.forward)
