@@ -21,12 +21,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 B_PER_GPU, NPTS, K_NN = 32, 1024, 20
 FLOP_PER_POINT = 28.19e6        # algorithmic fwd+bwd FLOP per point (reference op sequence)
 PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def pmc_gemm_traffic():
@@ -71,8 +71,16 @@ def synth_batch(B, N, device, seed=0):
 
 
 def make_args(cuda=True):
-    import golden_common as gc
-    return gc.make_args(dropout=0.5, cuda=cuda)
+    """The argparse fields the model and the losses read (PointDA/trainer.py:44-111; Models.py:85,175,255,269; model_utils.py:25,98-99,
+    133; mlsp.py:228,286,445-452) at the trainer's defaults."""
+    return argparse.Namespace(num_class=10, dropout=0.5, model="dgcnn", encoder_type=None, cuda=cuda, density_num_class=16,
+                              pergroup=2.0, DefRec_weight=0.5, normal_pred_weight=0.5, Density_weight=0.05, Scan_Rec_weight=0.5)
+
+
+def make_seg_args():
+    """PointSegDA/Models.py:25-28 (gpus), :257-258 (dropout), :353 (density_num_class), :370 (pergroup)."""
+    return argparse.Namespace(gpus=[0], dropout=0.5, density_num_class=16, pergroup=2.0, DefRec_weight=0.5, normal_pred_weight=0.5,
+                              Density_weight=0.05)
 
 
 def gpu_step(model, mlsp, args, batch, opt):
@@ -163,13 +171,135 @@ def cpu_baseline(budget_s=45.0):
             "runs": runs, "cpu_model": model_name, "physical_cores": physical, "logical_cpus": logical}
 
 
+PROF_CLASSES = 7          # include/mlsp_hip.h MLSP_PROF_CLASSES
+
+
+def profiled_steps(lib, step_fn, nsteps):
+    """`nsteps` untimed steps with the library's HIP-event hook armed (events on the launch stream around every launch of the priced
+    kernel families) -> (per-class [ms, launches, work] rows, [gemm ms, launches, flop, algorithmic bytes], seconds per step)."""
+    import ctypes
+    lib.mlsp_profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step_fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / nsteps
+    buf = (ctypes.c_double * 4)()
+    lib.mlsp_profile_end(buf)
+    cls = (ctypes.c_double * (3 * PROF_CLASSES))()
+    lib.mlsp_profile_classes(cls, PROF_CLASSES)
+    rows = [list(cls[3 * c:3 * c + 3]) for c in range(PROF_CLASSES)]
+    return rows, list(buf), dt
+
+
+def _kernel_entry(name, bound, row, nsteps, note):
+    """One `roofline_kernels` entry from a class row [ms, launches, work]: achieved = algorithmic work / HIP-event time."""
+    ms, n, work = row
+    if n <= 0 or ms <= 0:
+        return None
+    if bound == "hbm":
+        ach, peak, unit = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+    else:
+        ach, peak, unit = work / (ms * 1e-3) / 1e12, PEAK_FP32_TFLOPS, "TFLOP/s"
+    return {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+            "launches_per_step": n / nsteps, "avg_us": 1e3 * ms / n, "us_per_step": 1e3 * ms / nsteps, "note": note}
+
+
+def median_block_ms(step_fn, steps, repeats, warm):
+    for _ in range(warm):
+        step_fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / steps)
+    return 1e3 * sorted(ts)[len(ts) // 2]
+
+
+def secondary_workloads(lib, dev):
+    """BASELINE.json configs[3] and configs[4] on this GPU, AFTER the headline blocks (never inside its timed region): a few steps each,
+    median of three 10-step blocks, plus the GEMM family's roofline entry from one HIP-event-profiled block."""
+    from mlsp_amd import pointnet2 as p2, seg_models, functional as Fh
+    out = []
+    # configs[3]: PointNet++ set-abstraction encoder (hengshuang_transformer/pointnet_util.py:159-196), B=32 N=2048, fwd + bwd, fp32
+    torch.manual_seed(0)
+    B, N = 32, 2048
+    xyz = (torch.rand(B, N, 3) * 2 - 1).to(dev)
+    layers = [p2.PointNetSetAbstraction(512, 0.2, 32, 3, [64, 64, 128], False),
+              p2.PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 256], False),
+              p2.PointNetSetAbstraction(None, None, None, 259, [256, 512, 1024], True)]
+    for l in layers:
+        l.to(dev)
+    params = [p for l in layers for p in l.parameters()]
+
+    def sa_step():
+        for p in params:
+            p.grad = None
+        x, f = xyz, None
+        for l in layers:
+            x, f = l(x, f)
+        f.sum().backward()
+
+    ms = median_block_ms(sa_step, 10, 3, 4)
+    rows, g, _ = profiled_steps(lib, sa_step, 2)
+    ach = g[2] / (g[0] * 1e-3) / 1e12 if g[0] > 0 else 0.0
+    out.append({"workload": "PointNet++ SA encoder (3 set-abstraction layers: FPS + ball query + grouping + SA-MLP), fwd+bwd, B=32 N=2048 "
+                            "(BASELINE.json configs[3])", "ms_per_step": ms, "points_per_s": B * N / ms * 1e3, "dtype": "f32",
+                "roofline": {"kernel": "gemm_f32_kernel<*> (SA-MLP contractions)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+                             "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "share_of_step": g[0] / 2 / ms,
+                             "launches_per_step": g[1] / 2}})
+    del layers, params, xyz
+
+    # configs[4]: PointSegDA DGCNN_DefRec (PointSegDA/Models.py:197-242), N=2048, k=40, all heads, fwd + bwd + Adam, bf16 GEMM operands and
+    # bf16 activation storage (fp32 accumulation / statistics / kNN / losses); B=16 per GPU = the reference trainer's batch
+    B, N, K = 16, 2048, 40
+    torch.manual_seed(0)
+    seg = seg_models.DGCNN_DefRec(make_seg_args(), in_size=3, num_classes=8)
+    seg.k = seg.shared_layers.k = K
+    seg = seg.to(dev).train()
+    opt = torch.optim.Adam(seg.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+    x = torch.rand(B, 3, N, device=dev) * 2 - 1
+    w = {k: torch.randn(sh, device=dev) for k, sh in (("seg", (B, N, 8)), ("DefRec", (B, N, 3)), ("Normal", (B, N, 3)),
+                                                      ("density", (B * N, 16)), ("density_mse", (B * N,)))}
+
+    def seg_step():
+        opt.zero_grad()
+        o = seg(x, make_seg=True, activate_DefRec=True, activate_density_normal_ondef=True)
+        sum((o[k].float() * w[k]).mean() for k in w).backward()
+        opt.step()
+
+    with Fh.gemm_precision("bf16"), Fh.activation_storage("bf16"):
+        ms = median_block_ms(seg_step, 10, 3, 4)
+        rows, g, _ = profiled_steps(lib, seg_step, 2)
+    gbs = g[3] / (g[0] * 1e-3) / 1e9 if g[0] > 0 else 0.0
+    tfs = g[2] / (g[0] * 1e-3) / 1e12 if g[0] > 0 else 0.0
+    out.append({"workload": "PointSegDA DGCNN_DefRec + seg + 3 MLSP heads, fwd+bwd+Adam, B=16 N=2048 k=40 (BASELINE.json configs[4], one GPU)",
+                "ms_per_step": ms, "points_per_s": B * N / ms * 1e3, "dtype": "bf16 GEMM operands + bf16 activation storage, fp32 accumulate",
+                "roofline": {"kernel": "gemm_bf16_kernel<*> / gemm_f32_kernel<*> (every MFMA GEMM launch)", "bound": "hbm", "achieved": gbs,
+                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "mfma_tflops": tfs,
+                             "mfma_frac_of_bf16_dense_peak": tfs / PEAK_BF16_TFLOPS, "share_of_step": g[0] / 2 / ms,
+                             "launches_per_step": g[1] / 2,
+                             "note": "achieved = algorithmic operand + result bytes of the launches (A + B + C in their storage types) / "
+                                     "HIP-event time: at bf16 the contractions sit under the HBM roof, not the 2.5 PF matrix roof"},
+                "knn": [e for e in (_kernel_entry("kNN C=3, k=40, N=2048 (knn_mfma5 + row norms)", "hbm", rows[1], 2, "compulsory (C+k)*4 B/pt"),
+                                    _kernel_entry("kNN C=64, k=40, N=2048", "mfma", rows[2], 2, "2*N*C FLOP per point, one pass")) if e]})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: this many clouds in total, split over the ranks (SURVEY 8d config (2) secondary: 32). "
+                         "Default 0 = weak scaling, 32 clouds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] runs after the headline")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -183,6 +313,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_gpus = world if distributed else 1
+    if a.global_batch:
+        if a.global_batch % n_gpus:
+            raise SystemExit("--global-batch must be a multiple of the number of ranks")
+        b_local, scaling = a.global_batch // n_gpus, "strong"
+    else:
+        b_local, scaling = B_PER_GPU, "weak"
 
     from mlsp_amd import Models, mlsp, _lib
     from mlsp_amd.ddp import FlatGradSync
@@ -192,10 +329,13 @@ def main():
     model = Models.DGCNN(args).to(dev).train()
     sync = FlatGradSync(model)
     opt = sync.wrap(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, fused=True))   # trainer.py:258-259
-    batch = synth_batch(B_PER_GPU, NPTS, dev, seed=1000 + rank)
+    batch = synth_batch(b_local, NPTS, dev, seed=1000 + rank)
+
+    def one_step():
+        return gpu_step(model, mlsp, args, batch, opt)
 
     for _ in range(a.warmup):
-        gpu_step(model, mlsp, args, batch, opt)
+        one_step()
 
     def timed_block():
         """EXACTLY a.steps steps between two (barrier + synchronize) brackets; max over ranks."""
@@ -205,7 +345,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            last = gpu_step(model, mlsp, args, batch, opt)
+            last = one_step()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -217,7 +357,18 @@ def main():
             dt_ = t.item()
         return dt_, last
 
-    # One block of a.steps steps lasts ~0.15 s: the block is repeated and the MEDIAN block is the headline (a single short
+    # After --warmup steps the clocks / allocator / caches of a fresh process are still ramping (round 2: first block 10.5 ms against 5.75):
+    # untimed SETTLE blocks run until two consecutive ones agree to 1 % (at most 4); only then do the timed blocks start.  Every rank
+    # takes the same decision (block times are max-reduced over the ranks).
+    settle, prev = [], None
+    for _ in range(4):
+        dt_s, _ = timed_block()
+        settle.append(dt_s)
+        if prev is not None and abs(dt_s - prev) <= 0.01 * prev:
+            break
+        prev = dt_s
+
+    # One block of a.steps steps lasts ~0.1 s: the block is repeated and the MEDIAN block is the headline (a single short
     # sample is at the mercy of clock ramps and of whatever else the host does); min/max go into `blocks_ms_per_step`.
     blocks = []
     for _ in range(max(1, a.repeats)):
@@ -226,45 +377,51 @@ def main():
     dt = sorted(blocks)[len(blocks) // 2]
     assert torch.isfinite(loss).item()
 
-    # HIP events around every GEMM launch (the dominant kernel family): a separate, untimed block AFTER the timing
+    # HIP events around every launch of the priced kernel families: a separate, untimed block AFTER the timing
     prof_steps = 3
-    import ctypes
-    lib.mlsp_profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(prof_steps):
-        gpu_step(model, mlsp, args, batch, opt)
-    torch.cuda.synchronize()
-    prof_dt = (time.perf_counter() - t0) / prof_steps
-    buf = (ctypes.c_double * 4)()
-    lib.mlsp_profile_end(buf)
-    prof = list(buf)
+    rows, prof, prof_dt = profiled_steps(lib, one_step, prof_steps)
 
     if rank == 0:
-        n_gpus = world if distributed else 1
-        pts = B_PER_GPU * NPTS * n_gpus * a.steps
+        pts = b_local * NPTS * n_gpus * a.steps
         value = pts / dt
         out = {"metric": "points/sec fwd+bwd, DGCNN+MLSP B=32 N=1024 k=20", "value": value, "unit": "points/s",
                "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
                "blocks_ms_per_step": {"n": len(blocks), "median": 1e3 * dt / a.steps, "min": 1e3 * min(blocks) / a.steps,
-                                      "max": 1e3 * max(blocks) / a.steps},
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "DGCNN encoder + 3 MLSP heads + losses, fwd+bwd+Adam, B=32/GPU N=1024 k=20 fp32 "
-                                      "(BASELINE.json configs[1]), dropout 0.5, BN train",
-                          "global_batch": B_PER_GPU * n_gpus, "points_per_cloud": NPTS, "k": K_NN,
+                                      "max": 1e3 * max(blocks) / a.steps,
+                                      "untimed_settle_blocks": [round(1e3 * t / a.steps, 3) for t in settle]},
+               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "DGCNN encoder + 3 MLSP heads + losses, fwd+bwd+Adam, B=%d/GPU N=1024 k=20 fp32 "
+                                      "(BASELINE.json configs[1]), dropout 0.5, BN train" % b_local,
+                          "global_batch": b_local * n_gpus, "points_per_cloud": NPTS, "k": K_NN,
                           "parallelism": "dp%d" % n_gpus, "grad_allreduce": "1 x flat 18.2 MB fp32 per step (RCCL)"}}
         if prof and prof[1] > 0:
-            # prof = [total ms of the profiled kernel, launches, algorithmic FLOP summed over launches, 0]
+            # prof = [total ms of the profiled kernel, launches, algorithmic FLOP summed over launches, algorithmic bytes]
             ach = prof[2] / (prof[0] * 1e-3) / 1e12
             traffic, traffic_src = pmc_gemm_traffic()
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
-                               "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE), %s" % traffic_src,
+                               "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE), %s; algorithmic A+B+C bytes per "
+                                               "launch: %.0f" % (traffic_src, prof[3] / prof[1]),
                                "kernel": "gemm_f32_kernel<*> (every fp32 MFMA GEMM launch: fwd, dgrad, wgrad)",
                                "launches": int(prof[1]), "avg_us": 1e3 * prof[0] / prof[1],
                                "share_of_step": prof[0] / prof_steps / (1e3 * dt / a.steps),
                                "note": "achieved = sum(2*M*N*K of the launches: EXECUTED flops) / sum(HIP-event time of the "
                                        "launches), events on the launch stream, %d untimed steps after the timed blocks "
                                        "(%.2f ms/step with the events armed)" % (prof_steps, 1e3 * prof_dt)}
+            # the other families north_star names: kNN / gather against HBM, kNN distance sweeps and the T-Net stage against the matrix peak
+            ks = [_kernel_entry("kNN C=3 (knn_mfma5_kernel<4> + sqnorm), stages 0-1", "hbm", rows[1], prof_steps,
+                                "compulsory bytes (C+k)*4 per point; the kernel is select-bound, not HBM-bound (DESIGN 4)"),
+                  _kernel_entry("EdgeConv neighbour gather-reduce (edge_reduce_lds_kernel), 4 EdgeConv + T-Net conv1", "hbm", rows[4], prof_steps,
+                                "compulsory bytes: u half + indices in, msel + s1 + arg slot out; LDS-gather bound"),
+                  _kernel_entry("kNN C=64 (knn_mfma5_kernel<64>), stages 2-3", "mfma", rows[2], prof_steps,
+                                "algorithmic 2*N*C FLOP per point (one distance sweep; the kernel runs two)"),
+                  _kernel_entry("kNN C=128 (knn_mfma5_kernel<128>), stage 4", "mfma", rows[3], prof_steps,
+                                "algorithmic 2*N*C FLOP per point (one distance sweep; the kernel runs two)"),
+                  _kernel_entry("T-Net per-edge stage forward (tnet_edge_fwd2_kernel<20>)", "mfma", rows[5], prof_steps,
+                                "2*E*64*128 FLOP"),
+                  _kernel_entry("T-Net per-edge stage backward (tnet_edge_bwdg_kernel + prep / slab reduce / finish)", "mfma", rows[6],
+                                prof_steps, "reference FLOP 4*E*64*128 (the Gram form executes about a third of them)")]
+            out["roofline_kernels"] = [k for k in ks if k]
         else:
             out["roofline"] = {"bound": "mfma", "achieved": value * FLOP_PER_POINT / 1e12, "peak": PEAK_FP32_TFLOPS,
                                "unit": "TFLOP/s", "frac": value * FLOP_PER_POINT / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
@@ -275,13 +432,16 @@ def main():
         # distance sweeps of the five kNN stages (channel counts padded to the MFMA tile): both passes of the two 3-channel
         # stages, the exact pass B only of the 64 / 64 / 128-channel stages (their pass A runs on the bf16 matrix cores and is
         # not counted as fp32 work).
-        P = B_PER_GPU * NPTS
+        P = b_local * NPTS
         exec_flop = (prof[2] / prof_steps if prof and prof[1] > 0 else 0.0) + 3 * 2.0 * P * K_NN * 64 * 128 \
             + 2.0 * P * NPTS * (2 * (4 + 4) + (64 + 64 + 128))
         step_s = dt / a.steps
         out["executed_tflops"] = exec_flop / step_s / 1e12
         out["executed_mfma_frac"] = out["executed_tflops"] / PEAK_FP32_TFLOPS
         out["reference_flop_equivalent_frac"] = value / n_gpus * FLOP_PER_POINT / 1e12 / PEAK_FP32_TFLOPS
+        if n_gpus == 1 and not a.no_secondary:
+            del model, opt, sync, batch
+            out["secondary"] = secondary_workloads(lib, dev)
         if n_gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -316,9 +316,15 @@ int mlsp_set_gemm_precision(int mode);
 
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP
  * events on its launch stream.  mlsp_profile_end synchronises those events and fills
- * out[4] = {total ms in the kernel, launches, sum of algorithmic 2*M*N*K, 0}.  Not for production steps. */
+ * out[4] = {total ms in the kernel, launches, sum of algorithmic 2*M*N*K, sum of the A + B + C bytes}.  Not for production steps. */
 int mlsp_profile_begin(void);
 int mlsp_profile_end(double* out);
+/* Per kernel class of the same bracket (call after mlsp_profile_end): out [MLSP_PROF_CLASSES][3] = {ms, launches, algorithmic work}.
+ * Classes: 0 GEMM family (FLOP) | 1 kNN C <= 4 incl. its row norms (compulsory bytes: (C + k) * 4 per point) | 2 kNN C = 64 |
+ * 3 kNN C = 128 (FLOP: 2 N C per point) | 4 EdgeConv neighbour gather-reduce (compulsory bytes) | 5 T-Net per-edge stage forward |
+ * 6 its backward (FLOP of the 64 -> 128 per-edge contraction: 2 resp. 4 * E * 64 * 128). */
+#define MLSP_PROF_CLASSES 7
+int mlsp_profile_classes(double* out, int ncls);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,7 @@ SIGNATURES = {
     "mlsp_set_gemm_precision": [_I],
     "mlsp_profile_begin": [],
     "mlsp_profile_end": [_P],
+    "mlsp_profile_classes": [_P, _I],
     "mlsp_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _SZ, _P],
 }
 _RESTYPE = {"mlsp_strerror": _c.c_char_p, "mlsp_workspace_bytes": _SZ}

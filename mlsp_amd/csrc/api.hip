@@ -212,7 +212,13 @@ int mlsp_knn_f32(const float* x, int ldx, int B, int N, int C, int k, int32_t* i
     Workspace w(ws, ws_bytes);
     float* xx = w.take<float>((size_t)B * N);
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
-    CHECK(launch_knn(st, x, ldx, B, N, C, k, idx, xx));
+    {   // bench.py roofline_kernels: C <= 4 priced against HBM (compulsory bytes), C = 64 / 128 against the fp32 matrix peak
+        const int cls = C <= 4 ? MLSP_PROF_KNN_C3 : C == 64 ? MLSP_PROF_KNN_C64 : C == 128 ? MLSP_PROF_KNN_C128 : 0;
+        const int tok = prof_cls_begin(st, cls);
+        const int rc = launch_knn(st, x, ldx, B, N, C, k, idx, xx);
+        prof_cls_end(st, tok, C <= 4 ? (double)B * N * (C + k) * 4.0 : 2.0 * B * N * (double)N * C);
+        if (rc != MLSP_OK) return rc;
+    }
     if (rev_off) CHECK(launch_knn_reverse(st, idx, B, N, k, rev_off, rev_ent));
     return MLSP_OK;
 }
@@ -327,7 +333,12 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
     float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
     CHECK(launch_build_wd(st, W, Cout, C, Wd));
     CHECK(launch_gemm(st, false, true, P, 2 * Cout, C, x, ldx, Wd, C, uv, 2 * Cout, nullptr, nullptr, 0, slab, sf));
-    CHECK(launch_edge_reduce(st, uv, idx, gamma, P, N, Cout, k, msel, argsel, s1, part, &nparts));
+    {   // the neighbour gather + max/min + BN sums: compulsory bytes = u half + indices in, msel + s1 + arg slot out
+        const int tok = prof_cls_begin(st, MLSP_PROF_EDGE_REDUCE);
+        const int rc = launch_edge_reduce(st, uv, idx, gamma, P, N, Cout, k, msel, argsel, s1, part, &nparts);
+        prof_cls_end(st, tok, (double)P * (Cout * 4.0 + k * 4.0 + Cout * 9.0));
+        if (rc != MLSP_OK) return rc;
+    }
     if (training) {
         CHECK(launch_bn_finalize(st, part, nparts, (double)P * k, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale,
                                  shift, mean, invstd));
@@ -407,7 +418,12 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
         CHECK(launch_bn_eval_prepare(st, C1, gamma1, beta1, run_mean1, run_var1, eps, bn1_save, bn1_save + C1, bn1_save + 2 * C1,
                                      bn1_save + 3 * C1));
     }
-    CHECK(launch_tnet_edge_fwd(st, uv, idx, bn1_save, W2, gamma2, P, N, k, slope, zsel, argsel, part));
+    {
+        const int tok = prof_cls_begin(st, MLSP_PROF_TNET_FWD);
+        const int rc = launch_tnet_edge_fwd(st, uv, idx, bn1_save, W2, gamma2, P, N, k, slope, zsel, argsel, part);
+        prof_cls_end(st, tok, 2.0 * P * (double)k * C1 * C2);                  // the per-edge 64 -> 128 contraction
+        if (rc != MLSP_OK) return rc;
+    }
     if (training) {
         CHECK(launch_bn_finalize(st, part, np2, (double)P * k, C2, gamma2, beta2, run_mean2, run_var2, momentum, eps, bn2_save,
                                  bn2_save + C2, bn2_save + 2 * C2, bn2_save + 3 * C2));
@@ -467,7 +483,12 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
     CHECK(launch_bn_bwd_finalize(st, part, npr, (double)E, C2, dgamma2, dbeta2, mean_dz, mean_dzy));
     CHECK(launch_tnet_bwd_g(st, dOut, out, bn2_save, training ? mean_dz : nullptr, mean_dzy, P, slope, g, coef));
     int nparts = 0;
-    CHECK(launch_tnet_edge_bwd(st, uv, idx, bn1_save, W2, bn2_save, g, argsel, coef, P, N, k, slope, dhp, dW2part, part, dW2, &nparts));
+    {
+        const int tok = prof_cls_begin(st, MLSP_PROF_TNET_BWD);
+        const int rc = launch_tnet_edge_bwd(st, uv, idx, bn1_save, W2, bn2_save, g, argsel, coef, P, N, k, slope, dhp, dW2part, part, dW2, &nparts);
+        prof_cls_end(st, tok, 4.0 * P * (double)k * C1 * C2);                  // dgrad + wgrad of that contraction
+        if (rc != MLSP_OK) return rc;
+    }
     CHECK(launch_bn_bwd_finalize(st, part, nparts, (double)E, C1, dgamma1, dbeta1, m1, m2));
     if (!dx && C <= 4) {
         // the input cloud needs no gradient (DGCNN's T-Net reads the raw coordinates): dW1 straight from one sequential pass over dh'

@@ -902,24 +902,51 @@ static struct GemmProf {
     bool on = false;
     std::vector<hipEvent_t> ev;     // pairs
     size_t used = 0;
-    double flop = 0.0;
+    double flop = 0.0, bytes = 0.0;   // algorithmic: 2*M*N*K and the A + B + C bytes in their storage types
     struct Rec { int M, N, K, ta, tb, ns, bm, fused; };
     std::vector<Rec> rec;           // one per pair, for the MLSP_PROF_DUMP listing
 } g_prof;
 #define PROF_MAX_PAIRS 4096
 
+// ---- the same for the other kernel families the bench line prices (kNN per channel count, LDS gather-reduce, T-Net stages):
+// prof_cls_begin / prof_cls_end (common.h) bracket a launch with two events on its stream, `work` = its algorithmic bytes or FLOP.
+static struct ClsProf {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cls;
+    std::vector<double> work;
+    size_t used = 0;
+} g_cls;
+int prof_cls_begin(hipStream_t st, int cls) {
+    if (!g_prof.on || g_cls.used >= PROF_MAX_PAIRS || cls <= 0 || cls >= MLSP_PROF_NCLS || g_cls.ev.empty()) return -1;
+    const int tok = (int)g_cls.used++;
+    g_cls.cls[tok] = cls; g_cls.work[tok] = 0.0;
+    (void)hipEventRecord(g_cls.ev[2 * tok], st);
+    return tok;
+}
+void prof_cls_end(hipStream_t st, int tok, double work) {
+    if (tok < 0) return;
+    (void)hipEventRecord(g_cls.ev[2 * tok + 1], st);
+    g_cls.work[tok] = work;
+}
+
 extern "C" int mlsp_profile_begin(void) {
+    if (g_cls.ev.empty()) {
+        g_cls.ev.resize(2 * PROF_MAX_PAIRS); g_cls.cls.resize(PROF_MAX_PAIRS); g_cls.work.resize(PROF_MAX_PAIRS);
+        for (auto& e : g_cls.ev)
+            if (hipEventCreate(&e) != hipSuccess) { g_cls.ev.clear(); return MLSP_ERR_UNSUPPORTED; }
+    }
+    g_cls.used = 0;
     if (g_prof.ev.empty()) {
         g_prof.ev.resize(2 * PROF_MAX_PAIRS);
         g_prof.rec.resize(PROF_MAX_PAIRS);
         for (auto& e : g_prof.ev)
             if (hipEventCreate(&e) != hipSuccess) { g_prof.ev.clear(); return MLSP_ERR_UNSUPPORTED; }
     }
-    g_prof.used = 0; g_prof.flop = 0.0; g_prof.on = true;
+    g_prof.used = 0; g_prof.flop = 0.0; g_prof.bytes = 0.0; g_prof.on = true;
     return MLSP_OK;
 }
 
-// out[0] = total milliseconds inside gemm_f32_kernel, out[1] = launches, out[2] = sum of 2*M*N*K, out[3] = dropped launches
+// out[0] = total milliseconds inside gemm_f32_kernel, out[1] = launches, out[2] = sum of 2*M*N*K, out[3] = sum of the A + B + C bytes
 extern "C" int mlsp_profile_end(double* out) {
     g_prof.on = false;
     double ms = 0.0;
@@ -935,7 +962,28 @@ extern "C" int mlsp_profile_end(double* out) {
                     r.M, r.N, r.K, r.ns, r.bm, r.fused, t * 1e3, 2.0 * r.M * r.N * r.K / (t * 1e-3) / 1e12);
         }
     }
-    if (out) { out[0] = ms; out[1] = (double)g_prof.used; out[2] = g_prof.flop; out[3] = 0.0; }
+    if (out) { out[0] = ms; out[1] = (double)g_prof.used; out[2] = g_prof.flop; out[3] = g_prof.bytes; }
+    return MLSP_OK;
+}
+
+// out [MLSP_PROF_NCLS][3] = {milliseconds, launches, algorithmic work} per kernel class of the last begin/end bracket (class 0 = the
+// GEMM family, same figures as mlsp_profile_end).  Call after mlsp_profile_end.
+extern "C" int mlsp_profile_classes(double* out, int ncls) {
+    if (!out || ncls < MLSP_PROF_NCLS || g_prof.on) return MLSP_ERR_ARG;
+    for (int i = 0; i < 3 * ncls; ++i) out[i] = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
+        out[0] += t; out[1] += 1.0;
+    }
+    out[2] = g_prof.flop;
+    for (size_t i = 0; i < g_cls.used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_cls.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
+        if (hipEventElapsedTime(&t, g_cls.ev[2 * i], g_cls.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
+        const int c = g_cls.cls[i];
+        out[3 * c] += t; out[3 * c + 1] += 1.0; out[3 * c + 2] += g_cls.work[i];
+    }
     return MLSP_OK;
 }
 
@@ -1051,6 +1099,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0)};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;
+        g_prof.bytes += 4.0 * ((double)M * K + (double)K * N + (C ? (double)M * N : 0.0));
     }
     if (ns > 1) launch_splitk_reduce_any(st, slab, C, M, N, ldc, ns, bias, gbias, rows_per_group);
     return mlsp_launch_status();
@@ -1131,6 +1180,7 @@ int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const 
         g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + 4};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;
+        g_prof.bytes += (a_bf16 ? 2.0 : 4.0) * M * K + (b_bf16 ? 2.0 : 4.0) * K * N + (c_bf16 ? 2.0 : 4.0) * M * N;
     }
     if (ns > 1) launch_splitk_reduce_any(st, slab, (float*)C, M, N, ldc, ns, bias, gbias, rows_per_group);
     return mlsp_launch_status();

@@ -15,7 +15,7 @@ import torch.distributed as dist
 class FlatGradSync:
     """One flat fp32 bucket for every trainable gradient, all-reduced once per optimizer step.
 
-        sync = FlatGradSync(model)            # after model.to(device)
+        sync = FlatGradSync(model)            # after model.to(device); on every rank (it may create a host-side group)
         opt = sync.wrap(torch.optim.Adam(model.parameters(), ...))
         ...  loss.backward() (any number of times) ...
         opt.step()                            # step pre-hook: flatten -> ONE all-reduce(sum) -> /world_size; then the step
@@ -24,12 +24,22 @@ class FlatGradSync:
     Gradients are NOT pre-homed in the bucket during backward: autograd would then issue one `grad += new`
     kernel per parameter (77 launches, ~0.4 ms per step on MI355X).  Instead the gradients autograd produced
     are packed into the bucket by one multi-tensor copy right before the collective, and `.grad` is re-pointed
-    at the bucket views for the optimizer.  With world_size == 1 nothing is copied at all.
+    at the bucket views for the optimizer.  With world_size == 1 nothing is copied at all (unless `force=True`,
+    which runs the whole pack -> collective -> divide path on one rank: tests/test_gpu_ddp.py).
+
+    Which parameters step.  A parameter whose gradient is None is skipped by the optimizer (a head that did not run:
+    DGCNN.Rec_scan in the default modes) -- exactly what the reference's single process does.  Across ranks that set must be
+    the SAME or the replicas drift apart (one rank applies the averaged gradient, the other nothing), so before packing
+    the ranks exchange a presence bitmap (one byte per parameter, MAX-reduced) on a HOST-side group: a parameter that
+    has a gradient on ANY rank gets a (zero-filled) gradient on every rank.  The exchange runs on the CPU (gloo), not
+    on the GPU stream: the host is ~2 ms ahead of the device at that point, so it costs no device time and no
+    stream synchronisation.
     """
 
-    def __init__(self, model, process_group=None):
+    def __init__(self, model, process_group=None, force=False):
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.group = process_group
+        self.force = bool(force)
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
@@ -38,17 +48,32 @@ class FlatGradSync:
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.collectives = 0                  # device all-reduces issued so far (tests count them)
+        self.host_group = None
+        if self.world_size > 1:
+            backend = dist.get_backend(self.group)
+            # the presence bitmap travels host-side: the default group itself when it already is a CPU one
+            self.host_group = self.group if backend == "gloo" else dist.new_group(backend="gloo")
 
     @property
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def pack(self):
+    def presence(self):
+        """[n_params] bool list: does ANY rank hold a gradient for the parameter this step (host-side MAX-reduce)."""
+        local = torch.tensor([p.grad is not None for p in self.params], dtype=torch.uint8)
+        if self.world_size > 1:
+            dist.all_reduce(local, op=dist.ReduceOp.MAX, group=self.host_group)
+        return local.bool().tolist()
+
+    def pack(self, present=None):
         """Copy the present gradients into the bucket (absent ones count as zero) and alias .grad to the bucket.
         Idempotent: a gradient that already lives in its bucket view is left alone, and only the views of ABSENT
-        parameters are zeroed (a head that did not run this step, e.g. DGCNN.Rec_scan in the default modes)."""
+        parameters are zeroed (a head that did not run this step, e.g. DGCNN.Rec_scan in the default modes).
+        `present` (from presence()): parameters some OTHER rank has a gradient for get their zeroed view as .grad here,
+        so that every rank hands its optimizer the same set of parameters."""
         src, dst, absent = [], [], []
-        for v, p in zip(self.views, self.params):
+        for i, (v, p) in enumerate(zip(self.views, self.params)):
             if p.grad is None:
                 absent.append(v)
             elif p.grad.data_ptr() != v.data_ptr():
@@ -58,16 +83,18 @@ class FlatGradSync:
             torch._foreach_zero_(absent)
         if src:
             torch._foreach_copy_(dst, src)
-        for v, p in zip(self.views, self.params):
-            if p.grad is not None:
+        for i, (v, p) in enumerate(zip(self.views, self.params)):
+            if p.grad is not None or (present is not None and present[i]):
                 p.grad = v
         return self.flat
 
     def allreduce(self):
         ws = self.world_size
-        if ws > 1:
-            self.pack()
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if ws > 1 or self.force:
+            self.pack(self.presence())
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self.collectives += 1
             self.flat.div_(ws)
         return self.flat
 
@@ -79,7 +106,8 @@ class FlatGradSync:
         """Install the exchange on `optimizer` itself (a step pre-hook) and return it: the object stays a real
         torch.optim.Optimizer, so `CosineAnnealingLR(opt, ...)` (PointDA/trainer.py:260), `opt.state_dict()` and
         `opt.param_groups` keep working.  `opt.zero_grad()` (set_to_none=True, torch's default) drops the bucket views
-        again so that autograd assigns fresh gradients instead of accumulating into the bucket."""
+        again so that autograd assigns fresh gradients instead of accumulating into the bucket; with set_to_none=False the
+        gradients stay in their (zeroed) views and later backwards accumulate there -- correct, one add per parameter slower."""
         if not getattr(optimizer, "_mlsp_flat_sync", None):
             optimizer.register_step_pre_hook(lambda *_a, **_k: (self.allreduce(), None)[1])
             optimizer._mlsp_flat_sync = self

@@ -199,15 +199,20 @@ class SharedInputGrad:
     features): the first consumer to run backward allocates the input-gradient buffer, the others add into it through the
     beta = 1 epilogue of their dgrad GEMM and return the same tensor; `fan_out` then passes it upstream once.  Replaces three
     67 MB element-wise adds of the autograd engine per step."""
-    __slots__ = ("buf",)
+    __slots__ = ("buf", "task")
 
     def __init__(self):
         self.buf = None
+        self.task = None
 
     def claim(self, shape, device):
-        """-> (buffer, accumulate flag)"""
-        if self.buf is None:
+        """-> (buffer, accumulate flag).  The buffer belongs to ONE backward pass (autograd graph task): a buffer left behind by
+        a pass that never reached the fan_out node (torch.autograd.grad w.r.t. head parameters only, an exception mid-backward)
+        is dropped instead of being accumulated into."""
+        task = torch._C._current_graph_task_id()
+        if self.buf is None or self.task != task:
             self.buf = torch.empty(shape, dtype=torch.float32, device=device)
+            self.task = task
             return self.buf, 0
         return self.buf, 1
 
@@ -223,6 +228,8 @@ class _FanOut(Function):
     @once_differentiable
     def backward(ctx, *grads):
         acc, total, seen = ctx.acc, None, False
+        if acc.task != torch._C._current_graph_task_id():
+            acc.buf = None                      # stale: not written by this pass
         for g in grads:
             if g is None:
                 continue
@@ -231,7 +238,7 @@ class _FanOut(Function):
                     continue                    # the shared buffer already holds the sum of every consumer that used it
                 seen = True
             total = g if total is None else total + g
-        acc.buf = None
+        acc.buf = acc.task = None
         return total, None, None
 
 
@@ -560,6 +567,12 @@ def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, 
     `grad_accum`: the SharedInputGrad of a fan_out(X, n) whose alias this X is.  `chain=True`: the only consumer of the output is
     another pointmlp BN layer, so under activation_storage("bf16") Y / Z may be stored as bf16."""
     seed = _next_seed() if (training and p_drop > 0) else 0
+    if (not isinstance(X, DeferredAct) and X.dtype == torch.bfloat16 and not (
+            gamma is not None and X.dim() == 2 and X.stride(1) == 1 and
+            _lib.load().mlsp_pointmlp_mx_supported(X.shape[0], X.shape[1], W.shape[0], X.stride(0), 1, int(training)))):
+        # the producer stored its output as bf16 (its own shape allowed it) but THIS layer's shape is outside the bf16-storage
+        # kernels (e.g. a consumer whose GEMM splits K): widen once and run the fp32 layer; autograd narrows the gradient again
+        X = X.float()
     out_bf16 = bool(chain) and activation_storage.current == "bf16" and gamma is not None
     in_bn = in_cfg = None
     if isinstance(X, DeferredAct):

@@ -86,6 +86,20 @@ def flushing_forward(fn):
     return wrapper
 
 
+class _ZeroGradTie(torch.autograd.Function):
+    """y, with parameter `b` attached to the graph at an exactly-zero gradient: no elementwise pass, and y stays the tensor the
+    caller handed in (a column slice of its concatenation buffer keeps being that slice)."""
+
+    @staticmethod
+    def forward(ctx, y, b):
+        ctx.bshape, ctx.bdev = b.shape, b.device
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, torch.zeros(ctx.bshape, dtype=g.dtype, device=ctx.bdev)
+
+
 class conv_2d(nn.Module):
     """model_utils.py:45-63: 1x1 Conv2d + BatchNorm2d + ReLU | LeakyReLU(0.2)."""
 
@@ -136,7 +150,7 @@ class conv_2d(nn.Module):
                             eps=bn.eps, out=out)
             with torch.no_grad():
                 rm.add_(bn.momentum * b)
-            return y + 0.0 * b.sum()               # keeps bias in the graph with the zero gradient the reference gives it
+            return _ZeroGradTie.apply(y, b)        # keeps bias in the graph with the zero gradient the reference gives it
         return Fh.edgeconv(xp, graph, W, bn.weight, bn.bias, rm - b.detach(), rv, False, act=self.act, slope=0.2,
                            momentum=bn.momentum, eps=bn.eps, out=out)
 

@@ -296,7 +296,7 @@ class PointNetSetAbstraction(nn.Module):
             X = _fold_first_layer(xyz, new_xyz, points, idx, c0.weight.view(c0.out_channels, c0.in_channels), c0, self.mlp_bns[0],
                                   self.training)
             out = _sa_mlp(X, self.mlp_convs[1:], self.mlp_bns[1:], self.training, max_over=ns if self.fuse_max else 0)
-            return new_xyz, (out if self.fuse_max else Fh.segmax(out, ns)).view(B, S, -1)
+            return new_xyz, (out if self.fuse_max else _neigh_max(out, ns)).view(B, S, -1)
         else:
             new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, knn=self.knn,
                                                    fps_start=self.fps_start)
@@ -315,7 +315,7 @@ class PointNetSetAbstraction(nn.Module):
             out = _sa_mlp(X, self.mlp_convs, self.mlp_bns, self.training, first_weight=first_weight, max_over=ns)
         else:
             X = _sa_mlp(X, self.mlp_convs, self.mlp_bns, self.training, first_weight=first_weight)
-            out = Fh.colmax(X, B, ns) if self.group_all else Fh.segmax(X, ns)  # max over the neighbourhood
+            out = Fh.colmax(X, B, ns) if self.group_all else _neigh_max(X, ns)  # max over the neighbourhood
         return new_xyz, out.view(B, S, -1)
 
 
@@ -332,7 +332,12 @@ def _sa_mlp(X, convs, bns, training, first_weight=None, max_over=0):
                                       training=training, act=Fh.ACT_RELU, momentum=bn.momentum, eps=bn.eps)
         X = Fh.pointmlp(X, W, bias=conv.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv, training=training,
                         act=Fh.ACT_RELU, momentum=bn.momentum, eps=bn.eps)
-    return Fh.segmax(X, max_over) if max_over else X
+    return _neigh_max(X, max_over) if max_over else X
+
+
+def _neigh_max(X, k):
+    """max over every k consecutive rows: the uint8-slot segmax kernel up to k = 255, the int32-row column max beyond."""
+    return Fh.segmax(X, k) if k <= 255 else Fh.colmax(X, X.shape[0] // k, k)
 
 
 class PointNetSetAbstractionMsg(nn.Module):

@@ -71,6 +71,77 @@ def test_flat_grad_allreduce_world2():
         assert all(r[1:]), r
 
 
+def _worker_divergent(rank, world, port, q):
+    """Rank 1 does not run one head this step (a data-dependent branch: an empty target batch): rank 0 has gradients for it,
+    rank 1 has None.  Every rank must still hand its optimizer the same parameters, or Adam moves the head on rank 0 only."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mlsp_amd.ddp import FlatGradSync
+    torch.manual_seed(0)
+    model = torch.nn.ModuleDict({"enc": torch.nn.Linear(8, 8), "head_a": torch.nn.Linear(8, 4), "head_b": torch.nn.Linear(8, 4),
+                                 "never": torch.nn.Linear(8, 4)})
+    sync = FlatGradSync(model)
+    opt = sync.wrap(torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-5))
+    g = torch.Generator().manual_seed(200 + rank)
+    ok = True
+    for step in range(3):
+        x = torch.randn(6, 8, generator=g)
+        opt.zero_grad()
+        h = torch.relu(model["enc"](x))
+        loss = model["head_a"](h).pow(2).mean()
+        if rank == 0 or step == 2:                           # steps 0, 1: only rank 0 runs head_b; step 2: both do
+            loss = loss + model["head_b"](h).pow(2).mean()
+        loss.backward()
+        had_b = model["head_b"].weight.grad is not None
+        opt.step()
+        # head_b steps on BOTH ranks (rank 1 contributes zeros to the average); `never` is skipped on both
+        ok = ok and model["head_b"].weight.grad is not None and model["never"].weight.grad is None
+        ok = ok and (had_b or rank == 1)
+        w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        ok = ok and all(torch.equal(ws[0], t) for t in ws)   # replicas identical after every step
+    q.put((rank, ok, sync.collectives == 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_divergent_absent_gradients_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_divergent, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
+
+
+def test_force_runs_the_exchange_on_one_rank():
+    """force=True: pack -> (collective when a group exists) -> divide also at world size 1, bit-identical to the plain step."""
+    from mlsp_amd.ddp import FlatGradSync
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(5, 3), torch.nn.Linear(5, 3)
+    b.load_state_dict(a.state_dict())
+    sync = FlatGradSync(b, force=True)
+    oa = torch.optim.Adam(a.parameters(), lr=1e-2)
+    ob = sync.wrap(torch.optim.Adam(b.parameters(), lr=1e-2))
+    x = torch.randn(7, 5)
+    for _ in range(3):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            m(x).pow(2).mean().backward()
+            m(2 * x).pow(2).mean().backward()
+            o.step()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+
+
 def test_single_process_is_identity():
     from mlsp_amd.ddp import FlatGradSync
     m = torch.nn.Linear(3, 2)

@@ -285,6 +285,39 @@ def test_pointmlp_bf16_activation_storage(dev, M, C0, training):
     assert max(errs) < 3e-2, errs                                      # gradient tensors themselves are stored / multiplied in bf16
 
 
+@pytest.mark.parametrize("M", [8192, 16384, 32768])
+def test_bf16_storage_producer_consumer_shapes_disagree(dev, M):
+    """under activation_storage("bf16") a chained producer decides its output type from its OWN shape; at M = 8192 / 16384
+    the consumer's GEMM splits K and is outside the bf16-storage kernels.  The stack must run (the consumer widens its input once)
+    and agree with the fp32-storage stack to bf16 accuracy, forward and backward."""
+    Fh = _fh()
+    dims = [(512, 256), (256, 256), (256, 128)]
+    X = _rand((M, 512), 1).to(dev)
+    Ws = [(_rand((co, ci), 10 + i, 1.0 / ci ** 0.5)).to(dev) for i, (ci, co) in enumerate(dims)]
+    gs = [(1.0 + 0.1 * _rand((co,), 20 + i)).to(dev) for i, (_, co) in enumerate(dims)]
+    bs = [(0.1 * _rand((co,), 30 + i)).to(dev) for i, (_, co) in enumerate(dims)]
+
+    def run(store, prec):
+        x = X.clone().requires_grad_(True)
+        ws = [w.clone().requires_grad_(True) for w in Ws]
+        with Fh.gemm_precision(prec), Fh.activation_storage(store):
+            h = x
+            for i in range(3):
+                h = Fh.pointmlp(h, ws[i], gamma=gs[i], beta=bs[i], training=True, act=Fh.ACT_RELU, chain=(i < 2))
+            h.float().square().mean().backward()
+        return h.float().detach(), x.grad, [w.grad for w in ws]
+
+    o32, gx32, gw32 = run("fp32", "fp32")
+    o16, gx16, gw16 = run("bf16", "bf16")
+
+    def rel(a, b):
+        return ((a - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel(o16, o32) < 3e-2, rel(o16, o32)
+    assert rel(gx16, gx32) < 0.15, rel(gx16, gx32)       # (a rounded Y flips ReLU masks at the kink: see the emulation test above)
+    for a, b in zip(gw16, gw32):
+        assert rel(a, b) < 0.15, rel(a, b)
+
+
 # ----------------------------------------------------------------------------- pointmlp (Linear + BN + act)
 def _torch_pointmlp(X, W, bias, gbias, rpg, gamma, beta, rm, rv, training, act):
     Y = X @ W.t()
