@@ -12,16 +12,18 @@ from . import functional as Fh
 from .model_utils import transform_net, conv_2d, fc_layer, classifier, _bn_buffers, flushing_forward
 
 K = 20   # Models.py:13
+MERGE_HEAD_FIRST_LAYERS = True   # merged_first_layers(): the heads' first layers as one wide layer (tests switch it off to compare)
 
 
-def _bn_layer(X, conv, bn, training, act, p_drop=0.0, gbias=None, rows_per_group=0, W=None, grad_accum=None, chain=False):
+def _bn_layer(X, conv, bn, training, act, p_drop=0.0, gbias=None, rows_per_group=0, W=None, grad_accum=None, chain=False,
+              grad_cols=None):
     """Conv1d(k=1, bias=False) + BatchNorm1d + act (+dropout) on a [rows, Cin] matrix."""
     rm, rv = _bn_buffers(bn, training)
     if W is None:
         W = conv.weight.view(conv.out_channels, conv.in_channels)
     return Fh.pointmlp(X, W, bias=conv.bias, gbias=gbias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
                        rows_per_group=rows_per_group, training=training, act=act, slope=0.2, p_drop=p_drop,
-                       momentum=bn.momentum, eps=bn.eps, grad_accum=grad_accum, chain=chain)
+                       momentum=bn.momentum, eps=bn.eps, grad_accum=grad_accum, chain=chain, grad_cols=grad_cols)
 
 
 def _first_head_layer(head, x_cat, x5, N, act, p_drop, grad_accum=None):
@@ -33,6 +35,51 @@ def _first_head_layer(head, x_cat, x5, N, act, p_drop, grad_accum=None):
     gb = Fh.pointmlp(x5, W5, training=head.training)                   # [B, Cout]
     return _bn_layer(x_cat, head.conv1, head.bn1, head.training, act, p_drop=p_drop, gbias=gb, rows_per_group=N,
                      W=Wc, grad_accum=grad_accum, chain=True)
+
+
+def merged_first_layers(heads, x_cat, x5, N, grad_accum=None):
+    """conv1 + bn1 + ReLU + dropout of SEVERAL heads on the same input (Models.py:156-160 feeds every head the same concatenation;
+    :192, :226, :273 are the three first layers) as ONE layer of sum(of1) output channels: one wide GEMM over x_cat instead of one
+    per head, one per-cloud-bias product with x5, one BatchNorm pass over all the channels (BatchNorm is per channel, so running the
+    three BatchNorm1d side by side is exact), and in backward ONE K = sum(of1) dgrad and one wgrad -- x_cat and its gradient are read
+    and written once per step instead of once per head.  The heads' parameters keep their identity (state_dict keys, optimizer
+    entries): their storage is re-homed back to back (functional.rehome_adjacent) so that the merged operands are views.
+    -> (h1 [P, sum of1] column slices per head, SharedColumnGrad for the consumers' `grad_cols`)."""
+    mods = list(heads)
+    training, p_drop = mods[0].training, mods[0].dp1.p
+    Cc = x_cat.shape[1]
+    # (the replicas nn.DataParallel builds per forward share their buffers with the wrapped module: never re-point those)
+    own = not any(getattr(m, "_is_replica", False) for m in mods)
+    W = Fh.row_blocks([m.conv1.weight for m in mods], rehome=own)               # [sum of1, Cc + 1024, 1]
+    W = W.view(W.shape[0], W.shape[1])
+    Wc, W5 = Fh.split_columns(W, Cc)
+    has_bias = mods[0].conv1.bias is not None
+    bias = Fh.row_blocks([m.conv1.bias for m in mods], rehome=own) if has_bias else None
+    gamma = Fh.row_blocks([m.bn1.weight for m in mods], rehome=own)
+    beta = Fh.row_blocks([m.bn1.bias for m in mods], rehome=own)
+    bufs = [_bn_buffers(m.bn1, training) for m in mods]
+    rm, rv = Fh.merged_buffers([b[0] for b in bufs], rehome=own), Fh.merged_buffers([b[1] for b in bufs], rehome=own)
+    gb = Fh.pointmlp(x5, W5, training=training)                                  # [B, sum of1]: the x5 half as a per-cloud bias
+    bn = mods[0].bn1
+    h1 = Fh.pointmlp(x_cat, Wc, bias=bias, gbias=gb, gamma=gamma, beta=beta, run_mean=rm.tensor, run_var=rv.tensor, rows_per_group=N,
+                     training=training, act=Fh.ACT_RELU, slope=0.2, p_drop=p_drop, momentum=bn.momentum, eps=bn.eps,
+                     grad_accum=grad_accum, chain=True)
+    if training:
+        rm.writeback()
+        rv.writeback()
+    return Fh.split_columns_shared(h1, [m.conv1.out_channels for m in mods])
+
+
+def can_merge_first_layers(heads):
+    """distinct heads, same input width / bias setting / dropout rate / BatchNorm hyper-parameters / mode; plain (non-deferred)
+    activations"""
+    mods = list(heads)
+    if not MERGE_HEAD_FIRST_LAYERS or len(mods) < 2 or len({id(m) for m in mods}) != len(mods) or Fh._DEFER_CHAINS:
+        return False
+    m0 = mods[0]
+    return all(m.conv1.in_channels == m0.conv1.in_channels and (m.conv1.bias is None) == (m0.conv1.bias is None) and
+               m.dp1.p == m0.dp1.p and m.training == m0.training and m.bn1.momentum == m0.bn1.momentum and m.bn1.eps == m0.bn1.eps and
+               m.conv1.out_channels % 128 == 0 for m in mods)
 
 
 class _RegionHead(nn.Module):
@@ -52,8 +99,8 @@ class _RegionHead(nn.Module):
         self.conv3 = nn.Conv1d(self.of2, self.of3, kernel_size=1, bias=False)
         self.conv4 = nn.Conv1d(self.of3, 3, kernel_size=1, bias=False)
 
-    def _tail(self, h, B, N):
-        h = _bn_layer(h, self.conv2, self.bn2, self.training, Fh.ACT_RELU, p_drop=self.dp2.p, chain=True)
+    def _tail(self, h, B, N, grad_cols=None):
+        h = _bn_layer(h, self.conv2, self.bn2, self.training, Fh.ACT_RELU, p_drop=self.dp2.p, chain=True, grad_cols=grad_cols)
         h = _bn_layer(h, self.conv3, self.bn3, self.training, Fh.ACT_RELU)
         h = Fh.pointmlp(h, self.conv4.weight.view(3, self.of3), training=self.training)
         return h.view(B, N, 3)                                       # == x.permute(0,2,1) of the reference
@@ -61,6 +108,10 @@ class _RegionHead(nn.Module):
     def rows(self, x_cat, x5, B, N, grad_accum=None):
         h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p, grad_accum)
         return self._tail(h, B, N)
+
+    def rows_from_first(self, h1, B, N, grad_cols=None):
+        """the layers after conv1/bn1/dp1, on this head's column slice of merged_first_layers()"""
+        return self._tail(h1, B, N, grad_cols=grad_cols)
 
     @flushing_forward
     def forward(self, x):
@@ -103,8 +154,8 @@ class Density_prediction(nn.Module):
                 self.fc2.weight[0, i] = args.pergroup * i               # Models.py:267-270
         self.fc2.weight.requires_grad = False
 
-    def _tail(self, h):
-        h = self.mlp1(h, p_drop=self.dp1.p, chain=True)                  # dp1 applied twice (:273,:278)
+    def _tail(self, h, grad_cols=None):
+        h = self.mlp1(h, p_drop=self.dp1.p, chain=True, grad_cols=grad_cols)   # dp1 applied twice (:273,:278)
         h = self.mlp2(h, p_drop=self.dp2.p)
         logits = Fh.pointmlp(h, self.mlp3.weight, bias=self.mlp3.bias, training=self.training)
         return Fh.density_tail(logits, self.fc2.weight)
@@ -112,6 +163,9 @@ class Density_prediction(nn.Module):
     def rows(self, x_cat, x5, B, N, grad_accum=None):
         h = _first_head_layer(self, x_cat, x5, N, Fh.ACT_RELU, self.dp1.p, grad_accum)
         return self._tail(h)
+
+    def rows_from_first(self, h1, B, N, grad_cols=None):
+        return self._tail(h1, grad_cols=grad_cols)
 
     @flushing_forward
     def forward(self, x):
@@ -226,7 +280,8 @@ class DGCNN(nn.Module):
                 heads.append(("density", self.Density_cls))
             if activate_density_normal_ondef:
                 heads += [("DefRec", self.DefRec), ("density", self.Density_cls), ("Normal", self.Norm_pred)]
-        aliases, acc = Fh.fan_out(x_cat, 1 + len(heads))
+        merge = can_merge_first_layers([h for _, h in heads])
+        aliases, acc = Fh.fan_out(x_cat, 2 if merge else 1 + len(heads))
         rm5, rv5 = _bn_buffers(self.bn5, self.training)                             # conv5+bn5+LReLU+max (Models.py:132-136)
         x5 = Fh.pointmlp_colmax(aliases[0], self.conv5.weight.view(1024, -1), self.bn5.weight, self.bn5.bias, rm5, rv5, B, N,
                                 training=self.training, act=Fh.ACT_LRELU, slope=0.2, momentum=self.bn5.momentum,
@@ -235,6 +290,18 @@ class DGCNN(nn.Module):
         logits["cls"] = self.C(x5)
         if visualization:
             return x5
+        if merge:
+            # every head's first layer reads the same [x_cat | x5]: ONE wide layer, then each head continues on its column slice
+            slices, cols = merged_first_layers([h for _, h in heads], aliases[1], x5, N, grad_accum=acc)
+            col = 0
+            for (key, head), h1 in zip(heads, slices):
+                out = head.rows_from_first(h1, B, N, grad_cols=(cols, col))
+                col += h1.shape[1]
+                if key == "density":
+                    logits['density'], logits['density_mse'] = out
+                else:
+                    logits[key] = out
+            return logits
         for (key, head), xa in zip(heads, aliases[1:]):
             if key == "density":
                 logits['density'], logits['density_mse'] = head.rows(xa, x5, B, N, grad_accum=acc)

@@ -289,6 +289,150 @@ def split_columns(W, c):
     return _SplitColumns.apply(W, c)
 
 
+class _RowBlocks(Function):
+    """[sum n_i, ...] matrix made of the row blocks `parts` (parameters of several modules that one merged layer uses as ONE operand).
+    When the blocks already lie back to back in one storage (rehome_adjacent) the result is a zero-copy view of it; otherwise one
+    torch.cat.  Backward hands every part its row slice of the gradient as a view (no split copies)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ctx.rows = [p.shape[0] for p in parts]
+        if _adjacent(parts):
+            p0 = parts[0]
+            shape = (sum(ctx.rows),) + tuple(p0.shape[1:])
+            return p0.new_empty(0).set_(p0.untyped_storage(), p0.storage_offset(), shape, p0.stride())
+        return torch.cat([p.detach() for p in parts], dim=0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        outs, o = [], 0
+        for n in ctx.rows:
+            outs.append(g[o:o + n])
+            o += n
+        return tuple(outs)
+
+
+def _adjacent(parts):
+    """are the (contiguous, same dtype / device) tensors laid out back to back in ONE storage, in this order?"""
+    p0 = parts[0]
+    if not p0.is_contiguous():
+        return False
+    base, end = p0.untyped_storage().data_ptr(), p0.data_ptr() + p0.numel() * p0.element_size()
+    for p in parts[1:]:
+        if (not p.is_contiguous() or p.dtype != p0.dtype or p.device != p0.device or p.untyped_storage().data_ptr() != base
+                or p.data_ptr() != end or tuple(p.shape[1:]) != tuple(p0.shape[1:])):
+            return False
+        end = p.data_ptr() + p.numel() * p.element_size()
+    return True
+
+
+def rehome_adjacent(parts):
+    """Move the storage of module parameters / buffers `parts` into ONE buffer, back to back (each keeps its identity, shape and
+    values: `.data` is re-pointed at a view), so that a merged layer reads them as one operand without a concatenation per step.
+    Only for genuine leaves (nn.Parameter or plain buffers outside any autograd graph); idempotent; survives optimizer updates
+    (in place) and load_state_dict (copy_); after model.to() / deepcopy / DataParallel replication the tensors may be separate again
+    and row_blocks() falls back to torch.cat (or this is called again)."""
+    if _adjacent(parts):
+        return True
+    p0 = parts[0]
+    for p in parts:
+        if (p.grad_fn is not None or p.dtype != p0.dtype or p.device != p0.device or tuple(p.shape[1:]) != tuple(p0.shape[1:])
+                or (p.requires_grad and not isinstance(p, torch.nn.Parameter))):
+            return False
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(p.shape[0], -1) for p in parts], dim=0).contiguous()
+        o = 0
+        for p in parts:
+            p.data = flat[o:o + p.shape[0]].view(p.shape)
+            o += p.shape[0]
+    return _adjacent(parts)
+
+
+def row_blocks(parts, rehome=True):
+    """One operand out of the row blocks `parts` (see _RowBlocks); `rehome`: make them adjacent first when they are leaves."""
+    parts = list(parts)
+    if len(parts) == 1:
+        return parts[0]
+    if rehome:
+        rehome_adjacent(parts)
+    return _RowBlocks.apply(*parts)
+
+
+class merged_buffers:
+    """Running statistics of several BatchNorm modules as ONE vector for a merged layer.  `.tensor` is a zero-copy view when the
+    buffers are (or could be made) adjacent, else a concatenated copy that `.writeback()` scatters back after the kernel updated it."""
+
+    def __init__(self, bufs, rehome=True):
+        self.bufs = list(bufs)
+        if len(self.bufs) == 1:
+            self.tensor, self.copied = self.bufs[0], False
+        elif (rehome_adjacent(self.bufs) if rehome else _adjacent(self.bufs)):
+            b0 = self.bufs[0]
+            self.tensor = b0.new_empty(0).set_(b0.untyped_storage(), b0.storage_offset(), (sum(b.shape[0] for b in self.bufs),), (1,))
+            self.copied = False
+        else:
+            self.tensor, self.copied = torch.cat(self.bufs), True
+
+    def writeback(self):
+        if self.copied:
+            with torch.no_grad():
+                torch._foreach_copy_(self.bufs, list(torch.split(self.tensor, [b.shape[0] for b in self.bufs])))
+
+
+class SharedColumnGrad:
+    """Gradient of a [M, sum w_i] matrix whose consumers each read ONE column slice (the merged first layer of the heads feeds three
+    stacks): the consumers write their input gradients straight into the column slices of one buffer (row pitch = the full width)
+    and `split_columns_shared` passes that buffer upstream -- no concatenation of the slices' gradients (134 MB per step)."""
+    __slots__ = ("buf", "task", "width")
+
+    def __init__(self, width):
+        self.buf, self.task, self.width = None, None, width
+
+    def claim(self, M, col, w, device, dtype):
+        task = torch._C._current_graph_task_id()
+        if self.buf is None or self.task != task or self.buf.shape[0] != M or self.buf.dtype != dtype:
+            self.buf = torch.empty((M, self.width), dtype=dtype, device=device)
+            self.task = task
+        return self.buf[:, col:col + w]
+
+
+class _SplitColumnsShared(Function):
+    @staticmethod
+    def forward(ctx, H, acc, widths):
+        ctx.acc, ctx.widths = acc, widths
+        ctx.meta = (H.shape[0], H.dtype, H.device)
+        outs, o = [], 0
+        for w in widths:
+            outs.append(H[:, o:o + w])
+            o += w
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        acc = ctx.acc
+        M, dtype, dev = ctx.meta
+        if acc.buf is None or acc.task != torch._C._current_graph_task_id() or acc.buf.shape[0] != M or acc.buf.dtype != dtype:
+            acc.buf = torch.empty((M, acc.width), dtype=dtype, device=dev)
+        buf, o = acc.buf, 0
+        for g, w in zip(grads, ctx.widths):
+            sl = buf[:, o:o + w]
+            if g is None:
+                sl.zero_()
+            elif g.data_ptr() != sl.data_ptr() or g.stride() != sl.stride():
+                sl.copy_(g)
+            o += w
+        acc.buf = acc.task = None
+        return buf, None, None
+
+
+def split_columns_shared(H, widths):
+    """column slices of H for consumers that support `grad_cols=` (pointmlp): -> (slices, SharedColumnGrad)."""
+    acc = SharedColumnGrad(sum(widths))
+    return _SplitColumnsShared.apply(H, acc, tuple(widths)), acc
+
+
 class _EdgeConv(Function):
     @staticmethod
     def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out_buf=None):
@@ -451,9 +595,10 @@ class DeferredAct:
 class _PointMLP(Function):
     @staticmethod
     def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,
-                momentum, eps, grad_accum=None, out_bf16=False, in_bn=None, in_cfg=None, defer_out=False):
+                momentum, eps, grad_accum=None, out_bf16=False, in_bn=None, in_cfg=None, defer_out=False, grad_cols=None):
         lib = _lib.load()
         X = _rows(X, allow_bf16=True)
+        ctx.grad_cols = grad_cols
         _lib.require_gpu(X, W)
         if W.stride(1) != 1:
             W = W.contiguous()
@@ -516,7 +661,7 @@ class _PointMLP(Function):
     @once_differentiable
     def backward(ctx, dZ, _dbn=None):
         if dZ is None:
-            return (None,) * 21
+            return (None,) * 22
         lib = _lib.load()
         X, W, Y, bn_save = ctx.saved_tensors
         has_bn, training, act, slope, p, seed, has_bias, G, rpg = ctx.cfg
@@ -527,10 +672,14 @@ class _PointMLP(Function):
         dev = dZ.device
         M, Cin = X.shape
         Cout = W.shape[0]
-        dX, accumulate = None, 0
+        dX, accumulate, lddx = None, 0, Cin
         if ctx.needs_input_grad[0]:
             if ctx.grad_accum is not None and not x_bf16:
                 dX, accumulate = ctx.grad_accum.claim((M, Cin), dev)
+            elif ctx.grad_cols is not None:           # X is a column slice of a wider matrix: write into the same slice of ITS gradient
+                acc, col = ctx.grad_cols
+                dX = acc.claim(M, col, Cin, dev, X.dtype)
+                lddx = dX.stride(0)
             else:
                 dX = torch.empty((M, Cin), dtype=X.dtype, device=dev)
         dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
@@ -542,30 +691,31 @@ class _PointMLP(Function):
         if mx:
             _lib.check(lib.mlsp_pointmlp_bwd_mx(
                 dZ.data_ptr(), X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, Y.data_ptr(),
-                int(out_bf16), bn_save.data_ptr(), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate,
+                int(out_bf16), bn_save.data_ptr(), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
                 dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_mx")
         elif ctx.in_bn is not None:
             iact, islope, ip, iseed = ctx.in_cfg
             _lib.check(lib.mlsp_pointmlp_bwd_chain_f32(
                 dZ.data_ptr(), X.data_ptr(), X.stride(0), ctx.in_bn.data_ptr(), iact, islope, ip, iseed, M, Cin, W.data_ptr(), W.stride(0),
-                Cout, _lib.ptr(Y), _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate,
+                Cout, _lib.ptr(Y), _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
                 dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_chain_f32")
         else:
             _lib.check(lib.mlsp_pointmlp_bwd_f32(
                 dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
-                _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), Cin, accumulate, dW.data_ptr(),
+                _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate, dW.data_ptr(),
                 _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_f32")
-        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 15
+        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 16
 
 
 def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, run_var=None, rows_per_group=0,
-             training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5, grad_accum=None, chain=False):
+             training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5, grad_accum=None, chain=False, grad_cols=None):
     """Linear/1x1-conv (+bias, +per-group bias) [+ BatchNorm + act + dropout] on a [M,Cin] row matrix.
     `grad_accum`: the SharedInputGrad of a fan_out(X, n) whose alias this X is.  `chain=True`: the only consumer of the output is
-    another pointmlp BN layer, so under activation_storage("bf16") Y / Z may be stored as bf16."""
+    another pointmlp BN layer, so under activation_storage("bf16") Y / Z may be stored as bf16.  `grad_cols` = (SharedColumnGrad, first
+    column): X is that column slice of a split_columns_shared() matrix."""
     seed = _next_seed() if (training and p_drop > 0) else 0
     if (not isinstance(X, DeferredAct) and X.dtype == torch.bfloat16 and not (
             gamma is not None and X.dim() == 2 and X.stride(1) == 1 and
@@ -581,7 +731,7 @@ def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, 
     defer_out = (bool(chain) and gamma is not None and activation_storage.current == "fp32" and gemm_precision.current == "fp32"
                  and X.shape[0] > 32 and X.dtype == torch.float32 and _DEFER_CHAINS)
     out, bn_save = _PointMLP.apply(X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop,
-                                   seed, momentum, eps, grad_accum, out_bf16, in_bn, in_cfg, defer_out)
+                                   seed, momentum, eps, grad_accum, out_bf16, in_bn, in_cfg, defer_out, grad_cols)
     if defer_out:
         return DeferredAct(out, bn_save, act, slope, float(p_drop) if training else 0.0, seed)
     return out

@@ -182,7 +182,7 @@ class fc_layer(nn.Module):
         self.act = _ACT[activation]
 
     @flushing_forward
-    def forward(self, x, p_drop=0.0, chain=False):
+    def forward(self, x, p_drop=0.0, chain=False, grad_cols=None):
         """x [M,in] -> [M,out]; `p_drop` fuses the Dropout that follows this layer in the reference; `chain`: the output only
         feeds another Linear+BN layer (it may then be stored as bf16 under functional.activation_storage("bf16"))."""
         lin = self.fc[0]
@@ -197,7 +197,7 @@ class fc_layer(nn.Module):
         rm, rv = _bn_buffers(bn, self.training)
         return Fh.pointmlp(x, lin.weight, bias=lin.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
                            training=self.training, act=self.act, slope=0.2, p_drop=p_drop, momentum=bn.momentum, eps=bn.eps,
-                           chain=chain)
+                           chain=chain, grad_cols=grad_cols)
 
 
 class transform_net(nn.Module):

@@ -272,6 +272,55 @@ def test_module_api_surface(dev):
     assert pv.shape == (128, 16) and dn.shape == (128,)
 
 
+def test_merged_head_first_layers_equal_separate(dev):
+    """Models.merged_first_layers (the three heads' conv1 + bn1 as ONE wide layer, parameters re-homed back to back) against the
+    one-layer-per-head path: same logits, losses, gradients and running statistics; parameters keep identity / state_dict /
+    deepcopy / optimizer behaviour; a subset of heads and the eval mode take the merged path as well."""
+    from mlsp_amd import Models, functional as Fh
+    args = gc.make_args(cuda=True)
+    inp = {k: v.to(dev) for k, v in gc.make_inputs(4, 4, 256).items()}
+    res = {}
+    for merged in (False, True):
+        Models.MERGE_HEAD_FIRST_LAYERS = merged
+        try:
+            m = _model(4, dev).train()
+            ids = {n: id(p) for n, p in m.named_parameters()}
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+            logits = m(inp["x"], activate_density_normal_ondef=True)
+            loss, _ = _gpu_total_loss(args, logits, inp)
+            loss.backward()
+            grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+            opt.step()
+            with torch.no_grad():
+                two = m(inp["x"], activate_DefRec=True, activate_normal=True)             # a two-head subset
+                m.eval()
+                ev = m(inp["x"], activate_density_normal_ondef=True)
+            assert ids == {n: id(p) for n, p in m.named_parameters()}
+            adjacent = Fh._adjacent([m.DefRec.conv1.weight, m.Density_cls.conv1.weight, m.Norm_pred.conv1.weight])
+            assert adjacent == merged
+            m2 = copy.deepcopy(m)
+            m2.load_state_dict(m.state_dict(), strict=True)
+            with torch.no_grad():
+                ev2 = m2(inp["x"], activate_density_normal_ondef=True)
+            assert all(torch.equal(ev[k], ev2[k]) for k in ev)
+            res[merged] = (logits, loss.item(), grads, {k: v.clone() for k, v in m.state_dict().items()}, two, ev)
+        finally:
+            Models.MERGE_HEAD_FIRST_LAYERS = True
+    (la, lossa, ga, sa, twoa, eva), (lb, lossb, gb_, sb, twob, evb) = res[False], res[True]
+    for k in HEAD_KEYS:
+        np.testing.assert_allclose(lb[k].detach().cpu().numpy(), la[k].detach().cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(evb[k].cpu().numpy(), eva[k].cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg="eval " + k)
+    for k in twoa:
+        np.testing.assert_allclose(twob[k].cpu().numpy(), twoa[k].cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg="two " + k)
+    assert abs(lossa - lossb) <= 1e-5 * abs(lossa)
+    assert set(ga) == set(gb_)
+    for k in ga:
+        rel = ((ga[k] - gb_[k]).norm() / (ga[k].norm() + 1e-30)).item()
+        assert rel < 1e-4, (k, rel)
+    for k in sa:                                                          # parameters after the Adam step + running statistics
+        np.testing.assert_allclose(sb[k].float().cpu().numpy(), sa[k].float().cpu().numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+
+
 def test_dataparallel_and_replica_threads(dev):
     """PointDA/trainer.py:251-253 wraps the model in nn.DataParallel: replicas run forward in one Python thread each.  (1) the
     wrapper works end to end on this box's GPU; (2) two model copies driven concurrently by torch's own parallel_apply (two
