@@ -142,13 +142,13 @@ def require_gpu(*tensors):
                                    "fallback (the CPU restatement lives in oracle/ and is test-only)" % t.device)
 
 
-# one scratch buffer per device, grown on demand (all launches are stream-ordered)
+# one scratch buffer per (device, stream), grown on demand (the launches of one stream are ordered; two streams must not share one)
 _workspaces = {}
 
 
 def workspace(device, rows, cin, cout):
     need = load().mlsp_workspace_bytes(int(rows), int(cin), int(cout))
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(int(need), dtype=torch.uint8, device=device)

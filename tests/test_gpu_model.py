@@ -290,20 +290,22 @@ def test_merged_head_first_layers_equal_separate(dev):
             loss, _ = _gpu_total_loss(args, logits, inp)
             loss.backward()
             grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
-            opt.step()
+            state = {k: v.clone() for k, v in m.state_dict().items()}                     # running statistics of this forward
             with torch.no_grad():
                 two = m(inp["x"], activate_DefRec=True, activate_normal=True)             # a two-head subset
                 m.eval()
                 ev = m(inp["x"], activate_density_normal_ondef=True)
+            opt.step()                                                                    # updates in place, through the re-homed views
+            assert all(torch.isfinite(p).all().item() for p in m.parameters())
             assert ids == {n: id(p) for n, p in m.named_parameters()}
             adjacent = Fh._adjacent([m.DefRec.conv1.weight, m.Density_cls.conv1.weight, m.Norm_pred.conv1.weight])
             assert adjacent == merged
             m2 = copy.deepcopy(m)
             m2.load_state_dict(m.state_dict(), strict=True)
             with torch.no_grad():
-                ev2 = m2(inp["x"], activate_density_normal_ondef=True)
-            assert all(torch.equal(ev[k], ev2[k]) for k in ev)
-            res[merged] = (logits, loss.item(), grads, {k: v.clone() for k, v in m.state_dict().items()}, two, ev)
+                ev1, ev2 = m(inp["x"], activate_density_normal_ondef=True), m2(inp["x"], activate_density_normal_ondef=True)
+            assert all(torch.equal(ev1[k], ev2[k]) for k in ev1)
+            res[merged] = (logits, loss.item(), grads, state, two, ev)
         finally:
             Models.MERGE_HEAD_FIRST_LAYERS = True
     (la, lossa, ga, sa, twoa, eva), (lb, lossb, gb_, sb, twob, evb) = res[False], res[True]
@@ -317,7 +319,7 @@ def test_merged_head_first_layers_equal_separate(dev):
     for k in ga:
         rel = ((ga[k] - gb_[k]).norm() / (ga[k].norm() + 1e-30)).item()
         assert rel < 1e-4, (k, rel)
-    for k in sa:                                                          # parameters after the Adam step + running statistics
+    for k in sa:                                                          # running statistics (and the untouched parameters)
         np.testing.assert_allclose(sb[k].float().cpu().numpy(), sa[k].float().cpu().numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
 
 
