@@ -287,19 +287,9 @@ class DGCNN(nn.Module):
                                 training=self.training, act=Fh.ACT_LRELU, slope=0.2, momentum=self.bn5.momentum,
                                 eps=self.bn5.eps, grad_accum=acc)                  # [B,1024]
 
-        # the classifier (three per-cloud layers on B rows: small latency-bound launches) runs on the side stream beside the heads'
-        # wide layers; autograd runs its backward there as well
-        with Fh.on_side_stream(x.device, enabled=bool(heads)):
-            logits["cls"] = self.C(x5)
+        logits["cls"] = self.C(x5)
         if visualization:
             return x5
-        try:
-            return self._heads(logits, heads, merge, aliases, acc, x5, B, N)
-        finally:
-            if heads:
-                Fh.join_side_stream(x.device, logits["cls"])
-
-    def _heads(self, logits, heads, merge, aliases, acc, x5, B, N):
         if merge:
             # every head's first layer reads the same [x_cat | x5]: ONE wide layer, then each head continues on its column slice
             slices, cols = merged_first_layers([h for _, h in heads], aliases[1], x5, N, grad_accum=acc)

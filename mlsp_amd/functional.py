@@ -6,7 +6,6 @@ reference's channel-major [B, C, N] at its boundary only.
 """
 import itertools
 import os
-import threading
 
 import torch
 from torch.autograd import Function
@@ -89,87 +88,12 @@ class activation_storage:
         return False
 
 
-# ---- side stream: work the forward pass does not wait for -------------------------------------------------------------------------
-# The reverse neighbour index of a graph stage is only read by the BACKWARD pass, and the classifier (three per-cloud layers on 32
-# rows) feeds nothing but its own loss: both are chains of small, latency-bound launches that occupy a few CUs.  They run on a
-# second HIP stream beside the wide GEMM / gather kernels of the main stream (measured in round 2: a chain of small kernels hides
-# beside a big GEMM, two big kernels do not).  Event-ordered in both directions; torch's autograd runs a node's backward on the
-# stream its forward ran on and orders the streams itself.  MLSP_NO_SIDE_STREAM=1 keeps everything on the caller's stream (A/B).
-_USE_SIDE = os.environ.get("MLSP_NO_SIDE_STREAM") is None
-
-
-class _SideState(threading.local):
-    def __init__(self):
-        self.streams = {}
-
-
-_side = _SideState()
-
-
-def side_stream(device):
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _side.streams.get(idx)
-    if st is None:
-        st = _side.streams[idx] = torch.cuda.Stream(device=idx)
-    return st
-
-
-class on_side_stream:
-    """`with on_side_stream(dev, enabled):` -- the body's launches go to the side stream, ordered after everything the caller's
-    stream has queued so far; join_side_stream() (or a consumer's wait on an event) orders them before later work."""
-
-    def __init__(self, device, enabled=True):
-        self.enabled = bool(enabled) and _USE_SIDE and device.type == "cuda"
-        self.device, self.ctx = device, None
-
-    def __enter__(self):
-        if self.enabled:
-            st = side_stream(self.device)
-            st.wait_stream(torch.cuda.current_stream(self.device))
-            self.ctx = torch.cuda.stream(st)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-
-def join_side_stream(device, *tensors):
-    """the caller's stream waits for the side stream; `tensors` produced there are marked as used on the caller's stream too"""
-    if _USE_SIDE and device.type == "cuda" and _side.streams.get(device.index if device.index is not None else torch.cuda.current_device()):
-        cur = torch.cuda.current_stream(device)
-        cur.wait_stream(side_stream(device))
-        for t in tensors:
-            t.record_stream(cur)
-
-
 class KnnGraph:
-    """kNN indices of one graph stage plus the reverse index needed by the backward passes (`rev_ready`: the event after which the
-    reverse index, built on the side stream, may be read; None when it was built in stream order)."""
-    __slots__ = ("idx", "_rev_off", "_rev_ent", "B", "N", "k", "rev_ready")
+    """kNN indices of one graph stage plus the reverse index needed by the backward passes."""
+    __slots__ = ("idx", "rev_off", "rev_ent", "B", "N", "k")
 
-    def __init__(self, idx, rev_off, rev_ent, B, N, k, rev_ready=None):
-        self.idx, self._rev_off, self._rev_ent, self.B, self.N, self.k, self.rev_ready = idx, rev_off, rev_ent, B, N, k, rev_ready
-
-    def _sync_rev(self):
-        if self.rev_ready is not None:
-            cur = torch.cuda.current_stream(self.idx.device)
-            cur.wait_event(self.rev_ready)
-            self._rev_off.record_stream(cur)
-            self._rev_ent.record_stream(cur)
-            self.rev_ready = None
-
-    @property
-    def rev_off(self):
-        self._sync_rev()
-        return self._rev_off
-
-    @property
-    def rev_ent(self):
-        self._sync_rev()
-        return self._rev_ent
+    def __init__(self, idx, rev_off, rev_ent, B, N, k):
+        self.idx, self.rev_off, self.rev_ent, self.B, self.N, self.k = idx, rev_off, rev_ent, B, N, k
 
 
 _forced_graphs = None   # test hook: list of index tensors consumed by successive knn_graph calls
@@ -218,24 +142,12 @@ def knn_graph(xp, B, N, k, need_reverse=True):
     P, C = xp.shape
     assert P == B * N
     idx = torch.empty((P, k), dtype=torch.int32, device=xp.device)
-    need_reverse = need_reverse and torch.is_grad_enabled()      # only a backward pass reads it
-    ws, wsn = _lib.workspace(xp.device, P, C, 1)
-    if need_reverse and _USE_SIDE:
-        # indices on the caller's stream; their transpose (read by the backward pass only) on the side stream
-        _lib.check(lib.mlsp_knn_f32(xp.data_ptr(), xp.stride(0), B, N, C, k, idx.data_ptr(), None, None, ws, wsn, _lib.stream()),
-                   "mlsp_knn_f32")
-        with on_side_stream(xp.device) as side:
-            rev_off = torch.empty((P + 1,), dtype=torch.int32, device=xp.device)
-            rev_ent = torch.empty((P * k,), dtype=torch.int32, device=xp.device)
-            idx.record_stream(torch.cuda.current_stream(xp.device))
-            _lib.check(lib.mlsp_knn_reverse(idx.data_ptr(), B, N, k, rev_off.data_ptr(), rev_ent.data_ptr(), _lib.stream()),
-                       "mlsp_knn_reverse")
-            ready = torch.cuda.current_stream(xp.device).record_event()
-        return KnnGraph(idx, rev_off, rev_ent, B, N, k, ready)
     rev_off = rev_ent = None
+    need_reverse = need_reverse and torch.is_grad_enabled()      # only a backward pass reads the reverse index
     if need_reverse:
         rev_off = torch.empty((P + 1,), dtype=torch.int32, device=xp.device)
         rev_ent = torch.empty((P * k,), dtype=torch.int32, device=xp.device)
+    ws, wsn = _lib.workspace(xp.device, P, C, 1)
     _lib.check(lib.mlsp_knn_f32(xp.data_ptr(), xp.stride(0), B, N, C, k, idx.data_ptr(), _lib.ptr(rev_off),
                                 _lib.ptr(rev_ent), ws, wsn, _lib.stream()), "mlsp_knn_f32")
     return KnnGraph(idx, rev_off, rev_ent, B, N, k)
