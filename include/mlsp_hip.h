@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 6
+#define MLSP_ABI_VERSION 7
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -68,16 +68,20 @@ int mlsp_graph_feature_bwd_f32(const float* dF, const int32_t* rev_off, const in
  * W [Cout][2C] in the reference's Conv2d layout.  Saved for backward: uv [P][2Cout], msel [P][Cout],
  * argsel [P][Cout] u8, s1 [P][Cout], bn_save [4][Cout].  out (row pitch ldo >= Cout) and dOut (row pitch lddo) may be column
  * slices of a wider matrix: the four EdgeConv outputs are written straight into the [P][512] concatenation of
- * PointDA/Models.py:131 (no torch.cat pass) and its gradient is read in place. */
+ * PointDA/Models.py:131 (no torch.cat pass) and its gradient is read in place.
+ * Wd [2Cout][C] (nullable): the folded weight [Wa ; Wb - Wa] the forward builds anyway; a caller that keeps it and hands it to the
+ * backward saves the rebuild.  dx (row pitch lddx >= C) may be a column slice as well, and with dx_accumulate != 0 the input
+ * gradient is ADDED to it: layer l+1 adds its input gradient into layer l's slice of the concatenation's gradient, which is the
+ * sum autograd would otherwise form with a separate pass. */
 int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int act, float slope, int training,
                           int B, int N, int C, int Cout, int k, float* out, int ldo, float* uv, float* msel, uint8_t* argsel,
-                          float* s1, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          float* s1, float* bn_save, float* Wd, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
                           const float* W, const float* out, int ldo, const float* uv, const float* msel, const uint8_t* argsel,
-                          const float* s1, const float* bn_save, int act, float slope, int training, int B, int N, int C,
-                          int Cout, int k, float* dx, float* dW, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                          mlsp_stream_t stream);
+                          const float* s1, const float* bn_save, const float* Wd, int act, float slope, int training, int B, int N,
+                          int C, int Cout, int k, float* dx, int lddx, int dx_accumulate, float* dW, float* dgamma, float* dbeta,
+                          void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* Fused per-edge stage of the T-Net (PointDA/model_utils.py:111-115: conv2d1 6->64, conv2d2 64->128 per EDGE, max over k),
  * dgcnn branch (bias-free convs, LeakyReLU).  x [P][C] point-major (C = 3), W1 [C1][2C], W2 [C2][C1]; requires C1 = 64, C2 = 128

@@ -258,14 +258,21 @@ class DGCNN(nn.Module):
         # (:131): no torch.cat pass forward, no split copies backward
         convs = (self.conv1, self.conv2, self.conv3, self.conv4)
         x_cat_buf = torch.empty((B * N, sum(c.conv[0].out_channels for c in convs)), dtype=torch.float32, device=x.device)
-        feats, h, col = [], xp, 0
-        for conv in convs:
+        # A layer's output has two consumers: its slice of x_cat and the next layer.  The next layer ADDS its input gradient into
+        # that slice of x_cat's gradient (fan_out + join_columns(accs=)): no separate accumulation pass per layer in backward.
+        feats, accs, h, col, acc_in = [], [], xp, 0, None
+        for li, conv in enumerate(convs):
             g = Fh.knn_graph(h, B, N, k)
             w = conv.conv[0].out_channels
-            h = conv.edge(h, g, out=x_cat_buf[:, col:col + w])
-            feats.append(h)
+            out = conv.edge(h, g, out=x_cat_buf[:, col:col + w], grad_accum=acc_in)
+            if li + 1 < len(convs):
+                (to_cat, h), acc_in = Fh.fan_out(out, 2)
+            else:
+                to_cat, acc_in = out, None
+            feats.append(to_cat)
+            accs.append(acc_in)
             col += w
-        x_cat = Fh.join_columns(x_cat_buf, feats)                                  # [P,512]
+        x_cat = Fh.join_columns(x_cat_buf, feats, accs)                            # [P,512]
 
         # conv5 and every active head read x_cat: their input gradients are summed in ONE buffer (functional.SharedInputGrad)
         heads = []

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLSP_HIP_LIB") or os.path.join(_HERE, "libmlsp_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c = ctypes
 _P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
@@ -26,9 +26,9 @@ SIGNATURES = {
     "mlsp_graph_feature_fwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_graph_feature_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_edgeconv_fwd_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _F, _I, _I, _I, _I, _I, _I,
-                              _P, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
-    "mlsp_edgeconv_bwd_f32": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I,
-                              _P, _P, _P, _P, _P, _SZ, _P],
+                              _P, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_edgeconv_bwd_f32": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I,
+                              _P, _I, _I, _P, _P, _P, _P, _SZ, _P],
     "mlsp_tnet_edge_fwd_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I,
                                _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_tnet_edge_bwd_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I,

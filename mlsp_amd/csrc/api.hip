@@ -319,12 +319,12 @@ int mlsp_graph_feature_bwd_f32(const float* dF, const int32_t* rev_off, const in
 int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int act, float slope, int training,
                           int B, int N, int C, int Cout, int k, float* out, int ldo, float* uv, float* msel, uint8_t* argsel,
-                          float* s1, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          float* s1, float* bn_save, float* Wd_out, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     if (!x || !idx || !W || !gamma || !beta || !out || !uv || !msel || !argsel || !s1 || !bn_save) return MLSP_ERR_ARG;
     if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || k > 255 || ldx < C || ldo < Cout) return MLSP_ERR_ARG;
     const int P = B * N;
     Workspace w(ws, ws_bytes);
-    float* Wd = w.take<float>((size_t)2 * Cout * C);
+    float* Wd = Wd_out ? Wd_out : w.take<float>((size_t)2 * Cout * C);     // Wd_out: kept by the caller for the backward pass
     int nparts = edge_reduce_parts(P);
     double* part = w.take<double>((size_t)nparts * 2 * Cout);
     size_t sf = gemm_slab_floats(P, 2 * Cout, C);
@@ -352,16 +352,16 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
 
 int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
                           const float* W, const float* out, int ldo, const float* uv, const float* msel, const uint8_t* argsel,
-                          const float* s1, const float* bn_save, int act, float slope, int training, int B, int N, int C,
-                          int Cout, int k, float* dx, float* dW, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                          mlsp_stream_t st) {
+                          const float* s1, const float* bn_save, const float* Wd_in, int act, float slope, int training, int B, int N, int C,
+                          int Cout, int k, float* dx, int lddx, int dx_accumulate, float* dW, float* dgamma, float* dbeta, void* ws,
+                          size_t ws_bytes, mlsp_stream_t st) {
     if (!dOut || !x || !rev_off || !rev_ent || !W || !out || !uv || !msel || !argsel || !s1 || !bn_save || !dW || !dgamma ||
         !dbeta)
         return MLSP_ERR_ARG;
-    if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || ldx < C || lddo < Cout || ldo < Cout) return MLSP_ERR_ARG;
+    if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || ldx < C || lddo < Cout || ldo < Cout || (dx && lddx < C)) return MLSP_ERR_ARG;
     const int P = B * N;
     Workspace w(ws, ws_bytes);
-    float* Wd = w.take<float>((size_t)2 * Cout * C);
+    float* Wd = Wd_in ? nullptr : w.take<float>((size_t)2 * Cout * C);
     float* dWd = w.take<float>((size_t)2 * Cout * C);
     float* gz = w.take<float>((size_t)P * Cout);
     float* duv = w.take<float>((size_t)P * 2 * Cout);
@@ -380,8 +380,11 @@ int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, 
     const float* mdz = training ? mean_dz : nullptr;
     CHECK(launch_edge_bwd_point(st, dOut, out, uv, s1, P, Cout, k, scale, mean, invstd, mdz, mean_dzy, act, slope, gz, duv, lddo, ldo));
     CHECK(launch_edge_bwd_gather(st, gz, argsel, uv, rev_off, rev_ent, P, N, Cout, scale, mean, invstd, mdz, mean_dzy, duv));
-    CHECK(launch_build_wd(st, W, Cout, C, Wd));
-    if (dx) CHECK(launch_gemm(st, false, false, P, C, 2 * Cout, duv, 2 * Cout, Wd, C, dx, C, nullptr, nullptr, 0, slab, sf));
+    // (the forward's [Wa ; Wb - Wa] is reused when the caller kept it; beta = 1: dx is added into a slice of a wider gradient)
+    const float* Wdc = Wd_in;
+    if (!Wdc && dx) { CHECK(launch_build_wd(st, W, Cout, C, Wd)); Wdc = Wd; }
+    if (dx) CHECK(launch_gemm(st, false, false, P, C, 2 * Cout, duv, 2 * Cout, Wdc, C, dx, lddx, nullptr, nullptr, 0, slab, sf, nullptr,
+                              nullptr, nullptr, nullptr, dx_accumulate != 0));
     CHECK(launch_gemm(st, true, false, 2 * Cout, C, P, duv, 2 * Cout, x, ldx, dWd, C, nullptr, nullptr, 0, slab, sf));
     CHECK(launch_unbuild_wd(st, dWd, Cout, C, dW));
     return MLSP_OK;

@@ -575,7 +575,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_n64_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = acc[j][r] + bv[j];
+            float v = acc[j][r] + bv[j];
+            if (epi && p.accumulate) v += Cout[(size_t)row * p.ldc + j * 32 + l31];       // beta = 1 (never with split K)
             Cout[(size_t)row * p.ldc + j * 32 + l31] = v;
             cs[j] += v; cq[j] = fmaf(v, v, cq[j]);
         }
@@ -1061,7 +1062,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     // lean output pass: every row of a tile takes the same per-cloud bias row, byte offsets inside a wave's region fit 31 bits
     p.fast_out = (fast && (!gbias || rows_per_group % bm == 0) && (long)p.ldc * 4 * 64 < (1L << 30) && !old_epilogue) ? 1 : 0;
     const bool n64 = !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
-                     (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && !accumulate && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
+                     (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
     if (n64) {
         dim3 g64(M / 128, ns);
         if (!ta && tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, true>), g64, dim3(256), 0, st, p);

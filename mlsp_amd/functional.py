@@ -254,22 +254,29 @@ class _JoinColumns(Function):
     backward hands each producer its column slice of the gradient as a strided view (no torch.cat, no split copies)."""
 
     @staticmethod
-    def forward(ctx, base, *parts):
+    def forward(ctx, base, accs, *parts):
         ctx.widths = [p.shape[1] for p in parts]
+        ctx.accs = accs
         return base.view_as(base)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         outs, o = [], 0
-        for w in ctx.widths:
-            outs.append(g[:, o:o + w])
+        task = torch._C._current_graph_task_id()
+        for i, w in enumerate(ctx.widths):
+            sl = g[:, o:o + w]
+            outs.append(sl)
+            if ctx.accs is not None and ctx.accs[i] is not None:
+                # the OTHER consumer of this producer's output (the next EdgeConv layer) adds its input gradient into the slice
+                ctx.accs[i].buf, ctx.accs[i].task = sl, task
             o += w
-        return (None,) + tuple(outs)
+        return (None, None) + tuple(outs)
 
 
-def join_columns(base, parts):
-    return _JoinColumns.apply(base, *parts)
+def join_columns(base, parts, accs=None):
+    """`accs[i]` (optional SharedInputGrad of a fan_out(parts[i], 2)): see _JoinColumns.backward."""
+    return _JoinColumns.apply(base, accs, *parts)
 
 
 class _SplitColumns(Function):
@@ -436,7 +443,7 @@ def split_columns_shared(H, widths):
 
 class _EdgeConv(Function):
     @staticmethod
-    def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out_buf=None):
+    def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out_buf=None, grad_accum=None):
         lib = _lib.load()
         xp = _rows(xp)
         _lib.require_gpu(xp, W2d, gamma)
@@ -455,31 +462,38 @@ class _EdgeConv(Function):
         s1 = torch.empty((P, Cout), dtype=torch.float32, device=dev)
         argsel = torch.empty((P, Cout), dtype=torch.uint8, device=dev)
         bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev)
+        keep_wd = torch.is_grad_enabled() and xp.requires_grad          # the folded weight, kept for the backward's dgrad
+        Wd = torch.empty((2 * Cout, C), dtype=torch.float32, device=dev) if keep_wd else None
         ws, wsn = _lib.workspace(dev, P, C, 2 * Cout)
         _lib.check(lib.mlsp_edgeconv_fwd_f32(
             xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
             _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, act, slope, int(training), graph.B, graph.N, C, Cout,
             graph.k, out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
-            bn_save.data_ptr(), ws, wsn, _lib.stream()), "mlsp_edgeconv_fwd_f32")
+            bn_save.data_ptr(), _lib.ptr(Wd), ws, wsn, _lib.stream()), "mlsp_edgeconv_fwd_f32")
         if out_buf is not None:
             out = out_buf.view_as(out_buf)      # a fresh alias: the Function's output, distinct from its (non-differentiable) input
-        ctx.save_for_backward(xp, W2d, out, uv, msel, argsel, s1, bn_save)
+        ctx.save_for_backward(xp, W2d, out, uv, msel, argsel, s1, bn_save, Wd)
         ctx.cfg = (graph, training, act, slope, C, Cout)
+        ctx.grad_accum = grad_accum
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dOut):
         lib = _lib.load()
-        xp, W2d, out, uv, msel, argsel, s1, bn_save = ctx.saved_tensors
+        xp, W2d, out, uv, msel, argsel, s1, bn_save, Wd = ctx.saved_tensors
         graph, training, act, slope, C, Cout = ctx.cfg
         if graph.rev_off is None:
             raise RuntimeError("EdgeConv backward needs the reverse neighbour index (knn_graph(need_reverse=True))")
         dOut = _rows(dOut)                      # a column slice of the concatenation's gradient is read in place
         dev = dOut.device
         P = xp.shape[0]
-        need_dx = ctx.needs_input_grad[0]
-        dx = torch.empty((P, C), dtype=torch.float32, device=dev) if need_dx else None
+        dx, accumulate = None, 0
+        if ctx.needs_input_grad[0]:
+            if ctx.grad_accum is not None:      # the input is a column slice of the concatenation: add into that slice of its gradient
+                dx, accumulate = ctx.grad_accum.claim((P, C), dev)
+            else:
+                dx = torch.empty((P, C), dtype=torch.float32, device=dev)
         dW = torch.empty_like(W2d)
         dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev)
@@ -487,15 +501,18 @@ class _EdgeConv(Function):
         _lib.check(lib.mlsp_edgeconv_bwd_f32(
             dOut.data_ptr(), dOut.stride(0), xp.data_ptr(), xp.stride(0), graph.rev_off.data_ptr(), graph.rev_ent.data_ptr(),
             W2d.data_ptr(), out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
-            bn_save.data_ptr(), act, slope, int(training), graph.B, graph.N, C, Cout, graph.k, _lib.ptr(dx), dW.data_ptr(),
-            dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()), "mlsp_edgeconv_bwd_f32")
-        return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+            bn_save.data_ptr(), _lib.ptr(Wd), act, slope, int(training), graph.B, graph.N, C, Cout, graph.k, _lib.ptr(dx),
+            dx.stride(0) if dx is not None else C, accumulate, dW.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn,
+            _lib.stream()), "mlsp_edgeconv_bwd_f32")
+        return (dx, dW, dgamma, dbeta) + (None,) * 10
 
 
-def edgeconv(xp, graph, W2d, gamma, beta, run_mean, run_var, training, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5, out=None):
+def edgeconv(xp, graph, W2d, gamma, beta, run_mean, run_var, training, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5, out=None,
+             grad_accum=None):
     """Fused get_graph_feature + conv_2d + max over k (Models.py:115-129).  xp [P,C] -> [P,Cout].  `out`: a [P,Cout] column
-    slice of a wider buffer to write the result into (see join_columns)."""
-    return _EdgeConv.apply(xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out)
+    slice of a wider buffer to write the result into (see join_columns).  `grad_accum`: the SharedInputGrad of a fan_out whose alias
+    xp is (join_columns(..., accs=) points it at xp's slice of the concatenation's gradient: the input gradient is added there)."""
+    return _EdgeConv.apply(xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out, grad_accum)
 
 
 class _TnetEdge(Function):

@@ -7,8 +7,8 @@ TAG=${1:-rX}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-python3 bench.py --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
+python3 bench.py --no-cpu-baseline --no-secondary > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $ARGS > "$OUT/stats.log" 2>&1
 if [ "${2:-}" = "pmc" ]; then
   for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do
