@@ -12,6 +12,10 @@ from . import functional as Fh
 from .model_utils import transform_net, conv_2d, fc_layer, classifier, _bn_buffers, flushing_forward
 
 K = 20   # Models.py:13
+# EdgeConv layer l+1 adding its input gradient straight into layer l's slice of the x_cat gradient (fan_out + join_columns(accs=))
+# instead of autograd's three accumulation passes: measured 20-40 us SLOWER per step on MI355X (the beta = 1 output pass of the
+# narrow dgrad GEMMs costs more than the element-wise adds it removes): off.
+EDGE_GRAD_INTO_SLICE = False
 MERGE_HEAD_FIRST_LAYERS = True   # merged_first_layers(): the heads' first layers as one wide layer (tests switch it off to compare)
 
 
@@ -265,10 +269,10 @@ class DGCNN(nn.Module):
             g = Fh.knn_graph(h, B, N, k)
             w = conv.conv[0].out_channels
             out = conv.edge(h, g, out=x_cat_buf[:, col:col + w], grad_accum=acc_in)
-            if li + 1 < len(convs):
+            if li + 1 < len(convs) and EDGE_GRAD_INTO_SLICE:
                 (to_cat, h), acc_in = Fh.fan_out(out, 2)
             else:
-                to_cat, acc_in = out, None
+                to_cat, h, acc_in = out, out, None
             feats.append(to_cat)
             accs.append(acc_in)
             col += w

@@ -215,39 +215,27 @@ __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* 
     const int rows_per_part = (N + CSR_SPLIT - 1) / CSR_SPLIT;
     const int p0 = part * rows_per_part, p1 = min(N, p0 + rows_per_part);
     const float* gb = g + (size_t)b * Cout;
-    // short lists: one wave per row.  All W rows of the list (<= CSR_LONG) are requested before the first FMA: the chain of
-    // dependent L2 round trips (one per entry) was what this kernel spent its time on; the summation order is unchanged.
+    // short lists: one wave per row
     for (int p = p0 + wave; p < p1; p += nw) {
-        const int e0 = off[p], e1 = off[p + 1], ne = e1 - e0;
-        if (ne == 0 || ne > CSR_LONG) continue;
+        const int e0 = off[p], e1 = off[p + 1];
+        if (e0 == e1 || e1 - e0 > CSR_LONG) continue;
         float* o = dX + ((size_t)b * N + p) * lddx;
-        int cs[CSR_LONG];
-        float gs[CSR_LONG];
-#pragma unroll
-        for (int e = 0; e < CSR_LONG; ++e) {
-            cs[e] = lst[e0 + (e < ne ? e : 0)];
-            gs[e] = e < ne ? gb[cs[e]] : 0.f;
-        }
         for (int i0 = 0; i0 < Cin; i0 += 256) {
-            float acc[4], wv[CSR_LONG][4];
+            float acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                 // the read of the read-modify-write goes out with the W loads
                 int i = i0 + lane + 64 * u;
                 acc[u] = i < Cin ? o[i] : 0.f;
             }
-#pragma unroll
-            for (int e = 0; e < CSR_LONG; ++e)
+            for (int e = e0; e < e1; ++e) {
+                const int c = lst[e];
+                const float gv = gb[c];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     int i = i0 + lane + 64 * u;
-                    wv[e][u] = (e < ne && i < Cin) ? W[(size_t)cs[e] * ldw + i] : 0.f;
+                    if (i < Cin) acc[u] = fmaf(gv, W[(size_t)c * ldw + i], acc[u]);
                 }
-#pragma unroll
-            for (int e = 0; e < CSR_LONG; ++e)
-                if (e < ne) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[u] = fmaf(gs[e], wv[e][u], acc[u]);
-                }
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int i = i0 + lane + 64 * u;
@@ -262,25 +250,14 @@ __global__ __launch_bounds__(1024) void colmax_scatter_rows_kernel(const float* 
         float* o = dX + ((size_t)b * N + p) * lddx;
         for (int i0 = 0; i0 < Cin; i0 += 256) {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int eb = e0 + wave; eb < e1; eb += 4 * nw) {        // four of this wave's entries in flight, added in list order
-                float wv[4][4], gv[4];
+            for (int e = e0 + wave; e < e1; e += nw) {
+                const int c = lst[e];
+                const float gv = gb[c];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int e = eb + q * nw;
-                    const int c = lst[e < e1 ? e : e0];
-                    gv[q] = e < e1 ? gb[c] : 0.f;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int i = i0 + lane + 64 * u;
-                        wv[q][u] = (e < e1 && i < Cin) ? W[(size_t)c * ldw + i] : 0.f;
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    int i = i0 + lane + 64 * u;
+                    if (i < Cin) acc[u] = fmaf(gv, W[(size_t)c * ldw + i], acc[u]);
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (eb + q * nw < e1) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[u] = fmaf(gv[q], wv[q][u], acc[u]);
-                    }
             }
             __syncthreads();                               // previous slice's readers are done with red
 #pragma unroll

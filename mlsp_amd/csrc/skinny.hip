@@ -37,7 +37,7 @@ struct SkinnyFwdArgs {
 };
 
 #define SK_WAVES 8           // waves per workgroup (2 per SIMD -> 256 VGPRs each): the K range is cut 8 ways
-#define SK_BATCH 16          // chunks (of 8 k) whose loads are all in flight before the first MFMA of the batch
+#define SK_BATCH 8           // chunks (of 8 k) whose loads are all in flight before the first MFMA of the batch
 
 // sum of the SK_WAVES partial tiles in wave order; result in wave 0 (other waves return false)
 __device__ __forceinline__ bool sk_reduce_tiles(f32x16& acc, float (*red)[16][64], int wave, int lane) {

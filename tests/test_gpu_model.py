@@ -327,6 +327,30 @@ def test_merged_head_first_layers_equal_separate(dev):
         np.testing.assert_allclose(sb[k].float().cpu().numpy(), sa[k].float().cpu().numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
 
 
+def test_edge_grad_into_slice_equals_autograd(dev):
+    """Models.EDGE_GRAD_INTO_SLICE (off by default: measured slower): layer l+1 adds its input gradient into layer l's column slice of
+    the x_cat gradient through the dgrad GEMM's beta = 1 epilogue and dx row pitch (mlsp_edgeconv_bwd_f32 lddx / dx_accumulate)
+    instead of autograd's accumulation: same gradients."""
+    from mlsp_amd import Models
+    args = gc.make_args(cuda=True)
+    inp = {k: v.to(dev) for k, v in gc.make_inputs(6, 3, 256).items()}
+    grads = {}
+    for flag in (False, True):
+        Models.EDGE_GRAD_INTO_SLICE = flag
+        try:
+            m = _model(6, dev).train()
+            loss, _ = _gpu_total_loss(args, m(inp["x"], activate_density_normal_ondef=True), inp)
+            loss.backward()
+            grads[flag] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            Models.EDGE_GRAD_INTO_SLICE = False
+    assert set(grads[False]) == set(grads[True])
+    for k, a in grads[False].items():
+        rel = ((a - grads[True][k]).norm() / (a.norm() + 1e-30)).item()
+        direct = k.split(".")[0] in ("DefRec", "Norm_pred", "Density_cls", "C", "conv5", "bn5", "conv4")
+        assert rel < (1e-5 if direct else 0.1), (k, rel)          # upstream of the re-associated sums: ill-conditioned (DESIGN.md 2)
+
+
 def test_dataparallel_and_replica_threads(dev):
     """PointDA/trainer.py:251-253 wraps the model in nn.DataParallel: replicas run forward in one Python thread each.  (1) the
     wrapper works end to end on this box's GPU; (2) two model copies driven concurrently by torch's own parallel_apply (two
