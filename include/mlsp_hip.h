@@ -162,6 +162,28 @@ int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int
                                  int training, int act, float slope, float* dX, int dx_accumulate, float* dW, float* dgamma, float* dbeta,
                                  void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
+/* Several Linear (+bias) layers side by side under ONE BatchNorm + activation (+dropout) pass: layer d of the three MLSP heads
+ * (PointDA/Models.py:193-196 position, :227-230 normal, :274-279 cardinality) in one [M][sum Cout] matrix.  Segment s:
+ *   Y[:, y_s : y_s + Cout_s] = X[:, x_col_s : x_col_s + Cin_s] W_s^T (+ bias_s),   y_s = Cout_0 + ... + Cout_{s-1}
+ * gamma / beta / running statistics / dgamma / dbeta / dbias are [C] vectors over all the channels (C = sum Cout <= 1024), bn_save
+ * [4][C].  chan [2][C]: per channel the negative-side factor of the activation max(a, f a) (0 ReLU, 0.2 LeakyReLU, 1 none) and the
+ * dropout switch (0 / 1; rate p_drop, counter hash of element row * C + channel).  `segs` and `dW` (one [Cout_s][Cin_s] gradient per
+ * segment) are HOST arrays.  Backward: dX [M][..] (row pitch lddx; nullable) gets segment s's input gradient in columns x_col_s..;
+ * segments reading the same columns add up.  MLSP_ERR_UNSUPPORTED (mlsp_multimlp_supported() == 0) when a column slice is not
+ * 16-byte aligned or C > 1024: run one mlsp_pointmlp_* per segment instead. */
+typedef struct mlsp_seg {
+    const float* W;        /* [Cout][Cin], row pitch ldw */
+    const float* bias;     /* [Cout] or NULL */
+    int ldw, x_col, Cin, Cout;
+} mlsp_seg_t;
+int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg);
+int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* gamma, const float* beta,
+                          float* run_mean, float* run_var, float momentum, float eps, int training, const float* chan, float p_drop,
+                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* Y,
+                          const float* bn_save, int training, const float* chan, float p_drop, uint64_t seed, float* dX, int lddx,
+                          float* const* dW, float* dbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+
 /* max over the k edges of every point (`.max(dim=-1)`, model_utils.py:114) on an edge-major matrix */
 int mlsp_segmax_fwd_f32(const float* Z, int P, int k, int C, float* out, uint8_t* argk, mlsp_stream_t stream);
 int mlsp_segmax_bwd_f32(const float* dOut, const uint8_t* argk, int P, int k, int C, float* dZ, mlsp_stream_t stream);

@@ -16,6 +16,7 @@ K = 20   # Models.py:13
 # instead of autograd's three accumulation passes: measured 20-40 us SLOWER per step on MI355X (the beta = 1 output pass of the
 # narrow dgrad GEMMs costs more than the element-wise adds it removes): off.
 EDGE_GRAD_INTO_SLICE = False
+MERGE_HEAD_TAILS = True          # merged_tails(): the heads' later layers depth by depth in shared wide matrices
 MERGE_HEAD_FIRST_LAYERS = True   # merged_first_layers(): the heads' first layers as one wide layer (tests switch it off to compare)
 
 
@@ -48,7 +49,7 @@ def merged_first_layers(heads, x_cat, x5, N, grad_accum=None):
     three BatchNorm1d side by side is exact), and in backward ONE K = sum(of1) dgrad and one wgrad -- x_cat and its gradient are read
     and written once per step instead of once per head.  The heads' parameters keep their identity (state_dict keys, optimizer
     entries): their storage is re-homed back to back (functional.rehome_adjacent) so that the merged operands are views.
-    -> (h1 [P, sum of1] column slices per head, SharedColumnGrad for the consumers' `grad_cols`)."""
+    -> (h1 [P, sum of1], [of1 per head]): head i continues on columns sum(of1[:i]) .. of h1."""
     mods = list(heads)
     training, p_drop = mods[0].training, mods[0].dp1.p
     Cc = x_cat.shape[1]
@@ -71,7 +72,62 @@ def merged_first_layers(heads, x_cat, x5, N, grad_accum=None):
     if training:
         rm.writeback()
         rv.writeback()
-    return Fh.split_columns_shared(h1, [m.conv1.out_channels for m in mods])
+    return h1, [m.conv1.out_channels for m in mods]
+
+
+def merged_tails(heads, h1, widths, B, N):
+    """The layers after conv1 of several heads, depth by depth (csrc/multi.hip): every head has two Linear + BatchNorm + activation
+    layers and a final Linear (Models.py:193-197, :227-231, :274-285), so layer d of ALL heads is one [P, sum Cout] matrix -- each
+    head's Linear writes its column slice, ONE BatchNorm + activation + dropout pass (per-channel activation parameters) serves all
+    of them, forward and backward.  Returns the heads' outputs in order, or None when a shape / mode is outside that kernel (the
+    caller then runs the heads one by one on their slices of h1)."""
+    mods = list(heads)
+    training = mods[0].training
+    own = not any(getattr(m, "_is_replica", False) for m in mods)
+    specs = [m.tail_spec() for m in mods]            # per head: [(W, bias, bn, negative-side factor, dropout rate)] x 2
+    if any(len(sp) != 2 for sp in specs):
+        return None
+    X, in_w = h1, list(widths)
+    for d in range(2):
+        layer = [sp[d] for sp in specs]
+        rates = {float(l[4]) for l in layer if l[4] > 0}
+        bn0 = layer[0][2]
+        if len(rates) > 1 or any(l[2].momentum != bn0.momentum or l[2].eps != bn0.eps for l in layer):
+            return None if d == 0 else _tails_one_by_one(mods, X, in_w, B, N, first=1)
+        x_cols, o = [], 0
+        for w in in_w:
+            x_cols.append(o)
+            o += w
+        Ws = [l[0] for l in layer]
+        if any(W.shape[1] != w for W, w in zip(Ws, in_w)) or not Fh.multimlp_supported(X.shape[0], X, Ws, x_cols):
+            return None if d == 0 else _tails_one_by_one(mods, X, in_w, B, N, first=1)
+        gamma = Fh.row_blocks([l[2].weight for l in layer], rehome=own)
+        beta = Fh.row_blocks([l[2].bias for l in layer], rehome=own)
+        bufs = [_bn_buffers(l[2], training) for l in layer]
+        rm, rv = Fh.merged_buffers([b[0] for b in bufs], rehome=own), Fh.merged_buffers([b[1] for b in bufs], rehome=own)
+        chan = Fh.channel_params(X.device, tuple((W.shape[0], float(l[3]), l[4] > 0) for W, l in zip(Ws, layer)))
+        X = Fh.multimlp(X, [(xc, W, l[1]) for xc, W, l in zip(x_cols, Ws, layer)], gamma, beta, rm.tensor, rv.tensor, chan,
+                        training=training, p_drop=(rates.pop() if rates else 0.0), momentum=bn0.momentum, eps=bn0.eps)
+        if training:
+            rm.writeback()
+            rv.writeback()
+        in_w = [W.shape[0] for W in Ws]
+    slices, cols = Fh.split_columns_shared(X, in_w)
+    outs, col = [], 0
+    for m, sl in zip(mods, slices):
+        outs.append(m.tail_final(sl, B, N, grad_cols=(cols, col)))
+        col += sl.shape[1]
+    return outs
+
+
+def _tails_one_by_one(mods, X, in_w, B, N, first):
+    """fallback of merged_tails after its first merged depth: the remaining layers head by head on their column slices of X"""
+    slices, cols = Fh.split_columns_shared(X, in_w)
+    outs, col = [], 0
+    for m, sl in zip(mods, slices):
+        outs.append(m.tail_from(sl, B, N, first, grad_cols=(cols, col)))
+        col += sl.shape[1]
+    return outs
 
 
 def can_merge_first_layers(heads):
@@ -116,6 +172,20 @@ class _RegionHead(nn.Module):
     def rows_from_first(self, h1, B, N, grad_cols=None):
         """the layers after conv1/bn1/dp1, on this head's column slice of merged_first_layers()"""
         return self._tail(h1, B, N, grad_cols=grad_cols)
+
+    def tail_spec(self):
+        """the two Linear + BatchNorm + ReLU (+dropout) layers after conv1: (W, bias, bn, negative-side factor, dropout rate)"""
+        return [(self.conv2.weight.view(self.of2, self.of1), self.conv2.bias, self.bn2, 0.0, self.dp2.p),
+                (self.conv3.weight.view(self.of3, self.of2), self.conv3.bias, self.bn3, 0.0, 0.0)]
+
+    def tail_final(self, h, B, N, grad_cols=None):
+        h = Fh.pointmlp(h, self.conv4.weight.view(3, self.of3), training=self.training, grad_cols=grad_cols)
+        return h.view(B, N, 3)
+
+    def tail_from(self, h, B, N, first, grad_cols=None):
+        assert first == 1
+        h = _bn_layer(h, self.conv3, self.bn3, self.training, Fh.ACT_RELU, grad_cols=grad_cols)
+        return self.tail_final(h, B, N)
 
     @flushing_forward
     def forward(self, x):
@@ -170,6 +240,22 @@ class Density_prediction(nn.Module):
 
     def rows_from_first(self, h1, B, N, grad_cols=None):
         return self._tail(h1, grad_cols=grad_cols)
+
+    def tail_spec(self):
+        out = []
+        for mlp, dp in ((self.mlp1, self.dp1), (self.mlp2, self.dp2)):        # dp1 follows conv1 AND mlp1 (Models.py:273,278)
+            lin, bn = mlp.fc[0], mlp.fc[1]
+            out.append((lin.weight, lin.bias, bn, 0.2 if mlp.act == Fh.ACT_LRELU else 0.0, dp.p))
+        return out
+
+    def tail_final(self, h, B, N, grad_cols=None):
+        logits = Fh.pointmlp(h, self.mlp3.weight, bias=self.mlp3.bias, training=self.training, grad_cols=grad_cols)
+        return Fh.density_tail(logits, self.fc2.weight)
+
+    def tail_from(self, h, B, N, first, grad_cols=None):
+        assert first == 1
+        h = self.mlp2(h, p_drop=self.dp2.p, grad_cols=grad_cols)
+        return self.tail_final(h, B, N)
 
     @flushing_forward
     def forward(self, x):
@@ -302,12 +388,18 @@ class DGCNN(nn.Module):
         if visualization:
             return x5
         if merge:
-            # every head's first layer reads the same [x_cat | x5]: ONE wide layer, then each head continues on its column slice
-            slices, cols = merged_first_layers([h for _, h in heads], aliases[1], x5, N, grad_accum=acc)
-            col = 0
-            for (key, head), h1 in zip(heads, slices):
-                out = head.rows_from_first(h1, B, N, grad_cols=(cols, col))
-                col += h1.shape[1]
+            # every head's first layer reads the same [x_cat | x5]: ONE wide layer; then the heads continue depth by depth in shared
+            # wide matrices (merged_tails), or one by one on their column slices of h1 where that does not apply
+            mods = [h for _, h in heads]
+            h1, widths = merged_first_layers(mods, aliases[1], x5, N, grad_accum=acc)
+            outs = merged_tails(mods, h1, widths, B, N) if MERGE_HEAD_TAILS else None
+            if outs is None:
+                slices, cols = Fh.split_columns_shared(h1, widths)
+                outs, col = [], 0
+                for head, sl in zip(mods, slices):
+                    outs.append(head.rows_from_first(sl, B, N, grad_cols=(cols, col)))
+                    col += sl.shape[1]
+            for (key, _), out in zip(heads, outs):
                 if key == "density":
                     logits['density'], logits['density_mse'] = out
                 else:

@@ -83,12 +83,22 @@ SIGNATURES = {
     "mlsp_transform3_bwd_f32": [_P, _P, _P, _I, _I, _P, _P, _P],
     "mlsp_collapse_to_point_f32": [_P, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P],
     "mlsp_scan_select_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _P],
+    "mlsp_multimlp_supported": [_I, _P, _I],
+    "mlsp_multimlp_fwd_f32": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _F, _F, _I, _P, _F, _U64, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_multimlp_bwd_f32": [_P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _F, _U64, _P, _I, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_set_gemm_precision": [_I],
     "mlsp_profile_begin": [],
     "mlsp_profile_end": [_P],
     "mlsp_profile_classes": [_P, _I],
     "mlsp_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _SZ, _P],
 }
+
+
+class Seg(_c.Structure):
+    """mlsp_seg_t of include/mlsp_hip.h"""
+    _fields_ = [("W", _P), ("bias", _P), ("ldw", _I), ("x_col", _I), ("Cin", _I), ("Cout", _I)]
+
+
 _RESTYPE = {"mlsp_strerror": _c.c_char_p, "mlsp_workspace_bytes": _SZ}
 
 _lib = None

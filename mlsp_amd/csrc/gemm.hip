@@ -40,7 +40,8 @@ struct GemmArgs {
     // activated output while it is staged: act(x * scale[c] + shift[c]), dropout by the counter hash of element row * x_ld + c.
     // XF == 1: A is [M][K] row-major, c = k.  XF == 2: B is [K][N] k-major (the wgrad's X), c = n.
     const float* x_scale; const float* x_shift; int x_act; float x_slope; uint32_t x_thresh; float x_inv_keep; uint64_t x_seed; int x_ld;
-    double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][N] (BN batch statistics)
+    double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][stat_ld] (BN batch statistics)
+    int stat_ld;                    // columns of a statistics row (N, or the width of the wider matrix C is a column slice of)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
     float* sel_val; int* sel_row;   // [ntm][N] extreme of each 128-row panel and the global row attaining it (first occurrence)
 };
@@ -276,8 +277,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
         }
         __syncthreads();
         if (tid < 128 && n0 + tid < p.N) {
-            p.stat_part[((size_t)tm * 2 + 0) * p.N + n0 + tid] = (double)red[0 * 128 + tid] + (double)red[2 * 128 + tid];
-            p.stat_part[((size_t)tm * 2 + 1) * p.N + n0 + tid] = (double)red[1 * 128 + tid] + (double)red[3 * 128 + tid];
+            p.stat_part[((size_t)tm * 2 + 0) * p.stat_ld + n0 + tid] = (double)red[0 * 128 + tid] + (double)red[2 * 128 + tid];
+            p.stat_part[((size_t)tm * 2 + 1) * p.stat_ld + n0 + tid] = (double)red[1 * 128 + tid] + (double)red[3 * 128 + tid];
         }
     }
 }
@@ -590,8 +591,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_n64_kernel(GemmArgs p) {
         }
         __syncthreads();
         if (tid < 64) {
-            p.stat_part[((size_t)tm * 2 + 0) * p.N + tid] = ((double)red[0 * 64 + tid] + (double)red[2 * 64 + tid]) + ((double)red[4 * 64 + tid] + (double)red[6 * 64 + tid]);
-            p.stat_part[((size_t)tm * 2 + 1) * p.N + tid] = ((double)red[1 * 64 + tid] + (double)red[3 * 64 + tid]) + ((double)red[5 * 64 + tid] + (double)red[7 * 64 + tid]);
+            p.stat_part[((size_t)tm * 2 + 0) * p.stat_ld + tid] = ((double)red[0 * 64 + tid] + (double)red[2 * 64 + tid]) + ((double)red[4 * 64 + tid] + (double)red[6 * 64 + tid]);
+            p.stat_part[((size_t)tm * 2 + 1) * p.stat_ld + tid] = ((double)red[1 * 64 + tid] + (double)red[3 * 64 + tid]) + ((double)red[5 * 64 + tid] + (double)red[7 * 64 + tid]);
         }
     }
 }
@@ -1008,7 +1009,9 @@ bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, in
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                 size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
-                int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr) {
+                int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0) {
+    // stat_ld (0: N): C is a column slice of a [M][stat_ld] matrix whose BatchNorm statistics are taken as ONE vector (multi.hip):
+    // stat_part points at this slice's first column of the [panels][2][stat_ld] partial rows
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
     if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
     // one tiny dimension (3 coordinates, 3 / 16 outputs): streaming VALU kernels priced against HBM, not MFMA tiles (thin.hip)
@@ -1032,7 +1035,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     p.accumulate = accumulate ? 1 : 0;
     p.fast_out = 0;
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
-    p.stat_part = stat_part;
+    p.stat_part = stat_part; p.stat_ld = stat_ld > 0 ? stat_ld : N;
     p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
     p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0;
     if (xf) {
@@ -1130,7 +1133,7 @@ int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const 
     if (ns > 1 && c_bf16) return MLSP_ERR_UNSUPPORTED;                   // a split result is reduced in fp32
     if (stat_part && ns != 1) return MLSP_ERR_ARG;
     p.accumulate = accumulate ? 1 : 0; p.c_bf16 = c_bf16; p.fast_out = 0;
-    p.stat_part = stat_part; p.sel_gamma = nullptr; p.sel_val = nullptr; p.sel_row = nullptr;
+    p.stat_part = stat_part; p.stat_ld = N; p.sel_gamma = nullptr; p.sel_val = nullptr; p.sel_row = nullptr;
     const int ktiles = (K + BK - 1) / BK;
     const int kts = (ktiles + ns - 1) / ns;
     ns = (ktiles + kts - 1) / kts;

@@ -1,0 +1,279 @@
+// Several Linear (+bias) layers SIDE BY SIDE under ONE BatchNorm + activation (+dropout) pass.
+//
+// The three masked-local-structure heads (PointDA/Models.py:165-285) are three stacks of the same depth on the same points:
+//   position / normal head   conv2 256->256 + bn2 + ReLU + dropout | conv3 256->128 + bn3 + ReLU        (:193-196, :227-230)
+//   cardinality head         mlp1  512->256 + BN + LeakyReLU + dropout | mlp2 256->256 + BN + LeakyReLU + dropout  (:274-279)
+// BatchNorm, the activation and dropout are per-channel operations, so layer d of all heads can live in ONE [M][sum Cout] matrix:
+// each head's Linear writes its column slice (its own GEMM launch, BatchNorm sums out of the GEMM epilogue into the slice's
+// columns of one partial buffer), and ONE statistics finalisation + ONE streaming pass serve all of them.  Backward likewise: one
+// reduction, one finalisation, one apply pass, then per head the dgrad into its column slice of dX and the wgrad.
+// Per channel the activation is max(a, slope_c * a) (slope 0 = ReLU, 0.2 = LeakyReLU, 1 = none) and dropout is on or off
+// (chan [2][C]: slope row, dropout-switch row); all dropout channels share one rate.
+// Versus one mlsp_pointmlp_* call per head: 2 finalisations + 2 streaming launches fewer per layer forward, 6 fewer backward.
+#include "common.h"
+#include "../../include/mlsp_hip.h"
+
+int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
+                double* stat_part, const float* sel_gamma, float* sel_val, int* sel_row, bool accumulate, const GemmXf* xf, int stat_ld);
+int gemm_panel_rows(int M, int N, int K);
+int gemm_stat_parts(int M, int N, int K);
+size_t gemm_slab_floats(int M, int N, int K);
+int bn_vec_parts(int M);
+int launch_colstats_n(hipStream_t st, const float* Y, int M, int C, int ld, double* part, int* nparts_out);
+int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
+                       const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
+                       float* shift, float* save_mean, float* save_invstd);
+int launch_bn_eval_prepare(hipStream_t st, int C, const float* gamma, const float* beta, const float* run_mean,
+                           const float* run_var, float eps, float* scale, float* shift, float* save_mean, float* save_invstd);
+int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
+                           float* mean_dz, float* mean_dzy);
+int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out);
+
+#define MROWS 64          // rows per workgroup of the streaming passes (== VROWS of bn.hip: bn_vec_parts)
+
+// ---- streaming passes with per-channel activation parameters: a thread owns 4 consecutive channels and walks rows -------------------
+// tpr = C / 4 threads cover a row (16-byte accesses), nrg = 256 / tpr rows per step; threads beyond nrg * tpr idle (C = 768: 64 of 256)
+__global__ __launch_bounds__(256) void multi_act_fwd_kernel(const float* __restrict__ Y, float* __restrict__ Z, int M, int C,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ chan, uint32_t thresh, float inv_keep,
+                                                            uint64_t seed) {
+    const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
+    const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
+    if (rg >= nrg) return;
+    const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+    const f32x4 sl = *(const f32x4*)(chan + c), dr = *(const f32x4*)(chan + C + c);
+    const bool anyd = thresh && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f);
+    const int r0 = blockIdx.x * MROWS, r1 = min(M, r0 + MROWS);
+    for (int r = r0 + rg; r < r1; r += nrg) {
+        const size_t i = (size_t)r * C + c;
+        const f32x4 y = *(const f32x4*)(Y + i);
+        const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = fmaf(y[e], sc[e], sh[e]);
+            a = a > 0.f ? a : a * sl[e];
+            if (thresh && dr[e] != 0.f) a = ((hq >> (8 * e)) & 255u) >= thresh ? a * inv_keep : 0.f;
+            o[e] = a;
+        }
+        *(f32x4*)(Z + i) = o;
+    }
+}
+
+// gradient w.r.t. the BatchNorm output of element e of an aligned quad (hash hq of the quad)
+__device__ __forceinline__ float multi_dz_prime(float dz, float y, float sc, float sh, float sl, float dr, uint32_t thresh, float inv_keep,
+                                                uint32_t hq, int e) {
+    if (thresh && dr != 0.f) dz = ((hq >> (8 * e)) & 255u) >= thresh ? dz * inv_keep : 0.f;
+    const float a = fmaf(y, sc, sh);
+    if (!(a > 0.f)) dz *= sl;
+    return dz;
+}
+
+__global__ __launch_bounds__(256) void multi_bwd_reduce_kernel(const float* __restrict__ dZ, const float* __restrict__ Y, int M, int C,
+                                                               const float* __restrict__ bn, const float* __restrict__ chan,
+                                                               uint32_t thresh, float inv_keep, uint64_t seed, double* __restrict__ part) {
+    __shared__ double shd[256 * 8];
+    const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
+    const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (rg < nrg) {
+        const f32x4 sc = *(const f32x4*)(bn + c), sh = *(const f32x4*)(bn + C + c);
+        const f32x4 mu = *(const f32x4*)(bn + 2 * C + c), is = *(const f32x4*)(bn + 3 * C + c);
+        const f32x4 sl = *(const f32x4*)(chan + c), dr = *(const f32x4*)(chan + C + c);
+        const bool anyd = thresh && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f);
+        const int r0 = blockIdx.x * MROWS, r1 = min(M, r0 + MROWS);
+        for (int r = r0 + rg; r < r1; r += nrg) {
+            const size_t i = (size_t)r * C + c;
+            const f32x4 y = *(const f32x4*)(Y + i), dz = *(const f32x4*)(dZ + i);
+            const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = multi_dz_prime(dz[e], y[e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
+                s[e] += d; q[e] += (double)d * ((y[e] - mu[e]) * is[e]);
+            }
+        }
+    }
+    // sum over the row groups, in group order; one partial row [2][C] per workgroup
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { shd[tid * 8 + e] = s[e]; shd[tid * 8 + 4 + e] = q[e]; }
+    __syncthreads();
+    if (tid < tpr) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < nrg; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += shd[(g * tpr + tid) * 8 + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            part[((size_t)blockIdx.x * 2 + 0) * C + tid * 4 + e] = a[e];
+            part[((size_t)blockIdx.x * 2 + 1) * C + tid * 4 + e] = a[4 + e];
+        }
+    }
+}
+
+// dY = scale * (dz' - mean_dz - yhat * mean_dzy)   (mean_dz == null: eval mode, dY = scale * dz')
+__global__ __launch_bounds__(256) void multi_bwd_apply_kernel(const float* __restrict__ dZ, const float* __restrict__ Y, float* __restrict__ dY,
+                                                              int M, int C, const float* __restrict__ bn, const float* __restrict__ chan,
+                                                              const float* __restrict__ mean_dz, const float* __restrict__ mean_dzy,
+                                                              uint32_t thresh, float inv_keep, uint64_t seed) {
+    const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
+    const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
+    if (rg >= nrg) return;
+    const f32x4 sc = *(const f32x4*)(bn + c), sh = *(const f32x4*)(bn + C + c);
+    const f32x4 sl = *(const f32x4*)(chan + c), dr = *(const f32x4*)(chan + C + c);
+    const bool anyd = thresh && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f);
+    f32x4 mu = {0, 0, 0, 0}, k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0};
+    if (mean_dz) {
+        mu = *(const f32x4*)(bn + 2 * C + c);
+        k1 = *(const f32x4*)(mean_dz + c);
+        const f32x4 is = *(const f32x4*)(bn + 3 * C + c), mz = *(const f32x4*)(mean_dzy + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k2[e] = is[e] * mz[e];
+    }
+    const int r0 = blockIdx.x * MROWS, r1 = min(M, r0 + MROWS);
+    for (int r = r0 + rg; r < r1; r += nrg) {
+        const size_t i = (size_t)r * C + c;
+        const f32x4 y = *(const f32x4*)(Y + i), dz = *(const f32x4*)(dZ + i);
+        const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = multi_dz_prime(dz[e], y[e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
+            d = d - k1[e] - (y[e] - mu[e]) * k2[e];
+            o[e] = sc[e] * d;
+        }
+        *(f32x4*)(dY + i) = o;
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------------
+#define MCHECK(x) do { int _r = (x); if (_r != MLSP_OK) return _r; } while (0)
+
+static int multi_check(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, int& Ctot, int& xw) {
+    if (!X || !segs || nseg < 1 || nseg > 8 || M <= 32) return MLSP_ERR_ARG;
+    Ctot = 0; xw = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const mlsp_seg_t& g = segs[s];
+        if (!g.W || g.Cin <= 0 || g.Cout <= 0 || g.ldw < g.Cin || g.x_col < 0 || g.x_col + g.Cin > ldx) return MLSP_ERR_ARG;
+        if (g.Cout % 4 || g.x_col % 4 || g.Cin % 4) return MLSP_ERR_UNSUPPORTED;          // 16-byte column slices
+        Ctot += g.Cout;
+        if (g.x_col + g.Cin > xw) xw = g.x_col + g.Cin;
+    }
+    if (Ctot > 1024) return MLSP_ERR_UNSUPPORTED;
+    return MLSP_OK;
+}
+
+extern "C" {
+
+int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg) {
+    int Ctot = 0, xw = 0;
+    if (!segs || nseg < 1) return 0;
+    int ldx = 0;
+    for (int s = 0; s < nseg; ++s) ldx = segs[s].x_col + segs[s].Cin > ldx ? segs[s].x_col + segs[s].Cin : ldx;
+    static const float dummy = 0.f;
+    if (multi_check(&dummy, ldx, M, segs, nseg, Ctot, xw) != MLSP_OK) return 0;
+    return 1;
+}
+
+int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* gamma, const float* beta,
+                          float* run_mean, float* run_var, float momentum, float eps, int training, const float* chan, float p_drop,
+                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    int Ctot, xw;
+    MCHECK(multi_check(X, ldx, M, segs, nseg, Ctot, xw));
+    if (!gamma || !beta || !chan || !Y || !Z || !bn_save || p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
+    if (!training && (!run_mean || !run_var)) return MLSP_ERR_ARG;
+    if (!mlsp_multimlp_supported(M, segs, nseg)) return MLSP_ERR_UNSUPPORTED;
+    if ((((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)chan | (uintptr_t)bn_save) & 15) != 0) return MLSP_ERR_UNSUPPORTED;
+    Workspace w(ws, ws_bytes);
+    // BatchNorm sums out of the GEMM epilogues when every segment uses the same row-panel height (their partial rows then line up)
+    bool fused = training != 0;
+    const int bm = gemm_panel_rows(M, segs[0].Cout, segs[0].Cin);
+    for (int s = 0; s < nseg && fused; ++s)
+        fused = gemm_stat_parts(M, segs[s].Cout, segs[s].Cin) > 0 && gemm_panel_rows(M, segs[s].Cout, segs[s].Cin) == bm;
+    int nparts = fused ? (M + bm - 1) / bm : bn_vec_parts(M);
+    const int npmax = nparts > bn_vec_parts(M) ? nparts : bn_vec_parts(M);
+    double* part = w.take<double>((size_t)(npmax > (M + 255) / 256 ? npmax : (M + 255) / 256) * 2 * Ctot);
+    size_t sf = 0;                                             // (small M: a segment's GEMM may split K; then the statistics are a separate pass)
+    for (int s = 0; s < nseg; ++s) { const size_t f = gemm_slab_floats(M, segs[s].Cout, segs[s].Cin); sf = f > sf ? f : sf; }
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    int ycol = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const mlsp_seg_t& g = segs[s];
+        MCHECK(launch_gemm(st, false, true, M, g.Cout, g.Cin, X + g.x_col, ldx, g.W, g.ldw, Y + ycol, Ctot, g.bias, nullptr, 0, slab, sf,
+                           fused ? part + ycol : nullptr, nullptr, nullptr, nullptr, false, nullptr, Ctot));
+        ycol += g.Cout;
+    }
+    float* scale = bn_save, *shift = bn_save + Ctot, *mean = bn_save + 2 * Ctot, *invstd = bn_save + 3 * Ctot;
+    if (training) {
+        if (!fused) MCHECK(launch_colstats_n(st, Y, M, Ctot, Ctot, part, &nparts));
+        MCHECK(launch_bn_finalize(st, part, nparts, (double)M, Ctot, gamma, beta, run_mean, run_var, momentum, eps, scale, shift, mean, invstd));
+    } else {
+        MCHECK(launch_bn_eval_prepare(st, Ctot, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
+    }
+    const float pd = training ? p_drop : 0.f;
+    hipLaunchKernelGGL(multi_act_fwd_kernel, dim3(bn_vec_parts(M)), dim3(256), 0, st, Y, Z, M, Ctot, scale, shift, chan, dropout_thresh8(pd),
+                       dropout_inv_keep8(pd), seed);
+    return mlsp_launch_status();
+}
+
+int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* Y,
+                          const float* bn_save, int training, const float* chan, float p_drop, uint64_t seed, float* dX, int lddx,
+                          float* const* dW, float* dbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    int Ctot, xw;
+    MCHECK(multi_check(X, ldx, M, segs, nseg, Ctot, xw));
+    if (!dZ || !Y || !bn_save || !chan || !dW || !dgamma || !dbeta || (dX && lddx < xw)) return MLSP_ERR_ARG;
+    if (!mlsp_multimlp_supported(M, segs, nseg)) return MLSP_ERR_UNSUPPORTED;
+    if ((((uintptr_t)Y | (uintptr_t)dZ | (uintptr_t)chan | (uintptr_t)bn_save) & 15) != 0) return MLSP_ERR_UNSUPPORTED;
+    Workspace w(ws, ws_bytes);
+    float* dY = w.take<float>((size_t)M * Ctot);
+    const int nparts = bn_vec_parts(M);
+    double* part = w.take<double>((size_t)nparts * 2 * Ctot);
+    float* mean_dz = w.take<float>(Ctot);
+    float* mean_dzy = w.take<float>(Ctot);
+    size_t sf = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const size_t f = gemm_slab_floats(segs[s].Cout, segs[s].Cin, M), f2 = dX ? gemm_slab_floats(M, segs[s].Cin, segs[s].Cout) : 0;
+        sf = f > sf ? f : sf; sf = f2 > sf ? f2 : sf;
+    }
+    float* slab = sf ? w.take<float>(sf) : nullptr;
+    if (!w.ok()) return MLSP_ERR_WORKSPACE;
+    const float pd = training ? p_drop : 0.f;
+    const uint32_t th = dropout_thresh8(pd);
+    const float ik = dropout_inv_keep8(pd);
+    hipLaunchKernelGGL(multi_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, Ctot, bn_save, chan, th, ik, seed, part);
+    MCHECK(launch_bn_bwd_finalize(st, part, nparts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy));
+    hipLaunchKernelGGL(multi_bwd_apply_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, dY, M, Ctot, bn_save, chan,
+                       training ? mean_dz : (const float*)nullptr, mean_dzy, th, ik, seed);
+    MCHECK(mlsp_launch_status());
+    int ycol = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const mlsp_seg_t& g = segs[s];
+        if (!dW[s]) return MLSP_ERR_ARG;
+        if (dX) {
+            bool acc = false;                                  // a second segment on the same input columns adds (partial overlaps: rejected)
+            for (int t = 0; t < s; ++t) {
+                const bool same = segs[t].x_col == g.x_col && segs[t].Cin == g.Cin;
+                const bool apart = segs[t].x_col + segs[t].Cin <= g.x_col || g.x_col + g.Cin <= segs[t].x_col;
+                if (!same && !apart) return MLSP_ERR_UNSUPPORTED;
+                acc |= same;
+            }
+            MCHECK(launch_gemm(st, false, false, M, g.Cin, g.Cout, dY + ycol, Ctot, g.W, g.ldw, dX + g.x_col, lddx, nullptr, nullptr, 0, slab, sf,
+                               nullptr, nullptr, nullptr, nullptr, acc, nullptr, 0));
+        }
+        MCHECK(launch_gemm(st, true, false, g.Cout, g.Cin, M, dY + ycol, Ctot, X + g.x_col, ldx, dW[s], g.Cin, nullptr, nullptr, 0, slab, sf,
+                           nullptr, nullptr, nullptr, nullptr, false, nullptr, 0));
+        ycol += g.Cout;
+    }
+    if (dbias) {
+        if (training) {      // a bias in front of a batch-statistics BatchNorm: analytically zero gradient
+            hipError_t e = hipMemsetAsync(dbias, 0, (size_t)Ctot * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        } else {
+            MCHECK(launch_colsum(st, dY, M, Ctot, part, dbias));
+        }
+    }
+    return MLSP_OK;
+}
+
+}  // extern "C"

@@ -441,6 +441,115 @@ def split_columns_shared(H, widths):
     return _SplitColumnsShared.apply(H, acc, tuple(widths)), acc
 
 
+class _MultiMLP(Function):
+    """Several Linear (+bias) layers side by side under ONE BatchNorm + activation (+dropout) pass (include/mlsp_hip.h
+    mlsp_multimlp_*_f32; csrc/multi.hip).  X [M, ldx] fp32; segment s reads columns x_cols[s] .. + Cin_s and writes its Cout_s columns."""
+
+    @staticmethod
+    def forward(ctx, X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, *wb):
+        lib = _lib.load()
+        n = len(x_cols)
+        Ws, bs = list(wb[:n]), list(wb[n:])
+        X = _rows(X)
+        _lib.require_gpu(X, gamma, chan, *Ws)
+        Ws = [w if w.stride(1) == 1 else w.contiguous() for w in Ws]
+        bs = [b.contiguous() if b is not None else None for b in bs]
+        M = X.shape[0]
+        Ctot = sum(w.shape[0] for w in Ws)
+        dev = X.device
+        segs = (_lib.Seg * n)()
+        for i, (w, b, xc) in enumerate(zip(Ws, bs, x_cols)):
+            segs[i].W, segs[i].bias, segs[i].ldw, segs[i].x_col, segs[i].Cin, segs[i].Cout = w.data_ptr(), _lib.ptr(b), w.stride(0), xc, w.shape[1], w.shape[0]
+        Y = torch.empty((M, Ctot), dtype=torch.float32, device=dev)
+        Z = torch.empty((M, Ctot), dtype=torch.float32, device=dev)
+        bn_save = torch.empty((4, Ctot), dtype=torch.float32, device=dev)
+        p = float(p_drop) if training else 0.0
+        ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
+        _lib.check(lib.mlsp_multimlp_fwd_f32(X.data_ptr(), X.stride(0), M, segs, n, gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean),
+                                             _lib.ptr(run_var), momentum, eps, int(training), chan.data_ptr(), p, seed, Y.data_ptr(),
+                                             Z.data_ptr(), bn_save.data_ptr(), ws, wsn, _lib.stream()), "mlsp_multimlp_fwd_f32")
+        ctx.save_for_backward(X, Y, bn_save, chan, *Ws)
+        ctx.cfg = (tuple(x_cols), bool(training), p, seed, [b is not None for b in bs])
+        ctx.mark_non_differentiable(bn_save)
+        ctx.set_materialize_grads(False)
+        return Z, bn_save
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dZ, _dbn=None):
+        x_cols, training, p, seed, has_b = ctx.cfg
+        n = len(x_cols)
+        if dZ is None:
+            return (None,) * (12 + 2 * n)
+        lib = _lib.load()
+        X, Y, bn_save, chan = ctx.saved_tensors[:4]
+        Ws = ctx.saved_tensors[4:]
+        dZ = dZ.contiguous()
+        M, Ctot = Y.shape
+        dev = dZ.device
+        segs = (_lib.Seg * n)()
+        for i, (w, xc) in enumerate(zip(Ws, x_cols)):
+            segs[i].W, segs[i].bias, segs[i].ldw, segs[i].x_col, segs[i].Cin, segs[i].Cout = w.data_ptr(), None, w.stride(0), xc, w.shape[1], w.shape[0]
+        dX = None
+        if ctx.needs_input_grad[0]:
+            covered = sorted((xc, xc + w.shape[1]) for xc, w in zip(x_cols, Ws))
+            full = covered[0][0] == 0 and covered[-1][1] == X.shape[1] and all(a[1] >= b[0] for a, b in zip(covered, covered[1:]))
+            dX = (torch.empty if full else torch.zeros)((M, X.shape[1]), dtype=torch.float32, device=dev)
+        dWs = [torch.empty((w.shape[0], w.shape[1]), dtype=torch.float32, device=dev) for w in Ws]
+        dwp = (_lib._c.c_void_p * n)(*[d.data_ptr() for d in dWs])
+        dbias = torch.empty((Ctot,), dtype=torch.float32, device=dev) if any(has_b) else None
+        dgamma = torch.empty((Ctot,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((Ctot,), dtype=torch.float32, device=dev)
+        ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
+        _lib.check(lib.mlsp_multimlp_bwd_f32(dZ.data_ptr(), X.data_ptr(), X.stride(0), M, segs, n, Y.data_ptr(), bn_save.data_ptr(),
+                                             int(training), chan.data_ptr(), p, seed, _lib.ptr(dX), dX.stride(0) if dX is not None else 0,
+                                             dwp, _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()),
+                   "mlsp_multimlp_bwd_f32")
+        dbs, o = [], 0
+        for w, hb in zip(Ws, has_b):
+            dbs.append(dbias[o:o + w.shape[0]] if hb else None)
+            o += w.shape[0]
+        return (dX, dgamma, dbeta) + (None,) * 9 + tuple(dWs) + tuple(dbs)
+
+
+_chan_cache = {}
+
+
+def channel_params(device, spec):
+    """[2, C] device tensor of per-channel activation parameters for multimlp, built once per configuration:
+    spec = ((Cout, negative-side factor, dropout on), ...) per segment."""
+    key = (device, tuple(spec))
+    t = _chan_cache.get(key)
+    if t is None:
+        sl = torch.cat([torch.full((c,), float(f)) for c, f, _ in spec])
+        dr = torch.cat([torch.full((c,), 1.0 if d else 0.0) for c, _, d in spec])
+        t = _chan_cache[key] = torch.stack((sl, dr)).contiguous().to(device)
+    return t
+
+
+def multimlp_supported(M, X, Ws, x_cols):
+    if (activation_storage.current != "fp32" or gemm_precision.current != "fp32" or X.dtype != torch.float32 or X.dim() != 2
+            or X.stride(1) != 1 or not X.is_cuda):
+        return False
+    n = len(Ws)
+    segs = (_lib.Seg * n)()
+    for i, (w, xc) in enumerate(zip(Ws, x_cols)):
+        segs[i].W, segs[i].bias, segs[i].ldw, segs[i].x_col, segs[i].Cin, segs[i].Cout = 0, None, w.shape[1], xc, w.shape[1], w.shape[0]
+    return bool(_lib.load().mlsp_multimlp_supported(int(M), segs, n))
+
+
+def multimlp(X, segs, gamma, beta, run_mean, run_var, chan, training=True, p_drop=0.0, momentum=0.1, eps=1e-5):
+    """segs = [(x_col, W [Cout, Cin], bias | None), ...] -> Z [M, sum Cout]: every segment's Linear on its column slice of X, then ONE
+    BatchNorm (batch statistics over the M rows, all channels), per-channel activation and dropout (chan from channel_params)."""
+    x_cols = tuple(int(s[0]) for s in segs)
+    Ws = [s[1] for s in segs]
+    bs = [s[2] for s in segs]
+    any_drop = training and p_drop > 0
+    seed = _next_seed() if any_drop else 0
+    out, _ = _MultiMLP.apply(X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, *Ws, *bs)
+    return out
+
+
 class _EdgeConv(Function):
     @staticmethod
     def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out_buf=None, grad_accum=None):

@@ -446,6 +446,77 @@ def test_skinny_dropout_mask_consistent_fwd_bwd(dev):
         assert err < 2e-3, (name, err)
 
 
+# ----------------------------------------------------------------------------- several Linear layers under one BatchNorm pass
+@pytest.mark.parametrize("M,training", [(32768, True), (2048, True), (4096, False)])
+def test_multimlp_vs_one_pointmlp_per_segment(dev, M, training):
+    """csrc/multi.hip: three Linear layers side by side (two 256->256 without bias, one 512->256 with bias; ReLU / ReLU / LeakyReLU)
+    under ONE BatchNorm + activation pass against one Fh.pointmlp per segment: outputs, input gradient, weight / bias / BatchNorm
+    gradients and running statistics.  M = 32768: statistics out of the GEMM epilogues; M = 2048: split-K segments."""
+    Fh = _fh()
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(M, 1024, generator=g).to(dev)
+    specs = [(0, 256, 256, False, Fh.ACT_RELU, 0.0), (256, 256, 256, False, Fh.ACT_RELU, 0.0), (512, 512, 256, True, Fh.ACT_LRELU, 0.2)]
+    Ws = [(torch.randn(co, ci, generator=g) / ci ** 0.5).to(dev) for _, ci, co, _, _, _ in specs]
+    bs = [(0.1 * torch.randn(co, generator=g)).to(dev) if hb else None for _, _, co, hb, _, _ in specs]
+    gam = [(torch.rand(co, generator=g) + 0.5).to(dev) * (1 if i else -1) for i, (_, _, co, _, _, _) in enumerate(specs)]
+    bet = [(0.1 * torch.randn(co, generator=g)).to(dev) for _, _, co, _, _, _ in specs]
+    wout = torch.randn(M, 768, generator=g).to(dev)
+
+    def run(multi):
+        x = X.clone().requires_grad_(True)
+        ws = [w.clone().requires_grad_(True) for w in Ws]
+        bb = [b.clone().requires_grad_(True) if b is not None else None for b in bs]
+        gs = [t.clone().requires_grad_(True) for t in gam]
+        be = [t.clone().requires_grad_(True) for t in bet]
+        rms = [torch.zeros(256, device=dev) for _ in specs]
+        rvs = [torch.ones(256, device=dev) for _ in specs]
+        if multi:
+            chan = Fh.channel_params(dev, tuple((co, sl, False) for _, _, co, _, _, sl in specs))
+            rm, rv = Fh.merged_buffers(rms, rehome=False), Fh.merged_buffers(rvs, rehome=False)
+            assert Fh.multimlp_supported(M, x, ws, [sp[0] for sp in specs])
+            z = Fh.multimlp(x, [(sp[0], w, b) for sp, w, b in zip(specs, ws, bb)], torch.cat(gs), torch.cat(be), rm.tensor, rv.tensor, chan,
+                            training=training)
+            rm.writeback(); rv.writeback()
+        else:
+            z = torch.cat([Fh.pointmlp(x[:, xc:xc + ci], w, bias=b, gamma=ga, beta=bt, run_mean=r1, run_var=r2, training=training, act=act)
+                           for (xc, ci, co, hb, act, sl), w, b, ga, bt, r1, r2 in zip(specs, ws, bb, gs, be, rms, rvs)], dim=1)
+        (z * wout).sum().backward()
+        grads = [x.grad] + [w.grad for w in ws] + [b.grad for b in bb if b is not None] + [t.grad for t in gs] + [t.grad for t in be]
+        return z.detach(), grads, rms + rvs
+
+    za, ga_, sa = run(False)
+    zb, gb_, sb = run(True)
+    np.testing.assert_allclose(zb.cpu().numpy(), za.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    for a, b in zip(ga_, gb_):
+        assert ((a - b).norm() / (a.norm() + 1e-20)).item() < 1e-4
+    for a, b in zip(sa, sb):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_multimlp_dropout_per_channel(dev):
+    """dropout switched per channel: the first segment's channels drop with rate 0.5 (zeros, survivors scaled by 2), the second's never;
+    backward uses the same mask (zero input gradient contribution exactly where the output was dropped)."""
+    Fh = _fh()
+    M = 4096
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(M, 256, generator=g).to(dev).requires_grad_(True)
+    W1, W2 = torch.eye(128).to(dev).requires_grad_(True), torch.eye(128).to(dev).requires_grad_(True)
+    gamma, beta = torch.ones(256, device=dev), torch.full((256,), 3.0, device=dev)          # outputs positive: no activation zeros
+    chan = Fh.channel_params(dev, ((128, 1.0, True), (128, 1.0, False)))
+    z = Fh.multimlp(X, [(0, W1, None), (128, W2, None)], gamma, beta, None, None, chan, training=True, p_drop=0.5)
+    dropped = (z[:, :128] == 0)
+    frac = dropped.float().mean().item()
+    assert 0.48 < frac < 0.52 and not (z[:, 128:] == 0).any().item()
+    # survivors are 2 x the un-dropped value
+    z0 = Fh.multimlp(X.detach(), [(0, W1.detach(), None), (128, W2.detach(), None)], gamma, beta, None, None, chan, training=True, p_drop=0.0)
+    np.testing.assert_allclose(z[:, :128][~dropped].detach().cpu().numpy(), 2 * z0[:, :128][~dropped].cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(z[:, 128:].detach().cpu().numpy(), z0[:, 128:].cpu().numpy(), rtol=1e-6)
+    torch.manual_seed(0)
+    wout = torch.randn(M, 256, device=dev)
+    (z * wout).sum().backward()
+    assert torch.isfinite(X.grad).all().item() and torch.isfinite(W1.grad).all().item()
+
+
 # ----------------------------------------------------------------------------- graph feature / max reductions
 def test_graph_feature_fwd_bwd(dev, golden_dir):
     from mlsp_amd import model_utils as mu

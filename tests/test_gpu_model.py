@@ -280,8 +280,9 @@ def test_merged_head_first_layers_equal_separate(dev):
     args = gc.make_args(cuda=True)
     inp = {k: v.to(dev) for k, v in gc.make_inputs(4, 4, 256).items()}
     res = {}
-    for merged in (False, True):
-        Models.MERGE_HEAD_FIRST_LAYERS = merged
+    for merged in (False, True, "tails"):
+        Models.MERGE_HEAD_FIRST_LAYERS = bool(merged)
+        Models.MERGE_HEAD_TAILS = merged == "tails"
         try:
             m = _model(4, dev).train()
             ids = {n: id(p) for n, p in m.named_parameters()}
@@ -299,7 +300,7 @@ def test_merged_head_first_layers_equal_separate(dev):
             assert all(torch.isfinite(p).all().item() for p in m.parameters())
             assert ids == {n: id(p) for n, p in m.named_parameters()}
             adjacent = Fh._adjacent([m.DefRec.conv1.weight, m.Density_cls.conv1.weight, m.Norm_pred.conv1.weight])
-            assert adjacent == merged
+            assert adjacent == bool(merged)
             m2 = copy.deepcopy(m)
             m2.load_state_dict(m.state_dict(), strict=True)
             with torch.no_grad():
@@ -307,8 +308,13 @@ def test_merged_head_first_layers_equal_separate(dev):
             assert all(torch.equal(ev1[k], ev2[k]) for k in ev1)
             res[merged] = (logits, loss.item(), grads, state, two, ev)
         finally:
-            Models.MERGE_HEAD_FIRST_LAYERS = True
-    (la, lossa, ga, sa, twoa, eva), (lb, lossb, gb_, sb, twob, evb) = res[False], res[True]
+            Models.MERGE_HEAD_FIRST_LAYERS = Models.MERGE_HEAD_TAILS = True
+    for other in (True, "tails"):
+        _compare_head_paths(res[False], res[other])
+
+
+def _compare_head_paths(ra, rb):
+    (la, lossa, ga, sa, twoa, eva), (lb, lossb, gb_, sb, twob, evb) = ra, rb
     for k in HEAD_KEYS:
         np.testing.assert_allclose(lb[k].detach().cpu().numpy(), la[k].detach().cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
         np.testing.assert_allclose(evb[k].cpu().numpy(), eva[k].cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg="eval " + k)
