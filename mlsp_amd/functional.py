@@ -534,7 +534,7 @@ def multimlp_supported(M, X, Ws, x_cols):
     n = len(Ws)
     segs = (_lib.Seg * n)()
     for i, (w, xc) in enumerate(zip(Ws, x_cols)):
-        segs[i].W, segs[i].bias, segs[i].ldw, segs[i].x_col, segs[i].Cin, segs[i].Cout = 0, None, w.shape[1], xc, w.shape[1], w.shape[0]
+        segs[i].W, segs[i].bias, segs[i].ldw, segs[i].x_col, segs[i].Cin, segs[i].Cout = 16, None, w.shape[1], xc, w.shape[1], w.shape[0]   # (shape query: W is not read)
     return bool(_lib.load().mlsp_multimlp_supported(int(M), segs, n))
 
 
