@@ -34,7 +34,7 @@ int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, fl
 
 // ---- streaming passes with per-channel activation parameters: a thread owns 4 consecutive channels and walks rows -------------------
 // tpr = C / 4 threads cover a row (16-byte accesses), nrg = 256 / tpr rows per step; threads beyond nrg * tpr idle (C = 768: 64 of 256)
-__global__ __launch_bounds__(256) void multi_act_fwd_kernel(const float* __restrict__ Y, float* __restrict__ Z, int M, int C,
+__global__ __launch_bounds__(256) void multi_act_fwd_kernel(const float* __restrict__ Y, float* __restrict__ Z, int M, int C, int rpb,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ chan, uint32_t thresh, float inv_keep,
                                                             uint64_t seed) {
@@ -44,20 +44,30 @@ __global__ __launch_bounds__(256) void multi_act_fwd_kernel(const float* __restr
     const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
     const f32x4 sl = *(const f32x4*)(chan + c), dr = *(const f32x4*)(chan + C + c);
     const bool anyd = thresh && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f);
-    const int r0 = blockIdx.x * MROWS, r1 = min(M, r0 + MROWS);
-    for (int r = r0 + rg; r < r1; r += nrg) {
-        const size_t i = (size_t)r * C + c;
-        const f32x4 y = *(const f32x4*)(Y + i);
-        const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
-        f32x4 o;
+    const int r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
+    for (int rb = r0 + rg; rb < r1; rb += 4 * nrg) {          // four rows in flight per thread
+        f32x4 y[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float a = fmaf(y[e], sc[e], sh[e]);
-            a = a > 0.f ? a : a * sl[e];
-            if (thresh && dr[e] != 0.f) a = ((hq >> (8 * e)) & 255u) >= thresh ? a * inv_keep : 0.f;
-            o[e] = a;
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb + u * nrg;
+            if (r < r1) y[u] = *(const f32x4*)(Y + (size_t)r * C + c);
         }
-        *(f32x4*)(Z + i) = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb + u * nrg;
+            if (r >= r1) break;
+            const size_t i = (size_t)r * C + c;
+            const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = fmaf(y[u][e], sc[e], sh[e]);
+                a = a > 0.f ? a : a * sl[e];
+                if (thresh && dr[e] != 0.f) a = ((hq >> (8 * e)) & 255u) >= thresh ? a * inv_keep : 0.f;
+                o[e] = a;
+            }
+            *(f32x4*)(Z + i) = o;
+        }
     }
 }
 
@@ -83,14 +93,24 @@ __global__ __launch_bounds__(256) void multi_bwd_reduce_kernel(const float* __re
         const f32x4 sl = *(const f32x4*)(chan + c), dr = *(const f32x4*)(chan + C + c);
         const bool anyd = thresh && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f);
         const int r0 = blockIdx.x * MROWS, r1 = min(M, r0 + MROWS);
-        for (int r = r0 + rg; r < r1; r += nrg) {
-            const size_t i = (size_t)r * C + c;
-            const f32x4 y = *(const f32x4*)(Y + i), dz = *(const f32x4*)(dZ + i);
-            const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
+        for (int rb = r0 + rg; rb < r1; rb += 4 * nrg) {      // four rows in flight per thread; summed in row order
+            f32x4 y[4], dz[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = multi_dz_prime(dz[e], y[e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
-                s[e] += d; q[e] += (double)d * ((y[e] - mu[e]) * is[e]);
+            for (int u = 0; u < 4; ++u) {
+                const int r = rb + u * nrg;
+                if (r < r1) { y[u] = *(const f32x4*)(Y + (size_t)r * C + c); dz[u] = *(const f32x4*)(dZ + (size_t)r * C + c); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rb + u * nrg;
+                if (r >= r1) break;
+                const size_t i = (size_t)r * C + c;
+                const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = multi_dz_prime(dz[u][e], y[u][e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
+                    s[e] += d; q[e] += (double)d * ((y[u][e] - mu[e]) * is[e]);
+                }
             }
         }
     }
@@ -113,7 +133,7 @@ __global__ __launch_bounds__(256) void multi_bwd_reduce_kernel(const float* __re
 
 // dY = scale * (dz' - mean_dz - yhat * mean_dzy)   (mean_dz == null: eval mode, dY = scale * dz')
 __global__ __launch_bounds__(256) void multi_bwd_apply_kernel(const float* __restrict__ dZ, const float* __restrict__ Y, float* __restrict__ dY,
-                                                              int M, int C, const float* __restrict__ bn, const float* __restrict__ chan,
+                                                              int M, int C, int rpb, const float* __restrict__ bn, const float* __restrict__ chan,
                                                               const float* __restrict__ mean_dz, const float* __restrict__ mean_dzy,
                                                               uint32_t thresh, float inv_keep, uint64_t seed) {
     const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
@@ -130,24 +150,42 @@ __global__ __launch_bounds__(256) void multi_bwd_apply_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) k2[e] = is[e] * mz[e];
     }
-    const int r0 = blockIdx.x * MROWS, r1 = min(M, r0 + MROWS);
-    for (int r = r0 + rg; r < r1; r += nrg) {
-        const size_t i = (size_t)r * C + c;
-        const f32x4 y = *(const f32x4*)(Y + i), dz = *(const f32x4*)(dZ + i);
-        const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
-        f32x4 o;
+    const int r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
+    for (int rb = r0 + rg; rb < r1; rb += 4 * nrg) {          // four rows in flight per thread
+        f32x4 y[4], dz[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float d = multi_dz_prime(dz[e], y[e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
-            d = d - k1[e] - (y[e] - mu[e]) * k2[e];
-            o[e] = sc[e] * d;
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb + u * nrg;
+            if (r < r1) { y[u] = *(const f32x4*)(Y + (size_t)r * C + c); dz[u] = *(const f32x4*)(dZ + (size_t)r * C + c); }
         }
-        *(f32x4*)(dY + i) = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb + u * nrg;
+            if (r >= r1) break;
+            const size_t i = (size_t)r * C + c;
+            const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = multi_dz_prime(dz[u][e], y[u][e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
+                d = d - k1[e] - (y[u][e] - mu[e]) * k2[e];
+                o[e] = sc[e] * d;
+            }
+            *(f32x4*)(dY + i) = o;
+        }
     }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------------
 #define MCHECK(x) do { int _r = (x); if (_r != MLSP_OK) return _r; } while (0)
+
+// rows per workgroup of the element-wise passes: enough workgroups for ~8 per CU (a thread keeps four rows in flight)
+static int multi_rows_per_block(int M, int C) {
+    const int nrg = 256 / (C / 4);
+    int rpb = 4 * nrg;                                         // one unrolled step
+    while (rpb < 64 && (long)(M + rpb - 1) / rpb > 4096) rpb *= 2;
+    return rpb;
+}
 
 static int multi_check(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, int& Ctot, int& xw) {
     if (!X || !segs || nseg < 1 || nseg > 8 || M <= 32) return MLSP_ERR_ARG;
@@ -212,8 +250,9 @@ int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs
         MCHECK(launch_bn_eval_prepare(st, Ctot, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
     }
     const float pd = training ? p_drop : 0.f;
-    hipLaunchKernelGGL(multi_act_fwd_kernel, dim3(bn_vec_parts(M)), dim3(256), 0, st, Y, Z, M, Ctot, scale, shift, chan, dropout_thresh8(pd),
-                       dropout_inv_keep8(pd), seed);
+    const int rpb = multi_rows_per_block(M, Ctot);
+    hipLaunchKernelGGL(multi_act_fwd_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, st, Y, Z, M, Ctot, rpb, scale, shift, chan,
+                       dropout_thresh8(pd), dropout_inv_keep8(pd), seed);
     return mlsp_launch_status();
 }
 
@@ -243,7 +282,8 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
     const float ik = dropout_inv_keep8(pd);
     hipLaunchKernelGGL(multi_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, Ctot, bn_save, chan, th, ik, seed, part);
     MCHECK(launch_bn_bwd_finalize(st, part, nparts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy));
-    hipLaunchKernelGGL(multi_bwd_apply_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, dY, M, Ctot, bn_save, chan,
+    const int rpb = multi_rows_per_block(M, Ctot);
+    hipLaunchKernelGGL(multi_bwd_apply_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, st, dZ, Y, dY, M, Ctot, rpb, bn_save, chan,
                        training ? mean_dz : (const float*)nullptr, mean_dzy, th, ik, seed);
     MCHECK(mlsp_launch_status());
     int ycol = 0;
