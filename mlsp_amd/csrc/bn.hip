@@ -262,14 +262,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_vec_kernel(const TY* __
         const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
         const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
         const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
-        for (int r = r0 + rg; r < r1; r += nrg) {
-            const size_t i = (size_t)r * C + c;
-            const f32x4 y = ld4<TY>(Y + i), dz = ld4<TY>(dZ + i);
-            const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;
+        for (int rb = r0 + rg; rb < r1; rb += 4 * nrg) {                    // four rows in flight per thread, summed in row order
+            f32x4 y[4], dz[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float d = dz_prime_q(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
-                s[e] += d; q[e] += (double)d * ((y[e] - mu[e]) * is[e]);
+            for (int u = 0; u < 4; ++u)
+                if (rb + u * nrg < r1) { y[u] = ld4<TY>(Y + (size_t)(rb + u * nrg) * C + c); dz[u] = ld4<TY>(dZ + (size_t)(rb + u * nrg) * C + c); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (rb + u * nrg >= r1) break;
+                const size_t i = (size_t)(rb + u * nrg) * C + c;
+                const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = dz_prime_q(dz[u][e], y[u][e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
+                    s[e] += d; q[e] += (double)d * ((y[u][e] - mu[e]) * is[e]);
+                }
             }
         }
     }
@@ -303,18 +310,25 @@ __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const TY* __restric
     if (rg >= nrg) return;
     const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
     const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
-    for (int r = r0 + rg; r < r1; r += nrg) {
-        const size_t i = (size_t)r * C + c;
-        const f32x4 y = ld4<TY>(Y + i);
-        f32x4 o;
-        const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;      // i is a multiple of 4: one hash for the quad
+    for (int rb = r0 + rg; rb < r1; rb += 4 * nrg) {                        // four rows in flight per thread (measured on the
+        f32x4 y[4];                                                         // per-channel twins in multi.hip: 6-17 % per pass)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float a = lrelu_or_relu(fmaf(y[e], sc[e], sh[e]), act, slope);
-            if (thresh) a = ((hq >> (8 * e)) & 255u) >= thresh ? a * inv_keep : 0.f;
-            o[e] = a;
+        for (int u = 0; u < 4; ++u)
+            if (rb + u * nrg < r1) y[u] = ld4<TY>(Y + (size_t)(rb + u * nrg) * C + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (rb + u * nrg >= r1) break;
+            const size_t i = (size_t)(rb + u * nrg) * C + c;
+            f32x4 o;
+            const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;  // i is a multiple of 4: one hash for the quad
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = lrelu_or_relu(fmaf(y[u][e], sc[e], sh[e]), act, slope);
+                if (thresh) a = ((hq >> (8 * e)) & 255u) >= thresh ? a * inv_keep : 0.f;
+                o[e] = a;
+            }
+            st4<TY>(Z + i, o);
         }
-        st4<TY>(Z + i, o);
     }
 }
 
@@ -345,19 +359,26 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const TY* __r
         for (int e = 0; e < 4; ++e) k2[e] = is[e] * mz[e];
     }
     const int r0 = blockIdx.x * VROWS, r1 = min(M, r0 + VROWS);
-    for (int r = r0 + rg; r < r1; r += nrg) {
-        const size_t i = (size_t)r * C + c;
-        const f32x4 y = ld4<TY>(Y + i), dz = ld4<TY>(dZ + i);
-        const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;
-        f32x4 o;
+    for (int rb = r0 + rg; rb < r1; rb += 4 * nrg) {                        // four rows in flight per thread
+        f32x4 y[4], dz[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float d = dz_prime_q(dz[e], y[e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
-            d = d - k1[e] - (y[e] - mu[e]) * k2[e];
-            o[e] = sc[e] * d;
+        for (int u = 0; u < 4; ++u)
+            if (rb + u * nrg < r1) { y[u] = ld4<TY>(Y + (size_t)(rb + u * nrg) * C + c); dz[u] = ld4<TY>(dZ + (size_t)(rb + u * nrg) * C + c); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (rb + u * nrg >= r1) break;
+            const size_t i = (size_t)(rb + u * nrg) * C + c;
+            const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = dz_prime_q(dz[u][e], y[u][e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
+                d = d - k1[e] - (y[u][e] - mu[e]) * k2[e];
+                o[e] = sc[e] * d;
+            }
+            st4<TY>(dY + i, o);
+            gs = gs + o;
         }
-        st4<TY>(dY + i, o);
-        gs = gs + o;
     }
     if (gpart) {
 #pragma unroll
