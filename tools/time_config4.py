@@ -26,7 +26,10 @@ def step():
     opt.step()
 
 
-for name, prec, store in (("fp32", "fp32", "fp32"), ("bf16 operands", "bf16", "fp32"), ("bf16 operands + bf16 activation storage", "bf16", "bf16")):
+MODES = (("fp32", "fp32", "fp32"), ("bf16 operands", "bf16", "fp32"), ("bf16 operands + bf16 activation storage", "bf16", "bf16"))
+if os.environ.get("C4_MODE") == "bf16":          # profiling: the configs[4] mode only
+    MODES = MODES[2:]
+for name, prec, store in MODES:
     with Fh.gemm_precision(prec), Fh.activation_storage(store):
         for _ in range(5):
             step()
