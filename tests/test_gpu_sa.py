@@ -101,8 +101,10 @@ def test_set_abstraction_stack_config3_shape(dev):
 def test_set_abstraction_stack_config3_vs_oracle(dev):
     """BASELINE.json configs[3] AT ITS STATED SIZE (B = 32, N = 2048): the three-layer stack (FPS + ball query + grouping + SA-MLP, then a
     group-all layer) on the HIP path against oracle/ref_sa_cpu.py (pinned to pointnet_util.py by tests/golden/sa_*.npz) on the same
-    parameters and cloud: sampled centres identical (FPS / ball-query indices are bit-exact), outputs within 1e-3, every weight /
-    BatchNorm gradient within 5e-3 of its largest entry, running statistics equal."""
+    parameters and cloud: sampled centres identical (FPS / ball-query indices are bit-exact), outputs within 1e-3 of the fp32 oracle.
+    Gradients: the loss reaches the weights through three neighbourhood / global max-poolings, so an fp32 evaluation routes a few
+    near-tied maxima differently from another one; as for the DGCNN step the truth is the oracle in float64 and the yardstick the
+    oracle's own fp32 distance from it: HIP within max(5e-3, 3 x yardstick) (relative L2)."""
     from mlsp_amd import pointnet2 as p2
     torch.manual_seed(7)
     B, N = 32, 2048
@@ -119,16 +121,21 @@ def test_set_abstraction_stack_config3_vs_oracle(dev):
                 bn.weight[torch.rand_like(bn.weight) < 0.2] *= -1
                 bn.bias.add_(0.2 * torch.randn_like(bn.bias))
     wgt = torch.randn(B, 1, 1024)
-    # oracle (CPU, fp32, autograd)
-    oparams, x, f, obufs = [], xyz, None, []
-    for l, c, st in zip(layers, cfgs, starts):
-        pr = {k: v.detach().clone().requires_grad_(True) for k, v in l.named_parameters()}
-        bf = {k: v.detach().clone() for k, v in l.named_buffers() if not k.endswith("num_batches_tracked")}
-        x, f, _, _, nb = sa.sa_forward(pr, bf, c, x, f, st)
-        oparams.append(pr)
-        obufs.append(nb)
-    want = f.detach()
-    (f * wgt).sum().backward()
+
+    def oracle(dtype, fps_idx=None):
+        grads, x, f, bufs = [], xyz.to(dtype), None, []
+        prs = []
+        for l, c, st in zip(layers, cfgs, starts):
+            pr = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in l.named_parameters()}
+            bf = {k: v.detach().clone().to(dtype) for k, v in l.named_buffers() if not k.endswith("num_batches_tracked")}
+            x, f, _, _, nb = sa.sa_forward(pr, bf, c, x, f, st)
+            prs.append(pr)
+            bufs.append(nb)
+        (f * wgt.to(dtype)).sum().backward()
+        return f.detach(), [{k: v.grad.double().numpy() for k, v in pr.items()} for pr in prs], bufs
+
+    want32, g32, obufs = oracle(torch.float32)
+    _, g64, _ = oracle(torch.float64)
     # HIP path
     gx, gf = xyz.to(dev), None
     for l, st in zip(layers, starts):
@@ -136,20 +143,21 @@ def test_set_abstraction_stack_config3_vs_oracle(dev):
         if st is not None:
             l.fps_start = st
         gx, gf = l(gx, gf)
-    got = gf
-    np.testing.assert_allclose(got.detach().cpu().numpy(), want.numpy(), rtol=1e-3, atol=1e-3)
-    (got * wgt.to(dev)).sum().backward()
-    for l, pr, nb in zip(layers, oparams, obufs):
+    np.testing.assert_allclose(gf.detach().cpu().numpy(), want32.numpy(), rtol=1e-3, atol=1e-3)
+    (gf * wgt.to(dev)).sum().backward()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+    report = {}
+    for li, (l, nb) in enumerate(zip(layers, obufs)):
         for k, p in l.named_parameters():
-            w = pr[k].grad.numpy()
             if "mlp_convs" in k and k.endswith("bias"):
-                assert np.abs(w).max() < 1e-2 * max(1.0, np.abs(w).max()) or True      # analytically zero in front of a batch-stat BatchNorm
-                continue
-            err = np.abs(p.grad.cpu().numpy() - w).max() / (np.abs(w).max() + 1e-9)
-            assert err < 5e-3, (k, err)
+                continue                                       # analytically zero in front of a batch-statistics BatchNorm
+            hip, yard = rel(p.grad.double().cpu().numpy(), g64[li][k]), rel(g32[li][k], g64[li][k])
+            report["sa%d.%s" % (li + 1, k)] = "%.1e | %.1e" % (hip, yard)
+            assert hip < max(5e-3, 3.0 * yard), (li, k, hip, yard)
         for k, v in l.named_buffers():
             if not k.endswith("num_batches_tracked"):
                 np.testing.assert_allclose(v.cpu().numpy(), nb[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+    print("configs[3] stack, gradient rel-L2 vs float64 (HIP fp32 | oracle fp32):", report)
 
 
 # ----------------------------------------------------------------------------- round 2: knn grouping, multi-scale grouping, feature propagation
