@@ -577,13 +577,14 @@ int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const fl
     const bool al = (((uintptr_t)uv | (uintptr_t)msel | (uintptr_t)s1 | (uintptr_t)gamma) & 15) == 0 && (((uintptr_t)argsel) & 3) == 0;
     if (nparts_used) *nparts_used = edge_reduce_parts(P);
 #ifndef EDGE_NO_LDS
-    if (al && Cout % ELDS_CS == 0 && P % N == 0 && N <= 4096 && k <= 32 && N % 4 == 0) {
+    if (al && Cout % ELDS_CS == 0 && P % N == 0 && N <= 4096 && k <= 40 && N % 4 == 0) {
         const int B = P / N, nsl = Cout / ELDS_CS;
         int psplit = 1;                                        // enough workgroups for two per CU, small neighbour-list stage
         while (psplit < 8 && (B * nsl * psplit < 512 || (N / psplit) * k * 2 > 16 * 1024) && N % (psplit * 2) == 0) psplit *= 2;
         const size_t lds = (size_t)N * ELDS_CS * sizeof(float) + align_up((size_t)((N + psplit - 1) / psplit) * k * 2, 16);
         if (lds <= 150 * 1024 && B * psplit <= edge_reduce_parts(P) && lds >= (size_t)2 * (256 / (ELDS_CS / 4)) * ELDS_CS * sizeof(double)) {
-            auto kern = k == 20 ? edge_reduce_lds_kernel<20, true> : k <= 20 ? edge_reduce_lds_kernel<20, false> : edge_reduce_lds_kernel<32, false>;
+            auto kern = k == 20 ? edge_reduce_lds_kernel<20, true> : k <= 20 ? edge_reduce_lds_kernel<20, false> : k <= 32 ? edge_reduce_lds_kernel<32, false>
+                      : k == 40 ? edge_reduce_lds_kernel<40, true> : edge_reduce_lds_kernel<40, false>;     // k = 40: BASELINE.json configs[4]
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return (int)e;

@@ -166,187 +166,13 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ x, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// v2: distance tiles on the matrix cores.  D[cand 32][query 32] = Xc Xq^T by v_mfma_f32_32x32x2_f32, which is
-// bit-for-bit a k-ordered fmaf chain (c = 2s on lanes 0-31, c = 2s+1 on lanes 32-63), i.e. exactly the
-// canonical dot product.  The accumulator map puts ONE query on each lane (col = lane&31) and 16
-// candidates in its registers, visited in ascending index order, so the per-lane top-K insertion of v1
-// applies unchanged.  Workgroup = 8 waves: waves 0-3 and 4-7 own the same 4x32 queries and scan the two
-// halves of the candidate tiles (two waves per SIMD: one wave's MFMAs overlap the other's VALU insertion).
-// Candidate tiles are staged k-major through LDS (double-buffered); query fragments stay in registers.
-// Channels are zero-padded to CT (fmaf(0,0,acc) == acc, so padding does not perturb the chain).
+// Distance tiles on the matrix cores (every kernel below).  D[cand 32][query 32] = Xc Xq^T by v_mfma_f32_32x32x2_f32, which is
+// bit-for-bit a k-ordered fmaf chain (c = 2s on lanes 0-31, c = 2s+1 on lanes 32-63), i.e. exactly the canonical dot product.
+// Candidate tiles are staged k-major through LDS [c][33]; channels are zero-padded to CT (fmaf(0,0,acc) == acc, so padding does not
+// perturb the chain).  (The round-1 list-merge kernel that kept k sorted entries per lane -- and spilled for k = 40 -- is gone: its
+// shapes run on the two-pass kernel, the few it does not take on the VALU kernel above.)
 #define KM_STRIDE 33
 
-template <int KMAX, int CT>
-__global__ __launch_bounds__(512) void knn_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
-                                                       int ld, int N, int C, int k, int vec_ok, int* __restrict__ idx) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int TILE = CT * KM_STRIDE;                 // floats per staged tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int grp = wave >> 2, qw = wave & 3, tl = tid & 255;
-    const int b = blockIdx.y;
-    const float* xb = x + (size_t)b * N * ld;
-    const float* xxb = xx_all + (size_t)b * N;
-    float* tiles = sm + (size_t)grp * 2 * TILE;          // [2 bufs][CT][33]
-    float* cxx = sm + (size_t)4 * TILE + grp * 64;       // [2 bufs][32]
-
-    const int q = blockIdx.x * 128 + qw * 32 + l31;
-    const bool qvalid = q < N;
-    float qb[CT / 2];
-#pragma unroll
-    for (int s = 0; s < CT / 2; ++s) {
-        int c = 2 * s + h;
-        qb[s] = (qvalid && c < C) ? xb[(size_t)q * ld + c] : 0.f;
-    }
-    const float xxq = qvalid ? xxb[q] : 0.f;
-
-    const int ntiles = (N + 31) / 32;
-    const int nt0 = (ntiles + 1) / 2;                    // tiles of group 0; group 1 gets the rest
-    const int tbeg = grp == 0 ? 0 : nt0;
-    const int tcnt = grp == 0 ? nt0 : ntiles - nt0;
-
-    constexpr int NLD = (32 * CT / 4 + 255) / 256;        // float4 loads per thread per tile
-    f32x4 stage[NLD];
-    auto g2r_tile = [&](int t) {
-        const int j0 = (tbeg + t) * 32;
-#pragma unroll
-        for (int p = 0; p < NLD; ++p) {
-            int f = tl + 256 * p;
-            int cand = f / (CT / 4), c = (f % (CT / 4)) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (f < 32 * CT / 4 && t < tcnt && j0 + cand < N) {
-                const float* g = xb + (size_t)(j0 + cand) * ld + c;
-                if (vec_ok && c + 3 < C) v = *(const f32x4*)g;
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (c + e < C) v[e] = g[e];
-                }
-            }
-            stage[p] = v;
-        }
-    };
-    auto r2s_tile = [&](int buf, int t) {
-        float* T = tiles + buf * TILE;
-#pragma unroll
-        for (int p = 0; p < NLD; ++p) {
-            int f = tl + 256 * p;
-            if (f < 32 * CT / 4) {
-                int cand = f / (CT / 4), c = (f % (CT / 4)) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) T[(c + e) * KM_STRIDE + cand] = stage[p][e];
-            }
-        }
-        if (tl < 32) {
-            int j = (tbeg + t) * 32 + tl;
-            cxx[buf * 32 + tl] = (t < tcnt && j < N) ? xxb[j] : 0.f;
-        }
-    };
-
-    TopK<KMAX> top;
-    top.init();
-
-    g2r_tile(0);
-    r2s_tile(0, 0);
-    __syncthreads();
-    for (int t = 0; t < nt0; ++t) {                       // both groups iterate nt0 times (uniform barriers)
-        const int buf = t & 1;
-        if (t + 1 < nt0) g2r_tile(t + 1);
-        if (t < tcnt) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float* T = tiles + buf * TILE + h * KM_STRIDE + l31;
-#pragma unroll
-            for (int s = 0; s < CT / 2; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(T[(2 * s) * KM_STRIDE], qb[s], acc, 0, 0, 0);
-            const int j0 = (tbeg + t) * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int j = j0 + i;
-                float tt = fmaf(2.0f, acc[r], -cxx[buf * 32 + i]);
-                float pd = tt - xxq;
-                if (j >= N) pd = -INFINITY;
-                if (__any(pd > top.v[KMAX - 1])) top.insert(pd, j);
-            }
-        }
-        if (t + 1 < nt0) r2s_tile(buf ^ 1, t + 1);
-        __syncthreads();
-    }
-
-    // merge the two half-lists of a query (lanes l and l^32) -- snapshot first, then insert
-    {
-        float ov[KMAX];
-        int oi[KMAX];
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) { ov[s] = __shfl_xor(top.v[s], 32, 64); oi[s] = __shfl_xor(top.id[s], 32, 64); }
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s)
-            if (__any(TopK<KMAX>::beats(ov[s], oi[s], top.v[KMAX - 1], top.id[KMAX - 1]))) top.insert(ov[s], oi[s]);
-    }
-    // merge the two candidate halves through LDS (tiles are dead after the last barrier above)
-    float* mv = sm;                                       // [4 qw][KMAX][32]
-    int* mi = (int*)(sm + 4 * KMAX * 32);
-    if (grp == 1 && h == 0) {
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) {
-            mv[(qw * KMAX + s) * 32 + l31] = top.v[s];
-            mi[(qw * KMAX + s) * 32 + l31] = top.id[s];
-        }
-    }
-    __syncthreads();
-    if (grp == 0) {
-        for (int s = 0; s < KMAX; ++s) {
-            float d = mv[(qw * KMAX + s) * 32 + l31];
-            int j = mi[(qw * KMAX + s) * 32 + l31];
-            if (__any(TopK<KMAX>::beats(d, j, top.v[KMAX - 1], top.id[KMAX - 1]))) top.insert(d, j);
-        }
-        if (qvalid && h == 0) {
-            int* o = idx + ((size_t)b * N + q) * k;
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s)
-                if (s < k) o[s] = top.id[s];
-        }
-    }
-}
-
-template <int KMAX, int CT>
-static int launch_knn_mfma_ct(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
-    size_t lds = ((size_t)4 * CT * KM_STRIDE + 128) * sizeof(float);
-    size_t merge = (size_t)2 * 4 * KMAX * 32 * sizeof(float);
-    if (merge > lds) lds = merge;
-    if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_mfma_kernel<KMAX, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    int vec_ok = (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
-    dim3 grid((N + 127) / 128, B);
-    hipLaunchKernelGGL((knn_mfma_kernel<KMAX, CT>), grid, dim3(512), lds, st, x, xx, ld, N, C, k, vec_ok, idx);
-    return mlsp_launch_status();
-}
-
-template <int KMAX>
-static int launch_knn_mfma(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
-    if (C <= 4) return launch_knn_mfma_ct<KMAX, 4>(st, x, ld, xx, B, N, C, k, idx);
-    if (C <= 16) return launch_knn_mfma_ct<KMAX, 16>(st, x, ld, xx, B, N, C, k, idx);
-    if (C <= 64) return launch_knn_mfma_ct<KMAX, 64>(st, x, ld, xx, B, N, C, k, idx);
-    if (C <= 128) return launch_knn_mfma_ct<KMAX, 128>(st, x, ld, xx, B, N, C, k, idx);
-    if (C <= 256) return launch_knn_mfma_ct<KMAX, 256>(st, x, ld, xx, B, N, C, k, idx);
-    return MLSP_ERR_UNSUPPORTED;
-}
-
-// ------------------------------------------------------------------------------------------------
-// v3: lane-distributed sorted lists.  The distance tile is computed TRANSPOSED, D[query 32][cand 32]
-// (A = queries in registers, B = candidate tile from LDS), so accumulator register r of a lane holds
-// query row rho(r, half) against candidate (lane & 31): the 32 lanes of a half-wave hold one query's 32
-// candidates of the tile.  Each query's running top-32 list lives SORTED ACROSS those 32 lanes (entry
-// rank = lane & 31), one register per query row.  Per tile and query: one compare + ballot finds the
-// candidates that beat the current k-th value (usually none after the first tiles); each survivor is
-// inserted with a constant number of wave instructions (broadcast it, shift the worse tail down by one
-// lane, drop it in place).  The two half-waves work on different queries in the same instructions.
-// The next tile's MFMA chain is issued in slices between the per-query selection steps so the matrix
-// pipe runs under the VALU work.  Same canonical arithmetic and total order as v1/v2 -> identical output.
 template <int CT>
 __global__ __launch_bounds__(256) void knn_mfma3_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
                                                         int ld, int N, int C, int k, int vec_ok, int* __restrict__ idx) {
@@ -1582,9 +1408,7 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
             if (rc != MLSP_ERR_UNSUPPORTED) return rc;
         }
         if (k <= 32) return launch_knn_mfma3(st, x, ld, xx_ws, B, N, C, k, idx);      // lane-distributed lists
-        if (k <= 20) return launch_knn_mfma<20>(st, x, ld, xx_ws, B, N, C, k, idx);
-        if (k <= 40) return launch_knn_mfma<40>(st, x, ld, xx_ws, B, N, C, k, idx);
-        return MLSP_ERR_UNSUPPORTED;
+        // 32 < k <= 40 on a shape the two-pass kernel does not take (ragged N, N < 128, 64 < C < 128 or C > 128): the VALU kernel
     }
     if (k <= 20) return launch_knn_k<20>(st, x, ld, xx_ws, B, N, C, k, idx);
     if (k <= 40) return launch_knn_k<40>(st, x, ld, xx_ws, B, N, C, k, idx);

@@ -91,8 +91,8 @@ def test_missing_library_fails_loudly(monkeypatch):
 
 def test_no_register_spills_in_hot_kernels():
     """The Makefile leaves per-kernel resource remarks next to the objects: no kernel of the hot path may spill VGPRs or
-    use scratch (a spilling kernel runs 5-20x slower on gfx950).  Known exception: the k = 40 / C = 256 list-merge kNN
-    (knn_mfma_kernel), kept only as the fallback for shapes outside BASELINE.json's configs."""
+    use scratch (a spilling kernel runs 5-20x slower on gfx950).  No exceptions (the round-1 list-merge kNN that spilled at
+    k = 40 is deleted)."""
     import glob, re
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "..", "mlsp_amd", "csrc", "build", "*.remarks")))
@@ -106,7 +106,7 @@ def test_no_register_spills_in_hot_kernels():
         scratch = re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)
         assert len(names) == len(spills) == len(scratch)
         for n, s, c in zip(names, spills, scratch):
-            if (int(s) or int(c)) and "knn_mfma_kernel" not in n:
+            if int(s) or int(c):
                 bad.append((os.path.basename(f), n, int(s), int(c)))
     assert not bad, bad
 

@@ -42,7 +42,9 @@ def _rand(shape, seed, scale=1.0):
                                      (32, 1024, 3, 20), (32, 1024, 64, 20), (32, 1024, 128, 20), (32, 2048, 64, 20),
                                      # k > 32 (configs[4]: k = 40): the two-pass select with 128 chunk maxima per query
                                      (2, 2048, 3, 40), (8, 2048, 64, 40), (3, 1024, 128, 40), (2, 512, 64, 33), (1, 256, 16, 48),
-                                     (1, 128, 64, 64), (2, 2048, 64, 64), (2, 1024, 64, 25), (1, 384, 100, 40)])
+                                     (1, 128, 64, 64), (2, 2048, 64, 64), (2, 1024, 64, 25), (1, 384, 100, 40),
+                                     # the VALU kernel: C > 256, and 32 < k <= 40 on shapes outside the two-pass kernel
+                                     (1, 200, 300, 20), (2, 150, 260, 40), (1, 96, 200, 36)])
 def test_knn_bit_exact_vs_oracle(dev, B, N, C, k):
     Fh = _fh()
     xp = _rand((B * N, C), 100 + N + C)
@@ -574,11 +576,13 @@ def _torch_edgeconv(xp, idx, W, gamma, beta, rm, rv, training, B, N):
     return y.transpose(2, 1).reshape(B * N, -1)
 
 
-@pytest.mark.parametrize("B,N,C,Cout,training", [(2, 128, 3, 64, True), (2, 96, 64, 64, True), (3, 64, 64, 128, True),
-                                                 (1, 200, 128, 256, True), (2, 100, 16, 40, False)])
-def test_edgeconv_fwd_bwd(dev, B, N, C, Cout, training):
+@pytest.mark.parametrize("B,N,C,Cout,training,k", [(2, 128, 3, 64, True, 20), (2, 96, 64, 64, True, 20), (3, 64, 64, 128, True, 20),
+                                                   (1, 200, 128, 256, True, 20), (2, 100, 16, 40, False, 20),
+                                                   # k = 40 (BASELINE.json configs[4]) / 36 / 28: the LDS-resident gather-reduce with 40- and 32-slot lists
+                                                   (2, 128, 3, 64, True, 40), (2, 256, 64, 64, True, 40), (1, 160, 64, 128, True, 36),
+                                                   (2, 128, 64, 64, False, 28)])
+def test_edgeconv_fwd_bwd(dev, B, N, C, Cout, training, k):
     Fh = _fh()
-    k = 20
     P = B * N
     xp = _rand((P, C), 1).requires_grad_(True)
     W = _rand((Cout, 2 * C), 2, 0.3).requires_grad_(True)
