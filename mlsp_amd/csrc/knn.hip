@@ -1393,7 +1393,8 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
     if (!x || !idx || !xx_ws || B <= 0 || N <= 0 || C <= 0 || k <= 0 || k > N || ld < C) return MLSP_ERR_ARG;
     int P = B * N;
     hipLaunchKernelGGL(sqnorm_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, C, xx_ws);
-    // matrix-core path for every C <= 256; the v1 VALU kernel remains for wider features
+    // matrix-core kernels for every C <= 256 (the widest graph stage of the reference is 128 channels); beyond that only what the
+    // VALU kernel's LDS tiles hold (C <= ~200 at k <= 40): MLSP_ERR_UNSUPPORTED otherwise
     if (C <= 256) {
         // two-pass threshold select pays once there are enough candidates per query; small clouds keep v3
         if (k <= 32 && C <= 128 && N >= 256) {

@@ -43,8 +43,8 @@ def _rand(shape, seed, scale=1.0):
                                      # k > 32 (configs[4]: k = 40): the two-pass select with 128 chunk maxima per query
                                      (2, 2048, 3, 40), (8, 2048, 64, 40), (3, 1024, 128, 40), (2, 512, 64, 33), (1, 256, 16, 48),
                                      (1, 128, 64, 64), (2, 2048, 64, 64), (2, 1024, 64, 25), (1, 384, 100, 40),
-                                     # the VALU kernel: C > 256, and 32 < k <= 40 on shapes outside the two-pass kernel
-                                     (1, 200, 300, 20), (2, 150, 260, 40), (1, 96, 200, 36)])
+                                     # the VALU kernel: 32 < k <= 40 on shapes outside the two-pass kernel (ragged N, N < 128, 64 < C < 128, C > 128)
+                                     (2, 150, 200, 40), (1, 96, 200, 36), (2, 100, 24, 33)])
 def test_knn_bit_exact_vs_oracle(dev, B, N, C, k):
     Fh = _fh()
     xp = _rand((B * N, C), 100 + N + C)
