@@ -377,6 +377,9 @@ class DGCNN(nn.Module):
                 heads.append(("density", self.Density_cls))
             if activate_density_normal_ondef:
                 heads += [("DefRec", self.DefRec), ("density", self.Density_cls), ("Normal", self.Norm_pred)]
+        # (merged layers: the position / normal / scan heads -- identical stacks -- side by side, so that their later layers can run as
+        # block-diagonal GEMM launches; the order inside the merged matrices is internal, the returned dict does not depend on it)
+        heads.sort(key=lambda kh: 0 if isinstance(kh[1], _RegionHead) else 1)
         merge = can_merge_first_layers([h for _, h in heads])
         aliases, acc = Fh.fan_out(x_cat, 2 if merge else 1 + len(heads))
         rm5, rv5 = _bn_buffers(self.bn5, self.training)                             # conv5+bn5+LReLU+max (Models.py:132-136)

@@ -61,6 +61,10 @@ struct GemmXf {
     const float* scale; const float* shift; int act; float slope; uint32_t thresh; float inv_keep; uint64_t seed; int ld; int which;
 };
 
+// Block-diagonal product in one GEMM launch (gemm.hip GemmArgs groups).  mode 1: output COLUMNS are grouped (forward: A = X + g * a_gs,
+// B = Bg[g] = W_g; dgrad alike); mode 2: output ROWS are grouped (wgrad: B = X + g * b_gs; A and C take the launch-wide row index).
+struct GemmGroups { int G, mode; long a_gs, b_gs; const float* Bg[4]; };
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -40,6 +40,10 @@ struct GemmArgs {
     // activated output while it is staged: act(x * scale[c] + shift[c]), dropout by the counter hash of element row * x_ld + c.
     // XF == 1: A is [M][K] row-major, c = k.  XF == 2: B is [K][N] k-major (the wgrad's X), c = n.
     const float* x_scale; const float* x_shift; int x_act; float x_slope; uint32_t x_thresh; float x_inv_keep; uint64_t x_seed; int x_ld;
+    // groups (FAST fp32 kernel only; launch_gemm `grp`): a block-diagonal product in ONE launch.  gmode 1 (forward / dgrad): column tiles
+    // [g * gtiles, (g + 1) * gtiles) form group g, whose A columns start at A + g * a_gs and whose B operand is Bg[g]; C, bias and
+    // the statistics keep the launch-wide column index.  gmode 2 (wgrad): ROW tiles are grouped, B = B + g * b_gs.
+    int gmode, gtiles; long a_gs, b_gs; const float* Bg[4];
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][stat_ld] (BN batch statistics)
     int stat_ld;                    // columns of a statistics row (N, or the width of the wider matrix C is a column slice of)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
@@ -301,7 +305,7 @@ __device__ __forceinline__ f32x4 xf_quad(const GemmArgs& p, f32x4 v, const f32x4
     return v;
 }
 
-template <bool TA, bool TB, int WM, bool FAST, int XF = 0>
+template <bool TA, bool TB, int WM, bool FAST, int XF = 0, int GRP = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     constexpr int BMT = 64 * WM, NPA = 2 * WM;
     // A tile is k-major in LDS either way; its GLOBAL source is k-major iff TA.  B's source is
@@ -337,6 +341,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     const int m0 = tm * BMT, n0 = tn * BN;
     const int kbeg = split * p.ksplit;
     const int kend = min(p.K, kbeg + p.ksplit);
+    // operand origins of this tile (groups: see GemmArgs); n0b = the tile's first column inside its group's B operand
+    const float* Ap = p.A;
+    const float* Bp = p.B;
+    int n0b = n0;
+    static_assert(GRP == 0 || (FAST && XF == 0), "groups: interior-tile kernel without operand transform");
+    if (GRP == 1) {
+        const int g = tn / p.gtiles;
+        Ap += (size_t)g * p.a_gs;
+        Bp = g == 0 ? p.Bg[0] : g == 1 ? p.Bg[1] : g == 2 ? p.Bg[2] : p.Bg[3];
+        n0b = (tn - g * p.gtiles) * BN;
+    } else if (GRP == 2) {
+        Bp += (size_t)(tm / p.gtiles) * p.b_gs;
+    }
 
 #ifdef GP_TIMELINE
     const long long tl0 = wall_clock64();
@@ -377,8 +394,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     int voa = 0, vob = 0, soa = 0, sob = 0;
     const int lda4 = p.lda * 4, ldb4 = p.ldb * 4;
     if (FAST) {
-        rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(TA ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg), 0, 0x7ffffff0, MLSP_BUF_FLAGS);
-        rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(!TB ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg), 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+        rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(TA ? Ap + (size_t)kbeg * p.lda + m0 : Ap + (size_t)m0 * p.lda + kbeg), 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+        rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(!TB ? Bp + (size_t)kbeg * p.ldb + n0b : Bp + (size_t)n0b * p.ldb + kbeg), 0, 0x7ffffff0, MLSP_BUF_FLAGS);
         voa = TA ? (NPA == 4 ? (tid >> 5) : (tid >> 4)) * lda4 + (NPA == 4 ? (tid & 31) : (tid & 15)) * 16 : (tid >> 3) * lda4 + (tid & 7) * 16;
         vob = !TB ? (tid >> 5) * ldb4 + (tid & 31) * 16 : (tid >> 3) * ldb4 + (tid & 7) * 16;
         g2r_buf<TA, NPA>(ra, rsa, voa, soa, lda4);
@@ -1009,18 +1026,21 @@ bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, in
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                 size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
-                int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0) {
+                int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0, const GemmGroups* grp = nullptr) {
+    // grp (nullable): block-diagonal product in one launch (GemmArgs groups; M / N are the LAUNCH's dimensions, K one group's).
+    // Only on the interior-tile fp32 kernel: MLSP_ERR_UNSUPPORTED otherwise (nothing launched; the caller launches group by group).
     // stat_ld (0: N): C is a column slice of a [M][stat_ld] matrix whose BatchNorm statistics are taken as ONE vector (multi.hip):
     // stat_part points at this slice's first column of the [panels][2][stat_ld] partial rows
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
     if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
     // one tiny dimension (3 coordinates, 3 / 16 outputs): streaming VALU kernels priced against HBM, not MFMA tiles (thin.hip)
-    if (!gbias && !stat_part && !sel_gamma && !accumulate && !xf) {
+    if (grp && (grp->G < 2 || grp->G > 4 || xf || sel_gamma || gbias || g_gemm_precision != 0 || (ta && tb))) return MLSP_ERR_UNSUPPORTED;
+    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf) {
         const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
     // per-cloud layers (<= 32 rows, or a 32-deep wgrad): one-pass skinny kernels, no split-K slab (skinny.hip)
-    if (!gbias && !stat_part && !sel_gamma && !accumulate && !xf && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
+    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
         const int rc = launch_skinny_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
@@ -1064,7 +1084,17 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     static const bool old_epilogue = getenv("MLSP_GEMM_OLD_EPILOGUE") != nullptr;       // read-once A/B switch (tools/ab)
     // lean output pass: every row of a tile takes the same per-cloud bias row, byte offsets inside a wave's region fit 31 bits
     p.fast_out = (fast && (!gbias || rows_per_group % bm == 0) && (long)p.ldc * 4 * 64 < (1L << 30) && !old_epilogue) ? 1 : 0;
-    const bool n64 = !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
+    p.gmode = 0; p.gtiles = 1; p.a_gs = p.b_gs = 0; p.Bg[0] = p.Bg[1] = p.Bg[2] = p.Bg[3] = B;
+    if (grp) {
+        const int per = (grp->mode == 1 ? N : M) / grp->G;                  // columns (mode 1) / rows (mode 2) of one group
+        const int tile = grp->mode == 1 ? BN : bm;
+        bool ok = fast && g_gemm_precision == 0 && (grp->mode == 1 || grp->mode == 2) && per * grp->G == (grp->mode == 1 ? N : M) && per % tile == 0;
+        for (int g = 0; g < grp->G && ok && grp->mode == 1; ++g) ok = grp->Bg[g] && (((uintptr_t)grp->Bg[g] & 15) == 0);
+        if (!ok) return MLSP_ERR_UNSUPPORTED;
+        p.gmode = grp->mode; p.gtiles = per / tile; p.a_gs = grp->a_gs; p.b_gs = grp->b_gs;
+        for (int g = 0; g < 4; ++g) p.Bg[g] = grp->mode == 1 ? grp->Bg[g < grp->G ? g : 0] : B;
+    }
+    const bool n64 = !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
                      (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
     if (n64) {
         dim3 g64(M / 128, ns);
@@ -1075,7 +1105,15 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
 #define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
-    if (xf) {                                             // operand transform: FAST fp32 instantiations only (gemm_xf_supported)
+    if (grp) {                                            // block-diagonal launch (validated above: fast, fp32)
+        if (grp->mode == 1 && !ta && tb) { if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, true, 0, 1>), grid, dim3(256), 0, st, p);
+                                           else hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, true, 0, 1>), grid, dim3(256), 0, st, p); }
+        else if (grp->mode == 1 && !ta && !tb) { if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, true, 0, 1>), grid, dim3(256), 0, st, p);
+                                                 else hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1, true, 0, 1>), grid, dim3(256), 0, st, p); }
+        else if (grp->mode == 2 && ta && !tb) { if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2, true, 0, 2>), grid, dim3(256), 0, st, p);
+                                                else hipLaunchKernelGGL((gemm_f32_kernel<true, false, 1, true, 0, 2>), grid, dim3(256), 0, st, p); }
+        else return MLSP_ERR_UNSUPPORTED;
+    } else if (xf) {                                      // operand transform: FAST fp32 instantiations only (gemm_xf_supported)
         if (xf->which == 1 && tb) {
             if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, true, 1>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, true, 1>), grid, dim3(256), 0, st, p);

@@ -12,10 +12,12 @@
 // Versus one mlsp_pointmlp_* call per head: 2 finalisations + 2 streaming launches fewer per layer forward, 6 fewer backward.
 #include "common.h"
 #include "../../include/mlsp_hip.h"
+#include <cstdlib>
 
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
-                double* stat_part, const float* sel_gamma, float* sel_val, int* sel_row, bool accumulate, const GemmXf* xf, int stat_ld);
+                double* stat_part, const float* sel_gamma, float* sel_val, int* sel_row, bool accumulate, const GemmXf* xf, int stat_ld,
+                const GemmGroups* grp = nullptr);
 int gemm_panel_rows(int M, int N, int K);
 int gemm_stat_parts(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K);
@@ -201,6 +203,21 @@ static int multi_check(const float* X, int ldx, int M, const mlsp_seg_t* segs, i
     return MLSP_OK;
 }
 
+// Length of the run of segments starting at s that ONE block-diagonal GEMM launch can take (gemm.hip GemmGroups): same shape and
+// weight pitch, no bias, input slices back to back, widths a multiple of the 128-wide tile, interior 16-byte-aligned operands.
+static int multi_group_run(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, int s) {
+    static const bool off = getenv("MLSP_NO_GROUPED_GEMM") != nullptr;          // read-once A/B switch
+    const mlsp_seg_t& a = segs[s];
+    if (off || a.bias || a.Cin % 128 || a.Cout % 128 || M % 128 || ldx % 4 || a.ldw % 4 || (((uintptr_t)X | (uintptr_t)a.W) & 15)) return 1;
+    int n = 1;
+    while (s + n < nseg && n < 4) {
+        const mlsp_seg_t& b = segs[s + n];
+        if (b.bias || b.Cin != a.Cin || b.Cout != a.Cout || b.ldw != a.ldw || b.x_col != a.x_col + n * a.Cin || ((uintptr_t)b.W & 15)) break;
+        ++n;
+    }
+    return n;
+}
+
 extern "C" {
 
 int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg) {
@@ -224,23 +241,29 @@ int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs
     if ((((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)chan | (uintptr_t)bn_save) & 15) != 0) return MLSP_ERR_UNSUPPORTED;
     Workspace w(ws, ws_bytes);
     // BatchNorm sums out of the GEMM epilogues when every segment uses the same row-panel height (their partial rows then line up)
+    // launches: runs of identical region-head segments go out as ONE block-diagonal GEMM (twice the tiles per launch: the second
+    // generation of tiles covers the first one's output pass), the others one by one
+    int run[8];
+    for (int s = 0; s < nseg; s += run[s]) { run[s] = multi_group_run(X, ldx, M, segs, nseg, s); for (int t = 1; t < run[s]; ++t) run[s + t] = 0; }
     bool fused = training != 0;
-    const int bm = gemm_panel_rows(M, segs[0].Cout, segs[0].Cin);
-    for (int s = 0; s < nseg && fused; ++s)
-        fused = gemm_stat_parts(M, segs[s].Cout, segs[s].Cin) > 0 && gemm_panel_rows(M, segs[s].Cout, segs[s].Cin) == bm;
+    const int bm = gemm_panel_rows(M, run[0] * segs[0].Cout, segs[0].Cin);
+    for (int s = 0; s < nseg && fused; s += run[s])
+        fused = gemm_stat_parts(M, run[s] * segs[s].Cout, segs[s].Cin) > 0 && gemm_panel_rows(M, run[s] * segs[s].Cout, segs[s].Cin) == bm;
     int nparts = fused ? (M + bm - 1) / bm : bn_vec_parts(M);
     const int npmax = nparts > bn_vec_parts(M) ? nparts : bn_vec_parts(M);
     double* part = w.take<double>((size_t)(npmax > (M + 255) / 256 ? npmax : (M + 255) / 256) * 2 * Ctot);
     size_t sf = 0;                                             // (small M: a segment's GEMM may split K; then the statistics are a separate pass)
-    for (int s = 0; s < nseg; ++s) { const size_t f = gemm_slab_floats(M, segs[s].Cout, segs[s].Cin); sf = f > sf ? f : sf; }
+    for (int s = 0; s < nseg; s += run[s]) { const size_t f = gemm_slab_floats(M, run[s] * segs[s].Cout, segs[s].Cin); sf = f > sf ? f : sf; }
     float* slab = sf ? w.take<float>(sf) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     int ycol = 0;
-    for (int s = 0; s < nseg; ++s) {
+    for (int s = 0; s < nseg; s += run[s]) {
         const mlsp_seg_t& g = segs[s];
-        MCHECK(launch_gemm(st, false, true, M, g.Cout, g.Cin, X + g.x_col, ldx, g.W, g.ldw, Y + ycol, Ctot, g.bias, nullptr, 0, slab, sf,
-                           fused ? part + ycol : nullptr, nullptr, nullptr, nullptr, false, nullptr, Ctot));
-        ycol += g.Cout;
+        GemmGroups grp = {run[s], 1, g.Cin, 0, {nullptr, nullptr, nullptr, nullptr}};
+        for (int t = 0; t < run[s]; ++t) grp.Bg[t] = segs[s + t].W;
+        MCHECK(launch_gemm(st, false, true, M, run[s] * g.Cout, g.Cin, X + g.x_col, ldx, g.W, g.ldw, Y + ycol, Ctot, g.bias, nullptr, 0, slab, sf,
+                           fused ? part + ycol : nullptr, nullptr, nullptr, nullptr, false, nullptr, Ctot, run[s] > 1 ? &grp : nullptr));
+        ycol += run[s] * g.Cout;
     }
     float* scale = bn_save, *shift = bn_save + Ctot, *mean = bn_save + 2 * Ctot, *invstd = bn_save + 3 * Ctot;
     if (training) {
@@ -270,9 +293,16 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
     double* part = w.take<double>((size_t)nparts * 2 * Ctot);
     float* mean_dz = w.take<float>(Ctot);
     float* mean_dzy = w.take<float>(Ctot);
+    int run[8];                                                 // block-diagonal launches: as in the forward; the wgrad needs the run's dW back to back
+    for (int s = 0; s < nseg; s += run[s]) {
+        run[s] = multi_group_run(X, ldx, M, segs, nseg, s);
+        for (int t = 1; t < run[s]; ++t)
+            if (!dW[s + t] || dW[s + t] != dW[s] + (size_t)t * segs[s].Cout * segs[s].Cin) { run[s] = 1; break; }
+        for (int t = 1; t < run[s]; ++t) run[s + t] = 0;
+    }
     size_t sf = 0;
-    for (int s = 0; s < nseg; ++s) {
-        const size_t f = gemm_slab_floats(segs[s].Cout, segs[s].Cin, M), f2 = dX ? gemm_slab_floats(M, segs[s].Cin, segs[s].Cout) : 0;
+    for (int s = 0; s < nseg; s += run[s]) {
+        const size_t f = gemm_slab_floats(run[s] * segs[s].Cout, segs[s].Cin, M), f2 = dX ? gemm_slab_floats(M, run[s] * segs[s].Cin, segs[s].Cout) : 0;
         sf = f > sf ? f : sf; sf = f2 > sf ? f2 : sf;
     }
     float* slab = sf ? w.take<float>(sf) : nullptr;
@@ -287,23 +317,28 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
                        training ? mean_dz : (const float*)nullptr, mean_dzy, th, ik, seed);
     MCHECK(mlsp_launch_status());
     int ycol = 0;
-    for (int s = 0; s < nseg; ++s) {
+    for (int s = 0; s < nseg; s += run[s]) {
         const mlsp_seg_t& g = segs[s];
-        if (!dW[s]) return MLSP_ERR_ARG;
+        const int G = run[s];
+        for (int t = 0; t < G; ++t) if (!dW[s + t]) return MLSP_ERR_ARG;
+        GemmGroups grp = {G, 1, g.Cout, 0, {nullptr, nullptr, nullptr, nullptr}};
+        for (int t = 0; t < G; ++t) grp.Bg[t] = segs[s + t].W;
         if (dX) {
-            bool acc = false;                                  // a second segment on the same input columns adds (partial overlaps: rejected)
+            bool acc = false;                                  // an earlier segment on the same input columns: add (partial overlaps: rejected)
             for (int t = 0; t < s; ++t) {
                 const bool same = segs[t].x_col == g.x_col && segs[t].Cin == g.Cin;
-                const bool apart = segs[t].x_col + segs[t].Cin <= g.x_col || g.x_col + g.Cin <= segs[t].x_col;
+                const bool apart = segs[t].x_col + segs[t].Cin <= g.x_col || g.x_col + G * g.Cin <= segs[t].x_col;
                 if (!same && !apart) return MLSP_ERR_UNSUPPORTED;
                 acc |= same;
             }
-            MCHECK(launch_gemm(st, false, false, M, g.Cin, g.Cout, dY + ycol, Ctot, g.W, g.ldw, dX + g.x_col, lddx, nullptr, nullptr, 0, slab, sf,
-                               nullptr, nullptr, nullptr, nullptr, acc, nullptr, 0));
+            if (acc && G > 1) return MLSP_ERR_UNSUPPORTED;
+            MCHECK(launch_gemm(st, false, false, M, G * g.Cin, g.Cout, dY + ycol, Ctot, g.W, g.ldw, dX + g.x_col, lddx, nullptr, nullptr, 0, slab, sf,
+                               nullptr, nullptr, nullptr, nullptr, acc, nullptr, 0, G > 1 ? &grp : nullptr));
         }
-        MCHECK(launch_gemm(st, true, false, g.Cout, g.Cin, M, dY + ycol, Ctot, X + g.x_col, ldx, dW[s], g.Cin, nullptr, nullptr, 0, slab, sf,
-                           nullptr, nullptr, nullptr, nullptr, false, nullptr, 0));
-        ycol += g.Cout;
+        GemmGroups grw = {G, 2, 0, g.Cin, {nullptr, nullptr, nullptr, nullptr}};
+        MCHECK(launch_gemm(st, true, false, G * g.Cout, g.Cin, M, dY + ycol, Ctot, X + g.x_col, ldx, dW[s], g.Cin, nullptr, nullptr, 0, slab, sf,
+                           nullptr, nullptr, nullptr, nullptr, false, nullptr, 0, G > 1 ? &grw : nullptr));
+        ycol += G * g.Cout;
     }
     if (dbias) {
         if (training) {      // a bias in front of a batch-statistics BatchNorm: analytically zero gradient

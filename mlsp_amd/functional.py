@@ -495,7 +495,12 @@ class _MultiMLP(Function):
             covered = sorted((xc, xc + w.shape[1]) for xc, w in zip(x_cols, Ws))
             full = covered[0][0] == 0 and covered[-1][1] == X.shape[1] and all(a[1] >= b[0] for a, b in zip(covered, covered[1:]))
             dX = (torch.empty if full else torch.zeros)((M, X.shape[1]), dtype=torch.float32, device=dev)
-        dWs = [torch.empty((w.shape[0], w.shape[1]), dtype=torch.float32, device=dev) for w in Ws]
+        # (one buffer, segment after segment: the weight gradients of a run of identical segments come out of one block-diagonal launch)
+        dflat = torch.empty((sum(w.shape[0] * w.shape[1] for w in Ws),), dtype=torch.float32, device=dev)
+        dWs, o = [], 0
+        for w in Ws:
+            dWs.append(dflat[o:o + w.shape[0] * w.shape[1]].view(w.shape[0], w.shape[1]))
+            o += w.shape[0] * w.shape[1]
         dwp = (_lib._c.c_void_p * n)(*[d.data_ptr() for d in dWs])
         dbias = torch.empty((Ctot,), dtype=torch.float32, device=dev) if any(has_b) else None
         dgamma = torch.empty((Ctot,), dtype=torch.float32, device=dev)
