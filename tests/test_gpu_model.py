@@ -299,7 +299,7 @@ def test_merged_head_first_layers_equal_separate(dev):
             opt.step()                                                                    # updates in place, through the re-homed views
             assert all(torch.isfinite(p).all().item() for p in m.parameters())
             assert ids == {n: id(p) for n, p in m.named_parameters()}
-            adjacent = Fh._adjacent([m.DefRec.conv1.weight, m.Density_cls.conv1.weight, m.Norm_pred.conv1.weight])
+            adjacent = Fh._adjacent([m.DefRec.conv1.weight, m.Norm_pred.conv1.weight, m.Density_cls.conv1.weight])   # region heads first
             assert adjacent == bool(merged)
             m2 = copy.deepcopy(m)
             m2.load_state_dict(m.state_dict(), strict=True)
