@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256) void edge_reduce_vec_kernel(const float* __res
 // (u16) are staged in LDS once; the k row gathers of every point then run at LDS rate instead of one L2 round trip per
 // neighbour row.  A thread owns (point, channel quad) and walks its k neighbours in slot order, so the first-occurrence
 // rule needs no cross-lane merge.  Partial BN statistics: one fp64 row per (cloud, chunk), each slice writes its columns.
-#define ELDS_CS 16
+#ifndef ELDS_CS
+#define ELDS_CS 8           // channels of a slice: 32 KB of LDS at N = 1024 (four workgroups per CU; 16 measured 2 % slower)
+#endif
 template <int KMAX, bool EXACT>     // EXACT: k == KMAX, the neighbour loop is straight-line (all index / row reads of a point in flight)
 __global__ __launch_bounds__(256) void edge_reduce_lds_kernel(const float* __restrict__ uv, const int* __restrict__ idx,
                                                               const float* __restrict__ gamma, int B, int N, int k, int Cout, int psplit,
