@@ -9,6 +9,7 @@
 #define MLSP_ERR_WORKSPACE (-2)  // workspace too small
 #define MLSP_ERR_UNSUPPORTED (-3)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
