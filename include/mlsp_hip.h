@@ -337,7 +337,9 @@ int mlsp_scan_select_f32(const float* X, int B, int N, int C, const double* R, i
 
 /* Operand precision of the GEMM family (process-wide switch, default 0).  0: fp32 MFMA, exact fp32 products -- the parity
  * contract of the fp32 configs.  1: operands rounded to bf16, fp32 accumulation (v_mfma_f32_32x32x16_bf16) for the launches on
- * the fast path (interior tiles, 16-byte aligned operands); BASELINE.json configs[4].  The kNN distances stay fp32 always. */
+ * the fast path (interior tiles, 16-byte aligned operands); BASELINE.json configs[4].  2: fp32-accurate products on the bf16 matrix
+ * cores for the same launches: every operand value split into three bf16 pieces, six piece products per multiply, fp32 accumulation
+ * (error at the level of an fp32 FMA chain; 6/16 of the f32-MFMA matrix time).  The kNN distances stay exact fp32 always. */
 int mlsp_set_gemm_precision(int mode);
 
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP

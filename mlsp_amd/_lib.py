@@ -108,6 +108,14 @@ class MlspLibraryError(RuntimeError):
     pass
 
 
+# GEMM products (include/mlsp_hip.h mlsp_set_gemm_precision; functional.gemm_precision is the switch).  The process default can be set
+# with MLSP_GEMM_PRECISION (tools/ab, the test-suite's mode sweep); an unknown name fails loudly at import.
+GEMM_PRECISION_MODES = {"fp32": 0, "bf16": 1, "bf16x6": 2}
+DEFAULT_GEMM_PRECISION = os.environ.get("MLSP_GEMM_PRECISION", "fp32")
+if DEFAULT_GEMM_PRECISION not in GEMM_PRECISION_MODES:
+    raise ValueError("MLSP_GEMM_PRECISION=%r: expected one of %s" % (DEFAULT_GEMM_PRECISION, sorted(GEMM_PRECISION_MODES)))
+
+
 def load():
     """Load libmlsp_hip.so and bind every symbol of include/mlsp_hip.h.  Raises if it is missing."""
     global _lib
@@ -125,6 +133,9 @@ def load():
     if lib.mlsp_abi_version() != ABI_VERSION:
         raise MlspLibraryError("mlsp_amd: ABI mismatch: library %d, python %d" % (lib.mlsp_abi_version(), ABI_VERSION))
     _lib = lib
+    rc = lib.mlsp_set_gemm_precision(GEMM_PRECISION_MODES[DEFAULT_GEMM_PRECISION])
+    if rc != 0:
+        raise MlspLibraryError("mlsp_amd: mlsp_set_gemm_precision(%s) failed (%d)" % (DEFAULT_GEMM_PRECISION, rc))
     return lib
 
 

@@ -764,9 +764,179 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     gemm_epilogue<WM, !NEDGE, CB16>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 }
 
-static int g_gemm_precision = 0;     // 0: fp32 MFMA (exact fp32 products); 1: bf16 operands, fp32 accumulation
+// ---- fp32-accurate products on the bf16 matrix cores (mlsp_set_gemm_precision(2)) ---------------------------------------------------
+// On gfx950 the f32 MFMA runs at 1/16 of the bf16 MFMA rate.  Every fp32 operand value is split, while its tile is staged, into three
+// bf16 pieces x = a + b + c (a = bf16(x), b = bf16(x - a), c = bf16(x - a - b): 8 + 8 + 8 significand bits, RNE, the remainders are exact
+// in fp32), and x y is taken as the six products a a' + (a b' + b a') + (a c' + c a' + b b') on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation.  Each piece product is exact (8 x 8 bits); the dropped terms (b c', c b', c c') are below 2^-25 |x y|: the result is as
+// accurate as an fp32 fused-multiply-add chain (tests/test_gpu_kernels.py::test_gemm_split_bf16_accuracy measures both against
+// float64) for 6/16 of the matrix time.  Interior-tile shapes with fp32 operands and output only; same epilogues as the fp32 kernel.
+// NOT a k-ordered fmaf chain: the kNN kernels (bit-exact canonical distances) never use it.
+//
+// Structure (measured in tools/x6: 1.55-1.65x the fp32 kernel on the 32768-row layers; the variants that lost are listed there):
+//   * one LDS buffer of six bf16 images (A: hi | mid | lo, B: hi | mid | lo), two workgroups per CU;
+//   * an operand whose global source is row-major ([rows][K]) is imaged [row][32 k + 8 pad] and read with one ds_read_b128 per fragment;
+//     one whose source is k-major ([K][rows]: the dgrad's W, both wgrad operands) is imaged [k][128 rows + 32 pad] -- written as it is
+//     loaded (8-byte rows, no transposing 2-byte stores) and read with two ds_read_b64_tr_b16 per fragment; the 320-byte pitch puts the
+//     four k-rows of a transposed read in four different 64-byte bank windows;
+//   * per K-tile: all 24 fragments of tile t are read, barrier, then the 48 (24) MFMAs of tile t run with the split + image write of tile
+//     t+1 and the global loads of tile t+2 hand-placed between them (gen_split_body.py -> gemm_split_body_wm*.inc), barrier.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define SX_PLANE 10240            // bytes of one bf16 image of a 128 x 32 operand tile: [128 rows][80 B] or [32 k][320 B]
+#define SX_RPITCH 80
+#define SX_KPITCH 320
+#define SX_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ uint32_t sx_cvt_pk(float lo, float hi) {       // one v_cvt_pk_bf16_f32 (RNE)
+    const f32x2 v = {lo, hi};
+    const bf16x2 b = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(uint32_t, b);
+}
+// three-way split of one staged quad into the three images (prologue only: the K loop uses the hand-placed stream)
+__device__ __forceinline__ void sx_split_store(const f32x4& x, char* d) {
+    uint32_t pk[3][2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const float x0 = x[2 * hh], x1 = x[2 * hh + 1];
+        pk[0][hh] = sx_cvt_pk(x0, x1);
+        const float r0 = x0 - __uint_as_float(pk[0][hh] << 16), r1 = x1 - __uint_as_float(pk[0][hh] & 0xffff0000u);
+        pk[1][hh] = sx_cvt_pk(r0, r1);
+        pk[2][hh] = sx_cvt_pk(r0 - __uint_as_float(pk[1][hh] << 16), r1 - __uint_as_float(pk[1][hh] & 0xffff0000u));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *(u32x2*)(d + q * SX_PLANE) = (u32x2){pk[q][0], pk[q][1]};
+}
+__device__ __forceinline__ f32x4 sx_bufload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+}
+// this lane's byte offset of a fragment inside an image (rows rb .. rb+31 of the tile start at + rb * (KMAJ ? 2 : SX_RPITCH))
+template <bool KMAJ>
+__device__ __forceinline__ int sx_frag_base(int lane) {
+    if (!KMAJ) return (lane & 31) * SX_RPITCH + 16 * (lane >> 5);
+    const int i = lane & 15;            // ds_read_b64_tr_b16: lane 4q + p of a 16-lane group supplies row (= k) q, columns 4p .. 4p+3
+    return (8 * (lane >> 5) + (i >> 2)) * SX_KPITCH + (16 * ((lane >> 4) & 1) + 4 * (i & 3)) * 2;
+}
+// fragment of the k16 step s2: rows = this lane's row of the 32-row window, k = 16 s2 + 8 h .. + 7
+template <bool KMAJ>
+__device__ __forceinline__ bf16x8 sx_frag(const char* img_at_window, int s2) {
+    if (!KMAJ) return *(const bf16x8*)(img_at_window + 32 * s2);
+    const char* a = img_at_window + 16 * s2 * SX_KPITCH;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SX_LDS bf16x4*)(a));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SX_LDS bf16x4*)(a + 4 * SX_KPITCH));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool TA, bool TB, int WM>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
+    constexpr bool KA = TA, KB = !TB;                                 // operand's global source is k-major
+    constexpr int BMT = 64 * WM, NQA = 2 * WM;                        // A quads (16-byte loads) of a tile per thread; B: 4
+    __shared__ __attribute__((aligned(16))) char simg[6 * SX_PLANE];  // 61,440 B
+    float* smem = (float*)simg;                                       // epilogue scratch (the images are dead by then)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = blockIdx.x;
+    int tm, tn;
+    if (p.xcd_map) {
+        const int xcd = bid & 7, q = bid >> 3;
+        tn = q % p.ntn;
+        tm = (q / p.ntn) * 8 + xcd;
+        if (tm >= p.ntm) return;
+    } else {
+        tn = bid % p.ntn;
+        tm = bid / p.ntn;
+    }
+    const int split = blockIdx.y;
+    const int m0 = tm * BMT, n0 = tn * BN;
+    const int kbeg = split * p.ksplit;
+    const int kend = min(p.K, kbeg + p.ksplit);
+    const int T = (kend - kbeg) / BK;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // operand origins of this tile (block-diagonal launches: GemmArgs groups, as gemm_f32_kernel<.., GRP>); n0b = first column inside the group's B
+    const float* Ap = p.A;
+    const float* Bp = p.B;
+    int n0b = n0;
+    if (p.gmode == 1) {
+        const int g = tn / p.gtiles;
+        Ap += (size_t)g * p.a_gs;
+        Bp = g == 0 ? p.Bg[0] : g == 1 ? p.Bg[1] : g == 2 ? p.Bg[2] : p.Bg[3];
+        n0b = (tn - g * p.gtiles) * BN;
+    } else if (p.gmode == 2) {
+        Bp += (size_t)(tm / p.gtiles) * p.b_gs;
+    }
+    // global loads through buffer descriptors based at the tile's first element of this K range (scalar); voa / vob = this thread's byte
+    // offset inside the tile (one register each, fixed); the K-tile advance and the quad step are scalar offsets: no vector instruction of
+    // the K loop computes an address.  soa / sob are clamped at the last tile (the stream always loads "tile t+2").
+    const int lda4 = p.lda * 4, ldb4 = p.ldb * 4;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(KA ? Ap + (size_t)kbeg * p.lda + m0 : Ap + (size_t)m0 * p.lda + kbeg), 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(KB ? Bp + (size_t)kbeg * p.ldb + n0b : Bp + (size_t)n0b * p.ldb + kbeg), 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+    const int voa = KA ? (NQA == 4 ? (tid >> 5) : (tid >> 4)) * lda4 + (NQA == 4 ? (tid & 31) : (tid & 15)) * 16 : (tid >> 3) * lda4 + (tid & 7) * 16;
+    const int vob = KB ? (tid >> 5) * ldb4 + (tid & 31) * 16 : (tid >> 3) * ldb4 + (tid & 7) * 16;
+    const int sta = KA ? BK * lda4 : BK * 4, stb = KB ? BK * ldb4 : BK * 4;                       // one K-tile on
+    const int qa_ = (KA ? (NQA == 4 ? 8 : 16) : 32) * lda4, qb_ = (KB ? 8 : 32) * ldb4;           // one quad on
+    const int enda = (T - 1) * sta, endb = (T - 1) * stb;
+    int soa = 0, sob = 0;
+#define SX_LOAD_A(q) sx_bufload(rsa, voa, soa + (q) * qa_)
+#define SX_LOAD_B(q) sx_bufload(rsb, vob, sob + (q) * qb_)
+    // this thread's place in the images
+    char* wa = simg + (KA ? (NQA == 4 ? (tid >> 5) * SX_KPITCH + (tid & 31) * 8 : (tid >> 4) * SX_KPITCH + (tid & 15) * 8) : (tid >> 3) * SX_RPITCH + (tid & 7) * 8);
+    char* wb = simg + 3 * SX_PLANE + (KB ? (tid >> 5) * SX_KPITCH + (tid & 31) * 8 : (tid >> 3) * SX_RPITCH + (tid & 7) * 8);
+    constexpr int WQA = KA ? (NQA == 4 ? 8 : 16) * SX_KPITCH : 32 * SX_RPITCH, WQB = KB ? 8 * SX_KPITCH : 32 * SX_RPITCH;
+    const char* fa = simg + sx_frag_base<KA>(lane) + (wm * 32 * WM) * (KA ? 2 : SX_RPITCH);
+    const char* fb = simg + 3 * SX_PLANE + sx_frag_base<KB>(lane) + (wn * 64) * (KB ? 2 : SX_RPITCH);
+    constexpr int FWA = 32 * (KA ? 2 : SX_RPITCH), FWB = 32 * (KB ? 2 : SX_RPITCH);               // next 32-row window
+    f32x4 raw[8];                                                     // [0, NQA) A quads, then 4 B quads of the tile being staged
+#pragma unroll
+    for (int q = 0; q < NQA; ++q) sx_split_store(SX_LOAD_A(q), wa + q * WQA);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sx_split_store(SX_LOAD_B(q), wb + q * WQB);
+    soa = min(soa + sta, enda); sob = min(sob + stb, endb);
+#pragma unroll
+    for (int q = 0; q < NQA; ++q) raw[q] = SX_LOAD_A(q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[NQA + q] = SX_LOAD_B(q);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        bf16x8 a[2][2][3], b[2][2][3];                               // [k16 step][32-row window][piece]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[s2][i][q] = sx_frag<KA>(fa + q * SX_PLANE + i * FWA, s2);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[s2][j][q] = sx_frag<KB>(fb + q * SX_PLANE + j * FWB, s2);
+            }
+        __syncthreads();                                              // every wave holds its fragments: the images may be overwritten
+        soa = min(soa + sta, enda); sob = min(sob + stb, endb);      // tile t+2 (past the end: a harmless repeat of the last tile)
+        uint32_t pk0[2], pk1[2], pk2[2];
+        float r0, r1, a1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (WM == 2) {
+#include "gemm_split_body_wm2.inc"
+        } else {
+#include "gemm_split_body_wm1.inc"
+        }
+        __syncthreads();
+    }
+#undef SX_LOAD_A
+#undef SX_LOAD_B
+    gemm_epilogue<WM, true, false>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
+}
+
+static int g_gemm_precision = 0;     // 0: fp32 MFMA (exact fp32 products); 1: bf16 operands, fp32 accumulation; 2: fp32-accurate six-product bf16 split (gemm_split_kernel)
+int gemm_precision_mode() { return g_gemm_precision; }
 extern "C" int mlsp_set_gemm_precision(int mode) {
-    if (mode != 0 && mode != 1) return MLSP_ERR_ARG;
+    if (mode != 0 && mode != 1 && mode != 2) return MLSP_ERR_ARG;
     g_gemm_precision = mode;
     return MLSP_OK;
 }
@@ -893,9 +1063,14 @@ int gemm_pick_split(int M, int N, int K) {
 
 // number of BN-statistic partial rows a stats-fused launch writes (0: the launch would split K, use colstats)
 // 64-row tiles when the 128-row grid is too small to keep ~3 workgroups per CU busy (and K is not split)
+// mode 2: does a contraction of `ktiles` K-tiles per workgroup and N columns go to the split kernel?  Short K loops stay on the fp32 kernel
+// (measured per launch on the headline step, tools/cmp_dump.py: the split kernel's longer prologue loses below these sizes)
+static bool gemm_split_pays(int N, int ktiles) { return ktiles >= 8 || (ktiles >= 4 && N >= 256); }
 static int gemm_pick_bm(int M, int N, int K) {
     long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN);
-    return (gemm_pick_split(M, N, K) == 1 && tiles128 < 1536 && M >= 256) ? 64 : 128;
+    // the split kernel amortises its operand split over the tile: 128 rows unless the grid would not fill the 512 workgroup slots
+    const long few = (g_gemm_precision == 2 && gemm_split_pays(N, (K + BK - 1) / BK)) ? 512 : 1536;
+    return (gemm_pick_split(M, N, K) == 1 && tiles128 < few && M >= 256) ? 64 : 128;
 }
 int gemm_stat_parts(int M, int N, int K) {
     if (gemm_pick_split(M, N, K) != 1) return 0;
@@ -1014,7 +1189,7 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
 // Can this contraction stage `which` (1: A [M][K] row-major, 2: B [K][N] k-major) through the operand transform?  Interior tiles,
 // 16-byte loads, fp32 operands, the MFMA tile kernels (not the thin / skinny / N = 64 ones).
 bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which) {
-    if (g_gemm_precision != 0) return false;
+    if (g_gemm_precision == 1) return false;          // (mode 2 keeps the fp32 transform kernels: exact fp32 either way)
     if (which == 1 ? ta : !(ta && !tb)) return false;
     if (M <= 32 || N < 32 || K < 32 || (ta && !tb && K <= 32)) return false;
     const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
@@ -1034,7 +1209,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
     if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
     // one tiny dimension (3 coordinates, 3 / 16 outputs): streaming VALU kernels priced against HBM, not MFMA tiles (thin.hip)
-    if (grp && (grp->G < 2 || grp->G > 4 || xf || sel_gamma || gbias || g_gemm_precision != 0 || (ta && tb))) return MLSP_ERR_UNSUPPORTED;
+    if (grp && (grp->G < 2 || grp->G > 4 || xf || sel_gamma || gbias || g_gemm_precision == 1 || (ta && tb))) return MLSP_ERR_UNSUPPORTED;
     if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf) {
         const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
@@ -1088,14 +1263,14 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (grp) {
         const int per = (grp->mode == 1 ? N : M) / grp->G;                  // columns (mode 1) / rows (mode 2) of one group
         const int tile = grp->mode == 1 ? BN : bm;
-        bool ok = fast && g_gemm_precision == 0 && (grp->mode == 1 || grp->mode == 2) && per * grp->G == (grp->mode == 1 ? N : M) && per % tile == 0;
+        bool ok = fast && g_gemm_precision != 1 && (grp->mode == 1 || grp->mode == 2) && per * grp->G == (grp->mode == 1 ? N : M) && per % tile == 0;
         for (int g = 0; g < grp->G && ok && grp->mode == 1; ++g) ok = grp->Bg[g] && (((uintptr_t)grp->Bg[g] & 15) == 0);
         if (!ok) return MLSP_ERR_UNSUPPORTED;
         p.gmode = grp->mode; p.gtiles = per / tile; p.a_gs = grp->a_gs; p.b_gs = grp->b_gs;
         for (int g = 0; g < 4; ++g) p.Bg[g] = grp->mode == 1 ? grp->Bg[g < grp->G ? g : 0] : B;
     }
     const bool n64 = !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
-                     (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && g_gemm_precision == 0 && (ns == 1 || p.ldc == N);
+                     (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && g_gemm_precision != 1 && (ns == 1 || p.ldc == N);
     if (n64) {
         dim3 g64(M / 128, ns);
         if (!ta && tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, true>), g64, dim3(256), 0, st, p);
@@ -1103,9 +1278,15 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         else hipLaunchKernelGGL((gemm_f32_n64_kernel<true, false>), g64, dim3(256), 0, st, p);
     } else
 #define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
+                                     else if (fast && g_gemm_precision == 2 && gemm_split_pays(N, kts)) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
-    if (grp) {                                            // block-diagonal launch (validated above: fast, fp32)
+    if (grp && g_gemm_precision == 2 && gemm_split_pays(N, kts)) {   // block-diagonal launch on the split kernel (groups are a run-time argument there)
+        if (grp->mode == 1 && !ta && tb) { if (bm == 128) GEMM_GO(false, true, 2); else GEMM_GO(false, true, 1); }
+        else if (grp->mode == 1 && !ta && !tb) { if (bm == 128) GEMM_GO(false, false, 2); else GEMM_GO(false, false, 1); }
+        else if (grp->mode == 2 && ta && !tb) { if (bm == 128) GEMM_GO(true, false, 2); else GEMM_GO(true, false, 1); }
+        else return MLSP_ERR_UNSUPPORTED;
+    } else if (grp) {                                     // block-diagonal launch (validated above: fast, fp32)
         if (grp->mode == 1 && !ta && tb) { if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 2, true, 0, 1>), grid, dim3(256), 0, st, p);
                                            else hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1, true, 0, 1>), grid, dim3(256), 0, st, p); }
         else if (grp->mode == 1 && !ta && !tb) { if (bm == 128) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, true, 0, 1>), grid, dim3(256), 0, st, p);

@@ -19,6 +19,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
                 double* stat_part, const float* sel_gamma, float* sel_val, int* sel_row, bool accumulate, const GemmXf* xf, int stat_ld,
                 const GemmGroups* grp = nullptr);
 int gemm_panel_rows(int M, int N, int K);
+int gemm_precision_mode();
 int gemm_stat_parts(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K);
 int bn_vec_parts(int M);
@@ -208,7 +209,7 @@ static int multi_check(const float* X, int ldx, int M, const mlsp_seg_t* segs, i
 static int multi_group_run(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, int s) {
     static const bool off = getenv("MLSP_NO_GROUPED_GEMM") != nullptr;          // read-once A/B switch
     const mlsp_seg_t& a = segs[s];
-    if (off || a.bias || a.Cin % 128 || a.Cout % 128 || M % 128 || ldx % 4 || a.ldw % 4 || (((uintptr_t)X | (uintptr_t)a.W) & 15)) return 1;
+    if (off || gemm_precision_mode() == 1 || a.bias || a.Cin % 128 || a.Cout % 128 || M % 128 || ldx % 4 || a.ldw % 4 || (((uintptr_t)X | (uintptr_t)a.W) & 15)) return 1;
     int n = 1;
     while (s + n < nseg && n < 4) {
         const mlsp_seg_t& b = segs[s + n];

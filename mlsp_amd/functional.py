@@ -41,14 +41,16 @@ def _rows(t, allow_bf16=False):
 
 class gemm_precision:
     """Context manager / switch for the operand precision of the GEMM family (include/mlsp_hip.h mlsp_set_gemm_precision):
-    "fp32" (default: exact fp32 products, the parity contract of the fp32 configs) or "bf16" (operands rounded to bf16, fp32
-    accumulation; BASELINE.json configs[4]).  kNN distances, BatchNorm statistics, reductions and losses stay fp32."""
-    _MODES = {"fp32": 0, "bf16": 1}
-    current = "fp32"
+    "fp32" (default: exact fp32 products on the f32 MFMA, the parity contract of the fp32 configs), "bf16" (operands rounded to bf16,
+    fp32 accumulation; BASELINE.json configs[4]) or "bf16x6" (fp32-ACCURATE products on the bf16 matrix cores: every operand split
+    into three bf16 pieces, six piece products per multiply, fp32 accumulation -- error at the level of an fp32 FMA chain, 6/16 of the
+    matrix time; opt-in).  kNN distances, BatchNorm statistics, reductions and losses stay fp32 (the kNN always exact fp32)."""
+    _MODES = _lib.GEMM_PRECISION_MODES
+    current = _lib.DEFAULT_GEMM_PRECISION
 
     def __init__(self, mode):
         if mode not in self._MODES:
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x6'")
         self.mode, self.prev = mode, None
 
     @classmethod
@@ -533,7 +535,7 @@ def channel_params(device, spec):
 
 
 def multimlp_supported(M, X, Ws, x_cols):
-    if (activation_storage.current != "fp32" or gemm_precision.current != "fp32" or X.dtype != torch.float32 or X.dim() != 2
+    if (activation_storage.current != "fp32" or gemm_precision.current == "bf16" or X.dtype != torch.float32 or X.dim() != 2
             or X.stride(1) != 1 or not X.is_cuda):
         return False
     n = len(Ws)

@@ -153,7 +153,7 @@ def test_gemm_bf16_operand_mode(dev, ta, tb, M, N, K):
     opA, opB = (A.t() if ta else A), (B.t() if tb else B)
     with Fh.gemm_precision("bf16"):
         got = Fh.gemm(A.to(dev), B.to(dev), ta=bool(ta), tb=bool(tb)).cpu().double()
-    assert Fh.gemm_precision.current == "fp32"
+    assert Fh.gemm_precision.current == Fh._lib.DEFAULT_GEMM_PRECISION
     fast = M % 64 == 0 and N % 128 == 0 and K % 32 == 0
     if fast:
         want = opA.bfloat16().double() @ opB.bfloat16().double()
@@ -201,6 +201,34 @@ def test_gemm_matches_fma_chain_bitwise(dev):
         acc = (acc + np.outer(a64[:, kk], b64[:, kk])).astype(np.float32).astype(np.float64)
     want = acc.astype(np.float32)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(False, True, 32768, 256, 512), (False, False, 32768, 512, 256), (True, False, 512, 256, 32768),
+                                          (False, True, 4096, 1024, 128), (False, True, 32768, 1024, 512), (False, False, 65536, 1024, 128),
+                                          (True, True, 256, 256, 16384), (True, False, 1024, 512, 32768), (False, True, 16384, 128, 64)])
+def test_gemm_split_bf16_accuracy(dev, ta, tb, M, N, K):
+    """gemm_precision("bf16x6"): products as six bf16 piece products on the bf16 matrix cores.  Against float64 its error must be at the
+    level of the exact-fp32 MFMA kernel's (both are fp32 accumulations of products exact to <= 2^-25): <= 2x that error and
+    <= 2e-6 relative L2 on random operands with a wide dynamic range.  The shapes cover both tile heights (64 / 128 rows), split-K, and
+    all four operand layouts (row-major images read with ds_read_b128, k-major images read with ds_read_b64_tr_b16)."""
+    Fh = _fh()
+    g = torch.Generator().manual_seed(11)
+    shpA, shpB = ((K, M) if ta else (M, K)), ((N, K) if tb else (K, N))
+    A = (torch.randn(shpA, generator=g) * torch.exp(2.0 * torch.randn(shpA, generator=g))).to(dev)
+    B = (torch.randn(shpB, generator=g) * torch.exp(2.0 * torch.randn(shpB, generator=g))).to(dev)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    exact = Fh.gemm(A, B, ta, tb).double()
+    with Fh.gemm_precision("bf16x6"):
+        split = Fh.gemm(A, B, ta, tb).double()
+    e32 = ((exact - ref).norm() / ref.norm()).item()
+    e6 = ((split - ref).norm() / ref.norm()).item()
+    m32 = ((exact - ref).abs().max() / ref.abs().max()).item()
+    m6 = ((split - ref).abs().max() / ref.abs().max()).item()
+    print("rel-L2 vs float64: fp32 MFMA %.2e, bf16x6 %.2e | max-abs / max: %.2e, %.2e" % (e32, e6, m32, m6))
+    assert not torch.equal(exact, split)                               # it really ran the other kernel
+    assert e6 < 2e-6 and e6 < 2.0 * e32 + 1e-8, (e6, e32)
+    assert m6 < 2.0 * m32 + 1e-7, (m6, m32)
+    assert Fh.gemm_precision.current == Fh._lib.DEFAULT_GEMM_PRECISION
 
 
 # ----------------------------------------------------------------------------- bf16 activation storage (configs[4])

@@ -519,7 +519,7 @@ def test_segda_config4_shape_vs_oracle(dev):
             grp = n.split(".")[0]
             worst[grp] = max(worst.get(grp, 0.0), rel(g16[n], g32[n]))
     print("configs[4] bf16 step, worst gradient rel-L2 vs the fp32 step per module:", {k: "%.3f" % v for k, v in worst.items()})
-    assert Fh.activation_storage.current == "fp32" and Fh.gemm_precision.current == "fp32"
+    assert Fh.activation_storage.current == "fp32" and Fh.gemm_precision.current == Fh._lib.DEFAULT_GEMM_PRECISION
 
 
 def test_segda_free_running_and_full_size(dev):
@@ -604,4 +604,4 @@ def test_bf16_operand_mode_on_segda_and_dgcnn(dev):
         out = m(x, activate_density_normal_ondef=True)
         sum(v.float().mean() for v in out.values()).backward()
     assert all(p.grad is None or torch.isfinite(p.grad).all().item() for p in m.parameters())
-    assert Fh.gemm_precision.current == "fp32"
+    assert Fh.gemm_precision.current == Fh._lib.DEFAULT_GEMM_PRECISION

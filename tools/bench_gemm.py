@@ -15,6 +15,7 @@ shapes = [  # (name, ta, tb, M, N, K)
     ("fc 32x1024x512", 0, 1, 32, 512, 1024), ("big 8192^2 x 1024", 0, 1, 8192, 8192, 1024),
 ]
 dev = torch.device("cuda:0")
+Fh.gemm_precision.set(os.environ.get("GEMM_PRECISION", "fp32"))          # fp32 | bf16 | bf16x6
 for name, ta, tb, M, N, K in shapes:
     A = torch.randn((K, M) if ta else (M, K), device=dev)
     B = torch.randn((N, K) if tb else (K, N), device=dev)
