@@ -27,6 +27,7 @@ FLOP_PER_POINT = 28.19e6        # algorithmic fwd+bwd FLOP per p
 PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6     # fp32-accurate product = six bf16 piece products (gemm_split_kernel)
 
 
 def pmc_gemm_traffic():
@@ -171,7 +172,7 @@ def cpu_baseline(budget_s=45.0):
             "runs": runs, "cpu_model": model_name, "physical_cores": physical, "logical_cpus": logical}
 
 
-PROF_CLASSES = 7          # include/mlsp_hip.h MLSP_PROF_CLASSES
+PROF_CLASSES = 8          # include/mlsp_hip.h MLSP_PROF_CLASSES
 
 
 def profiled_steps(lib, step_fn, nsteps):
@@ -245,12 +246,20 @@ def secondary_workloads(lib, dev):
 
     ms = median_block_ms(sa_step, 10, 3, 4)
     rows, g, _ = profiled_steps(lib, sa_step, 2)
-    ach = g[2] / (g[0] * 1e-3) / 1e12 if g[0] > 0 else 0.0
+    sp = rows[7]                                   # the launches that ran on the bf16-split kernel; the rest ran on the f32 MFMA kernels
+    f32_ms, f32_flop = g[0] - sp[0], g[2] - sp[2]
+    ach_sp = sp[2] / (sp[0] * 1e-3) / 1e12 if sp[0] > 0 else 0.0
+    ach32 = f32_flop / (f32_ms * 1e-3) / 1e12 if f32_ms > 0 else 0.0
+    roof = ({"kernel": "gemm_split_kernel<*> (SA-MLP contractions, six bf16 piece products per fp32 product)", "bound": "mfma", "achieved": ach_sp,
+             "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach_sp / PEAK_SPLIT_TFLOPS, "vs_f32_mfma_peak": ach_sp / PEAK_FP32_TFLOPS,
+             "share_of_step": sp[0] / 2 / ms, "launches_per_step": sp[1] / 2,
+             "f32_mfma_launches": {"achieved": ach32, "frac": ach32 / PEAK_FP32_TFLOPS, "share_of_step": f32_ms / 2 / ms,
+                                   "launches_per_step": (g[1] - sp[1]) / 2}} if sp[1] > 0 else
+            {"kernel": "gemm_f32_kernel<*> (SA-MLP contractions)", "bound": "mfma", "achieved": ach32, "peak": PEAK_FP32_TFLOPS,
+             "unit": "TFLOP/s", "frac": ach32 / PEAK_FP32_TFLOPS, "share_of_step": g[0] / 2 / ms, "launches_per_step": g[1] / 2})
     out.append({"workload": "PointNet++ SA encoder (3 set-abstraction layers: FPS + ball query + grouping + SA-MLP), fwd+bwd, B=32 N=2048 "
                             "(BASELINE.json configs[3])", "ms_per_step": ms, "points_per_s": B * N / ms * 1e3, "dtype": "f32",
-                "roofline": {"kernel": "gemm_f32_kernel<*> (SA-MLP contractions)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-                             "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "share_of_step": g[0] / 2 / ms,
-                             "launches_per_step": g[1] / 2}})
+                "gemm_products": Fh.gemm_precision.current, "roofline": roof})
     del layers, params, xyz
 
     # configs[4]: PointSegDA DGCNN_DefRec (PointSegDA/Models.py:197-242), N=2048, k=40, all heads, fwd + bwd + Adam, bf16 GEMM operands and
@@ -300,6 +309,7 @@ def main():
                          "Default 0 = weak scaling, 32 clouds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] runs after the headline")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the comparison blocks with every GEMM on the f32 MFMA")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -321,7 +331,7 @@ def main():
     else:
         b_local, scaling = B_PER_GPU, "weak"
 
-    from mlsp_amd import Models, mlsp, _lib
+    from mlsp_amd import Models, mlsp, _lib, functional as Fh
     from mlsp_amd.ddp import FlatGradSync
     lib = _lib.load()
     args = make_args()
@@ -381,6 +391,14 @@ def main():
     prof_steps = 3
     rows, prof, prof_dt = profiled_steps(lib, one_step, prof_steps)
 
+    # the same step with every GEMM on the f32 MFMA, for the record (not the headline): one settle block + the same number of blocks
+    f32_leg, f32_blocks = None, []
+    if Fh.gemm_precision.current == "bf16x6" and not a.no_fp32_leg:
+        with Fh.gemm_precision("fp32"):
+            timed_block()
+            f32_blocks = [timed_block()[0] for _ in range(max(1, a.repeats))]
+        f32_leg = sorted(f32_blocks)[len(f32_blocks) // 2]
+
     if rank == 0:
         pts = b_local * NPTS * n_gpus * a.steps
         value = pts / dt
@@ -393,21 +411,50 @@ def main():
                "config": {"workload": "DGCNN encoder + 3 MLSP heads + losses, fwd+bwd+Adam, B=%d/GPU N=1024 k=20 fp32 "
                                       "(BASELINE.json configs[1]), dropout 0.5, BN train" % b_local,
                           "global_batch": b_local * n_gpus, "points_per_cloud": NPTS, "k": K_NN,
-                          "parallelism": "dp%d" % n_gpus, "grad_allreduce": "1 x flat 18.2 MB fp32 per step (RCCL)"}}
+                          "parallelism": "dp%d" % n_gpus, "grad_allreduce": "1 x flat 18.2 MB fp32 per step (RCCL)",
+                          "gemm_products": "%s (bf16x6 = fp32 operands split exactly into three bf16 pieces, six piece products, fp32 "
+                                           "accumulation: error vs float64 below the f32-MFMA chain's, tests/test_gpu_kernels.py::"
+                                           "test_gemm_split_bf16_accuracy; MLSP_GEMM_PRECISION=fp32 runs every GEMM on the f32 MFMA)"
+                                           % Fh.gemm_precision.current}}
+        if f32_leg is not None:
+            out["fp32_mfma"] = {"ms_per_step": 1e3 * f32_leg / a.steps, "value": pts / f32_leg,
+                                "note": "the same step with every GEMM on the f32 MFMA (gemm_precision('fp32')): median of %d blocks "
+                                        "of %d steps, timed after the headline blocks in the same process" % (len(f32_blocks), a.steps)}
         if prof and prof[1] > 0:
-            # prof = [total ms of the profiled kernel, launches, algorithmic FLOP summed over launches, algorithmic bytes]
-            ach = prof[2] / (prof[0] * 1e-3) / 1e12
+            # prof = [total ms of the GEMM family, launches, algorithmic FLOP summed over launches, algorithmic bytes];
+            # rows[7] = the subset that ran on the bf16-split kernel (default mode "bf16x6"), the rest ran on the f32 MFMA kernels
             traffic, traffic_src = pmc_gemm_traffic()
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
-                               "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE), %s; algorithmic A+B+C bytes per "
-                                               "launch: %.0f" % (traffic_src, prof[3] / prof[1]),
-                               "kernel": "gemm_f32_kernel<*> (every fp32 MFMA GEMM launch: fwd, dgrad, wgrad)",
-                               "launches": int(prof[1]), "avg_us": 1e3 * prof[0] / prof[1],
-                               "share_of_step": prof[0] / prof_steps / (1e3 * dt / a.steps),
-                               "note": "achieved = sum(2*M*N*K of the launches: EXECUTED flops) / sum(HIP-event time of the "
-                                       "launches), events on the launch stream, %d untimed steps after the timed blocks "
-                                       "(%.2f ms/step with the events armed)" % (prof_steps, 1e3 * prof_dt)}
+            sp = rows[7]
+            step_ms = 1e3 * dt / a.steps
+            common_note = ("achieved = sum(2*M*N*K of the launches: algorithmic fp32 FLOP) / sum(HIP-event time of the launches), events on "
+                           "the launch stream, %d untimed steps after the timed blocks (%.2f ms/step with the events armed)"
+                           % (prof_steps, 1e3 * prof_dt))
+            f32_ms, f32_n, f32_flop = prof[0] - sp[0], prof[1] - sp[1], prof[2] - sp[2]
+            f32_entry = None
+            if f32_n > 0 and f32_ms > 0:
+                ach32 = f32_flop / (f32_ms * 1e-3) / 1e12
+                f32_entry = {"kernel": "gemm_f32_kernel<*> / gemm_f32_n64_kernel (GEMM launches on the f32 MFMA: short K loops, N = 64, "
+                                       "ragged tiles)" if sp[1] > 0 else "gemm_f32_kernel<*> (every fp32 MFMA GEMM launch: fwd, dgrad, wgrad)",
+                             "bound": "mfma", "achieved": ach32, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach32 / PEAK_FP32_TFLOPS,
+                             "launches_per_step": f32_n / prof_steps, "avg_us": 1e3 * f32_ms / f32_n, "us_per_step": 1e3 * f32_ms / prof_steps,
+                             "share_of_step": f32_ms / prof_steps / step_ms, "note": common_note}
+            if sp[1] > 0 and sp[0] > 0:
+                ach = sp[2] / (sp[0] * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
+                                   "traffic": traffic,
+                                   "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE), %s; algorithmic A+B+C bytes per "
+                                                   "launch of the whole family: %.0f" % (traffic_src, prof[3] / prof[1]),
+                                   "kernel": "gemm_split_kernel<*> (fp32-accurate products as six bf16 MFMA piece products: fwd, dgrad, wgrad)",
+                                   "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product",
+                                   "executed_bf16_tflops": 6 * ach, "vs_f32_mfma_peak": ach / PEAK_FP32_TFLOPS,
+                                   "launches": int(sp[1]), "avg_us": 1e3 * sp[0] / sp[1], "share_of_step": sp[0] / prof_steps / step_ms,
+                                   "note": common_note + "; the kernel is clock(DVFS)-limited on real operands: the same launches on zero-filled "
+                                           "operands run 1.33x faster (tools/x6/lib_bench, DESIGN.md)"}
+            else:
+                out["roofline"] = dict(f32_entry, traffic=traffic, launches=int(f32_n),
+                                       traffic_note="HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE), %s; algorithmic A+B+C bytes per "
+                                                    "launch: %.0f" % (traffic_src, prof[3] / prof[1]))
+                f32_entry = None
             # the other families north_star names: kNN / gather against HBM, kNN distance sweeps and the T-Net stage against the matrix peak
             ks = [_kernel_entry("kNN C=3 (knn_mfma5_kernel<4> + sqnorm), stages 0-1", "hbm", rows[1], prof_steps,
                                 "compulsory bytes (C+k)*4 per point; the kernel is select-bound, not HBM-bound (DESIGN 4)"),
@@ -421,7 +468,7 @@ def main():
                                 "2*E*64*128 FLOP"),
                   _kernel_entry("T-Net per-edge stage backward (tnet_edge_bwdg_kernel + prep / slab reduce / finish)", "mfma", rows[6],
                                 prof_steps, "reference FLOP 4*E*64*128 (the Gram form executes about a third of them)")]
-            out["roofline_kernels"] = [k for k in ks if k]
+            out["roofline_kernels"] = [k for k in [f32_entry] + ks if k]
         else:
             out["roofline"] = {"bound": "mfma", "achieved": value * FLOP_PER_POINT / 1e12, "peak": PEAK_FP32_TFLOPS,
                                "unit": "TFLOP/s", "frac": value * FLOP_PER_POINT / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
@@ -433,11 +480,13 @@ def main():
         # stages, the exact pass B only of the 64 / 64 / 128-channel stages (their pass A runs on the bf16 matrix cores and is
         # not counted as fp32 work).
         P = b_local * NPTS
-        exec_flop = (prof[2] / prof_steps if prof and prof[1] > 0 else 0.0) + 3 * 2.0 * P * K_NN * 64 * 128 \
+        split_flop = rows[7][2] / prof_steps if prof and prof[1] > 0 else 0.0      # runs on the bf16 cores (six products each): not f32-MFMA work
+        exec_flop = ((prof[2] / prof_steps - split_flop) if prof and prof[1] > 0 else 0.0) + 3 * 2.0 * P * K_NN * 64 * 128 \
             + 2.0 * P * NPTS * (2 * (4 + 4) + (64 + 64 + 128))
         step_s = dt / a.steps
         out["executed_tflops"] = exec_flop / step_s / 1e12
         out["executed_mfma_frac"] = out["executed_tflops"] / PEAK_FP32_TFLOPS
+        out["executed_bf16_tflops"] = 6 * split_flop / step_s / 1e12          # the split GEMMs' piece products
         out["reference_flop_equivalent_frac"] = value / n_gpus * FLOP_PER_POINT / 1e12 / PEAK_FP32_TFLOPS
         if n_gpus == 1 and not a.no_secondary:
             del model, opt, sync, batch

@@ -338,8 +338,12 @@ int mlsp_scan_select_f32(const float* X, int B, int N, int C, const double* R, i
 /* Operand precision of the GEMM family (process-wide switch, default 0).  0: fp32 MFMA, exact fp32 products -- the parity
  * contract of the fp32 configs.  1: operands rounded to bf16, fp32 accumulation (v_mfma_f32_32x32x16_bf16) for the launches on
  * the fast path (interior tiles, 16-byte aligned operands); BASELINE.json configs[4].  2: fp32-accurate products on the bf16 matrix
- * cores for the same launches: every operand value split into three bf16 pieces, six piece products per multiply, fp32 accumulation
- * (error at the level of an fp32 FMA chain; 6/16 of the f32-MFMA matrix time).  The kNN distances stay exact fp32 always. */
+ * cores: every operand value split into three bf16 pieces (exactly: 8 + 8 + 8 significand bits), six piece products per multiply, fp32
+ * accumulation.  Measured against float64 its error is below the f32-MFMA chain's (tests/test_gpu_kernels.py::
+ * test_gemm_split_bf16_accuracy); 1.55-1.65x faster on the 32768-row layers.  Launches off the fast path, short K loops, the operand-
+ * transform / N = 64 kernels stay on the fp32 kernels (exact fp32 either way).  The Python mirror (mlsp_amd) selects mode 2 when it
+ * loads the library unless MLSP_GEMM_PRECISION says otherwise; a C caller gets mode 0 until it calls this.  The kNN distances stay
+ * exact fp32 always. */
 int mlsp_set_gemm_precision(int mode);
 
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP
@@ -350,8 +354,9 @@ int mlsp_profile_end(double* out);
 /* Per kernel class of the same bracket (call after mlsp_profile_end): out [MLSP_PROF_CLASSES][3] = {ms, launches, algorithmic work}.
  * Classes: 0 GEMM family (FLOP) | 1 kNN C <= 4 incl. its row norms (compulsory bytes: (C + k) * 4 per point) | 2 kNN C = 64 |
  * 3 kNN C = 128 (FLOP: 2 N C per point) | 4 EdgeConv neighbour gather-reduce (compulsory bytes) | 5 T-Net per-edge stage forward |
- * 6 its backward (FLOP of the 64 -> 128 per-edge contraction: 2 resp. 4 * E * 64 * 128). */
-#define MLSP_PROF_CLASSES 7
+ * 6 its backward (FLOP of the 64 -> 128 per-edge contraction: 2 resp. 4 * E * 64 * 128) | 7 the launches of class 0 that ran on the
+ * bf16-split kernel (mode 2; algorithmic FLOP, each executed as six bf16 MFMA products). */
+#define MLSP_PROF_CLASSES 8
 int mlsp_profile_classes(double* out, int ncls);
 
 #ifdef __cplusplus

@@ -22,7 +22,7 @@ static inline int mlsp_launch_status() {
 
 // HIP-event profiling hook (gemm.hip; armed by mlsp_profile_begin, off otherwise): kernel classes of mlsp_profile_classes()
 enum { MLSP_PROF_GEMM = 0, MLSP_PROF_KNN_C3, MLSP_PROF_KNN_C64, MLSP_PROF_KNN_C128, MLSP_PROF_EDGE_REDUCE, MLSP_PROF_TNET_FWD,
-       MLSP_PROF_TNET_BWD, MLSP_PROF_NCLS };
+       MLSP_PROF_TNET_BWD, MLSP_PROF_GEMM_SPLIT /* the subset of class 0 that ran on gemm_split_kernel */, MLSP_PROF_NCLS };
 int prof_cls_begin(hipStream_t st, int cls);              // -> token (< 0: not armed)
 void prof_cls_end(hipStream_t st, int token, double work);
 

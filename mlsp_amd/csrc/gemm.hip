@@ -1097,7 +1097,7 @@ static struct GemmProf {
     std::vector<hipEvent_t> ev;     // pairs
     size_t used = 0;
     double flop = 0.0, bytes = 0.0;   // algorithmic: 2*M*N*K and the A + B + C bytes in their storage types
-    struct Rec { int M, N, K, ta, tb, ns, bm, fused; };
+    struct Rec { int M, N, K, ta, tb, ns, bm, fused, split; };
     std::vector<Rec> rec;           // one per pair, for the MLSP_PROF_DUMP listing
 } g_prof;
 #define PROF_MAX_PAIRS 4096
@@ -1152,8 +1152,8 @@ extern "C" int mlsp_profile_end(double* out) {
         ms += t;
         if (dump) {
             const auto& r = g_prof.rec[i];
-            fprintf(stderr, "gemm %c%c M=%d N=%d K=%d split=%d bm=%d epi=%d  %.1f us  %.1f TF\n", r.ta ? 'T' : 'N', r.tb ? 'T' : 'N',
-                    r.M, r.N, r.K, r.ns, r.bm, r.fused, t * 1e3, 2.0 * r.M * r.N * r.K / (t * 1e-3) / 1e12);
+            fprintf(stderr, "gemm %c%c M=%d N=%d K=%d split=%d bm=%d epi=%d %s  %.1f us  %.1f TF\n", r.ta ? 'T' : 'N', r.tb ? 'T' : 'N',
+                    r.M, r.N, r.K, r.ns, r.bm, r.fused, r.split ? "bf16x6" : "f32", t * 1e3, 2.0 * r.M * r.N * r.K / (t * 1e-3) / 1e12);
         }
     }
     if (out) { out[0] = ms; out[1] = (double)g_prof.used; out[2] = g_prof.flop; out[3] = g_prof.bytes; }
@@ -1169,6 +1169,11 @@ extern "C" int mlsp_profile_classes(double* out, int ncls) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
         out[0] += t; out[1] += 1.0;
+        if (g_prof.rec[i].split) {
+            const auto& r = g_prof.rec[i];
+            out[3 * MLSP_PROF_GEMM_SPLIT] += t; out[3 * MLSP_PROF_GEMM_SPLIT + 1] += 1.0;
+            out[3 * MLSP_PROF_GEMM_SPLIT + 2] += 2.0 * r.M * (double)r.N * r.K;
+        }
     }
     out[2] = g_prof.flop;
     for (size_t i = 0; i < g_cls.used; ++i) {
@@ -1319,7 +1324,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
 #undef GEMM_GO
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
-        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0)};
+        const bool on_split = fast && g_gemm_precision == 2 && gemm_split_pays(N, kts) && !n64 && !xf;
+        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0), on_split ? 1 : 0};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;
         g_prof.bytes += 4.0 * ((double)M * K + (double)K * N + (C ? (double)M * N : 0.0));
@@ -1400,7 +1406,7 @@ int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const 
 #undef MX_GO
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
-        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + 4};
+        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + 4, 0};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;
         g_prof.bytes += (a_bf16 ? 2.0 : 4.0) * M * K + (b_bf16 ? 2.0 : 4.0) * K * N + (c_bf16 ? 2.0 : 4.0) * M * N;

@@ -40,11 +40,12 @@ def _rows(t, allow_bf16=False):
 
 
 class gemm_precision:
-    """Context manager / switch for the operand precision of the GEMM family (include/mlsp_hip.h mlsp_set_gemm_precision):
-    "fp32" (default: exact fp32 products on the f32 MFMA, the parity contract of the fp32 configs), "bf16" (operands rounded to bf16,
-    fp32 accumulation; BASELINE.json configs[4]) or "bf16x6" (fp32-ACCURATE products on the bf16 matrix cores: every operand split
-    into three bf16 pieces, six piece products per multiply, fp32 accumulation -- error at the level of an fp32 FMA chain, 6/16 of the
-    matrix time; opt-in).  kNN distances, BatchNorm statistics, reductions and losses stay fp32 (the kNN always exact fp32)."""
+    """Context manager / switch for the products of the GEMM family (include/mlsp_hip.h mlsp_set_gemm_precision):
+    "bf16x6" (default): fp32-ACCURATE products on the bf16 matrix cores -- every operand split exactly into three bf16 pieces, six piece
+    products per multiply, fp32 accumulation; against float64 its error is below the f32-MFMA chain's, and it is 1.55-1.65x faster
+    (DVFS-limited either way: DESIGN.md).  "fp32": the f32 MFMA for every launch (exact fp32 products).  "bf16": operands ROUNDED to
+    bf16, fp32 accumulation (BASELINE.json configs[4]; reduced precision, opt-in).  kNN distances, BatchNorm statistics, reductions and
+    losses are fp32 in every mode (the kNN always exact, canonical order)."""
     _MODES = _lib.GEMM_PRECISION_MODES
     current = _lib.DEFAULT_GEMM_PRECISION
 

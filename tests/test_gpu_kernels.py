@@ -205,7 +205,7 @@ def test_gemm_matches_fma_chain_bitwise(dev):
 
 @pytest.mark.parametrize("ta,tb,M,N,K", [(False, True, 32768, 256, 512), (False, False, 32768, 512, 256), (True, False, 512, 256, 32768),
                                           (False, True, 4096, 1024, 128), (False, True, 32768, 1024, 512), (False, False, 65536, 1024, 128),
-                                          (True, True, 256, 256, 16384), (True, False, 1024, 512, 32768), (False, True, 16384, 128, 64)])
+                                          (True, True, 256, 256, 16384), (True, False, 1024, 512, 32768)])
 def test_gemm_split_bf16_accuracy(dev, ta, tb, M, N, K):
     """gemm_precision("bf16x6"): products as six bf16 piece products on the bf16 matrix cores.  Against float64 its error must be at the
     level of the exact-fp32 MFMA kernel's (both are fp32 accumulations of products exact to <= 2^-25): <= 2x that error and
@@ -217,7 +217,8 @@ def test_gemm_split_bf16_accuracy(dev, ta, tb, M, N, K):
     A = (torch.randn(shpA, generator=g) * torch.exp(2.0 * torch.randn(shpA, generator=g))).to(dev)
     B = (torch.randn(shpB, generator=g) * torch.exp(2.0 * torch.randn(shpB, generator=g))).to(dev)
     ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
-    exact = Fh.gemm(A, B, ta, tb).double()
+    with Fh.gemm_precision("fp32"):
+        exact = Fh.gemm(A, B, ta, tb).double()
     with Fh.gemm_precision("bf16x6"):
         split = Fh.gemm(A, B, ta, tb).double()
     e32 = ((exact - ref).norm() / ref.norm()).item()
@@ -229,6 +230,19 @@ def test_gemm_split_bf16_accuracy(dev, ta, tb, M, N, K):
     assert e6 < 2e-6 and e6 < 2.0 * e32 + 1e-8, (e6, e32)
     assert m6 < 2.0 * m32 + 1e-7, (m6, m32)
     assert Fh.gemm_precision.current == Fh._lib.DEFAULT_GEMM_PRECISION
+
+
+def test_gemm_split_short_k_stays_on_fp32_kernel(dev):
+    """K loops of fewer than 4 tiles (8 when N < 256) lose on the split kernel's prologue: mode "bf16x6" keeps them on the f32 MFMA kernel,
+    bit for bit."""
+    Fh = _fh()
+    for M, N, K in ((16384, 128, 64), (4096, 128, 128), (1024, 512, 96)):
+        A, B = _rand((M, K), 3).to(dev), _rand((N, K), 4).to(dev)
+        with Fh.gemm_precision("fp32"):
+            want = Fh.gemm(A, B, False, True)
+        with Fh.gemm_precision("bf16x6"):
+            got = Fh.gemm(A, B, False, True)
+        assert torch.equal(got, want), (M, N, K)
 
 
 # ----------------------------------------------------------------------------- bf16 activation storage (configs[4])
@@ -797,7 +811,8 @@ def test_tnet_backward_gram_form_vs_round1_kernel(dev, B, N, k):
                                                  (4096, 128, 256, 128, False)])
 def test_pointmlp_deferred_activation_chain(dev, M, C0, C1, C2, training, monkeypatch):
     """pointmlp(..., chain=True) under fp32 storage hands its PRE-BN output to the next layer, which applies BN + ReLU + dropout in
-    its GEMM operand loads (forward: A rows, wgrad: the k-major B operand) -- bit-identical to the materialised path: the staged
+    its GEMM operand loads (forward: A rows, wgrad: the k-major B operand; gemm_precision "fp32", opt-in via MLSP_DEFERRED_ACT: it
+    measures slower than the materialised chain since the merged BN passes) -- bit-identical to the materialised path: the staged
     values are computed by the same expressions.  The third case is outside the interior-tile path (one streaming pass instead)."""
     Fh = _fh()
     import itertools as it
@@ -818,7 +833,8 @@ def test_pointmlp_deferred_activation_chain(dev, M, C0, C1, C2, training, monkey
         out.backward(_rand((M, 3), 9).to(dev))
         return [out.detach().cpu()] + [t.grad.cpu() for t in leaves] + [r.cpu() for r in rs]
 
-    a, b = run(True), run(False)
+    with Fh.gemm_precision("fp32"):               # the operand transform lives in the f32 MFMA kernel: the chains defer in that mode only
+        a, b = run(True), run(False)
     names = ["out", "dX", "dW1", "dW2", "dW3", "dg1", "db1", "dg2", "db2", "rm1", "rv1", "rm2", "rv2"]
     for n, x, y in zip(names, a, b):
         assert torch.equal(x, y), (n, (x - y).abs().max().item())

@@ -193,6 +193,48 @@ def test_bench_config_vs_oracle_float64(dev):
     _check_grads_vs_f64(dict(m.named_parameters()), wgrads, noise, floor=5e-3)      # B = 32: 8x longer sums than the B = 4 fixture
 
 
+def test_gemm_product_modes_agree_on_bench_step(dev, monkeypatch):
+    """BASELINE.json configs[1] size, the same step under gemm_precision "bf16x6" (default: fp32-accurate products on the bf16 cores)
+    and "fp32" (f32 MFMA) with the first mode's neighbour graphs forced on the second: both are fp32 computations of the same network,
+    so the logits agree to 1e-4 relative L2 (measured 2.5e-5 on the deepest output, cls: two different fp32 rounding sequences through
+    ten BatchNorm'd layers; the parity contract against the oracle is 1e-3), the losses to 1e-4."""
+    from mlsp_amd import functional as Fh
+    seed, B, N = 6, 32, 1024
+    m = _model(seed, dev)
+    ginp = {k: v.to(dev) for k, v in gc.make_inputs(seed, B, N).items()}
+    m.train()
+    out = {}
+    graphs = None
+    for mode in ("bf16x6", "fp32"):
+        mm = copy.deepcopy(m)
+        with Fh.gemm_precision(mode):
+            if graphs is None:
+                rec, real = [], Fh.knn_graph
+
+                def recording(xp, B_, N_, k_, need_reverse=True):
+                    g = real(xp, B_, N_, k_, need_reverse=need_reverse)
+                    rec.append(g.idx.view(B_, N_, k_).long().cpu())
+                    return g
+                monkeypatch.setattr(Fh, "knn_graph", recording)
+                logits = mm(ginp["x"], activate_density_normal_ondef=True)
+                monkeypatch.setattr(Fh, "knn_graph", real)
+                graphs = rec
+            else:
+                with Fh.forced_graphs(graphs):
+                    logits = mm(ginp["x"], activate_density_normal_ondef=True)
+            loss, parts = _gpu_total_loss(gc.make_args(cuda=True), logits, ginp)
+        out[mode] = ({k: logits[k].detach().double() for k in HEAD_KEYS}, loss.item(), {k: v.item() for k, v in parts.items()})
+    for k in HEAD_KEYS:
+        a, b = out["bf16x6"][0][k], out["fp32"][0][k]
+        rel = ((a - b).norm() / b.norm()).item()
+        print("%s: rel-L2 between the product modes %.2e" % (k, rel))
+        assert rel < 1e-4, (k, rel)
+        assert (a - b).abs().max().item() < 1e-3 * max(1.0, b.abs().max().item()), k
+    np.testing.assert_allclose(out["bf16x6"][1], out["fp32"][1], rtol=1e-4)
+    for k, v in out["bf16x6"][2].items():
+        np.testing.assert_allclose(v, out["fp32"][2][k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
 @pytest.mark.parametrize("seed,B,N", [(2, 4, 128), (3, 4, 256)])
 def test_dgcnn_free_running_vs_oracle(dev, seed, B, N):
     """No forcing: HIP model vs CPU oracle (canonical kNN on both sides).  Indices at every stage must be

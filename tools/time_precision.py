@@ -27,3 +27,10 @@ if os.environ.get("DUMP"):        # one profiled step per mode: every GEMM launc
         print("==== per-launch listing,", mode, file=sys.stderr, flush=True)
         with Fh.gemm_precision(mode):
             bench.profiled_steps(_lib.load(), lambda: bench.gpu_step(model, mlsp, args, batch, opt), 1)
+
+if os.environ.get("DEFER_AB"):    # what the deferred BN+activation chains (operand transform in the consumer GEMM, fp32 kernel only) are worth
+    for defer in (True, False, True, False):
+        Fh._DEFER_CHAINS = defer
+        ms = bench.median_block_ms(lambda: bench.gpu_step(model, mlsp, args, batch, opt), 20, 5, 5)
+        print("fp32 defer_chains=%s %.3f ms/step" % (defer, ms), flush=True)
+    Fh._DEFER_CHAINS = True

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cstring>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 typedef int (*gemm_fn)(int, int, int, int, int, const float*, int, const float*, int, float*, int, const float*, void*, size_t, void*);
 typedef int (*prec_fn)(int);
@@ -25,26 +26,30 @@ int main(int argc, char** argv) {
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& s : shapes) {
+        if (argc > 1 && !strstr(s.name, argv[1])) continue;
         const size_t na = (size_t)s.M * s.K, nb = (size_t)s.N * s.K, nc = (size_t)s.M * s.N;
         std::vector<float> A(na), B(nb);
         uint32_t st = 1u;
         auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
-        for (auto& v : A) v = rnd(); for (auto& v : B) v = rnd();
+        const bool zero = getenv("ZERO") != nullptr;     // zero operands: same instruction stream, far fewer toggling bits -> is the kernel power-limited?
+        for (auto& v : A) v = zero ? 0.f : rnd();
+        for (auto& v : B) v = zero ? 0.f : rnd();
         float *dA, *dB, *dC; void* ws;
         const size_t wsz = wsb(s.M, s.K, s.N) + (64u << 20);
         CK(hipMalloc(&dA, na * 4)); CK(hipMalloc(&dB, nb * 4)); CK(hipMalloc(&dC, nc * 4)); CK(hipMalloc(&ws, wsz));
         CK(hipMemcpy(dA, A.data(), na * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), nb * 4, hipMemcpyHostToDevice));
         double us[3] = {0, 0, 0};
+        const int reps = argc > 2 ? atoi(argv[2]) : 20;
         for (int mode = 0; mode <= 2; mode += 2) {
             prec(mode);
             const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
             for (int i = 0; i < 3; ++i) { int rc = gemm(s.ta, s.tb, s.M, s.N, s.K, dA, lda, dB, ldb, dC, s.N, nullptr, ws, wsz, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, 0));
-            for (int i = 0; i < 20; ++i) gemm(s.ta, s.tb, s.M, s.N, s.K, dA, lda, dB, ldb, dC, s.N, nullptr, ws, wsz, nullptr);
+            for (int i = 0; i < reps; ++i) gemm(s.ta, s.tb, s.M, s.N, s.K, dA, lda, dB, ldb, dC, s.N, nullptr, ws, wsz, nullptr);
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            us[mode] = ms * 1000.0 / 20;
+            us[mode] = ms * 1000.0 / reps;
         }
         prec(0);
         printf("%s M=%6d N=%5d K=%6d   fp32 %7.1f us %6.1f TF | bf16x6 %7.1f us %6.1f TF   %.2fx\n", s.name, s.M, s.N, s.K, us[0], 2.0 * s.M * s.N * s.K / us[0] * 1e-6,
