@@ -5,7 +5,7 @@ OUT=$PWD/gpurun_out/prof_${1:-sq}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
-  --output-format csv -d "$OUT/sq" -o run -- python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-secondary > "$OUT/sq.log" 2>&1
+  --output-format csv -d "$OUT/sq" -o run -- python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-secondary --no-fp32-leg > "$OUT/sq.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
