@@ -618,10 +618,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_n64_kernel(GemmArgs p) {
 // Same tiling, epilogues and split-K protocol as gemm_f32_kernel<..., FAST>, but the fp32 operands are rounded to bf16 (RNE,
 // v_cvt_pk_bf16_f32) on their way into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 8x fewer MFMA
 // issues per K-tile and half the LDS traffic.  Both LDS images are row-major [row][32 + 8] bf16 (80-byte pitch: every
-// fragment is one 16-byte read); k-major global sources are transposed on the LDS write (2-byte stores).
+// fragment is one 16-byte read) for row-major global sources; k-major sources keep their layout in LDS ([k][rows], 320-byte pitch) and
+// their fragments are read with ds_read_b64_tr_b16 (round 3: the transposing 2-byte stores they replace were 16-way bank conflicts --
+// the dgrad / wgrad launches of configs[4] ran at a quarter of the forward's rate).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define BROW 40    // bf16 elements per LDS row
+
+// LDS images of a 128 x 32 bf16 operand tile, shared by gemm_bf16_kernel and gemm_split_kernel:
+//   global source row-major [rows][K]: image [row][32 k + 8 pad] (80-byte pitch), fragment = one ds_read_b128;
+//   global source k-major  [K][rows]: image [k][128 rows + 32 pad] (320-byte pitch) written as it is loaded (8 / 16-byte pieces of a k-row),
+//   fragment = two ds_read_b64_tr_b16 (the four k-rows of a transposed read fall in four different 64-byte bank windows).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define SX_PLANE 10240            // bytes of one bf16 image of a 128 x 32 operand tile: [128 rows][80 B] or [32 k][320 B]
+#define SX_RPITCH 80
+#define SX_KPITCH 320
+#define SX_LDS __attribute__((address_space(3)))
+
+// this lane's byte offset of a fragment inside an image (rows rb .. rb+31 of the tile start at + rb * (KMAJ ? 2 : SX_RPITCH))
+template <bool KMAJ>
+__device__ __forceinline__ int sx_frag_base(int lane) {
+    if (!KMAJ) return (lane & 31) * SX_RPITCH + 16 * (lane >> 5);
+    const int i = lane & 15;            // ds_read_b64_tr_b16: lane 4q + p of a 16-lane group supplies row (= k) q, columns 4p .. 4p+3
+    return (8 * (lane >> 5) + (i >> 2)) * SX_KPITCH + (16 * ((lane >> 4) & 1) + 4 * (i & 3)) * 2;
+}
+// fragment of the k16 step s2: rows = this lane's row of the 32-row window, k = 16 s2 + 8 h .. + 7
+template <bool KMAJ>
+__device__ __forceinline__ bf16x8 sx_frag(const char* img_at_window, int s2) {
+    if (!KMAJ) return *(const bf16x8*)(img_at_window + 32 * s2);
+    const char* a = img_at_window + 16 * s2 * SX_KPITCH;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SX_LDS bf16x4*)(a));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SX_LDS bf16x4*)(a + 4 * SX_KPITCH));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 
 template <bool SRC_KMAJOR, int NP>
 __device__ __forceinline__ void r2s_bf16(const f32x4 (&r)[4], __bf16* __restrict__ s, int tid) {
@@ -636,8 +667,10 @@ __device__ __forceinline__ void r2s_bf16(const f32x4 (&r)[4], __bf16* __restrict
         } else {
             const int k = NP == 4 ? (tid >> 5) + 8 * p : (tid >> 4) + 16 * p;
             const int row = (NP == 4 ? (tid & 31) : (tid & 15)) * 4;
+            bf16x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[(row + e) * BROW + k] = (__bf16)r[p][e];
+            for (int e = 0; e < 4; ++e) v[e] = (__bf16)r[p][e];
+            *(bf16x4*)((char*)s + k * SX_KPITCH + row * 2) = v;          // k-major image: no transpose on the write
         }
     }
 }
@@ -662,10 +695,7 @@ __device__ __forceinline__ void r2s_b16(const BfStage& r, __bf16* __restrict__ s
             *(bf16x8*)(s + ((tid >> 2) + 64 * p) * BROW + (tid & 3) * 8) = r.v[p];
         } else {
             const int k = (tid >> 4) + 16 * p, row = (tid & 15) * 8;
-            if (ROWS == 128 || row < ROWS) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s[(row + e) * BROW + k] = r.v[p][e];
-            }
+            if (ROWS == 128 || row < ROWS) *(bf16x8*)((char*)s + k * SX_KPITCH + row * 2) = r.v[p];
         }
     }
 }
@@ -735,7 +765,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
     const bool b_lane_ok = !NEDGE || n0 + (tid & 31) * 4 < p.N;
     const bool a_lane_ok = !AB16 || !TA || BMT == 128 || (tid & 15) * 8 < BMT;     // 64-row k-major bf16 tiles use half the lanes
-    const int arow = wm * (32 * WM) + l31, bcol = wn * 64 + l31;
+    const char* fa = (const char*)As + sx_frag_base<TA>(lane) + (wm * 32 * WM) * (TA ? 2 : SX_RPITCH);
+    const char* fb = (const char*)Bs + sx_frag_base<!TB>(lane) + (wn * 64) * (!TB ? 2 : SX_RPITCH);
+    constexpr int FWA = 32 * (TA ? 2 : SX_RPITCH), FWB = 32 * (!TB ? 2 : SX_RPITCH);               // next 32-row window
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         if (AB16) r2s_b16<TA, BMT>(sa, As, tid); else r2s_bf16<TA, NPA>(ra, As, tid);
         if (BB16) r2s_b16<!TB, 128>(sb, Bs, tid); else r2s_bf16<!TB, 4>(rb, Bs, tid);
@@ -748,13 +780,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int s2 = 0; s2 < BK / 16; ++s2) {                      // MFMA step: k = 16*s2 + 8*h .. +7
-            const int kk = 16 * s2 + 8 * h;
-            const bf16x8 a0 = *(const bf16x8*)(As + arow * BROW + kk);
-            const bf16x8 b0 = *(const bf16x8*)(Bs + bcol * BROW + kk), b1 = *(const bf16x8*)(Bs + (bcol + 32) * BROW + kk);
+            const bf16x8 a0 = sx_frag<TA>(fa, s2);
+            const bf16x8 b0 = sx_frag<!TB>(fb, s2), b1 = sx_frag<!TB>(fb + FWB, s2);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
             if (WM == 2) {
-                const bf16x8 a1 = *(const bf16x8*)(As + (arow + 32) * BROW + kk);
+                const bf16x8 a1 = sx_frag<TA>(fa + FWA, s2);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
             }
@@ -781,13 +812,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 //     four k-rows of a transposed read in four different 64-byte bank windows;
 //   * per K-tile: all 24 fragments of tile t are read, barrier, then the 48 (24) MFMAs of tile t run with the split + image write of tile
 //     t+1 and the global loads of tile t+2 hand-placed between them (gen_split_body.py -> gemm_split_body_wm*.inc), barrier.
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-#define SX_PLANE 10240            // bytes of one bf16 image of a 128 x 32 operand tile: [128 rows][80 B] or [32 k][320 B]
-#define SX_RPITCH 80
-#define SX_KPITCH 320
-#define SX_LDS __attribute__((address_space(3)))
-
 __device__ __forceinline__ uint32_t sx_cvt_pk(float lo, float hi) {       // one v_cvt_pk_bf16_f32 (RNE)
     const f32x2 v = {lo, hi};
     const bf16x2 b = __builtin_convertvector(v, bf16x2);
@@ -811,23 +835,6 @@ __device__ __forceinline__ f32x4 sx_bufload(__amdgpu_buffer_rsrc_t rs, int voff,
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
 }
-// this lane's byte offset of a fragment inside an image (rows rb .. rb+31 of the tile start at + rb * (KMAJ ? 2 : SX_RPITCH))
-template <bool KMAJ>
-__device__ __forceinline__ int sx_frag_base(int lane) {
-    if (!KMAJ) return (lane & 31) * SX_RPITCH + 16 * (lane >> 5);
-    const int i = lane & 15;            // ds_read_b64_tr_b16: lane 4q + p of a 16-lane group supplies row (= k) q, columns 4p .. 4p+3
-    return (8 * (lane >> 5) + (i >> 2)) * SX_KPITCH + (16 * ((lane >> 4) & 1) + 4 * (i & 3)) * 2;
-}
-// fragment of the k16 step s2: rows = this lane's row of the 32-row window, k = 16 s2 + 8 h .. + 7
-template <bool KMAJ>
-__device__ __forceinline__ bf16x8 sx_frag(const char* img_at_window, int s2) {
-    if (!KMAJ) return *(const bf16x8*)(img_at_window + 32 * s2);
-    const char* a = img_at_window + 16 * s2 * SX_KPITCH;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SX_LDS bf16x4*)(a));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SX_LDS bf16x4*)(a + 4 * SX_KPITCH));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
 template <bool TA, bool TB, int WM>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     constexpr bool KA = TA, KB = !TB;                                 // operand's global source is k-major

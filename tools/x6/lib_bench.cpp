@@ -1,4 +1,4 @@
-// Times mlsp_gemm_f32 of the BUILT library (mlsp_amd/libmlsp_hip.so) per shape in GEMM precision modes 0 (fp32 MFMA) and 2 (bf16x6 split).
+// Times mlsp_gemm_f32 of the BUILT library (mlsp_amd/libmlsp_hip.so) per shape in GEMM precision modes 0 (fp32 MFMA), 2 (bf16x6 split) and 1 (bf16 operands).
 //   hipcc -O2 -o tools/x6/lib_bench tools/x6/lib_bench.cpp -ldl        (run from the repo root; MLSP_HIP_LIB overrides the library path)
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dA, A.data(), na * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), nb * 4, hipMemcpyHostToDevice));
         double us[3] = {0, 0, 0};
         const int reps = argc > 2 ? atoi(argv[2]) : 20;
-        for (int mode = 0; mode <= 2; mode += 2) {
+        for (int mode = 0; mode <= 2; ++mode) {
             prec(mode);
             const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
             for (int i = 0; i < 3; ++i) { int rc = gemm(s.ta, s.tb, s.M, s.N, s.K, dA, lda, dB, ldb, dC, s.N, nullptr, ws, wsz, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
@@ -52,8 +52,8 @@ int main(int argc, char** argv) {
             us[mode] = ms * 1000.0 / reps;
         }
         prec(0);
-        printf("%s M=%6d N=%5d K=%6d   fp32 %7.1f us %6.1f TF | bf16x6 %7.1f us %6.1f TF   %.2fx\n", s.name, s.M, s.N, s.K, us[0], 2.0 * s.M * s.N * s.K / us[0] * 1e-6,
-               us[2], 2.0 * s.M * s.N * s.K / us[2] * 1e-6, us[0] / us[2]);
+        printf("%s M=%6d N=%5d K=%6d   fp32 %7.1f us %6.1f TF | bf16x6 %7.1f us %6.1f TF   %.2fx | bf16 operands %7.1f us %6.1f TF\n", s.name, s.M, s.N, s.K, us[0],
+               2.0 * s.M * s.N * s.K / us[0] * 1e-6, us[2], 2.0 * s.M * s.N * s.K / us[2] * 1e-6, us[0] / us[2], us[1], 2.0 * s.M * s.N * s.K / us[1] * 1e-6);
         fflush(stdout);
         CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(ws));
     }
