@@ -193,6 +193,22 @@ def test_bench_config_vs_oracle_float64(dev):
     _check_grads_vs_f64(dict(m.named_parameters()), wgrads, noise, floor=5e-3)      # B = 32: 8x longer sums than the B = 4 fixture
 
 
+def _run_recording_graphs(monkeypatch, Fh, fn):
+    """fn() with every neighbour graph it builds recorded: ([B, N, k] int64 index tensors on the host, in call order) for Fh.forced_graphs."""
+    rec, real = [], Fh.knn_graph
+
+    def recording(xp, B_, N_, k_, need_reverse=True):
+        g = real(xp, B_, N_, k_, need_reverse=need_reverse)
+        rec.append(g.idx.view(B_, N_, k_).long().cpu())
+        return g
+    monkeypatch.setattr(Fh, "knn_graph", recording)
+    try:
+        out = fn()
+    finally:
+        monkeypatch.setattr(Fh, "knn_graph", real)
+    return out, rec
+
+
 def test_gemm_product_modes_agree_on_bench_step(dev, monkeypatch):
     """BASELINE.json configs[1] size, the same step under gemm_precision "bf16x6" (default: fp32-accurate products on the bf16 cores)
     and "fp32" (f32 MFMA) with the first mode's neighbour graphs forced on the second: both are fp32 computations of the same network,
@@ -209,16 +225,7 @@ def test_gemm_product_modes_agree_on_bench_step(dev, monkeypatch):
         mm = copy.deepcopy(m)
         with Fh.gemm_precision(mode):
             if graphs is None:
-                rec, real = [], Fh.knn_graph
-
-                def recording(xp, B_, N_, k_, need_reverse=True):
-                    g = real(xp, B_, N_, k_, need_reverse=need_reverse)
-                    rec.append(g.idx.view(B_, N_, k_).long().cpu())
-                    return g
-                monkeypatch.setattr(Fh, "knn_graph", recording)
-                logits = mm(ginp["x"], activate_density_normal_ondef=True)
-                monkeypatch.setattr(Fh, "knn_graph", real)
-                graphs = rec
+                logits, graphs = _run_recording_graphs(monkeypatch, Fh, lambda: mm(ginp["x"], activate_density_normal_ondef=True))
             else:
                 with Fh.forced_graphs(graphs):
                     logits = mm(ginp["x"], activate_density_normal_ondef=True)
@@ -623,17 +630,25 @@ def test_pointnet_vs_reference_golden(dev, golden_dir):
     assert all(torch.isfinite(p.grad).all().item() for p in big.parameters() if p.grad is not None)
 
 
-def test_bf16_operand_mode_on_segda_and_dgcnn(dev):
+def test_bf16_operand_mode_on_segda_and_dgcnn(dev, monkeypatch):
     """BASELINE.json configs[4] arithmetic (bf16 operands, fp32 accumulation in the GEMM family): the PointSegDA model at its
-    N = 2048 shape and the DGCNN step run end to end; with the neighbour graphs pinned, the outputs stay close to the fp32 path."""
+    N = 2048 shape runs end to end.  Free-running, the dynamic graphs differ (near-tied neighbours flip), so distributions are compared;
+    with the fp32 run's neighbour graphs forced on the bf16 run the heads are held row-wise: relative L2 <= 3e-2 (operands rounded to 8
+    significand bits through ten layers; measured values are printed)."""
     from mlsp_amd import functional as Fh
     m = _seg_model(6, dev).train()
     x = (torch.rand(4, 3, 2048, generator=torch.Generator().manual_seed(6)) * 2 - 1).to(dev)
     with torch.no_grad():
         xp = x.transpose(2, 1).reshape(-1, 3)
-        ref = m(x, activate_density_normal_ondef=True)
+        ref, graphs = _run_recording_graphs(monkeypatch, Fh, lambda: m(x, activate_density_normal_ondef=True))
         with Fh.gemm_precision("bf16"):
             got = m(x, activate_density_normal_ondef=True)
+            with Fh.forced_graphs(graphs):
+                pinned = m(x, activate_density_normal_ondef=True)
+    for k in ("DefRec", "Normal", "density_mse"):
+        rel = ((pinned[k].double() - ref[k].double()).norm() / ref[k].double().norm()).item()
+        print("bf16 operands vs default products, graphs pinned, %s: rel-L2 %.2e" % (k, rel))
+        assert rel < 3e-2, (k, rel)
     for k in ("DefRec", "Normal", "density_mse"):
         assert torch.isfinite(got[k]).all().item()
     # the dynamic graph makes a row-wise comparison meaningless (near-tied neighbours flip); compare distribution-level statistics
