@@ -342,8 +342,8 @@ int mlsp_scan_select_f32(const float* X, int B, int N, int C, const double* R, i
  * accumulation.  Measured against float64 its error is below the f32-MFMA chain's (tests/test_gpu_kernels.py::
  * test_gemm_split_bf16_accuracy); 1.55-1.65x faster on the 32768-row layers.  Launches off the fast path, short K loops, the operand-
  * transform / N = 64 kernels stay on the fp32 kernels (exact fp32 either way).  The Python mirror (mlsp_amd) selects mode 2 when it
- * loads the library unless MLSP_GEMM_PRECISION says otherwise; a C caller gets mode 0 until it calls this.  The kNN distances stay
- * exact fp32 always. */
+ * loads the library unless MLSP_GEMM_PRECISION says otherwise; a C caller gets mode 0 until it calls this.  Mode 2 turns an infinite
+ * operand value into NaN (the f32 MFMA would give +-inf); finite data only.  The kNN distances stay exact fp32 always. */
 int mlsp_set_gemm_precision(int mode);
 
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP

@@ -802,7 +802,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 // accumulation.  Each piece product is exact (8 x 8 bits); the dropped terms (b c', c b', c c') are below 2^-25 |x y|: the result is as
 // accurate as an fp32 fused-multiply-add chain (tests/test_gpu_kernels.py::test_gemm_split_bf16_accuracy measures both against
 // float64) for 6/16 of the matrix time.  Interior-tile shapes with fp32 operands and output only; same epilogues as the fp32 kernel.
-// NOT a k-ordered fmaf chain: the kNN kernels (bit-exact canonical distances) never use it.
+// NOT a k-ordered fmaf chain: the kNN kernels (bit-exact canonical distances) never use it.  Non-finite operands: an infinite (or > bf16-max,
+// 3.39e38) operand value yields NaN where the f32 MFMA yields +-inf (inf - bf16(inf) is NaN); finite fp32 data -- everything this path
+// feeds it -- is covered by the accuracy test.
 //
 // Structure (measured in tools/x6: 1.55-1.65x the fp32 kernel on the 32768-row layers; the variants that lost are listed there):
 //   * one LDS buffer of six bf16 images (A: hi | mid | lo, B: hi | mid | lo), two workgroups per CU;

@@ -45,3 +45,8 @@ for _ in range(5):
     p2.query_ball_point(0.2, 32, xyz, new_xyz)
 e1.record(); torch.cuda.synchronize()
 print("ball query 512 x 2048, nsample 32: %.1f us" % (e0.elapsed_time(e1) / 5 * 1e3))
+if os.environ.get("DUMP"):        # every GEMM launch of one step with its HIP-event time on stderr
+    import bench
+    from mlsp_amd import _lib
+    os.environ["MLSP_PROF_DUMP"] = "1"
+    bench.profiled_steps(_lib.load(), step, 1)
