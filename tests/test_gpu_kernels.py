@@ -991,3 +991,22 @@ def test_pointmlp_segmax_vs_torch(dev, G, k, Cin, Cout, act, training, use_bias)
     if training:
         np.testing.assert_allclose(rmg.cpu().numpy(), rmc.numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(rvg.cpu().numpy(), rvc.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_gemm_fold64_weight_gradient(dev):
+    """A 64 x 64 weight gradient over many rows (SA level 1, conv2: dW = dY^T X over 524,288 edges) runs as ONE 128 x 128 interior-tile launch
+    over row PAIRS plus a 64 x 64 sum of its diagonal blocks (gemm.hip gemm_fold64): same result as the float64 product to fp32 accuracy,
+    in both product modes, and the non-foldable neighbours (pitch != 64, short K) keep their old path."""
+    Fh = _fh()
+    g = torch.Generator().manual_seed(5)
+    for K in (8192, 65536, 524288):
+        A, B = torch.randn(K, 64, generator=g).to(dev), torch.randn(K, 64, generator=g).to(dev)
+        ref = A.double().t() @ B.double()
+        for mode in ("fp32", "bf16x6"):
+            with Fh.gemm_precision(mode):
+                got = Fh.gemm(A, B, True, False).double()
+            rel = ((got - ref).norm() / ref.norm()).item()
+            assert rel < 2e-6, (K, mode, rel)
+    A, B = torch.randn(8192, 96, generator=g).to(dev), torch.randn(8192, 64, generator=g).to(dev)
+    got = Fh.gemm(A[:, :64], B, True, False).double()                      # pitch 96: not foldable
+    assert ((got - A[:, :64].double().t() @ B.double()).norm() / got.norm()).item() < 2e-6
