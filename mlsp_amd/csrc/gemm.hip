@@ -19,6 +19,7 @@
 // Block -> tile mapping keeps all column tiles of one 128-row panel on one XCD (blockIdx % 8 is the
 // XCD label under round-robin dispatch), so the activation panel is fetched into one L2 only.
 #include "common.h"
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -1072,13 +1073,17 @@ int gemm_pick_split(int M, int N, int K) {
 
 // number of BN-statistic partial rows a stats-fused launch writes (0: the launch would split K, use colstats)
 // 64-row tiles when the 128-row grid is too small to keep ~3 workgroups per CU busy (and K is not split)
-// mode 2: does a contraction of `ktiles` K-tiles per workgroup and N columns go to the split kernel?  Short K loops stay on the fp32 kernel
-// (measured per launch on the headline step, tools/cmp_dump.py: the split kernel's longer prologue loses below these sizes)
-static bool gemm_split_pays(int N, int ktiles) { return ktiles >= 8 || (ktiles >= 4 && N >= 256); }
+// mode 2: does a contraction of `ktiles` K-tiles per workgroup go to the split kernel?  Short K loops stay on the fp32 kernel (measured per
+// launch on the headline step, tools/cmp_dump.py, and per shape, tools/x6/lib_bench: the split kernel's longer prologue loses at K = 64 and,
+// at K = 128, on grids too small to hide it: few rows AND a single column tile)
+static bool gemm_split_pays(int M, int N, int ktiles) {
+    static const bool always = getenv("MLSP_GEMM_SPLIT_ALWAYS") != nullptr;        // read-once A/B switch (tools/x6/lib_bench)
+    return always || ktiles >= 8 || (ktiles >= 4 && (N >= 256 || M >= 16384));
+}
 static int gemm_pick_bm(int M, int N, int K) {
     long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN);
     // the split kernel amortises its operand split over the tile: 128 rows unless the grid would not fill the 512 workgroup slots
-    const long few = (g_gemm_precision == 2 && gemm_split_pays(N, (K + BK - 1) / BK)) ? 512 : 1536;
+    const long few = (g_gemm_precision == 2 && gemm_split_pays(M, N, (K + BK - 1) / BK)) ? 512 : 1536;
     return (gemm_pick_split(M, N, K) == 1 && tiles128 < few && M >= 256) ? 64 : 128;
 }
 int gemm_stat_parts(int M, int N, int K) {
@@ -1326,10 +1331,10 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         else hipLaunchKernelGGL((gemm_f32_n64_kernel<true, false>), g64, dim3(256), 0, st, p);
     } else
 #define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
-                                     else if (fast && g_gemm_precision == 2 && gemm_split_pays(N, kts)) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
+                                     else if (fast && g_gemm_precision == 2 && gemm_split_pays(M, N, kts)) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
-    if (grp && g_gemm_precision == 2 && gemm_split_pays(N, kts)) {   // block-diagonal launch on the split kernel (groups are a run-time argument there)
+    if (grp && g_gemm_precision == 2 && gemm_split_pays(M, N, kts)) {   // block-diagonal launch on the split kernel (groups are a run-time argument there)
         if (grp->mode == 1 && !ta && tb) { if (bm == 128) GEMM_GO(false, true, 2); else GEMM_GO(false, true, 1); }
         else if (grp->mode == 1 && !ta && !tb) { if (bm == 128) GEMM_GO(false, false, 2); else GEMM_GO(false, false, 1); }
         else if (grp->mode == 2 && ta && !tb) { if (bm == 128) GEMM_GO(true, false, 2); else GEMM_GO(true, false, 1); }
@@ -1367,7 +1372,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
 #undef GEMM_GO
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
-        const bool on_split = fast && g_gemm_precision == 2 && gemm_split_pays(N, kts) && !n64 && !xf;
+        const bool on_split = fast && g_gemm_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && !xf;
         g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0), on_split ? 1 : 0};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;

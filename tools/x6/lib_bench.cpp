@@ -23,6 +23,8 @@ int main(int argc, char** argv) {
         {"heads fwd   NT", 0, 1, 32768, 1024, 128}, {"head2 fwd   NT", 0, 1, 32768, 256, 256}, {"head2 dgrad NN", 0, 0, 32768, 256, 256},
         {"head2 wgrad TN", 1, 0, 256, 256, 32768}, {"dens1 fwd   NT", 0, 1, 32768, 512, 512}, {"edge4 uv    NT", 0, 1, 32768, 512, 128},
         {"edge4 wgrad TN", 1, 0, 512, 128, 32768}, {"big         NT", 0, 1, 8192, 8192, 1024},
+        {"sa 262k fwd NT", 0, 1, 262144, 128, 128}, {"sa 262k dgr NN", 0, 0, 262144, 128, 128}, {"sa 524k fwd NT", 0, 1, 524288, 128, 64},
+        {"sa 262k f2  NT", 0, 1, 262144, 256, 128}, {"edge uv K64 NT", 0, 1, 32768, 256, 64}, {"edge K128   NN", 0, 0, 32768, 128, 128}, {"heads K128  NT", 0, 1, 32768, 1024, 128},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& s : shapes) {
