@@ -155,3 +155,23 @@ def test_forward_bookkeeping_is_per_thread():
     assert not errs, errs
     for r in reps:
         assert int(r.bn.num_batches_tracked) == 50 and int(r.inner.bn.num_batches_tracked) == 50
+
+
+def test_gemm_precision_default_and_env_override():
+    """The Python mirror starts the library in "bf16x6" (fp32-accurate split products); MLSP_GEMM_PRECISION overrides the process default and
+    an unknown name fails at import, loudly."""
+    import subprocess, sys
+    from mlsp_amd import _lib, functional as Fh
+    assert _lib.GEMM_PRECISION_MODES == {"fp32": 0, "bf16": 1, "bf16x6": 2}
+    assert Fh.gemm_precision.current == _lib.DEFAULT_GEMM_PRECISION
+    code = "from mlsp_amd import functional as Fh; print(Fh.gemm_precision.current)"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("MLSP_GEMM_PRECISION", None)
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "bf16x6"
+    env["MLSP_GEMM_PRECISION"] = "fp32"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "fp32"
+    env["MLSP_GEMM_PRECISION"] = "fp16"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "MLSP_GEMM_PRECISION" in r.stderr
+    with pytest.raises(ValueError):
+        Fh.gemm_precision("tf32")

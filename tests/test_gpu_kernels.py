@@ -1010,3 +1010,25 @@ def test_gemm_fold64_weight_gradient(dev):
     A, B = torch.randn(8192, 96, generator=g).to(dev), torch.randn(8192, 64, generator=g).to(dev)
     got = Fh.gemm(A[:, :64], B, True, False).double()                      # pitch 96: not foldable
     assert ((got - A[:, :64].double().t() @ B.double()).norm() / got.norm()).item() < 2e-6
+
+
+def test_gemm_split_layouts_agree_and_are_linear(dev):
+    """Size-independent properties of the split kernel at the configs[1] layer size: the four operand layouts (row-major images / k-major
+    images read with ds_read_b64_tr_b16, in either operand) compute the same product to fp32 accuracy, and the kernel is linear in an
+    operand (C(A1 + A2, B) = C(A1, B) + C(A2, B) to fp32 accuracy; exactly so for a power-of-two scale)."""
+    Fh = _fh()
+    M, N, K = 32768, 512, 1024
+    A, B = _rand((M, K), 21).to(dev), _rand((N, K), 22).to(dev)
+    At, Bt = A.t().contiguous(), B.t().contiguous()
+    with Fh.gemm_precision("bf16x6"):
+        c_nt = Fh.gemm(A, B, False, True)
+        c_nn = Fh.gemm(A, Bt, False, False)
+        c_tt = Fh.gemm(At, B, True, True)
+        c_tn = Fh.gemm(At, Bt, True, False)
+        scale = c_nt.double().norm()
+        for other in (c_nn, c_tt, c_tn):
+            assert ((other.double() - c_nt.double()).norm() / scale).item() < 5e-7
+        assert torch.equal(Fh.gemm(A * 4.0, B, False, True), c_nt * 4.0)            # the split of 4x is 4 x the split of x
+        A2 = _rand((M, K), 23).to(dev)
+        lin = Fh.gemm(A + A2, B, False, True).double() - (c_nt.double() + Fh.gemm(A2, B, False, True).double())
+        assert (lin.norm() / scale).item() < 1e-6
