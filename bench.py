@@ -486,7 +486,8 @@ def main():
                                    "kernel": "gemm_split_kernel<*> (fp32-accurate products as six bf16 MFMA piece products: fwd, dgrad, wgrad)",
                                    "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product",
                                    "executed_bf16_tflops": 6 * ach, "vs_f32_mfma_peak": ach / PEAK_FP32_TFLOPS,
-                                   "launches": int(sp[1]), "avg_us": 1e3 * sp[0] / sp[1], "share_of_step": sp[0] / prof_steps / step_ms,
+                                   "launches": int(sp[1]), "launches_per_step": sp[1] / prof_steps, "avg_us": 1e3 * sp[0] / sp[1],
+                                   "share_of_step": sp[0] / prof_steps / step_ms,
                                    "note": common_note + "; the kernel is clock(DVFS)-limited on real operands: the same launches on zero-filled "
                                            "operands run 1.33x faster (tools/x6/lib_bench, DESIGN.md)"}
             else:
