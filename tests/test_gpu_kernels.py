@@ -1032,3 +1032,17 @@ def test_gemm_split_layouts_agree_and_are_linear(dev):
         A2 = _rand((M, K), 23).to(dev)
         lin = Fh.gemm(A + A2, B, False, True).double() - (c_nt.double() + Fh.gemm(A2, B, False, True).double())
         assert (lin.norm() / scale).item() < 1e-6
+
+
+def test_tnet_forward_accuracy_both_product_kernels(dev):
+    """The fused T-Net per-edge stage against a float64 evaluation of the reference's op sequence at (B=8, N=1024, k=20) and (4, 2048, 40):
+    relative L2 <= 4e-7 for the default kernel (f32 MFMA products) and for the opt-in one (MLSP_TNET_FWD_SPLIT=1: split products on the
+    bf16 cores).  The switch is read once per process, hence the subprocesses."""
+    import subprocess, sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    for env_extra in ({}, {"MLSP_TNET_FWD_SPLIT": "1"}):
+        env = dict(os.environ, **env_extra)
+        env.pop("MLSP_TNET_FWD_SPLIT", None) if not env_extra else None
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "tnet_acc.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
+        print(env_extra, r.stdout.strip().splitlines()[-2:])
+        assert r.returncode == 0, (env_extra, r.stdout[-500:], r.stderr[-500:])
