@@ -1243,6 +1243,7 @@ __global__ __launch_bounds__(256) void tnet_edge_bwd2_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+int gemm_precision_mode();        // gemm.hip
 int tnet_grid(int ntiles) { return ntiles < 512 ? ((ntiles + 7) / 8) * 8 : 512; }
 int tnet_points_per_tile(int k) { return k > 0 && k <= TN_ROWS ? (TN_ROWS / k > 8 ? 8 : TN_ROWS / k) : 0; }
 
@@ -1275,7 +1276,10 @@ int launch_tnet_edge_fwd(hipStream_t st, const float* uv, const int* idx, const 
         // read-once switch: MLSP_TNET_FWD_SPLIT=1 selects tnet_edge_fwd3_kernel (split products on the bf16 cores: forward 173 -> 125 us per step and
         // closer to float64, 1.7e-7 vs 2.0e-7 rel-L2, tools/tnet_acc.py).  Off by default: its last-bit differences move arg-max near-ties of the two
         // N = 128 gradient fixtures (tests/test_gpu_model.py: 2e-3 pins -> 6e-3..1.4e-2 through one re-routed maximum), and the pins stay as they are.
-        static const bool split_products = getenv("MLSP_TNET_FWD_SPLIT") != nullptr;
+        // In GEMM precision mode 1 (bf16 operands, BASELINE.json configs[4]) nothing is pinned to last-bit routing and the split kernel is far inside
+        // that mode's accuracy: it is the default there (configs[4] -60 us per step).
+        static const bool split_env = getenv("MLSP_TNET_FWD_SPLIT") != nullptr;
+        const bool split_products = split_env || gemm_precision_mode() == 1;
         if (!split_products) {
             if (k == 20) hipLaunchKernelGGL((tnet_edge_fwd2_kernel<20>), dim3(grid), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((tnet_edge_fwd2_kernel<40>), dim3(grid), dim3(256), 0, st, a);
