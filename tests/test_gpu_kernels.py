@@ -1036,13 +1036,13 @@ def test_gemm_split_layouts_agree_and_are_linear(dev):
 
 def test_tnet_forward_accuracy_both_product_kernels(dev):
     """The fused T-Net per-edge stage against a float64 evaluation of the reference's op sequence at (B=8, N=1024, k=20) and (4, 2048, 40):
-    relative L2 <= 4e-7 for the default kernel (f32 MFMA products) and for the opt-in one (MLSP_TNET_FWD_SPLIT=1: split products on the
-    bf16 cores).  The switch is read once per process, hence the subprocesses."""
+    relative L2 <= 4e-7 for the f32-MFMA kernel (MLSP_TNET_FWD_F32=1) and for the split-products kernel (MLSP_TNET_FWD_SPLIT=1; the default from
+    1024 tiles up, i.e. at both of these shapes).  The switches are read once per process, hence the subprocesses."""
     import subprocess, sys
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    for env_extra in ({}, {"MLSP_TNET_FWD_SPLIT": "1"}):
-        env = dict(os.environ, **env_extra)
-        env.pop("MLSP_TNET_FWD_SPLIT", None) if not env_extra else None
+    for env_extra in ({"MLSP_TNET_FWD_F32": "1"}, {"MLSP_TNET_FWD_SPLIT": "1"}):
+        env = {k: v for k, v in os.environ.items() if k not in ("MLSP_TNET_FWD_F32", "MLSP_TNET_FWD_SPLIT")}
+        env.update(env_extra)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "tnet_acc.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
         print(env_extra, r.stdout.strip().splitlines()[-2:])
         assert r.returncode == 0, (env_extra, r.stdout[-500:], r.stderr[-500:])

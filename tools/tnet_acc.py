@@ -1,5 +1,5 @@
 """Forward accuracy of the fused T-Net per-edge stage against a float64 evaluation of the reference's op sequence (training mode), for the
-kernel the library picks (default: f32 MFMA products; MLSP_TNET_FWD_SPLIT=1: split products on the bf16 cores).  Prints one line per
+kernel the library picks (MLSP_TNET_FWD_F32=1: f32 MFMA products; MLSP_TNET_FWD_SPLIT=1 or >= 1024 tiles: split products on the bf16 cores).  Prints one line per
 shape; `--check` exits non-zero when a relative L2 error exceeds 4e-7."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
