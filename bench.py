@@ -504,8 +504,8 @@ def main():
                                 "algorithmic 2*N*C FLOP per point (one distance sweep; the kernel runs two)"),
                   _kernel_entry("kNN C=128 (knn_mfma5_kernel<128>), stage 4", "mfma", rows[3], prof_steps,
                                 "algorithmic 2*N*C FLOP per point (one distance sweep; the kernel runs two)"),
-                  _kernel_entry("T-Net per-edge stage forward (tnet_edge_fwd2_kernel<20>)", "mfma", rows[5], prof_steps,
-                                "2*E*64*128 FLOP"),
+                  _kernel_entry("T-Net per-edge stage forward (tnet_edge_fwd3_kernel<20>: split products on the bf16 cores)", "mfma", rows[5], prof_steps,
+                                "2*E*64*128 algorithmic FLOP, priced against the f32 MFMA peak (the kernel executes 6x that on the bf16 cores)"),
                   _kernel_entry("T-Net per-edge stage backward (tnet_edge_bwdg_kernel + prep / slab reduce / finish)", "mfma", rows[6],
                                 prof_steps, "reference FLOP 4*E*64*128 (the Gram form executes about a third of them)")]
             out["roofline_kernels"] = [k for k in [f32_entry] + ks if k]
