@@ -205,12 +205,14 @@ def test_gemm_matches_fma_chain_bitwise(dev):
 
 @pytest.mark.parametrize("ta,tb,M,N,K", [(False, True, 32768, 256, 512), (False, False, 32768, 512, 256), (True, False, 512, 256, 32768),
                                           (False, True, 4096, 1024, 128), (False, True, 32768, 1024, 512), (False, False, 65536, 1024, 128),
-                                          (True, True, 256, 256, 16384), (True, False, 1024, 512, 32768)])
+                                          (True, True, 256, 256, 16384), (True, False, 1024, 512, 32768), (True, False, 2048, 2048, 512),
+                                          (True, True, 2048, 2560, 256), (False, False, 2048, 2048, 512)])
 def test_gemm_split_bf16_accuracy(dev, ta, tb, M, N, K):
     """gemm_precision("bf16x6"): products as six bf16 piece products on the bf16 matrix cores.  Against float64 its error must be at the
     level of the exact-fp32 MFMA kernel's (both are fp32 accumulations of products exact to <= 2^-25): <= 2x that error and
     <= 2e-6 relative L2 on random operands with a wide dynamic range.  The shapes cover both tile heights (64 / 128 rows), split-K, and
-    all four operand layouts (row-major images read with ds_read_b128, k-major images read with ds_read_b64_tr_b16)."""
+    all four operand layouts (row-major images read with ds_read_b128, k-major images read with ds_read_b64_tr_b16), the last three with a
+    k-major / row-major A operand on the 64-row tile (256-511 tiles of 128 rows, no split-K)."""
     Fh = _fh()
     g = torch.Generator().manual_seed(11)
     shpA, shpB = ((K, M) if ta else (M, K)), ((N, K) if tb else (K, N))
