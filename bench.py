@@ -324,6 +324,74 @@ def secondary_workloads(lib, dev):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: THIS process (which has not touched a GPU and never will) starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <argv>` as a child, passes rank 0's JSON line through and
+    returns the child's exit code (non-zero if any rank failed or no line came out).  The reference's own mechanism is nn.DataParallel
+    inside one process (PointDA/trainer.py:251-252); one process per GPU over RCCL replaces it."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)          # anything else the ranks print is not the result line
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        rc = 1
+    if line is not None:
+        got = json.loads(line).get("n_gpus")
+        if got != n:
+            print("bench.py: result line reports n_gpus=%r, asked for %d" % (got, n), file=sys.stderr)
+            rc = rc or 1
+        print(line)
+    return rc
+
+
+def stub_ranks(a, world, rank):
+    """Launcher / rendezvous / result-line check without a GPU (tests/test_bench_launcher_cpu.py): the ranks meet over gloo, a "step" is a
+    1 ms sleep, the line has the fields of the real one.  Never a measurement."""
+    import torch.distributed as dist
+    if os.environ.get("MLSP_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                      # (the test of "a failing rank fails the launcher")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(1e-3)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    if rank == 0:
+        print(json.dumps({"metric": "points/sec fwd+bwd, DGCNN+MLSP B=32 N=1024 k=20", "value": B_PER_GPU * NPTS * world * a.steps / dt,
+                          "unit": "points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub (no GPU work)",
+                          "config": {"workload": "launcher stub", "parallelism": "dp%d" % world}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,20 +404,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] runs after the headline")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the comparison blocks with every GEMM on the f32 MFMA")
+    ap.add_argument("--stub", action="store_true", help="launcher self-test: gloo ranks, no GPU, no kernels (never a measurement)")
     a = ap.parse_args()
 
-    import torch.distributed as dist
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # no launcher around us: become one.  Nothing in this process has initialised the GPU (and nothing will).
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = a.gpus > 1 or world > 1
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
+    if a.stub:
+        return stub_ranks(a, world, rank)
+
+    import torch.distributed as dist
+    distributed = world > 1
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    n_gpus = world if distributed else 1
+    n_gpus = world
     if a.global_batch:
         if a.global_batch % n_gpus:
             raise SystemExit("--global-batch must be a multiple of the number of ranks")
