@@ -12,11 +12,22 @@
  *     with mlsp_workspace_bytes).
  *   - every compute call is asynchronous on `stream`, re-entrant, never throws, and returns 0 on
  *     success, a negative MLSP_ERR_* code for bad arguments, or a positive hipError_t.  The compute
- *     entry points keep no mutable state of their own; the library has exactly two process-wide
- *     switches, both off by default and both set from the host thread that owns the training loop:
- *     mlsp_set_gemm_precision (operand rounding of the GEMM family) and mlsp_profile_begin/_end
- *     (HIP events around the GEMM launches).  Neither is touched by any compute call.  One environment variable is read once per
- *     process: MLSP_TNET_BWD_OLD=1 selects the round-1 T-Net backward kernel (A/B measurements, tools/time_tnet.py).
+ *     entry points keep no mutable state: what a call does is a function of its arguments alone, from any thread, on any stream
+ *     (ABI v8: the products of the GEMM family are the per-call `precision` argument below, not a library switch).  The only
+ *     process-wide object is the measurement hook mlsp_profile_begin/_end (HIP events around launches while armed; bench.py only,
+ *     never armed in a production step).  Environment variables read once per process, all A/B measurement switches:
+ *     MLSP_TNET_BWD_OLD=1 (round-1 T-Net backward kernel), MLSP_GEMM_SPLIT_ALWAYS, MLSP_GEMM_OLD_EPILOGUE.
+ *   - `precision` (every entry point that reaches a matrix-core contraction takes it, just before its workspace):
+ *       MLSP_PREC_F32    0  f32 MFMA, exact fp32 products (v_mfma_f32_32x32x2_f32);
+ *       MLSP_PREC_BF16   1  operands ROUNDED to bf16, fp32 accumulation (BASELINE.json configs[4]; reduced precision);
+ *       MLSP_PREC_BF16X6 2  fp32-ACCURATE products on the bf16 matrix cores: every operand value split exactly into three bf16 pieces
+ *                           (8 + 8 + 8 significand bits), six piece products per multiply, fp32 accumulation.  Against float64 its error
+ *                           is below the f32-MFMA chain's (tests/test_gpu_kernels.py::test_gemm_split_bf16_accuracy), 1.55-1.65x faster
+ *                           on the 32768-row layers.  THE MODE OF EVERY NUMBER bench.py REPORTS and the default of the Python mirror
+ *                           (MLSP_GEMM_PRECISION overrides it there).  An infinite operand becomes NaN (the f32 MFMA would give +-inf).
+ *     Launches off the interior-tile path, short K loops, operand-transform and N = 64 launches run on the f32 kernels in every mode
+ *     (exact fp32 either way); kNN distances, BatchNorm statistics, reductions and losses are fp32 in every mode.  A backward call
+ *     normally passes the precision of its forward (the Python mirror keeps it in the autograd context); nothing breaks if it differs.
  *   - activations are POINT-major fp32 row matrices: [rows][C] with rows = B*N points (or
  *     B*N*k edges), channels contiguous.  The reference itself moves to this layout before its
  *     gather (model_utils.py:35).  Indices are int32, local to their cloud (0..N-1).
@@ -34,11 +45,14 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 7
+#define MLSP_ABI_VERSION 8
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
 #define MLSP_ERR_UNSUPPORTED (-3)
+#define MLSP_PREC_F32 0
+#define MLSP_PREC_BF16 1
+#define MLSP_PREC_BF16X6 2
 
 int mlsp_abi_version(void);
 const char* mlsp_strerror(int code);
@@ -76,12 +90,12 @@ int mlsp_graph_feature_bwd_f32(const float* dF, const int32_t* rev_off, const in
 int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int act, float slope, int training,
                           int B, int N, int C, int Cout, int k, float* out, int ldo, float* uv, float* msel, uint8_t* argsel,
-                          float* s1, float* bn_save, float* Wd, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          float* s1, float* bn_save, float* Wd, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
                           const float* W, const float* out, int ldo, const float* uv, const float* msel, const uint8_t* argsel,
                           const float* s1, const float* bn_save, const float* Wd, int act, float slope, int training, int B, int N,
                           int C, int Cout, int k, float* dx, int lddx, int dx_accumulate, float* dW, float* dgamma, float* dbeta,
-                          void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* Fused per-edge stage of the T-Net (PointDA/model_utils.py:111-115: conv2d1 6->64, conv2d2 64->128 per EDGE, max over k),
  * dgcnn branch (bias-free convs, LeakyReLU).  x [P][C] point-major (C = 3), W1 [C1][2C], W2 [C2][C1]; requires C1 = 64, C2 = 128
@@ -91,12 +105,12 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
                            float* run_mean1, float* run_var1, const float* W2, const float* gamma2, const float* beta2,
                            float* run_mean2, float* run_var2, float momentum, float eps, float slope, int training, int B, int N,
                            int C, int C1, int C2, int k, float* out, float* uv, float* s1, float* bn1_save, float* zsel,
-                           uint8_t* argsel, float* bn2_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                           uint8_t* argsel, float* bn2_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int32_t* idx, const int32_t* rev_off,
                            const int32_t* rev_ent, const float* W1, const float* W2, const float* out, const float* uv,
                            const float* s1, const float* bn1_save, const float* zsel, const uint8_t* argsel, const float* bn2_save,
                            float slope, int training, int B, int N, int C, int C1, int C2, int k, float* dx, float* dW1,
-                           float* dgamma1, float* dbeta1, float* dW2, float* dgamma2, float* dbeta2, void* ws, size_t ws_bytes,
+                           float* dgamma1, float* dbeta1, float* dW2, float* dgamma2, float* dbeta2, int precision, void* ws, size_t ws_bytes,
                            mlsp_stream_t stream);
 
 /* Per-row MLP layer = Linear/1x1 conv (+bias) + BatchNorm + act + dropout:
@@ -117,36 +131,36 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
 int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                           const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                           float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
-                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope, float in_p_drop,
                                 uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                                 const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                                 float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
-                                uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                                uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope,
                                 float in_p_drop, uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                                 const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                                 int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
-                                float* dgbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                                float* dgbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                           const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                           int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
-                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* The same layer with its ACTIVATIONS stored as bf16 in HBM (BASELINE.json configs[4]: PointSegDA N=2048 k=40 "bf16 with MFMA edge-MLP";
  * PointSegDA/Models.py:245-385 head stacks).  x_bf16: X and dX are bf16 (else fp32); out_bf16: Y, Z, dZ and the internal dY are bf16.
  * W, bias, gbias, BatchNorm parameters / statistics, dW and every reduction stay fp32; products are bf16 x bf16 with fp32 accumulation.
  * BN layers on interior GEMM tiles only: mlsp_pointmlp_mx_supported() != 0, otherwise both entry points return MLSP_ERR_UNSUPPORTED and
  * the caller runs that layer through mlsp_pointmlp_*_f32. */
-int mlsp_pointmlp_mx_supported(int M, int Cin, int Cout, int ldx, int x_bf16, int training);
+int mlsp_pointmlp_mx_supported(int M, int Cin, int Cout, int ldx, int x_bf16, int training, int precision);
 int mlsp_pointmlp_fwd_mx(const void* X, int x_bf16, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                          const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                          float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop, uint64_t seed,
-                         void* Y, void* Z, int out_bf16, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                         void* Y, void* Z, int out_bf16, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_bwd_mx(const void* dZ, const void* X, int x_bf16, int ldx, int M, int Cin, const float* W, int ldw, int Cout,
                          const void* Y, int out_bf16, const float* bn_save, int training, int act, float slope, float p_drop,
                          uint64_t seed, int n_groups, int rows_per_group, void* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
-                         float* dgbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                         float* dgbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* Fused per-point conv (bias-free) + BatchNorm + act + max over the N points of each cloud:
  * conv5/bn5/LeakyReLU/adaptive_max_pool1d (PointDA/Models.py:132-136) and the T-Net's conv2d3 + torch.max(dim=2)
@@ -155,12 +169,12 @@ int mlsp_pointmlp_bwd_mx(const void* dZ, const void* X, int x_bf16, int ldx, int
  * contiguous (ldx == Cin) for the backward. */
 int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw, int Cout,
                                  const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
-                                 int training, int act, float slope, float* out, float* ysel, int32_t* arg, float* bn_save, void* ws,
+                                 int training, int act, float slope, float* out, float* ysel, int32_t* arg, float* bn_save, int precision, void* ws,
                                  size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw,
                                  int Cout, const float* out, const float* ysel, const int32_t* arg, const float* bn_save,
                                  int training, int act, float slope, float* dX, int dx_accumulate, float* dW, float* dgamma, float* dbeta,
-                                 void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                                 int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* Several Linear (+bias) layers side by side under ONE BatchNorm + activation (+dropout) pass: layer d of the three MLSP heads
  * (PointDA/Models.py:193-196 position, :227-230 normal, :274-279 cardinality) in one [M][sum Cout] matrix.  Segment s:
@@ -176,13 +190,13 @@ typedef struct mlsp_seg {
     const float* bias;     /* [Cout] or NULL */
     int ldw, x_col, Cin, Cout;
 } mlsp_seg_t;
-int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg);
+int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg, int precision);
 int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int training, const float* chan, float p_drop,
-                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* Y,
                           const float* bn_save, int training, const float* chan, float p_drop, uint64_t seed, float* dX, int lddx,
-                          float* const* dW, float* dbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          float* const* dW, float* dbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* max over the k edges of every point (`.max(dim=-1)`, model_utils.py:114) on an edge-major matrix */
 int mlsp_segmax_fwd_f32(const float* Z, int P, int k, int C, float* out, uint8_t* argk, mlsp_stream_t stream);
@@ -234,7 +248,7 @@ int mlsp_density_loss_bwd_f32(const float* pvec, const float* dens, const float*
 /* plain fp32 GEMM on the matrix cores (exposed for tests and the 3x3 input transform):
  * C[M][N] = opA(A) opB(B) + bias;  ta/tb as in gemm.hip */
 int mlsp_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                  const float* bias, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                  const float* bias, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* Label generators of the target branch (python-pcl in the reference, PARITY UNPINNED -- see labels.hip):
  * radius neighbour count behind cal_density (MLSP/mlsp.py:240-272; count excludes cloud index 0, capped at max_nn) and
@@ -280,10 +294,10 @@ int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const 
 int mlsp_pointmlp_segmax_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                                  const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
                                  int training, int act, float slope, int k, float* Y, float* out, float* ysel, uint8_t* argk, float* bn_save,
-                                 void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                                 int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_segmax_bwd_f32(const float* dOut, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                                  const float* ysel, const uint8_t* argk, const float* bn_save, int training, int act, float slope, int k,
-                                 float* dX, int lddx, float* dW, float* dbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                 float* dX, int lddx, float* dW, float* dbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes,
                                  mlsp_stream_t stream);
 
 /* Folded first layer of a set-abstraction MLP (pointnet_util.py:120-129 grouping + :185-190 first Conv2d + BatchNorm2d + ReLU): the
@@ -335,16 +349,7 @@ int mlsp_collapse_to_point_f32(float* X, int B, int N, const int32_t* choice, co
  * mask [B][N][C] is 0 on their first three channels and 1 elsewhere. */
 int mlsp_scan_select_f32(const float* X, int B, int N, int C, const double* R, int pixel, float* Xs, float* mask, mlsp_stream_t stream);
 
-/* Operand precision of the GEMM family (process-wide switch, default 0).  0: fp32 MFMA, exact fp32 products -- the parity
- * contract of the fp32 configs.  1: operands rounded to bf16, fp32 accumulation (v_mfma_f32_32x32x16_bf16) for the launches on
- * the fast path (interior tiles, 16-byte aligned operands); BASELINE.json configs[4].  2: fp32-accurate products on the bf16 matrix
- * cores: every operand value split into three bf16 pieces (exactly: 8 + 8 + 8 significand bits), six piece products per multiply, fp32
- * accumulation.  Measured against float64 its error is below the f32-MFMA chain's (tests/test_gpu_kernels.py::
- * test_gemm_split_bf16_accuracy); 1.55-1.65x faster on the 32768-row layers.  Launches off the fast path, short K loops, the operand-
- * transform / N = 64 kernels stay on the fp32 kernels (exact fp32 either way).  The Python mirror (mlsp_amd) selects mode 2 when it
- * loads the library unless MLSP_GEMM_PRECISION says otherwise; a C caller gets mode 0 until it calls this.  Mode 2 turns an infinite
- * operand value into NaN (the f32 MFMA would give +-inf); finite data only.  The kNN distances stay exact fp32 always. */
-int mlsp_set_gemm_precision(int mode);
+/* (ABI v7's process-wide mlsp_set_gemm_precision is gone: see `precision` in the conventions above.) */
 
 /* Measurement aid (bench.py `roofline`): while armed, every gemm_f32_kernel launch is bracketed by two HIP
  * events on its launch stream.  mlsp_profile_end synchronises those events and fills

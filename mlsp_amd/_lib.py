@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLSP_HIP_LIB") or os.path.join(_HERE, "libmlsp_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c = ctypes
 _P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
@@ -26,28 +26,28 @@ SIGNATURES = {
     "mlsp_graph_feature_fwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_graph_feature_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_edgeconv_fwd_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _F, _I, _I, _I, _I, _I, _I,
-                              _P, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+                              _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_edgeconv_bwd_f32": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _I,
-                              _P, _I, _I, _P, _P, _P, _P, _SZ, _P],
+                              _P, _I, _I, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_tnet_edge_fwd_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I,
-                               _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+                               _P, _P, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_tnet_edge_bwd_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I,
-                               _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+                               _P, _P, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_fwd_f32": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
-                              _P, _P, _P, _P, _SZ, _P],
+                              _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
-                              _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
+                              _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_fwd_chain_f32": [_P, _I, _P, _I, _F, _F, _U64, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
-                                    _P, _P, _P, _P, _SZ, _P],
+                                    _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_chain_f32": [_P, _P, _I, _P, _I, _F, _F, _U64, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
-                                    _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
-    "mlsp_pointmlp_mx_supported": [_I, _I, _I, _I, _I, _I],
+                                    _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
+    "mlsp_pointmlp_mx_supported": [_I, _I, _I, _I, _I, _I, _I],
     "mlsp_pointmlp_fwd_mx": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
-                             _P, _P, _I, _P, _P, _SZ, _P],
+                             _P, _P, _I, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_mx": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _F, _F, _U64, _I, _I,
-                             _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
-    "mlsp_pointmlp_colmax_fwd_f32": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _SZ, _P],
-    "mlsp_pointmlp_colmax_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _P, _I, _P, _P, _P, _P, _SZ, _P],
+                             _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
+    "mlsp_pointmlp_colmax_fwd_f32": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _P, _P, _P, _P, _I, _P, _SZ, _P],
+    "mlsp_pointmlp_colmax_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _P, _I, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_segmax_fwd_f32": [_P, _I, _I, _I, _P, _P, _P],
     "mlsp_segmax_bwd_f32": [_P, _P, _I, _I, _I, _P, _P],
     "mlsp_colmax_fwd_f32": [_P, _I, _I, _I, _P, _P, _P],
@@ -72,8 +72,8 @@ SIGNATURES = {
     "mlsp_group_reverse": [_P, _I, _I, _I, _I, _P, _P, _P],
     "mlsp_sa_group_fwd_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_sa_group_bwd_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
-    "mlsp_pointmlp_segmax_fwd_f32": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P, _SZ, _P],
-    "mlsp_pointmlp_segmax_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _P, _SZ, _P],
+    "mlsp_pointmlp_segmax_fwd_f32": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _I, _F, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
+    "mlsp_pointmlp_segmax_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_sa_fold_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _SZ, _P],
     "mlsp_sa_fold_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _SZ, _P],
     "mlsp_group_reverse_compact": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -83,14 +83,13 @@ SIGNATURES = {
     "mlsp_transform3_bwd_f32": [_P, _P, _P, _I, _I, _P, _P, _P],
     "mlsp_collapse_to_point_f32": [_P, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P],
     "mlsp_scan_select_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _P],
-    "mlsp_multimlp_supported": [_I, _P, _I],
-    "mlsp_multimlp_fwd_f32": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _F, _F, _I, _P, _F, _U64, _P, _P, _P, _P, _SZ, _P],
-    "mlsp_multimlp_bwd_f32": [_P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _F, _U64, _P, _I, _P, _P, _P, _P, _P, _SZ, _P],
-    "mlsp_set_gemm_precision": [_I],
+    "mlsp_multimlp_supported": [_I, _P, _I, _I],
+    "mlsp_multimlp_fwd_f32": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _F, _F, _I, _P, _F, _U64, _P, _P, _P, _I, _P, _SZ, _P],
+    "mlsp_multimlp_bwd_f32": [_P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _F, _U64, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_profile_begin": [],
     "mlsp_profile_end": [_P],
     "mlsp_profile_classes": [_P, _I],
-    "mlsp_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _SZ, _P],
+    "mlsp_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _SZ, _P],
 }
 
 
@@ -108,7 +107,7 @@ class MlspLibraryError(RuntimeError):
     pass
 
 
-# GEMM products (include/mlsp_hip.h mlsp_set_gemm_precision; functional.gemm_precision is the switch).  Default "bf16x6": fp32-accurate
+# GEMM products (include/mlsp_hip.h `precision`, a per-call argument; functional.gemm_precision chooses what the mirror passes).  Default "bf16x6": fp32-accurate
 # products on the bf16 matrix cores (three-way exact operand split, six piece products, fp32 accumulation; measured error below the
 # f32-MFMA chain's).  MLSP_GEMM_PRECISION=fp32 selects the f32 MFMA for every launch; an unknown name fails loudly at import.
 GEMM_PRECISION_MODES = {"fp32": 0, "bf16": 1, "bf16x6": 2}
@@ -134,9 +133,6 @@ def load():
     if lib.mlsp_abi_version() != ABI_VERSION:
         raise MlspLibraryError("mlsp_amd: ABI mismatch: library %d, python %d" % (lib.mlsp_abi_version(), ABI_VERSION))
     _lib = lib
-    rc = lib.mlsp_set_gemm_precision(GEMM_PRECISION_MODES[DEFAULT_GEMM_PRECISION])
-    if rc != 0:
-        raise MlspLibraryError("mlsp_amd: mlsp_set_gemm_precision(%s) failed (%d)" % (DEFAULT_GEMM_PRECISION, rc))
     return lib
 
 

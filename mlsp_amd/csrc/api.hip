@@ -198,7 +198,8 @@ size_t mlsp_workspace_bytes(int rows, int cin, int cout) {
 }
 
 int mlsp_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                  const float* bias, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                  const float* bias, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     Workspace w(ws, ws_bytes);
     size_t sf = gemm_slab_floats(M, N, K);
     float* slab = sf ? w.take<float>(sf) : nullptr;
@@ -319,7 +320,8 @@ int mlsp_graph_feature_bwd_f32(const float* dF, const int32_t* rev_off, const in
 int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const float* W, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int act, float slope, int training,
                           int B, int N, int C, int Cout, int k, float* out, int ldo, float* uv, float* msel, uint8_t* argsel,
-                          float* s1, float* bn_save, float* Wd_out, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          float* s1, float* bn_save, float* Wd_out, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!x || !idx || !W || !gamma || !beta || !out || !uv || !msel || !argsel || !s1 || !bn_save) return MLSP_ERR_ARG;
     if (B <= 0 || N <= 0 || C <= 0 || Cout <= 0 || k <= 0 || k > 255 || ldx < C || ldo < Cout) return MLSP_ERR_ARG;
     const int P = B * N;
@@ -353,8 +355,9 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
 int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, const int32_t* rev_off, const int32_t* rev_ent,
                           const float* W, const float* out, int ldo, const float* uv, const float* msel, const uint8_t* argsel,
                           const float* s1, const float* bn_save, const float* Wd_in, int act, float slope, int training, int B, int N, int C,
-                          int Cout, int k, float* dx, int lddx, int dx_accumulate, float* dW, float* dgamma, float* dbeta, void* ws,
+                          int Cout, int k, float* dx, int lddx, int dx_accumulate, float* dW, float* dgamma, float* dbeta, int precision, void* ws,
                           size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!dOut || !x || !rev_off || !rev_ent || !W || !out || !uv || !msel || !argsel || !s1 || !bn_save || !dW || !dgamma ||
         !dbeta)
         return MLSP_ERR_ARG;
@@ -394,7 +397,8 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
                            float* run_mean1, float* run_var1, const float* W2, const float* gamma2, const float* beta2,
                            float* run_mean2, float* run_var2, float momentum, float eps, float slope, int training, int B, int N,
                            int C, int C1, int C2, int k, float* out, float* uv, float* s1, float* bn1_save, float* zsel,
-                           uint8_t* argsel, float* bn2_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                           uint8_t* argsel, float* bn2_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!x || !idx || !W1 || !gamma1 || !beta1 || !W2 || !gamma2 || !beta2 || !out || !uv || !s1 || !bn1_save || !zsel || !argsel ||
         !bn2_save)
         return MLSP_ERR_ARG;
@@ -442,8 +446,9 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
                            const int32_t* rev_ent, const float* W1, const float* W2, const float* out, const float* uv,
                            const float* s1, const float* bn1_save, const float* zsel, const uint8_t* argsel, const float* bn2_save,
                            float slope, int training, int B, int N, int C, int C1, int C2, int k, float* dx, float* dW1,
-                           float* dgamma1, float* dbeta1, float* dW2, float* dgamma2, float* dbeta2, void* ws, size_t ws_bytes,
+                           float* dgamma1, float* dbeta1, float* dW2, float* dgamma2, float* dbeta2, int precision, void* ws, size_t ws_bytes,
                            mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!dOut || !x || !idx || !W1 || !W2 || !out || !uv || !s1 || !bn1_save || !zsel || !argsel || !bn2_save ||
         !dW1 || !dgamma1 || !dbeta1 || !dW2 || !dgamma2 || !dbeta2)
         return MLSP_ERR_ARG;
@@ -578,7 +583,8 @@ static int pointmlp_fwd_impl(const float* X, int ldx, int M, int Cin, const floa
 int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                           const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                           float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
-                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     return pointmlp_fwd_impl(X, ldx, M, Cin, W, ldw, Cout, bias, gbias, rows_per_group, gamma, beta, run_mean, run_var, momentum, eps,
                              training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, nullptr);
 }
@@ -587,7 +593,8 @@ int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const float* in_bn_s
                                 uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                                 const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                                 float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
-                                uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                                uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     const ChainIn in = {in_bn_save, in_act, in_slope, in_p_drop, in_seed};
     return pointmlp_fwd_impl(Xpre, ldx, M, Cin, W, ldw, Cout, bias, gbias, rows_per_group, gamma, beta, run_mean, run_var, momentum, eps,
                              training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, &in);
@@ -661,7 +668,8 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
 int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                           const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                           int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
-                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     return pointmlp_bwd_impl(dZ, X, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
                              rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, nullptr);
 }
@@ -670,7 +678,8 @@ int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, con
                                 float in_p_drop, uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                                 const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                                 int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
-                                float* dgbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                                float* dgbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     const ChainIn in = {in_bn_save, in_act, in_slope, in_p_drop, in_seed};
     return pointmlp_bwd_impl(dZ, Xpre, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
                              rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, &in);
@@ -683,7 +692,8 @@ int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, con
 int mlsp_pointmlp_segmax_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                                  const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
                                  int training, int act, float slope, int k, float* Y, float* out, float* ysel, uint8_t* argk, float* bn_save,
-                                 void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                                 int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!X || !W || !gamma || !beta || !Y || !out || !ysel || !argk || !bn_save || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin)
         return MLSP_ERR_ARG;
     if (k < 1 || k > 255 || M % k || Cout % 4) return MLSP_ERR_UNSUPPORTED;
@@ -708,8 +718,9 @@ int mlsp_pointmlp_segmax_fwd_f32(const float* X, int ldx, int M, int Cin, const 
 
 int mlsp_pointmlp_segmax_bwd_f32(const float* dOut, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                                  const float* ysel, const uint8_t* argk, const float* bn_save, int training, int act, float slope, int k,
-                                 float* dX, int lddx, float* dW, float* dbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                 float* dX, int lddx, float* dW, float* dbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes,
                                  mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!dOut || !X || !W || !Y || !ysel || !argk || !bn_save || !dW || !dgamma || !dbeta || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin ||
         ldw < Cin) return MLSP_ERR_ARG;
     if (k < 1 || k > 255 || M % k || Cout % 4) return MLSP_ERR_UNSUPPORTED;
@@ -750,7 +761,9 @@ int mlsp_pointmlp_segmax_bwd_f32(const float* dOut, const float* X, int ldx, int
 // out_bf16 how Y, Z (and dZ, dY) are.  Weights, biases, BN parameters / statistics and every weight gradient stay fp32; products are
 // bf16 x bf16 with fp32 accumulation (v_mfma_f32_32x32x16_bf16).  BN layers with fused statistics only (interior GEMM tiles):
 // MLSP_ERR_UNSUPPORTED otherwise -- mlsp_pointmlp_mx_supported() tells the caller beforehand, which then keeps that layer in fp32.
-int mlsp_pointmlp_mx_supported(int M, int Cin, int Cout, int ldx, int x_bf16, int training) {
+int mlsp_pointmlp_mx_supported(int M, int Cin, int Cout, int ldx, int x_bf16, int training, int precision) {
+    if (precision < 0 || precision > 2) return 0;
+    GemmPrecisionScope prec_scope_(precision);
     if (M <= 32 || Cin % 32 || Cout % 128 || M % 128) return 0;
     if (x_bf16 ? (ldx % 8) : (ldx % 4)) return 0;
     if (Cout > 1024 || 256 % (Cout / 4)) return 0;
@@ -762,10 +775,11 @@ int mlsp_pointmlp_mx_supported(int M, int Cin, int Cout, int ldx, int x_bf16, in
 int mlsp_pointmlp_fwd_mx(const void* X, int x_bf16, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                          const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                          float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop, uint64_t seed,
-                         void* Y, void* Z, int out_bf16, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                         void* Y, void* Z, int out_bf16, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!X || !W || !Y || !Z || !gamma || !beta || !bn_save || ldw < Cin || ldx < Cin) return MLSP_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
-    if (!mlsp_pointmlp_mx_supported(M, Cin, Cout, ldx, x_bf16, training)) return MLSP_ERR_UNSUPPORTED;
+    if (!mlsp_pointmlp_mx_supported(M, Cin, Cout, ldx, x_bf16, training, precision)) return MLSP_ERR_UNSUPPORTED;
     Workspace w(ws, ws_bytes);
     const int fused_parts = training ? gemm_stat_parts(M, Cout, Cin) : 0;
     double* part = w.take<double>((size_t)(fused_parts ? fused_parts : 1) * 2 * Cout);
@@ -787,10 +801,11 @@ int mlsp_pointmlp_fwd_mx(const void* X, int x_bf16, int ldx, int M, int Cin, con
 int mlsp_pointmlp_bwd_mx(const void* dZ, const void* X, int x_bf16, int ldx, int M, int Cin, const float* W, int ldw, int Cout,
                          const void* Y, int out_bf16, const float* bn_save, int training, int act, float slope, float p_drop,
                          uint64_t seed, int n_groups, int rows_per_group, void* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
-                         float* dgbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                         float* dgbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!dZ || !X || !W || !Y || !bn_save || !dW || !dgamma || !dbeta || ldw < Cin || ldx < Cin) return MLSP_ERR_ARG;
     if (dgbias && (n_groups <= 0 || rows_per_group <= 0 || (long)n_groups * rows_per_group != M)) return MLSP_ERR_ARG;
-    if (!mlsp_pointmlp_mx_supported(M, Cin, Cout, ldx, x_bf16, training)) return MLSP_ERR_UNSUPPORTED;
+    if (!mlsp_pointmlp_mx_supported(M, Cin, Cout, ldx, x_bf16, training, precision)) return MLSP_ERR_UNSUPPORTED;
     if (dbias && !training) return MLSP_ERR_UNSUPPORTED;
     Workspace w(ws, ws_bytes);
     void* dY = w.take<char>((size_t)M * Cout * (out_bf16 ? 2 : 4));
@@ -825,8 +840,9 @@ int mlsp_pointmlp_bwd_mx(const void* dZ, const void* X, int x_bf16, int ldx, int
 
 int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw, int Cout,
                                  const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
-                                 int training, int act, float slope, float* out, float* ysel, int32_t* arg, float* bn_save, void* ws,
+                                 int training, int act, float slope, float* out, float* ysel, int32_t* arg, float* bn_save, int precision, void* ws,
                                  size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!X || !W || !gamma || !beta || !out || !ysel || !arg || !bn_save) return MLSP_ERR_ARG;
     if (B <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
     const int P = B * N;
@@ -864,7 +880,8 @@ int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin,
 int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int B, int N, int Cin, const float* W, int ldw,
                                  int Cout, const float* out, const float* ysel, const int32_t* arg, const float* bn_save,
                                  int training, int act, float slope, float* dX, int dx_accumulate, float* dW, float* dgamma, float* dbeta,
-                                 void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                                 int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     if (!dOut || !X || !W || !out || !ysel || !arg || !bn_save || !dW || !dgamma || !dbeta) return MLSP_ERR_ARG;
     if (B <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || ldx != Cin || ldw < Cin) return MLSP_ERR_ARG;
     const int P = B * N;

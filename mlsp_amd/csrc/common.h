@@ -26,6 +26,20 @@ enum { MLSP_PROF_GEMM = 0, MLSP_PROF_KNN_C3, MLSP_PROF_KNN_C64, MLSP_PROF_KNN_C1
 int prof_cls_begin(hipStream_t st, int cls);              // -> token (< 0: not armed)
 void prof_cls_end(hipStream_t st, int token, double work);
 
+// Products of the GEMM family are a PER-CALL argument of every entry point that reaches it (include/mlsp_hip.h `precision`): 0 f32 MFMA,
+// 1 bf16-rounded operands, 2 fp32-accurate six-product bf16 split.  An entry point opens a GemmPrecisionScope from its argument; the
+// launch helpers below it read gemm_precision_mode().  The value lives in a thread-local for the duration of that one call (restored on
+// exit, so nested / concurrent calls on any threads never see each other's mode): nothing outlives a call, the library keeps no switch.
+struct GemmPrecisionScope {
+    int prev;
+    explicit GemmPrecisionScope(int mode);
+    ~GemmPrecisionScope();
+    GemmPrecisionScope(const GemmPrecisionScope&) = delete;
+    GemmPrecisionScope& operator=(const GemmPrecisionScope&) = delete;
+};
+int gemm_precision_mode();
+#define PREC_SCOPE(mode_) if ((mode_) < 0 || (mode_) > 2) return MLSP_ERR_ARG; GemmPrecisionScope prec_scope_(mode_)
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // simple bump allocator over the caller-provided workspace

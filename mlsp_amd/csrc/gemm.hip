@@ -943,13 +943,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     gemm_epilogue<WM, true, false>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 }
 
-static int g_gemm_precision = 0;     // 0: fp32 MFMA (exact fp32 products); 1: bf16 operands, fp32 accumulation; 2: fp32-accurate six-product bf16 split (gemm_split_kernel)
-int gemm_precision_mode() { return g_gemm_precision; }
-extern "C" int mlsp_set_gemm_precision(int mode) {
-    if (mode != 0 && mode != 1 && mode != 2) return MLSP_ERR_ARG;
-    g_gemm_precision = mode;
-    return MLSP_OK;
-}
+// the calling entry point's `precision` argument for the duration of that call (common.h GemmPrecisionScope): 0: fp32 MFMA (exact fp32
+// products); 1: bf16 operands, fp32 accumulation; 2: fp32-accurate six-product bf16 split (gemm_split_kernel)
+static thread_local int tl_call_precision = 0;
+int gemm_precision_mode() { return tl_call_precision; }
+GemmPrecisionScope::GemmPrecisionScope(int mode) : prev(tl_call_precision) { tl_call_precision = mode; }
+GemmPrecisionScope::~GemmPrecisionScope() { tl_call_precision = prev; }
 
 // sum the split-K slabs (fixed order -> bitwise reproducible) and apply the epilogue
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N, int ldc,
@@ -1083,7 +1082,7 @@ static bool gemm_split_pays(int M, int N, int ktiles) {
 static int gemm_pick_bm(int M, int N, int K) {
     long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN);
     // the split kernel amortises its operand split over the tile: 128 rows unless the grid would not fill the 512 workgroup slots
-    const long few = (g_gemm_precision == 2 && gemm_split_pays(M, N, (K + BK - 1) / BK)) ? 512 : 1536;
+    const long few = (tl_call_precision == 2 && gemm_split_pays(M, N, (K + BK - 1) / BK)) ? 512 : 1536;
     return (gemm_pick_split(M, N, K) == 1 && tiles128 < few && M >= 256) ? 64 : 128;
 }
 int gemm_stat_parts(int M, int N, int K) {
@@ -1225,7 +1224,7 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
 // Can this contraction stage `which` (1: A [M][K] row-major, 2: B [K][N] k-major) through the operand transform?  Interior tiles,
 // 16-byte loads, fp32 operands, the MFMA tile kernels (not the thin / skinny / N = 64 ones).
 bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which) {
-    if (g_gemm_precision == 1) return false;          // (mode 2 keeps the fp32 transform kernels: exact fp32 either way)
+    if (tl_call_precision == 1) return false;          // (mode 2 keeps the fp32 transform kernels: exact fp32 either way)
     if (which == 1 ? ta : !(ta && !tb)) return false;
     if (M <= 32 || N < 32 || K < 32 || (ta && !tb && K <= 32)) return false;
     const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
@@ -1245,7 +1244,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
     if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
     // one tiny dimension (3 coordinates, 3 / 16 outputs): streaming VALU kernels priced against HBM, not MFMA tiles (thin.hip)
-    if (grp && (grp->G < 2 || grp->G > 4 || xf || sel_gamma || gbias || g_gemm_precision == 1 || (ta && tb))) return MLSP_ERR_UNSUPPORTED;
+    if (grp && (grp->G < 2 || grp->G > 4 || xf || sel_gamma || gbias || tl_call_precision == 1 || (ta && tb))) return MLSP_ERR_UNSUPPORTED;
     if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf) {
         const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
@@ -1316,25 +1315,25 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (grp) {
         const int per = (grp->mode == 1 ? N : M) / grp->G;                  // columns (mode 1) / rows (mode 2) of one group
         const int tile = grp->mode == 1 ? BN : bm;
-        bool ok = fast && g_gemm_precision != 1 && (grp->mode == 1 || grp->mode == 2) && per * grp->G == (grp->mode == 1 ? N : M) && per % tile == 0;
+        bool ok = fast && tl_call_precision != 1 && (grp->mode == 1 || grp->mode == 2) && per * grp->G == (grp->mode == 1 ? N : M) && per % tile == 0;
         for (int g = 0; g < grp->G && ok && grp->mode == 1; ++g) ok = grp->Bg[g] && (((uintptr_t)grp->Bg[g] & 15) == 0);
         if (!ok) return MLSP_ERR_UNSUPPORTED;
         p.gmode = grp->mode; p.gtiles = per / tile; p.a_gs = grp->a_gs; p.b_gs = grp->b_gs;
         for (int g = 0; g < 4; ++g) p.Bg[g] = grp->mode == 1 ? grp->Bg[g < grp->G ? g : 0] : B;
     }
     const bool n64 = !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
-                     (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && g_gemm_precision != 1 && (ns == 1 || p.ldc == N);
+                     (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && tl_call_precision != 1 && (ns == 1 || p.ldc == N);
     if (n64) {
         dim3 g64(M / 128, ns);
         if (!ta && tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, true>), g64, dim3(256), 0, st, p);
         else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, false>), g64, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_f32_n64_kernel<true, false>), g64, dim3(256), 0, st, p);
     } else
-#define GEMM_GO(TA_, TB_, WM_) do { if (fast && g_gemm_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
-                                     else if (fast && g_gemm_precision == 2 && gemm_split_pays(M, N, kts)) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
+#define GEMM_GO(TA_, TB_, WM_) do { if (fast && tl_call_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
+                                     else if (fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts)) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
-    if (grp && g_gemm_precision == 2 && gemm_split_pays(M, N, kts)) {   // block-diagonal launch on the split kernel (groups are a run-time argument there)
+    if (grp && tl_call_precision == 2 && gemm_split_pays(M, N, kts)) {   // block-diagonal launch on the split kernel (groups are a run-time argument there)
         if (grp->mode == 1 && !ta && tb) { if (bm == 128) GEMM_GO(false, true, 2); else GEMM_GO(false, true, 1); }
         else if (grp->mode == 1 && !ta && !tb) { if (bm == 128) GEMM_GO(false, false, 2); else GEMM_GO(false, false, 1); }
         else if (grp->mode == 2 && ta && !tb) { if (bm == 128) GEMM_GO(true, false, 2); else GEMM_GO(true, false, 1); }
@@ -1372,7 +1371,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
 #undef GEMM_GO
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
-        const bool on_split = fast && g_gemm_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && !xf;
+        const bool on_split = fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && !xf;
         g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0), on_split ? 1 : 0};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;

@@ -221,7 +221,9 @@ static int multi_group_run(const float* X, int ldx, int M, const mlsp_seg_t* seg
 
 extern "C" {
 
-int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg) {
+int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg, int precision) {
+    if (precision < 0 || precision > 2) return 0;
+    GemmPrecisionScope prec_scope_(precision);
     int Ctot = 0, xw = 0;
     if (!segs || nseg < 1) return 0;
     int ldx = 0;
@@ -233,12 +235,13 @@ int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg) {
 
 int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int training, const float* chan, float p_drop,
-                          uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     int Ctot, xw;
     MCHECK(multi_check(X, ldx, M, segs, nseg, Ctot, xw));
     if (!gamma || !beta || !chan || !Y || !Z || !bn_save || p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
     if (!training && (!run_mean || !run_var)) return MLSP_ERR_ARG;
-    if (!mlsp_multimlp_supported(M, segs, nseg)) return MLSP_ERR_UNSUPPORTED;
+    if (!mlsp_multimlp_supported(M, segs, nseg, precision)) return MLSP_ERR_UNSUPPORTED;
     if ((((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)chan | (uintptr_t)bn_save) & 15) != 0) return MLSP_ERR_UNSUPPORTED;
     Workspace w(ws, ws_bytes);
     // BatchNorm sums out of the GEMM epilogues when every segment uses the same row-panel height (their partial rows then line up)
@@ -282,11 +285,12 @@ int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs
 
 int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* Y,
                           const float* bn_save, int training, const float* chan, float p_drop, uint64_t seed, float* dX, int lddx,
-                          float* const* dW, float* dbias, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          float* const* dW, float* dbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    PREC_SCOPE(precision);
     int Ctot, xw;
     MCHECK(multi_check(X, ldx, M, segs, nseg, Ctot, xw));
     if (!dZ || !Y || !bn_save || !chan || !dW || !dgamma || !dbeta || (dX && lddx < xw)) return MLSP_ERR_ARG;
-    if (!mlsp_multimlp_supported(M, segs, nseg)) return MLSP_ERR_UNSUPPORTED;
+    if (!mlsp_multimlp_supported(M, segs, nseg, precision)) return MLSP_ERR_UNSUPPORTED;
     if ((((uintptr_t)Y | (uintptr_t)dZ | (uintptr_t)chan | (uintptr_t)bn_save) & 15) != 0) return MLSP_ERR_UNSUPPORTED;
     Workspace w(ws, ws_bytes);
     float* dY = w.take<float>((size_t)M * Ctot);

@@ -1274,13 +1274,12 @@ int launch_tnet_edge_fwd(hipStream_t st, const float* uv, const int* idx, const 
         a.TP = TF_ROWS / k;
         a.ntiles = (P / N) * ((N + a.TP - 1) / a.TP);
         // tnet_edge_fwd3_kernel (split products on the bf16 cores; closer to float64 than the f32-MFMA kernel: 1.7e-7 vs 2.0e-7 rel-L2,
-        // tools/tnet_acc.py) from 1024 tiles up: B = 32, N = 1024 forward op 222 -> 173 us, B = 8 81 -> 70 us; below that the op is enqueue-bound
-        // and the two kernels take the same time (tools/time_tnet.py: 88 vs 84 us at B = 4, N = 128).  Keeping the small launches on the f32 kernel
-        // also keeps the arg-max routing of the two N = 128 gradient fixtures (tests/test_gpu_model.py: with the split kernel one re-routed maximum
-        // moves their 2e-3 gradient pins to 6e-3 .. 1.4e-2; the float64-oracle test at the benchmarked size holds with it).  Always on under bf16
-        // GEMM operands (configs[4]: nothing there is pinned to last-bit routing).  Read-once switches: MLSP_TNET_FWD_SPLIT=1 / MLSP_TNET_FWD_F32=1.
+        // tools/tnet_acc.py) whenever the call's `precision` asks for products on the bf16 cores (modes 1 and 2), tnet_edge_fwd2_kernel
+        // (f32 MFMA) in mode 0 -- the product mode decides, at every size: B = 32, N = 1024 forward op 222 -> 173 us, B = 8 81 -> 70 us; small
+        // launches are enqueue-bound and the two kernels take the same time (tools/time_tnet.py: 88 vs 84 us at B = 4, N = 128).
+        // Read-once A/B switches: MLSP_TNET_FWD_SPLIT=1 / MLSP_TNET_FWD_F32=1.
         static const bool split_env = getenv("MLSP_TNET_FWD_SPLIT") != nullptr, f32_env = getenv("MLSP_TNET_FWD_F32") != nullptr;
-        const bool split_products = !f32_env && (split_env || gemm_precision_mode() == 1 || a.ntiles >= 1024);
+        const bool split_products = !f32_env && (split_env || gemm_precision_mode() != 0);
         if (!split_products) {
             if (k == 20) hipLaunchKernelGGL((tnet_edge_fwd2_kernel<20>), dim3(grid), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((tnet_edge_fwd2_kernel<40>), dim3(grid), dim3(256), 0, st, a);

@@ -6,6 +6,7 @@ reference's channel-major [B, C, N] at its boundary only.
 """
 import itertools
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -39,15 +40,27 @@ def _rows(t, allow_bf16=False):
     return t
 
 
-class gemm_precision:
-    """Context manager / switch for the products of the GEMM family (include/mlsp_hip.h mlsp_set_gemm_precision):
-    "bf16x6" (default): fp32-ACCURATE products on the bf16 matrix cores -- every operand split exactly into three bf16 pieces, six piece
-    products per multiply, fp32 accumulation; against float64 its error is below the f32-MFMA chain's, and it is 1.55-1.65x faster
-    (DVFS-limited either way: DESIGN.md).  "fp32": the f32 MFMA for every launch (exact fp32 products).  "bf16": operands ROUNDED to
-    bf16, fp32 accumulation (BASELINE.json configs[4]; reduced precision, opt-in).  kNN distances, BatchNorm statistics, reductions and
-    losses are fp32 in every mode (the kNN always exact, canonical order)."""
+class _PrecisionMeta(type):
+    @property
+    def current(cls):
+        """name of the mode the calling thread's next forward will pass to the library"""
+        return getattr(cls._tls, "mode", None) or cls.default
+
+
+class gemm_precision(metaclass=_PrecisionMeta):
+    """Which products the GEMM family computes -- the `precision` ARGUMENT of every C entry point that reaches the matrix cores
+    (include/mlsp_hip.h; the library itself keeps no switch).  "bf16x6" (default): fp32-ACCURATE products on the bf16 matrix cores --
+    every operand split exactly into three bf16 pieces, six piece products per multiply, fp32 accumulation; against float64 its error
+    is below the f32-MFMA chain's, and it is 1.55-1.65x faster (DVFS-limited either way: DESIGN.md).  "fp32": the f32 MFMA for every
+    launch (exact fp32 products).  "bf16": operands ROUNDED to bf16, fp32 accumulation (BASELINE.json configs[4]; reduced precision,
+    opt-in).  kNN distances, BatchNorm statistics, reductions and losses are fp32 in every mode (the kNN always exact, canonical order).
+
+    `with gemm_precision(mode):` applies to the forwards the CALLING THREAD runs inside the block; every autograd Function stores the
+    mode of its forward and hands the same one to its backward, whenever and on whichever thread that runs.  `gemm_precision.set(mode)`
+    changes the process default (threads without a `with` block: nn.DataParallel replicas)."""
     _MODES = _lib.GEMM_PRECISION_MODES
-    current = _lib.DEFAULT_GEMM_PRECISION
+    default = _lib.DEFAULT_GEMM_PRECISION
+    _tls = threading.local()
 
     def __init__(self, mode):
         if mode not in self._MODES:
@@ -56,16 +69,22 @@ class gemm_precision:
 
     @classmethod
     def set(cls, mode):
-        _lib.check(_lib.load().mlsp_set_gemm_precision(cls._MODES[mode]), "mlsp_set_gemm_precision")
-        cls.current = mode
+        if mode not in cls._MODES:
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x6'")
+        cls.default = mode
+
+    @classmethod
+    def code(cls):
+        """the integer the C ABI takes (MLSP_PREC_*) for the calling thread's current mode"""
+        return cls._MODES[cls.current]
 
     def __enter__(self):
-        self.prev = gemm_precision.current
-        gemm_precision.set(self.mode)
+        self.prev = getattr(gemm_precision._tls, "mode", None)
+        gemm_precision._tls.mode = self.mode
         return self
 
     def __exit__(self, *exc):
-        gemm_precision.set(self.prev)
+        gemm_precision._tls.mode = self.prev
         return False
 
 
@@ -119,6 +138,56 @@ class forced_graphs:
         global _forced_graphs
         _forced_graphs = None
         return False
+
+
+_sel_forced = None      # test hook: arg-max selections consumed by successive selecting ops (forced_selections)
+_sel_record = None      # test hook: list the selecting ops append their own selections to (recorded_selections)
+
+
+class forced_selections:
+    """Context manager (tests only), the counterpart of forced_graphs for the network's OTHER discrete choices: the arg-max of every
+    max-pool (T-Net per-edge stage, T-Net / conv5 max over the points, the four EdgeConv max over k).  Successive selecting ops overwrite
+    the selection they computed with the given one before saving it for the backward, so a gradient comparison against a reference no
+    longer depends on which of two candidates that agree to the last bit wins (a re-routed maximum moves a whole gradient row; the
+    forward VALUE differs by that last bit only).  Layouts: max over k -> [P, C] slot numbers; max over N -> [B, C] point numbers local
+    to the cloud.  Call order in DGCNN: tnet_edge, its colmax, EdgeConv 1-4, conv5's colmax."""
+
+    def __init__(self, sel_list):
+        self.sel_list = list(sel_list)
+
+    def __enter__(self):
+        global _sel_forced
+        _sel_forced = list(self.sel_list)
+        return self
+
+    def __exit__(self, *exc):
+        global _sel_forced
+        _sel_forced = None
+        return False
+
+
+class recorded_selections:
+    """Context manager (tests only): `.sel` collects a copy of every selecting op's arg-max tensor, in call order."""
+
+    def __enter__(self):
+        global _sel_record
+        self.sel = _sel_record = []
+        return self
+
+    def __exit__(self, *exc):
+        global _sel_record
+        _sel_record = None
+        return False
+
+
+def _selection_hook(arg):
+    """`arg`: the selection a forward kernel just wrote (uint8 slots or int32 rows), before it is saved for the backward."""
+    if _sel_record is not None:
+        _sel_record.append(arg.detach().clone())
+    if _sel_forced is not None:
+        want = _sel_forced.pop(0)
+        assert tuple(want.shape) == tuple(arg.shape), (want.shape, arg.shape)
+        arg.copy_(want.to(device=arg.device, dtype=arg.dtype))
 
 
 _identity_rows = {}
@@ -451,6 +520,7 @@ class _MultiMLP(Function):
     @staticmethod
     def forward(ctx, X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, *wb):
         lib = _lib.load()
+        prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         n = len(x_cols)
         Ws, bs = list(wb[:n]), list(wb[n:])
         X = _rows(X)
@@ -470,7 +540,7 @@ class _MultiMLP(Function):
         ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
         _lib.check(lib.mlsp_multimlp_fwd_f32(X.data_ptr(), X.stride(0), M, segs, n, gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean),
                                              _lib.ptr(run_var), momentum, eps, int(training), chan.data_ptr(), p, seed, Y.data_ptr(),
-                                             Z.data_ptr(), bn_save.data_ptr(), ws, wsn, _lib.stream()), "mlsp_multimlp_fwd_f32")
+                                             Z.data_ptr(), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_multimlp_fwd_f32")
         ctx.save_for_backward(X, Y, bn_save, chan, *Ws)
         ctx.cfg = (tuple(x_cols), bool(training), p, seed, [b is not None for b in bs])
         ctx.mark_non_differentiable(bn_save)
@@ -511,7 +581,7 @@ class _MultiMLP(Function):
         ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
         _lib.check(lib.mlsp_multimlp_bwd_f32(dZ.data_ptr(), X.data_ptr(), X.stride(0), M, segs, n, Y.data_ptr(), bn_save.data_ptr(),
                                              int(training), chan.data_ptr(), p, seed, _lib.ptr(dX), dX.stride(0) if dX is not None else 0,
-                                             dwp, _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()),
+                                             dwp, _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()),
                    "mlsp_multimlp_bwd_f32")
         dbs, o = [], 0
         for w, hb in zip(Ws, has_b):
@@ -543,7 +613,7 @@ def multimlp_supported(M, X, Ws, x_cols):
     segs = (_lib.Seg * n)()
     for i, (w, xc) in enumerate(zip(Ws, x_cols)):
         segs[i].W, segs[i].bias, segs[i].ldw, segs[i].x_col, segs[i].Cin, segs[i].Cout = 16, None, w.shape[1], xc, w.shape[1], w.shape[0]   # (shape query: W is not read)
-    return bool(_lib.load().mlsp_multimlp_supported(int(M), segs, n))
+    return bool(_lib.load().mlsp_multimlp_supported(int(M), segs, n, gemm_precision.code()))
 
 
 def multimlp(X, segs, gamma, beta, run_mean, run_var, chan, training=True, p_drop=0.0, momentum=0.1, eps=1e-5):
@@ -562,6 +632,7 @@ class _EdgeConv(Function):
     @staticmethod
     def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out_buf=None, grad_accum=None):
         lib = _lib.load()
+        prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         xp = _rows(xp)
         _lib.require_gpu(xp, W2d, gamma)
         W2d = W2d.contiguous()
@@ -586,7 +657,9 @@ class _EdgeConv(Function):
             xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
             _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, act, slope, int(training), graph.B, graph.N, C, Cout,
             graph.k, out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
-            bn_save.data_ptr(), _lib.ptr(Wd), ws, wsn, _lib.stream()), "mlsp_edgeconv_fwd_f32")
+            bn_save.data_ptr(), _lib.ptr(Wd), prec, ws, wsn, _lib.stream()), "mlsp_edgeconv_fwd_f32")
+        if _sel_record is not None or _sel_forced is not None:
+            _selection_hook(argsel)
         if out_buf is not None:
             out = out_buf.view_as(out_buf)      # a fresh alias: the Function's output, distinct from its (non-differentiable) input
         ctx.save_for_backward(xp, W2d, out, uv, msel, argsel, s1, bn_save, Wd)
@@ -619,7 +692,7 @@ class _EdgeConv(Function):
             dOut.data_ptr(), dOut.stride(0), xp.data_ptr(), xp.stride(0), graph.rev_off.data_ptr(), graph.rev_ent.data_ptr(),
             W2d.data_ptr(), out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
             bn_save.data_ptr(), _lib.ptr(Wd), act, slope, int(training), graph.B, graph.N, C, Cout, graph.k, _lib.ptr(dx),
-            dx.stride(0) if dx is not None else C, accumulate, dW.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn,
+            dx.stride(0) if dx is not None else C, accumulate, dW.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn,
             _lib.stream()), "mlsp_edgeconv_bwd_f32")
         return (dx, dW, dgamma, dbeta) + (None,) * 10
 
@@ -636,6 +709,7 @@ class _TnetEdge(Function):
     @staticmethod
     def forward(ctx, xp, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, graph, training, slope, momentum, eps):
         lib = _lib.load()
+        prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         xp = _rows(xp)
         _lib.require_gpu(xp, W1, W2)
         W1, W2 = W1.contiguous(), W2.contiguous()
@@ -655,7 +729,9 @@ class _TnetEdge(Function):
             xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W1.data_ptr(), g1.data_ptr(), b1.data_ptr(), _lib.ptr(rm1),
             _lib.ptr(rv1), W2.data_ptr(), g2.data_ptr(), b2.data_ptr(), _lib.ptr(rm2), _lib.ptr(rv2), momentum, eps, slope,
             int(training), graph.B, graph.N, C, C1, C2, graph.k, out.data_ptr(), uv.data_ptr(), s1.data_ptr(), bn1.data_ptr(),
-            zsel.data_ptr(), argsel.data_ptr(), bn2.data_ptr(), ws, wsn, _lib.stream()), "mlsp_tnet_edge_fwd_f32")
+            zsel.data_ptr(), argsel.data_ptr(), bn2.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_tnet_edge_fwd_f32")
+        if _sel_record is not None or _sel_forced is not None:
+            _selection_hook(argsel)
         ctx.save_for_backward(xp, W1, W2, out, uv, s1, bn1, zsel, argsel, bn2)
         ctx.cfg = (graph, training, slope, C, C1, C2)
         return out
@@ -683,7 +759,7 @@ class _TnetEdge(Function):
             _lib.ptr(graph.rev_ent), W1.data_ptr(), W2.data_ptr(), out.data_ptr(), uv.data_ptr(), s1.data_ptr(), bn1.data_ptr(),
             zsel.data_ptr(), argsel.data_ptr(), bn2.data_ptr(), slope, int(training), graph.B, graph.N, C, C1, C2, graph.k,
             _lib.ptr(dx), dW1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
-            ws, wsn, _lib.stream()), "mlsp_tnet_edge_bwd_f32")
+            ctx.prec, ws, wsn, _lib.stream()), "mlsp_tnet_edge_bwd_f32")
         return (dx, dW1, dg1, db1, None, None, dW2, dg2, db2) + (None,) * 7
 
 
@@ -732,6 +808,7 @@ class _PointMLP(Function):
     def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,
                 momentum, eps, grad_accum=None, out_bf16=False, in_bn=None, in_cfg=None, defer_out=False, grad_cols=None):
         lib = _lib.load()
+        prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         X = _rows(X, allow_bf16=True)
         ctx.grad_cols = grad_cols
         _lib.require_gpu(X, W)
@@ -744,7 +821,7 @@ class _PointMLP(Function):
         has_bn = gamma is not None
         x_bf16 = X.dtype == torch.bfloat16
         mx = x_bf16 or out_bf16            # bf16 activation storage on either side of this layer (mlsp_pointmlp_*_mx)
-        if mx and not (has_bn and lib.mlsp_pointmlp_mx_supported(M, Cin, Cout, X.stride(0), int(x_bf16), int(training))):
+        if mx and not (has_bn and lib.mlsp_pointmlp_mx_supported(M, Cin, Cout, X.stride(0), int(x_bf16), int(training), prec)):
             if x_bf16:
                 raise RuntimeError("pointmlp: bf16 input on a layer the bf16-storage kernels do not cover (M=%d Cin=%d Cout=%d)" % (M, Cin, Cout))
             mx = out_bf16 = False
@@ -765,20 +842,20 @@ class _PointMLP(Function):
             _lib.check(lib.mlsp_pointmlp_fwd_mx(
                 X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
                 int(rows_per_group), gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
-                int(training), act, slope, p, seed, Y.data_ptr(), Z.data_ptr(), int(out_bf16), bn_save.data_ptr(), ws, wsn,
+                int(training), act, slope, p, seed, Y.data_ptr(), Z.data_ptr(), int(out_bf16), bn_save.data_ptr(), prec, ws, wsn,
                 _lib.stream()), "mlsp_pointmlp_fwd_mx")
         elif in_bn is not None:
             iact, islope, ip, iseed = in_cfg
             _lib.check(lib.mlsp_pointmlp_fwd_chain_f32(
                 X.data_ptr(), X.stride(0), in_bn.data_ptr(), iact, islope, ip, iseed, M, Cin, W.data_ptr(), W.stride(0), Cout,
                 _lib.ptr(bias), _lib.ptr(gbias), int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean),
-                _lib.ptr(run_var), momentum, eps, int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), ws, wsn,
+                _lib.ptr(run_var), momentum, eps, int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), prec, ws, wsn,
                 _lib.stream()), "mlsp_pointmlp_fwd_chain_f32")
         else:
             _lib.check(lib.mlsp_pointmlp_fwd_f32(
                 X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
                 int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
-                int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), ws, wsn, _lib.stream()),
+                int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_fwd_f32")
         ctx.in_bn, ctx.in_cfg = in_bn, in_cfg
         ctx.save_for_backward(X, W, Y, bn_save)
@@ -827,20 +904,20 @@ class _PointMLP(Function):
             _lib.check(lib.mlsp_pointmlp_bwd_mx(
                 dZ.data_ptr(), X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, Y.data_ptr(),
                 int(out_bf16), bn_save.data_ptr(), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
-                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()),
+                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_mx")
         elif ctx.in_bn is not None:
             iact, islope, ip, iseed = ctx.in_cfg
             _lib.check(lib.mlsp_pointmlp_bwd_chain_f32(
                 dZ.data_ptr(), X.data_ptr(), X.stride(0), ctx.in_bn.data_ptr(), iact, islope, ip, iseed, M, Cin, W.data_ptr(), W.stride(0),
                 Cout, _lib.ptr(Y), _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
-                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
+                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ctx.prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_chain_f32")
         else:
             _lib.check(lib.mlsp_pointmlp_bwd_f32(
                 dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
                 _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate, dW.data_ptr(),
-                _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ws, wsn, _lib.stream()),
+                _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ctx.prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_f32")
         return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 16
 
@@ -854,7 +931,7 @@ def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, 
     seed = _next_seed() if (training and p_drop > 0) else 0
     if (not isinstance(X, DeferredAct) and X.dtype == torch.bfloat16 and not (
             gamma is not None and X.dim() == 2 and X.stride(1) == 1 and
-            _lib.load().mlsp_pointmlp_mx_supported(X.shape[0], X.shape[1], W.shape[0], X.stride(0), 1, int(training)))):
+            _lib.load().mlsp_pointmlp_mx_supported(X.shape[0], X.shape[1], W.shape[0], X.stride(0), 1, int(training), gemm_precision.code()))):
         # the producer stored its output as bf16 (its own shape allowed it) but THIS layer's shape is outside the bf16-storage
         # kernels (e.g. a consumer whose GEMM splits K): widen once and run the fp32 layer; autograd narrows the gradient again
         X = X.float()
@@ -876,6 +953,7 @@ class _PointMLPColMax(Function):
     @staticmethod
     def forward(ctx, X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps, grad_accum=None):
         lib = _lib.load()
+        prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         ctx.grad_accum = grad_accum
         X = X.contiguous()
         _lib.require_gpu(X, W)
@@ -893,7 +971,9 @@ class _PointMLPColMax(Function):
         _lib.check(lib.mlsp_pointmlp_colmax_fwd_f32(
             X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, gamma.data_ptr(), beta.data_ptr(),
             _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, int(training), act, slope, out.data_ptr(), ysel.data_ptr(),
-            arg.data_ptr(), bn_save.data_ptr(), ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_fwd_f32")
+            arg.data_ptr(), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_fwd_f32")
+        if _sel_record is not None or _sel_forced is not None:
+            _selection_hook(arg)
         ctx.save_for_backward(X, W, out, ysel, arg, bn_save)
         ctx.cfg = (B, N, training, act, slope)
         return out
@@ -921,7 +1001,7 @@ class _PointMLPColMax(Function):
         _lib.check(lib.mlsp_pointmlp_colmax_bwd_f32(
             dOut.data_ptr(), X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, out.data_ptr(),
             ysel.data_ptr(), arg.data_ptr(), bn_save.data_ptr(), int(training), act, slope, _lib.ptr(dX), accumulate, dW.data_ptr(),
-            dgamma.data_ptr(), dbeta.data_ptr(), ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_bwd_f32")
+            dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_bwd_f32")
         return (dX, dW, dgamma, dbeta) + (None,) * 10
 
 
@@ -973,6 +1053,7 @@ class _PointMLPSegMax(Function):
     @staticmethod
     def forward(ctx, X, W, bias, gamma, beta, run_mean, run_var, k, training, act, slope, momentum, eps):
         lib = _lib.load()
+        prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         X = _rows(X)
         _lib.require_gpu(X, W)
         if W.stride(1) != 1:
@@ -990,7 +1071,7 @@ class _PointMLPSegMax(Function):
         _lib.check(lib.mlsp_pointmlp_segmax_fwd_f32(X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias),
                                                     gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean), _lib.ptr(run_var), float(momentum),
                                                     float(eps), int(training), int(act), float(slope), int(k), Y.data_ptr(), out.data_ptr(),
-                                                    ysel.data_ptr(), argk.data_ptr(), bn_save.data_ptr(), ws, wsn, _lib.stream()),
+                                                    ysel.data_ptr(), argk.data_ptr(), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()),
                    "mlsp_pointmlp_segmax_fwd_f32")
         ctx.save_for_backward(X, W, Y, ysel, argk, bn_save)
         ctx.cfg = (int(k), bool(training), int(act), float(slope), bias is not None)
@@ -1015,7 +1096,7 @@ class _PointMLPSegMax(Function):
         _lib.check(lib.mlsp_pointmlp_segmax_bwd_f32(dOut.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout,
                                                     Y.data_ptr(), ysel.data_ptr(), argk.data_ptr(), bn_save.data_ptr(), int(training), act, slope,
                                                     k, _lib.ptr(dX), Cin, dW.data_ptr(), _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(),
-                                                    ws, wsn, _lib.stream()), "mlsp_pointmlp_segmax_bwd_f32")
+                                                    ctx.prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_segmax_bwd_f32")
         return dX, dW, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
@@ -1298,5 +1379,5 @@ def gemm(A, B, ta=False, tb=False, bias=None):
     C = torch.empty((M, N), dtype=torch.float32, device=A.device)
     ws, wsn = _lib.workspace(A.device, max(M, 1), max(K, 1), max(N, 1))
     _lib.check(lib.mlsp_gemm_f32(int(ta), int(tb), M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0),
-                                 C.data_ptr(), N, _lib.ptr(bias), ws, wsn, _lib.stream()), "mlsp_gemm_f32")
+                                 C.data_ptr(), N, _lib.ptr(bias), gemm_precision.code(), ws, wsn, _lib.stream()), "mlsp_gemm_f32")
     return C

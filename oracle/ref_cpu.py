@@ -53,6 +53,7 @@ class _Ctx:
         self.knn_fn = knn_fn
         self.new_buffers = {}
         self.knn_idx = []
+        self.sel = []          # arg-max of every max-pool, in call order (tests: mlsp_amd.functional.forced_selections)
         self.feats = {}
 
     def bn(self, y, prefix, reduce_dims):
@@ -78,6 +79,18 @@ class _Ctx:
             mean, var = self.p[prefix + ".running_mean"], self.p[prefix + ".running_var"]
         yhat = (y - mean.view(shape)) / torch.sqrt(var.view(shape) + BN_EPS)
         return yhat * g.view(shape) + b.view(shape)
+
+    def max_k(self, x):
+        """max over the k neighbours of [B, C, N, k]; records the winning slot as [B*N, C] (the HIP path's point-major layout)"""
+        v, a = x.max(dim=-1)
+        self.sel.append(a.permute(0, 2, 1).reshape(-1, a.shape[1]))
+        return v
+
+    def max_n(self, x):
+        """max over the N points of [B, C, N]; records the winning point (local to its cloud) as [B, C]"""
+        v, a = x.max(dim=2)
+        self.sel.append(a)
+        return v
 
     def drop(self, x):
         if self.training and self.dropout_p > 0:
@@ -110,9 +123,9 @@ def _transform_net(c, x0, prefix="input_transform_net"):
     """transform_net.forward (model_utils.py:108-127), dgcnn branch."""
     x = _conv2d_bn_lrelu(c, x0, prefix + ".conv2d1")
     x = _conv2d_bn_lrelu(c, x, prefix + ".conv2d2")
-    x = x.max(dim=-1, keepdim=True)[0]
+    x = c.max_k(x).unsqueeze(-1)
     x = _conv2d_bn_lrelu(c, x, prefix + ".conv2d3")
-    x = x.max(dim=2)[0].reshape(x.shape[0], -1)
+    x = c.max_n(x[..., 0]).reshape(x.shape[0], -1)
     x = _fc_bn_act(c, x, prefix + ".fc1")
     x = _fc_bn_act(c, x, prefix + ".fc2")
     x = x @ c.p[prefix + ".fc3.weight"].t() + c.p[prefix + ".fc3.bias"]
@@ -172,12 +185,12 @@ def dgcnn_forward(params, x, training=True, dropout_p=0.0, k=K_DEFAULT, knn_fn=k
     feats = []
     h = xt
     for name in ("conv1", "conv2", "conv3", "conv4"):
-        h = _conv2d_bn_lrelu(c, graph(h), name).max(dim=-1)[0]
+        h = c.max_k(_conv2d_bn_lrelu(c, graph(h), name))
         feats.append(h)
     x_cat = torch.cat(feats, dim=1)
     c.feats["x_cat"] = x_cat
     x5 = F.leaky_relu(c.bn(_conv1d(c, x_cat, "conv5.weight"), "bn5", (0, 2)), 0.2)
-    x5 = x5.max(dim=2)[0]
+    x5 = c.max_n(x5)
     logits = {"cls": _classifier(c, x5)}
     if visualization:
         out = x5

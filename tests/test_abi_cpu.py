@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
         import ctypes
         for kind, ct in zip(kinds, _lib.SIGNATURES[name]):
             assert (ct is ctypes.c_void_p) == (kind == "p"), (name, args)
-    assert lib.mlsp_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.mlsp_abi_version() == _lib.ABI_VERSION == 8
     assert b"workspace" in lib.mlsp_strerror(-2)
     assert lib.mlsp_workspace_bytes(32768, 512, 1024) > 32768 * 1024 * 4
 
@@ -92,7 +92,9 @@ def test_missing_library_fails_loudly(monkeypatch):
 def test_no_register_spills_in_hot_kernels():
     """The Makefile leaves per-kernel resource remarks next to the objects: no kernel of the hot path may spill VGPRs or
     use scratch (a spilling kernel runs 5-20x slower on gfx950).  No exceptions (the round-1 list-merge kNN that spilled at
-    k = 40 is deleted)."""
+    k = 40 is deleted).  SGPR spills are a different thing on gfx950 -- the compiler parks scalars in lanes of a VGPR
+    (v_writelane_b32 / v_readlane_b32, no memory traffic: ScratchSize stays 0, which is asserted) -- and the tile kernels with a dozen
+    buffer descriptors and pre-computed scalar offsets all have some; test_sgpr_spills_stay_out_of_the_hot_loops bounds them."""
     import glob, re
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "..", "mlsp_amd", "csrc", "build", "*.remarks")))
@@ -109,6 +111,39 @@ def test_no_register_spills_in_hot_kernels():
             if int(s) or int(c):
                 bad.append((os.path.basename(f), n, int(s), int(c)))
     assert not bad, bad
+
+
+# kernel family -> ceiling of "SGPRs Spill" (the figures of the round-4 build plus a margin).  A scalar spill is a v_writelane / v_readlane
+# pair into a spare VGPR, never memory; what would hurt is a reload inside a K loop, so the ceilings are held where they were measured
+# harmless: gemm_split_kernel's K-tile body (gemm_split_body_wm*.inc) addresses everything through loop-invariant descriptors and
+# immediate offsets, and DESIGN.md section 10 lists the readlane count of the loop bodies.
+SGPR_SPILL_CEILING = {"gemm_split_kernel": 64, "gemm_f32_kernel": 64, "gemm_bf16_kernel": 64, "edge_reduce_lds_kernel": 180,
+                      "knn_mfma5_kernel": 220, "knn_mfma4_kernel": 96, "knn_kernel": 300, "knn_query_kernel": 80,
+                      "tnet_edge_fwd2_kernel": 96, "tnet_edge_fwd3_kernel": 96, "tnet_edge_bwdg_kernel": 112}
+
+
+def test_sgpr_spills_stay_bounded():
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "..", "mlsp_amd", "csrc", "build", "*.remarks")))
+    if not files:
+        pytest.skip("library not built here (build/*.remarks absent)")
+    over, seen = [], set()
+    for f in files:
+        txt = open(f).read()
+        names = re.findall(r"Function Name: (\S+)", txt)
+        spills = re.findall(r"SGPRs Spill: (\d+)", txt)
+        assert len(names) == len(spills)
+        for n, s in zip(names, spills):
+            fam = next((k for k in SGPR_SPILL_CEILING if re.search(r"\d" + k + r"I", n)), None)
+            if int(s) and fam is None:
+                over.append((n, int(s), "no ceiling recorded"))
+            elif fam is not None:
+                seen.add(fam)
+                if int(s) > SGPR_SPILL_CEILING[fam]:
+                    over.append((n, int(s), SGPR_SPILL_CEILING[fam]))
+    assert not over, over
+    assert {"gemm_split_kernel", "edge_reduce_lds_kernel"} <= seen
 
 
 def test_forward_bookkeeping_is_per_thread():
@@ -157,8 +192,63 @@ def test_forward_bookkeeping_is_per_thread():
         assert int(r.bn.num_batches_tracked) == 50 and int(r.inner.bn.num_batches_tracked) == 50
 
 
+def test_no_process_wide_dispatch_state_in_the_library():
+    """the compute entry points hold no global mutable state.  The GEMM product mode is an ARGUMENT of every entry point that
+    reaches the matrix cores (ABI v8): the v7 switch is neither exported nor present in the sources, and no file-scope mutable `g_*`
+    variable takes part in dispatch (the only process-wide objects are the measurement hook's event tables in gemm.hip)."""
+    import ctypes, glob
+    from mlsp_amd import _lib
+    lib = _lib.load()
+    assert not hasattr(lib, "mlsp_set_gemm_precision")
+    protos = _header_prototypes()
+    with_prec = [n for n, (_, _, args) in protos.items() if re.search(r"\bint precision\b", args)]
+    assert len(with_prec) == 19, sorted(with_prec)
+    for n in ("mlsp_gemm_f32", "mlsp_pointmlp_fwd_f32", "mlsp_pointmlp_bwd_f32", "mlsp_edgeconv_fwd_f32", "mlsp_tnet_edge_fwd_f32",
+              "mlsp_multimlp_fwd_f32", "mlsp_pointmlp_colmax_bwd_f32"):
+        assert n in with_prec, n
+    bad = []
+    for f in glob.glob(os.path.join(ROOT, "mlsp_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mlsp_amd", "csrc", "*.h")):
+        for i, line in enumerate(open(f), 1):
+            if re.match(r"\s*static\s+(?!const|constexpr|inline|__device__|__global__|thread_local)[^()=;]*\bg_\w+\s*(=|;)", line):
+                bad.append((os.path.basename(f), i, line.strip()))
+    assert not bad, bad
+    # a bad mode is an argument error, not a silent default
+    assert lib.mlsp_gemm_f32(0, 0, 8, 8, 8, None, 8, None, 8, None, 8, None, 7, None, 0, None) == -1
+
+
+def test_gemm_precision_is_per_thread_and_saved_per_call():
+    """`with gemm_precision(m)` changes what THIS thread's forwards pass; another thread keeps the process default; set() moves the default."""
+    import threading
+    from mlsp_amd import functional as Fh
+    seen = {}
+    ev_in, ev_out = threading.Event(), threading.Event()
+
+    def other():
+        ev_in.wait(10)
+        seen["other"] = (Fh.gemm_precision.current, Fh.gemm_precision.code())
+        ev_out.set()
+    t = threading.Thread(target=other)
+    t.start()
+    base = Fh.gemm_precision.current
+    with Fh.gemm_precision("fp32"):
+        assert Fh.gemm_precision.current == "fp32" and Fh.gemm_precision.code() == 0
+        with Fh.gemm_precision("bf16"):
+            assert Fh.gemm_precision.code() == 1
+            ev_in.set()
+            ev_out.wait(10)
+        assert Fh.gemm_precision.current == "fp32"
+    t.join()
+    assert Fh.gemm_precision.current == base
+    assert seen["other"] == (base, Fh._lib.GEMM_PRECISION_MODES[base])
+    Fh.gemm_precision.set("fp32")
+    try:
+        assert Fh.gemm_precision.current == "fp32"
+    finally:
+        Fh.gemm_precision.set(base)
+
+
 def test_gemm_precision_default_and_env_override():
-    """The Python mirror starts the library in "bf16x6" (fp32-accurate split products); MLSP_GEMM_PRECISION overrides the process default and
+    """The Python mirror passes "bf16x6" (fp32-accurate split products) unless told otherwise; MLSP_GEMM_PRECISION overrides the process default and
     an unknown name fails at import, loudly."""
     import subprocess, sys
     from mlsp_amd import _lib, functional as Fh

@@ -247,6 +247,50 @@ def test_gemm_split_short_k_stays_on_fp32_kernel(dev):
         assert torch.equal(got, want), (M, N, K)
 
 
+def test_precision_is_per_call_two_threads_and_late_backward(dev):
+    """ABI v8: the product mode is an argument of each call, not a library switch.  (1) Two threads that run layers in DIFFERENT modes at
+    the same time (own streams, 40 interleaved rounds) get bit for bit what each mode gives alone.  (2) A backward that runs after its
+    `with gemm_precision(...)` block has exited uses the forward's products (the mode travels in the autograd context)."""
+    import threading
+    Fh = _fh()
+    M, Cin, Cout = 8192, 256, 256
+    X = _rand((M, Cin), 31).to(dev)
+    W = _rand((Cout, Cin), 32).to(dev)
+    gamma, beta = (_rand((Cout,), 33).abs() + 0.5).to(dev), _rand((Cout,), 34).to(dev)
+
+    def layer(mode, stream=None):
+        xs, ws = X.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            with Fh.gemm_precision(mode):
+                z = Fh.pointmlp(xs, ws, gamma=gamma, beta=beta, training=True, act=Fh.ACT_RELU)
+                c = Fh.gemm(X, W, False, True)
+            z.square().sum().backward()            # outside the block: the context's mode decides, not the thread's current one
+            torch.cuda.current_stream().synchronize()
+        return z.detach(), c, xs.grad, ws.grad
+
+    alone = {m: layer(m) for m in ("fp32", "bf16x6")}
+    assert not torch.equal(alone["fp32"][0], alone["bf16x6"][0]) and not torch.equal(alone["fp32"][3], alone["bf16x6"][3])
+    errs, barrier = [], threading.Barrier(2)
+
+    def worker(mode):
+        try:
+            st = torch.cuda.Stream()
+            for _ in range(40):
+                barrier.wait(30)
+                got = layer(mode, st)
+                for a, b in zip(got, alone[mode]):
+                    assert torch.equal(a, b), mode
+        except Exception as e:                      # noqa: BLE001
+            errs.append((mode, repr(e)))
+            barrier.abort()
+    ts = [threading.Thread(target=worker, args=(m,)) for m in ("fp32", "bf16x6")]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert Fh.gemm_precision.current == Fh._lib.DEFAULT_GEMM_PRECISION
+
+
 # ----------------------------------------------------------------------------- bf16 activation storage (configs[4])
 class _RoundBF16(torch.autograd.Function):
     """x -> bf16(x) with a straight-through gradient: where the storage-mode kernels round, the emulation rounds."""

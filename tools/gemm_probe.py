@@ -30,7 +30,7 @@ def time_lib(path):
     lib = ctypes.CDLL(path)
     P = ctypes.c_void_p
     I = ctypes.c_int
-    lib.mlsp_gemm_f32.argtypes = [I, I, I, I, I, P, I, P, I, P, I, P, P, ctypes.c_size_t, P]
+    lib.mlsp_gemm_f32.argtypes = [I, I, I, I, I, P, I, P, I, P, I, P, I, P, ctypes.c_size_t, P]
     dev = torch.device("cuda:0")
     ws = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
@@ -41,7 +41,7 @@ def time_lib(path):
         C = torch.empty(M, N, device=dev)
         def run():
             rc = lib.mlsp_gemm_f32(ta, tb, M, N, K, A.data_ptr(), A.shape[1], B.data_ptr(), B.shape[1], C.data_ptr(), N, None,
-                                   ws.data_ptr(), ws.numel(), st)
+                                   int(os.environ.get('GEMM_PRECISION_CODE', '2')), ws.data_ptr(), ws.numel(), st)
             assert rc == 0, rc
         for _ in range(3): run()
         torch.cuda.synchronize()

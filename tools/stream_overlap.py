@@ -4,7 +4,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from mlsp_amd import _lib
+from mlsp_amd import _lib, functional as Fh
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
@@ -18,7 +18,7 @@ def mk(ta, tb, M, N, K):
     ws = torch.empty(1 << 27, dtype=torch.uint8, device=dev)
     def run(stream):
         rc = lib.mlsp_gemm_f32(ta, tb, M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), N, None,
-                               ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream.cuda_stream))
+                               Fh.gemm_precision.code(), ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream.cuda_stream))
         assert rc == 0, rc
     return run
 

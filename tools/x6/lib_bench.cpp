@@ -7,8 +7,7 @@
 #include <vector>
 #include <cstring>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
-typedef int (*gemm_fn)(int, int, int, int, int, const float*, int, const float*, int, float*, int, const float*, void*, size_t, void*);
-typedef int (*prec_fn)(int);
+typedef int (*gemm_fn)(int, int, int, int, int, const float*, int, const float*, int, float*, int, const float*, int, void*, size_t, void*);   // ABI v8: precision is a per-call argument
 typedef size_t (*ws_fn)(int, int, int);
 struct Shape { const char* name; int ta, tb, M, N, K; };
 int main(int argc, char** argv) {
@@ -16,7 +15,6 @@ int main(int argc, char** argv) {
     void* h = dlopen(path, RTLD_NOW);
     if (!h) { printf("dlopen %s: %s\n", path, dlerror()); return 1; }
     gemm_fn gemm = (gemm_fn)dlsym(h, "mlsp_gemm_f32");
-    prec_fn prec = (prec_fn)dlsym(h, "mlsp_set_gemm_precision");
     ws_fn wsb = (ws_fn)dlsym(h, "mlsp_workspace_bytes");
     const Shape shapes[] = {
         {"conv5 fwd   NT", 0, 1, 32768, 1024, 512}, {"conv5 dgrad NN", 0, 0, 32768, 512, 1024}, {"conv5 wgrad TN", 1, 0, 1024, 512, 32768},
@@ -43,17 +41,15 @@ int main(int argc, char** argv) {
         double us[3] = {0, 0, 0};
         const int reps = argc > 2 ? atoi(argv[2]) : 20;
         for (int mode = 0; mode <= 2; ++mode) {
-            prec(mode);
             const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
-            for (int i = 0; i < 3; ++i) { int rc = gemm(s.ta, s.tb, s.M, s.N, s.K, dA, lda, dB, ldb, dC, s.N, nullptr, ws, wsz, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
+            for (int i = 0; i < 3; ++i) { int rc = gemm(s.ta, s.tb, s.M, s.N, s.K, dA, lda, dB, ldb, dC, s.N, nullptr, mode, ws, wsz, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, 0));
-            for (int i = 0; i < reps; ++i) gemm(s.ta, s.tb, s.M, s.N, s.K, dA, lda, dB, ldb, dC, s.N, nullptr, ws, wsz, nullptr);
+            for (int i = 0; i < reps; ++i) gemm(s.ta, s.tb, s.M, s.N, s.K, dA, lda, dB, ldb, dC, s.N, nullptr, mode, ws, wsz, nullptr);
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             us[mode] = ms * 1000.0 / reps;
         }
-        prec(0);
         printf("%s M=%6d N=%5d K=%6d   fp32 %7.1f us %6.1f TF | bf16x6 %7.1f us %6.1f TF   %.2fx | bf16 operands %7.1f us %6.1f TF\n", s.name, s.M, s.N, s.K, us[0],
                2.0 * s.M * s.N * s.K / us[0] * 1e-6, us[2], 2.0 * s.M * s.N * s.K / us[2] * 1e-6, us[0] / us[2], us[1], 2.0 * s.M * s.N * s.K / us[1] * 1e-6);
         fflush(stdout);
