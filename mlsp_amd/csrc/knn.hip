@@ -13,6 +13,7 @@
 #include "common.h"
 #include <type_traits>
 #include <math.h>
+#include <cstdlib>
 
 #define KNN_QB 64      // queries per workgroup
 #define KNN_TJ 32      // candidates per LDS tile per wave
@@ -1388,10 +1389,20 @@ static int launch_knn_k(hipStream_t st, const float* x, int ld, const float* xx,
     return mlsp_launch_status();
 }
 
-// xx_ws: [B*N] floats of workspace
-int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws) {
+bool knn6_supported(int B, int N, int C, int k);                       // knn6.hip
+size_t knn6_plane_bytes(int P, int C);
+int launch_knn6(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, void* planes);
+
+// xx_ws: [B*N] floats of workspace; planes (nullable): knn6_plane_bytes(B*N, C) bytes of workspace for the v6 kernel's bf16 images
+int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws, void* planes, size_t plane_bytes) {
     if (!x || !idx || !xx_ws || B <= 0 || N <= 0 || C <= 0 || k <= 0 || k > N || ld < C) return MLSP_ERR_ARG;
     int P = B * N;
+    // v6 (knn6.hip): k <= 24 on whole 128-query chunks -- the five graph stages of DGCNN.  MLSP_KNN_V5=1: read-once A/B switch.
+    static const bool force_v5 = getenv("MLSP_KNN_V5") != nullptr;
+    if (!force_v5 && planes && knn6_supported(B, N, C, k) && plane_bytes >= knn6_plane_bytes(P, C) && (C > 16 || getenv("MLSP_KNN_V6_ALL"))) {   // (C <= 16 stays on v5 until v6's selection phases beat it there)
+        const int rc = launch_knn6(st, x, ld, B, N, C, k, idx, xx_ws, planes);
+        if (rc != MLSP_ERR_UNSUPPORTED) return rc;
+    }
     hipLaunchKernelGGL(sqnorm_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, C, xx_ws);
     // matrix-core kernels for every C <= 256 (the widest graph stage of the reference is 128 channels); beyond that only what the
     // VALU kernel's LDS tiles hold (C <= ~200 at k <= 40): MLSP_ERR_UNSUPPORTED otherwise

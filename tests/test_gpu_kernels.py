@@ -43,6 +43,9 @@ def _rand(shape, seed, scale=1.0):
                                      # k > 32 (configs[4]: k = 40): the two-pass select with 128 chunk maxima per query
                                      (2, 2048, 3, 40), (8, 2048, 64, 40), (3, 1024, 128, 40), (2, 512, 64, 33), (1, 256, 16, 48),
                                      (1, 128, 64, 64), (2, 2048, 64, 64), (2, 1024, 64, 25), (1, 384, 100, 40),
+                                     # v6 (knn6.hip: k <= 24, N % 128 == 0): fewest tiles, ragged tile-ring tails, k = 1 / 24, unaligned rows
+                                     (1, 128, 3, 1), (2, 128, 64, 24), (2, 256, 3, 24), (3, 384, 5, 20), (2, 1152, 64, 20), (1, 1152, 3, 20),
+                                     (2, 640, 33, 7), (1, 2048, 128, 24), (16, 128, 16, 20),
                                      # the VALU kernel: 32 < k <= 40 on shapes outside the two-pass kernel (ragged N, N < 128, 64 < C < 128, C > 128)
                                      (2, 150, 200, 40), (1, 96, 200, 36), (2, 100, 24, 33)])
 def test_knn_bit_exact_vs_oracle(dev, B, N, C, k):
@@ -77,6 +80,37 @@ def test_knn_duplicates_and_strided_input(dev):
     got = Fh.knn_graph(sl, 2, 128, 20).idx.view(2, 128, 20).cpu().numpy()
     want = knn_canon.knn_point_major(sl.cpu().contiguous().view(2, 128, 64), 20)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("C,scale", [(3, 1e-6), (64, 1e-6), (3, 3e-4), (128, 1e-5), (64, 0.0)])
+def test_knn_near_duplicates_need_exact_distances(dev, C, scale):
+    """v6 ranks survivors by split-bf16 distances and recomputes the canonical fp32 distance only where two survivors are closer than
+    the error bound.  Clouds made of 32 tight clusters (copies of a point + noise of 1e-6 .. 3e-4, or exact copies) put MANY candidates
+    inside that bound -- some queries overflow their survivor lists (exact path), the rest resolve dozens of ambiguous pairs per query:
+    indices must still be bit-exact."""
+    Fh = _fh()
+    B, N, k = 3, 512, 20
+    g = torch.Generator().manual_seed(77 + C)
+    centres = torch.rand(B, 32, C, generator=g) * 2 - 1
+    x = centres[:, torch.arange(N) % 32, :] + scale * torch.randn(B, N, C, generator=g)
+    want = knn_canon.knn_point_major(x, k)
+    got = Fh.knn_graph(x.view(B * N, C).to(dev), B, N, k).idx.view(B, N, k).cpu().numpy()
+    assert np.array_equal(got, want), "mismatching rows: %d" % int((got != want).any(-1).sum())
+
+
+def test_knn_nonfinite_rows_do_not_poison_the_others(dev):
+    """A point with an infinite coordinate makes every bound of its cloud infinite: the exact path decides, and the finite points still
+    get their canonical neighbours among the finite candidates (a NaN / inf distance is never selected, oracle/knn_canon.c)."""
+    Fh = _fh()
+    B, N, C, k = 2, 256, 3, 20
+    x = _rand((B, N, C), 91)
+    x[1, 7, 0] = float("inf")
+    want = knn_canon.knn_point_major(x, k)
+    got = Fh.knn_graph(x.view(B * N, C).to(dev), B, N, k).idx.view(B, N, k).cpu().numpy()
+    assert np.array_equal(got[0], want[0])
+    finite = np.ones(N, bool)
+    finite[7] = False
+    assert np.array_equal(got[1][finite], want[1][finite])
 
 
 @pytest.mark.parametrize("k", [20, 28, 40, 64])
@@ -253,7 +287,7 @@ def test_precision_is_per_call_two_threads_and_late_backward(dev):
     `with gemm_precision(...)` block has exited uses the forward's products (the mode travels in the autograd context)."""
     import threading
     Fh = _fh()
-    M, Cin, Cout = 8192, 256, 256
+    M, Cin, Cout = 32768, 256, 256        # (enough tiles that K is not split: the K = 256 loop then runs on the split kernel in mode "bf16x6")
     X = _rand((M, Cin), 31).to(dev)
     W = _rand((Cout, Cin), 32).to(dev)
     gamma, beta = (_rand((Cout,), 33).abs() + 0.5).to(dev), _rand((Cout,), 34).to(dev)
