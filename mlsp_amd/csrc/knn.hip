@@ -696,7 +696,7 @@ __device__ __forceinline__ u64 knn_key(float pd, int j) {
 // pd' >= tau', hence pd >= tau' - eps: tau = tau' - eps_q with eps_q = 2^-14 (xx_q + max_j xx_j) is still a proven bound (a NaN bound
 // becomes -inf: everything survives, the exact fallback sweep takes over).  A few more survivors reach pass B; the indices stay bit-exact.
 typedef __bf16 kbf16x8 __attribute__((ext_vector_type(8)));
-#define KNN5_EPS 6.103515625e-05f          // 2^-14
+#define KNN5_EPS 1.220703125e-04f           // 2^-13: worst-case budget of the split products + fp32 accumulation is 2^-13.9 (knn6.hip header)
 __device__ __forceinline__ void knn_split8(const float (&b)[8], kbf16x8& hi, kbf16x8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

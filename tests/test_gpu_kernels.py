@@ -98,6 +98,20 @@ def test_knn_near_duplicates_need_exact_distances(dev, C, scale):
     assert np.array_equal(got, want), "mismatching rows: %d" % int((got != want).any(-1).sum())
 
 
+@pytest.mark.parametrize("C,offset,B,N", [(64, 3.0, 4, 1024), (128, 1.5, 2, 1024), (64, 50.0, 2, 512), (3, 20.0, 2, 1024)])
+def test_knn_clouds_far_from_the_origin(dev, C, offset, B, N):
+    """Graph-stage features sit far from the origin compared with their spread (BatchNorm + LeakyReLU + max over k).  v6 sweeps the
+    cloud in coordinates relative to its first point (error of the split products ~ the centred norms) and budgets the canonical
+    arithmetic's own rounding on the raw coordinates separately; with a large offset the canonical fp32 distances are coarse (many exact
+    ties): indices must still be bit-exact."""
+    Fh = _fh()
+    k = 20
+    x = _rand((B, N, C), 300 + C) * 0.5 + offset
+    want = knn_canon.knn_point_major(x, k)
+    got = Fh.knn_graph(x.view(B * N, C).to(dev), B, N, k).idx.view(B, N, k).cpu().numpy()
+    assert np.array_equal(got, want), "mismatching rows: %d" % int((got != want).any(-1).sum())
+
+
 def test_knn_nonfinite_rows_do_not_poison_the_others(dev):
     """A point with an infinite coordinate makes every bound of its cloud infinite: the exact path decides, and the finite points still
     get their canonical neighbours among the finite candidates (a NaN / inf distance is never selected, oracle/knn_canon.c)."""
