@@ -579,10 +579,12 @@ def main():
                                 "compulsory bytes (C+k)*4 per point; the kernel is select-bound, not HBM-bound (DESIGN 4)"),
                   _kernel_entry("EdgeConv neighbour gather-reduce (edge_reduce_lds_kernel), 4 EdgeConv + T-Net conv1", "hbm", rows[4], prof_steps,
                                 "compulsory bytes: u half + indices in, msel + s1 + arg slot out; LDS-gather bound"),
-                  _kernel_entry("kNN C=64 (knn_mfma5_kernel<64>), stages 2-3", "mfma", rows[2], prof_steps,
-                                "algorithmic 2*N*C FLOP per point (one distance sweep; the kernel runs two)"),
-                  _kernel_entry("kNN C=128 (knn_mfma5_kernel<128>), stage 4", "mfma", rows[3], prof_steps,
-                                "algorithmic 2*N*C FLOP per point (one distance sweep; the kernel runs two)"),
+                  _kernel_entry("kNN C=64 (knn6_prep_kernel<64> + knn6_kernel<64>), stages 2-3", "mfma", rows[2], prof_steps,
+                                "algorithmic 2*N*C FLOP per point (one distance sweep) against the f32 MFMA peak; the kernel runs two split-bf16 "
+                                "sweeps (3 bf16 products each) and resolves only the ambiguous survivors in canonical fp32"),
+                  _kernel_entry("kNN C=128 (knn6_prep_kernel<128> + knn6_kernel<128>), stage 4", "mfma", rows[3], prof_steps,
+                                "algorithmic 2*N*C FLOP per point (one distance sweep) against the f32 MFMA peak; two split-bf16 sweeps + exact "
+                                "resolution of the ambiguous survivors"),
                   _kernel_entry("T-Net per-edge stage forward (tnet_edge_fwd3_kernel<20>: split products on the bf16 cores)", "mfma", rows[5], prof_steps,
                                 "2*E*64*128 algorithmic FLOP, priced against the f32 MFMA peak (the kernel executes 6x that on the bf16 cores)"),
                   _kernel_entry("T-Net per-edge stage backward (tnet_edge_bwdg_kernel + prep / slab reduce / finish)", "mfma", rows[6],

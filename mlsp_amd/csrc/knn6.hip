@@ -22,16 +22,23 @@
 //     Pass A: 64 running maxima per query (16 registers x 2 half-wave lanes x 2 candidate halves), tau = their k-th largest: at least k
 //     candidates have pd' >= tau, so the true k-th best is >= tau - E and every true neighbour has pd' >= tau - 2 E (X = the cloud's
 //     largest squared norm): pass B keeps exactly those (~1.4 k of N).
-//   * Exactness: a survivor whose pd' is farther than 2 E from every other survivor's (X = the largest norm among the query's
-//     survivors) has its rank decided by pd' alone: F1 counts, per survivor, the survivors ahead of it and those inside its 2 E window.
-//     The others (~10-20 %) get their canonical distance from an fmaf chain over the fp32 rows (lane per pair, batched per wave), then
-//     a recount under the full order (value desc, index asc) over lists that mix exact and approximate values -- safe, because an
-//     unambiguous value differs from every other by more than 2 E and an exact one from its approximation by at most E.
+//   * Coordinates: the sweeps run on x - x_first(cloud) (distances are translation invariant, the split products' error scales with the
+//     norms of what is multiplied); the canonical value's own rounding on the RAW coordinates is budgeted separately:
+//     E = 2^-13 (xc_q + Xc) + (C + 4) 2^-23 (xx_q + Xx), xc = centred, xx = raw squared norms.
+//   * Exactness: a survivor whose pd' is farther than 2 E from its neighbours in rank (Xc = the largest centred norm among the query's
+//     survivors) has its rank decided by pd' alone.  One lane per query sorts the query's <= 32 survivors in registers (bitonic network),
+//     flags the gaps within 2 E, the flagged (~10-40 %) get their canonical distance from an fmaf chain over the fp32 rows (pairs packed
+//     densely over the wave), and odd-even passes under the full order (value desc, index asc) settle the flagged runs -- safe, because
+//     an unflagged value differs from its neighbours by more than 2 E and an exact one from its approximation by at most E.  Queries
+//     with more than 32 survivors (or exact lists) take a counting path with the same logic.
 //   * Any list overflow (massive ties: more than 24 survivors in a quarter of a query's candidates) or NaN / inf bound sends the whole
 //     workgroup through an exact path: f32 MFMA tiles from the fp32 rows, per-lane sorted top-k lists in registers, the same final.
-// Measured (B = 32, N = 1024, k = 20, one call incl. the prep kernel): C = 64 78 us (v5 113), C = 128 104 us (v5 176); C = 3 60 us (v5 49:
-// the selection phases run one wave per SIMD here and dominate when the sweeps are trivial, so C <= 16 stays on v5).  Phase cycles per
-// wave at C = 64 (tools/knn6_stamps.py): sweeps 20 k + 43 k, tau 5 k, list conversion 9 k, F1 43 k, F2 10 k.
+// Measured on MI355X (B = 32, N = 1024, k = 20, one call incl. the prep kernel; uniform random clouds): C = 64 74 us (v5 113), C = 128 105 us
+// (v5 176), N = 2048 C = 64 95 us (v5 176); C = 3 54 us (v5 49: the selection phases dominate when the sweeps are trivial, so C <= 16 stays
+// on v5).  Inside the DGCNN step (features of a 3-D manifold: small gaps between neighbours relative to the norms, 2-3x more ambiguous
+// pairs): 89 / 129 us against 118 / 165.  Phase cycles per wave at C = 64, two waves per SIMD (tools/knn6_stamps.py): sweeps 17 k + 27 k,
+// tau 5.5 k, list conversion 5 k, sort / flag / settle 26 k, exact distances 16 k (bound by cache-line transactions: every 16-byte piece
+// of a gathered row is its own transaction; a cooperative fetch through LDS lost to its chain of dependent steps as written here).
 #include "common.h"
 #include <math.h>
 #include <type_traits>
@@ -47,7 +54,6 @@ typedef int k6i32x4 __attribute__((ext_vector_type(4)));
 #define K6_LSTR 232         // bytes between lists (58 dwords: 16 consecutive lists start in 16 different even banks)
 #define K6_XS 68            // floats per query of the tau exchange image (16-byte aligned rows, 4-bank skew)
 #define K6_EPS 1.220703125e-04f      // 2^-13 (error budget in the header)
-#define K6_WL 512           // items of a wave's work list of ambiguous survivors (4 bytes each)
 
 // byte offset of the 16-byte piece (point row of its tile, half h) of block kb, plane p (0 hi, 1 lo) of tile T
 __device__ __forceinline__ size_t k6_piece(size_t T, int nkb, int kb, int p, int h, int row) {
@@ -107,19 +113,20 @@ __device__ __forceinline__ void k6_static_for(F&& f) {
 // candidate beats list entry (value desc, index asc); false for a NaN candidate
 __device__ __forceinline__ bool k6_beats(float d, int j, float pv, int pi) { return d > pv || (d == pv && j < pi); }
 
-// Workgroup = 4 waves = 128 queries x all N candidates of their cloud.  Wave w: dg = w & 1 picks 64 queries (two 32-query groups A / B
-// that share every candidate fragment the wave loads: half the fragment traffic per MFMA, and group A's selection work runs under
-// group B's MFMAs), ch = w >> 1 the half of the candidates it sweeps.  One wave per SIMD (the register file is the prefetch buffer:
-// K6_PF tiles of fragments in flight per wave), no barrier inside a sweep.
+// Workgroup = 8 waves = 128 queries x all N candidates of their cloud.  Wave w: qg = w & 3 picks a group of 32 queries, ch = w >> 2 the
+// half of the candidates it sweeps: two waves per SIMD (the selection phases are vector-issue bound, and a lone wave issues at half rate),
+// no barrier inside a sweep.  (Two query groups per wave against the same fragments -- half the fragment traffic -- was built and measured:
+// the sweeps gain 10 %, every selection phase loses 2x at one wave per SIMD.)
 template <int CT>
-__global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float* __restrict__ x, int ld, const float* __restrict__ xx_all, const float* __restrict__ xc_all,
+__global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, int ld, const float* __restrict__ xx_all, const float* __restrict__ xc_all,
                                                    const char* __restrict__ planes, int N, int C, int k, int* __restrict__ idx, int B) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int NKB = CT / 16;                              // 16-channel blocks = bf16 MFMA K steps per tile
-    constexpr int PF = NKB >= 4 ? 2 : 4;        // tiles of fragments in flight (the ring holds PF * NKB blocks of 2 x 4 registers)
+    constexpr int PF = NKB >= 8 ? 1 : NKB >= 4 ? 2 : 4;      // tiles of fragments in flight (the ring holds PF * NKB blocks of 2 x 4 registers)
     constexpr int NR = PF * NKB;
+    constexpr int UNR = NKB >= 8 ? 2 : 8;                     // tiles per loop trip (see `sweep`; 4 at C = 128 costs two spilled registers)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // (scalar: addresses below stay in SGPRs)
-    const int l31 = lane & 31, h = lane >> 5, dg = wave & 1, ch = wave >> 1;
+    const int l31 = lane & 31, h = lane >> 5, qg = wave & 3, ch = wave >> 2;
     int b, chunk;
     xcd_cloud_map(blockIdx.x, N / 128, B, b, chunk);
     const float* xxb = xx_all + (size_t)b * N;                // canonical squared norms (raw coordinates)
@@ -128,14 +135,14 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
     const float* xb = x + (size_t)b * N * ld;
     const int nt2 = N / 64;                                   // 32-candidate tiles of this wave's half
 
-    char* lists = (char*)sm;                                  // [512 lists][K6_LSTR]; list = ((g*2 + ch)*2 + h)*32 + query of group g
+    char* lists = (char*)sm;                                  // [512 lists][K6_LSTR]; list = ((qg*2 + ch)*2 + h)*32 + query of the group
     float* xch = sm;                                          // tau exchange image [128 queries][K6_XS], dead before pass B
-    float* nxx = (float*)(lists + 512 * K6_LSTR);             // [N]  -xx_j / 2
+    float* nxx = (float*)(lists + 512 * K6_LSTR);             // [N]  -xc_j / 2
     float* tauv = nxx + N;                                    // [128]
     int* cnts = (int*)(tauv + 128);                           // [128 queries][4 quarters]
     float* red = (float*)(cnts + 512);                        // [16]
-    unsigned* wlbase = (unsigned*)(red + 16);                 // [4 waves][K6_WL] work lists of ambiguous survivors
-    float* lmn = (float*)(wlbase + 4 * K6_WL);                          // [128 queries][4 quarters] min of -xx_j / 2 over the list's survivors
+    unsigned* wlbase = (unsigned*)(red + 16);                 // [8 waves][512 words]: fast final: [16 queries][32] candidate / exact value of the ambiguous; slow final: work list
+    float* lmn = (float*)(wlbase + 8 * 512);                  // [128 queries][4 quarters] min of -xc_j / 2 over the list's survivors
     const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)sm);       // LDS byte address of `lists`
 
 #ifdef K6_STAMP
@@ -150,32 +157,30 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
     float xcmax, xxmax;
     {
         float m = 0.f, mr = 0.f;
-        for (int j = tid; j < N; j += 256) { const float v = xcb[j]; nxx[j] = -0.5f * v; m = fmaxf(m, v); mr = fmaxf(mr, xxb[j]); }
+        for (int j = tid; j < N; j += 512) { const float v = xcb[j]; nxx[j] = -0.5f * v; m = fmaxf(m, v); mr = fmaxf(mr, xxb[j]); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); mr = fmaxf(mr, __shfl_xor(mr, o, 64)); }
-        if (lane == 0) { red[wave] = m; red[4 + wave] = mr; }
+        if (lane == 0) { red[wave] = m; red[8 + wave] = mr; }
         __syncthreads();
-        xcmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        xxmax = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        xcmax = red[0]; xxmax = red[8];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { xcmax = fmaxf(xcmax, red[w]); xxmax = fmaxf(xxmax, red[8 + w]); }
     }
     // |pd' - pd_canonical| <= K6_EPS (xc_q + xc_j)  [split products on the centred coordinates, header]
     //                        + K6_CANON (xx_q + xx_j)  [the canonical value's own distance from -|x_q - x_j|^2: an fmaf chain of C terms, the two
     //                          norms and two more roundings on the RAW coordinates: < (C + 4) 2^-23 (xx_q + xx_j)]
     const float K6_CANON = (float)(C + 4) * 1.1920929e-07f;
-    const int gA = dg * 2, gB = dg * 2 + 1;                   // the wave's two query groups (of the workgroup's four)
-    const int qA0 = chunk * 128 + gA * 32;                    // first query of group A, local to the cloud; group B = + 32
-    const float xxqA = xxb[qA0 + l31], xxqB = xxb[qA0 + 32 + l31];          // raw (exact path)
-    const float xcqA = xcb[qA0 + l31], xcqB = xcb[qA0 + 32 + l31];          // centred (sweeps)
-    const float EqA = K6_EPS * (xcqA + xcmax) + K6_CANON * (xxqA + xxmax), EqB = K6_EPS * (xcqB + xcmax) + K6_CANON * (xxqB + xxmax);
+    const int q0 = chunk * 128 + qg * 32;                     // first query of this wave's group, local to the cloud
+    const float xxq = xxb[q0 + l31];                          // raw (exact path, canonical bound)
+    const float xcq = xcb[q0 + l31];                          // centred (sweeps)
+    const float Eq = K6_EPS * (xcq + xcmax) + K6_CANON * (xxq + xxmax);
 
     // ---------------------------------------------------------------------------------------------------------------- approximate sweeps
-    k6bf16x8 qhA[NKB], qlA[NKB], qhB[NKB], qlB[NKB];          // B operands: query row l31 of each group, channels 16 kb + 8 h .. + 7
+    k6bf16x8 qh[NKB], ql[NKB];                                // B operand: query row l31 of the group, channels 16 kb + 8 h .. + 7
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        qhA[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (qA0 >> 5), NKB, kb, 0, h, l31));
-        qlA[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (qA0 >> 5), NKB, kb, 1, h, l31));
-        qhB[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (qA0 >> 5) + 1, NKB, kb, 0, h, l31));
-        qlB[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (qA0 >> 5) + 1, NKB, kb, 1, h, l31));
+        qh[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (q0 >> 5), NKB, kb, 0, h, l31));
+        ql[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (q0 >> 5), NKB, kb, 1, h, l31));
     }
     const unsigned voff = (unsigned)(h * 512 + l31 * 16);     // this lane's 16 bytes inside a fragment KiB
     const char* cand0 = planes + (T0 + (size_t)ch * nt2) * (NKB * 2048);     // (uniform) first tile of this wave's half
@@ -184,40 +189,34 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
         ah = *(const k6bf16x8*)(p + voff);
         al = *(const k6bf16x8*)(p + 1024 + voff);
     };
-    // one sweep over the half: sel(accA, accB, tl) sees the finished 32 x 32 tiles of both groups:
-    // acc[r] = a(query l31 of the group, candidate (r & 3) + 8 (r >> 2) + 4 h of the tile)
+    // one sweep over the half: sel(acc, tl) sees the finished 32 x 32 tile: acc[r] = a(query l31, candidate (r & 3) + 8 (r >> 2) + 4 h of the tile).
     // Fragment ring: slot (tile % PF, block) is refilled right after its use with the tile PF ahead; a scheduling barrier after every
     // refill keeps the loads where they are written (the scheduler otherwise sinks them next to their use: prefetch distance zero).
     // The compiler drains the memory counter once per loop trip (its wait-count analysis merges pessimistically at the back edge), so a
     // trip covers UNR tiles: the drain exposes one L2 latency per UNR tiles of MFMA work.
-    constexpr int UNR = NKB >= 8 ? 4 : 8;
     auto sweep = [&](auto&& sel) {
         k6bf16x8 fh[NR], fl[NR];
         auto tile = [&](auto SLOT, auto RING, int tl, int tn, auto&& sel_) {  // tn: the tile that refills this ring slot (always loaded: no branch)
             constexpr int s0 = decltype(SLOT)::value * NKB;
             constexpr bool ring = decltype(RING)::value;
-            f32x16 accA, accB;
+            f32x16 acc;
             const float* p = nxx + (ch * nt2 + tl) * 32 + 4 * h;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = *(const f32x4*)(p + 8 * g);
-                accA[4 * g] = v[0]; accA[4 * g + 1] = v[1]; accA[4 * g + 2] = v[2]; accA[4 * g + 3] = v[3];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 v = *(const f32x4*)(p + 8 * g4);
+                acc[4 * g4] = v[0]; acc[4 * g4 + 1] = v[1]; acc[4 * g4 + 2] = v[2]; acc[4 * g4 + 3] = v[3];
             }
-            accB = accA;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s0 + kb], qhA[kb], accA, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s0 + kb], qhB[kb], accB, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s0 + kb], qhA[kb], accA, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s0 + kb], qhB[kb], accB, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s0 + kb], qlA[kb], accA, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s0 + kb], qlB[kb], accB, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s0 + kb], qh[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s0 + kb], qh[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s0 + kb], ql[kb], acc, 0, 0, 0);
                 if (ring) {
                     frag_load(tn, kb, fh[s0 + kb], fl[s0 + kb]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            sel_(accA, accB, tl);
+            sel_(acc, tl);
         };
         const int nmain = (nt2 / UNR) * UNR;
         if (nmain > 0) {
@@ -242,35 +241,31 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
     };
 
     K6_T(1);
-    // ---- pass A: 16 running maxima per lane and group (acc domain: a = dot' - xx_j / 2 is monotone in the distance for a fixed query)
+    // ---- pass A: 16 running maxima per lane (acc domain: a = dot' - xc_j / 2 is monotone in the distance for a fixed query)
     {
-        float cmA[16], cmB[16];
+        float cm[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { cmA[r] = -INFINITY; cmB[r] = -INFINITY; }
-        sweep([&](const f32x16& accA, const f32x16& accB, int) {
+        for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
+        sweep([&](const f32x16& acc, int) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { cmA[r] = fmaxf(cmA[r], accA[r]); cmB[r] = fmaxf(cmB[r], accB[r]); }
+            for (int r = 0; r < 16; ++r) cm[r] = fmaxf(cm[r], acc[r]);
         });
         K6_T(2);
-        float* dA = xch + (gA * 32 + l31) * K6_XS + (ch * 2 + h) * 16;
-        float* dB = xch + (gB * 32 + l31) * K6_XS + (ch * 2 + h) * 16;
+        float* dst = xch + (qg * 32 + l31) * K6_XS + (ch * 2 + h) * 16;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 va = {cmA[4 * g], cmA[4 * g + 1], cmA[4 * g + 2], cmA[4 * g + 3]};
-            const f32x4 vb = {cmB[4 * g], cmB[4 * g + 1], cmB[4 * g + 2], cmB[4 * g + 3]};
-            *(f32x4*)(dA + 4 * g) = va;
-            *(f32x4*)(dB + 4 * g) = vb;
-        }
+        for (int g4 = 0; g4 < 4; ++g4) { const f32x4 v = {cm[4 * g4], cm[4 * g4 + 1], cm[4 * g4 + 2], cm[4 * g4 + 3]}; *(f32x4*)(dst + 4 * g4) = v; }
     }
     __syncthreads();
 #if defined(K6_PROBE) && K6_PROBE == 1
     return;
 #endif
     K6_T(3);
-    // tau = k-th largest of a query's 64 maxima: one lane per query (wave w sorts group w with its first half-wave), bitonic network in registers
-    if (lane < 32) {
+    // tau = k-th largest of a query's 64 maxima: one lane per query (the ch = 0 wave of a group: one wave per SIMD; lanes 32-63 mirror), bitonic
+    // network in registers
+    if (ch == 0) {
+        const int qs = qg * 32 + l31;
         float v[64];
-        const float* src = xch + (wave * 32 + l31) * K6_XS;
+        const float* src = xch + qs * K6_XS;
 #pragma unroll
         for (int i4 = 0; i4 < 16; ++i4) {
             const f32x4 t = *(const f32x4*)(src + 4 * i4);
@@ -292,55 +287,47 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
         float t = v[0];
 #pragma unroll
         for (int i = 1; i < K6_KMAX; ++i) t = (i == k - 1) ? v[i] : t;
-        tauv[wave * 32 + l31] = t;
+        if (lane < 32) tauv[qs] = t;
     }
     __syncthreads();                                          // tau complete; the exchange image (aliases the lists) is dead from here on
 #if defined(K6_PROBE) && K6_PROBE == 2
     return;
 #endif
     K6_T(4);
-    float thrA = tauv[gA * 32 + l31] - EqA, thrB = tauv[gB * 32 + l31] - EqB;  // acc domain: pd' >= tau_pd - 2 E  <=>  a >= a_tau - E
-    thrA = thrA == thrA ? thrA : -INFINITY;                   // NaN bound: everything survives, the lists overflow, the exact path takes over
-    thrB = thrB == thrB ? thrB : -INFINITY;
+    float thr = tauv[qg * 32 + l31] - Eq;                     // acc domain: pd' >= tau_pd - 2 E  <=>  a >= a_tau - E
+    thr = thr == thr ? thr : -INFINITY;                       // NaN bound: everything survives, the lists overflow, the exact path takes over
 
-    // ---- pass B: survivors -> this lane's private lists (acc-domain value, candidate index); always stored at the cursor, kept when it moves on
-    char* LBA = lists + (size_t)((((gA * 2 + ch) * 2 + h) * 32 + l31) * K6_LSTR);
-    char* LBB = lists + (size_t)((((gB * 2 + ch) * 2 + h) * 32 + l31) * K6_LSTR);
+    // ---- pass B: survivors -> this lane's private list (acc-domain value, candidate index)
     // per pair: v_cmpx (exec = survivors) / ds_write2_b32 {value, index} at the cursor / cursor += 8 under that mask / exec back to all lanes:
     // three vector instructions and no branch; the cursor is clamped every 4 appends (lists have 4 entries of slack).
-    const unsigned baseA = lds0 + (unsigned)((((gA * 2 + ch) * 2 + h) * 32 + l31) * K6_LSTR);
-    const unsigned baseB = lds0 + (unsigned)((((gB * 2 + ch) * 2 + h) * 32 + l31) * K6_LSTR);
-    unsigned adA = baseA, adB = baseB, topA = baseA, topB = baseB;
-    sweep([&](const f32x16& accA, const f32x16& accB, int tl) {
+    char* LB = lists + (size_t)((((qg * 2 + ch) * 2 + h) * 32 + l31) * K6_LSTR);
+    const unsigned base = lds0 + (unsigned)((((qg * 2 + ch) * 2 + h) * 32 + l31) * K6_LSTR);
+    unsigned ad = base, top = base;
+    sweep([&](const f32x16& acc, int tl) {
         const int jb = (ch * nt2 + tl) * 32 + 4 * h;
         int jv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) jv[r] = jb + (r & 3) + 8 * (r >> 2);
         // The compiler does not place the MFMA -> VALU / LDS read wait states for instructions INSIDE an asm statement: a visible VALU read of
-        // each accumulator (gate) comes first -- the hazard recognizer pads in front of it -- and every append depends on the gate.
-        const float gateA = fmaxf(accA[0], accA[15]), gateB = fmaxf(accB[0], accB[15]);
+        // the accumulator (gate) comes first -- the hazard recognizer pads in front of it -- and every append depends on the gate.
+        const float gate = fmaxf(acc[0], acc[15]);
 #define K6_APPEND(ad_, val_, thr_, j_, gate_) asm volatile("v_cmpx_ge_f32_e32 vcc, %1, %2\n\tds_write2_b32 %0, %1, %3 offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, -1" \
                                                            : "+v"(ad_) : "v"(val_), "v"(thr_), "v"(j_), "v"(gate_) : "vcc", "memory")
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            K6_APPEND(adA, accA[r], thrA, jv[r], gateA);
-            if ((r & 3) == 3) { topA = max(topA, adA); adA = min(adA, baseA + K6_CAP * 8); }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            K6_APPEND(adB, accB[r], thrB, jv[r], gateB);
-            if ((r & 3) == 3) { topB = max(topB, adB); adB = min(adB, baseB + K6_CAP * 8); }
+            K6_APPEND(ad, acc[r], thr, jv[r], gate);
+            if ((r & 3) == 3) { top = max(top, ad); ad = min(ad, base + K6_CAP * 8); }
         }
 #undef K6_APPEND
     });
-    int cntA = (int)(adA - baseA) >> 3, cntB = (int)(adB - baseB) >> 3;
-    const int ovf = (topA > baseA + K6_CAP * 8 || topB > baseB + K6_CAP * 8) ? K6_CAP + 1 : 0;
+    int cnt = (int)(ad - base) >> 3;
+    const int ovf = (top > base + K6_CAP * 8) ? 1 : 0;
     K6_T(5);
     bool exact_lists = false;
-    if (__syncthreads_or(ovf > K6_CAP ? 1 : 0)) {
+    if (__syncthreads_or(ovf)) {
         // ------------------------------------------------------------------------------------------------------------ exact path (rare)
         // f32 MFMA tiles straight from the fp32 rows (same transposed layout; the MFMA chain is the canonical fmaf chain, channels
-        // ascending), every lane keeps the exact top-K6_KMAX of ITS quarter of the candidates in a sorted register list; group A, then B.
+        // ascending), every lane keeps the exact top-K6_KMAX of ITS quarter of the candidates in a sorted register list.
         const bool vec = (ld & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (C & 3) == 0;
         // fragment of 32 channels [c0, c0 + 32) of a row for the f32 MFMA: f[s] = row[c0 + 2 s + h], zero beyond C (16 K-steps of 2 channels)
         auto load_frag = [&](const float* row, int c0, float (&f)[16]) {
@@ -354,71 +341,62 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < 16; ++s) f[s] = (c0 + 2 * s + h < C) ? row[c0 + 2 * s + h] : 0.f;
+                for (int s_ = 0; s_ < 16; ++s_) f[s_] = (c0 + 2 * s_ + h < C) ? row[c0 + 2 * s_ + h] : 0.f;
             }
         };
-        for (int sg = 0; sg < 2; ++sg) {
-            const float* qrowp = xb + (size_t)(qA0 + 32 * sg + l31) * ld;
-            const float xxq = sg ? xxqB : xxqA;
-            float tv[K6_KMAX];
-            int ti[K6_KMAX];
+        const float* qrowp = xb + (size_t)(q0 + l31) * ld;
+        float tv[K6_KMAX];
+        int ti[K6_KMAX];
 #pragma unroll
-            for (int s = 0; s < K6_KMAX; ++s) { tv[s] = -INFINITY; ti[s] = 0x7fffffff; }
-            for (int tl = 0; tl < nt2; ++tl) {
-                const int j0 = (ch * nt2 + tl) * 32;
-                const float* crowp = xb + (size_t)(j0 + l31) * ld;
-                f32x16 acc;
+        for (int s_ = 0; s_ < K6_KMAX; ++s_) { tv[s_] = -INFINITY; ti[s_] = 0x7fffffff; }
+        for (int tl = 0; tl < nt2; ++tl) {
+            const int j0 = (ch * nt2 + tl) * 32;
+            const float* crowp = xb + (size_t)(j0 + l31) * ld;
+            f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                for (int c0 = 0; c0 < C; c0 += 32) {           // channels ascending: the canonical chain (query fragments re-read: rare path)
-                    float ca[16], qa[16];
-                    load_frag(crowp, c0, ca);
-                    load_frag(qrowp, c0, qa);
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int c0 = 0; c0 < C; c0 += 32) {               // channels ascending: the canonical chain (query fragments re-read: rare path)
+                float ca[16], qa[16];
+                load_frag(crowp, c0, ca);
+                load_frag(qrowp, c0, qa);
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[s], qa[s], acc, 0, 0, 0);
-                }
+                for (int s_ = 0; s_ < 16; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[s_], qa[s_], acc, 0, 0, 0);
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = j0 + 4 * h + (r & 3) + 8 * (r >> 2);
-                    const float xxj = xxb[j];                                // canonical norm of the raw row
-                    const float pd = fmaf(2.0f, acc[r], -xxj) - xxq;
-                    if (k6_beats(pd, j, tv[K6_KMAX - 1], ti[K6_KMAX - 1])) {
-                        bool bs[K6_KMAX];
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + 4 * h + (r & 3) + 8 * (r >> 2);
+                const float xxj = xxb[j];                                    // canonical norm of the raw row
+                const float pd = fmaf(2.0f, acc[r], -xxj) - xxq;
+                if (k6_beats(pd, j, tv[K6_KMAX - 1], ti[K6_KMAX - 1])) {
+                    bool bs[K6_KMAX];
 #pragma unroll
-                        for (int s = 0; s < K6_KMAX; ++s) bs[s] = k6_beats(pd, j, tv[s], ti[s]);
+                    for (int s_ = 0; s_ < K6_KMAX; ++s_) bs[s_] = k6_beats(pd, j, tv[s_], ti[s_]);
 #pragma unroll
-                        for (int s = K6_KMAX - 1; s > 0; --s) {
-                            tv[s] = bs[s - 1] ? tv[s - 1] : (bs[s] ? pd : tv[s]);
-                            ti[s] = bs[s - 1] ? ti[s - 1] : (bs[s] ? j : ti[s]);
-                        }
-                        tv[0] = bs[0] ? pd : tv[0];
-                        ti[0] = bs[0] ? j : ti[0];
+                    for (int s_ = K6_KMAX - 1; s_ > 0; --s_) {
+                        tv[s_] = bs[s_ - 1] ? tv[s_ - 1] : (bs[s_] ? pd : tv[s_]);
+                        ti[s_] = bs[s_ - 1] ? ti[s_ - 1] : (bs[s_] ? j : ti[s_]);
                     }
+                    tv[0] = bs[0] ? pd : tv[0];
+                    ti[0] = bs[0] ? j : ti[0];
                 }
             }
-            char* LB = sg ? LBB : LBA;
-            int c = 0;
+        }
+        cnt = 0;
 #pragma unroll
-            for (int s = 0; s < K6_KMAX; ++s) {
-                if (s < k && ti[s] != 0x7fffffff) {
-                    const k6u32x2 e = {(unsigned)__float_as_int(tv[s]), (unsigned)ti[s]};
-                    *(k6u32x2*)(LB + s * 8) = e;
-                    c = s + 1;
-                }
+        for (int s_ = 0; s_ < K6_KMAX; ++s_) {
+            if (s_ < k && ti[s_] != 0x7fffffff) {
+                const k6u32x2 e = {(unsigned)__float_as_int(tv[s_]), (unsigned)ti[s_]};
+                *(k6u32x2*)(LB + s_ * 8) = e;
+                cnt = s_ + 1;
             }
-            if (sg) cntB = c; else cntA = c;
         }
         exact_lists = true;
     }
     K6_T(6);
-    // ---- F0: every lane moves ITS lists to the pd domain (pd' = 2 a - xx_q; the exact path stored pd itself) and fills them to the end with
-    //      {-inf, 0} (never ahead of, never close to a real entry: the counting loops below read whole blocks unmasked)
-#pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
-        char* LB = sg ? LBB : LBA;
-        const int cnt = sg ? cntB : cntA;
-        const float xxq = sg ? xcqB : xcqA;                    // (centred norm: the sweeps' coordinates)
-        float mn = 0.f;                                        // min of -xx_j / 2 = -(largest squared norm among this list's survivors) / 2
+    // ---- F0: every lane moves ITS list to the pd domain (pd' = 2 a - xc_q; the exact path stored pd itself) and fills it to the end with
+    //      {-inf, 0} (never ahead of, never close to a real entry: the counting loops of the slow final read whole blocks unmasked)
+    {
+        float mn = 0.f;                                        // min of -xc_j / 2 = -(largest centred squared norm among this list's survivors) / 2
 #pragma unroll
         for (int p0 = 0; p0 < K6_LENT; p0 += 4) {
             k6u32x2 v[4];
@@ -427,15 +405,15 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float a = __int_as_float((int)v[u][0]);
-                const float p = exact_lists ? a : fmaf(2.0f, a, -xxq);
+                const float p = exact_lists ? a : fmaf(2.0f, a, -xcq);
                 const bool live = p0 + u < cnt;
                 const k6u32x2 w = {(unsigned)__float_as_int(live ? p : -INFINITY), live ? v[u][1] : 0u};
                 *(k6u32x2*)(LB + (p0 + u) * 8) = w;
                 if (live) mn = fminf(mn, nxx[v[u][1] & 4095u]);
             }
         }
-        cnts[((sg ? gB : gA) * 32 + l31) * 4 + ch * 2 + h] = cnt;
-        lmn[((sg ? gB : gA) * 32 + l31) * 4 + ch * 2 + h] = mn;
+        cnts[(qg * 32 + l31) * 4 + ch * 2 + h] = cnt;
+        lmn[(qg * 32 + l31) * 4 + ch * 2 + h] = mn;
     }
     __syncthreads();
 #if defined(K6_PROBE) && K6_PROBE == 3
@@ -443,31 +421,189 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
 #endif
 
     // ---------------------------------------------------------------------------------------------------------------- final: exact ranks
-    // wave w finishes the 32 queries of group w, two per trip (one per half-wave); lane l31 owns entries l31 + 32 s of the query's
-    // concatenated quarter lists.  F1: rank by counting over the keys (blocks of 8 entries per quarter read at once), keys scattered by
-    // rank, neighbours in rank compared: a survivor within 2 E of the next / previous one is AMBIGUOUS (E from the largest norm among the
-    // query's survivors).  The unambiguous are written out at once, the ambiguous go to the wave's work list.  F2 (once per wave, all
-    // lanes busy): canonical distance of every listed pair (fmaf chain over the fp32 rows), exact keys back into the lists, recount.
     K6_T(7);
-    // wave w finishes the 32 queries of group w, two per trip (one per half-wave); lane l31 owns entries l31 + 32 s of the query's
-    // concatenated quarter lists.  F1, per entry of the query: rank += (pd'_e > mine), near += (|pd'_e - mine| <= 2 E) -- five cheap vector
-    // instructions, blocks of 12 entries per quarter read at once; E from the largest norm among the query's survivors.  near > 1 (I count
-    // myself): AMBIGUOUS -> the wave's work list; everyone else is written out at once (an unambiguous rank is final: see the header).
-    // F2 (once per wave, all lanes busy): canonical distance of every listed pair (fmaf chain over the fp32 rows) back into the lists,
-    // then a recount under the full order (value desc, index asc).
     const bool xvec = (ld & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (C & 3) == 0;
-    const int g = wave;                                        // the group this wave finishes
-    unsigned* wl = wlbase + wave * K6_WL;                      // items: entry offset / 8 | query of the workgroup << 16
-    int wcnt = 0;                                              // wave-uniform
-    const float xq_all = xxb[chunk * 128 + g * 32 + l31];     // squared norms of the wave's 32 queries, one per lane (both halves): raw ...
-    const float xcq_all = xcb[chunk * 128 + g * 32 + l31];    // ... and centred
-    auto list_at = [&](int qlc_, int t) -> char* { return lists + (size_t)((((g * 2 + (t >> 1)) * 2 + (t & 1)) * 32 + qlc_) * K6_LSTR); };
-    auto flush = [&]() {
+    auto list_at = [&](int qlc_, int t) -> char* { return lists + (size_t)((((qg * 2 + (t >> 1)) * 2 + (t & 1)) * 32 + qlc_) * K6_LSTR); };
 #ifdef K6_STAMP
-        const long long f0_ = (long long)__builtin_amdgcn_s_memtime();
-        st_items += wcnt; st_flushes++;
+    auto put_stamps = [&]() {
+        K6_T(8);
+        __syncthreads();
+        if (lane == 0 && blockIdx.x < 32) {       // diagnostic build only (tools/knn6_stamps.py): stamps go behind the fragment image in the caller's workspace
+            int* o = (int*)(const_cast<char*>(planes) + (size_t)B * N * CT * 4 + (size_t)B * N * 4) + (blockIdx.x * 8 + wave) * 16;
+            for (int i = 1; i <= 8; ++i) o[i - 1] = (int)(stamp[i] - stamp[i - 1]);
+            o[8] = (int)st_f2; o[9] = st_items; o[10] = st_flushes; o[11] = (int)(stamp[8] - stamp[0]);
+        }
+    };
 #endif
-        // F2a: exact distances
+    // ---- fast final (every query of the group has at most 32 survivors -- the normal case): ONE LANE PER QUERY.  Wave (qg, ch) finishes queries
+    // ch * 16 .. + 15 of its group; lane l serves query l & 15 (the four lanes of a query mirror each other).  The lane pulls its query's survivors into
+    // registers, sorts them by pd' (bitonic network, 240 compare-exchanges, no memory traffic), flags the ones whose gap to a neighbour in
+    // rank is within 2 E, gets their canonical distances (all flagged pairs of the wave packed densely over its lanes: fmaf chains over the fp32
+    // rows), and settles the order inside the flagged runs with odd-even passes under the full order (value desc,
+    // index asc).  An unflagged survivor never moves: its gaps exceed 2 E.
+    {
+        const int qlc = ch * 16 + (lane & 15);
+        const int qq = qg * 32 + qlc, qrow = chunk * 128 + qq;
+        const k6i32x4 c4 = *(const k6i32x4*)(cnts + qq * 4);
+        const int p1 = c4[0], p2 = p1 + c4[1], p3 = p2 + c4[2], n = p3 + c4[3];
+        int nmaxw = n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nmaxw = max(nmaxw, __shfl_xor(nmaxw, o, 64));
+        if (!exact_lists && nmaxw <= 32) {
+            const f32x4 m4 = *(const f32x4*)(lmn + qq * 4);
+            const float xm = -2.0f * fminf(fminf(m4[0], m4[1]), fminf(m4[2], m4[3]));
+            const float xqr = xxb[qrow], xqc = xcb[qrow];
+            const float E2 = 2.0f * (K6_EPS * (xqc + xm) + K6_CANON * (xqr + xxmax));
+            const char* Lb0 = list_at(qlc, 0);
+            const char* Lb1 = list_at(qlc, 1);
+            const char* Lb2 = list_at(qlc, 2);
+            const char* Lb3 = list_at(qlc, 3);
+            float pv[32];
+            int jv[32];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const int t = (e >= p1) + (e >= p2) + (e >= p3);
+                const char* Lt = t == 0 ? Lb0 : t == 1 ? Lb1 : t == 2 ? Lb2 : Lb3;
+                const int pos = e - (t == 0 ? 0 : t == 1 ? p1 : t == 2 ? p2 : p3);
+                const k6u32x2 v = *(const k6u32x2*)(Lt + (e < n ? pos : 0) * 8);
+                pv[e] = e < n ? __int_as_float((int)v[0]) : -INFINITY;
+                jv[e] = e < n ? (int)v[1] : 0x7fffffff;
+            }
+#pragma unroll
+            for (int k2 = 2; k2 <= 32; k2 <<= 1)
+#pragma unroll
+                for (int jj = k2 >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+                    for (int a = 0; a < 32; ++a) {
+                        const int c = a ^ jj;
+                        if (c > a) {
+                            const bool desc = (a & k2) == 0;               // this pair keeps the larger value at the lower position
+                            const bool sw = desc ? pv[a] < pv[c] : pv[a] > pv[c];
+                            const float ta = sw ? pv[c] : pv[a], tc = sw ? pv[a] : pv[c];
+                            const int ja = sw ? jv[c] : jv[a], jc = sw ? jv[a] : jv[c];
+                            pv[a] = ta; pv[c] = tc; jv[a] = ja; jv[c] = jc;
+                        }
+                    }
+            // flag: gap to the next survivor in rank not provably larger than 2 E (dead tail entries: -inf, never flagged)
+            unsigned amb = 0u;
+#pragma unroll
+            for (int a = 0; a < 31; ++a) amb |= (a + 1 < n && !(pv[a] - pv[a + 1] > E2)) ? (3u << a) : 0u;
+#if defined(K6_PROBE) && K6_PROBE == 4
+            amb = 0u;
+#endif
+            const int nflag = __builtin_popcount(amb);
+            unsigned* slots = wlbase + wave * 512 + (lane & 15) * 32;      // [32] candidate index in, canonical distance out
+            {
+                int c = 0;
+#pragma unroll
+                for (int a = 0; a < 32; ++a) {
+                    if ((amb >> a) & 1u) { slots[c] = (unsigned)jv[a]; ++c; }
+                }
+            }
+            int fmaxw = nflag;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) fmaxw = max(fmaxw, __shfl_xor(fmaxw, o, 64));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#ifdef K6_STAMP
+            const long long f0_ = (long long)__builtin_amdgcn_s_memtime();
+            st_items += nflag; st_flushes = fmaxw;
+#endif
+            // Canonical distances of the flagged pairs, DENSELY packed over the wave's lanes: pair i of the wave = (query, slot) by a prefix sum of
+            // the 16 queries' flag counts (the counts differ a lot from query to query: slot-by-slot rounds ran at a third of the lanes).  Both rows
+            // fetched whole (2 x 16 x 16 bytes in flight per lane at C = 64), fmaf chain channels ascending.  (Staging the rows through LDS with
+            // cooperative, fully coalesced fetches was built and measured: 2x slower -- the phase is bound by its chain of dependent steps, not by
+            // cache-line transactions.)
+            if (fmaxw > 0) {
+                int offs[17];
+                offs[0] = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) offs[q + 1] = offs[q] + __builtin_amdgcn_readlane(nflag, q);      // (scalar)
+                const int total = offs[16];
+                unsigned* wslots = wlbase + wave * 512;
+                const int qbase = chunk * 128 + qg * 32 + ch * 16;
+                for (int i0 = 0; i0 < total; i0 += 64) {
+                    const int i = i0 + lane;
+                    if (i < total) {
+                        int q = 0, ob = 0;
+#pragma unroll
+                        for (int t = 1; t < 16; ++t) { const bool ge = i >= offs[t]; q = ge ? t : q; ob = ge ? offs[t] : ob; }
+                        unsigned* sp = wslots + q * 32 + (i - ob);
+                        const int j = (int)*sp;
+                        const int qr = qbase + q;
+                        const float* rq = xb + (size_t)qr * ld;
+                        const float* rj = xb + (size_t)j * ld;
+                        float acc = 0.f;
+                        if (!xvec) {
+                            for (int c = 0; c < C; ++c) acc = fmaf(rq[c], rj[c], acc);
+                        } else {
+                            constexpr int CHV = CT >= 128 ? 8 : 16;        // float4 pieces of both rows in flight (register budget at C = 128)
+                            for (int c = 0; c < C; c += 4 * CHV) {
+                                f32x4 a4[CHV], b4[CHV];
+#pragma unroll
+                                for (int u = 0; u < CHV; ++u)
+                                    if (c + 4 * u < C) { a4[u] = *(const f32x4*)(rq + c + 4 * u); b4[u] = *(const f32x4*)(rj + c + 4 * u); }
+#pragma unroll
+                                for (int u = 0; u < CHV; ++u)
+                                    if (c + 4 * u < C) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) acc = fmaf(a4[u][e], b4[u][e], acc);
+                                    }
+                            }
+                        }
+                        const float t2 = fmaf(2.0f, acc, -xxb[j]);
+                        *sp = (unsigned)__float_as_int(t2 - xxb[qr]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+#ifdef K6_STAMP
+            st_f2 += (long long)__builtin_amdgcn_s_memtime() - f0_;
+#endif
+            {
+                int c = 0;
+#pragma unroll
+                for (int a = 0; a < 32; ++a) {
+                    if ((amb >> a) & 1u) { pv[a] = __int_as_float((int)slots[c]); ++c; }
+                }
+            }
+            // settle the flagged runs: odd-even transposition passes under the full order until nothing moves (a run of r entries needs <= r passes)
+            if (fmaxw > 0) {
+                for (int pass = 0; pass < 32; ++pass) {
+                    bool moved = false;
+#pragma unroll
+                    for (int par = 0; par < 2; ++par)
+#pragma unroll
+                        for (int a = par; a < 31; a += 2) {
+                            const bool sw = k6_beats(pv[a + 1], jv[a + 1], pv[a], jv[a]);
+                            const float ta = sw ? pv[a + 1] : pv[a], tc = sw ? pv[a] : pv[a + 1];
+                            const int ja = sw ? jv[a + 1] : jv[a], jc = sw ? jv[a] : jv[a + 1];
+                            pv[a] = ta; pv[a + 1] = tc; jv[a] = ja; jv[a + 1] = jc;
+                            moved |= sw;
+                        }
+                    if (!__any(moved)) break;
+                }
+            }
+            if (lane < 16) {
+                int* out = idx + ((size_t)b * N + qrow) * k;
+#pragma unroll
+                for (int a = 0; a < K6_KMAX; ++a)
+                    if (a < k && a < n) out[a] = jv[a];
+            }
+#ifdef K6_STAMP
+            put_stamps();
+#endif
+            return;
+        }
+    }
+    // ---- slow final (a query with more than 32 survivors, or exact lists): rank by counting, two queries per trip (one per half-wave); lane l31
+    // owns entries l31 + 32 s of the query's concatenated quarter lists.  Per entry of the query: rank += (pd'_e > mine), near += (|pd'_e - mine|
+    // <= 2 E).  near > 1 (I count myself): AMBIGUOUS -> the wave's work list; everyone else is written out at once.  Flush: canonical distance
+    // of every listed pair back into the lists, then a recount under the full order (value desc, index asc).
+    unsigned* wl = wlbase + wave * 512;                        // items: entry offset / 8 | query of the workgroup << 16
+    int wcnt = 0;                                              // wave-uniform
+    auto flush = [&]() {
         for (int i0 = 0; i0 < wcnt; i0 += 64) {
             const int i = i0 + lane;
             if (i < wcnt) {
@@ -501,7 +637,6 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // F2b: recount against the query's lists (exact values where it matters, approximate ones elsewhere: safe, see the header)
         for (int i0 = 0; i0 < wcnt; i0 += 64) {
             const int i = i0 + lane;
             const bool on = i < wcnt;
@@ -526,35 +661,20 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
             if (on && rank < k) idx[((size_t)b * N + chunk * 128 + qq_) * k + rank] = jm;
         }
         wcnt = 0;
-#ifdef K6_STAMP
-        st_f2 += (long long)__builtin_amdgcn_s_memtime() - f0_;
-#endif
     };
-
-    for (int it = 0; it < 16; ++it) {
-        const int qlc = it * 2 + h;                            // query of the group
-        const int qq = g * 32 + qlc;                           // query of the workgroup
+    for (int it = 0; it < 8; ++it) {
+        const int qlc = ch * 16 + it * 2 + h;                  // query of the group
+        const int qq = qg * 32 + qlc;                          // query of the workgroup
         const int qrow = chunk * 128 + qq;                     // query of the cloud
-        const float xq0 = __builtin_amdgcn_readlane(xq_all, it * 2), xq1 = __builtin_amdgcn_readlane(xq_all, it * 2 + 1);
-        const float xq = h ? xq1 : xq0;
-        const float xc0 = __builtin_amdgcn_readlane(xcq_all, it * 2), xc1 = __builtin_amdgcn_readlane(xcq_all, it * 2 + 1);
-        const float xcq = h ? xc1 : xc0;
+        const float xq = xxb[qrow], xqc = xcb[qrow];
         const char* L0 = list_at(qlc, 0);
         const char* L1 = list_at(qlc, 1);
         const char* L2 = list_at(qlc, 2);
         const char* L3 = list_at(qlc, 3);
-        float pe[48];                                          // first 12 values of every quarter: issued before anything depends on the counts
-#pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            pe[u] = *(const float*)(L0 + u * 8);
-            pe[12 + u] = *(const float*)(L1 + u * 8);
-            pe[24 + u] = *(const float*)(L2 + u * 8);
-            pe[36 + u] = *(const float*)(L3 + u * 8);
-        }
         const k6i32x4 c4 = *(const k6i32x4*)(cnts + qq * 4);
         const f32x4 m4 = *(const f32x4*)(lmn + qq * 4);
         const float xm = -2.0f * fminf(fminf(m4[0], m4[1]), fminf(m4[2], m4[3]));       // largest centred squared norm among the query's survivors
-        const float E2 = exact_lists ? 0.0f : 2.0f * (K6_EPS * (xcq + xm) + K6_CANON * (xq + xxmax));     // (exact lists: only exact ties go through the full-order recount)
+        const float E2 = exact_lists ? 0.0f : 2.0f * (K6_EPS * (xqc + xm) + K6_CANON * (xq + xxmax));     // (exact lists: only exact ties go through the full-order recount)
         const int p1 = c4[0], p2 = p1 + c4[1], p3 = p2 + c4[2], n = p3 + c4[3];
         const int nmax = max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 32));
         int cmx = max(max(c4[0], c4[1]), max(c4[2], c4[3]));
@@ -569,12 +689,7 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
             const float pm = __int_as_float((int)me[0]);
             const int j = (int)me[1];
             int rank = 0, near = 0;
-#pragma unroll
-            for (int u = 0; u < 48; ++u) {
-                rank += pe[u] > pm ? 1 : 0;
-                near += fabsf(pe[u] - pm) <= E2 ? 1 : 0;
-            }
-            for (int p0 = 12; p0 < cmx; p0 += 4) {             // a quarter with more than 12 survivors (rare)
+            for (int p0 = 0; p0 < cmx; p0 += 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float a0 = *(const float*)(L0 + (p0 + u) * 8), a1 = *(const float*)(L1 + (p0 + u) * 8);
@@ -583,10 +698,7 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
                     near += (fabsf(a0 - pm) <= E2 ? 1 : 0) + (fabsf(a1 - pm) <= E2 ? 1 : 0) + (fabsf(a2 - pm) <= E2 ? 1 : 0) + (fabsf(a3 - pm) <= E2 ? 1 : 0);
                 }
             }
-            bool amb = valid && !(near <= 1);                  // another survivor inside my 2 E window (I count once myself)
-#if defined(K6_PROBE) && K6_PROBE == 4
-            amb = false;
-#endif
+            const bool amb = valid && !(near <= 1);            // another survivor inside my 2 E window (I count once myself)
             if (valid && !amb && rank < k) idx[((size_t)b * N + qrow) * k + rank] = j;
             const unsigned long long m = __ballot(amb);
             if (m) {
@@ -595,24 +707,18 @@ __global__ __launch_bounds__(256, CT <= 16 ? 2 : 1) void knn6_kernel(const float
                 wcnt += __builtin_popcountll(m);
             }
         }
-        if (wcnt > K6_WL - 192 || (it == 15 && wcnt > 0)) {    // (a trip adds at most 2 x 96 items)
+        if (wcnt > 512 - 192 || (it == 7 && wcnt > 0)) {       // (a trip adds at most 2 x 96 items)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             flush();
         }
     }
 #ifdef K6_STAMP
-    K6_T(8);
-    __syncthreads();
-    if (lane == 0 && blockIdx.x < 64) {           // diagnostic build only (tools/knn6_stamps.py): stamps go behind the fragment image in the caller's workspace
-        int* o = (int*)(const_cast<char*>(planes) + (size_t)B * N * CT * 4 + (size_t)B * N * 4) + (blockIdx.x * 4 + wave) * 16;
-        for (int i = 1; i <= 8; ++i) o[i - 1] = (int)(stamp[i] - stamp[i - 1]);
-        o[8] = (int)st_f2; o[9] = st_items; o[10] = st_flushes; o[11] = (int)(stamp[8] - stamp[0]);
-    }
+    put_stamps();
 #endif
 }
 
-size_t knn6_lds_bytes(int N) { return (size_t)512 * K6_LSTR + (size_t)N * 4 + 128 * 4 + 512 * 4 + 64 + (size_t)4 * K6_WL * 4 + 512 * 4; }
+size_t knn6_lds_bytes(int N) { return (size_t)512 * K6_LSTR + (size_t)N * 4 + 128 * 4 + 512 * 4 + 64 + (size_t)8 * 512 * 4 + 512 * 4; }
 
 // shapes v6 takes (the rest stays on knn.hip's kernels)
 bool knn6_supported(int B, int N, int C, int k) {
@@ -629,7 +735,7 @@ static int knn6_go(hipStream_t st, const float* x, int ld, int B, int N, int C, 
     const size_t lds = knn6_lds_bytes(N);
     hipError_t e = hipFuncSetAttribute((const void*)knn6_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((knn6_kernel<CT>), dim3((N / 128) * B), dim3(256), lds, st, x, ld, xx, xc, planes, N, C, k, idx, B);
+    hipLaunchKernelGGL((knn6_kernel<CT>), dim3((N / 128) * B), dim3(512), lds, st, x, ld, xx, xc, planes, N, C, k, idx, B);
     return mlsp_launch_status();
 }
 

@@ -27,6 +27,6 @@ for (B, N, C, k) in [(32, 1024, 3, 20), (32, 1024, 64, 20), (32, 1024, 128, 20)]
     # workspace layout of mlsp_knn_f32 (api.hip): xx [B*N] floats (256-byte aligned bump allocator), then the fragment image, then the stamps
     CT = 16 if C <= 16 else 64 if C <= 64 else 128
     off = ((B * N * 4 + 255) // 256) * 256 + B * N * CT * 4 + B * N * 4
-    st = ws[off:off + 64 * 4 * 16 * 4].view(torch.int32).view(256, 16).cpu().numpy()[:, :12]
+    st = ws[off:off + 32 * 8 * 16 * 4].view(torch.int32).view(256, 16).cpu().numpy()[:, :12]
     med = np.median(st, axis=0)
     print("C=%d:" % C, ", ".join("%s %d" % (n, v) for n, v in zip(names, med)), "| total us at 2.4 GHz: %.1f" % (med[11] / 2400.0))
