@@ -16,6 +16,7 @@
 #include "common.h"
 #include <math.h>
 #include <cstdlib>
+#include <type_traits>
 
 #define TN_C1 64
 #define TN_C2 128
@@ -1204,6 +1205,524 @@ template <int MODE, int KR> __global__ __launch_bounds__(512) void tnet_edge_bwd
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Backward, round 4 (product modes 1 / 2, even k in [8, 64]): the same Gram form with the SPARSE half turned into dense products on the
+// bf16 matrix cores.  gsel (one non-zero per point and channel) is never stored: its MFMA fragments are built in registers from the
+// tile's g / arg-max tables -- a compare per element instead of a register-indexed FMA per non-zero and lane (~70 clocks each, which
+// bounded tnet_edge_bwdg_kernel).  Every fp32 value is split into three bf16 pieces as in gemm_split_kernel (six piece products, fp32
+// accumulation).  Per 128-row tile:
+//     waves 0-3 (row block rb = wave): dH = [gsel | H'] [W2 ; -M]   (K = 128 + 64) for both 32-channel tiles: 144 MFMAs; the epilogue
+//                (dh' = dH act'(a), BN1-backward sums) runs on the accumulators after the barrier, while the next tile is staged;
+//     waves 4-7 (o tile mt = wave - 4):  G1 += gsel^T H' (K = 128 rows, both channel tiles) and one tile of the Gram matrix H'^T H'
+//                from the same B fragments: 144 MFMAs.
+// LDS images are [row][piece][64 channels] bf16 with a 448-byte row pitch (= 192 mod 256: the four k-rows of a transposed read fall in
+// four different 64-byte bank windows); H' is read both ways (row-major A fragments for H' M, transposed for the products over rows), its
+// 16-byte slots are XOR-swizzled inside each 64-byte block by (row >> 2) & 3 so that the ds_read_b128 pattern is conflict-free as well.
+// H' (56 KB) + W2 (56 KB) + -M (28 KB) + tables = 148 KB, one workgroup of 8 waves per CU.
+typedef __bf16 tbf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int tu32x2 __attribute__((ext_vector_type(2)));
+#define TB_PITCH 448
+#define TB_LDS __attribute__((address_space(3)))
+struct TnetBwdSLds {
+    char Hp[TN_ROWS * TB_PITCH];                  // H' [row][piece][64 c], swizzled
+    char Wp[TN_C2 * TB_PITCH];                    // W2 [o][piece][64 c]
+    char Mp[TN_C1 * TB_PITCH];                    // -M [c1][piece][64 c]
+    unsigned short gp[TN_MAXTP * 3 * TN_C2];      // g of the tile's points, three bf16 pieces [pt][piece][o]
+    uint8_t ap[TN_MAXTP * TN_C2];                 // their arg-max slots [pt][o]
+    uint2 gq[TN_MAXTP * TN_C2];                   // the same packed per (pt, o): {piece 0 | piece 1 << 16, piece 2 | slot << 16}
+    float S1[4 * TN_C1];                          // scale1, shift1, mean1, invstd1
+    float cv[TN_C1];
+    float Vs[TN_MAXTP * TN_C1];                   // centre rows v_i of the tile being staged
+};
+typedef TB_LDS char* tb_lds_ptr;                  // 32-bit LDS addresses: one register each, 16-bit instruction offsets
+__device__ __forceinline__ tbf16x8 tb_tr(tb_lds_ptr lo, tb_lds_ptr hi) {
+    const tbf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((TB_LDS tbf16x4*)lo);
+    const tbf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((TB_LDS tbf16x4*)hi);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// acc += a b with the six piece products, smallest first
+__device__ __forceinline__ void tb_mac6(f32x16& acc, const tbf16x8 (&a)[3], const tbf16x8 (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+// two / three independent accumulation chains, interleaved: a chain by itself waits for each result
+__device__ __forceinline__ void tb_mac6x2(f32x16& c0, f32x16& c1, const tbf16x8 (&a0)[3], const tbf16x8 (&b0)[3], const tbf16x8 (&a1)[3],
+                                          const tbf16x8 (&b1)[3]) {
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[i]], b0[PB[i]], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA[i]], b1[PB[i]], c1, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void tb_mac6x3(f32x16& c0, f32x16& c1, f32x16& c2, const tbf16x8 (&a0)[3], const tbf16x8 (&b0)[3],
+                                          const tbf16x8 (&a1)[3], const tbf16x8 (&b1)[3], const tbf16x8 (&a2)[3], const tbf16x8 (&b2)[3]) {
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[i]], b0[PB[i]], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA[i]], b1[PB[i]], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[PA[i]], b2[PB[i]], c2, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void tb_split1(float x, unsigned short& a, unsigned short& b, unsigned short& c) {
+    const uint32_t pa = tn_cvt_pk(x, 0.f);
+    const float r = x - __uint_as_float(pa << 16);
+    const uint32_t pb = tn_cvt_pk(r, 0.f);
+    const uint32_t pc = tn_cvt_pk(r - __uint_as_float(pb << 16), 0.f);
+    a = (unsigned short)pa; b = (unsigned short)pb; c = (unsigned short)pc;
+}
+
+// the workgroup's tile walk without a division per tile (tn_tile's order: XCD-aware when the cloud count and the grid allow it); three
+// positions (tiles m, m + 1, m + 2) share the parameters
+struct TbWalkParams { int tpc, per, cstep, B; };
+struct TbWalk {
+    int cloud, tic;
+    __device__ __forceinline__ void init(TbWalkParams& w, int B_, int N, int TP) {
+        w.B = B_; w.tpc = (N + TP - 1) / TP;
+        int L;
+        if ((B_ & 7) == 0 && (gridDim.x & 7) == 0) { L = blockIdx.x >> 3; w.per = gridDim.x >> 3; w.cstep = 8; cloud = (blockIdx.x & 7) + 8 * (L / w.tpc); }
+        else { L = blockIdx.x; w.per = gridDim.x; w.cstep = 1; cloud = L / w.tpc; }
+        tic = L % w.tpc;
+    }
+    __device__ __forceinline__ bool ok(const TbWalkParams& w) const { return cloud < w.B; }
+    __device__ __forceinline__ void next(const TbWalkParams& w) {
+        tic += w.per;
+        while (tic >= w.tpc) { tic -= w.tpc; cloud += w.cstep; }
+    }
+};
+
+__global__ __launch_bounds__(512) void tnet_edge_bwds_kernel(
+    const float* __restrict__ uv, const int* __restrict__ idx, const float* __restrict__ bn1, const float* __restrict__ W2,
+    const float* __restrict__ Mc, const float* __restrict__ g, const uint8_t* __restrict__ argsel, float* __restrict__ dhp,
+    float* __restrict__ slabs, double* __restrict__ part1, int P, int N, int k, int TP, float slope) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    TnetBwdSLds& L = *reinterpret_cast<TnetBwdSLds*>(smraw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    for (int e = tid; e < (int)(sizeof(TnetBwdSLds) / 16); e += 512) ((f32x4*)smraw)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    {   // W2 pieces: thread -> row o, 16 channels
+        const int o = tid >> 2, q4 = tid & 3;
+        const f32x4* src = (const f32x4*)(W2 + (size_t)o * TN_C1 + 16 * q4);
+        char* dst = L.Wp + o * TB_PITCH + 32 * q4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 x = src[e];
+            uint32_t pa[2], pb[2], pc[2];
+            tn_split2(x[0], x[1], pa[0], pb[0], pc[0]);
+            tn_split2(x[2], x[3], pa[1], pb[1], pc[1]);
+            *(uint2*)(dst + 8 * e) = make_uint2(pa[0], pa[1]);
+            *(uint2*)(dst + 128 + 8 * e) = make_uint2(pb[0], pb[1]);
+            *(uint2*)(dst + 256 + 8 * e) = make_uint2(pc[0], pc[1]);
+        }
+    }
+    {   // -M pieces: thread -> row c1, 8 channels
+        const int c1 = tid >> 3, q8 = tid & 7;
+        const f32x4* src = (const f32x4*)(Mc + (size_t)c1 * TN_C1 + 8 * q8);
+        char* dst = L.Mp + c1 * TB_PITCH + 16 * q8;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const f32x4 x = src[e];
+            uint32_t pa[2], pb[2], pc[2];
+            tn_split2(-x[0], -x[1], pa[0], pb[0], pc[0]);
+            tn_split2(-x[2], -x[3], pa[1], pb[1], pc[1]);
+            *(uint2*)(dst + 8 * e) = make_uint2(pa[0], pa[1]);
+            *(uint2*)(dst + 128 + 8 * e) = make_uint2(pb[0], pb[1]);
+            *(uint2*)(dst + 256 + 8 * e) = make_uint2(pc[0], pc[1]);
+        }
+    }
+    if (tid < 4 * TN_C1) L.S1[tid] = bn1[tid];
+    if (tid < TN_C1) L.cv[tid] = Mc[TN_C1 * TN_C1 + tid];
+    // gather role: 4 threads per tile row, 16 channels each
+    const int grow = tid >> 2, gq = tid & 3;
+    const int gpt = grow / k, gslot = grow - gpt * k;
+    const float rslope = 1.0f / slope;
+    (void)rslope;
+    const int kinv = 65536 / k + 1;                            // (r * kinv) >> 16 == r / k for r < 128, 8 <= k <= 64
+
+    // Every global load of the walk is UNCONDITIONAL (clamped addresses, masks applied where the value is consumed): a load under a
+    // branch whose other side writes the same register makes the compiler drain the whole memory queue right there (measured: 4,000 clocks
+    // per tile at the top of the loop).
+    TbWalkParams wp;
+    TbWalk wc, wn, wnn;                                        // tiles m, m + 1, m + 2 of this workgroup
+    struct RowIdx { int raw, base; bool valid; };
+    auto row_index = [&](const TbWalk& w) -> RowIdx {         // uv row of this thread's neighbour in tile w (raw: still in flight)
+        const int pt0_ = w.cloud * N + w.tic * TP, npts_ = min(TP, N - w.tic * TP);
+        const bool valid = w.ok(wp) && gpt < npts_;
+        RowIdx r;
+        r.raw = idx[valid ? (size_t)(pt0_ + gpt) * k + gslot : (size_t)0]; r.base = w.cloud * N; r.valid = valid;
+        return r;
+    };
+    auto row_of = [&](const RowIdx& r) -> int { return r.valid ? r.base + r.raw : -1; };     // -1 = padding row
+    // the centre term v_i is the same for the k rows of a point: TP rows staged through LDS (Vs), one float per thread
+    auto load_rows = [&](int j, int pt0_, f32x4 (&u)[4], float& vst) {
+        const f32x4* up = (const f32x4*)(uv + (size_t)max(j, 0) * 2 * TN_C1 + 16 * gq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = up[e];
+        vst = uv[(size_t)min(pt0_ + (tid >> 6), P - 1) * 2 * TN_C1 + TN_C1 + (tid & 63)];
+    };
+    // g / arg-max slots of a tile's points: g values tid and tid + 512 (point = value >> 7, channel = value & 127) with their own slot bytes
+    // (the packed table of waves 4-7), and the same bytes in the byte table of waves 0-3; npts_ == 0: nothing is stored
+    auto load_scal = [&](int pt0_, int npts_, float (&gv)[2], uint8_t (&ab)[2]) {
+        const int last = max(npts_ * TN_C2 - 1, 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const size_t at = (size_t)pt0_ * TN_C2 + min(tid + 512 * e, last);
+            gv[e] = g[at]; ab[e] = argsel[at];
+        }
+    };
+    auto store_scal = [&](int npts_, const float (&gv)[2], const uint8_t (&ab)[2]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = tid + 512 * e, pt = i >> 7, o = i & 127;
+            unsigned short a, b, c;
+            tb_split1(i < npts_ * TN_C2 ? gv[e] : 0.f, a, b, c);
+            L.gp[(pt * 3 + 0) * TN_C2 + o] = a; L.gp[(pt * 3 + 1) * TN_C2 + o] = b; L.gp[(pt * 3 + 2) * TN_C2 + o] = c;
+            L.gq[i] = make_uint2((uint32_t)a | ((uint32_t)b << 16), (uint32_t)c | ((uint32_t)ab[e] << 16));
+            L.ap[i] = ab[e];                                   // (points past npts_ have g = 0: their slots do not matter)
+        }
+    };
+    auto store_rows = [&](int j, const f32x4 (&u)[4]) {       // Vs holds the tile's centre rows
+        char* dst = L.Hp + grow * TB_PITCH;
+        const int x = ((grow >> 2) & 3) << 4;
+        const float* vs = L.Vs + min(gpt, TN_MAXTP - 1) * TN_C1 + 16 * gq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 vv = *(const f32x4*)(vs + 4 * e);
+            float hv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ch = 16 * gq + 4 * e + c;
+                hv[c] = j >= 0 ? lrelu(fmaf(u[e][c] + vv[c], L.S1[ch], L.S1[TN_C1 + ch]), slope) : 0.f;
+            }
+            uint32_t pa[2], pb[2], pc[2];
+            tn_split2(hv[0], hv[1], pa[0], pb[0], pc[0]);
+            tn_split2(hv[2], hv[3], pa[1], pb[1], pc[1]);
+            const int off = (32 * gq + 8 * e) ^ x;
+            *(uint2*)(dst + off) = make_uint2(pa[0], pa[1]);
+            *(uint2*)(dst + 128 + off) = make_uint2(pb[0], pb[1]);
+            *(uint2*)(dst + 256 + off) = make_uint2(pc[0], pc[1]);
+        }
+    };
+
+    // fragment addressing.  Transposed reads (ds_read_b64_tr_b16): lane 4q + p of a 16-lane group supplies k-row q, columns 4p .. 4p+3
+    const int ti = lane & 15, tg16 = (lane >> 4) & 1;
+    const int tcol = 32 * tg16 + 8 * (ti & 3);                                  // byte column inside a 64-byte (32-channel) block
+    const int trow_lo = 8 * h + (ti >> 2), trow_hi = trow_lo + 4;
+    const tb_lds_ptr lds = (tb_lds_ptr)smraw;
+    constexpr int OFF_HP = 0, OFF_WP = TN_ROWS * TB_PITCH, OFF_MP = OFF_WP + TN_C2 * TB_PITCH, OFF_GP = OFF_MP + TN_C1 * TB_PITCH,
+                  OFF_AP = OFF_GP + TN_MAXTP * 3 * TN_C2 * 2, OFF_GQ = OFF_AP + TN_MAXTP * TN_C2;
+    static_assert(OFF_AP == offsetof(TnetBwdSLds, ap) && OFF_GP == offsetof(TnetBwdSLds, gp) && OFF_GQ == offsetof(TnetBwdSLds, gq), "LDS layout");
+    const tb_lds_ptr wlo = lds + OFF_WP + trow_lo * TB_PITCH + tcol;             // + 16 s * TB_PITCH + 64 ct + 128 piece
+    const tb_lds_ptr mlo = lds + OFF_MP + trow_lo * TB_PITCH + tcol;
+    const tb_lds_ptr hlo = lds + OFF_HP + trow_lo * TB_PITCH + (tcol ^ (((2 * h) & 3) << 4));
+    const tb_lds_ptr hhi = lds + OFF_HP + trow_hi * TB_PITCH + (tcol ^ (((2 * h + 1) & 3) << 4));
+    const int mt = wave & 3, gi = mt >> 1, gj = mt & 1;
+    // identity B fragment (waves 0-3): H' M's A fragments times the identity put H' itself -- exactly, the pieces sum to the fp32 value --
+    // into the accumulator layout of dH, where the epilogue needs it.  Rebuilt at its four uses per tile (12 instructions; eight registers)
+    auto ident = [&](int sp) -> tbf16x8 {
+        uint32_t d[4];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            const int k0_ = 16 * sp + 8 * h + 2 * i2;
+            d[i2] = (k0_ == l31 ? 0x3f80u : 0u) | (k0_ + 1 == l31 ? 0x3f800000u : 0u);
+        }
+        return tn_pack8(d);
+    };
+    // accumulators: waves 0-3 use acc[0..1] for the dH tile and acch[0..1] for H' in the same layout (cleared per tile), waves 4-7 keep G1
+    // (acc[0..1]) and the Gram tile (acch[0]) across the whole walk -- the same registers, the role of a wave never changes
+    f32x16 acc[2], acch[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acch[0][r] = 0.f; acch[1][r] = 0.f; }
+    double sd[2] = {0.0, 0.0}, sdh[2] = {0.0, 0.0}, shs[2] = {0.0, 0.0};
+
+#ifdef TB_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define TB_STAMP(i_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[i_] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define TB_STAMP(i_)
+#endif
+    bool pend = false; int ppt0 = 0, pnvalid = 0;              // waves 0-3: the epilogue of (channel tile 1, previous tile) is still due
+    wc.init(wp, P / N, N, TP);
+    wn = wc; wn.next(wp);
+    wnn = wn; wnn.next(wp);
+    __syncthreads();                                           // S1 is read by store_rows
+    if (wc.ok(wp)) {
+        f32x4 u[4]; float vst;
+        const int j0 = row_of(row_index(wc));
+        const int pt0_ = wc.cloud * N + wc.tic * TP, npts_ = min(TP, N - wc.tic * TP);
+        float gv[2]; uint8_t ab[2];
+        load_rows(j0, pt0_, u, vst);
+        load_scal(pt0_, npts_, gv, ab);
+        L.Vs[tid] = vst;
+        __syncthreads();
+        store_rows(j0, u);
+        store_scal(npts_, gv, ab);
+    }
+    RowIdx jn = row_index(wn);
+    __syncthreads();
+#ifdef TB_STAMPS
+    tprev = __builtin_amdgcn_s_memtime();
+#endif
+    while (wc.ok(wp)) {
+        const int pt0 = wc.cloud * N + wc.tic * TP, npts = min(TP, N - wc.tic * TP);
+        const int pt0n = wn.ok(wp) ? wn.cloud * N + wn.tic * TP : pt0, nptsn = wn.ok(wp) ? min(TP, N - wn.tic * TP) : 0;
+        const int nvalid = npts * k;
+        f32x4 u[4]; float vst;
+        float gv[2]; uint8_t ab[2];
+        const int jrow = row_of(jn);
+        load_rows(jrow, pt0n, u, vst);                         // next tile's rows and scalars in flight during this tile's products
+        load_scal(pt0n, nptsn, gv, ab);
+        const RowIdx jnn = row_index(wnn);
+        TB_STAMP(0);
+        int opq;                                               // an opaque zero: keeps the role-specific addressing below out of the loop-invariant set
+        asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
+        if (wave < 4) {
+            // this lane's tile row as the M index of dH
+            const int arow = 32 * wave + l31 + opq;
+            int apt = (arow * kinv) >> 16;
+            uint32_t slotrep = (uint32_t)(arow - apt * k) * 0x01010101u;
+            if (apt >= TP) { apt = 0; slotrep = 0x7f7f7f7fu; }                   // rows past the tile's points: no slot matches
+            const tb_lds_ptr gpb = lds + OFF_GP + (apt * 3 * TN_C2 + 8 * h) * 2; // + 32 s (+ 256 per piece)
+            const tb_lds_ptr apb = lds + OFF_AP + apt * TN_C2 + 8 * h;           // + 16 s
+            const int ax = ((arow >> 2) & 3) << 4;
+            const tb_lds_ptr hrow = lds + OFF_HP + arow * TB_PITCH + ((16 * h) ^ (ax & 16));     // + (32 s) ^ (ax & 32) + 128 piece
+            // Two passes over the 12 k16 steps (8 of gsel W2: A fragment = this row's 8 channels o, non-zero where the arg-max slot is this
+            // row's slot; then 4 of H' (-M)), one per 32-channel tile ct.  The register epilogue of the OTHER tile rides between the MFMAs:
+            // pass 0 carries the epilogue of (ct = 1, previous tile), pass 1 that of (ct = 0, this tile) -- a vector instruction issued
+            // while another wave streams MFMAs waits about one MFMA slot, inside the issuing wave's own stream it is free (see
+            // tnet_edge_fwd3_kernel).  The A fragments are rebuilt in the second pass (30 vector instructions per step, hidden the same way).
+            auto ld_g = [&](int s_, u32x4 (&gp_)[3], tu32x2& aw_) {
+                gp_[0] = *(TB_LDS const u32x4*)(gpb + 32 * s_); gp_[1] = *(TB_LDS const u32x4*)(gpb + 2 * TN_C2 + 32 * s_);
+                gp_[2] = *(TB_LDS const u32x4*)(gpb + 4 * TN_C2 + 32 * s_);
+                aw_ = *(TB_LDS const tu32x2*)(apb + 16 * s_);
+            };
+            auto ld_h = [&](int s_, tbf16x8 (&a_)[3]) {
+                const tb_lds_ptr ar = hrow + ((32 * s_) ^ (ax & 32));
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a_[q] = *(TB_LDS const tbf16x8*)(ar + 128 * q);
+            };
+            // A wave issues in order and stalls at an MFMA whose accumulator is still in the pipe: everything else of a step (the LDS requests
+            // of step s + 1, the two epilogue entries, the masks and A fragment of step s + 1) is placed BETWEEN the six dependent MFMAs of
+            // step s, one scheduling barrier per slot.
+            auto pass = [&](auto ct_tag, bool epi_on, int ept0, int envalid) {
+                constexpr int ct = decltype(ct_tag)::value, ec = 1 - ct;       // products of tile ct, epilogue of tile ec
+                constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};      // piece products, smallest first
+                auto ld_b = [&](tb_lds_ptr base, int s_, tbf16x8 (&b_)[3]) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const tb_lds_ptr w = base + 16 * s_ * TB_PITCH + 64 * ct + 128 * q;
+                        b_[q] = tb_tr(w, w + 4 * TB_PITCH);
+                    }
+                };
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[ct][r] = 0.f; acch[ct][r] = 0.f; }
+                const int c = 32 * ec + l31;
+                const float cvc = L.cv[c];
+                float lsd = 0.f, lsh = 0.f, lhs = 0.f;
+                const int lim = epi_on ? envalid - (32 * wave + 4 * h) : 0;      // valid rows of this lane: map(r) < lim
+                float* dp = dhp + ((size_t)ept0 * k + 32 * wave + 4 * h) * TN_C1 + c;
+                auto epi = [&](int r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    const float hv = acch[ec][r];
+                    const float dH = acc[ec][r] - cvc;
+                    const float dd = dH * (hv > 0.f ? 1.f : slope);
+                    if (dr < lim) { dp[dr * TN_C1] = dd; lsd += dd; }
+                    lsh = fmaf(dH, hv, lsh); lhs += hv;       // rows past the tile's points have h' = 0
+                };
+                uint32_t mk[4];
+                auto masks = [&](const tu32x2& aw_) {
+                    const uint32_t t0 = aw_[0] ^ slotrep, t1 = aw_[1] ^ slotrep;         // bytes < 0x80: zero where the slot matches
+                    const uint32_t f0 = ((((t0 + 0x7f7f7f7fu) >> 7) & 0x01010101u) ^ 0x01010101u) * 0xffu;
+                    const uint32_t f1 = ((((t1 + 0x7f7f7f7fu) >> 7) & 0x01010101u) ^ 0x01010101u) * 0xffu;
+                    mk[0] = __builtin_amdgcn_perm(0u, f0, 0x01010000u); mk[1] = __builtin_amdgcn_perm(0u, f0, 0x03030202u);
+                    mk[2] = __builtin_amdgcn_perm(0u, f1, 0x01010000u); mk[3] = __builtin_amdgcn_perm(0u, f1, 0x03030202u);
+                };
+                auto frag = [&](const u32x4& gp_) -> tbf16x8 {
+                    const uint32_t d[4] = {gp_[0] & mk[0], gp_[1] & mk[1], gp_[2] & mk[2], gp_[3] & mk[3]};
+                    return tn_pack8(d);
+                };
+                tbf16x8 a[3], bc[3];
+                {
+                    u32x4 gp0[3]; tu32x2 aw0;
+                    ld_g(0, gp0, aw0); ld_b(wlo, 0, bc);
+                    masks(aw0);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) a[q] = frag(gp0[q]);
+                }
+#pragma unroll
+                for (int s = 0; s < 12; ++s) {
+                    u32x4 gpn[3]; tu32x2 awn; tbf16x8 bn_[3], an[3];
+#pragma unroll
+                    for (int i2 = 0; i2 < 6; ++i2) {
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[i2]], bc[PB[i2]], acc[ct], 0, 0, 0);
+                        if (i2 == 0) {                         // requests of step s + 1
+                            if (s + 1 < 8) { ld_g(s + 1, gpn, awn); ld_b(wlo, s + 1, bn_); }
+                            else if (s + 1 < 12) { ld_h(s + 1 - 8, an); ld_b(mlo, s + 1 - 8, bn_); }
+                        }
+                        if (s < 8 && i2 == 1) epi(2 * s);
+                        if (s < 8 && i2 == 2) epi(2 * s + 1);
+                        if (s + 1 < 8) {                       // A fragment of step s + 1
+                            if (i2 == 3) masks(awn);
+                            if (i2 == 4) { an[0] = frag(gpn[0]); an[1] = frag(gpn[1]); }
+                            if (i2 == 5) an[2] = frag(gpn[2]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (s >= 8 && ((s - 8) >> 1) == ct) {      // H' itself for the epilogue: channels 16 (s - 8) .. + 15 belong to tile (s - 8) >> 1
+                        const tbf16x8 idf = ident((s - 8) & 1);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) acch[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], idf, acch[ct], 0, 0, 0);
+                    }
+                    if (s + 1 < 12) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) { bc[q] = bn_[q]; a[q] = an[q]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (epi_on) {
+                    // BN1-backward sum of dh' hhat with hhat = ((a - shift) / scale - mean) invstd = alpha a - beta, taken as alpha sum(dH h') -
+                    // beta sum(dh'): dh' a = dH h' on both sides of the activation (slope * (h' / slope) = h' to the last bit or one)
+                    const float sc = L.S1[c], sh = L.S1[TN_C1 + c], mu = L.S1[2 * TN_C1 + c], is = L.S1[3 * TN_C1 + c];
+                    const float rsc = sc != 0.f ? 1.0f / sc : 0.f;
+                    sd[ec] += lsd; sdh[ec] += (rsc * is) * lsh - ((sh * rsc + mu) * is) * lsd; shs[ec] += lhs;
+                }
+            };
+            pass(std::integral_constant<int, 0>{}, pend, ppt0, pnvalid);
+            TB_STAMP(1);
+            pass(std::integral_constant<int, 1>{}, true, pt0, nvalid);
+            pend = true; ppt0 = pt0; pnvalid = nvalid;
+            TB_STAMP(3);
+        } else {
+            // ---- G1 += gsel^T H' and the Gram tile (gi, gj): K = the tile's rows; A fragment = channel `go_` of the 8 rows of the k16 step
+            const int go_ = 32 * mt + l31 + opq;               // this lane's output channel o as the M index of G1
+            const tb_lds_ptr gqb = lds + OFF_GQ + go_ * 8;     // + pt * 1024
+            tbf16x8 bhc[2][3];
+            tu32x2 ec[2];
+            auto ld_bh = [&](int s_, tbf16x8 (&b_)[2][3]) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        b_[nt][q] = tb_tr(hlo + 16 * s_ * TB_PITCH + 64 * nt + 128 * q, hhi + 16 * s_ * TB_PITCH + 64 * nt + 128 * q);
+            };
+            auto ld_e = [&](int s_, tu32x2 (&e_)[2]) {          // packed (pieces, slot) of channel go_ for the two points the 8-row window covers
+                const int pA = ((16 * s_ + 8 * h) * kinv) >> 16;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) e_[w] = *(TB_LDS const tu32x2*)(gqb + min(pA + w, TN_MAXTP - 1) * (TN_C2 * 8));
+            };
+            // the 18 MFMAs of a step run as three independent chains (G1 tile 0, G1 tile 1, Gram); the operands of step s + 1 are requested
+            // before them.  (Hand-placing the fragment construction between the MFMAs as in waves 0-3 was measured slower: 15.4 vs 10.4
+            // thousand clocks per tile -- three chains already keep the wave issuing.)
+            ld_bh(0, bhc); ld_e(0, ec);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                tbf16x8 bhn[2][3];
+                tu32x2 en[2];
+                if (s + 1 < 8) { ld_bh(s + 1, bhn); ld_e(s + 1, en); }
+                const int r0 = 16 * s + 8 * h;
+                const int pA = (r0 * kinv) >> 16;
+                uint32_t d[3][4];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) d[q][i2] = 0u;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int pX = pA + w;
+                    const int e = pX * k + (int)(ec[w][1] >> 16) - r0;
+                    const int di = ((unsigned)e < 8u && pX < TP) ? (e >> 1) : 4;
+                    const int sh = (e & 1) << 4;
+                    const uint32_t t[3] = {(ec[w][0] & 0xffffu) << sh, (ec[w][0] >> 16) << sh, (ec[w][1] & 0xffffu) << sh};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) d[q][i2] = di == i2 ? t[q] : d[q][i2];
+                }
+                tbf16x8 a[3];
+                a[0] = tn_pack8(d[0]); a[1] = tn_pack8(d[1]); a[2] = tn_pack8(d[2]);
+                tb_mac6x3(acc[0], acc[1], acch[0], a, bhc[0], a, bhc[1], gi ? bhc[1] : bhc[0], gj ? bhc[1] : bhc[0]);
+                if (s + 1 < 8) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) bhc[nt][q] = bhn[nt][q];
+                    ec[0] = en[0]; ec[1] = en[1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            TB_STAMP(1);
+        }
+        L.Vs[tid] = vst;                                       // (Vs is only read between the two barriers)
+        __syncthreads();                                       // every wave has read its fragments: the images may be overwritten
+        TB_STAMP(4);
+        if (wn.ok(wp)) { store_rows(jrow, u); store_scal(nptsn, gv, ab); }
+        TB_STAMP(5);
+        __syncthreads();
+        TB_STAMP(6);
+        wc = wn; wn = wnn; wnn.next(wp); jn = jnn;
+    }
+    if (wave < 4 && pend) {                                    // the last tile's second channel tile
+        const int c = 32 + l31;
+        const float sc = L.S1[c], sh = L.S1[TN_C1 + c], mu = L.S1[2 * TN_C1 + c], is = L.S1[3 * TN_C1 + c], cvc = L.cv[c];
+        const float rsc = sc != 0.f ? 1.0f / sc : 0.f;
+        float lsd = 0.f, lsh = 0.f, lhs = 0.f;
+        const int lim = pnvalid - (32 * wave + 4 * h);
+        float* dp = dhp + ((size_t)ppt0 * k + 32 * wave + 4 * h) * TN_C1 + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const float hv = acch[1][r];
+            const float dH = acc[1][r] - cvc;
+            const float dd = dH * (hv > 0.f ? 1.f : slope);
+            if (dr < lim) { dp[dr * TN_C1] = dd; lsd += dd; }
+            lsh = fmaf(dH, hv, lsh); lhs += hv;
+        }
+        sd[1] += lsd; sdh[1] += (rsc * is) * lsh - ((sh * rsc + mu) * is) * lsd; shs[1] += lhs;
+    }
+    // ---- per-workgroup partials: G1 [128][64], Gram [64][64], colsum(H') [64]; BN1-backward sums
+    float* slab = slabs + (size_t)blockIdx.x * TG_SLAB;
+    double* red = reinterpret_cast<double*>(L.Hp);            // [3 kinds][4 row blocks][64 channels]
+    if (wave >= 4) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h) * TN_C1 + 32 * nt + l31] = acc[nt][r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[TN_C2 * TN_C1 + (32 * gi + (r & 3) + 8 * (r >> 2) + 4 * h) * TN_C1 + 32 * gj + l31] = acch[0][r];
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const double a = sd[ct] + __shfl_xor(sd[ct], 32, 64), b = sdh[ct] + __shfl_xor(sdh[ct], 32, 64), c3 = shs[ct] + __shfl_xor(shs[ct], 32, 64);
+            if (h == 0) {
+                const int c = 32 * ct + l31;
+                red[(0 * 4 + wave) * 64 + c] = a; red[(1 * 4 + wave) * 64 + c] = b; red[(2 * 4 + wave) * 64 + c] = c3;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 3 * TN_C1) {
+        const int kind = tid >> 6, c = tid & 63;
+        const double t = (red[(kind * 4 + 0) * 64 + c] + red[(kind * 4 + 1) * 64 + c]) + (red[(kind * 4 + 2) * 64 + c] + red[(kind * 4 + 3) * 64 + c]);
+        if (kind < 2) part1[((size_t)blockIdx.x * 2 + kind) * TN_C1 + c] = t;
+        else slab[TN_C2 * TN_C1 + TN_C1 * TN_C1 + c] = (float)t;
+    }
+#ifdef TB_STAMPS
+    __syncthreads();
+    if (lane == 0 && (wave == 0 || wave == 4)) {              // diagnostic build only: overwrites this workgroup's G1 partial
+        unsigned long long* o = (unsigned long long*)slab + (wave ? 16 : 0);
+        o[0] = 0x5354414d50533031ull + (wave ? 1 : 0);
+        for (int q = 0; q < 8; ++q) o[1 + q] = tsum[q];
+    }
+#endif
+}
+#undef TB_STAMP
+
 // Fold dh' onto the points (BN1 backward in closed form), wave per point, lane = channel (64):
 //   g_e = scale1*(dh'_e - m1 - hhat_e*m2);  dv_i = sum_s g_(i,s);  du_j = sum_{e in rev(j)} g_e
 __global__ __launch_bounds__(256) void tnet_edge_bwd2_kernel(const float* __restrict__ dhp, const float* __restrict__ uv,
@@ -1340,12 +1859,22 @@ int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const 
         float* Mc = slabs + (size_t)nb * TG_SLAB;
         float* R = Mc + TN_C1 * TN_C1 + TN_C1;
         hipLaunchKernelGGL(tnet_bwd_prep_kernel, dim3(TN_C1 / 4 + 1), dim3(256), 0, st, W2, coef, bn2, Mc);
-        const size_t lds = sizeof(TnetBwdGLds);
-        auto kern = k <= 20 ? tnet_edge_bwdg_kernel<0, 20> : k <= 24 ? tnet_edge_bwdg_kernel<0, 24> : k <= 32 ? tnet_edge_bwdg_kernel<0, 32>
-                  : k <= 40 ? tnet_edge_bwdg_kernel<1, 40> : tnet_edge_bwdg_kernel<2, 32>;
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, st, uv, idx, bn1, W2, Mc, g, argsel, dhp, slabs, part1, P, N, k, TP, slope);
+        // products on the bf16 cores (modes 1 and 2): the dense split form (tnet_edge_bwds_kernel); mode 0 keeps exact fp32 products with
+        // the register-indexed sparse half.  Read-once A/B switch: MLSP_TNET_BWD_F32=1.
+        static const bool f32_env = getenv("MLSP_TNET_BWD_F32") != nullptr;
+        if (!f32_env && gemm_precision_mode() != 0 && k % 2 == 0 && k >= 8 && k <= 64) {
+            const size_t lds = sizeof(TnetBwdSLds);
+            hipError_t e = hipFuncSetAttribute((const void*)tnet_edge_bwds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(tnet_edge_bwds_kernel, dim3(nb), dim3(512), lds, st, uv, idx, bn1, W2, Mc, g, argsel, dhp, slabs, part1, P, N, k, TP, slope);
+        } else {
+            const size_t lds = sizeof(TnetBwdGLds);
+            auto kern = k <= 20 ? tnet_edge_bwdg_kernel<0, 20> : k <= 24 ? tnet_edge_bwdg_kernel<0, 24> : k <= 32 ? tnet_edge_bwdg_kernel<0, 32>
+                      : k <= 40 ? tnet_edge_bwdg_kernel<1, 40> : tnet_edge_bwdg_kernel<2, 32>;
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, st, uv, idx, bn1, W2, Mc, g, argsel, dhp, slabs, part1, P, N, k, TP, slope);
+        }
         int rc = mlsp_launch_status();
         if (rc) return rc;
         rc = launch_slab_reduce(st, slabs, R, TG_SLAB / TN_C1, TN_C1, TN_C1, nb);
