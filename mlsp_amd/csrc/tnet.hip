@@ -223,24 +223,31 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd2_kernel(TnetFwdArgs p) {
     __syncthreads();
     // neighbour indices of the rows this thread gathers in a tile (-1: padding); tile m+1's are fetched under tile m's MFMA phase so
     // that only ONE dependent global round trip (the rows themselves) sits on a tile's critical path
-    auto tile_rows = [&](int t0, int np, int (&jr)[3]) {
-        const int base = (t0 / p.N) * p.N;
+    // The index loads are UNCONDITIONAL and their values stay raw until the next tile's gather uses them (okm: which of the three are real
+    // rows, jbase: the cloud's first point): `ok ? base + idx[..] : -1` makes the compiler wait for the load -- and for every row load issued
+    // before it -- right there, three memory round trips in a row per tile.
+    auto tile_rows = [&](int t0, int np, int (&jraw)[3], int& okm_) {
+        okm_ = 0;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int item = tid + 256 * u, row = item >> 2;
             const int pt = row / K, s = row - pt * K;
             const bool ok = item < TF_ROWS * 4 && pt < np;
+            okm_ |= ok ? 1 << u : 0;
 #ifdef TF_PROBE_NOGATHER
-            jr[u] = ok ? t0 + pt : -1;
+            jraw[u] = t0 + pt - (t0 / p.N) * p.N;
 #else
-            jr[u] = ok ? base + p.idx[(size_t)(t0 + pt) * K + s] : -1;
+            jraw[u] = p.idx[ok ? (size_t)(t0 + pt) * K + s : (size_t)0];
 #endif
         }
     };
     bool have = tn_tile(0, Bc, p.N, PT, pt0, npts);
-    int jrow[3] = {-1, -1, -1}, jnext[3] = {-1, -1, -1};
-    if (have) tile_rows(pt0, npts, jrow);
+    int jraw[3] = {0, 0, 0}, okm = 0, jbase = 0;
+    if (have) { tile_rows(pt0, npts, jraw, okm); jbase = (pt0 / p.N) * p.N; }
     for (int m = 0; have; ++m) {
+        int jrow[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) jrow[u] = (okm >> u) & 1 ? jbase + jraw[u] : -1;
         // ---- gather: 160 rows x 4 quarter rows (16 channels) of u_j over 256 threads, everything in flight before the first use;
         //      the centre term v_i is the same for the K rows of a point: PT rows staged through LDS (Vs) instead of 160
         f32x4 ur[3][4];
@@ -256,7 +263,8 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd2_kernel(TnetFwdArgs p) {
             }
         }
         const bool haven = tn_tile(m + 1, Bc, p.N, PT, pt0n, nptsn);
-        if (haven) tile_rows(pt0n, nptsn, jnext);
+        int jnext[3], okn;
+        tile_rows(haven ? pt0n : pt0, haven ? nptsn : 0, jnext, okn);
         __syncthreads();                              // every wave is done reading the previous tile's H (and Vs)
         if (tid < PT * 16) *(f32x4*)(Vs + 4 * tid) = vstage;
         __syncthreads();
@@ -363,7 +371,8 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd2_kernel(TnetFwdArgs p) {
         }
         have = haven; pt0 = pt0n; npts = nptsn;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) jrow[u] = jnext[u];
+        for (int u = 0; u < 3; ++u) jraw[u] = jnext[u];
+        okm = okn; jbase = (pt0n / p.N) * p.N;
     }
     // per-workgroup BN2 partials: the two lane halves hold different rows of the same column
     ssum += __shfl_xor(ssum, 32, 64);
@@ -438,24 +447,31 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
     __syncthreads();
     // neighbour indices of the rows this thread gathers in a tile (-1: padding); tile m+1's are fetched under tile m's MFMA phase so
     // that only ONE dependent global round trip (the rows themselves) sits on a tile's critical path
-    auto tile_rows = [&](int t0, int np, int (&jr)[3]) {
-        const int base = (t0 / p.N) * p.N;
+    // The index loads are UNCONDITIONAL and their values stay raw until the next tile's gather uses them (okm: which of the three are real
+    // rows, jbase: the cloud's first point): `ok ? base + idx[..] : -1` makes the compiler wait for the load -- and for every row load issued
+    // before it -- right there, three memory round trips in a row per tile.
+    auto tile_rows = [&](int t0, int np, int (&jraw)[3], int& okm_) {
+        okm_ = 0;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int item = tid + 256 * u, row = item >> 2;
             const int pt = row / K, s = row - pt * K;
             const bool ok = item < TF_ROWS * 4 && pt < np;
+            okm_ |= ok ? 1 << u : 0;
 #ifdef TF_PROBE_NOGATHER
-            jr[u] = ok ? t0 + pt : -1;
+            jraw[u] = t0 + pt - (t0 / p.N) * p.N;
 #else
-            jr[u] = ok ? base + p.idx[(size_t)(t0 + pt) * K + s] : -1;
+            jraw[u] = p.idx[ok ? (size_t)(t0 + pt) * K + s : (size_t)0];
 #endif
         }
     };
     bool have = tn_tile(0, Bc, p.N, PT, pt0, npts);
-    int jrow[3] = {-1, -1, -1}, jnext[3] = {-1, -1, -1};
-    if (have) tile_rows(pt0, npts, jrow);
+    int jraw[3] = {0, 0, 0}, okm = 0, jbase = 0;
+    if (have) { tile_rows(pt0, npts, jraw, okm); jbase = (pt0 / p.N) * p.N; }
     for (int m = 0; have; ++m) {
+        int jrow[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) jrow[u] = (okm >> u) & 1 ? jbase + jraw[u] : -1;
         // ---- gather: 160 rows x 4 quarter rows (16 channels) of u_j over 256 threads, everything in flight before the first use;
         //      the centre term v_i is the same for the K rows of a point: PT rows staged through LDS (Vs) instead of 160
         f32x4 ur[3][4];
@@ -471,7 +487,8 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
             }
         }
         const bool haven = tn_tile(m + 1, Bc, p.N, PT, pt0n, nptsn);
-        if (haven) tile_rows(pt0n, nptsn, jnext);
+        int jnext[3], okn;
+        tile_rows(haven ? pt0n : pt0, haven ? nptsn : 0, jnext, okn);
         __syncthreads();                              // every wave is done reading the previous tile's H (and Vs)
         if (tid < PT * 16) *(f32x4*)(Vs + 4 * tid) = vstage;
         __syncthreads();
@@ -580,7 +597,8 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
         }
         have = haven; pt0 = pt0n; npts = nptsn;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) jrow[u] = jnext[u];
+        for (int u = 0; u < 3; ++u) jraw[u] = jnext[u];
+        okm = okn; jbase = (pt0n / p.N) * p.N;
     }
     // per-workgroup BN2 partials: the two lane halves hold different rows of the same column
     ssum += tn_xhalf_d(ssum, h);
