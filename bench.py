@@ -608,8 +608,8 @@ def main():
                                 "2*E*64*128 algorithmic FLOP, priced against the f32 MFMA peak (the kernel executes 6x that on the bf16 cores)"),
                   _kernel_entry("T-Net per-edge stage backward (tnet_edge_bwds_kernel: Gram form, dense split products on the bf16 cores; + prep / slab "
                                 "reduce / finish)", "mfma", rows[6], prof_steps,
-                                "reference FLOP 4*E*64*128, priced against the f32 MFMA peak (the Gram form executes 1,152 bf16 MFMAs per 128-row "
-                                "tile: 0.9x the reference FLOP count as bf16 piece products)")]
+                                "reference FLOP 4*E*64*128, priced against the f32 MFMA peak (the kernel executes 1,152 bf16 MFMAs per 128-row "
+                                "tile: 9x the reference FLOP count as bf16 piece products, 1.5x as six-product fp32 equivalents)")]
             out["roofline_kernels"] = [k for k in [f32_entry] + ks if k]
         else:
             out["roofline"] = {"bound": "mfma", "achieved": value * FLOP_PER_POINT / 1e12, "peak": PEAK_FP32_TFLOPS,
