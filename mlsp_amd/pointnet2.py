@@ -118,7 +118,8 @@ class _Interp3(Function):
 
 
 class _Group(Function):
-    """[xyz_j - new_xyz_i | feat_j] edge rows (pointnet_util.py:120-129); gradient flows to the features only."""
+    """[xyz_j - new_xyz_i | feat_j] edge rows (pointnet_util.py:120-129).  Gradients: features and both coordinate operands (the
+    reference gets them through autograd of `grouped_xyz - new_xyz`, :122-124; the neighbour indices carry none)."""
 
     @staticmethod
     def forward(ctx, xyz, new_xyz, feat, idx):
@@ -134,7 +135,7 @@ class _Group(Function):
         _lib.check(lib.mlsp_sa_group_fwd_f32(x.data_ptr(), x.stride(1), _lib.ptr(f), D, q.data_ptr(), q.stride(1), idx32.data_ptr(),
                                              B, N, S, ns, G.data_ptr(), _lib.stream()), "mlsp_sa_group_fwd_f32")
         ctx.save_for_backward(idx32)
-        ctx.dims = (B, N, S, ns, D)
+        ctx.dims = (B, N, S, ns, D, xyz.shape[-1], new_xyz.shape[-1])
         return G
 
     @staticmethod
@@ -142,19 +143,35 @@ class _Group(Function):
     def backward(ctx, dG):
         lib = _lib.load()
         (idx32,) = ctx.saved_tensors
-        B, N, S, ns, D = ctx.dims
-        if D == 0 or not ctx.needs_input_grad[2]:
+        B, N, S, ns, D, Cx, Cq = ctx.dims
+        need_x, need_q, need_f = ctx.needs_input_grad[0], ctx.needs_input_grad[1], D > 0 and ctx.needs_input_grad[2]
+        if not (need_x or need_q or need_f):
             return None, None, None, None
         dG = dG.contiguous()
         dev = dG.device
-        rev_off = torch.empty((B * N + 1,), dtype=torch.int32, device=dev)
-        rev_ent = torch.empty((B * S * ns,), dtype=torch.int32, device=dev)
-        _lib.check(lib.mlsp_group_reverse(idx32.data_ptr(), B, S, N, ns, rev_off.data_ptr(), rev_ent.data_ptr(), _lib.stream()),
-                   "mlsp_group_reverse")
-        dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
-        _lib.check(lib.mlsp_sa_group_bwd_f32(dG.data_ptr(), D, rev_off.data_ptr(), rev_ent.data_ptr(), B, N, S, ns, dfeat.data_ptr(),
-                                             _lib.stream()), "mlsp_sa_group_bwd_f32")
-        return None, None, dfeat, None
+        dxyz = dq = dfeat = None
+        if need_x or need_f:
+            rev_off = torch.empty((B * N + 1,), dtype=torch.int32, device=dev)
+            rev_ent = torch.empty((B * S * ns,), dtype=torch.int32, device=dev)
+            _lib.check(lib.mlsp_group_reverse(idx32.data_ptr(), B, S, N, ns, rev_off.data_ptr(), rev_ent.data_ptr(), _lib.stream()),
+                       "mlsp_group_reverse")
+        if need_f:
+            dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+            _lib.check(lib.mlsp_sa_group_bwd_f32(dG.data_ptr(), D, rev_off.data_ptr(), rev_ent.data_ptr(), B, N, S, ns, dfeat.data_ptr(),
+                                                 _lib.stream()), "mlsp_sa_group_bwd_f32")
+        if need_x:
+            # d xyz_j = sum of the coordinate columns over the groups j sits in: the same reverse-index gather, with the three
+            # coordinate columns standing where the kernel expects feature columns (rows [. . . | dx dy dz])
+            gx = torch.zeros((B * S * ns, 6), dtype=torch.float32, device=dev)
+            gx[:, 3:] = dG[:, :3]
+            d3 = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+            _lib.check(lib.mlsp_sa_group_bwd_f32(gx.data_ptr(), 3, rev_off.data_ptr(), rev_ent.data_ptr(), B, N, S, ns, d3.data_ptr(),
+                                                 _lib.stream()), "mlsp_sa_group_bwd_f32")
+            dxyz = d3 if Cx == 3 else torch.nn.functional.pad(d3, (0, Cx - 3))
+        if need_q:
+            d3 = -dG[:, :3].reshape(B, S, ns, 3).sum(2)       # every slot of a group subtracts its centre
+            dq = d3 if Cq == 3 else torch.nn.functional.pad(d3, (0, Cq - 3))
+        return dxyz, dq, dfeat, None
 
 
 class _SAFold(Function):
@@ -235,8 +252,6 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, knn=
     """pointnet_util.py:99-136: FPS centres, ball-query neighbourhoods, centred coordinates + features.
     Returns new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D] (+ grouped_xyz, fps_idx with returnfps)."""
     B, N, C = xyz.shape
-    if xyz.requires_grad:
-        raise NotImplementedError("gradients with respect to the coordinates are not built (the reference never needs them)")
     fps_idx = farthest_point_sample(xyz, npoint, start=fps_start)
     new_xyz = index_points(xyz, fps_idx)
     idx = knn_point(nsample, xyz, new_xyz) if knn else query_ball_point(radius, nsample, xyz, new_xyz)      # :116-120
@@ -285,9 +300,8 @@ class PointNetSetAbstraction(nn.Module):
             new_xyz, new_points = sample_and_group_all(xyz, points)
             S, ns = 1, xyz.shape[1]
         elif self.fold_first and _fold_supported(self.mlp_convs[0], self.nsample) and len(self.mlp_convs) > 1:
-            # sample_and_group (pointnet_util.py:99-136) without its output tensor: the first conv is folded onto the points
-            if xyz.requires_grad:
-                raise NotImplementedError("gradients with respect to the coordinates are not built (the reference never needs them)")
+            # sample_and_group (pointnet_util.py:99-136) without its output tensor: the first conv is folded onto the points (the
+            # coordinates' gradient flows through the two K = 3 products u and w of _fold_first_layer, like the features')
             S, ns = self.npoint, self.nsample
             fps_idx = farthest_point_sample(xyz, S, start=self.fps_start)
             new_xyz = index_points(xyz, fps_idx)

@@ -167,6 +167,74 @@ def test_set_abstraction_stack_config3_vs_oracle(dev):
     assert not bad, bad
 
 
+# ----------------------------------------------------------------------------- round 4: gradients with respect to the coordinates
+@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("B,N,S,radius,ns,D,mlp", [(3, 256, 48, 0.45, 16, 5, [32, 64]), (2, 200, 40, 0.5, 12, 0, [16, 32, 64])])
+def test_set_abstraction_coordinate_gradients_vs_oracle(dev, fold, B, N, S, radius, ns, D, mlp):
+    """d loss / d xyz of a set-abstraction layer (pointnet_util.py:120-124: `grouped_xyz - new_xyz` is differentiable in both operands, the
+    sampled centres are rows of xyz; FPS / ball-query indices carry no gradient) on both paths -- the grouped tensor (_Group) and the
+    folded first layer (the two K = 3 products) -- against the autograd of oracle/ref_sa_cpu.sa_forward in float64 on the same indices."""
+    from mlsp_amd import pointnet2 as p2
+    torch.manual_seed(3)
+    xyz = torch.rand(B, N, 3) * 2 - 1
+    feat = torch.randn(B, N, D) if D else None
+    layer = p2.PointNetSetAbstraction(S, radius, ns, 3 + D, mlp, False)
+    with torch.no_grad():
+        for bn in layer.mlp_bns:
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    start = torch.arange(B) % N
+    cfg = dict(npoint=S, radius=radius, nsample=ns, D=D, mlp=mlp, group_all=False)
+    wgt = torch.randn(B, S, mlp[-1])
+
+    def oracle(dtype):
+        pr = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in layer.named_parameters()}
+        bf = {k: v.detach().clone().to(dtype) for k, v in layer.named_buffers() if not k.endswith("num_batches_tracked")}
+        x = xyz.detach().clone().to(dtype).requires_grad_(True)
+        f = feat.detach().clone().to(dtype).requires_grad_(True) if D else None
+        _, out, fps_idx, gidx, _ = sa.sa_forward(pr, bf, cfg, x, f, start)
+        (out * wgt.to(dtype)).sum().backward()
+        return out.detach(), x.grad, (f.grad if D else None), fps_idx, gidx
+
+    o64, dx64, df64, fps64, gidx64 = oracle(torch.float64)
+    o32, dx32, _, fps32, gidx32 = oracle(torch.float32)
+    layer = layer.to(dev).train()
+    layer.fold_first, layer.fps_start = fold, start
+    if not fold:
+        layer.fuse_max = False
+    gx = xyz.detach().clone().to(dev).requires_grad_(True)
+    gf = feat.detach().clone().to(dev).requires_grad_(True) if D else None
+    new_xyz, out = layer(gx, gf)
+    assert torch.equal(fps32, fps64) and torch.equal(gidx32, gidx64)            # the float64 oracle groups the same points
+    np.testing.assert_allclose(out.detach().cpu().numpy(), o32.numpy(), rtol=1e-3, atol=1e-3)
+    (out * wgt.to(dev)).sum().backward()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+    hip, yard = rel(gx.grad.double().cpu().numpy(), dx64.numpy()), rel(dx32.double().numpy(), dx64.numpy())
+    print("d xyz rel-L2 vs float64: HIP %.2e | fp32 oracle %.2e (fold_first=%s)" % (hip, yard, fold))
+    assert hip < max(2e-3, 5.0 * yard), (hip, yard)
+    assert gx.grad.abs().max().item() > 0
+    if D:
+        assert rel(gf.grad.double().cpu().numpy(), df64.numpy()) < 2e-3
+
+
+def test_group_coordinate_gradients_closed_form(dev):
+    """_Group alone: d/d xyz and d/d new_xyz of sum(W * [xyz_j - c_i | f_j]) are a scatter of W's coordinate columns onto the grouped points
+    and minus their per-group sums (pointnet_util.py:120-124)."""
+    from mlsp_amd import pointnet2 as p2
+    torch.manual_seed(5)
+    B, N, S, ns, D = 2, 120, 30, 9, 4
+    xyz = (torch.rand(B, N, 3) * 2 - 1).to(dev).requires_grad_(True)
+    ctr = (torch.rand(B, S, 3) * 2 - 1).to(dev).requires_grad_(True)
+    feat = torch.randn(B, N, D).to(dev).requires_grad_(True)
+    idx = torch.randint(0, N, (B, S, ns)).to(dev)
+    W = torch.randn(B * S * ns, 3 + D).to(dev)
+    (p2._Group.apply(xyz, ctr, feat, idx) * W).sum().backward()
+    x2, c2, f2 = (t.detach().clone().requires_grad_(True) for t in (xyz, ctr, feat))
+    G = torch.cat([p2.index_points(x2, idx) - c2[:, :, None], p2.index_points(f2, idx)], -1).reshape(B * S * ns, 3 + D)
+    (G * W).sum().backward()
+    for got, want in ((xyz.grad, x2.grad), (ctr.grad, c2.grad), (feat.grad, f2.grad)):
+        assert (got - want).abs().max().item() < 1e-4 * (want.abs().max().item() + 1.0)
+
+
 # ----------------------------------------------------------------------------- round 2: knn grouping, multi-scale grouping, feature propagation
 from test_sa_oracle_cpu import split_state
 
