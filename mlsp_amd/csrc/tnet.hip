@@ -2006,20 +2006,20 @@ __global__ __launch_bounds__(64) void tnet_bwd_xmom_kernel(const float* __restri
 #pragma unroll
             for (int b = 0; b < 4; ++b) aj[a][b] = 0.f;
         for (int s0 = 0; s0 < k; s0 += 16) {                              // sixteen neighbours' coordinates in flight
+            // unconditional loads (clamped slot / coordinate, masked afterwards): a load under a branch whose other side writes the
+            // register makes the compiler wait for it on the spot -- sixteen round trips in a row instead of one
             int j[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) j[u] = s0 + u < k ? base + idx[(size_t)i * k + s0 + u] : -1;
-            float v[16][3];
+            for (int u = 0; u < 16; ++u) j[u] = idx[(size_t)i * k + min(s0 + u, k - 1)];
+            float v[16][4];
 #pragma unroll
             for (int u = 0; u < 16; ++u)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) v[u][c] = (j[u] >= 0 && c < C) ? x[(size_t)j[u] * ldx + c] : 0.f;
-            float v3[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v3[u] = (j[u] >= 0 && C > 3) ? x[(size_t)j[u] * ldx + 3] : 0.f;
+                for (int c = 0; c < 4; ++c) v[u][c] = x[(size_t)(base + j[u]) * ldx + min(c, C - 1)];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const float vv[4] = {v[u][0], v[u][1], v[u][2], v3[u]};
+                const bool on = s0 + u < k;
+                const float vv[4] = {on ? v[u][0] : 0.f, (on && C > 1) ? v[u][1] : 0.f, (on && C > 2) ? v[u][2] : 0.f, (on && C > 3) ? v[u][3] : 0.f};
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     xb[a] += vv[a];

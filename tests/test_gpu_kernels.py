@@ -831,7 +831,8 @@ def test_chamfer_edge_cases(dev):
 # ----------------------------------------------------------------------------- fused T-Net per-edge stage
 @pytest.mark.parametrize("B,N,k,training", [(2, 128, 20, True), (3, 50, 20, True), (1, 77, 7, True), (2, 64, 20, False),
                                             (2, 96, 24, True), (2, 80, 32, True), (2, 100, 40, True), (1, 130, 48, True),
-                                            (8, 70, 16, True)])
+                                            (8, 70, 16, True), (2, 90, 8, True), (3, 66, 10, True), (1, 140, 64, True),
+                                            (16, 33, 12, True)])
 def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
     """tnet.hip (LDS-resident gather + MFMA) against the reference's op sequence in torch on the CPU:
     graph feature -> conv 6->64 + BN + LReLU -> conv 64->128 + BN + LReLU -> max over k."""
@@ -891,8 +892,9 @@ def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
 
 @pytest.mark.parametrize("B,N,k", [(8, 512, 20), (4, 512, 40)])
 def test_tnet_backward_gram_form_vs_round1_kernel(dev, B, N, k):
-    """Two independent backward kernels of the fused stage: the Gram form (dZ never formed, register-indexed sparse part) and the
-    round-1 kernel (three MFMA products on the dZ tile, MLSP_TNET_BWD_OLD=1; read once per process, hence the subprocesses)."""
+    """Three independent backward kernels of the fused stage: the dense split-product Gram form (the default), the f32 Gram form with the
+    register-indexed sparse part (MLSP_TNET_BWD_F32=1) and the round-1 kernel (three MFMA products on the dZ tile, MLSP_TNET_BWD_OLD=1);
+    the switches are read once per process, hence the subprocesses."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("cmp_tnet_bwd", os.path.join(os.path.dirname(__file__), "..", "tools", "cmp_tnet_bwd.py"))
     mod = importlib.util.module_from_spec(spec)

@@ -1,6 +1,8 @@
-"""Gradients of the fused T-Net per-edge stage: the Gram-form backward (tnet_edge_bwdg_kernel) against the round-1 kernel that forms
-the dZ tile (MLSP_TNET_BWD_OLD=1).  The switch is read once per process, so each variant runs in its own process (GPU box).
-Usage: python tools/cmp_tnet_bwd.py [B N k]  -> one line per gradient: max |new - old| / max |old|."""
+"""Gradients of the fused T-Net per-edge stage from its three independent backward kernels: the dense split-product Gram form
+(tnet_edge_bwds_kernel, the default), the f32 Gram form with the register-indexed sparse half (tnet_edge_bwdg_kernel,
+MLSP_TNET_BWD_F32=1) and the round-1 kernel that forms the dZ tile (MLSP_TNET_BWD_OLD=1).  The switches are read once per process, so
+each variant runs in its own process (GPU box).
+Usage: python tools/cmp_tnet_bwd.py [B N k]  -> one line per gradient: max |variant - old| / max |old| for both Gram forms."""
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -29,11 +31,16 @@ def compare(B=32, N=1024, k=20):
         child = os.path.join(d, "child.py")
         open(child, "w").write(CHILD)
         outs = []
-        for tag, extra in (("new", {}), ("old", {"MLSP_TNET_BWD_OLD": "1"})):
+        for tag, extra in (("split", {}), ("f32", {"MLSP_TNET_BWD_F32": "1"}), ("old", {"MLSP_TNET_BWD_OLD": "1"})):
             f = os.path.join(d, tag + ".pt")
             subprocess.check_call([sys.executable, child, ROOT, f, str(B), str(N), str(k)], env=dict(os.environ, **extra))
             outs.append(torch.load(f))
-    return {n: ((p - q).abs().max() / q.abs().max()).item() for n, p, q in zip(NAMES, *outs)}
+    split, f32, old = outs
+    res = {}
+    for n, a, b, q in zip(NAMES, split, f32, old):
+        res[n] = ((a - q).abs().max() / q.abs().max()).item()
+        res[n + " (f32 Gram form)"] = ((b - q).abs().max() / q.abs().max()).item()
+    return res
 
 
 if __name__ == "__main__":
