@@ -465,6 +465,12 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
 #endif
         }
     };
+#ifdef TF3_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define TF3_STAMP(i_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[i_] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define TF3_STAMP(i_)
+#endif
     bool have = tn_tile(0, Bc, p.N, PT, pt0, npts);
     int jraw[3] = {0, 0, 0}, okm = 0, jbase = 0;
     if (have) { tile_rows(pt0, npts, jraw, okm); jbase = (pt0 / p.N) * p.N; }
@@ -489,9 +495,12 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
         const bool haven = tn_tile(m + 1, Bc, p.N, PT, pt0n, nptsn);
         int jnext[3], okn;
         tile_rows(haven ? pt0n : pt0, haven ? nptsn : 0, jnext, okn);
+        TF3_STAMP(0);
         __syncthreads();                              // every wave is done reading the previous tile's H (and Vs)
+        TF3_STAMP(1);
         if (tid < PT * 16) *(f32x4*)(Vs + 4 * tid) = vstage;
         __syncthreads();
+        TF3_STAMP(2);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int item = tid + 256 * u, row = item >> 2, qt = item & 3;
@@ -516,7 +525,9 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
                 }
             }
         }
+        TF3_STAMP(3);
         __syncthreads();
+        TF3_STAMP(4);
         // ---- Z = H W2^T for this wave's 32 columns, one row block after the other; the register epilogue of block b - 1 (per point
         //      max / min over its K rows with the first arg-max, BN2 sums: ~6 vector instructions per element) is issued BETWEEN the
         //      MFMAs of block b.  A vector instruction that has to squeeze in between another wave's back-to-back MFMAs waits about one
@@ -581,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        TF3_STAMP(5);
 #pragma unroll
         for (int r = 0; r < 16; ++r) epi(4, r);
         ssum += s1; ssq += s2;
@@ -595,6 +607,7 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
                 p.argsel[(size_t)(pt0 + q) * TN_C2 + o] = (uint8_t)bslot[q];
             }
         }
+        TF3_STAMP(6);
         have = haven; pt0 = pt0n; npts = nptsn;
 #pragma unroll
         for (int u = 0; u < 3; ++u) jraw[u] = jnext[u];
@@ -607,7 +620,16 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
         p.part[((size_t)blockIdx.x * 2 + 0) * TN_C2 + o] = ssum;
         p.part[((size_t)blockIdx.x * 2 + 1) * TN_C2 + o] = ssq;
     }
+#ifdef TF3_STAMPS
+    if (tid == 0) {                                            // diagnostic build only: overwrites this workgroup's BN2 partial
+        unsigned long long* o2 = (unsigned long long*)(p.part + (size_t)blockIdx.x * 2 * TN_C2);
+        o2[0] = 0x5446335354414d50ull;
+        for (int q = 0; q < 8; ++q) o2[1 + q] = tsum[q];
+    }
+#endif
 }
+#undef TF3_STAMP
+
 
 // t = act(scale2 * zsel + shift2)        [P][128]
 __global__ __launch_bounds__(256) void tnet_out_kernel(const float* __restrict__ zsel, const float* __restrict__ bn2, size_t total,
