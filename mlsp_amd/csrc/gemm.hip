@@ -930,6 +930,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
         soa = min(soa + sta, enda); sob = min(sob + stb, endb);      // tile t+2 (past the end: a harmless repeat of the last tile)
         uint32_t pk0[2], pk1[2], pk2[2];
         float r0, r1, a1;
+#ifdef SX_XF_ABLATION
+        // ablation (tools/x6/xf_ablation.sh): scale * x + shift and a LeakyReLU as max(t, slope t) on every A element with run-time identity
+        // parameters (1, 0, 1): the results do not change, the split stage carries the three vector instructions per element an operand
+        // transform would add (its per-K-tile scale / shift loads and the dropout hash are NOT included: a lower bound)
+        const float xf_sc = p.x_inv_keep, xf_sh = p.x_slope, xf_sl = p.x_inv_keep;
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (WM == 2) {
 #include "gemm_split_body_wm2.inc"

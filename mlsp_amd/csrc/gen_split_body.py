@@ -21,6 +21,11 @@ def micro(m):
     x0, x1 = f"raw[{qd}][{2 * hh}]", f"raw[{qd}][{2 * hh + 1}]"
     L = []
     if ms == 0:
+        if qd < NQA:                  # ablation build only (-DSX_XF_ABLATION, tools/x6/xf_ablation.sh): the vector cost of an operand transform on A
+            L += ["#ifdef SX_XF_ABLATION",
+                  f"{x0} = fmaf({x0}, xf_sc, xf_sh); {x1} = fmaf({x1}, xf_sc, xf_sh);",
+                  f"{x0} = fmaxf({x0}, {x0} * xf_sl); {x1} = fmaxf({x1}, {x1} * xf_sl);",
+                  "#endif"]
         L += [f"pk0[{hh}] = sx_cvt_pk({x0}, {x1});",
               f"a1 = __uint_as_float(pk0[{hh}] & 0xffff0000u);",
               f"r0 = {x0} - __uint_as_float(pk0[{hh}] << 16);"]
