@@ -26,14 +26,15 @@
 //     norms of what is multiplied); the canonical value's own rounding on the RAW coordinates is budgeted separately:
 //     E = 2^-13 (xc_q + Xc) + (C + 4) 2^-23 (xx_q + Xx), xc = centred, xx = raw squared norms.
 //   * Exactness: a survivor whose pd' is farther than 2 E from its neighbours in rank (Xc = the largest centred norm among the query's
-//     survivors) has its rank decided by pd' alone.  One lane per query sorts the query's <= 32 survivors in registers (bitonic network),
+//     survivors) has its rank decided by pd' alone.  Four lanes per query sort the query's <= 32 survivors in registers (bitonic network, the
+//     exchanges at distance 8 / 16 through v_permlane16 / 32_swap),
 //     flags the gaps within 2 E, the flagged (~10-40 %) get their canonical distance from an fmaf chain over the fp32 rows (pairs packed
 //     densely over the wave), and odd-even passes under the full order (value desc, index asc) settle the flagged runs -- safe, because
 //     an unflagged value differs from its neighbours by more than 2 E and an exact one from its approximation by at most E.  Queries
 //     with more than 32 survivors (or exact lists) take a counting path with the same logic.
 //   * Any list overflow (massive ties: more than 24 survivors in a quarter of a query's candidates) or NaN / inf bound sends the whole
 //     workgroup through an exact path: f32 MFMA tiles from the fp32 rows, per-lane sorted top-k lists in registers, the same final.
-// Measured on MI355X (B = 32, N = 1024, k = 20, one call incl. the prep kernel; uniform random clouds): C = 64 74 us (v5 113), C = 128 105 us
+// Measured on MI355X (B = 32, N = 1024, k = 20, one call incl. the prep kernel; uniform random clouds): C = 64 71 us (v5 113), C = 128 103 us
 // (v5 176), N = 2048 C = 64 95 us (v5 176); C = 3 54 us (v5 49: the selection phases dominate when the sweeps are trivial, so C <= 16 stays
 // on v5).  Inside the DGCNN step (features of a 3-D manifold: small gaps between neighbours relative to the norms, 2-3x more ambiguous
 // pairs): 89 / 129 us against 118 / 165.  Phase cycles per wave at C = 64, two waves per SIMD (tools/knn6_stamps.py): sweeps 17 k + 27 k,
@@ -435,14 +436,16 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
         }
     };
 #endif
-    // ---- fast final (every query of the group has at most 32 survivors -- the normal case): ONE LANE PER QUERY.  Wave (qg, ch) finishes queries
-    // ch * 16 .. + 15 of its group; lane l serves query l & 15 (the four lanes of a query mirror each other).  The lane pulls its query's survivors into
-    // registers, sorts them by pd' (bitonic network, 240 compare-exchanges, no memory traffic), flags the ones whose gap to a neighbour in
-    // rank is within 2 E, gets their canonical distances (all flagged pairs of the wave packed densely over its lanes: fmaf chains over the fp32
-    // rows), and settles the order inside the flagged runs with odd-even passes under the full order (value desc,
-    // index asc).  An unflagged survivor never moves: its gaps exceed 2 E.
+    // ---- fast final (every query of the group has at most 32 survivors -- the normal case): FOUR LANES PER QUERY.  Wave (qg, ch) finishes queries
+    // ch * 16 .. + 15 of its group; lane l serves query l & 15 and holds rank positions 8 m .. 8 m + 7 of its 32 (m = l >> 4).  The four lanes pull the
+    // query's survivors into registers and sort them by pd' with a bitonic network whose exchanges at distance 8 / 16 cross lanes (v_permlane16 /
+    // 32_swap, no LDS): 72 compare-exchanges per lane instead of the 240 of one lane per query.  Then as before: the ones whose gap to a neighbour in
+    // rank is within 2 E are flagged, get their canonical distances (all flagged pairs of the wave packed densely over its lanes: fmaf chains over
+    // the fp32 rows), and the flagged runs are settled with odd-even passes under the full order (value desc, index asc); the pair across a lane
+    // boundary goes through two shuffles.  An unflagged survivor never moves: its gaps exceed 2 E.
     {
-        const int qlc = ch * 16 + (lane & 15);
+        const int ql = lane & 15, m = lane >> 4;
+        const int qlc = ch * 16 + ql;
         const int qq = qg * 32 + qlc, qrow = chunk * 128 + qq;
         const k6i32x4 c4 = *(const k6i32x4*)(cnts + qq * 4);
         const int p1 = c4[0], p2 = p1 + c4[1], p3 = p2 + c4[2], n = p3 + c4[3];
@@ -458,45 +461,89 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
             const char* Lb1 = list_at(qlc, 1);
             const char* Lb2 = list_at(qlc, 2);
             const char* Lb3 = list_at(qlc, 3);
-            float pv[32];
-            int jv[32];
+            float pv[8];
+            int jv[8];
 #pragma unroll
-            for (int e = 0; e < 32; ++e) {
+            for (int i = 0; i < 8; ++i) {
+                const int e = 8 * m + i;
                 const int t = (e >= p1) + (e >= p2) + (e >= p3);
                 const char* Lt = t == 0 ? Lb0 : t == 1 ? Lb1 : t == 2 ? Lb2 : Lb3;
                 const int pos = e - (t == 0 ? 0 : t == 1 ? p1 : t == 2 ? p2 : p3);
                 const k6u32x2 v = *(const k6u32x2*)(Lt + (e < n ? pos : 0) * 8);
-                pv[e] = e < n ? __int_as_float((int)v[0]) : -INFINITY;
-                jv[e] = e < n ? (int)v[1] : 0x7fffffff;
+                pv[i] = e < n ? __int_as_float((int)v[0]) : -INFINITY;
+                jv[i] = e < n ? (int)v[1] : 0x7fffffff;
             }
+            // value of the same register in lane ^ 16 / lane ^ 32
+            auto x16 = [&](unsigned v) -> unsigned { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (m & 1) ? r[0] : r[1]; };
+            auto x32 = [&](unsigned v) -> unsigned { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (m & 2) ? r[0] : r[1]; };
+            auto cex_local = [&](int jj, bool desc) {          // positions a, a ^ jj inside the lane; desc: the larger value to the lower position
 #pragma unroll
-            for (int k2 = 2; k2 <= 32; k2 <<= 1)
+                for (int a = 0; a < 8; ++a) {
+                    const int c = a ^ jj;
+                    if (c > a) {
+                        const bool sw = desc ? pv[a] < pv[c] : pv[a] > pv[c];
+                        const float ta = sw ? pv[c] : pv[a], tc = sw ? pv[a] : pv[c];
+                        const int ja = sw ? jv[c] : jv[a], jc = sw ? jv[a] : jv[c];
+                        pv[a] = ta; pv[c] = tc; jv[a] = ja; jv[c] = jc;
+                    }
+                }
+            };
+            auto cex_cross = [&](bool by32, bool desc) {       // positions 8 m + i and 8 (m ^ 1 | m ^ 2) + i: the lane with the lower m is the lower position
+                const bool low = by32 ? (m & 2) == 0 : (m & 1) == 0;
 #pragma unroll
-                for (int jj = k2 >> 1; jj > 0; jj >>= 1)
+                for (int i = 0; i < 8; ++i) {
+                    const float ov = __uint_as_float(by32 ? x32(__float_as_uint(pv[i])) : x16(__float_as_uint(pv[i])));
+                    const int oj = (int)(by32 ? x32((unsigned)jv[i]) : x16((unsigned)jv[i]));
+                    const bool sw = low ? (desc ? pv[i] < ov : pv[i] > ov) : (desc ? ov < pv[i] : ov > pv[i]);
+                    pv[i] = sw ? ov : pv[i]; jv[i] = sw ? oj : jv[i];
+                }
+            };
+            // bitonic network over positions a = 8 m + i; a pair keeps the larger value at the lower position iff (a & k2) == 0
 #pragma unroll
-                    for (int a = 0; a < 32; ++a) {
+            for (int a = 0; a < 8; a += 2) {                    // k2 = 2
+                const bool desc = (a & 2) == 0;
+                const bool sw = desc ? pv[a] < pv[a + 1] : pv[a] > pv[a + 1];
+                const float ta = sw ? pv[a + 1] : pv[a], tc = sw ? pv[a] : pv[a + 1];
+                const int ja = sw ? jv[a + 1] : jv[a], jc = sw ? jv[a] : jv[a + 1];
+                pv[a] = ta; pv[a + 1] = tc; jv[a] = ja; jv[a + 1] = jc;
+            }
+            {                                                   // k2 = 4: jj = 2, 1; direction by bit 2 of the position
+#pragma unroll
+                for (int jj = 2; jj > 0; jj >>= 1)
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) {
                         const int c = a ^ jj;
                         if (c > a) {
-                            const bool desc = (a & k2) == 0;               // this pair keeps the larger value at the lower position
+                            const bool desc = (a & 4) == 0;
                             const bool sw = desc ? pv[a] < pv[c] : pv[a] > pv[c];
                             const float ta = sw ? pv[c] : pv[a], tc = sw ? pv[a] : pv[c];
                             const int ja = sw ? jv[c] : jv[a], jc = sw ? jv[a] : jv[c];
                             pv[a] = ta; pv[c] = tc; jv[a] = ja; jv[c] = jc;
                         }
                     }
+            }
+            { const bool d8 = (m & 1) == 0; cex_local(4, d8); cex_local(2, d8); cex_local(1, d8); }                      // k2 = 8
+            { const bool d16 = (m & 2) == 0; cex_cross(false, d16); cex_local(4, d16); cex_local(2, d16); cex_local(1, d16); }   // k2 = 16
+            { cex_cross(true, true); cex_cross(false, true); cex_local(4, true); cex_local(2, true); cex_local(1, true); }       // k2 = 32
             // flag: gap to the next survivor in rank not provably larger than 2 E (dead tail entries: -inf, never flagged)
+            const float nxt0 = __shfl(pv[0], lane + 16, 64), prv7 = __shfl(pv[7], lane - 16, 64);
             unsigned amb = 0u;
 #pragma unroll
-            for (int a = 0; a < 31; ++a) amb |= (a + 1 < n && !(pv[a] - pv[a + 1] > E2)) ? (3u << a) : 0u;
+            for (int i = 0; i < 7; ++i) amb |= (8 * m + i + 1 < n && !(pv[i] - pv[i + 1] > E2)) ? (3u << i) : 0u;
+            amb |= (m < 3 && 8 * m + 8 < n && !(pv[7] - nxt0 > E2)) ? 0x80u : 0u;
+            amb |= (m > 0 && 8 * m < n && !(prv7 - pv[0] > E2)) ? 1u : 0u;
 #if defined(K6_PROBE) && K6_PROBE == 4
             amb = 0u;
 #endif
-            const int nflag = __builtin_popcount(amb);
-            unsigned* slots = wlbase + wave * 512 + (lane & 15) * 32;      // [32] candidate index in, canonical distance out
+            const int nfl = __builtin_popcount(amb);           // this lane's flagged entries; the query's: the four lanes' sum
+            const int f0 = __shfl(nfl, ql, 64), f1 = __shfl(nfl, ql + 16, 64), f2 = __shfl(nfl, ql + 32, 64), f3 = __shfl(nfl, ql + 48, 64);
+            const int nflag = f0 + f1 + f2 + f3;
+            const int foff = m == 0 ? 0 : m == 1 ? f0 : m == 2 ? f0 + f1 : f0 + f1 + f2;
+            unsigned* slots = wlbase + wave * 512 + ql * 32 + foff;      // this lane's part of the query's [32]: candidate index in, canonical distance out
             {
                 int c = 0;
 #pragma unroll
-                for (int a = 0; a < 32; ++a) {
+                for (int a = 0; a < 8; ++a) {
                     if ((amb >> a) & 1u) { slots[c] = (unsigned)jv[a]; ++c; }
                 }
             }
@@ -507,7 +554,7 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
             __builtin_amdgcn_wave_barrier();
 #ifdef K6_STAMP
             const long long f0_ = (long long)__builtin_amdgcn_s_memtime();
-            st_items += nflag; st_flushes = fmaxw;
+            st_items += nfl; st_flushes = fmaxw;
 #endif
             // Canonical distances of the flagged pairs, DENSELY packed over the wave's lanes: pair i of the wave = (query, slot) by a prefix sum of
             // the 16 queries' flag counts (the counts differ a lot from query to query: slot-by-slot rounds ran at a third of the lanes).  Both rows
@@ -564,7 +611,7 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
             {
                 int c = 0;
 #pragma unroll
-                for (int a = 0; a < 32; ++a) {
+                for (int a = 0; a < 8; ++a) {
                     if ((amb >> a) & 1u) { pv[a] = __int_as_float((int)slots[c]); ++c; }
                 }
             }
@@ -573,23 +620,40 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
                 for (int pass = 0; pass < 32; ++pass) {
                     bool moved = false;
 #pragma unroll
-                    for (int par = 0; par < 2; ++par)
+                    for (int a = 0; a < 7; a += 2) {             // positions (8 m + a, + 1), a even: inside the lane
+                        const bool sw = k6_beats(pv[a + 1], jv[a + 1], pv[a], jv[a]);
+                        const float ta = sw ? pv[a + 1] : pv[a], tc = sw ? pv[a] : pv[a + 1];
+                        const int ja = sw ? jv[a + 1] : jv[a], jc = sw ? jv[a] : jv[a + 1];
+                        pv[a] = ta; pv[a + 1] = tc; jv[a] = ja; jv[a + 1] = jc;
+                        moved |= sw;
+                    }
 #pragma unroll
-                        for (int a = par; a < 31; a += 2) {
-                            const bool sw = k6_beats(pv[a + 1], jv[a + 1], pv[a], jv[a]);
-                            const float ta = sw ? pv[a + 1] : pv[a], tc = sw ? pv[a] : pv[a + 1];
-                            const int ja = sw ? jv[a + 1] : jv[a], jc = sw ? jv[a] : jv[a + 1];
-                            pv[a] = ta; pv[a + 1] = tc; jv[a] = ja; jv[a + 1] = jc;
-                            moved |= sw;
-                        }
+                    for (int a = 1; a < 7; a += 2) {
+                        const bool sw = k6_beats(pv[a + 1], jv[a + 1], pv[a], jv[a]);
+                        const float ta = sw ? pv[a + 1] : pv[a], tc = sw ? pv[a] : pv[a + 1];
+                        const int ja = sw ? jv[a + 1] : jv[a], jc = sw ? jv[a] : jv[a + 1];
+                        pv[a] = ta; pv[a + 1] = tc; jv[a] = ja; jv[a + 1] = jc;
+                        moved |= sw;
+                    }
+                    {                                            // the odd pair across the lane boundary: (8 m + 7, 8 (m + 1))
+                        const float nv = __shfl(pv[0], lane + 16, 64), pvv = __shfl(pv[7], lane - 16, 64);
+                        const int nj = __shfl(jv[0], lane + 16, 64), pj = __shfl(jv[7], lane - 16, 64);
+                        const bool swh = m < 3 && k6_beats(nv, nj, pv[7], jv[7]);       // the next lane's first entry beats my last one
+                        const bool swl = m > 0 && k6_beats(pv[0], jv[0], pvv, pj);      // my first entry beats the previous lane's last one
+                        pv[7] = swh ? nv : pv[7]; jv[7] = swh ? nj : jv[7];
+                        pv[0] = swl ? pvv : pv[0]; jv[0] = swl ? pj : jv[0];
+                        moved |= swh | swl;
+                    }
                     if (!__any(moved)) break;
                 }
             }
-            if (lane < 16) {
+            {
                 int* out = idx + ((size_t)b * N + qrow) * k;
 #pragma unroll
-                for (int a = 0; a < K6_KMAX; ++a)
-                    if (a < k && a < n) out[a] = jv[a];
+                for (int a = 0; a < 8; ++a) {
+                    const int pos = 8 * m + a;
+                    if (pos < k && pos < n) out[pos] = jv[a];
+                }
             }
 #ifdef K6_STAMP
             put_stamps();
