@@ -1381,8 +1381,6 @@ __global__ __launch_bounds__(512) void tnet_edge_bwds_kernel(
     // gather role: 4 threads per tile row, 16 channels each
     const int grow = tid >> 2, gq = tid & 3;
     const int gpt = grow / k, gslot = grow - gpt * k;
-    const float rslope = 1.0f / slope;
-    (void)rslope;
     const int kinv = 65536 / k + 1;                            // (r * kinv) >> 16 == r / k for r < 128, 8 <= k <= 64
 
     // Every global load of the walk is UNCONDITIONAL (clamped addresses, masks applied where the value is consumed): a load under a
