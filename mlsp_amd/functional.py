@@ -650,7 +650,9 @@ class _EdgeConv(Function):
         s1 = torch.empty((P, Cout), dtype=torch.float32, device=dev)
         argsel = torch.empty((P, Cout), dtype=torch.uint8, device=dev)
         bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev)
-        keep_wd = torch.is_grad_enabled() and xp.requires_grad          # the folded weight, kept for the backward's dgrad
+        # the folded weight, kept for the backward's dgrad (grad mode is OFF inside Function.forward: ctx.needs_input_grad is what tells
+        # whether a backward will want dx; `torch.is_grad_enabled() and ...` here never kept it and the backward rebuilt it, 4 launches per step)
+        keep_wd = bool(ctx.needs_input_grad[0])
         Wd = torch.empty((2 * Cout, C), dtype=torch.float32, device=dev) if keep_wd else None
         ws, wsn = _lib.workspace(dev, P, C, 2 * Cout)
         _lib.check(lib.mlsp_edgeconv_fwd_f32(
