@@ -45,7 +45,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 8
+#define MLSP_ABI_VERSION 9
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -121,24 +121,32 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
  * Backward: dx_accumulate != 0 adds the input gradient to what dX already holds (beta = 1 in the dgrad epilogue): the four consumers
  * of the concatenated encoder features (conv5 and the three heads, Models.py:132,156-160) sum their gradients in one buffer instead of
  * three 67 MB element-wise adds.
- * Chained layers (the output of one Linear+BN+act layer feeds exactly one other such layer: conv1 -> conv2 -> conv3 of the heads,
- * Models.py:192-196): the producer is called with Z == NULL (only Y, the pre-BN output, and bn_save are written: the streaming
- * BN+act pass is skipped), the consumer through mlsp_pointmlp_fwd_chain_f32 / mlsp_pointmlp_bwd_chain_f32 with Xpre = the producer's
- * Y [M][Cin], in_bn_save = its bn_save [4][Cin] and its act / slope / dropout (p already 0 in eval mode) / seed: act(Xpre * scale +
- * shift) and the dropout mask are applied while the GEMM stages the operand (forward: A rows; wgrad: the k-major B operand), or by one
- * streaming pass into the workspace for shapes outside the interior-tile path.  The gradients the consumer returns in dX are with
- * respect to the ACTIVATED input, i.e. exactly the dZ the producer's mlsp_pointmlp_bwd_f32 expects. */
+ * Chained layers (the output of a Linear+BN+act layer feeds only other such layers: conv1 -> conv2 -> conv3 -> conv4 of the heads,
+ * Models.py:192-197): the producer is called with Z == NULL (only Y, the pre-BN output, and bn_save are written: the streaming
+ * BN+act pass is skipped), the consumer through mlsp_pointmlp_fwd_chain_f32 / mlsp_pointmlp_bwd_chain_f32 with Xpre pointing at its
+ * input columns inside the producer's Y and an mlsp_defer_t that describes the producer: act(Xpre * scale + shift) and the dropout mask
+ * are applied while the GEMM stages the operand (forward: A rows; wgrad: the k-major B operand) -- on the split-product kernel, the f32
+ * MFMA kernel and the streaming kernels of the 3 / 16-channel output layers alike, bit-identical to the product over the materialised
+ * tensor -- or by one streaming pass into the workspace for shapes outside those kernels.  The gradients the consumer returns in dX are
+ * with respect to the ACTIVATED input, i.e. exactly the dZ the producer's backward expects. */
+typedef struct mlsp_defer {
+    const float* bn_save;  /* the producer's [4][ld]: scale | shift | mean | invstd (device) */
+    int ld;                /* the producer's width: row pitch of its Y and of bn_save; its dropout stream is indexed row * ld + column */
+    int col;               /* first column of THIS consumer's input inside the producer's Y (Xpre == Y + col) */
+    int act;               /* the producer's activation on these columns: 0 none, 1 ReLU, 2 LeakyReLU(slope) */
+    float slope;
+    float p_drop;          /* its dropout rate on these columns (0: none / eval mode) */
+    uint64_t seed;         /* ... and the seed of that dropout stream */
+} mlsp_defer_t;
 int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                           const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                           float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
                           uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
-int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope, float in_p_drop,
-                                uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const mlsp_defer_t* in, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                                 const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                                 float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
                                 uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
-int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope,
-                                float in_p_drop, uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const mlsp_defer_t* in, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                                 const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                                 int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
                                 float* dgbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
@@ -184,17 +192,21 @@ int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int
  * dropout switch (0 / 1; rate p_drop, counter hash of element row * C + channel).  `segs` and `dW` (one [Cout_s][Cin_s] gradient per
  * segment) are HOST arrays.  Backward: dX [M][..] (row pitch lddx; nullable) gets segment s's input gradient in columns x_col_s..;
  * segments reading the same columns add up.  MLSP_ERR_UNSUPPORTED (mlsp_multimlp_supported() == 0) when a column slice is not
- * 16-byte aligned or C > 1024: run one mlsp_pointmlp_* per segment instead. */
+ * 16-byte aligned or C > 1024: run one mlsp_pointmlp_* per segment instead.
+ * Chaining (ABI v9): `in` (HOST array of nseg descriptors, or NULL) says that X is the PRE-BatchNorm output of the previous merged layer
+ * (in[s].col == segs[s].x_col): every segment's GEMM -- single or block-diagonal -- transforms its operand while staging it (forward:
+ * A; backward: the X side of the weight gradient), see mlsp_defer_t above.  Z == NULL in the forward: this layer's own BatchNorm +
+ * activation + dropout pass is left to ITS consumers (Y and bn_save are written). */
 typedef struct mlsp_seg {
     const float* W;        /* [Cout][Cin], row pitch ldw */
     const float* bias;     /* [Cout] or NULL */
     int ldw, x_col, Cin, Cout;
 } mlsp_seg_t;
 int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg, int precision);
-int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* gamma, const float* beta,
+int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const mlsp_defer_t* in, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int training, const float* chan, float p_drop,
                           uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
-int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* Y,
+int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const mlsp_defer_t* in, const float* Y,
                           const float* bn_save, int training, const float* chan, float p_drop, uint64_t seed, float* dX, int lddx,
                           float* const* dW, float* dbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 

@@ -21,14 +21,14 @@ MERGE_HEAD_FIRST_LAYERS = True   # merged_first_layers(): the heads' first layer
 
 
 def _bn_layer(X, conv, bn, training, act, p_drop=0.0, gbias=None, rows_per_group=0, W=None, grad_accum=None, chain=False,
-              grad_cols=None):
+              grad_cols=None, defer=False):
     """Conv1d(k=1, bias=False) + BatchNorm1d + act (+dropout) on a [rows, Cin] matrix."""
     rm, rv = _bn_buffers(bn, training)
     if W is None:
         W = conv.weight.view(conv.out_channels, conv.in_channels)
     return Fh.pointmlp(X, W, bias=conv.bias, gbias=gbias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
                        rows_per_group=rows_per_group, training=training, act=act, slope=0.2, p_drop=p_drop,
-                       momentum=bn.momentum, eps=bn.eps, grad_accum=grad_accum, chain=chain, grad_cols=grad_cols)
+                       momentum=bn.momentum, eps=bn.eps, grad_accum=grad_accum, chain=chain, grad_cols=grad_cols, defer=defer)
 
 
 def _first_head_layer(head, x_cat, x5, N, act, p_drop, grad_accum=None):
@@ -105,9 +105,11 @@ def merged_tails(heads, h1, widths, B, N):
         beta = Fh.row_blocks([l[2].bias for l in layer], rehome=own)
         bufs = [_bn_buffers(l[2], training) for l in layer]
         rm, rv = Fh.merged_buffers([b[0] for b in bufs], rehome=own), Fh.merged_buffers([b[1] for b in bufs], rehome=own)
-        chan = Fh.channel_params(X.device, tuple((W.shape[0], float(l[3]), l[4] > 0) for W, l in zip(Ws, layer)))
+        spec = tuple((W.shape[0], float(l[3]), l[4] > 0) for W, l in zip(Ws, layer))
+        chan = Fh.channel_params(X.device, spec)
+        # (chain: the consumers of both merged depths are GEMM layers -- the next depth, then the heads' final Linear layers)
         X = Fh.multimlp(X, [(xc, W, l[1]) for xc, W, l in zip(x_cols, Ws, layer)], gamma, beta, rm.tensor, rv.tensor, chan,
-                        training=training, p_drop=(rates.pop() if rates else 0.0), momentum=bn0.momentum, eps=bn0.eps)
+                        training=training, p_drop=(rates.pop() if rates else 0.0), momentum=bn0.momentum, eps=bn0.eps, chain=True, spec=spec)
         if training:
             rm.writeback()
             rv.writeback()
@@ -131,10 +133,9 @@ def _tails_one_by_one(mods, X, in_w, B, N, first):
 
 
 def can_merge_first_layers(heads):
-    """distinct heads, same input width / bias setting / dropout rate / BatchNorm hyper-parameters / mode; plain (non-deferred)
-    activations"""
+    """distinct heads, same input width / bias setting / dropout rate / BatchNorm hyper-parameters / mode"""
     mods = list(heads)
-    if not MERGE_HEAD_FIRST_LAYERS or len(mods) < 2 or len({id(m) for m in mods}) != len(mods) or Fh._DEFER_CHAINS:
+    if not MERGE_HEAD_FIRST_LAYERS or len(mods) < 2 or len({id(m) for m in mods}) != len(mods):
         return False
     m0 = mods[0]
     return all(m.conv1.in_channels == m0.conv1.in_channels and (m.conv1.bias is None) == (m0.conv1.bias is None) and
@@ -161,7 +162,7 @@ class _RegionHead(nn.Module):
 
     def _tail(self, h, B, N, grad_cols=None):
         h = _bn_layer(h, self.conv2, self.bn2, self.training, Fh.ACT_RELU, p_drop=self.dp2.p, chain=True, grad_cols=grad_cols)
-        h = _bn_layer(h, self.conv3, self.bn3, self.training, Fh.ACT_RELU)
+        h = _bn_layer(h, self.conv3, self.bn3, self.training, Fh.ACT_RELU, defer=True)      # (consumer: the final Linear)
         h = Fh.pointmlp(h, self.conv4.weight.view(3, self.of3), training=self.training)
         return h.view(B, N, 3)                                       # == x.permute(0,2,1) of the reference
 
@@ -184,7 +185,7 @@ class _RegionHead(nn.Module):
 
     def tail_from(self, h, B, N, first, grad_cols=None):
         assert first == 1
-        h = _bn_layer(h, self.conv3, self.bn3, self.training, Fh.ACT_RELU, grad_cols=grad_cols)
+        h = _bn_layer(h, self.conv3, self.bn3, self.training, Fh.ACT_RELU, grad_cols=grad_cols, defer=True)
         return self.tail_final(h, B, N)
 
     @flushing_forward
@@ -230,7 +231,7 @@ class Density_prediction(nn.Module):
 
     def _tail(self, h, grad_cols=None):
         h = self.mlp1(h, p_drop=self.dp1.p, chain=True, grad_cols=grad_cols)   # dp1 applied twice (:273,:278)
-        h = self.mlp2(h, p_drop=self.dp2.p)
+        h = self.mlp2(h, p_drop=self.dp2.p, defer=True)                        # (consumer: the final Linear)
         logits = Fh.pointmlp(h, self.mlp3.weight, bias=self.mlp3.bias, training=self.training)
         return Fh.density_tail(logits, self.fc2.weight)
 
@@ -254,7 +255,7 @@ class Density_prediction(nn.Module):
 
     def tail_from(self, h, B, N, first, grad_cols=None):
         assert first == 1
-        h = self.mlp2(h, p_drop=self.dp2.p, grad_cols=grad_cols)
+        h = self.mlp2(h, p_drop=self.dp2.p, grad_cols=grad_cols, defer=True)
         return self.tail_final(h, B, N)
 
     @flushing_forward

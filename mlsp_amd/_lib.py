@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLSP_HIP_LIB") or os.path.join(_HERE, "libmlsp_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c = ctypes
 _P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
@@ -37,9 +37,9 @@ SIGNATURES = {
                               _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
                               _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
-    "mlsp_pointmlp_fwd_chain_f32": [_P, _I, _P, _I, _F, _F, _U64, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
+    "mlsp_pointmlp_fwd_chain_f32": [_P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
                                     _P, _P, _P, _I, _P, _SZ, _P],
-    "mlsp_pointmlp_bwd_chain_f32": [_P, _P, _I, _P, _I, _F, _F, _U64, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
+    "mlsp_pointmlp_bwd_chain_f32": [_P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
                                     _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_mx_supported": [_I, _I, _I, _I, _I, _I, _I],
     "mlsp_pointmlp_fwd_mx": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
@@ -84,8 +84,8 @@ SIGNATURES = {
     "mlsp_collapse_to_point_f32": [_P, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P],
     "mlsp_scan_select_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _P],
     "mlsp_multimlp_supported": [_I, _P, _I, _I],
-    "mlsp_multimlp_fwd_f32": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _F, _F, _I, _P, _F, _U64, _P, _P, _P, _I, _P, _SZ, _P],
-    "mlsp_multimlp_bwd_f32": [_P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _F, _U64, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P],
+    "mlsp_multimlp_fwd_f32": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _F, _U64, _P, _P, _P, _I, _P, _SZ, _P],
+    "mlsp_multimlp_bwd_f32": [_P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P, _F, _U64, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_profile_begin": [],
     "mlsp_profile_end": [_P],
     "mlsp_profile_classes": [_P, _I],
@@ -96,6 +96,11 @@ SIGNATURES = {
 class Seg(_c.Structure):
     """mlsp_seg_t of include/mlsp_hip.h"""
     _fields_ = [("W", _P), ("bias", _P), ("ldw", _I), ("x_col", _I), ("Cin", _I), ("Cout", _I)]
+
+
+class Defer(_c.Structure):
+    """mlsp_defer_t of include/mlsp_hip.h: the producer of a chained layer's input (its pre-BatchNorm matrix is what X points into)"""
+    _fields_ = [("bn_save", _P), ("ld", _I), ("col", _I), ("act", _I), ("slope", _F), ("p_drop", _F), ("seed", _U64)]
 
 
 _RESTYPE = {"mlsp_strerror": _c.c_char_p, "mlsp_workspace_bytes": _SZ}

@@ -22,6 +22,7 @@ int launch_colsum_groups_b16(hipStream_t st, const void* X, int G, int rows_per_
 int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, int panel_rows,
                          float* ysel, int* arg);
 int gemm_panel_rows(int M, int N, int K);
+int launch_xf_materialize(hipStream_t st, const float* X, int ldx, int M, int C, const GemmXf& xf, float* out);   // multi.hip
 int gemm_stat_parts(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K);
 int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws, void* planes, size_t plane_bytes);
@@ -517,25 +518,30 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
     return MLSP_OK;
 }
 
-// The input of a chained layer: X holds the PRE-BatchNorm output of the previous layer; its BN scale / shift, activation and dropout
-// are applied while the GEMM stages the operand (GemmXf), or by one streaming pass into the workspace when the shape is not covered.
-struct ChainIn { const float* bn_save; int act; float slope; float p_drop; uint64_t seed; };
-static GemmXf chain_xf(const ChainIn& in, int Cin, int which) {
+// The input of a chained layer (mlsp_defer_t): X points into the PRE-BatchNorm output of the previous layer; its BN scale / shift,
+// activation and dropout are applied while the GEMM stages the operand (GemmXf), or by one streaming pass into the workspace when the shape
+// is not covered.
+static bool defer_ok(const mlsp_defer_t* in) {
+    return in->bn_save && in->ld > 0 && in->col >= 0 && in->p_drop >= 0.f && in->p_drop < 1.f && in->act >= 0 && in->act <= 2;
+}
+static GemmXf chain_xf(const mlsp_defer_t& in, int which) {
     GemmXf x;
-    x.scale = in.bn_save; x.shift = in.bn_save + Cin; x.act = in.act; x.slope = in.slope; x.thresh = dropout_thresh8(in.p_drop);
-    x.inv_keep = dropout_inv_keep8(in.p_drop); x.seed = in.seed; x.ld = Cin; x.which = which;
+    x.scale = in.bn_save + in.col; x.shift = in.bn_save + in.ld + in.col; x.act = in.act; x.slope = in.slope; x.thresh = dropout_thresh8(in.p_drop);
+    x.inv_keep = dropout_inv_keep8(in.p_drop); x.seed = in.seed; x.ld = in.ld; x.col = in.col; x.which = which;
     return x;
 }
+// a LeakyReLU slope outside [0, 1] takes the streaming pass: the fused transform writes the activation as one max
+static bool defer_fusable(const mlsp_defer_t& in) { return !(in.act == 2 && !(in.slope >= 0.f && in.slope <= 1.f)); }
 
 static int pointmlp_fwd_impl(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                              const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                              float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
                              uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st,
-                             const ChainIn* in) {
+                             const mlsp_defer_t* in) {
     if (!X || !W || (!Z && !gamma) || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
     if (gamma && (!beta || !Y || !bn_save)) return MLSP_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
-    if (in && (!in->bn_save || in->p_drop < 0.f || in->p_drop >= 1.f)) return MLSP_ERR_ARG;
+    if (in && (!defer_ok(in) || in->col + Cin > in->ld)) return MLSP_ERR_ARG;
     // per-cloud layers (batch <= 32 rows): Linear + BatchNorm1d + activation + dropout in ONE kernel (skinny.hip)
     if (gamma && !gbias && M <= 32 && !in && Z)
         return launch_skinny_linear_bn_act(st, X, ldx, M, Cin, W, ldw, Cout, bias, gamma, beta, run_mean, run_var, momentum, eps,
@@ -549,16 +555,13 @@ static int pointmlp_fwd_impl(const float* X, int ldx, int M, int Cin, const floa
     float* slab = sf ? w.take<float>(sf) : nullptr;
     GemmXf xf_s; const GemmXf* xf = nullptr;
     if (in) {
-        // (a LeakyReLU slope outside [0, 1] takes the streaming pass: the fused transform writes the activation as one max)
-        if (!(in->act == 2 && !(in->slope >= 0.f && in->slope <= 1.f)) && gemm_xf_supported(false, true, M, Cout, Cin, X, ldx, W, ldw, 1)) {
-            xf_s = chain_xf(*in, Cin, 1); xf = &xf_s;
-        }
+        xf_s = chain_xf(*in, 1);
+        if (defer_fusable(*in) && gemm_xf_supported(false, true, M, Cout, Cin, X, ldx, W, ldw, 1)) xf = &xf_s;
         else {                                             // shape outside the fused path: materialise the activated input once
-            if (ldx != Cin) return MLSP_ERR_UNSUPPORTED;
             float* Xa = w.take<float>((size_t)M * Cin);
             if (!w.ok()) return MLSP_ERR_WORKSPACE;
-            CHECK(launch_bn_act_fwd(st, X, Xa, (size_t)M, Cin, in->bn_save, in->bn_save + Cin, in->act, in->slope, in->p_drop, in->seed));
-            X = Xa;
+            CHECK(launch_xf_materialize(st, X, ldx, M, Cin, xf_s, Xa));
+            X = Xa; ldx = Cin;
         }
     }
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
@@ -593,21 +596,20 @@ int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* 
                              training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, nullptr);
 }
 
-int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope, float in_p_drop,
-                                uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
+int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const mlsp_defer_t* in, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                                 const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                                 float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
                                 uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     PREC_SCOPE(precision);
-    const ChainIn in = {in_bn_save, in_act, in_slope, in_p_drop, in_seed};
+    if (!in) return MLSP_ERR_ARG;
     return pointmlp_fwd_impl(Xpre, ldx, M, Cin, W, ldw, Cout, bias, gbias, rows_per_group, gamma, beta, run_mean, run_var, momentum, eps,
-                             training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, &in);
+                             training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, in);
 }
 
 static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                              const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                              int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
-                             float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st, const ChainIn* in) {
+                             float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st, const mlsp_defer_t* in) {
     if (!dZ || !X || !W || !dW || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
     if (has_bn && (!Y || !bn_save || !dgamma || !dbeta)) return MLSP_ERR_ARG;
     if (dgbias && (n_groups <= 0 || rows_per_group <= 0 || (long)n_groups * rows_per_group != M)) return MLSP_ERR_ARG;
@@ -623,16 +625,14 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     float* gscratch = dgbias ? w.take<float>((size_t)n_groups * 16 * Cout) : nullptr;
     GemmXf xf_s; const GemmXf* xf = nullptr;            // chained input: the wgrad reads the previous layer's pre-BN output
     if (in) {
-        if (!in->bn_save || M <= 32) return MLSP_ERR_ARG;
-        if (!(in->act == 2 && !(in->slope >= 0.f && in->slope <= 1.f)) && gemm_xf_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx, 2)) {
-            xf_s = chain_xf(*in, Cin, 2); xf = &xf_s;
-        }
+        if (!defer_ok(in) || in->col + Cin > in->ld || M <= 32) return MLSP_ERR_ARG;
+        xf_s = chain_xf(*in, 2);
+        if (defer_fusable(*in) && gemm_xf_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx, 2)) xf = &xf_s;
         else {
-            if (ldx != Cin) return MLSP_ERR_UNSUPPORTED;
             float* Xa = w.take<float>((size_t)M * Cin);
             if (!w.ok()) return MLSP_ERR_WORKSPACE;
-            CHECK(launch_bn_act_fwd(st, X, Xa, (size_t)M, Cin, in->bn_save, in->bn_save + Cin, in->act, in->slope, in->p_drop, in->seed));
-            X = Xa;
+            CHECK(launch_xf_materialize(st, X, ldx, M, Cin, xf_s, Xa));
+            X = Xa; ldx = Cin;
         }
     }
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
@@ -678,15 +678,14 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
                              rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, nullptr);
 }
 
-int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const float* in_bn_save, int in_act, float in_slope,
-                                float in_p_drop, uint64_t in_seed, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
+int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const mlsp_defer_t* in, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                                 const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                                 int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
                                 float* dgbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     PREC_SCOPE(precision);
-    const ChainIn in = {in_bn_save, in_act, in_slope, in_p_drop, in_seed};
+    if (!in) return MLSP_ERR_ARG;
     return pointmlp_bwd_impl(dZ, Xpre, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
-                             rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, &in);
+                             rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, in);
 }
 
 // ---- Linear + BatchNorm + act + max over the k rows of every group (last conv of a set-abstraction MLP + the neighbourhood max) ------

@@ -72,8 +72,10 @@ __device__ __forceinline__ void xcd_cloud_map(int bid, int bpc, int B, int& clou
 
 // Operand transform of a GEMM (gemm.hip): the operand holds the PRE-BatchNorm output of the previous layer; act(x * scale[c] + shift[c])
 // and that layer's dropout are applied while the tile is staged.  which: 1 = A ([M][K] row-major, c = k), 2 = B ([K][N] k-major, c = n).
+// scale / shift point at the operand's FIRST channel; ld / col: row pitch of the matrix the previous layer wrote and the operand's first
+// column in it (the dropout stream is indexed by the element's place in that matrix: a column slice of a merged layer keeps its mask).
 struct GemmXf {
-    const float* scale; const float* shift; int act; float slope; uint32_t thresh; float inv_keep; uint64_t seed; int ld; int which;
+    const float* scale; const float* shift; int act; float slope; uint32_t thresh; float inv_keep; uint64_t seed; int ld; int which; int col;
 };
 
 // Block-diagonal product in one GEMM launch (gemm.hip GemmArgs groups).  mode 1: output COLUMNS are grouped (forward: A = X + g * a_gs,
@@ -106,6 +108,20 @@ __device__ __forceinline__ uint32_t dropout_hash4(uint64_t seed, uint64_t quad) 
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t i, uint32_t thresh) {
     return ((dropout_hash4(seed, i >> 2) >> (8 * ((uint32_t)i & 3))) & 255u) >= thresh;
 }
+// The operand transform on one aligned quad (the arithmetic of bn_act_fwd_vec_kernel / multi_act_fwd_kernel, element by element):
+// act(v * sc + sh) with the activation as ONE max (slope = effective negative-side factor in [0, 1]), then dropout by byte e of the
+// quad's hash.  XfDev: what a kernel needs of a GemmXf; xH = the launch-uniform half of dropout_hash4 (quad index < 2^32).
+struct XfDev { const float* scale; const float* shift; float slope, inv_keep; uint32_t thresh, xH; int ld, col; };
+__device__ __forceinline__ f32x4 xf_apply_quad(f32x4 v, const f32x4& sc, const f32x4& sh, float slope, uint32_t thresh, float inv_keep, uint32_t hq) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = fmaf(v[e], sc[e], sh[e]);
+        a = fmaxf(a, a * slope);
+        if (thresh) a = ((hq >> (8 * e)) & 255u) >= thresh ? a * inv_keep : 0.f;
+        v[e] = a;
+    }
+    return v;
+}
 // host side: the byte threshold of a rate and the matching rescale
 static inline uint32_t dropout_thresh8(float p) {
     if (!(p > 0.f)) return 0u;
@@ -115,4 +131,13 @@ static inline uint32_t dropout_thresh8(float p) {
 static inline float dropout_inv_keep8(float p) {
     const uint32_t t = dropout_thresh8(p);
     return t ? 256.0f / (float)(256u - t) : 1.0f;
+}
+
+// host: device-side view of a GemmXf (effective slope: 1 no activation, 0 ReLU, the LeakyReLU slope otherwise)
+static inline uint32_t mix32_host(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+static inline XfDev xf_dev(const GemmXf& x) {
+    XfDev d;
+    d.scale = x.scale; d.shift = x.shift; d.slope = x.act == 0 ? 1.f : x.act == 1 ? 0.f : x.slope; d.inv_keep = x.inv_keep; d.thresh = x.thresh;
+    d.xH = mix32_host((uint32_t)x.seed) ^ (uint32_t)(x.seed >> 32) * 0x9e3779b9U; d.ld = x.ld; d.col = x.col;
+    return d;
 }

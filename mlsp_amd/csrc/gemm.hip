@@ -40,7 +40,9 @@ struct GemmArgs {
     // operand transform (XF != 0): the operand is the PRE-BatchNorm output of the previous layer and is turned into that layer's
     // activated output while it is staged: act(x * scale[c] + shift[c]), dropout by the counter hash of element row * x_ld + c.
     // XF == 1: A is [M][K] row-major, c = k.  XF == 2: B is [K][N] k-major (the wgrad's X), c = n.
-    const float* x_scale; const float* x_shift; int x_act; float x_slope; uint32_t x_thresh; float x_inv_keep; uint64_t x_seed; int x_ld;
+    // x_col: the operand's first column inside the [rows][x_ld] matrix the previous layer wrote (a column slice of a merged layer's output):
+    // the dropout stream is indexed by the element's place in THAT matrix; x_scale / x_shift already point at the slice's first channel.
+    const float* x_scale; const float* x_shift; int x_act; float x_slope; uint32_t x_thresh; float x_inv_keep; uint64_t x_seed; int x_ld; int x_col;
     // groups (FAST fp32 kernel only; launch_gemm `grp`): a block-diagonal product in ONE launch.  gmode 1 (forward / dgrad): column tiles
     // [g * gtiles, (g + 1) * gtiles) form group g, whose A columns start at A + g * a_gs and whose B operand is Bg[g]; C, bias and
     // the statistics keep the launch-wide column index.  gmode 2 (wgrad): ROW tiles are grouped, B = B + g * b_gs.
@@ -415,12 +417,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
         if (XF == 1) {                                    // rows m0 + (tid >> 3) + 32 q, channels kt + 4 (tid & 7) ..
 #pragma unroll
             for (int q = 0; q < NPA; ++q)
-                ra[q] = xf_quad(p, ra[q], xs, xh, (uint64_t)(m0 + (tid >> 3) + 32 * q) * p.x_ld + kt + (tid & 7) * 4);
+                ra[q] = xf_quad(p, ra[q], xs, xh, (uint64_t)(m0 + (tid >> 3) + 32 * q) * p.x_ld + p.x_col + kt + (tid & 7) * 4);
         }
         if (XF == 2) {                                    // rows (points) kt + (tid >> 5) + 8 q, channels n0 + 4 (tid & 31) ..
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                rb[q] = xf_quad(p, rb[q], xs, xh, (uint64_t)(kt + (tid >> 5) + 8 * q) * p.x_ld + n0 + (tid & 31) * 4);
+                rb[q] = xf_quad(p, rb[q], xs, xh, (uint64_t)(kt + (tid >> 5) + 8 * q) * p.x_ld + p.x_col + n0 + (tid & 31) * 4);
         }
     };
     if (XF) xf_tile(kbeg);
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_n64_kernel(GemmArgs p) {
     }
 }
 
-// ---- bf16-operand variant (opt-in, mlsp_set_gemm_precision(1); BASELINE.json configs[4]) -------------------------------
+// ---- bf16-operand variant (opt-in: `precision` = MLSP_PREC_BF16 of the calling entry point; BASELINE.json configs[4]) ------
 // Same tiling, epilogues and split-K protocol as gemm_f32_kernel<..., FAST>, but the fp32 operands are rounded to bf16 (RNE,
 // v_cvt_pk_bf16_f32) on their way into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 8x fewer MFMA
 // issues per K-tile and half the LDS traffic.  Both LDS images are row-major [row][32 + 8] bf16 (80-byte pitch: every
@@ -636,6 +638,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define SX_RPITCH 80
 #define SX_KPITCH 320
 #define SX_LDS __attribute__((address_space(3)))
+#define SX_XF_KMAX 1024          // channels (K range of one workgroup) of an A-side operand transform in gemm_split_kernel
 
 // this lane's byte offset of a fragment inside an image (rows rb .. rb+31 of the tile start at + rb * (KMAJ ? 2 : SX_RPITCH))
 template <bool KMAJ>
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     gemm_epilogue<WM, !NEDGE, CB16>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 }
 
-// ---- fp32-accurate products on the bf16 matrix cores (mlsp_set_gemm_precision(2)) ---------------------------------------------------
+// ---- fp32-accurate products on the bf16 matrix cores (`precision` = MLSP_PREC_BF16X6 of the calling entry point) ----------------------
 // On gfx950 the f32 MFMA runs at 1/16 of the bf16 MFMA rate.  Every fp32 operand value is split, while its tile is staged, into three
 // bf16 pieces x = a + b + c (a = bf16(x), b = bf16(x - a), c = bf16(x - a - b): 8 + 8 + 8 significand bits, RNE, the remainders are exact
 // in fp32), and x y is taken as the six products a a' + (a b' + b a') + (a c' + c a' + b b') on v_mfma_f32_32x32x16_bf16 with fp32
@@ -838,11 +841,21 @@ __device__ __forceinline__ f32x4 sx_bufload(__amdgpu_buffer_rsrc_t rs, int voff,
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
 }
-template <bool TA, bool TB, int WM>
+// XF (operand transform, GemmArgs x_*): the staged fp32 values of ONE operand are the previous layer's PRE-BatchNorm output and become its
+// activated output -- act(x * scale[c] + shift[c]), then that layer's dropout (XD) -- right before they are split: the same arithmetic, in
+// the same order, as the streaming pass it replaces (bn_act_fwd_vec_kernel / multi_act_fwd_kernel), so the product is bit-identical to the
+// one over the materialised tensor.  XF == 1: A row-major [M][K], channel = k (forward of the consumer layer); XF == 2: B k-major [K][N],
+// channel = n (the consumer's weight gradient, X^T side).  Both also in block-diagonal launches (the group's channels start at
+// g * a_gs / g * b_gs).  The vector work rides in the split stream's slots (gen_split_body.py: SX_XF_A / SX_XF_B).
+template <bool TA, bool TB, int WM, int XF = 0, bool XD = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
+    static_assert(XF == 0 || (XF == 1 && !TA) || (XF == 2 && !TB), "XF == 1: A row-major; XF == 2: B k-major");
+    static_assert(XF != 0 || !XD, "dropout only with a transform");
     constexpr bool KA = TA, KB = !TB;                                 // operand's global source is k-major
     constexpr int BMT = 64 * WM, NQA = 2 * WM;                        // A quads (16-byte loads) of a tile per thread; B: 4
     __shared__ __attribute__((aligned(16))) char simg[6 * SX_PLANE];  // 61,440 B
+    constexpr int XFS = XF == 1 ? 2 * SX_XF_KMAX : 4;
+    __shared__ __attribute__((aligned(16))) float xfs[XFS];           // XF == 1: scale | shift of this workgroup's K range (<= SX_XF_KMAX channels)
     float* smem = (float*)simg;                                       // epilogue scratch (the images are dead by then)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -883,6 +896,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     } else if (p.gmode == 2) {
         Bp += (size_t)(tm / p.gtiles) * p.b_gs;
     }
+    // first channel of the transformed operand's group inside x_scale / x_shift (block-diagonal launches)
+    const int xgc = XF == 1 ? (p.gmode == 1 ? (tn / p.gtiles) * (int)p.a_gs : 0) : XF == 2 ? (p.gmode == 2 ? (tm / p.gtiles) * (int)p.b_gs : 0) : 0;
     // global loads through buffer descriptors based at the tile's first element of this K range (scalar); voa / vob = this thread's byte
     // offset inside the tile (one register each, fixed); the K-tile advance and the quad step are scalar offsets: no vector instruction of
     // the K loop computes an address.  soa / sob are clamped at the last tile (the stream always loads "tile t+2").
@@ -905,10 +920,51 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     const char* fb = simg + 3 * SX_PLANE + sx_frag_base<KB>(lane) + (wn * 64) * (KB ? 2 : SX_RPITCH);
     constexpr int FWA = 32 * (KA ? 2 : SX_RPITCH), FWB = 32 * (KB ? 2 : SX_RPITCH);               // next 32-row window
     f32x4 raw[8];                                                     // [0, NQA) A quads, then 4 B quads of the tile being staged
+    // ---- operand transform state (XF): xsc / xsh = scale / shift of this thread's channel quad of the tile being staged (XF == 1: reloaded
+    // from LDS per K-tile; XF == 2: fixed), xq = index of the aligned element quad (row * x_ld + x_col + channel) / 4 of this thread's
+    // quad 0 of that tile in the producer's matrix (one dropout hash per quad: common.h dropout_hash4), xqs / xqt = its step per staged
+    // quad / per K-tile (uniform).  Host: x_ld % 4 == 0, x_col % 4 == 0, rows * x_ld < 2^34 (the hash's high word is launch-uniform).
+    f32x4 xsc = {0.f, 0.f, 0.f, 0.f}, xsh = {0.f, 0.f, 0.f, 0.f};
+    uint32_t xq = 0, xhq = 0, xH = 0;
+    int xqs = 0, xqt = 0;
+    const float xslope = p.x_slope, xik = p.x_inv_keep;
+    const uint32_t xth = p.x_thresh;
+    if (XD) xH = mix32((uint32_t)p.x_seed) ^ (uint32_t)(p.x_seed >> 32) * 0x9e3779b9U;
+    if (XF == 1) {
+        for (int i = tid * 4; i < T * BK; i += 1024) {
+            *(f32x4*)(xfs + i) = *(const f32x4*)(p.x_scale + xgc + kbeg + i);
+            *(f32x4*)(xfs + SX_XF_KMAX + i) = *(const f32x4*)(p.x_shift + xgc + kbeg + i);
+        }
+        __syncthreads();
+        xsc = *(const f32x4*)(xfs + (tid & 7) * 4); xsh = *(const f32x4*)(xfs + SX_XF_KMAX + (tid & 7) * 4);
+        xq = (uint32_t)(((uint64_t)(m0 + (tid >> 3)) * (uint64_t)p.x_ld + (uint64_t)(p.x_col + xgc + kbeg + (tid & 7) * 4)) >> 2);
+        xqs = 8 * p.x_ld; xqt = BK / 4;
+    } else if (XF == 2) {
+        const int ch = xgc + n0b + (tid & 31) * 4;
+        xsc = *(const f32x4*)(p.x_scale + ch); xsh = *(const f32x4*)(p.x_shift + ch);
+        xq = (uint32_t)(((uint64_t)(kbeg + (tid >> 5)) * (uint64_t)p.x_ld + (uint64_t)(p.x_col + ch)) >> 2);
+        xqs = 2 * p.x_ld; xqt = 8 * p.x_ld;
+    }
+    auto xf_pair = [&](f32x4& v, int hh) {                            // elements 2 hh, 2 hh + 1 of a staged quad
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) sx_split_store(SX_LOAD_A(q), wa + q * WQA);
+        for (int e = 0; e < 2; ++e) {
+            const int c = 2 * hh + e;
+            float a = fmaf(v[c], xsc[c], xsh[c]);
+            a = fmaxf(a, a * xslope);                                 // x_slope in [0, 1]: == (a > 0 ? a : a * slope)
+            if (XD) a = ((xhq >> (8 * c)) & 255u) >= xth ? a * xik : 0.f;
+            v[c] = a;
+        }
+    };
+#define SX_XF_A(q_, hh_) do { if constexpr (XF == 1) { if (XD && (hh_) == 0) xhq = mix32((xq + (uint32_t)((q_) * xqs)) ^ xH); xf_pair(raw[q_], hh_); } } while (0)
+#define SX_XF_B(q_, hh_) do { if constexpr (XF == 2) { if (XD && (hh_) == 0) xhq = mix32((xq + (uint32_t)((q_) * xqs)) ^ xH); xf_pair(raw[NQA + (q_)], hh_); } } while (0)
+    // after a tile's quads are transformed: on to the tile after it (the stream always stages "tile t+1"; past the end a harmless repeat)
+#define SX_XF_NEXT(tnext_) do { if constexpr (XF != 0) { xq += (uint32_t)xqt; if constexpr (XF == 1) { const int tc_ = min((tnext_), T - 1) * BK + (tid & 7) * 4; \
+        xsc = *(const f32x4*)(xfs + tc_); xsh = *(const f32x4*)(xfs + SX_XF_KMAX + tc_); } } } while (0)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sx_split_store(SX_LOAD_B(q), wb + q * WQB);
+    for (int q = 0; q < NQA; ++q) { raw[q] = SX_LOAD_A(q); SX_XF_A(q, 0); SX_XF_A(q, 1); sx_split_store(raw[q], wa + q * WQA); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { raw[NQA + q] = SX_LOAD_B(q); SX_XF_B(q, 0); SX_XF_B(q, 1); sx_split_store(raw[NQA + q], wb + q * WQB); }
+    SX_XF_NEXT(1);
     soa = min(soa + sta, enda); sob = min(sob + stb, endb);
 #pragma unroll
     for (int q = 0; q < NQA; ++q) raw[q] = SX_LOAD_A(q);
@@ -930,22 +986,20 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
         soa = min(soa + sta, enda); sob = min(sob + stb, endb);      // tile t+2 (past the end: a harmless repeat of the last tile)
         uint32_t pk0[2], pk1[2], pk2[2];
         float r0, r1, a1;
-#ifdef SX_XF_ABLATION
-        // ablation (tools/x6/xf_ablation.sh): scale * x + shift and a LeakyReLU as max(t, slope t) on every A element with run-time identity
-        // parameters (1, 0, 1): the results do not change, the split stage carries the three vector instructions per element an operand
-        // transform would add (its per-K-tile scale / shift loads and the dropout hash are NOT included: a lower bound)
-        const float xf_sc = p.x_inv_keep, xf_sh = p.x_slope, xf_sl = p.x_inv_keep;
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if (WM == 2) {
 #include "gemm_split_body_wm2.inc"
         } else {
 #include "gemm_split_body_wm1.inc"
         }
+        SX_XF_NEXT(t + 2);
         __syncthreads();
     }
 #undef SX_LOAD_A
 #undef SX_LOAD_B
+#undef SX_XF_A
+#undef SX_XF_B
+#undef SX_XF_NEXT
     gemm_epilogue<WM, true, false>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 }
 
@@ -1225,18 +1279,31 @@ extern "C" int mlsp_profile_classes(double* out, int ncls) {
 int launch_skinny_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                        float* C, int ldc, const float* bias);
 int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                     int ldc, const float* bias, float* slab, size_t slab_floats);
+                     int ldc, const float* bias, float* slab, size_t slab_floats, const GemmXf* xf);
+bool thin_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which);
 
 // Can this contraction stage `which` (1: A [M][K] row-major, 2: B [K][N] k-major) through the operand transform?  Interior tiles,
 // 16-byte loads, fp32 operands, the MFMA tile kernels (not the thin / skinny / N = 64 ones).
+// (mode 2: gemm_split_kernel<.., XF, XD> where the split kernel pays, the fp32 transform kernels on the short-K launches: exact fp32
+// products either way.  On the split kernel the A-side transform keeps the scale / shift of a workgroup's K range in LDS: <= SX_XF_KMAX.)
 bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which) {
-    if (tl_call_precision == 1) return false;          // (mode 2 keeps the fp32 transform kernels: exact fp32 either way)
+    if (tl_call_precision == 1) return false;
+    if (thin_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, which)) return true;       // the streaming kernels of thin.hip transform too
     if (which == 1 ? ta : !(ta && !tb)) return false;
     if (M <= 32 || N < 32 || K < 32 || (ta && !tb && K <= 32)) return false;
     const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
     int ns = gemm_pick_split(M, N, K);
     const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
+    const int ktiles = (K + BK - 1) / BK, kts = (ktiles + ns - 1) / ns;
+    if (which == 1 && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && kts * BK > SX_XF_KMAX) return false;
     return vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0) && (long)(ta ? M : K) * lda * 4 < (1L << 30) && (long)K * ldb * 4 < (1L << 30);
+}
+
+// will a transform launch of this shape run on gemm_split_kernel (the only kernel that transforms inside a block-diagonal launch)?
+bool gemm_xf_on_split(bool ta, bool tb, int M, int N, int K, int which) {
+    if (tl_call_precision != 2) return false;
+    const int ns = gemm_pick_split(M, N, K), ktiles = (K + BK - 1) / BK, kts = (ktiles + ns - 1) / ns;
+    return gemm_split_pays(M, N, kts) && (which != 1 || kts * BK <= SX_XF_KMAX);
 }
 
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
@@ -1248,13 +1315,16 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     // stat_ld (0: N): C is a column slice of a [M][stat_ld] matrix whose BatchNorm statistics are taken as ONE vector (multi.hip):
     // stat_part points at this slice's first column of the [panels][2][stat_ld] partial rows
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !sel_gamma)) return MLSP_ERR_ARG;
-    if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
     // one tiny dimension (3 coordinates, 3 / 16 outputs): streaming VALU kernels priced against HBM, not MFMA tiles (thin.hip)
-    if (grp && (grp->G < 2 || grp->G > 4 || xf || sel_gamma || gbias || tl_call_precision == 1 || (ta && tb))) return MLSP_ERR_UNSUPPORTED;
-    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf) {
-        const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats);
+    if (grp && (grp->G < 2 || grp->G > 4 || sel_gamma || gbias || tl_call_precision == 1 || (ta && tb))) return MLSP_ERR_UNSUPPORTED;
+    // a transform in a block-diagonal launch: split kernel only; the dropout stream is indexed in 32 bits per aligned quad
+    if (xf && ((xf->ld & 3) || (xf->col & 3) || (((uintptr_t)xf->scale | (uintptr_t)xf->shift) & 15) || (double)(xf->which == 1 ? M : K) * xf->ld >= 17179869184.0))
+        return MLSP_ERR_UNSUPPORTED;
+    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && (!xf || tl_call_precision != 1)) {
+        const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats, xf);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
+    if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
     if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && !bias && C && gemm_fold64(ta, tb, M, N, K, lda, ldb) &&
         (((uintptr_t)A | (uintptr_t)B) & 15) == 0) {
         const size_t inner = gemm_slab_floats(128, 128, K / 2);
@@ -1290,11 +1360,11 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
     p.stat_part = stat_part; p.stat_ld = stat_ld > 0 ? stat_ld : N;
     p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
-    p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0;
+    p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0; p.x_col = 0;
     if (xf) {
         p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_thresh = xf->thresh;
         p.x_slope = xf->act == 0 ? 1.f : xf->act == 1 ? 0.f : xf->slope;          // effective negative-side factor (xf_quad)
-        p.x_inv_keep = xf->inv_keep; p.x_seed = xf->seed; p.x_ld = xf->ld;
+        p.x_inv_keep = xf->inv_keep; p.x_seed = xf->seed; p.x_ld = xf->ld; p.x_col = xf->col;
     }
     int ktiles = (K + BK - 1) / BK;
     int kts = (ktiles + ns - 1) / ns;
@@ -1327,6 +1397,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         p.gmode = grp->mode; p.gtiles = per / tile; p.a_gs = grp->a_gs; p.b_gs = grp->b_gs;
         for (int g = 0; g < 4; ++g) p.Bg[g] = grp->mode == 1 ? grp->Bg[g < grp->G ? g : 0] : B;
     }
+    const bool xf_split = xf && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && (xf->which != 1 || kts * BK <= SX_XF_KMAX);
+    if (grp && xf && !xf_split) return MLSP_ERR_UNSUPPORTED;             // (the fp32 transform kernels take no groups: nothing launched)
     const bool n64 = !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
                      (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && tl_call_precision != 1 && (ns == 1 || p.ldc == N);
     if (n64) {
@@ -1339,7 +1411,16 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
                                      else if (fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts)) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
-    if (grp && tl_call_precision == 2 && gemm_split_pays(M, N, kts)) {   // block-diagonal launch on the split kernel (groups are a run-time argument there)
+    if (xf_split) {                                                      // operand transform on the split kernel, plain or block-diagonal
+#define SPLIT_XF_GO(TA_, TB_, XF_) do { if (bm == 128) { if (xf->thresh) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 2, XF_, true>), grid, dim3(256), 0, st, p); \
+                                                          else hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 2, XF_, false>), grid, dim3(256), 0, st, p); } \
+                                         else { if (xf->thresh) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 1, XF_, true>), grid, dim3(256), 0, st, p); \
+                                                else hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 1, XF_, false>), grid, dim3(256), 0, st, p); } } while (0)
+        if (xf->which == 1 && !ta && tb && (!grp || grp->mode == 1)) SPLIT_XF_GO(false, true, 1);
+        else if (xf->which == 2 && ta && !tb && (!grp || grp->mode == 2)) SPLIT_XF_GO(true, false, 2);
+        else return MLSP_ERR_UNSUPPORTED;
+#undef SPLIT_XF_GO
+    } else if (grp && tl_call_precision == 2 && gemm_split_pays(M, N, kts)) {   // block-diagonal launch on the split kernel (groups are a run-time argument there)
         if (grp->mode == 1 && !ta && tb) { if (bm == 128) GEMM_GO(false, true, 2); else GEMM_GO(false, true, 1); }
         else if (grp->mode == 1 && !ta && !tb) { if (bm == 128) GEMM_GO(false, false, 2); else GEMM_GO(false, false, 1); }
         else if (grp->mode == 2 && ta && !tb) { if (bm == 128) GEMM_GO(true, false, 2); else GEMM_GO(true, false, 1); }
@@ -1377,7 +1458,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
 #undef GEMM_GO
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
-        const bool on_split = fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && !xf;
+        const bool on_split = fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && (!xf || xf_split);
         g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0), on_split ? 1 : 0};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;

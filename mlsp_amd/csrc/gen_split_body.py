@@ -8,7 +8,7 @@ slot closed by sched_barrier(0) so the compiler keeps the placement.
 Per K-tile (32 deep) a wave issues 24 * WM MFMAs (2 k16 steps x WM x 2 accumulators x 6 piece products).  The MFMA shadow is 32 cycles = 8
 issue slots of 4; between two MFMAs sit one (WM = 1: one or two) micro-steps of the three-way bf16 split of the NEXT tile's operands
 (16 / 12 element pairs x 3 micro-steps), and after each finished quad its three image writes and the global load of the quad after next.
-Names used: acc, a[s2][i][q], b[s2][j][q], raw[8], pk0/pk1/pk2[2], r0, r1, a1, wa, wb, WQA, WQB, SX_LOAD_A/B (see the kernel)."""
+Names used: acc, a[s2][i][q], b[s2][j][q], raw[8], pk0/pk1/pk2[2], r0, r1, a1, wa, wb, WQA, WQB, SX_LOAD_A/B, SX_XF_A/B (see the kernel)."""
 import sys
 WM = int(sys.argv[1])
 QA = [1, 0, 2, 0, 1, 0]          # smallest products first, the leading one last
@@ -21,11 +21,9 @@ def micro(m):
     x0, x1 = f"raw[{qd}][{2 * hh}]", f"raw[{qd}][{2 * hh + 1}]"
     L = []
     if ms == 0:
-        if qd < NQA:                  # ablation build only (-DSX_XF_ABLATION, tools/x6/xf_ablation.sh): the vector cost of an operand transform on A
-            L += ["#ifdef SX_XF_ABLATION",
-                  f"{x0} = fmaf({x0}, xf_sc, xf_sh); {x1} = fmaf({x1}, xf_sc, xf_sh);",
-                  f"{x0} = fmaxf({x0}, {x0} * xf_sl); {x1} = fmaxf({x1}, {x1} * xf_sl);",
-                  "#endif"]
+        # operand transform (gemm_split_kernel<.., XF, XD>): this pair of the staged quad becomes the previous layer's activated output
+        # before it is split; SX_XF_A / SX_XF_B expand to nothing in the instantiations without a transform on that operand
+        L += [f"SX_XF_A({qd}, {hh});" if qd < NQA else f"SX_XF_B({qd - NQA}, {hh});"]
         L += [f"pk0[{hh}] = sx_cvt_pk({x0}, {x1});",
               f"a1 = __uint_as_float(pk0[{hh}] & 0xffff0000u);",
               f"r0 = {x0} - __uint_as_float(pk0[{hh}] << 16);"]

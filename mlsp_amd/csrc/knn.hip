@@ -19,9 +19,13 @@
 #define KNN_TJ 32      // candidates per LDS tile per wave
 
 // squared norms with the canonical chain
-__global__ void sqnorm_kernel(const float* __restrict__ x, int ld, int P, int C, float* __restrict__ xx) {
+// `idx` (nullable): the kNN output [P][k], zero-filled here -- a row with fewer than k comparable candidates (NaN coordinates) keeps index 0
+// in the positions the selection kernels never write, as oracle/knn_canon.c does; no gather downstream sees an uninitialised index
+__global__ void sqnorm_kernel(const float* __restrict__ x, int ld, int P, int C, float* __restrict__ xx, int* __restrict__ idx, int k) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
+    if (idx)
+        for (int s = 0; s < k; ++s) idx[(size_t)i * k + s] = 0;
     const float* r = x + (size_t)i * ld;
     float acc = 0.f;
     if ((C & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)x) & 15) == 0) {      // same chain (c ascending), 16-byte loads, four in flight
@@ -1403,7 +1407,7 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
         const int rc = launch_knn6(st, x, ld, B, N, C, k, idx, xx_ws, planes);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
-    hipLaunchKernelGGL(sqnorm_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, C, xx_ws);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, C, xx_ws, idx, k);
     // matrix-core kernels for every C <= 256 (the widest graph stage of the reference is 128 channels); beyond that only what the
     // VALU kernel's LDS tiles hold (C <= ~200 at k <= 40): MLSP_ERR_UNSUPPORTED otherwise
     if (C <= 256) {

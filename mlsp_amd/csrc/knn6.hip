@@ -12,8 +12,8 @@
 //   * TRANSPOSED tiles: A = 32 candidates, B = 32 queries, so a lane owns ONE query (column) and its 16 accumulator registers are 16
 //     candidates of the tile.  Per-query state (threshold, survivor cursor) is per-lane: the survivor pass is v_cmpx / ds_write2 / add per
 //     pair, no ballots, no scalar branches.  The accumulator starts at -xx_j / 2 (one LDS read per 4 rows), so a = dot' - xx_j / 2
-//     orders like the distance and pd' = 2 a - xx_q.  A wave carries TWO query groups (64 queries) against half the candidates: every
-//     fragment it loads feeds both (the vector-memory path, 64 B / clk / CU, is what bounds one group per wave).
+//     orders like the distance and pd' = 2 a - xx_q.  A wave carries ONE query group (32 queries) against half the candidates, two waves
+//     per SIMD (two groups per wave against the same fragments was measured and rejected: see the kernel's comment).
 //   * BOTH sweeps use the split-bf16 products hi hi + lo hi + hi lo.  Error budget (worst case, not typical): bf16 has 8 significant
 //     bits, so |x - hi| <= 2^-8 |x|, |x - hi - lo| <= 2^-16 |x|; the dropped terms (lo lo, the two residual products) are at most
 //     3 x 2^-16 |x_q,c x_j,c| per channel, i.e. |2 dot' - 2 dot| <= 3 x 2^-16 (xx_q + xx_j) = 2^-14.4 (xx_q + xx_j); the fp32 accumulation
@@ -68,9 +68,13 @@ __device__ __forceinline__ size_t k6_piece(size_t T, int nkb, int kb, int p, int
 // EdgeConv output), and bounds in terms of the raw norms would declare most survivors ambiguous.
 template <int CT>
 __global__ __launch_bounds__(256) void knn6_prep_kernel(const float* __restrict__ x, int ld, int P, int N, int C, float* __restrict__ xx,
-                                                        float* __restrict__ xc, char* __restrict__ planes) {
+                                                        float* __restrict__ xc, char* __restrict__ planes, int* __restrict__ idx, int k) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
+    // Every output row starts as k zeros: a query with fewer than k comparable candidates (NaN coordinates -- its own or its cloud's) keeps
+    // index 0 in the positions the main kernel does not write, as oracle/knn_canon.c does; the gathers downstream never see an
+    // uninitialised index.
+    for (int s = 0; s < k; ++s) idx[(size_t)i * k + s] = 0;
     const float* r = x + (size_t)i * ld;
     const float* r0 = x + (size_t)(i / N) * N * ld;           // first point of the cloud
     const bool vec = (ld & 3) == 0 && (((uintptr_t)x) & 15) == 0;
@@ -158,7 +162,12 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
     float xcmax, xxmax;
     {
         float m = 0.f, mr = 0.f;
-        for (int j = tid; j < N; j += 512) { const float v = xcb[j]; nxx[j] = -0.5f * v; m = fmaxf(m, v); mr = fmaxf(mr, xxb[j]); }
+        // (fmaxf drops a NaN operand: a NaN norm -- a NaN coordinate, or an infinite first point of the cloud, the origin of the centred
+        // image -- becomes an infinite bound here, and an infinite bound sends the workgroup through the exact path below)
+        for (int j = tid; j < N; j += 512) {
+            const float v = xcb[j], w = xxb[j];
+            nxx[j] = -0.5f * v; m = fmaxf(m, v == v ? v : INFINITY); mr = fmaxf(mr, w == w ? w : INFINITY);
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); mr = fmaxf(mr, __shfl_xor(mr, o, 64)); }
         if (lane == 0) { red[wave] = m; red[8 + wave] = mr; }
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
 #endif
     K6_T(4);
     float thr = tauv[qg * 32 + l31] - Eq;                     // acc domain: pd' >= tau_pd - 2 E  <=>  a >= a_tau - E
-    thr = thr == thr ? thr : -INFINITY;                       // NaN bound: everything survives, the lists overflow, the exact path takes over
+    thr = thr == thr ? thr : -INFINITY;                       // (a non-finite bound Eq sends the workgroup through the exact path: `ovf` below)
 
     // ---- pass B: survivors -> this lane's private list (acc-domain value, candidate index)
     // per pair: v_cmpx (exec = survivors) / ds_write2_b32 {value, index} at the cursor / cursor += 8 under that mask / exec back to all lanes:
@@ -322,7 +331,9 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
 #undef K6_APPEND
     });
     int cnt = (int)(ad - base) >> 3;
-    const int ovf = (top > base + K6_CAP * 8) ? 1 : 0;
+    // overflow (massive ties), or no usable bound: a non-finite norm in the cloud (the approximate values of a NaN row are NaN and survive
+    // no comparison, so they would not overflow anything: ask for the exact path outright)
+    const int ovf = (top > base + K6_CAP * 8 || !(Eq < INFINITY)) ? 1 : 0;
     K6_T(5);
     bool exact_lists = false;
     if (__syncthreads_or(ovf)) {
@@ -795,7 +806,7 @@ size_t knn6_plane_bytes(int P, int C) { return (size_t)P * 2 * knn6_padded_chann
 template <int CT>
 static int knn6_go(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, float* xc, char* planes) {
     const int P = B * N;
-    hipLaunchKernelGGL((knn6_prep_kernel<CT>), dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, N, C, xx, xc, planes);
+    hipLaunchKernelGGL((knn6_prep_kernel<CT>), dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, N, C, xx, xc, planes, idx, k);
     const size_t lds = knn6_lds_bytes(N);
     hipError_t e = hipFuncSetAttribute((const void*)knn6_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

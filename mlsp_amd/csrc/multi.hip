@@ -19,6 +19,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
                 double* stat_part, const float* sel_gamma, float* sel_val, int* sel_row, bool accumulate, const GemmXf* xf, int stat_ld,
                 const GemmGroups* grp = nullptr);
 int gemm_panel_rows(int M, int N, int K);
+bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which);
+bool gemm_xf_on_split(bool ta, bool tb, int M, int N, int K, int which);
 int gemm_precision_mode();
 int gemm_stat_parts(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K);
@@ -179,8 +181,65 @@ __global__ __launch_bounds__(256) void multi_bwd_apply_kernel(const float* __res
     }
 }
 
+// ---- the operand transform as a streaming pass (fallback of the chained layers for shapes the GEMM kernels do not transform) ---------
+// out [M][C] contiguous = act(X * scale + shift) with the producer's dropout; X [M][..] row pitch ldx is a column slice (first column
+// xf.col) of the producer's [M][xf.ld] matrix; xf.scale / xf.shift point at the slice's first channel.
+__global__ __launch_bounds__(256) void xf_materialize_kernel(const float* __restrict__ X, int ldx, int M, int C, XfDev xf, float* __restrict__ out, int ldo, int vec) {
+    if (vec) {
+        const int cq = C >> 2;
+        const size_t total = (size_t)M * cq;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const int r = (int)(i / cq), q = (int)(i - (size_t)r * cq);
+            const f32x4 v = *(const f32x4*)(X + (size_t)r * ldx + 4 * q);
+            const f32x4 sc = *(const f32x4*)(xf.scale + 4 * q), sh = *(const f32x4*)(xf.shift + 4 * q);
+            const uint32_t qi = (uint32_t)(((uint64_t)r * xf.ld + xf.col + 4 * q) >> 2);
+            *(f32x4*)(out + (size_t)r * ldo + 4 * q) = xf_apply_quad(v, sc, sh, xf.slope, xf.thresh, xf.inv_keep, xf.thresh ? mix32(qi ^ xf.xH) : 0u);
+        }
+    } else {
+        const size_t total = (size_t)M * C;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const int r = (int)(i / C), c = (int)(i - (size_t)r * C);
+            float a = fmaf(X[(size_t)r * ldx + c], xf.scale[c], xf.shift[c]);
+            a = fmaxf(a, a * xf.slope);
+            if (xf.thresh) {
+                const uint64_t e = (uint64_t)r * xf.ld + xf.col + c;
+                a = ((mix32((uint32_t)(e >> 2) ^ xf.xH) >> (8 * ((uint32_t)e & 3))) & 255u) >= xf.thresh ? a * xf.inv_keep : 0.f;
+            }
+            out[(size_t)r * ldo + c] = a;
+        }
+    }
+}
+int launch_xf_materialize_ld(hipStream_t st, const float* X, int ldx, int M, int C, const GemmXf& xf, float* out, int ldo) {
+    if (!X || !out || M <= 0 || C <= 0 || ldo < C || (double)M * xf.ld >= 17179869184.0) return MLSP_ERR_ARG;
+    const int vec = (C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && xf.ld % 4 == 0 && xf.col % 4 == 0 &&
+                     (((uintptr_t)X | (uintptr_t)out | (uintptr_t)xf.scale | (uintptr_t)xf.shift) & 15) == 0) ? 1 : 0;
+    const size_t work = vec ? (size_t)M * (C / 4) : (size_t)M * C;
+    size_t blocks = (work + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(xf_materialize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, M, C, xf_dev(xf), out, ldo, vec);
+    return mlsp_launch_status();
+}
+int launch_xf_materialize(hipStream_t st, const float* X, int ldx, int M, int C, const GemmXf& xf, float* out) {
+    return launch_xf_materialize_ld(st, X, ldx, M, C, xf, out, C);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------------------
 #define MCHECK(x) do { int _r = (x); if (_r != MLSP_OK) return _r; } while (0)
+
+// deferred input of a segment (mlsp_defer_t, include/mlsp_hip.h): the transform a GEMM applies to that segment's operand
+static bool multi_defer_ok(const mlsp_defer_t& d, const mlsp_seg_t& g) {
+    return d.bn_save && d.ld > 0 && d.col == g.x_col && d.col + g.Cin <= d.ld && d.p_drop >= 0.f && d.p_drop < 1.f && d.act >= 0 && d.act <= 2;
+}
+static GemmXf multi_xf(const mlsp_defer_t& in, int which) {
+    GemmXf x;
+    x.scale = in.bn_save + in.col; x.shift = in.bn_save + in.ld + in.col; x.act = in.act; x.slope = in.slope; x.thresh = dropout_thresh8(in.p_drop);
+    x.inv_keep = dropout_inv_keep8(in.p_drop); x.seed = in.seed; x.ld = in.ld; x.col = in.col; x.which = which;
+    return x;
+}
+static bool multi_defer_same(const mlsp_defer_t& a, const mlsp_defer_t& b) {
+    return a.bn_save == b.bn_save && a.ld == b.ld && a.act == b.act && a.slope == b.slope && a.p_drop == b.p_drop && a.seed == b.seed;
+}
+static bool multi_defer_fusable(const mlsp_defer_t& in) { return !(in.act == 2 && !(in.slope >= 0.f && in.slope <= 1.f)); }
 
 // rows per workgroup of the element-wise passes: enough workgroups for ~8 per CU (a thread keeps four rows in flight)
 static int multi_rows_per_block(int M, int C) {
@@ -206,7 +265,7 @@ static int multi_check(const float* X, int ldx, int M, const mlsp_seg_t* segs, i
 
 // Length of the run of segments starting at s that ONE block-diagonal GEMM launch can take (gemm.hip GemmGroups): same shape and
 // weight pitch, no bias, input slices back to back, widths a multiple of the 128-wide tile, interior 16-byte-aligned operands.
-static int multi_group_run(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, int s) {
+static int multi_group_run(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, int s, const mlsp_defer_t* in = nullptr) {
     static const bool off = getenv("MLSP_NO_GROUPED_GEMM") != nullptr;          // read-once A/B switch
     const mlsp_seg_t& a = segs[s];
     if (off || gemm_precision_mode() == 1 || a.bias || a.Cin % 128 || a.Cout % 128 || M % 128 || ldx % 4 || a.ldw % 4 || (((uintptr_t)X | (uintptr_t)a.W) & 15)) return 1;
@@ -214,6 +273,7 @@ static int multi_group_run(const float* X, int ldx, int M, const mlsp_seg_t* seg
     while (s + n < nseg && n < 4) {
         const mlsp_seg_t& b = segs[s + n];
         if (b.bias || b.Cin != a.Cin || b.Cout != a.Cout || b.ldw != a.ldw || b.x_col != a.x_col + n * a.Cin || ((uintptr_t)b.W & 15)) break;
+        if (in && !multi_defer_same(in[s], in[s + n])) break;                   // one transform per launch
         ++n;
     }
     return n;
@@ -233,22 +293,34 @@ int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg, int precisi
     return 1;
 }
 
-int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* gamma, const float* beta,
+int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const mlsp_defer_t* in, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int training, const float* chan, float p_drop,
                           uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     PREC_SCOPE(precision);
     int Ctot, xw;
     MCHECK(multi_check(X, ldx, M, segs, nseg, Ctot, xw));
-    if (!gamma || !beta || !chan || !Y || !Z || !bn_save || p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
+    if (!gamma || !beta || !chan || !Y || !bn_save || p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;      // Z == NULL: activation deferred to the consumers
     if (!training && (!run_mean || !run_var)) return MLSP_ERR_ARG;
     if (!mlsp_multimlp_supported(M, segs, nseg, precision)) return MLSP_ERR_UNSUPPORTED;
     if ((((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)chan | (uintptr_t)bn_save) & 15) != 0) return MLSP_ERR_UNSUPPORTED;
+    if (in) for (int s = 0; s < nseg; ++s) if (!multi_defer_ok(in[s], segs[s])) return MLSP_ERR_ARG;
     Workspace w(ws, ws_bytes);
     // BatchNorm sums out of the GEMM epilogues when every segment uses the same row-panel height (their partial rows then line up)
     // launches: runs of identical region-head segments go out as ONE block-diagonal GEMM (twice the tiles per launch: the second
     // generation of tiles covers the first one's output pass), the others one by one
     int run[8];
-    for (int s = 0; s < nseg; s += run[s]) { run[s] = multi_group_run(X, ldx, M, segs, nseg, s); for (int t = 1; t < run[s]; ++t) run[s + t] = 0; }
+    bool fuse[8] = {false, false, false, false, false, false, false, false};    // deferred input: the run's GEMM transforms its A operand itself
+    bool any_mat = false;
+    for (int s = 0; s < nseg; s += run[s]) {
+        run[s] = multi_group_run(X, ldx, M, segs, nseg, s, in);
+        if (in) {
+            const mlsp_seg_t& g = segs[s];
+            if (run[s] > 1 && !gemm_xf_on_split(false, true, M, run[s] * g.Cout, g.Cin, 1)) run[s] = 1;
+            fuse[s] = multi_defer_fusable(in[s]) && gemm_xf_supported(false, true, M, run[s] * g.Cout, g.Cin, X + g.x_col, ldx, g.W, g.ldw, 1);
+            any_mat |= !fuse[s];
+        }
+        for (int t = 1; t < run[s]; ++t) run[s + t] = 0;
+    }
     bool fused = training != 0;
     const int bm = gemm_panel_rows(M, run[0] * segs[0].Cout, segs[0].Cin);
     for (int s = 0; s < nseg && fused; s += run[s])
@@ -259,14 +331,28 @@ int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs
     size_t sf = 0;                                             // (small M: a segment's GEMM may split K; then the statistics are a separate pass)
     for (int s = 0; s < nseg; s += run[s]) { const size_t f = gemm_slab_floats(M, run[s] * segs[s].Cout, segs[s].Cin); sf = f > sf ? f : sf; }
     float* slab = sf ? w.take<float>(sf) : nullptr;
+    float* Xa = any_mat ? w.take<float>((size_t)M * ldx) : nullptr;     // activated copies of the slices whose GEMM cannot transform (same layout as X)
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     int ycol = 0;
     for (int s = 0; s < nseg; s += run[s]) {
         const mlsp_seg_t& g = segs[s];
         GemmGroups grp = {run[s], 1, g.Cin, 0, {nullptr, nullptr, nullptr, nullptr}};
         for (int t = 0; t < run[s]; ++t) grp.Bg[t] = segs[s + t].W;
-        MCHECK(launch_gemm(st, false, true, M, run[s] * g.Cout, g.Cin, X + g.x_col, ldx, g.W, g.ldw, Y + ycol, Ctot, g.bias, nullptr, 0, slab, sf,
-                           fused ? part + ycol : nullptr, nullptr, nullptr, nullptr, false, nullptr, Ctot, run[s] > 1 ? &grp : nullptr));
+        const float* Xs = X;
+        GemmXf xf_s; const GemmXf* xf = nullptr;
+        if (in) {
+            xf_s = multi_xf(in[s], 1);
+            if (fuse[s]) xf = &xf_s;
+            else {
+                for (int t = 0; t < run[s]; ++t) {              // (a run without a fused transform: slice by slice into the activated copy)
+                    const GemmXf xt = multi_xf(in[s + t], 1);
+                    MCHECK(launch_xf_materialize_ld(st, X + segs[s + t].x_col, ldx, M, segs[s + t].Cin, xt, Xa + segs[s + t].x_col, ldx));
+                }
+                Xs = Xa;
+            }
+        }
+        MCHECK(launch_gemm(st, false, true, M, run[s] * g.Cout, g.Cin, Xs + g.x_col, ldx, g.W, g.ldw, Y + ycol, Ctot, g.bias, nullptr, 0, slab, sf,
+                           fused ? part + ycol : nullptr, nullptr, nullptr, nullptr, false, xf, Ctot, run[s] > 1 ? &grp : nullptr));
         ycol += run[s] * g.Cout;
     }
     float* scale = bn_save, *shift = bn_save + Ctot, *mean = bn_save + 2 * Ctot, *invstd = bn_save + 3 * Ctot;
@@ -276,6 +362,7 @@ int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs
     } else {
         MCHECK(launch_bn_eval_prepare(st, Ctot, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
     }
+    if (!Z) return MLSP_OK;                                    // deferred: the consumers apply scale / shift / activation / dropout themselves
     const float pd = training ? p_drop : 0.f;
     const int rpb = multi_rows_per_block(M, Ctot);
     hipLaunchKernelGGL(multi_act_fwd_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, st, Y, Z, M, Ctot, rpb, scale, shift, chan,
@@ -283,7 +370,7 @@ int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs
     return mlsp_launch_status();
 }
 
-int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const float* Y,
+int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const mlsp_defer_t* in, const float* Y,
                           const float* bn_save, int training, const float* chan, float p_drop, uint64_t seed, float* dX, int lddx,
                           float* const* dW, float* dbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     PREC_SCOPE(precision);
@@ -292,6 +379,7 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
     if (!dZ || !Y || !bn_save || !chan || !dW || !dgamma || !dbeta || (dX && lddx < xw)) return MLSP_ERR_ARG;
     if (!mlsp_multimlp_supported(M, segs, nseg, precision)) return MLSP_ERR_UNSUPPORTED;
     if ((((uintptr_t)Y | (uintptr_t)dZ | (uintptr_t)chan | (uintptr_t)bn_save) & 15) != 0) return MLSP_ERR_UNSUPPORTED;
+    if (in) for (int s = 0; s < nseg; ++s) if (!multi_defer_ok(in[s], segs[s])) return MLSP_ERR_ARG;
     Workspace w(ws, ws_bytes);
     float* dY = w.take<float>((size_t)M * Ctot);
     const int nparts = bn_vec_parts(M);
@@ -299,10 +387,18 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
     float* mean_dz = w.take<float>(Ctot);
     float* mean_dzy = w.take<float>(Ctot);
     int run[8];                                                 // block-diagonal launches: as in the forward; the wgrad needs the run's dW back to back
+    bool fuse[8] = {false, false, false, false, false, false, false, false};    // deferred input: the run's weight-gradient GEMM transforms its B operand (X) itself
+    bool any_mat = false;
     for (int s = 0; s < nseg; s += run[s]) {
-        run[s] = multi_group_run(X, ldx, M, segs, nseg, s);
+        run[s] = multi_group_run(X, ldx, M, segs, nseg, s, in);
         for (int t = 1; t < run[s]; ++t)
             if (!dW[s + t] || dW[s + t] != dW[s] + (size_t)t * segs[s].Cout * segs[s].Cin) { run[s] = 1; break; }
+        if (in) {
+            const mlsp_seg_t& g = segs[s];
+            if (run[s] > 1 && !gemm_xf_on_split(true, false, run[s] * g.Cout, g.Cin, M, 2)) run[s] = 1;
+            fuse[s] = multi_defer_fusable(in[s]) && gemm_xf_supported(true, false, run[s] * g.Cout, g.Cin, M, dY, Ctot, X + g.x_col, ldx, 2);
+            any_mat |= !fuse[s];
+        }
         for (int t = 1; t < run[s]; ++t) run[s + t] = 0;
     }
     size_t sf = 0;
@@ -311,6 +407,7 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
         sf = f > sf ? f : sf; sf = f2 > sf ? f2 : sf;
     }
     float* slab = sf ? w.take<float>(sf) : nullptr;
+    float* Xa = any_mat ? w.take<float>((size_t)M * ldx) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float pd = training ? p_drop : 0.f;
     const uint32_t th = dropout_thresh8(pd);
@@ -340,9 +437,22 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
             MCHECK(launch_gemm(st, false, false, M, G * g.Cin, g.Cout, dY + ycol, Ctot, g.W, g.ldw, dX + g.x_col, lddx, nullptr, nullptr, 0, slab, sf,
                                nullptr, nullptr, nullptr, nullptr, acc, nullptr, 0, G > 1 ? &grp : nullptr));
         }
+        const float* Xs = X;
+        GemmXf xf_s; const GemmXf* xf = nullptr;
+        if (in) {
+            xf_s = multi_xf(in[s], 2);
+            if (fuse[s]) xf = &xf_s;
+            else {
+                for (int t = 0; t < G; ++t) {
+                    const GemmXf xt = multi_xf(in[s + t], 2);
+                    MCHECK(launch_xf_materialize_ld(st, X + segs[s + t].x_col, ldx, M, segs[s + t].Cin, xt, Xa + segs[s + t].x_col, ldx));
+                }
+                Xs = Xa;
+            }
+        }
         GemmGroups grw = {G, 2, 0, g.Cin, {nullptr, nullptr, nullptr, nullptr}};
-        MCHECK(launch_gemm(st, true, false, G * g.Cout, g.Cin, M, dY + ycol, Ctot, X + g.x_col, ldx, dW[s], g.Cin, nullptr, nullptr, 0, slab, sf,
-                           nullptr, nullptr, nullptr, nullptr, false, nullptr, 0, G > 1 ? &grw : nullptr));
+        MCHECK(launch_gemm(st, true, false, G * g.Cout, g.Cin, M, dY + ycol, Ctot, Xs + g.x_col, ldx, dW[s], g.Cin, nullptr, nullptr, 0, slab, sf,
+                           nullptr, nullptr, nullptr, nullptr, false, xf, 0, G > 1 ? &grw : nullptr));
         ycol += G * g.Cout;
     }
     if (dbias) {

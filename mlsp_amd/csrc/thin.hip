@@ -50,16 +50,20 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------- small N
 // 16 lanes per row: lane g takes the k-quads g, g+16, ... of the row (16-byte coalesced loads), keeps N partial dot products, and the
 // 16 partials of a row are summed with xor-shuffles in a fixed order.  B is staged as Bs[n][k].
-template <bool TB, int NMAX>
+// XF: A holds the PRE-BatchNorm output of the previous layer (GemmXf / XfDev): every loaded quad becomes that layer's activated output
+// first (scale / shift of the K channels staged behind Bs; one dropout hash per quad).
+template <bool TB, int NMAX, bool XF = false>
 __global__ __launch_bounds__(256) void thin_smalln_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                           float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
-                                                          int K) {
-    extern __shared__ __attribute__((aligned(16))) float Bs[];          // [N][K]
+                                                          int K, XfDev xf) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];          // [N][K] (+ XF: scale [K], shift [K])
     const int tid = threadIdx.x;
     for (int i = tid; i < K * N; i += 256) {
         const int n = i / K, k = i - n * K;
         Bs[i] = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
     }
+    float* xs = Bs + K * N;
+    if (XF) for (int i = tid; i < K; i += 256) { xs[i] = xf.scale[i]; xs[K + i] = xf.shift[i]; }
     __syncthreads();
     const int g = tid & 15, sub = tid >> 4;                              // 16 row slots per workgroup pass
     const int kq = K >> 2;
@@ -72,7 +76,13 @@ __global__ __launch_bounds__(256) void thin_smalln_kernel(const float* __restric
 #pragma unroll
         for (int n = 0; n < NMAX; ++n) { acc0[n] = 0.f; acc1[n] = 0.f; }
         for (int q = g; q < kq; q += 16) {
-            const f32x4 x0 = *(const f32x4*)(a0 + 4 * q), x1 = *(const f32x4*)(a1 + 4 * q);
+            f32x4 x0 = *(const f32x4*)(a0 + 4 * q), x1 = *(const f32x4*)(a1 + 4 * q);
+            if (XF) {
+                const f32x4 sc = *(const f32x4*)(xs + 4 * q), sh = *(const f32x4*)(xs + K + 4 * q);
+                const uint32_t q0 = (uint32_t)(((uint64_t)r0 * xf.ld + xf.col + 4 * q) >> 2), q1 = (uint32_t)(((uint64_t)(r1 < M ? r1 : r0) * xf.ld + xf.col + 4 * q) >> 2);
+                x0 = xf_apply_quad(x0, sc, sh, xf.slope, xf.thresh, xf.inv_keep, xf.thresh ? mix32(q0 ^ xf.xH) : 0u);
+                x1 = xf_apply_quad(x1, sc, sh, xf.slope, xf.thresh, xf.inv_keep, xf.thresh ? mix32(q1 ^ xf.xH) : 0u);
+            }
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
@@ -104,10 +114,12 @@ __global__ __launch_bounds__(256) void thin_smalln_kernel(const float* __restric
 // D[s][l] = sum_k S[k][s] * L[k][l]  (S: [K, ns <= 16], L: [K, nl], nl % 4 == 0).  A workgroup owns a K chunk: thread = (column quad
 // of L, row group); it accumulates ns x 4 partials over its rows, the row groups are summed through LDS in a fixed order and the
 // chunk's partial goes to slab[chunk] in the layout of C (ds = stride of s, dl = stride of l), reduced afterwards in slab order.
-template <int NS>
+// XF: the LARGE side L holds the pre-BatchNorm output of the previous layer (the weight gradient of a layer whose input activation was
+// never materialised): this thread's channel quad keeps its scale / shift in registers, every loaded quad is transformed first.
+template <int NS, bool XF = false>
 __global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ S, int lds_, const float* __restrict__ L, int ldl,
                                                       float* __restrict__ slab, size_t slab_stride, int ds, int dl, int K, int ns, int nl,
-                                                      int rows_per_chunk) {
+                                                      int rows_per_chunk, XfDev xf) {
     extern __shared__ __attribute__((aligned(16))) float red[];         // [row groups][NS][nl]
     const int tid = threadIdx.x;
     const int nq = nl >> 2, ngr = 256 / nq;                              // nq in {32, 64, 128}: 8 / 4 / 2 row groups
@@ -117,6 +129,8 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ 
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (gr < ngr) {
+        f32x4 xsc = {0.f, 0.f, 0.f, 0.f}, xsh = {0.f, 0.f, 0.f, 0.f};
+        if (XF) { xsc = *(const f32x4*)(xf.scale + 4 * q); xsh = *(const f32x4*)(xf.shift + 4 * q); }
         for (int kb = k0 + gr; kb < k1; kb += 4 * ngr) {                 // four rows per thread in flight
             f32x4 lv[4];
             float sv[4][NS];
@@ -125,6 +139,10 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ 
                 const int k = kb + u * ngr;
                 const bool ok = k < k1;
                 lv[u] = ok ? *(const f32x4*)(L + (size_t)k * ldl + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (XF && ok) {
+                    const uint32_t qi = (uint32_t)(((uint64_t)k * xf.ld + xf.col + 4 * q) >> 2);
+                    lv[u] = xf_apply_quad(lv[u], xsc, xsh, xf.slope, xf.thresh, xf.inv_keep, xf.thresh ? mix32(qi ^ xf.xH) : 0u);
+                }
                 const float* sp = S + (size_t)(ok ? k : k0) * lds_;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) sv[u][s] = (s < ns) ? sp[s] : 0.f;
@@ -163,10 +181,17 @@ size_t thin_tn_slab_floats(int M, int N, int K) {
 }
 
 // Returns MLSP_ERR_UNSUPPORTED when the shape is not thin (the caller continues with the MFMA kernels).
+// xf (nullable): operand transform (common.h GemmXf); which == 1: A of the small-N kernel, which == 2: the wide B of the A^T B kernel.
+// Any other combination with a transform: MLSP_ERR_UNSUPPORTED.
 int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                     int ldc, const float* bias, float* slab, size_t slab_floats) {
+                     int ldc, const float* bias, float* slab, size_t slab_floats, const GemmXf* xf) {
     auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-    if (!ta && K <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && M >= 1024 && ldc % 4 == 0 && al16(C) && al16(bias)) {
+    XfDev xd = {nullptr, nullptr, 1.f, 1.f, 0u, 0u, 0, 0};
+    if (xf) {
+        if ((xf->ld & 3) || (xf->col & 3) || !al16(xf->scale) || !al16(xf->shift) || (double)(xf->which == 1 ? M : K) * xf->ld >= 17179869184.0) return MLSP_ERR_UNSUPPORTED;
+        xd = xf_dev(*xf);
+    }
+    if (!xf && !ta && K <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && M >= 1024 && ldc % 4 == 0 && al16(C) && al16(bias)) {
         const int nq = N / 4;
         if (256 % nq) return MLSP_ERR_UNSUPPORTED;
         const int rpb = 4 * 256 / nq;                                     // four passes of the workgroup per block
@@ -176,34 +201,47 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
         else hipLaunchKernelGGL((thin_smallk_kernel<false>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb);
         return mlsp_launch_status();
     }
-    if (!ta && N <= 16 && K % 4 == 0 && K >= 64 && K <= 1024 && M >= 1024 && lda % 4 == 0 && al16(A)) {
-        const size_t lds = (size_t)K * N * sizeof(float);
+    if ((!xf || xf->which == 1) && !ta && N <= 16 && K % 4 == 0 && K >= 64 && K <= 1024 && M >= 1024 && lda % 4 == 0 && al16(A)) {
+        const size_t lds = (size_t)K * (N + (xf ? 2 : 0)) * sizeof(float);
         int blocks = (M + 31) / 32;
         if (blocks > 512) blocks = 512;                                      // B is staged once per workgroup: keep many rows per workgroup
-#define THIN_SN(TBV) do { if (N <= 4) hipLaunchKernelGGL((thin_smalln_kernel<TBV, 4>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K); \
-                          else hipLaunchKernelGGL((thin_smalln_kernel<TBV, 16>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K); } while (0)
-        if (tb) THIN_SN(true); else THIN_SN(false);
+#define THIN_SN(TBV, XFV) do { if (N <= 4) hipLaunchKernelGGL((thin_smalln_kernel<TBV, 4, XFV>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, xd); \
+                               else hipLaunchKernelGGL((thin_smalln_kernel<TBV, 16, XFV>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, xd); } while (0)
+        if (xf) { if (tb) THIN_SN(true, true); else THIN_SN(false, true); }
+        else if (tb) THIN_SN(true, false); else THIN_SN(false, false);
 #undef THIN_SN
         return mlsp_launch_status();
     }
+    if (xf && xf->which != 2) return MLSP_ERR_UNSUPPORTED;
     if (ta && !tb && !bias) {
         const size_t need = thin_tn_slab_floats(M, N, K);
         if (!need || !slab || slab_floats < need) return MLSP_ERR_UNSUPPORTED;
         const int chunks = (K + THIN_TN_ROWS - 1) / THIN_TN_ROWS;
         const bool small_m = M <= 16 && N % 4 == 0 && N >= 64;
         if (small_m ? (ldb % 4 || !al16(B)) : (lda % 4 || !al16(A))) return MLSP_ERR_UNSUPPORTED;   // the wide operand is read 16 bytes per lane
+        if (xf && !small_m) return MLSP_ERR_UNSUPPORTED;                                            // the transform is on B = the wide side
         // small side S, large side L; partial slabs are written in C's [M][N] layout
         const float* S = small_m ? A : B; const int lds_ = small_m ? lda : ldb; const int ns = small_m ? M : N;
         const float* L = small_m ? B : A; const int ldl = small_m ? ldb : lda; const int nl = small_m ? N : M;
         const int ds = small_m ? N : 1, dl = small_m ? 1 : N;
         const int ngr = 256 / (nl / 4);
-#define THIN_TN(NSV) hipLaunchKernelGGL((thin_tn_kernel<NSV>), dim3(chunks), dim3(256), (size_t)ngr * NSV * nl * sizeof(float), st, S, lds_, L, ldl, \
-                                        slab, (size_t)M * N, ds, dl, K, ns, nl, THIN_TN_ROWS)
-        if (ns <= 4) THIN_TN(4); else THIN_TN(16);
+#define THIN_TN(NSV, XFV) hipLaunchKernelGGL((thin_tn_kernel<NSV, XFV>), dim3(chunks), dim3(256), (size_t)ngr * NSV * nl * sizeof(float), st, S, lds_, L, ldl, \
+                                             slab, (size_t)M * N, ds, dl, K, ns, nl, THIN_TN_ROWS, xd)
+        if (xf) { if (ns <= 4) THIN_TN(4, true); else THIN_TN(16, true); }
+        else if (ns <= 4) THIN_TN(4, false); else THIN_TN(16, false);
 #undef THIN_TN
         int rc = mlsp_launch_status();
         if (rc != MLSP_OK) return rc;
         return launch_slab_reduce(st, slab, C, M, N, ldc, chunks);
     }
     return MLSP_ERR_UNSUPPORTED;
+}
+
+// does launch_thin_gemm take this contraction WITH an operand transform on `which` (1: A of the small-N kernel, 2: the wide B of A^T B)?
+// (conditions of the two branches above; the slab is the caller's: gemm_slab_floats covers thin_tn_slab_floats)
+bool thin_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which) {
+    auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    if (which == 1) return !ta && N <= 16 && K % 4 == 0 && K >= 64 && K <= 1024 && M >= 1024 && lda % 4 == 0 && al16(A);
+    if (which == 2) return ta && !tb && thin_tn_slab_floats(M, N, K) != 0 && M <= 16 && N % 4 == 0 && N >= 64 && ldb % 4 == 0 && al16(B);
+    return false;
 }

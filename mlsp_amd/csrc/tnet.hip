@@ -1258,7 +1258,7 @@ template <int MODE, int KR> __global__ __launch_bounds__(512) void tnet_edge_bwd
 // LDS images are [row][piece][64 channels] bf16 with a 448-byte row pitch (= 192 mod 256: the four k-rows of a transposed read fall in
 // four different 64-byte bank windows); H' is read both ways (row-major A fragments for H' M, transposed for the products over rows), its
 // 16-byte slots are XOR-swizzled inside each 64-byte block by (row >> 2) & 3 so that the ds_read_b128 pattern is conflict-free as well.
-// H' (56 KB) + W2 (56 KB) + -M (28 KB) + tables = 148 KB, one workgroup of 8 waves per CU.
+// H' (56 KB) + W2 (56 KB) + -M (28 KB) + tables = sizeof(TnetBwdSLds), about 158 KB of the CU's 160: one workgroup of 8 waves per CU.
 typedef __bf16 tbf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int tu32x2 __attribute__((ext_vector_type(2)));
 #define TB_PITCH 448
@@ -1341,6 +1341,7 @@ __global__ __launch_bounds__(512) void tnet_edge_bwds_kernel(
     const float* __restrict__ Mc, const float* __restrict__ g, const uint8_t* __restrict__ argsel, float* __restrict__ dhp,
     float* __restrict__ slabs, double* __restrict__ part1, int P, int N, int k, int TP, float slope) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    static_assert(sizeof(TnetBwdSLds) <= 160 * 1024, "tnet_edge_bwds_kernel: the LDS image must fit one CU");
     TnetBwdSLds& L = *reinterpret_cast<TnetBwdSLds*>(smraw);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;

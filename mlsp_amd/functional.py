@@ -508,17 +508,27 @@ class _SplitColumnsShared(Function):
 
 
 def split_columns_shared(H, widths):
-    """column slices of H for consumers that support `grad_cols=` (pointmlp): -> (slices, SharedColumnGrad)."""
+    """column slices of H for consumers that support `grad_cols=` (pointmlp): -> (slices, SharedColumnGrad).  H may be a DeferredAct
+    (its slices are DeferredActs over views of the pre-BN matrix)."""
     acc = SharedColumnGrad(sum(widths))
+    if isinstance(H, DeferredAct):
+        outs, subs, o = _SplitColumnsShared.apply(H.y, acc, tuple(widths)), [], 0
+        for sl, w in zip(outs, widths):
+            subs.append(H.sub(sl, o))
+            o += w
+        return tuple(subs), acc
     return _SplitColumnsShared.apply(H, acc, tuple(widths)), acc
 
 
 class _MultiMLP(Function):
     """Several Linear (+bias) layers side by side under ONE BatchNorm + activation (+dropout) pass (include/mlsp_hip.h
-    mlsp_multimlp_*_f32; csrc/multi.hip).  X [M, ldx] fp32; segment s reads columns x_cols[s] .. + Cin_s and writes its Cout_s columns."""
+    mlsp_multimlp_*_f32; csrc/multi.hip).  X [M, ldx] fp32; segment s reads columns x_cols[s] .. + Cin_s and writes its Cout_s columns.
+    `in_defs` (tuple of DeferredAct.desc() per segment, or None): X is the previous merged layer's PRE-BatchNorm output and every
+    segment's GEMM applies that layer's scale / shift / activation / dropout while it stages its operand.  `defer_out`: this layer's own
+    activation pass is left to its consumers: the Function returns Y (pre-BN) in place of Z."""
 
     @staticmethod
-    def forward(ctx, X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, *wb):
+    def forward(ctx, X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, in_defs, defer_out, *wb):
         lib = _lib.load()
         prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         n = len(x_cols)
@@ -533,19 +543,23 @@ class _MultiMLP(Function):
         segs = (_lib.Seg * n)()
         for i, (w, b, xc) in enumerate(zip(Ws, bs, x_cols)):
             segs[i].W, segs[i].bias, segs[i].ldw, segs[i].x_col, segs[i].Cin, segs[i].Cout = w.data_ptr(), _lib.ptr(b), w.stride(0), xc, w.shape[1], w.shape[0]
+        defs = None
+        if in_defs is not None:
+            defs = (_lib.Defer * n)(*[_defer_struct(d) for d in in_defs])
         Y = torch.empty((M, Ctot), dtype=torch.float32, device=dev)
-        Z = torch.empty((M, Ctot), dtype=torch.float32, device=dev)
+        Z = None if defer_out else torch.empty((M, Ctot), dtype=torch.float32, device=dev)
         bn_save = torch.empty((4, Ctot), dtype=torch.float32, device=dev)
         p = float(p_drop) if training else 0.0
         ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
-        _lib.check(lib.mlsp_multimlp_fwd_f32(X.data_ptr(), X.stride(0), M, segs, n, gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean),
+        _lib.check(lib.mlsp_multimlp_fwd_f32(X.data_ptr(), X.stride(0), M, segs, n, defs, gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean),
                                              _lib.ptr(run_var), momentum, eps, int(training), chan.data_ptr(), p, seed, Y.data_ptr(),
-                                             Z.data_ptr(), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_multimlp_fwd_f32")
+                                             _lib.ptr(Z), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_multimlp_fwd_f32")
         ctx.save_for_backward(X, Y, bn_save, chan, *Ws)
         ctx.cfg = (tuple(x_cols), bool(training), p, seed, [b is not None for b in bs])
+        ctx.in_defs = in_defs
         ctx.mark_non_differentiable(bn_save)
         ctx.set_materialize_grads(False)
-        return Z, bn_save
+        return (Y.view_as(Y) if defer_out else Z), bn_save
 
     @staticmethod
     @once_differentiable
@@ -553,7 +567,7 @@ class _MultiMLP(Function):
         x_cols, training, p, seed, has_b = ctx.cfg
         n = len(x_cols)
         if dZ is None:
-            return (None,) * (12 + 2 * n)
+            return (None,) * (14 + 2 * n)
         lib = _lib.load()
         X, Y, bn_save, chan = ctx.saved_tensors[:4]
         Ws = ctx.saved_tensors[4:]
@@ -563,6 +577,9 @@ class _MultiMLP(Function):
         segs = (_lib.Seg * n)()
         for i, (w, xc) in enumerate(zip(Ws, x_cols)):
             segs[i].W, segs[i].bias, segs[i].ldw, segs[i].x_col, segs[i].Cin, segs[i].Cout = w.data_ptr(), None, w.stride(0), xc, w.shape[1], w.shape[0]
+        defs = None
+        if ctx.in_defs is not None:
+            defs = (_lib.Defer * n)(*[_defer_struct(d) for d in ctx.in_defs])
         dX = None
         if ctx.needs_input_grad[0]:
             covered = sorted((xc, xc + w.shape[1]) for xc, w in zip(x_cols, Ws))
@@ -579,7 +596,7 @@ class _MultiMLP(Function):
         dgamma = torch.empty((Ctot,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((Ctot,), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
-        _lib.check(lib.mlsp_multimlp_bwd_f32(dZ.data_ptr(), X.data_ptr(), X.stride(0), M, segs, n, Y.data_ptr(), bn_save.data_ptr(),
+        _lib.check(lib.mlsp_multimlp_bwd_f32(dZ.data_ptr(), X.data_ptr(), X.stride(0), M, segs, n, defs, Y.data_ptr(), bn_save.data_ptr(),
                                              int(training), chan.data_ptr(), p, seed, _lib.ptr(dX), dX.stride(0) if dX is not None else 0,
                                              dwp, _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()),
                    "mlsp_multimlp_bwd_f32")
@@ -587,7 +604,7 @@ class _MultiMLP(Function):
         for w, hb in zip(Ws, has_b):
             dbs.append(dbias[o:o + w.shape[0]] if hb else None)
             o += w.shape[0]
-        return (dX, dgamma, dbeta) + (None,) * 9 + tuple(dWs) + tuple(dbs)
+        return (dX, dgamma, dbeta) + (None,) * 11 + tuple(dWs) + tuple(dbs)
 
 
 _chan_cache = {}
@@ -606,6 +623,8 @@ def channel_params(device, spec):
 
 
 def multimlp_supported(M, X, Ws, x_cols):
+    if isinstance(X, DeferredAct):
+        X = X.y
     if (activation_storage.current != "fp32" or gemm_precision.current == "bf16" or X.dtype != torch.float32 or X.dim() != 2
             or X.stride(1) != 1 or not X.is_cuda):
         return False
@@ -616,15 +635,27 @@ def multimlp_supported(M, X, Ws, x_cols):
     return bool(_lib.load().mlsp_multimlp_supported(int(M), segs, n, gemm_precision.code()))
 
 
-def multimlp(X, segs, gamma, beta, run_mean, run_var, chan, training=True, p_drop=0.0, momentum=0.1, eps=1e-5):
+def multimlp(X, segs, gamma, beta, run_mean, run_var, chan, training=True, p_drop=0.0, momentum=0.1, eps=1e-5, chain=False, spec=None):
     """segs = [(x_col, W [Cout, Cin], bias | None), ...] -> Z [M, sum Cout]: every segment's Linear on its column slice of X, then ONE
-    BatchNorm (batch statistics over the M rows, all channels), per-channel activation and dropout (chan from channel_params)."""
+    BatchNorm (batch statistics over the M rows, all channels), per-channel activation and dropout (chan from channel_params).
+    X may be a DeferredAct (the previous merged layer's pre-BN output).  `chain=True` (every consumer is a pointmlp / multimlp) with
+    `spec` = the channel_params spec of THIS layer: the result is a DeferredAct, the BN + activation pass is left to the consumers."""
     x_cols = tuple(int(s[0]) for s in segs)
     Ws = [s[1] for s in segs]
     bs = [s[2] for s in segs]
     any_drop = training and p_drop > 0
     seed = _next_seed() if any_drop else 0
-    out, _ = _MultiMLP.apply(X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, *Ws, *bs)
+    in_defs = None
+    if isinstance(X, DeferredAct):
+        in_defs = tuple(X.desc(xc, w.shape[1]) for xc, w in zip(x_cols, Ws))
+        assert X.col == 0 and X.y.shape[1] == X.ld, "multimlp reads column slices of the producer's whole matrix"
+        X = X.y
+    defer_out = bool(chain) and spec is not None and _can_defer(X.shape[0], X.dtype)
+    out, bn_save = _MultiMLP.apply(X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, in_defs, defer_out,
+                                   *Ws, *bs)
+    if defer_out:
+        p = float(p_drop) if training else 0.0
+        return DeferredAct(out, bn_save, out.shape[1], 0, tuple((c, f, bool(d) and p > 0) for c, f, d in spec), p, seed)
     return out
 
 
@@ -774,23 +805,25 @@ def tnet_edge_supported(W1, W2, k):
     return W1.shape[0] == 64 and tuple(W2.shape) == (128, 64) and 1 <= k <= 128
 
 
-# Deferred activations of chained layers (DeferredAct below) are opt-in: MLSP_DEFERRED_ACT=1.  Measured on the DGCNN step they remove
-# six streaming passes (-98 us) and cost +66 us in the twelve consumer GEMMs (vector work does not hide under the matrix pipe on
-# gfx950), i.e. -0.5 % step time for a GEMM family that runs 4 % slower -- not worth it by default; profitable where the consumer has
-# <= 128 output channels.
-_DEFER_CHAINS = os.environ.get("MLSP_DEFERRED_ACT") is not None
+# Deferred activations of chained layers (DeferredAct below): a Linear+BN+act(+dropout) layer whose consumers are all GEMM layers writes
+# only its pre-BatchNorm output; the consumers apply scale / shift / activation / dropout while they stage their operand
+# (gemm_split_kernel<.., XF, XD>, the f32 transform kernels, the thin streaming kernels).  On by default in the "bf16x6" and "fp32" product
+# modes with fp32 activation storage; MLSP_DEFERRED_ACT=0 restores the materialised chain (an A/B switch, read once).
+_DEFER_CHAINS = os.environ.get("MLSP_DEFERRED_ACT", "1") not in ("0", "")
 
 
 class DeferredAct:
-    """Output of a chained Linear+BN+act layer (pointmlp(..., chain=True), fp32 storage) whose BatchNorm scale / shift, activation
-    and dropout have NOT been applied yet: `y` is the pre-BN GEMM output, an autograd tensor that stands for the activated output
-    (gradients flowing into it are gradients w.r.t. the activated value), `bn_save` [4, C] the layer's scale | shift | mean | invstd.
-    The only legal consumer is another pointmlp, which applies the transform in its GEMM operand loads (include/mlsp_hip.h
-    mlsp_pointmlp_*_chain_f32): the streaming BN+act pass and the activated tensor disappear."""
-    __slots__ = ("y", "bn_save", "act", "slope", "p", "seed")
+    """Output of a chained Linear+BN+act layer (pointmlp / multimlp with chain=True, fp32 storage) whose BatchNorm scale / shift,
+    activation and dropout have NOT been applied yet.  `y`: columns [col, col + width) of the producer's pre-BN matrix [M, ld] -- an
+    autograd tensor that STANDS FOR the activated output (gradients flowing into it are gradients w.r.t. the activated value);
+    `bn_save` [4, ld]: the producer's scale | shift | mean | invstd; `spec`: ((width, negative-side factor, dropout on), ...) covering
+    the columns of `y` in order (factor 0 = ReLU, 0.2 = LeakyReLU(0.2), 1 = no activation); `p`, `seed`: the producer's dropout stream.
+    Legal consumers: pointmlp (a slice with ONE spec entry), multimlp (segments inside one spec entry each), split_columns_shared."""
+    __slots__ = ("y", "bn_save", "ld", "col", "spec", "p", "seed")
 
-    def __init__(self, y, bn_save, act, slope, p, seed):
-        self.y, self.bn_save, self.act, self.slope, self.p, self.seed = y, bn_save, int(act), float(slope), float(p), int(seed)
+    def __init__(self, y, bn_save, ld, col, spec, p, seed):
+        self.y, self.bn_save, self.ld, self.col, self.spec, self.p, self.seed = y, bn_save, int(ld), int(col), tuple(spec), float(p), int(seed)
+        assert sum(w for w, _, _ in self.spec) == y.shape[1], (self.spec, y.shape)
 
     @property
     def shape(self):
@@ -804,11 +837,52 @@ class DeferredAct:
     def dtype(self):
         return self.y.dtype
 
+    def dim(self):
+        return self.y.dim()
+
+    def entry(self, c0, width):
+        """(negative-side factor, dropout rate) of the columns [c0, c0 + width) of y -- they must lie inside one spec entry"""
+        o = 0
+        for w, fac, drop in self.spec:
+            if o <= c0 and c0 + width <= o + w:
+                return float(fac), (self.p if drop else 0.0)
+            o += w
+        raise ValueError("DeferredAct: columns [%d, %d) straddle activations %r" % (c0, c0 + width, self.spec))
+
+    def desc(self, c0=0, width=None):
+        """mlsp_defer_t fields of the columns [c0, c0 + width) of y: (bn_save tensor, ld, col, act, slope, p_drop, seed)"""
+        width = self.y.shape[1] - c0 if width is None else width
+        fac, p = self.entry(c0, width)
+        return (self.bn_save, self.ld, self.col + c0, ACT_LRELU, fac, p, self.seed)
+
+    def sub(self, y_slice, c0):
+        """the DeferredAct of a column slice `y_slice` = y[:, c0 : c0 + w] (an autograd view of y)"""
+        w, spec, o = y_slice.shape[1], [], 0
+        for sw, fac, drop in self.spec:
+            lo, hi = max(o, c0), min(o + sw, c0 + w)
+            if hi > lo:
+                spec.append((hi - lo, fac, drop))
+            o += sw
+        return DeferredAct(y_slice, self.bn_save, self.ld, self.col + c0, spec, self.p, self.seed)
+
+
+def _defer_struct(d):
+    """ctypes mlsp_defer_t from DeferredAct.desc()"""
+    bn, ld, col, act, slope, p, seed = d
+    s = _lib.Defer()
+    s.bn_save, s.ld, s.col, s.act, s.slope, s.p_drop, s.seed = bn.data_ptr(), ld, col, act, slope, p, seed
+    return s
+
+
+def _can_defer(M, dtype):
+    return (_DEFER_CHAINS and activation_storage.current == "fp32" and gemm_precision.current in ("fp32", "bf16x6") and M > 32
+            and dtype == torch.float32)
+
 
 class _PointMLP(Function):
     @staticmethod
     def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,
-                momentum, eps, grad_accum=None, out_bf16=False, in_bn=None, in_cfg=None, defer_out=False, grad_cols=None):
+                momentum, eps, grad_accum=None, out_bf16=False, in_def=None, defer_out=False, grad_cols=None):
         lib = _lib.load()
         prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         X = _rows(X, allow_bf16=True)
@@ -827,7 +901,7 @@ class _PointMLP(Function):
             if x_bf16:
                 raise RuntimeError("pointmlp: bf16 input on a layer the bf16-storage kernels do not cover (M=%d Cin=%d Cout=%d)" % (M, Cin, Cout))
             mx = out_bf16 = False
-        assert not (mx and (in_bn is not None or defer_out)), "bf16 activation storage and deferred activations are exclusive"
+        assert not (mx and (in_def is not None or defer_out)), "bf16 activation storage and deferred activations are exclusive"
         assert not defer_out or has_bn
         odt = torch.bfloat16 if out_bf16 else torch.float32
         Z = None if defer_out else torch.empty((M, Cout), dtype=odt, device=dev)
@@ -846,10 +920,10 @@ class _PointMLP(Function):
                 int(rows_per_group), gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
                 int(training), act, slope, p, seed, Y.data_ptr(), Z.data_ptr(), int(out_bf16), bn_save.data_ptr(), prec, ws, wsn,
                 _lib.stream()), "mlsp_pointmlp_fwd_mx")
-        elif in_bn is not None:
-            iact, islope, ip, iseed = in_cfg
+        elif in_def is not None:
+            ds = _defer_struct(in_def)
             _lib.check(lib.mlsp_pointmlp_fwd_chain_f32(
-                X.data_ptr(), X.stride(0), in_bn.data_ptr(), iact, islope, ip, iseed, M, Cin, W.data_ptr(), W.stride(0), Cout,
+                X.data_ptr(), X.stride(0), _lib._c.byref(ds), M, Cin, W.data_ptr(), W.stride(0), Cout,
                 _lib.ptr(bias), _lib.ptr(gbias), int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean),
                 _lib.ptr(run_var), momentum, eps, int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), prec, ws, wsn,
                 _lib.stream()), "mlsp_pointmlp_fwd_chain_f32")
@@ -859,7 +933,7 @@ class _PointMLP(Function):
                 int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
                 int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_fwd_f32")
-        ctx.in_bn, ctx.in_cfg = in_bn, in_cfg
+        ctx.in_def = in_def
         ctx.save_for_backward(X, W, Y, bn_save)
         ctx.cfg = (has_bn, training, act, slope, p, seed, bias is not None, gbias.shape[0] if gbias is not None else 0,
                    int(rows_per_group))
@@ -875,7 +949,7 @@ class _PointMLP(Function):
     @once_differentiable
     def backward(ctx, dZ, _dbn=None):
         if dZ is None:
-            return (None,) * 22
+            return (None,) * 21
         lib = _lib.load()
         X, W, Y, bn_save = ctx.saved_tensors
         has_bn, training, act, slope, p, seed, has_bias, G, rpg = ctx.cfg
@@ -908,10 +982,10 @@ class _PointMLP(Function):
                 int(out_bf16), bn_save.data_ptr(), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
                 dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_mx")
-        elif ctx.in_bn is not None:
-            iact, islope, ip, iseed = ctx.in_cfg
+        elif ctx.in_def is not None:
+            ds = _defer_struct(ctx.in_def)
             _lib.check(lib.mlsp_pointmlp_bwd_chain_f32(
-                dZ.data_ptr(), X.data_ptr(), X.stride(0), ctx.in_bn.data_ptr(), iact, islope, ip, iseed, M, Cin, W.data_ptr(), W.stride(0),
+                dZ.data_ptr(), X.data_ptr(), X.stride(0), _lib._c.byref(ds), M, Cin, W.data_ptr(), W.stride(0),
                 Cout, _lib.ptr(Y), _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
                 dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ctx.prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_chain_f32")
@@ -921,16 +995,20 @@ class _PointMLP(Function):
                 _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate, dW.data_ptr(),
                 _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ctx.prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_f32")
-        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 16
+        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 15
 
 
 def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, run_var=None, rows_per_group=0,
-             training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5, grad_accum=None, chain=False, grad_cols=None):
+             training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5, grad_accum=None, chain=False, grad_cols=None,
+             defer=False):
     """Linear/1x1-conv (+bias, +per-group bias) [+ BatchNorm + act + dropout] on a [M,Cin] row matrix.
     `grad_accum`: the SharedInputGrad of a fan_out(X, n) whose alias this X is.  `chain=True`: the only consumer of the output is
     another pointmlp BN layer, so under activation_storage("bf16") Y / Z may be stored as bf16.  `grad_cols` = (SharedColumnGrad, first
-    column): X is that column slice of a split_columns_shared() matrix."""
+    column): X is that column slice of a split_columns_shared() matrix.  `defer=True`: every consumer of the output is a GEMM layer
+    (pointmlp / multimlp, with or without BatchNorm): under fp32 storage the result may be a DeferredAct (`chain=True` implies it)."""
     seed = _next_seed() if (training and p_drop > 0) else 0
+    if isinstance(X, DeferredAct) and grad_cols is not None:
+        assert grad_cols[0].width == X.ld and grad_cols[1] == X.col, "grad_cols of a deferred slice: its columns in the producer's matrix"
     if (not isinstance(X, DeferredAct) and X.dtype == torch.bfloat16 and not (
             gamma is not None and X.dim() == 2 and X.stride(1) == 1 and
             _lib.load().mlsp_pointmlp_mx_supported(X.shape[0], X.shape[1], W.shape[0], X.stride(0), 1, int(training), gemm_precision.code()))):
@@ -938,16 +1016,17 @@ def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, 
         # kernels (e.g. a consumer whose GEMM splits K): widen once and run the fp32 layer; autograd narrows the gradient again
         X = X.float()
     out_bf16 = bool(chain) and activation_storage.current == "bf16" and gamma is not None
-    in_bn = in_cfg = None
+    in_def = None
     if isinstance(X, DeferredAct):
-        in_bn, in_cfg, X = X.bn_save, (X.act, X.slope, X.p, X.seed), X.y
-    # fp32 storage: a chained layer leaves its BN + activation (+ dropout) to its consumer's GEMM operand loads
-    defer_out = (bool(chain) and gamma is not None and activation_storage.current == "fp32" and gemm_precision.current == "fp32"
-                 and X.shape[0] > 32 and X.dtype == torch.float32 and _DEFER_CHAINS)
+        in_def, X = X.desc(), X.y
+    # fp32 storage: a chained layer leaves its BN + activation (+ dropout) to its consumers' GEMM operand loads
+    defer_out = bool(chain or defer) and gamma is not None and _can_defer(X.shape[0], X.dtype)
     out, bn_save = _PointMLP.apply(X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop,
-                                   seed, momentum, eps, grad_accum, out_bf16, in_bn, in_cfg, defer_out, grad_cols)
+                                   seed, momentum, eps, grad_accum, out_bf16, in_def, defer_out, grad_cols)
     if defer_out:
-        return DeferredAct(out, bn_save, act, slope, float(p_drop) if training else 0.0, seed)
+        fac = 1.0 if act == ACT_NONE else 0.0 if act == ACT_RELU else float(slope)
+        p = float(p_drop) if training else 0.0
+        return DeferredAct(out, bn_save, out.shape[1], 0, ((out.shape[1], fac, p > 0),), p, seed)
     return out
 
 

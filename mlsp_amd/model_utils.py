@@ -182,9 +182,10 @@ class fc_layer(nn.Module):
         self.act = _ACT[activation]
 
     @flushing_forward
-    def forward(self, x, p_drop=0.0, chain=False, grad_cols=None):
+    def forward(self, x, p_drop=0.0, chain=False, grad_cols=None, defer=False):
         """x [M,in] -> [M,out]; `p_drop` fuses the Dropout that follows this layer in the reference; `chain`: the output only
-        feeds another Linear+BN layer (it may then be stored as bf16 under functional.activation_storage("bf16"))."""
+        feeds another Linear+BN layer (it may then be stored as bf16 under functional.activation_storage("bf16")); `defer`: it only
+        feeds GEMM layers (functional.pointmlp)."""
         lin = self.fc[0]
         if not self.has_bn:
             # fc_layer(bn=False) (model_utils.py:80-84): Linear + activation = the fused layer with an identity BatchNorm in eval
@@ -197,7 +198,7 @@ class fc_layer(nn.Module):
         rm, rv = _bn_buffers(bn, self.training)
         return Fh.pointmlp(x, lin.weight, bias=lin.bias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
                            training=self.training, act=self.act, slope=0.2, p_drop=p_drop, momentum=bn.momentum, eps=bn.eps,
-                           chain=chain, grad_cols=grad_cols)
+                           chain=chain, grad_cols=grad_cols, defer=defer)
 
 
 class transform_net(nn.Module):
