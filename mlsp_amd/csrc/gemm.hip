@@ -846,7 +846,7 @@ __device__ __forceinline__ f32x4 sx_bufload(__amdgpu_buffer_rsrc_t rs, int voff,
 // the same order, as the streaming pass it replaces (bn_act_fwd_vec_kernel / multi_act_fwd_kernel), so the product is bit-identical to the
 // one over the materialised tensor.  XF == 1: A row-major [M][K], channel = k (forward of the consumer layer); XF == 2: B k-major [K][N],
 // channel = n (the consumer's weight gradient, X^T side).  Both also in block-diagonal launches (the group's channels start at
-// g * a_gs / g * b_gs).  The vector work rides in the split stream's slots (gen_split_body.py: SX_XF_A / SX_XF_B).
+// g * a_gs / g * b_gs).  The vector work rides in the split stream's slots (gen_split_body.py variants xa / xad / xb / xbd).
 template <bool TA, bool TB, int WM, int XF = 0, bool XD = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     static_assert(XF == 0 || (XF == 1 && !TA) || (XF == 2 && !TB), "XF == 1: A row-major; XF == 2: B k-major");
@@ -955,15 +955,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
             v[c] = a;
         }
     };
-#define SX_XF_A(q_, hh_) do { if constexpr (XF == 1) { if (XD && (hh_) == 0) xhq = mix32((xq + (uint32_t)((q_) * xqs)) ^ xH); xf_pair(raw[q_], hh_); } } while (0)
-#define SX_XF_B(q_, hh_) do { if constexpr (XF == 2) { if (XD && (hh_) == 0) xhq = mix32((xq + (uint32_t)((q_) * xqs)) ^ xH); xf_pair(raw[NQA + (q_)], hh_); } } while (0)
+#define SX_XF_HASH_A(q_) do { if constexpr (XF == 1 && XD) xhq = mix32((xq + (uint32_t)((q_) * xqs)) ^ xH); } while (0)
+#define SX_XF_HASH_B(q_) do { if constexpr (XF == 2 && XD) xhq = mix32((xq + (uint32_t)((q_) * xqs)) ^ xH); } while (0)
+#define SX_XF_A(q_, hh_) do { if constexpr (XF == 1) xf_pair(raw[q_], hh_); } while (0)
+#define SX_XF_B(q_, hh_) do { if constexpr (XF == 2) xf_pair(raw[NQA + (q_)], hh_); } while (0)
     // after a tile's quads are transformed: on to the tile after it (the stream always stages "tile t+1"; past the end a harmless repeat)
 #define SX_XF_NEXT(tnext_) do { if constexpr (XF != 0) { xq += (uint32_t)xqt; if constexpr (XF == 1) { const int tc_ = min((tnext_), T - 1) * BK + (tid & 7) * 4; \
         xsc = *(const f32x4*)(xfs + tc_); xsh = *(const f32x4*)(xfs + SX_XF_KMAX + tc_); } } } while (0)
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) { raw[q] = SX_LOAD_A(q); SX_XF_A(q, 0); SX_XF_A(q, 1); sx_split_store(raw[q], wa + q * WQA); }
+    for (int q = 0; q < NQA; ++q) { raw[q] = SX_LOAD_A(q); SX_XF_HASH_A(q); SX_XF_A(q, 0); SX_XF_A(q, 1); sx_split_store(raw[q], wa + q * WQA); }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { raw[NQA + q] = SX_LOAD_B(q); SX_XF_B(q, 0); SX_XF_B(q, 1); sx_split_store(raw[NQA + q], wb + q * WQB); }
+    for (int q = 0; q < 4; ++q) { raw[NQA + q] = SX_LOAD_B(q); SX_XF_HASH_B(q); SX_XF_B(q, 0); SX_XF_B(q, 1); sx_split_store(raw[NQA + q], wb + q * WQB); }
     SX_XF_NEXT(1);
     soa = min(soa + sta, enda); sob = min(sob + stb, endb);
 #pragma unroll
@@ -987,10 +989,37 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
         uint32_t pk0[2], pk1[2], pk2[2];
         float r0, r1, a1;
         __builtin_amdgcn_sched_barrier(0);
-        if (WM == 2) {
+        // (one generated body per (tile height, transformed operand, dropout): gen_split_body.py spreads the vector work over the MFMA slots)
+        if constexpr (XF == 0) {
+            if (WM == 2) {
 #include "gemm_split_body_wm2.inc"
-        } else {
+            } else {
 #include "gemm_split_body_wm1.inc"
+            }
+        } else if constexpr (XF == 1 && !XD) {
+            if (WM == 2) {
+#include "gemm_split_body_wm2_xa.inc"
+            } else {
+#include "gemm_split_body_wm1_xa.inc"
+            }
+        } else if constexpr (XF == 1 && XD) {
+            if (WM == 2) {
+#include "gemm_split_body_wm2_xad.inc"
+            } else {
+#include "gemm_split_body_wm1_xad.inc"
+            }
+        } else if constexpr (XF == 2 && !XD) {
+            if (WM == 2) {
+#include "gemm_split_body_wm2_xb.inc"
+            } else {
+#include "gemm_split_body_wm1_xb.inc"
+            }
+        } else {
+            if (WM == 2) {
+#include "gemm_split_body_wm2_xbd.inc"
+            } else {
+#include "gemm_split_body_wm1_xbd.inc"
+            }
         }
         SX_XF_NEXT(t + 2);
         __syncthreads();
@@ -999,6 +1028,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
 #undef SX_LOAD_B
 #undef SX_XF_A
 #undef SX_XF_B
+#undef SX_XF_HASH_A
+#undef SX_XF_HASH_B
 #undef SX_XF_NEXT
     gemm_epilogue<WM, true, false>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 }

@@ -987,6 +987,7 @@ def test_merged_layers_deferred_activation_chain(dev, M, training, mode, monkeyp
     Fh = _fh()
     import itertools as it
     C0 = 512
+    torch.manual_seed(1234)          # (the dropout streams are keyed by torch.initial_seed(), which is random per process by default)
 
     def run(defer):
         monkeypatch.setattr(Fh, "_DEFER_CHAINS", defer)
@@ -1030,8 +1031,10 @@ def test_merged_layers_deferred_activation_chain(dev, M, training, mode, monkeyp
         else:
             # mode "fp32": the f32 transform kernels take no block-diagonal launch, so the deferred path runs the two region-head segments
             # one by one -- with another row-panel height, i.e. another grouping of the BatchNorm partial sums: last-bit differences
+            # ... and a last-bit difference in a pre-activation flips a ReLU for a handful of the 10^7 elements, which moves a whole
+            # gradient row: outputs / statistics at rounding level, gradients at the level of that re-routing
             rel = ((x - y).double().norm() / (y.double().norm() + 1e-30)).item()
-            assert rel < 2e-5, (i, tuple(x.shape), rel)
+            assert rel < (1e-5 if i < 3 or i >= len(a) - 6 else 5e-3), (i, tuple(x.shape), rel)
 
 
 # ----------------------------------------------------------------------------- conv + BN + act + max over N (Gram backward)
