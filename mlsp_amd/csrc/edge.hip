@@ -15,6 +15,7 @@
 // reverse index built by knn.hip (deterministic, no float atomics).
 #include "common.h"
 #include <math.h>
+#include <cstdlib>
 
 #define EDGE_PTS_PER_WAVE 16
 
@@ -247,6 +248,105 @@ __global__ __launch_bounds__(256) void edge_reduce_lds_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             b4[e] = best[e]; s4[e] = s1[e]; a4 |= (uint32_t)(bs[e] & 255) << (8 * e);
+            ps[e] += (double)s1[e] + (double)k * v[e];
+            pq[e] += (double)s2[e] + 2.0 * (double)v[e] * s1[e] + (double)k * v[e] * v[e];
+        }
+        *(f32x4*)(msel + i * Cout + c0 + 4 * q) = b4;
+        *(f32x4*)(s1out + i * Cout + c0 + 4 * q) = s4;
+        *(uint32_t*)(argsel + i * Cout + c0 + 4 * q) = a4;
+    }
+    __syncthreads();                                           // Us is dead: reuse it for the fp64 column reduction
+    double* red = (double*)esm;                                // [2][PL][CS]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[(0 * PL + pl) * CS + 4 * q + e] = ps[e]; red[(1 * PL + pl) * CS + 4 * q + e] = pq[e]; }
+    __syncthreads();
+    if (tid < 2 * CS) {
+        const int which = tid / CS, c = tid % CS;
+        double a = 0.0;
+        for (int u = 0; u < PL; ++u) a += red[(which * PL + u) * CS + c];
+        part[((size_t)(b * psplit + ch) * 2 + which) * Cout + c0 + c] = a;
+    }
+}
+
+// ---- round 5: the same reduction with WIDE slices, one workgroup of 1024 threads per CU -----------------------------------------------
+// Where edge_reduce_lds_kernel's time went (rocprofv3, B = 32, N = 1024, k = 20: 23 / 36 / 70 us at Cout = 64 / 128 / 256 for ~4 / 8 / 16 us
+// of vector work): 8-channel slices are 32-byte pieces of 512 .. 2048-byte rows -- a quarter of every cache line fetched is used -- and
+// with the point range cut in four (to keep the u16 neighbour lists small) every workgroup stages its slice of the WHOLE cloud for a
+// quarter of the points: 134 MB of staging per launch at Cout = 256, line traffic 4x that.  Here a slice is CS = 16 channels (64-byte
+// half lines), staged ONCE per (cloud, slice) when the grid allows, 64 KB per workgroup of 512 threads, two workgroups per CU (N <= 1024;
+// one of 1024 threads for N <= 2048); a thread = (point, channel quad) walks the k neighbours of its point in slot order.  The neighbour
+// indices are not staged: the lanes of a point read the same 80 bytes from global (one broadcast line).  The selection runs on t = +-u (sign
+// of the BatchNorm scale folded in at staging: the max search is one compare, the sums are the same IEEE operations on negated values).
+template <int KMAX, bool EXACT, int CS, int NT>
+__global__ __launch_bounds__(NT) void edge_reduce_wide_kernel(const float* __restrict__ uv, const int* __restrict__ idx,
+                                                                const float* __restrict__ gamma, int B, int N, int k, int Cout, int psplit,
+                                                                float* __restrict__ msel, uint8_t* __restrict__ argsel,
+                                                                float* __restrict__ s1out, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float esm[];
+    constexpr int QPP = CS / 4, PL = NT / QPP;                 // quads per point, points per pass
+    float* Us = esm;                                           // [N][CS]  (+-u)
+    const int tid = threadIdx.x;
+    const int nsl = Cout / CS, bpc = nsl * psplit;
+    int b, r;
+    xcd_cloud_map(blockIdx.x, bpc, B, b, r);                   // all workgroups of a cloud on one XCD: uv rows come from its L2
+    const int sl = r % nsl, ch = r / nsl;
+    const int c0 = sl * CS, ld = 2 * Cout;
+    const int pper = (N + psplit - 1) / psplit, pbeg = ch * pper, pend = min(N, pbeg + pper);
+    const int q = tid % QPP, pl = tid / QPP;
+    const float* ub = uv + (size_t)b * N * ld;
+    const f32x4 g4 = *(const f32x4*)(gamma + c0 + 4 * q);
+    f32x4 sg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sg[e] = g4[e] >= 0.f ? 1.f : -1.f;
+    for (int row = pl; row < N; row += 4 * PL) {               // four rows in flight per thread
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (row + u * PL < N) v[u] = *(const f32x4*)(ub + (size_t)(row + u * PL) * ld + c0 + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (row + u * PL < N) *(f32x4*)(Us + (row + u * PL) * CS + 4 * q) = v[u] * sg;
+    }
+    __syncthreads();
+    double ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+    for (int il = pbeg + pl; il < pend; il += PL) {
+        const size_t i = (size_t)b * N + il;
+        const int* irow = idx + i * k;
+        int jr[KMAX];
+        if (EXACT && (KMAX % 4) == 0) {                        // k * 4 bytes per row, rows 16-byte aligned when k % 4 == 0
+#pragma unroll
+            for (int s4 = 0; s4 < KMAX / 4; ++s4) {
+                const int4 t = *(const int4*)(irow + 4 * s4);
+                jr[4 * s4] = t.x; jr[4 * s4 + 1] = t.y; jr[4 * s4 + 2] = t.z; jr[4 * s4 + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) jr[s] = (EXACT || s < k) ? irow[s] : 0;
+        }
+        const f32x4 v = *(const f32x4*)(uv + i * ld + Cout + c0 + 4 * q);
+        float best[4];
+        f32x2 s1a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2a = {0.f, 0.f}, s2b = {0.f, 0.f};
+        int bs[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            if (EXACT || s < k) {
+                const f32x4 t = *(const f32x4*)(Us + jr[s] * CS + 4 * q);
+                const f32x2 ta = {t[0], t[1]}, tb = {t[2], t[3]};
+                s1a += ta; s1b += tb;
+                s2a = __builtin_elementwise_fma(ta, ta, s2a); s2b = __builtin_elementwise_fma(tb, tb, s2b);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool take = (s == 0) || (t[e] > best[e]);
+                    best[e] = take ? t[e] : best[e]; bs[e] = take ? s : bs[e];
+                }
+            }
+        }
+        const float s1[4] = {s1a[0] * sg[0], s1a[1] * sg[1], s1b[0] * sg[2], s1b[1] * sg[3]}, s2[4] = {s2a[0], s2a[1], s2b[0], s2b[1]};
+        f32x4 b4, s4;
+        uint32_t a4 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b4[e] = best[e] * sg[e]; s4[e] = s1[e]; a4 |= (uint32_t)(bs[e] & 255) << (8 * e);
             ps[e] += (double)s1[e] + (double)k * v[e];
             pq[e] += (double)s2[e] + 2.0 * (double)v[e] * s1[e] + (double)k * v[e] * v[e];
         }
@@ -587,6 +687,31 @@ int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const fl
     const bool al = (((uintptr_t)uv | (uintptr_t)msel | (uintptr_t)s1 | (uintptr_t)gamma) & 15) == 0 && (((uintptr_t)argsel) & 3) == 0;
     if (nparts_used) *nparts_used = edge_reduce_parts(P);
 #ifndef EDGE_NO_LDS
+    static const bool no_wide = getenv("MLSP_EDGE_NO_WIDE") != nullptr;       // read-once A/B switch (tools/ab)
+    if (!no_wide && al && P % N == 0 && N % 4 == 0 && (k == 20 || k == 40 || k <= 32) && Cout % 32 == 0 && N <= 2048) {
+        // wide slices: CS = 32 channels, one 1024-thread workgroup per CU while the cloud's slice fits (N <= 1024: 128 KB), else 16
+        static const int force_cs = getenv("MLSP_EDGE_WIDE_CS") ? atoi(getenv("MLSP_EDGE_WIDE_CS")) : 0;     // read-once A/B switch: 16 -> 16-channel slices, 512 threads, two workgroups per CU
+        // measured (B = 32, N = 1024, k = 20, five launches of a step): 32 channels x 1024 threads 143 us, 16 x 512 (two workgroups per CU: one
+        // stages while the other gathers) 129 us, 8 x 256 141 us; the round-4 kernel 182 us
+        const int B = P / N, CS = force_cs == 8 ? 8 : (force_cs == 32 && N <= 1024) ? 32 : 16, nsl = Cout / CS;
+        const int NT = CS == 8 ? 256 : (CS == 16 && N <= 1024) ? 512 : 1024;
+        const int want = NT == 256 ? 1024 : NT == 512 ? 512 : 256;
+        int psplit = 1;                                        // cut the point range only to give every CU its workgroup(s)
+        while (psplit < 8 && B * nsl * psplit < want && N % (psplit * 2) == 0) psplit *= 2;
+        const size_t lds = (size_t)N * CS * sizeof(float);
+        const size_t red = (size_t)2 * (NT / (CS / 4)) * CS * sizeof(double);
+        if ((lds > red ? lds : red) <= 150 * 1024 && B * psplit <= edge_reduce_parts(P)) {
+            const size_t ldsz = lds > red ? lds : red;
+#define EW_GO(KM, EX) do { auto kern = CS == 32 ? edge_reduce_wide_kernel<KM, EX, 32, 1024> : CS == 8 ? edge_reduce_wide_kernel<KM, EX, 8, 256> : NT == 512 ? edge_reduce_wide_kernel<KM, EX, 16, 512> : edge_reduce_wide_kernel<KM, EX, 16, 1024>; \
+                hipError_t e_ = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz); \
+                if (e_ != hipSuccess) return (int)e_; \
+                hipLaunchKernelGGL(kern, dim3(B * nsl * psplit), dim3(NT), ldsz, st, uv, idx, gamma, B, N, k, Cout, psplit, msel, argsel, s1, part); } while (0)
+            if (k == 20) EW_GO(20, true); else if (k <= 20) EW_GO(20, false); else if (k <= 32) EW_GO(32, false); else EW_GO(40, true);
+#undef EW_GO
+            if (nparts_used) *nparts_used = B * psplit;
+            return mlsp_launch_status();
+        }
+    }
     if (al && Cout % ELDS_CS == 0 && P % N == 0 && N <= 4096 && k <= 40 && N % 4 == 0) {
         const int B = P / N, nsl = Cout / ELDS_CS;
         int psplit = 1;                                        // enough workgroups for two per CU, small neighbour-list stage
