@@ -31,9 +31,9 @@ def _transform_net(c, x0, prefix="input_transform_net"):
     """PointSegDA/Models.py:119-143: Conv2d(bias=False)+LeakyReLU x2, max over k, conv, max over N, fc+LeakyReLU x2, fc3 + I."""
     x = F.leaky_relu(_conv2d(c, x0, prefix + ".conv2d1.conv.0"), 0.2)
     x = F.leaky_relu(_conv2d(c, x, prefix + ".conv2d2.conv.0"), 0.2)
-    x = x.max(dim=-1, keepdim=True)[0]
+    x = c.max_k(x).unsqueeze(-1)                     # (max pools through the context: their arg-max is recorded, ref_cpu._Ctx.sel)
     x = F.leaky_relu(_conv2d(c, x, prefix + ".conv2d3.conv.0"), 0.2)
-    x = x.max(dim=2)[0].reshape(x.shape[0], -1)
+    x = c.max_n(x[..., 0]).reshape(x.shape[0], -1)
     x = F.leaky_relu(x @ c.p[prefix + ".fc1.fc.0.weight"].t() + c.p[prefix + ".fc1.fc.0.bias"], 0.2)
     x = F.leaky_relu(x @ c.p[prefix + ".fc2.fc.0.weight"].t() + c.p[prefix + ".fc2.fc.0.bias"], 0.2)
     x = x @ c.p[prefix + ".fc3.weight"].t() + c.p[prefix + ".fc3.bias"]
@@ -81,11 +81,11 @@ def dgcnn_defrec_forward(params, x, training=True, dropout_p=0.0, k=K_DEFAULT, k
     T = _transform_net(c, graph(x))
     h = torch.matmul(T, x)
     sl = "shared_layers"
-    x1 = _conv2d(c, _conv2d(c, graph(h), sl + ".conv1"), sl + ".conv2").max(dim=-1)[0]
-    x2 = _conv2d(c, _conv2d(c, graph(x1), sl + ".conv3"), sl + ".conv4").max(dim=-1)[0]
-    x3 = _conv2d(c, graph(x2), sl + ".conv5").max(dim=-1)[0]
+    x1 = c.max_k(_conv2d(c, _conv2d(c, graph(h), sl + ".conv1"), sl + ".conv2"))
+    x2 = c.max_k(_conv2d(c, _conv2d(c, graph(x1), sl + ".conv3"), sl + ".conv4"))
+    x3 = c.max_k(_conv2d(c, graph(x2), sl + ".conv5"))
     x123 = torch.cat((x1, x2, x3), dim=1)
-    x5 = _conv1d(c, x123, sl + ".conv6").max(dim=2)[0]
+    x5 = c.max_n(_conv1d(c, x123, sl + ".conv6"))
     head_in = torch.cat((x123, x5.unsqueeze(2).expand(B, x5.shape[1], N)), dim=1)
     logits = {}
     if make_seg:

@@ -331,30 +331,59 @@ def test_gemm_product_modes_agree_on_bench_step(dev, monkeypatch):
         np.testing.assert_allclose(v, out["fp32"][2][k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
-# per-stage ceiling of neighbour SETS that may differ from the oracle's when nothing is forced (fraction of the B*N rows of a stage): the
-# measured counts are printed; a kernel change that moves them is visible here.  Stage 0 (raw cloud) is bit-exact by construction.
-FREE_RUN_SET_FLIP_CEILING = 0.03        # measured on MI355X (round 4): B=4 N=128: 0 rows, B=4 N=256: 0 / 0 / 1 / 6 / 19 of 1024, B=32 N=1024: printed by the test
+# Free-running parity (nothing forced): the dynamic graph is discontinuous -- a last-bit difference in a feature flips a near-tied
+# neighbour, moves that row by O(1), and the next stage's graph inherits it (one flipped row at stage 2 became 6 and 19 at stages 3 and 4
+# of the B = 4, N = 256 case) -- so "how close is free-running" needs a YARDSTICK: the reference's own operators in fp32 on the CPU
+# (oracle/ref_torch_modules.py::StockDGCNN with the canonical fp32 kNN) measured against the SAME network in float64 (matmul + topk in
+# double: the truth).  Measured on MI355X (round 5; rows whose neighbour SET differs from the truth per stage, HIP | stock fp32 CPU):
+#     B = 4,  N = 128 (512 rows):      0 0 0 0 0            | 0 0 0 0 0
+#     B = 4,  N = 256 (1,024 rows):    0 0 1 6 19           | 0 0 0 0 0
+#     B = 32, N = 1024 (32,768 rows):  1 363 1133 5062 12514 | 1 363 1128 5063 12504
+# At the bench size ANY fp32 evaluation parts from the float64 graphs (the fp32 distance formula -xx - inner - xx^T cancels badly on
+# 3-D coordinates: 363 rows at the transformed-cloud stage) and the HIP path does so exactly as often as the reference's operators do.
+# Bars: at the FIRST stage where the HIP graph differs, at most max(FREE_RUN_MIN_ROWS, FREE_RUN_FLIP_FACTOR x the yardstick's count)
+# rows (independent events); downstream (inherited flips) at most max(FACTOR x yardstick, FREE_RUN_CASCADE_CAP of the rows); outputs:
+# 1e-3 element-wise when nothing flipped, else rel-L2 from the truth <= max(1e-3, FACTOR x the yardstick's, sqrt(flipped fraction)).
+FREE_RUN_FLIP_FACTOR = 3
+FREE_RUN_MIN_ROWS = 2
+FREE_RUN_CASCADE_CAP = 0.03
+
+
+def _stock_free_run(m_hip, x, dtype, knn_fn):
+    """the reference's operator sequence on the CPU in `dtype`, free-running: -> (logits, the five [B, N, k] index tensors it built)"""
+    from oracle import ref_torch_modules as rtm
+    rec = []
+
+    def spy(x_, k_):
+        idx = knn_fn(x_, k_)
+        rec.append(idx.clone().long())
+        return idx
+    ref = rtm.StockDGCNN(gc.make_args(dropout=0.0), knn_fn=spy)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m_hip.state_dict().items()}, strict=True)
+    ref = ref.to(dtype).train()
+    with torch.no_grad():
+        out = ref(x.cpu().to(dtype), activate_density_normal_ondef=True)
+    return out, rec
 
 
 @pytest.mark.parametrize("seed,B,N", [(2, 4, 128), (3, 4, 256), (5, 32, 1024)])
 def test_dgcnn_free_running_vs_oracle(dev, seed, B, N):
-    """No forcing: HIP model vs CPU oracle (canonical kNN on both sides), up to BASELINE.json configs[1]'s own size (B = 32, N = 1024).
-    Identical indices at every stage are not guaranteed wherever the oracle's features equal ours only to the last bit, so compare
-    stage by stage: the first stage (raw cloud) bit-exact, the later stages' flipped rows counted and held under a ceiling, logits
-    within 1e-3 when no neighbour set flipped."""
+    """No forcing, up to BASELINE.json configs[1]'s own size (B = 32, N = 1024): the raw-cloud graph bit-exact with the canonical kNN;
+    at the four feature-space stages the neighbour sets that differ from the float64 truth are counted and held to the yardstick above;
+    the five outputs are held to 1e-3 element-wise when no set flipped and to the yardstick's relative-L2 distance from the truth
+    otherwise (a flipped neighbour changes its row by O(1): DESIGN.md section 2)."""
     from mlsp_amd import functional as Fh
+    from oracle import ref_torch_modules as rtm
     m = _model(seed, dev)
     inp = gc.make_inputs(seed, B, N)
-    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-    with torch.no_grad():
-        want, _, ctx = ref_cpu.dgcnn_forward(params, inp["x"], training=True, knn_fn=knn_canon.knn,
-                                             activate_density_normal_ondef=True, return_ctx=True)
+    truth, idx64 = _stock_free_run(m, inp["x"], torch.float64, rtm.knn_matmul_topk)
+    yard, idx32 = _stock_free_run(m, inp["x"], torch.float32, knn_canon.knn)
     seen = []
     orig = Fh.knn_graph
 
     def spy(xp, B_, N_, k_, need_reverse=True):
         gr = orig(xp, B_, N_, k_, need_reverse)
-        seen.append(gr.idx.view(B_, N_, k_).cpu())
+        seen.append(gr.idx.view(B_, N_, k_).cpu().long())
         return gr
     Fh.knn_graph = spy
     try:
@@ -363,19 +392,27 @@ def test_dgcnn_free_running_vs_oracle(dev, seed, B, N):
             got = m(inp["x"].to(dev), activate_density_normal_ondef=True)
     finally:
         Fh.knn_graph = orig
-    assert torch.equal(seen[0].long(), ctx.knn_idx[0]), "raw-cloud kNN must be bit-exact"
-    flips = [int((a.long() != b).any(-1).sum()) for a, b in zip(seen, ctx.knn_idx)]
-    set_flips = [int((a.long().sort(-1)[0] != b.sort(-1)[0]).any(-1).sum()) for a, b in zip(seen, ctx.knn_idx)]
-    print("B=%d N=%d free-running graph vs oracle: rows whose ORDER differs per stage %s, rows whose neighbour SET differs %s (of %d rows)"
-          % (B, N, flips, set_flips, B * N))
-    assert all(f <= max(1, FREE_RUN_SET_FLIP_CEILING * B * N) for f in set_flips), set_flips
-    if sum(set_flips) == 0:
-        for key in HEAD_KEYS:
-            np.testing.assert_allclose(got[key].cpu().numpy(), want[key].numpy(), rtol=1e-3, atol=1e-3, err_msg=key)
-    else:   # a flipped neighbour changes its row by O(1): hold the bulk of the outputs instead of every element
-        for key in HEAD_KEYS:
-            a, b = got[key].cpu().double(), want[key].double()
-            print("   %s: rel-L2 %.2e" % (key, ((a - b).norm() / b.norm()).item()))
+    assert torch.equal(seen[0], idx32[0]), "raw-cloud kNN must be bit-exact with the canonical arithmetic"
+
+    def set_flips(a, b):
+        return [int((x.sort(-1)[0] != y.sort(-1)[0]).any(-1).sum()) for x, y in zip(a, b)]
+    hip_f, yard_f = set_flips(seen, idx64), set_flips(idx32, idx64)
+    print("B=%d N=%d free-running, rows (of %d) whose neighbour SET differs from the float64 truth per stage: HIP %s | stock fp32 CPU %s"
+          % (B, N, B * N, hip_f, yard_f))
+    first = next((s for s, h in enumerate(hip_f) if h), None)
+    for s, (h, y) in enumerate(zip(hip_f, yard_f)):
+        bar = max(FREE_RUN_MIN_ROWS, FREE_RUN_FLIP_FACTOR * y) if s == first else max(FREE_RUN_FLIP_FACTOR * y, FREE_RUN_CASCADE_CAP * B * N)
+        assert h <= bar, (s, hip_f, yard_f)
+    worst = max(hip_f) / float(B * N)
+    for key in HEAD_KEYS:
+        t = truth[key].double()
+        rel_h = ((got[key].cpu().double() - t).norm() / t.norm()).item()
+        rel_y = ((yard[key].double() - t).norm() / t.norm()).item()
+        print("   %s: rel-L2 from the float64 truth: HIP %.2e | stock fp32 CPU %.2e" % (key, rel_h, rel_y))
+        if sum(hip_f) == 0:
+            np.testing.assert_allclose(got[key].cpu().numpy(), t.float().numpy(), rtol=1e-3, atol=1e-3, err_msg=key)
+        else:
+            assert rel_h <= max(1e-3, FREE_RUN_FLIP_FACTOR * rel_y, worst ** 0.5), (key, rel_h, rel_y, worst)
 
 
 def test_module_api_surface(dev):
@@ -607,6 +644,37 @@ def test_segda_vs_reference_golden(dev, golden_dir, fname, seed, B, N, K):
     st = m.state_dict()
     for key in [k[4:] for k in g if k.startswith("run/")]:
         np.testing.assert_allclose(st[key].cpu().numpy(), g["run/" + key], rtol=1e-3, atol=1e-5, err_msg=key)
+    # Tight gradient pin (the method of the DGCNN fixtures): the reference's graphs AND the float64 oracle's max-pool selections forced,
+    # every gradient against the FLOAT64 oracle, bar = max(5e-3, 3 x the distance of the oracle's own fp32 run from float64)
+    from oracle import ref_seg_cpu
+    wts = {key: torch.from_numpy(g["w/" + key]) for key in SEG_KEYS}
+
+    def oracle_run(dtype):
+        ref = copy.deepcopy(_seg_model(seed, torch.device("cpu"), K=K)).to(dtype)
+        params = dict(ref.state_dict(keep_vars=True))
+        it = iter(forced)
+        out, _, ctx = ref_seg_cpu.dgcnn_defrec_forward(params, x.cpu().to(dtype), training=True, k=(K or 20), knn_fn=lambda x_, k_: next(it),
+                                                       make_seg=True, activate_DefRec=True, activate_density_normal_ondef=True, return_ctx=True)
+        sum((out[key] * wts[key].to(dtype)).sum() / out[key].numel() for key in SEG_KEYS).backward()
+        return [a.clone() for a in ctx.sel], {n: q.grad.double().numpy() for n, q in ref.named_parameters() if q.grad is not None}
+    sel64, g64 = oracle_run(torch.float64)
+    _, g32 = oracle_run(torch.float32)
+    m2 = _seg_model(seed, dev, K=K)
+    m2.train()
+    with Fh.forced_graphs(forced), Fh.forced_selections(sel64):
+        lg = m2(x, make_seg=True, activate_DefRec=True, activate_density_normal_ondef=True)
+    sum((lg[key] * wts[key].to(dev)).sum() / lg[key].numel() for key in SEG_KEYS).backward()
+    worst = (None, 0.0, 0.0)
+    for n, q in m2.named_parameters():
+        if q.grad is None or n not in g64 or (n.startswith("shared_layers") and n.endswith(".bias")):
+            continue
+        den = np.linalg.norm(g64[n]) + 1e-30
+        rel = np.linalg.norm(q.grad.cpu().double().numpy() - g64[n]) / den
+        yard = np.linalg.norm(g32[n] - g64[n]) / den
+        if rel > worst[1]:
+            worst = (n, rel, yard)
+        assert rel <= max(5e-3, 3 * yard), (n, rel, yard)
+    print("%s: worst gradient vs float64 with forced selections: %s rel %.2e (fp32 oracle itself %.2e)" % ((fname,) + worst))
     m.eval()
     with torch.no_grad(), Fh.forced_graphs(forced):
         le = m(x, make_seg=True, activate_DefRec=True, activate_density_normal_ondef=True)
