@@ -54,6 +54,45 @@ def pmc_gemm_traffic(kernel="gemm_f32_kernel"):
     return (tot / n if n else None), os.path.relpath(f, root)
 
 
+def pmc_split_traffic_by_kind():
+    """HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE) of gemm_split_kernel by kind -- forward <false, true, ..>, dgrad <false, false, ..>,
+    wgrad <true, false, ..> -- from the newest committed rocprofv3 --pmc summary: ({kind: (bytes per launch, launches)}, source)."""
+    import csv, glob, re
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = glob.glob(os.path.join(root, "profiles", "pmc_r*", "summary*.csv"))
+    if not files:
+        return {}, None
+    f = max(files, key=lambda p: (int(re.search(r"pmc_r(\d+)", p).group(1)), p))
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"gemm_split_kernel<(false|true), (false|true)", r["kernel"])
+        if not m:
+            continue
+        kind = "wgrad" if m.group(1) == "true" else ("fwd" if m.group(2) == "true" else "dgrad")
+        l = int(r["launches"])
+        t, n = acc.get(kind, (0.0, 0))
+        acc[kind] = (t + l * (2 * float(r["fetch_KB_per_launch_raw"]) + float(r["write_KB_per_launch"])) * 1024, n + l)
+    return {k: (t / n, n) for k, (t, n) in acc.items() if n}, os.path.relpath(f, root)
+
+
+def committed_launch_count():
+    """(kernel launches per step, launches under 8 us per step, source) from the newest committed rocprofv3 kernel statistics of this
+    bench (profiles/r<round>_bench_kernel_stats.csv; steps in the trace = calls of tnet_edge_bwds_kernel, once per step)."""
+    import csv, glob, re
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = [p for p in glob.glob(os.path.join(root, "profiles", "r*_bench_kernel_stats*.csv")) if re.search(r"r(\d+)_bench_kernel_stats", p)]
+    if not files:
+        return None, None, None
+    f = max(files, key=lambda p: (int(re.search(r"r(\d+)_bench_kernel_stats", p).group(1)), p))
+    rows = list(csv.DictReader(open(f)))
+    steps = next((int(r["Calls"]) for r in rows if r["Name"].startswith("tnet_edge_bwds_kernel")), 0)
+    if not steps:
+        return None, None, os.path.relpath(f, root)
+    n = sum(int(r["Calls"]) for r in rows) / steps
+    small = sum(int(r["Calls"]) for r in rows if float(r["AverageNs"]) < 8000.0) / steps
+    return n, small, os.path.relpath(f, root)
+
+
 def synth_batch(B, N, device, seed=0):
     """x ~ U[-1,1), first-41-points mask, N(0,1) normals, counts U{0..30} -> soft 16-bin label."""
     g = torch.Generator().manual_seed(seed)
@@ -209,6 +248,9 @@ def profiled_steps(lib, step_fn, nsteps):
     cls = (ctypes.c_double * (3 * PROF_CLASSES))()
     lib.mlsp_profile_classes(cls, PROF_CLASSES)
     rows = [list(cls[3 * c:3 * c + 3]) for c in range(PROF_CLASSES)]
+    kinds = (ctypes.c_double * 12)()
+    lib.mlsp_profile_split_kinds(kinds)
+    profiled_steps.split_kinds = {k: list(kinds[4 * i:4 * i + 4]) for i, k in enumerate(("fwd", "dgrad", "wgrad"))}    # [ms, launches, FLOP, bytes]
     return rows, list(buf), dt
 
 
@@ -343,6 +385,139 @@ def secondary_workloads(lib, dev):
     return out
 
 
+def trainer_shaped_workload(dev, steps=10, repeats=3):
+    """One optimizer step as PointDA/trainer.py runs it (lines 374-571, the default flags of train.sh: Density_normal_viainput,
+    Normal_ondef, Density_ondef, PCM), on synthetic loaders, B = 32 clouds per domain, N = 1024, with the model and the MLSP functions
+    imported through the drop-in shim paths the unmodified trainer uses: source branch = deform_input -> forward (position head) ->
+    masked Chamfer -> backward, PCM.mix_shapes -> forward (classifier) -> mixup CE -> backward; target branch = normals + cardinality
+    labels ON DEVICE (the trainer's per-cloud python-pcl loops, trainer.py:525-536) -> deform_input -> forward (three
+    heads) -> three losses with the trainer's inline masked normal loss (:551-556) -> backward; Adam.  Per-component device time from
+    HIP events on the launch stream; beside it the numpy restatements of the label generators and the corruption (oracle/labels_np.py,
+    oracle/ref_corrupt_np.py) timed on this box's host cores: what the reference's CPU loops cost per step."""
+    import numpy as np
+    import torch.nn.functional as F
+    shim = os.path.join(ROOT, "mlsp_amd", "shims")
+    sys.path.insert(0, shim)
+    try:
+        from PointDA.Models import DGCNN                     # trainer.py:14
+        from MLSP import PCM, mlsp                           # trainer.py:15
+        import pcl                                           # trainer.py:18
+        from mlsp_amd import pc_utils
+        args = make_args()
+        args.radius, args.near, args.DefRec_dist, args.mixup_params = 0.135, 20, "volume_based_voxels", 1.0      # trainer.py:103-119
+        torch.manual_seed(0)
+        np.random.seed(0)
+        model = DGCNN(args).to(dev).train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+        criterion = torch.nn.CrossEntropyLoss()
+        lookup = torch.Tensor(pc_utils.region_mean(3)).to(dev)
+        B, N = B_PER_GPU, NPTS
+        g = torch.Generator().manual_seed(0)
+        # clouds in [-0.66, 0.66]^3: the centre voxel of the 3 x 3 x 3 grid holds ~N/8 >= 40 points (deform_input's minimum)
+        src = ((torch.rand(B, N, 3, generator=g) * 2 - 1) * 0.66).to(dev)
+        trg = ((torch.rand(B, N, 3, generator=g) * 2 - 1) * 0.66).to(dev)
+        src_label = torch.randint(0, 10, (B,), generator=g).to(dev)
+        names = ["src deform_input", "src fwd(DefRec)+Chamfer+bwd", "src PCM.mix_shapes (2 x FPS)", "src fwd(cls)+CE+bwd",
+                 "trgt normals k=20 (device)", "trgt cal_density (device)", "trgt deform_input", "trgt fwd(3 heads)+losses+bwd", "Adam"]
+        ev = None
+
+        def mark(i):
+            if ev is not None:
+                ev[i].record()
+
+        def step():
+            opt.zero_grad()
+            mark(0)
+            sd = src.permute(0, 2, 1)                         # the trainer's non-contiguous [B,3,N] view
+            orig = sd.clone()
+            sd, smask = mlsp.deform_input(sd, lookup, args.DefRec_dist, dev)
+            mark(1)
+            mlsp.calc_loss(args, model(sd, activate_DefRec=True), orig, smask).backward()
+            mark(2)
+            mixed, vals = PCM.mix_shapes(args, orig.clone(), src_label)
+            mark(3)
+            PCM.calc_loss(args, model(mixed, activate_DefRec=False), vals, criterion).backward()
+            mark(4)
+            normal_gt = mlsp.estimate_normals(trg, near=args.near)
+            mark(5)
+            dl, dml = mlsp.cal_density_gpu(trg, args.radius, args.density_num_class, args.pergroup)
+            mark(6)
+            td = trg.permute(0, 2, 1)
+            torig = td.clone()
+            td, mask = mlsp.deform_input(td, lookup, args.DefRec_dist, dev)
+            mark(7)
+            lp = model(td, activate_density_normal_ondef=True)
+            loss = mlsp.calc_loss(args, lp, torig, mask)
+            mask_cord = mask.permute(0, 2, 1)[:, :, 0] * 26 + 1
+            npred, ngt = F.normalize(lp["Normal"], p=2, dim=-1), F.normalize(normal_gt, p=2, dim=-1)
+            loss = loss + args.normal_pred_weight * (-torch.sum(torch.abs(torch.sum(npred * ngt, dim=-1)) * mask_cord) / torch.sum(mask_cord))
+            kl, mae = mlsp.densityloss(args, lp, dml.reshape(-1), dl.reshape(-1, args.density_num_class), mask=mask_cord.reshape(-1))
+            (loss + kl + mae).backward()
+            mark(8)
+            opt.step()
+            mark(9)
+
+        ms = median_block_ms(step, steps, repeats, 3)
+        blocks = median_block_ms.last_blocks
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
+        comp = [0.0] * 9
+        nprof = 5
+        for _ in range(nprof):
+            step()
+            torch.cuda.synchronize()
+            for i in range(9):
+                comp[i] += ev[i].elapsed_time(ev[i + 1]) / nprof
+        ev = None
+        # the unmodified trainer's label loop through the pcl shim: B host round trips per step (trainer.py:525-531)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(B):
+            cloud = pcl.PointCloud()
+            cloud.from_array(np.array(trg[i].cpu().numpy(), dtype=np.float32))
+            ne = cloud.make_NormalEstimation()
+            ne.set_SearchMethod(cloud.make_kdtree())
+            ne.set_KSearch(args.near)
+            ne.compute().to_array()
+        shim_loop_ms = 1e3 * (time.perf_counter() - t0)
+        # CPU beside it: numpy restatements on a bounded sample of the same clouds, scaled to B clouds
+        from oracle import labels_np, ref_corrupt_np, knn_canon
+        nb = 4
+        tc = trg[:nb].cpu()
+        t0 = time.perf_counter()
+        labels_np.cal_density(tc.numpy(), args.radius, args.density_num_class, args.pergroup)
+        t_den = (time.perf_counter() - t0) * B / nb
+        t0 = time.perf_counter()
+        idx = knn_canon.knn_point_major(tc, args.near)
+        for i in range(nb):
+            labels_np.knn_normals(tc[i].numpy(), idx[i])
+        t_nrm = (time.perf_counter() - t0) * B / nb
+        Xc = tc.permute(0, 2, 1).contiguous().numpy()
+        t0 = time.perf_counter()
+        ref_corrupt_np.deform(Xc, lookup.cpu().numpy(), np.random.permutation(27), np.random.randn(nb, 3, N).astype(np.float32))
+        t_def = (time.perf_counter() - t0) * B / nb * 2          # two deform_input calls per step
+        t0 = time.perf_counter()
+        ref_corrupt_np.mix_shapes(Xc, np.random.permutation(nb), 0.5, np.zeros(nb, np.int64), np.zeros(nb, np.int64), np.random.permutation(N))
+        t_mix = (time.perf_counter() - t0) * B / nb
+        return {"workload": "trainer-shaped optimizer step (PointDA/trainer.py:374-571 through the shim imports): source DefRec + PCM "
+                            "branches, target branch with on-device normals / cardinality labels / deform_input, 3 forwards + 3 backwards "
+                            "+ Adam, B=%d per domain, N=%d" % (B, N),
+                "ms_per_step": ms, "blocks_ms_per_step": blocks, "points_per_s": 2 * B * N / ms * 1e3,
+                "points_note": "source + target clouds of one step",
+                "components_us": {n: round(1e3 * c, 1) for n, c in zip(names, comp)},
+                "components_note": "HIP events on the launch stream, mean of %d steps (host-side gaps inside a component included)" % nprof,
+                "unmodified_trainer_label_loop_ms": shim_loop_ms,
+                "unmodified_trainer_label_loop_note": "the trainer's own per-cloud pcl loop (trainer.py:525-531) served by mlsp_amd/shims/pcl.py: "
+                                                      "%d host round trips; the batched device entry (mlsp.estimate_normals) is what `components_us` times" % B,
+                "cpu_numpy_restatements_ms_per_step": {"cal_density (radius count)": round(1e3 * t_den, 1), "normals k=20 (kNN + PCA)": round(1e3 * t_nrm, 1),
+                                                       "deform_input x2": round(1e3 * t_def, 1), "PCM.mix_shapes (FPS)": round(1e3 * t_mix, 1)},
+                "cpu_note": "oracle/labels_np.py + oracle/ref_corrupt_np.py (python-pcl itself is absent: SURVEY 8c) on %d clouds, scaled to %d; "
+                            "host threads as numpy / OpenMP default" % (nb, B)}
+    finally:
+        sys.path.remove(shim)
+        for mod in ("PointDA", "PointDA.Models", "MLSP", "MLSP.mlsp", "MLSP.PCM", "pcl"):
+            sys.modules.pop(mod, None)
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -458,6 +633,11 @@ def main():
     from mlsp_amd import Models, mlsp, _lib, functional as Fh
     from mlsp_amd.ddp import FlatGradSync
     lib = _lib.load()
+    # One process per GPU: autograd's per-device worker threads have nothing to run in parallel, and handing every backward node to
+    # another thread costs 0.4 ms of the 3.2 ms the host needs to enqueue a step (tools/r5/host_profile.py: 3.17 -> 2.77 ms on the
+    # host-bound probe).  The backward then runs on the calling thread; results are identical.  (recommended with
+    # torchrun; nn.DataParallel -- several devices in ONE process -- keeps the default.)
+    torch.autograd.set_multithreading_enabled(False)
     args = make_args()
     torch.manual_seed(0)                                   # identical replicas on every rank
     model = Models.DGCNN(args).to(dev).train()
@@ -554,6 +734,7 @@ def main():
             out["fp32_mfma"] = {"ms_per_step": 1e3 * f32_leg / a.steps, "value": pts / f32_leg,
                                 "note": "the same step with every GEMM on the f32 MFMA (gemm_precision('fp32')): median of %d blocks "
                                         "of %d steps, timed after the headline blocks in the same process" % (len(f32_blocks), a.steps)}
+        P_ROWS = b_local * NPTS
         if prof and prof[1] > 0:
             # prof = [total ms of the GEMM family, launches, algorithmic FLOP summed over launches, algorithmic bytes];
             # rows[7] = the subset that ran on the bf16-split kernel (default mode "bf16x6"), the rest ran on the f32 MFMA kernels
@@ -577,10 +758,32 @@ def main():
                              "share_of_step": f32_ms / prof_steps / step_ms, "note": common_note}
             if sp[1] > 0 and sp[0] > 0:
                 ach = sp[2] / (sp[0] * 1e-3) / 1e12
+                # HBM-side bytes (committed --pmc passes) and algorithmic bytes over the SAME launches: the split kernel's, by instantiation
+                kinds = getattr(profiled_steps, "split_kinds", {})
+                pmc_kind, pmc_src = pmc_split_traffic_by_kind()
+                by_kind, alg_all, tr_all, n_all = {}, 0.0, 0.0, 0.0
+                for kname, (kms, kn, kflop, kbytes) in kinds.items():
+                    if kn <= 0:
+                        continue
+                    e = {"launches_per_step": kn / prof_steps, "avg_us": 1e3 * kms / kn, "achieved_tflops": kflop / (kms * 1e-3) / 1e12,
+                         "algorithmic_bytes_per_launch": kbytes / kn}
+                    if kname in pmc_kind:
+                        e["traffic_per_launch"] = pmc_kind[kname][0]
+                        e["traffic_over_algorithmic"] = pmc_kind[kname][0] / (kbytes / kn)
+                        tr_all += pmc_kind[kname][0] * kn
+                    alg_all += kbytes
+                    n_all += kn
+                    by_kind[kname] = e
+                if pmc_kind and n_all:
+                    traffic, traffic_src = tr_all / n_all, pmc_src
                 out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                                    "traffic": traffic, "traffic_source": "committed profile (%s), not measured in this run" % traffic_src,
-                                   "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE), %s; algorithmic A+B+C bytes per "
-                                                   "launch of the whole family: %.0f" % (traffic_src, prof[3] / prof[1]),
+                                   "algorithmic_bytes_per_launch": alg_all / n_all if n_all else None,
+                                   "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, %s) and algorithmic bytes per launch (A + B + C, "
+                                                   "split-K slabs written once and read once by the reduce) over the SAME launches: the ones that ran on "
+                                                   "gemm_split_kernel, weighted by this run's launch mix; `by_kind` has them per instantiation "
+                                                   "(fwd / dgrad / wgrad)" % traffic_src,
+                                   "by_kind": by_kind,
                                    "kernel": "gemm_split_kernel<*> (fp32-accurate products as six bf16 MFMA piece products: fwd, dgrad, wgrad)",
                                    "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product",
                                    "executed_bf16_tflops": 6 * ach, "vs_f32_mfma_peak": ach / PEAK_FP32_TFLOPS,
@@ -594,10 +797,22 @@ def main():
                                                     "launch: %.0f" % (traffic_src, prof[3] / prof[1]))
                 f32_entry = None
             # the other families north_star names: kNN / gather against HBM, kNN distance sweeps and the T-Net stage against the matrix peak
-            ks = [_kernel_entry("kNN C=3 (knn_mfma5_kernel<4> + sqnorm), stages 0-1", "hbm", rows[1], prof_steps,
-                                "compulsory bytes (C+k)*4 per point; the kernel is select-bound, not HBM-bound (DESIGN 4)"),
-                  _kernel_entry("EdgeConv neighbour gather-reduce (edge_reduce_lds_kernel), 4 EdgeConv + T-Net conv1", "hbm", rows[4], prof_steps,
-                                "compulsory bytes: u half + indices in, msel + s1 + arg slot out; LDS-gather bound"),
+            knn3 = _kernel_entry("kNN C=3 (distance + select kernel + row norms), stages 0-1", "hbm", rows[1], prof_steps,
+                                 "compulsory bytes (C+k)*4 per point: brute-force kNN on 3 channels is not HBM-bound; `second_roof` prices the "
+                                 "same launches against the vector-ALU distance + select bound of SURVEY 8d")
+            if knn3 is not None:
+                # N^2 (C FMA + compare) per cloud -> per query N candidates x (C FMAs + the two norm terms + one compare) vector
+                # lane-operations; the chip issues PEAK_FP32_TFLOPS / 2 of them per second (an FMA counts as two FLOP)
+                lane_ops = 2 * P_ROWS * NPTS * (3 + 3)            # two launches per step (raw and transformed cloud), C = 3
+                secs = knn3["us_per_step"] * 1e-6
+                peak_ops = PEAK_FP32_TFLOPS / 2 * 1e12
+                knn3["second_roof"] = {"bound": "valu", "achieved": lane_ops / secs / 1e12, "peak": peak_ops / 1e12, "unit": "T lane-op/s",
+                                       "frac": lane_ops / secs / peak_ops,
+                                       "note": "N*(C+3) vector lane-operations per query (C FMAs, two norm terms, one compare) -- the distance + "
+                                               "select work a brute-force kNN cannot avoid; k-selection bookkeeping not counted"}
+            ks = [knn3,
+                  _kernel_entry("EdgeConv neighbour gather-reduce (edge_reduce_wide_kernel), 4 EdgeConv + T-Net conv1", "hbm", rows[4], prof_steps,
+                                "compulsory bytes: u half + indices in, msel + s1 + arg slot out (17 B per point and channel)"),
                   _kernel_entry("kNN C=64 (knn6_prep_kernel<64> + knn6_kernel<64>), stages 2-3", "mfma", rows[2], prof_steps,
                                 "algorithmic 2*N*C FLOP per point (one distance sweep) against the f32 MFMA peak; the kernel runs two split-bf16 "
                                 "sweeps (3 bf16 products each) and resolves only the ambiguous survivors in canonical fp32"),
@@ -630,9 +845,15 @@ def main():
         out["executed_mfma_frac"] = out["executed_tflops"] / PEAK_FP32_TFLOPS
         out["executed_bf16_tflops"] = 6 * split_flop / step_s / 1e12          # the split GEMMs' piece products
         out["reference_flop_equivalent_frac"] = value / n_gpus * FLOP_PER_POINT / 1e12 / PEAK_FP32_TFLOPS
+        nl, nsmall, lsrc = committed_launch_count()
+        if nl is not None:
+            out["launches_per_step"] = nl
+            out["launches_under_8us_per_step"] = nsmall
+            out["launches_source"] = "committed rocprofv3 kernel statistics (%s), not counted in this run" % lsrc
         if n_gpus == 1 and not a.no_secondary:
             del model, opt, sync, batch
             out["secondary"] = secondary_workloads(lib, dev)
+            out["secondary"].append(trainer_shaped_workload(dev))
         if n_gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

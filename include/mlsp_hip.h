@@ -375,6 +375,8 @@ int mlsp_profile_end(double* out);
  * bf16-split kernel (mode 2; algorithmic FLOP, each executed as six bf16 MFMA products). */
 #define MLSP_PROF_CLASSES 8
 int mlsp_profile_classes(double* out, int ncls);
+/* out [3][4]: {ms, launches, algorithmic FLOP, algorithmic bytes} of the bracket's gemm_split_kernel launches by kind (forward, dgrad, wgrad). */
+int mlsp_profile_split_kinds(double* out);
 
 #ifdef __cplusplus
 }

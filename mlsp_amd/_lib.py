@@ -89,6 +89,7 @@ SIGNATURES = {
     "mlsp_profile_begin": [],
     "mlsp_profile_end": [_P],
     "mlsp_profile_classes": [_P, _I],
+    "mlsp_profile_split_kinds": [_P],
     "mlsp_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _SZ, _P],
 }
 
@@ -155,7 +156,9 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of torch's current HIP stream on the current device (the C-level getter: torch.cuda.current_stream() builds a Python
+    Stream object per call, ~10 us -- sixty of them per step were a tenth of the enqueue time)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def require_gpu(*tensors):
@@ -169,9 +172,17 @@ def require_gpu(*tensors):
 _workspaces = {}
 
 
+_ws_need = {}
+
+
 def workspace(device, rows, cin, cout):
-    need = load().mlsp_workspace_bytes(int(rows), int(cin), int(cout))
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), stream())
+    """(pointer, bytes) of this (device, stream)'s scratch buffer, grown to what mlsp_workspace_bytes asks for the shape (memoised: a pure
+    function of the three sizes)."""
+    shape = (int(rows), int(cin), int(cout))
+    need = _ws_need.get(shape)
+    if need is None:
+        need = _ws_need[shape] = load().mlsp_workspace_bytes(*shape)
+    key = (device.index if device.index is not None else torch._C._cuda_getDevice(), stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(int(need), dtype=torch.uint8, device=device)

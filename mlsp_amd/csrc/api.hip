@@ -177,6 +177,22 @@ int launch_knn_normals(hipStream_t st, const float* x, int ld, const int* idx, i
 #define CHECK(x) do { int _r = (x); if (_r != MLSP_OK) return _r; } while (0)
 #define SLAB_BOUND_FLOATS ((size_t)16 << 20)   /* 64 MiB of fp32: bound on any split-K slab (gemm_pick_split) */
 
+#include <mutex>
+#include <unordered_map>
+hipError_t mlsp_lds_limit(const void* fn, size_t lds) {
+    static std::mutex mu;
+    static std::unordered_map<uint64_t, size_t> raised;          // (device, kernel) -> limit already set
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t key = (uint64_t)(uintptr_t)fn * 64u + (uint64_t)(dev & 63);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = raised.find(key);
+    if (it != raised.end() && it->second >= lds) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) raised[key] = lds;
+    return e;
+}
+
 extern "C" {
 
 int mlsp_abi_version(void) { return MLSP_ABI_VERSION; }

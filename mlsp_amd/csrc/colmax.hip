@@ -316,7 +316,7 @@ int launch_colmax_scatter_rows(hipStream_t st, const float* g, const int* arg, c
     size_t lds = ((size_t)2 * N + 1 + 3 * Cout + 16 * 256) * sizeof(int);
     if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)colmax_scatter_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)colmax_scatter_rows_kernel, lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(colmax_scatter_rows_kernel, dim3(CSR_SPLIT, B), dim3(1024), lds, st, g, arg, W, ldw, N, Cout, Cin, dX, lddx);

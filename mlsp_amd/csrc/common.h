@@ -40,6 +40,11 @@ struct GemmPrecisionScope {
 int gemm_precision_mode();
 #define PREC_SCOPE(mode_) if ((mode_) < 0 || (mode_) > 2) return MLSP_ERR_ARG; GemmPrecisionScope prec_scope_(mode_)
 
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) -- at most once per (device, kernel, size): the host call
+// costs tens of microseconds, a dozen of them per step put the enqueue thread behind the GPU on slower hosts.  (api.hip; a cache of
+// what was already asked of the runtime, not dispatch state: the same launches happen with or without it.)
+hipError_t mlsp_lds_limit(const void* fn, size_t lds);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // simple bump allocator over the caller-provided workspace

@@ -176,7 +176,7 @@ int launch_collapse_to_point(hipStream_t st, float* X, int B, int N, const int* 
     const size_t lds = (size_t)N * 5 * sizeof(float);
     if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)collapse_to_point_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)collapse_to_point_kernel, lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(collapse_to_point_kernel, dim3(B), dim3(1024), lds, st, X, N, choice, u, noise, r2, min_pts, mask, chosen);
@@ -188,7 +188,7 @@ int launch_scan_select(hipStream_t st, const float* X, int B, int N, int C, cons
     const size_t lds = (size_t)N * (sizeof(double) + sizeof(int));
     if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)scan_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)scan_select_kernel, lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(scan_select_kernel, dim3(B), dim3(1024), lds, st, X, N, C, R, pixel, Xs, mask);

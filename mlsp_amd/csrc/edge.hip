@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void edge_reduce_lds_kernel(const float* __res
 // indices are not staged: the lanes of a point read the same 80 bytes from global (one broadcast line).  The selection runs on t = +-u (sign
 // of the BatchNorm scale folded in at staging: the max search is one compare, the sums are the same IEEE operations on negated values).
 template <int KMAX, bool EXACT, int CS, int NT>
-__global__ __launch_bounds__(NT) void edge_reduce_wide_kernel(const float* __restrict__ uv, const int* __restrict__ idx,
+__global__ __launch_bounds__(NT, 4) void edge_reduce_wide_kernel(const float* __restrict__ uv, const int* __restrict__ idx,
                                                                 const float* __restrict__ gamma, int B, int N, int k, int Cout, int psplit,
                                                                 float* __restrict__ msel, uint8_t* __restrict__ argsel,
                                                                 float* __restrict__ s1out, double* __restrict__ part) {
@@ -309,35 +309,39 @@ __global__ __launch_bounds__(NT) void edge_reduce_wide_kernel(const float* __res
     }
     __syncthreads();
     double ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+    constexpr int KC = (KMAX % 20 == 0) ? 20 : KMAX;           // neighbours per batch of index loads + row gathers (k = 40: two batches, 128 registers hold)
     for (int il = pbeg + pl; il < pend; il += PL) {
         const size_t i = (size_t)b * N + il;
         const int* irow = idx + i * k;
-        int jr[KMAX];
-        if (EXACT && (KMAX % 4) == 0) {                        // k * 4 bytes per row, rows 16-byte aligned when k % 4 == 0
-#pragma unroll
-            for (int s4 = 0; s4 < KMAX / 4; ++s4) {
-                const int4 t = *(const int4*)(irow + 4 * s4);
-                jr[4 * s4] = t.x; jr[4 * s4 + 1] = t.y; jr[4 * s4 + 2] = t.z; jr[4 * s4 + 3] = t.w;
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s) jr[s] = (EXACT || s < k) ? irow[s] : 0;
-        }
         const f32x4 v = *(const f32x4*)(uv + i * ld + Cout + c0 + 4 * q);
         float best[4];
         f32x2 s1a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2a = {0.f, 0.f}, s2b = {0.f, 0.f};
         int bs[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (int s0 = 0; s0 < KMAX; s0 += KC) {                // (not unrolled: the second batch's index loads must not be hoisted over the first)
+            int jr[KC];
+            if (EXACT && (KC % 4) == 0) {                      // k * 4 bytes per row, rows 16-byte aligned when k % 4 == 0
 #pragma unroll
-        for (int s = 0; s < KMAX; ++s) {
-            if (EXACT || s < k) {
-                const f32x4 t = *(const f32x4*)(Us + jr[s] * CS + 4 * q);
-                const f32x2 ta = {t[0], t[1]}, tb = {t[2], t[3]};
-                s1a += ta; s1b += tb;
-                s2a = __builtin_elementwise_fma(ta, ta, s2a); s2b = __builtin_elementwise_fma(tb, tb, s2b);
+                for (int s4 = 0; s4 < KC / 4; ++s4) {
+                    const int4 t = *(const int4*)(irow + s0 + 4 * s4);
+                    jr[4 * s4] = t.x; jr[4 * s4 + 1] = t.y; jr[4 * s4 + 2] = t.z; jr[4 * s4 + 3] = t.w;
+                }
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool take = (s == 0) || (t[e] > best[e]);
-                    best[e] = take ? t[e] : best[e]; bs[e] = take ? s : bs[e];
+                for (int s = 0; s < KC; ++s) jr[s] = (EXACT || s0 + s < k) ? irow[s0 + s] : 0;
+            }
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                if (EXACT || s0 + s < k) {
+                    const f32x4 t = *(const f32x4*)(Us + jr[s] * CS + 4 * q);
+                    const f32x2 ta = {t[0], t[1]}, tb = {t[2], t[3]};
+                    s1a += ta; s1b += tb;
+                    s2a = __builtin_elementwise_fma(ta, ta, s2a); s2b = __builtin_elementwise_fma(tb, tb, s2b);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool take = (s0 + s == 0) || (t[e] > best[e]);
+                        best[e] = take ? t[e] : best[e]; bs[e] = take ? s0 + s : bs[e];
+                    }
                 }
             }
         }
@@ -703,8 +707,7 @@ int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const fl
         if ((lds > red ? lds : red) <= 150 * 1024 && B * psplit <= edge_reduce_parts(P)) {
             const size_t ldsz = lds > red ? lds : red;
 #define EW_GO(KM, EX) do { auto kern = CS == 32 ? edge_reduce_wide_kernel<KM, EX, 32, 1024> : CS == 8 ? edge_reduce_wide_kernel<KM, EX, 8, 256> : NT == 512 ? edge_reduce_wide_kernel<KM, EX, 16, 512> : edge_reduce_wide_kernel<KM, EX, 16, 1024>; \
-                hipError_t e_ = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz); \
-                if (e_ != hipSuccess) return (int)e_; \
+                if (ldsz > 64 * 1024) { hipError_t e_ = mlsp_lds_limit((const void*)kern, ldsz); if (e_ != hipSuccess) return (int)e_; } \
                 hipLaunchKernelGGL(kern, dim3(B * nsl * psplit), dim3(NT), ldsz, st, uv, idx, gamma, B, N, k, Cout, psplit, msel, argsel, s1, part); } while (0)
             if (k == 20) EW_GO(20, true); else if (k <= 20) EW_GO(20, false); else if (k <= 32) EW_GO(32, false); else EW_GO(40, true);
 #undef EW_GO
@@ -721,7 +724,7 @@ int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const fl
             auto kern = k == 20 ? edge_reduce_lds_kernel<20, true> : k <= 20 ? edge_reduce_lds_kernel<20, false> : k <= 32 ? edge_reduce_lds_kernel<32, false>
                       : k == 40 ? edge_reduce_lds_kernel<40, true> : edge_reduce_lds_kernel<40, false>;     // k = 40: BASELINE.json configs[4]
             if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t e = mlsp_lds_limit((const void*)kern, lds);
                 if (e != hipSuccess) return (int)e;
             }
             hipLaunchKernelGGL(kern, dim3(B * nsl * psplit), dim3(256), lds, st, uv, idx, gamma, B, N, k, Cout, psplit, msel, argsel, s1, part);

@@ -1307,6 +1307,25 @@ extern "C" int mlsp_profile_classes(double* out, int ncls) {
     return MLSP_OK;
 }
 
+// out [3][4] = {milliseconds, launches, algorithmic FLOP, algorithmic A + B + C bytes (split-K slabs: written and read once more)} of the
+// launches of the last bracket that ran on gemm_split_kernel, by kind: 0 forward (A row-major, B = W as stored), 1 dgrad, 2 wgrad
+// (k-major A).  bench.py prices each kind's HBM-side bytes (rocprofv3 --pmc, per template instantiation) against these.
+extern "C" int mlsp_profile_split_kinds(double* out) {
+    if (!out || g_prof.on) return MLSP_ERR_ARG;
+    for (int i = 0; i < 12; ++i) out[i] = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        const auto& r = g_prof.rec[i];
+        if (!r.split) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
+        const int kind = r.ta ? 2 : (r.tb ? 0 : 1);
+        double* o = out + 4 * kind;
+        o[0] += t; o[1] += 1.0; o[2] += 2.0 * r.M * (double)r.N * r.K;
+        o[3] += 4.0 * ((double)r.M * r.K + (double)r.K * r.N + (double)r.M * r.N * (r.ns > 1 ? 2.0 * r.ns + 1.0 : 1.0));
+    }
+    return MLSP_OK;
+}
+
 int launch_skinny_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                        float* C, int ldc, const float* bias);
 int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,

@@ -339,7 +339,7 @@ static int launch_knn_mfma3_ct(hipStream_t st, const float* x, int ld, const flo
     size_t lds = ((size_t)2 * CT * KM_STRIDE + 96) * sizeof(float);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_mfma3_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)knn_mfma3_kernel<CT>, lds);
         if (e != hipSuccess) return (int)e;
     }
     int vec_ok = (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
@@ -637,7 +637,7 @@ static int launch_knn_mfma4_ct(hipStream_t st, const float* x, int ld, const flo
     size_t lds = ((size_t)2 * CT * KM_STRIDE + 96 + 2 * 4 * 32 * KNN4_CAP) * sizeof(float);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_mfma4_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)knn_mfma4_kernel<CT>, lds);
         if (e != hipSuccess) return (int)e;
     }
     int vec_ok = (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
@@ -1333,7 +1333,7 @@ template <int CT, bool VEC, bool RES, int KB>
 static int launch_knn_mfma5_ct(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx,
                                size_t lds) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_mfma5_kernel<CT, VEC, RES, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)knn_mfma5_kernel<CT, VEC, RES, KB>, lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL((knn_mfma5_kernel<CT, VEC, RES, KB>), dim3((N / 128) * B), dim3(512), lds, st, x, xx, ld, N, C, k, idx, B);
@@ -1385,7 +1385,7 @@ static int launch_knn_k(hipStream_t st, const float* x, int ld, const float* xx,
         size_t lds = knn_lds_bytes(KMAX, C, true);
         if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)knn_kernel<KMAX, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = mlsp_lds_limit((const void*)knn_kernel<KMAX, 0>, lds);
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL((knn_kernel<KMAX, 0>), grid, block, lds, st, x, xx, ld, N, C, k, idx);
@@ -1603,7 +1603,7 @@ static int launch_reverse(hipStream_t st, const int* idx, int B, int S, int N, i
     const size_t lds = (size_t)(2 * dper + 1 + 2 * RV_CAP) * sizeof(int);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)knn_reverse_kernel, lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(knn_reverse_kernel, dim3(B * nsplit), dim3(1024), lds, st, idx, N, k, rev_off, rev_ent, B, S, nsplit, skip_pad, rev_cnt);

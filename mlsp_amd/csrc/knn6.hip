@@ -808,7 +808,7 @@ static int knn6_go(hipStream_t st, const float* x, int ld, int B, int N, int C, 
     const int P = B * N;
     hipLaunchKernelGGL((knn6_prep_kernel<CT>), dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, N, C, xx, xc, planes, idx, k);
     const size_t lds = knn6_lds_bytes(N);
-    hipError_t e = hipFuncSetAttribute((const void*)knn6_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = mlsp_lds_limit((const void*)knn6_kernel<CT>, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((knn6_kernel<CT>), dim3((N / 128) * B), dim3(512), lds, st, x, ld, xx, xc, planes, N, C, k, idx, B);
     return mlsp_launch_status();

@@ -102,7 +102,7 @@ int launch_radius_count(hipStream_t st, const float* x, int ld, int B, int N, fl
     size_t lds = (size_t)3 * N * sizeof(float);
     if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)radius_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)radius_count_kernel, lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(radius_count_kernel, dim3((N + 255) / 256, B), dim3(256), lds, st, x, ld, N, radius * radius, max_nn, count);

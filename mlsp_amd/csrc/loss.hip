@@ -438,7 +438,7 @@ int launch_chamfer_fwd(hipStream_t st, const float* pred, const float* gold, con
     size_t lds = (size_t)10 * N * sizeof(float);
     if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)chamfer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)chamfer_fwd_kernel, lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(chamfer_fwd_kernel, dim3(B), dim3(1024), lds, st, pred, gold, mask, N, per_cloud, argA, argB);
@@ -457,7 +457,7 @@ int launch_chamfer_dir_fwd(hipStream_t st, const float* p1, const float* p2, con
     size_t lds = (size_t)6 * N * sizeof(float);
     if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)chamfer_dir_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)chamfer_dir_fwd_kernel, lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(chamfer_dir_fwd_kernel, dim3(B), dim3(1024), lds, st, p1, p2, mc, N, per_cloud, arg);

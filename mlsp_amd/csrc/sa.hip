@@ -213,7 +213,7 @@ int launch_fps(hipStream_t st, const float* xyz, int ldx, int B, int N, int S, c
     size_t lds = ((size_t)3 * N + 32) * sizeof(float);
     if (lds > 150 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mlsp_lds_limit((const void*)fps_kernel, lds);
         if (e != hipSuccess) return (int)e;
     }
     if (N <= 2048 && N >= 64) {

@@ -1807,7 +1807,7 @@ int tnet_points_per_tile(int k) { return k > 0 && k <= TN_ROWS ? (TN_ROWS / k > 
 
 static int tnet_set_lds(const void* fn) {
     size_t lds = (size_t)TN_LDS_FLOATS * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = mlsp_lds_limit(fn, lds);
     return e == hipSuccess ? MLSP_OK : (int)e;
 }
 
@@ -1903,14 +1903,14 @@ int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const 
         static const bool f32_env = getenv("MLSP_TNET_BWD_F32") != nullptr;
         if (!f32_env && gemm_precision_mode() != 0 && k % 2 == 0 && k >= 8 && k <= 64) {
             const size_t lds = sizeof(TnetBwdSLds);
-            hipError_t e = hipFuncSetAttribute((const void*)tnet_edge_bwds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = mlsp_lds_limit((const void*)tnet_edge_bwds_kernel, lds);
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL(tnet_edge_bwds_kernel, dim3(nb), dim3(512), lds, st, uv, idx, bn1, W2, Mc, g, argsel, dhp, slabs, part1, P, N, k, TP, slope);
         } else {
             const size_t lds = sizeof(TnetBwdGLds);
             auto kern = k <= 20 ? tnet_edge_bwdg_kernel<0, 20> : k <= 24 ? tnet_edge_bwdg_kernel<0, 24> : k <= 32 ? tnet_edge_bwdg_kernel<0, 32>
                       : k <= 40 ? tnet_edge_bwdg_kernel<1, 40> : tnet_edge_bwdg_kernel<2, 32>;
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = mlsp_lds_limit((const void*)kern, lds);
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, st, uv, idx, bn1, W2, Mc, g, argsel, dhp, slabs, part1, P, N, k, TP, slope);
         }

@@ -669,6 +669,9 @@ def test_segda_vs_reference_golden(dev, golden_dir, fname, seed, B, N, K):
         if q.grad is None or n not in g64 or (n.startswith("shared_layers") and n.endswith(".bias")):
             continue
         den = np.linalg.norm(g64[n]) + 1e-30
+        if den < 1e-9 * (1.0 + np.linalg.norm(q.detach().cpu().numpy())):      # a bias in front of a batch-statistics BatchNorm: analytically zero
+            assert np.linalg.norm(q.grad.cpu().numpy()) < 1e-5, n
+            continue
         rel = np.linalg.norm(q.grad.cpu().double().numpy() - g64[n]) / den
         yard = np.linalg.norm(g32[n] - g64[n]) / den
         if rel > worst[1]:
