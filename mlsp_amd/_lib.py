@@ -6,6 +6,7 @@ every op raises.  Build the library with `python -c "import __graft_entry__ as g
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -136,10 +137,29 @@ def load():
         fn = getattr(lib, name)         # AttributeError if a declared symbol is not exported
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, _I)
+        if _SZ in args and _P in args:
+            # An entry point that takes the caller's workspace enqueues SEVERAL kernels that hand data to each other through it.  ctypes
+            # drops the GIL inside the call, so two Python threads driving one device (nn.DataParallel's replica threads on one GPU,
+            # torch's parallel_apply) could interleave their launches on the shared stream and overwrite each other's scratch data:
+            # one call at a time per process (an uncontended lock costs ~0.1 us; the launches themselves stay asynchronous).
+            setattr(lib, name, _serialised(fn))
     if lib.mlsp_abi_version() != ABI_VERSION:
         raise MlspLibraryError("mlsp_amd: ABI mismatch: library %d, python %d" % (lib.mlsp_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+_call_lock = threading.Lock()
+
+
+def _serialised(fn):
+    lock = _call_lock
+
+    def call(*a):
+        with lock:
+            return fn(*a)
+    call.__name__ = getattr(fn, "__name__", "mlsp_entry")
+    return call
 
 
 def check(rc, what):
