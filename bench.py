@@ -725,7 +725,7 @@ def main():
                "config": {"workload": "DGCNN encoder + 3 MLSP heads + losses, fwd+bwd+Adam, B=%d/GPU N=1024 k=20 fp32 "
                                       "(BASELINE.json configs[1]), dropout 0.5, BN train" % b_local,
                           "global_batch": b_local * n_gpus, "points_per_cloud": NPTS, "k": K_NN,
-                          "parallelism": "dp%d" % n_gpus, "grad_allreduce": "1 x flat 18.2 MB fp32 per step (RCCL)",
+                          "parallelism": "dp%d" % n_gpus, "grad_allreduce": "1 x flat 18.2 MB fp32 per step (RCCL); no host-side exchange (presence='uniform', verified in-band)",
                           "gemm_products": "%s (bf16x6 = fp32 operands split exactly into three bf16 pieces, six piece products, fp32 "
                                            "accumulation: error vs float64 below the f32-MFMA chain's, tests/test_gpu_kernels.py::"
                                            "test_gemm_split_bf16_accuracy; MLSP_GEMM_PRECISION=fp32 runs every GEMM on the f32 MFMA)"

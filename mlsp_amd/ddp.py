@@ -29,20 +29,34 @@ class FlatGradSync:
 
     Which parameters step.  A parameter whose gradient is None is skipped by the optimizer (a head that did not run:
     DGCNN.Rec_scan in the default modes) -- exactly what the reference's single process does.  Across ranks that set must be
-    the SAME or the replicas drift apart (one rank applies the averaged gradient, the other nothing), so before packing
-    the ranks exchange a presence bitmap (one byte per parameter, MAX-reduced) on a HOST-side group: a parameter that
-    has a gradient on ANY rank gets a (zero-filled) gradient on every rank.  The exchange runs on the CPU (gloo), not
-    on the GPU stream: the host is ~2 ms ahead of the device at that point, so it costs no device time and no
-    stream synchronisation.
+    the SAME or the replicas drift apart (one rank applies the averaged gradient, the other nothing).  Two policies (`presence=`):
+
+    "uniform" (default): every rank runs the same heads in a step -- true for PointDA/trainer.py, whose branches depend on flags, not
+        on the data -- so nothing is exchanged on the host.  It is VERIFIED, not assumed: two 10-bit hashes of the local pattern (and
+        their squares) ride at the end of the gradient bucket through the same RCCL all-reduce; the sums come back through a pinned
+        buffer without a stream synchronisation and are checked at the NEXT step (by then the copy has long landed): if the ranks'
+        patterns differed the step raises and names the remedy.  Cost per step: 16 bytes in the bucket, one 16-byte async copy.
+    "exchange": the ranks exchange a presence bitmap (one byte per parameter, MAX-reduced) on a HOST-side gloo group before packing: a
+        parameter that has a gradient on ANY rank gets a (zero-filled) gradient on every rank -- for loops with data-dependent
+        branches.  It is a BLOCKING host collective per step: 0.57 ms (world 2) / 3.2 ms (world 8, eight processes on eight cores)
+        median over loopback on the build container (tools/r5/gloo_latency.py), against the ~1 ms the host runs ahead of the device
+        at opt.step() (tools/r5/host_profile.py) -- which is why it is no longer the default.
     """
 
-    def __init__(self, model, process_group=None, force=False):
+    _NCHK = 4                                 # trailing bucket elements of the uniform-presence check: h1, h1^2, h2, h2^2
+
+    def __init__(self, model, process_group=None, force=False, presence="uniform"):
+        if presence not in ("uniform", "exchange"):
+            raise ValueError("presence must be 'uniform' or 'exchange'")
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.group = process_group
         self.force = bool(force)
+        self.presence_mode = presence
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._bucket = torch.zeros(self.numel + self._NCHK, dtype=torch.float32, device=dev)
+        self.flat = self._bucket[:self.numel]                 # the gradients; the check words sit behind them in the same allocation
+        self._chk = self._bucket[self.numel:]
         self.views = []
         off = 0
         for p in self.params:
@@ -50,7 +64,8 @@ class FlatGradSync:
             off += p.numel()
         self.collectives = 0                  # device all-reduces issued so far (tests count them)
         self.host_group = None
-        if self.world_size > 1:
+        self._pending = None                  # (host copy of the summed check words, event | None, world size) of the previous step
+        if self.world_size > 1 and presence == "exchange":
             backend = dist.get_backend(self.group)
             # the presence bitmap travels host-side: the default group itself when it already is a CPU one
             self.host_group = self.group if backend == "gloo" else dist.new_group(backend="gloo")
@@ -60,11 +75,31 @@ class FlatGradSync:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def presence(self):
-        """[n_params] bool list: does ANY rank hold a gradient for the parameter this step (host-side MAX-reduce)."""
+        """[n_params] bool list: does ANY rank hold a gradient for the parameter this step (host-side MAX-reduce; "exchange" mode)."""
         local = torch.tensor([p.grad is not None for p in self.params], dtype=torch.uint8)
-        if self.world_size > 1:
-            dist.all_reduce(local, op=dist.ReduceOp.MAX, group=self.host_group)
+        if self.world_size > 1 and self.presence_mode == "exchange":
+            dist.all_reduce(local, op=dist.ReduceOp.MAX, group=self.host_group)    # (host_group None = the default group, when that is a gloo one)
         return local.bool().tolist()
+
+    def _local_hashes(self):
+        import zlib
+        bits = bytes(1 if p.grad is not None else 0 for p in self.params)
+        c = zlib.crc32(bits)
+        return float(c & 1023), float((c >> 10) & 1023)
+
+    def _verify_previous(self):
+        """Check the summed pattern hashes of the PREVIOUS step's all-reduce (uniform mode): equal patterns <=> ws * sum(h^2) == sum(h)^2."""
+        if self._pending is None:
+            return
+        host, ev, ws = self._pending
+        self._pending = None
+        if ev is not None and not ev.query():
+            ev.synchronize()
+        s1, q1, s2, q2 = (int(round(v)) for v in host.tolist())
+        if ws * q1 != s1 * s1 or ws * q2 != s2 * s2:
+            raise RuntimeError("FlatGradSync(presence='uniform'): in the previous step the ranks did not hold gradients for the same set of "
+                               "parameters (a data-dependent branch skipped a head on some rank).  The replicas have diverged; construct "
+                               "FlatGradSync(..., presence='exchange') for such loops.")
 
     def pack(self, present=None):
         """Copy the present gradients into the bucket (absent ones count as zero) and alias .grad to the bucket.
@@ -91,10 +126,26 @@ class FlatGradSync:
     def allreduce(self):
         ws = self.world_size
         if ws > 1 or self.force:
-            self.pack(self.presence())
+            uniform = self.presence_mode == "uniform"
+            if uniform:
+                self._verify_previous()
+                self.pack(None)
+                h1, h2 = self._local_hashes()
+                self._chk.copy_(torch.tensor([h1, h1 * h1, h2, h2 * h2], dtype=torch.float32), non_blocking=True)
+            else:
+                self.pack(self.presence())
             if dist.is_available() and dist.is_initialized():
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self._bucket if uniform else self.flat, op=dist.ReduceOp.SUM, group=self.group)
                 self.collectives += 1
+                if uniform:                   # the summed check words travel back without a synchronisation; read at the next step
+                    if self._bucket.is_cuda:
+                        host = torch.empty(self._NCHK, dtype=torch.float32, pin_memory=True)
+                        host.copy_(self._chk, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        self._pending = (host, ev, ws)
+                    else:
+                        self._pending = (self._chk.clone(), None, ws)
             self.flat.div_(ws)
         return self.flat
 

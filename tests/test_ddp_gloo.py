@@ -81,7 +81,7 @@ def _worker_divergent(rank, world, port, q):
     torch.manual_seed(0)
     model = torch.nn.ModuleDict({"enc": torch.nn.Linear(8, 8), "head_a": torch.nn.Linear(8, 4), "head_b": torch.nn.Linear(8, 4),
                                  "never": torch.nn.Linear(8, 4)})
-    sync = FlatGradSync(model)
+    sync = FlatGradSync(model, presence="exchange")           # data-dependent branches: the host-side bitmap exchange
     opt = sync.wrap(torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-5))
     g = torch.Generator().manual_seed(200 + rank)
     ok = True
@@ -176,3 +176,109 @@ def test_pack_with_absent_gradients_is_idempotent():
     opt.step()
     opt.zero_grad()
     assert all(p.grad is None for p in m.parameters())
+
+
+def _worker_dgcnn(rank, world, port, q):
+    """The REAL DGCNN's parameter list through FlatGradSync (the slice of the N > 1 path that needs no kernels): 4,548,899 trainable
+    elements in ONE bucket, Density_cls.fc2 (frozen, PointDA/Models.py:267-270) outside it, Rec_scan (a head the default modes never run)
+    absent on every rank, a head that ran on rank 0 only present everywhere after the exchange, replicas identical after Adam."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import golden_common as gc
+    from mlsp_amd import Models
+    from mlsp_amd.ddp import FlatGradSync
+    torch.manual_seed(0)
+    model = Models.DGCNN(gc.make_args(dropout=0.5))            # CPU module: construction and state need no kernel
+    sync = FlatGradSync(model, presence="exchange")            # (step 0 is rank-divergent on purpose)
+    opt = sync.wrap(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5))
+    ok_size = sync.numel == 4548899 and len(sync.params) == sum(1 for p in model.parameters() if p.requires_grad)
+    ok_frozen = all(p is not model.Density_cls.fc2.weight for p in sync.params)
+    named = dict(model.named_parameters())
+    g = torch.Generator().manual_seed(300 + rank)
+    for step in range(2):
+        opt.zero_grad()
+        # synthetic gradients stand in for two backward passes of a step: everything but Rec_scan; the normal head on rank 0 only
+        for n, p_ in named.items():
+            if not p_.requires_grad or n.startswith("Rec_scan") or (n.startswith("Norm_pred") and rank == 1 and step == 0):
+                continue
+            p_.grad = torch.randn(p_.shape, generator=g)
+        local = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in sync.params])
+        opt.step()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        ok_avg = torch.allclose(sync.flat, sum(gathered) / world, atol=1e-6)
+        ok_present = model.Norm_pred.conv1.weight.grad is not None and model.Rec_scan.conv1.weight.grad is None
+        w = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()])
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        ok_same = all(torch.equal(ws[0], t) for t in ws)
+        if not (ok_avg and ok_present and ok_same):
+            break
+    q.put((rank, ok_size, ok_frozen, ok_avg, ok_present, ok_same, sync.collectives == 2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_real_dgcnn_parameter_list_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dgcnn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
+
+
+def _worker_uniform_check(rank, world, port, q):
+    """Default policy "uniform": no host exchange; a step in which the ranks' gradient patterns differ is DETECTED at the next step
+    (the pattern hashes ride in the gradient bucket) and raises."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mlsp_amd.ddp import FlatGradSync
+    torch.manual_seed(0)
+    model = torch.nn.ModuleDict({"enc": torch.nn.Linear(8, 8), "head_a": torch.nn.Linear(8, 4), "head_b": torch.nn.Linear(8, 4)})
+    sync = FlatGradSync(model)
+    assert sync.presence_mode == "uniform" and sync.host_group is None
+    opt = sync.wrap(torch.optim.SGD(model.parameters(), lr=1e-2))
+    g = torch.Generator().manual_seed(400 + rank)
+    raised_at = None
+    for step in range(4):
+        x = torch.randn(6, 8, generator=g)
+        opt.zero_grad()
+        h = torch.relu(model["enc"](x))
+        loss = model["head_a"](h).pow(2).mean()
+        if not (step == 1 and rank == 1):                     # step 1: rank 1 skips head_b -- the patterns differ
+            loss = loss + model["head_b"](h).pow(2).mean()
+        loss.backward()
+        try:
+            opt.step()
+        except RuntimeError as e:
+            raised_at = (step, "presence='exchange'" in str(e))
+            break
+    q.put((rank, raised_at == (2, True)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uniform_presence_is_verified_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_uniform_check, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
