@@ -1396,6 +1396,9 @@ static int launch_knn_k(hipStream_t st, const float* x, int ld, const float* xx,
 bool knn6_supported(int B, int N, int C, int k);                       // knn6.hip
 size_t knn6_plane_bytes(int P, int C);
 int launch_knn6(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, void* planes);
+bool knn6_vex_supported(int B, int N, int C, int k);
+size_t knn6_vex_bytes(int P);
+int launch_knn6_vex(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, void* cand);
 
 // xx_ws: [B*N] floats of workspace; planes (nullable): knn6_plane_bytes(B*N, C) bytes of workspace for the v6 kernel's bf16 images
 int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws, void* planes, size_t plane_bytes) {
@@ -1403,7 +1406,14 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
     int P = B * N;
     // v6 (knn6.hip): k <= 24 on whole 128-query chunks -- the five graph stages of DGCNN.  MLSP_KNN_V5=1: read-once A/B switch.
     static const bool force_v5 = getenv("MLSP_KNN_V5") != nullptr;
-    if (!force_v5 && planes && knn6_supported(B, N, C, k) && plane_bytes >= knn6_plane_bytes(P, C) && (C > 16 || getenv("MLSP_KNN_V6_ALL"))) {   // (C <= 16 stays on v5 until v6's selection phases beat it there)
+    static const bool v6_all = getenv("MLSP_KNN_V6_ALL") != nullptr;
+    static const bool no_vex = getenv("MLSP_KNN_NO_VEX") != nullptr;         // read-once A/B switch: C <= 3 back on the MFMA kernel
+    // C <= 3 (raw and transformed cloud): the v6 skeleton with vector-exact sweeps (knn6.hip VEX)
+    if (!force_v5 && !no_vex && planes && knn6_vex_supported(B, N, C, k) && plane_bytes >= knn6_vex_bytes(P)) {
+        const int rc = launch_knn6_vex(st, x, ld, B, N, C, k, idx, xx_ws, planes);
+        if (rc != MLSP_ERR_UNSUPPORTED) return rc;
+    }
+    if (!force_v5 && planes && knn6_supported(B, N, C, k) && plane_bytes >= knn6_plane_bytes(P, C) && (C > 16 || v6_all)) {   // (C <= 16 stays on v5 until v6's selection phases beat it there)
         const int rc = launch_knn6(st, x, ld, B, N, C, k, idx, xx_ws, planes);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }

@@ -110,6 +110,23 @@ __global__ __launch_bounds__(256) void knn6_prep_kernel(const float* __restrict_
     xc[i] = accc;
 }
 
+// VEX mode (C <= 3: the raw and the transformed cloud of DGCNN): no image, no centring -- the sweeps compute the CANONICAL distance itself
+// with vector FMAs, so every survivor's value is exact and nothing has to be re-resolved.  Per point {x0, x1, x2, xx} (zero-padded
+// coordinates: fmaf(0, 0, acc) == acc), xx = the canonical chain; the output rows start as zeros (see knn6_prep_kernel).
+__global__ __launch_bounds__(256) void knn6_prep_vex_kernel(const float* __restrict__ x, int ld, int P, int C, float* __restrict__ xx,
+                                                            f32x4* __restrict__ cand, int* __restrict__ idx, int k) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    for (int s = 0; s < k; ++s) idx[(size_t)i * k + s] = 0;
+    const float* r = x + (size_t)i * ld;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) { v[c] = r[c]; acc = fmaf(r[c], r[c], acc); }
+    v[3] = acc;
+    xx[i] = acc;
+    cand[i] = v;
+}
+
 template <int I, int Nn, class F>
 __device__ __forceinline__ void k6_static_for(F&& f) {
     if constexpr (I < Nn) { f(std::integral_constant<int, I>{}); k6_static_for<I + 1, Nn>(f); }
@@ -122,7 +139,15 @@ __device__ __forceinline__ bool k6_beats(float d, int j, float pv, int pi) { ret
 // half of the candidates it sweeps: two waves per SIMD (the selection phases are vector-issue bound, and a lone wave issues at half rate),
 // no barrier inside a sweep.  (Two query groups per wave against the same fragments -- half the fragment traffic -- was built and measured:
 // the sweeps gain 10 %, every selection phase loses 2x at one wave per SIMD.)
-template <int CT>
+// Measured (B = 32, N = 1024, k = 20): 37.7 us per call against 41.5 on knn_mfma5_kernel<4>; stamps (tools/knn6_stamps.py, clocks per
+// workgroup): pass A 11.7 k, pass B 24.7 k, tau 5.5 k, final 11.4 k of 64 k -- the sweeps are LDS-issue bound, not vector bound: every
+// ds_read_b128 of a candidate row serves 64 (query, candidate) pairs whatever the arithmetic (16 reads per tile and wave, 8 waves), and
+// the masked survivor append doubles that in pass B.  Going below needs several queries per lane against one candidate read (another
+// wave <-> query map, i.e. another list layout): not built.
+// VEX (C <= 3, N <= 1024): `planes` is the {x0, x1, x2, xx} array of knn6_prep_vex_kernel; the cloud's 16 KB of it are staged in LDS (in the
+// final's work-list area, dead until then) and the two sweeps are plain vector code: three FMAs, the two norm terms -- the canonical value,
+// bit for bit -- per pair.  Lists hold exact distances (E = 0): the final flags only exact ties, which the full order settles by index.
+template <int CT, bool VEX = false>
 __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, int ld, const float* __restrict__ xx_all, const float* __restrict__ xc_all,
                                                    const char* __restrict__ planes, int N, int C, int k, int* __restrict__ idx, int B) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -164,6 +189,11 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
         float m = 0.f, mr = 0.f;
         // (fmaxf drops a NaN operand: a NaN norm -- a NaN coordinate, or an infinite first point of the cloud, the origin of the centred
         // image -- becomes an infinite bound here, and an infinite bound sends the workgroup through the exact path below)
+        if (VEX) {
+            const f32x4* cg = (const f32x4*)planes + (size_t)b * N;
+            f32x4* cl = (f32x4*)wlbase;                       // the cloud {x, xx}: the final's work lists live here later
+            for (int j = tid; j < N; j += 512) { const f32x4 v = cg[j]; cl[j] = v; mr = fmaxf(mr, v[3] == v[3] ? v[3] : INFINITY); }
+        } else
         for (int j = tid; j < N; j += 512) {
             const float v = xcb[j], w = xxb[j];
             nxx[j] = -0.5f * v; m = fmaxf(m, v == v ? v : INFINITY); mr = fmaxf(mr, w == w ? w : INFINITY);
@@ -182,15 +212,21 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
     const float K6_CANON = (float)(C + 4) * 1.1920929e-07f;
     const int q0 = chunk * 128 + qg * 32;                     // first query of this wave's group, local to the cloud
     const float xxq = xxb[q0 + l31];                          // raw (exact path, canonical bound)
-    const float xcq = xcb[q0 + l31];                          // centred (sweeps)
-    const float Eq = K6_EPS * (xcq + xcmax) + K6_CANON * (xxq + xxmax);
+    const float xcq = VEX ? 0.f : xcb[q0 + l31];              // centred (sweeps)
+    // VEX: the lists hold the canonical values themselves -- no error to budget; a non-finite norm still asks for the exact path
+    const float Eq = VEX ? (xxmax < INFINITY ? 0.f : INFINITY) : K6_EPS * (xcq + xcmax) + K6_CANON * (xxq + xxmax);
 
     // ---------------------------------------------------------------------------------------------------------------- approximate sweeps
     k6bf16x8 qh[NKB], ql[NKB];                                // B operand: query row l31 of the group, channels 16 kb + 8 h .. + 7
+    f32x4 qv = {0.f, 0.f, 0.f, 0.f};                          // VEX: this lane's query {x0, x1, x2, xx}
+    if constexpr (VEX) {
+        qv = ((const f32x4*)wlbase)[q0 + l31];
+    } else {
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        qh[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (q0 >> 5), NKB, kb, 0, h, l31));
-        ql[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (q0 >> 5), NKB, kb, 1, h, l31));
+        for (int kb = 0; kb < NKB; ++kb) {
+            qh[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (q0 >> 5), NKB, kb, 0, h, l31));
+            ql[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (q0 >> 5), NKB, kb, 1, h, l31));
+        }
     }
     const unsigned voff = (unsigned)(h * 512 + l31 * 16);     // this lane's 16 bytes inside a fragment KiB
     const char* cand0 = planes + (T0 + (size_t)ch * nt2) * (NKB * 2048);     // (uniform) first tile of this wave's half
@@ -205,6 +241,26 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
     // The compiler drains the memory counter once per loop trip (its wait-count analysis merges pessimistically at the back edge), so a
     // trip covers UNR tiles: the drain exposes one L2 latency per UNR tiles of MFMA work.
     auto sweep = [&](auto&& sel) {
+        if constexpr (VEX) {
+            // vector sweep: acc[r] = the CANONICAL distance of (query l31, candidate (r & 3) + 8 (r >> 2) + 4 h of the tile): dot = fmaf chain
+            // over the channels from +0, t = fl(2 dot - xx_j), pd = fl(t - xx_i) (oracle/knn_canon.c).  The 32 lanes of a half read the same
+            // candidate: one LDS broadcast per row.
+            const f32x4* cl = (const f32x4*)wlbase;
+            for (int tl = 0; tl < nt2; ++tl) {
+                const f32x4* cp = cl + (ch * nt2 + tl) * 32 + 4 * h;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 c = cp[(r & 3) + 8 * (r >> 2)];
+                    float d = fmaf(qv[0], c[0], 0.f);
+                    d = fmaf(qv[1], c[1], d);
+                    d = fmaf(qv[2], c[2], d);
+                    acc[r] = fmaf(2.0f, d, -c[3]) - qv[3];
+                }
+                sel(acc, tl);
+            }
+            return;
+        }
         k6bf16x8 fh[NR], fl[NR];
         auto tile = [&](auto SLOT, auto RING, int tl, int tn, auto&& sel_) {  // tn: the tile that refills this ring slot (always loaded: no branch)
             constexpr int s0 = decltype(SLOT)::value * NKB;
@@ -417,11 +473,11 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float a = __int_as_float((int)v[u][0]);
-                const float p = exact_lists ? a : fmaf(2.0f, a, -xcq);
+                const float p = (exact_lists || VEX) ? a : fmaf(2.0f, a, -xcq);
                 const bool live = p0 + u < cnt;
                 const k6u32x2 w = {(unsigned)__float_as_int(live ? p : -INFINITY), live ? v[u][1] : 0u};
                 *(k6u32x2*)(LB + (p0 + u) * 8) = w;
-                if (live) mn = fminf(mn, nxx[v[u][1] & 4095u]);
+                if (!VEX && live) mn = fminf(mn, nxx[v[u][1] & 4095u]);
             }
         }
         cnts[(qg * 32 + l31) * 4 + ch * 2 + h] = cnt;
@@ -466,8 +522,8 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
         if (!exact_lists && nmaxw <= 32) {
             const f32x4 m4 = *(const f32x4*)(lmn + qq * 4);
             const float xm = -2.0f * fminf(fminf(m4[0], m4[1]), fminf(m4[2], m4[3]));
-            const float xqr = xxb[qrow], xqc = xcb[qrow];
-            const float E2 = 2.0f * (K6_EPS * (xqc + xm) + K6_CANON * (xqr + xxmax));
+            const float xqr = xxb[qrow], xqc = VEX ? 0.f : xcb[qrow];
+            const float E2 = VEX ? 0.0f : 2.0f * (K6_EPS * (xqc + xm) + K6_CANON * (xqr + xxmax));     // (VEX: exact values, only exact ties are flagged)
             const char* Lb0 = list_at(qlc, 0);
             const char* Lb1 = list_at(qlc, 1);
             const char* Lb2 = list_at(qlc, 2);
@@ -741,7 +797,7 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
         const int qlc = ch * 16 + it * 2 + h;                  // query of the group
         const int qq = qg * 32 + qlc;                          // query of the workgroup
         const int qrow = chunk * 128 + qq;                     // query of the cloud
-        const float xq = xxb[qrow], xqc = xcb[qrow];
+        const float xq = xxb[qrow], xqc = VEX ? 0.f : xcb[qrow];
         const char* L0 = list_at(qlc, 0);
         const char* L1 = list_at(qlc, 1);
         const char* L2 = list_at(qlc, 2);
@@ -749,7 +805,7 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
         const k6i32x4 c4 = *(const k6i32x4*)(cnts + qq * 4);
         const f32x4 m4 = *(const f32x4*)(lmn + qq * 4);
         const float xm = -2.0f * fminf(fminf(m4[0], m4[1]), fminf(m4[2], m4[3]));       // largest centred squared norm among the query's survivors
-        const float E2 = exact_lists ? 0.0f : 2.0f * (K6_EPS * (xqc + xm) + K6_CANON * (xq + xxmax));     // (exact lists: only exact ties go through the full-order recount)
+        const float E2 = (exact_lists || VEX) ? 0.0f : 2.0f * (K6_EPS * (xqc + xm) + K6_CANON * (xq + xxmax));     // (exact values: only exact ties go through the full-order recount)
         const int p1 = c4[0], p2 = p1 + c4[1], p3 = p2 + c4[2], n = p3 + c4[3];
         const int nmax = max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 32));
         int cmx = max(max(c4[0], c4[1]), max(c4[2], c4[3]));
@@ -796,6 +852,22 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
 size_t knn6_lds_bytes(int N) { return (size_t)512 * K6_LSTR + (size_t)N * 4 + 128 * 4 + 512 * 4 + 64 + (size_t)8 * 512 * 4 + 512 * 4; }
 
 // shapes v6 takes (the rest stays on knn.hip's kernels)
+// the vector-exact mode of the kernel: C <= 3 on whole 128-query chunks, the cloud's {x, xx} image in the 16 KB work-list area
+bool knn6_vex_supported(int B, int N, int C, int k) {
+    return B > 0 && N >= 128 && N % 128 == 0 && N <= 1024 && C >= 1 && C <= 3 && k >= 1 && k <= K6_KMAX && k <= N;
+}
+size_t knn6_vex_bytes(int P) { return (size_t)P * 16; }
+int launch_knn6_vex(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, void* cand) {
+    if (!knn6_vex_supported(B, N, C, k) || !cand || (((uintptr_t)cand) & 15)) return MLSP_ERR_UNSUPPORTED;
+    const int P = B * N;
+    hipLaunchKernelGGL(knn6_prep_vex_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, C, xx, (f32x4*)cand, idx, k);
+    const size_t lds = knn6_lds_bytes(N);
+    hipError_t e = mlsp_lds_limit((const void*)knn6_kernel<16, true>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((knn6_kernel<16, true>), dim3((N / 128) * B), dim3(512), lds, st, x, ld, xx, xx, (const char*)cand, N, C, k, idx, B);
+    return mlsp_launch_status();
+}
+
 bool knn6_supported(int B, int N, int C, int k) {
     return B > 0 && N >= 128 && N % 128 == 0 && N <= 4096 && C >= 1 && C <= 128 && k >= 1 && k <= K6_KMAX && k <= N &&
            knn6_lds_bytes(N) <= 160 * 1024;
