@@ -45,7 +45,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 9
+#define MLSP_ABI_VERSION 10
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -146,14 +146,25 @@ int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const mlsp_defer_t* 
                                 const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                                 float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
                                 uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+/* BatchNorm-backward reduction fused into the consumer's dgrad (round 5).  The gradient w.r.t. a chained layer's activated output is
+ * produced by its CONSUMER's dgrad; that launch (gemm_split_kernel's output pass, the small-K streaming kernel) can multiply it by the
+ * producer's activation derivative and dropout mask right there, store the masked gradient d' and leave the producer's column sums of
+ * d' and d' * yhat per 128-row panel: the producer's streaming reduction pass (a full read of dZ and Y) disappears.
+ *   consumer: in_stats != NULL ([M / 128][2][in->ld] doubles, indexed by the producer's column) -- legal when
+ *             mlsp_*_bwd_stats_parts() > 0 for the layer; dX then holds d', not dZ;
+ *   producer: pre_stats != NULL ([pre_parts][2][Cout]) -- dZ is d', its sums are given: finalisation + the BatchNorm part only.
+ * All consumers of a producer must do it or none (they all write columns of the same dX and the same partial rows). */
+int mlsp_pointmlp_bwd_stats_parts(int M, int Cin, int Cout, int ldw, int lddx, int precision);
 int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const mlsp_defer_t* in, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                                 const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                                 int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
-                                float* dgbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                                float* dgbias, float* dgamma, float* dbeta, double* in_stats, const double* pre_stats, int pre_parts,
+                                int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                           const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                           int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
-                          float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          float* dgamma, float* dbeta, const double* pre_stats, int pre_parts, int precision, void* ws, size_t ws_bytes,
+                          mlsp_stream_t stream);
 
 /* The same layer with its ACTIVATIONS stored as bf16 in HBM (BASELINE.json configs[4]: PointSegDA N=2048 k=40 "bf16 with MFMA edge-MLP";
  * PointSegDA/Models.py:245-385 head stacks).  x_bf16: X and dX are bf16 (else fp32); out_bf16: Y, Z, dZ and the internal dY are bf16.
@@ -206,9 +217,11 @@ int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg, int precisi
 int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const mlsp_defer_t* in, const float* gamma, const float* beta,
                           float* run_mean, float* run_var, float momentum, float eps, int training, const float* chan, float p_drop,
                           uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+int mlsp_multimlp_bwd_stats_parts(int M, const mlsp_seg_t* segs, int nseg, int ldx, int lddx, int precision);
 int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const mlsp_defer_t* in, const float* Y,
                           const float* bn_save, int training, const float* chan, float p_drop, uint64_t seed, float* dX, int lddx,
-                          float* const* dW, float* dbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          float* const* dW, float* dbias, float* dgamma, float* dbeta, double* in_stats, const double* pre_stats, int pre_parts,
+                          int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 
 /* max over the k edges of every point (`.max(dim=-1)`, model_utils.py:114) on an edge-major matrix */
 int mlsp_segmax_fwd_f32(const float* Z, int P, int k, int C, float* out, uint8_t* argk, mlsp_stream_t stream);

@@ -8,7 +8,7 @@
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
                 double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr, int* sel_row = nullptr,
-                bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0, const GemmGroups* grp = nullptr);
+                bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0, const GemmGroups* grp = nullptr, const GemmBs* bs = nullptr);
 bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which);
 int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A, int a_bf16, int lda, const void* B, int b_bf16,
                    int ldb, void* C, int c_bf16, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
@@ -73,7 +73,9 @@ int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int
 int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* scale,
                       const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
                       float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy,
-                      float* gpart = nullptr, int rows_per_group = 0, int* gpart_slabs = nullptr);
+                      float* gpart = nullptr, int rows_per_group = 0, int* gpart_slabs = nullptr, const double* pre_stats = nullptr, int pre_parts = 0);
+int gemm_bs_parts(int M, int N, int K, int lda, int ldb, int ldc);
+int thin_bs_parts(int M, int N, int K);
 int launch_colsum_groups_fin(hipStream_t st, const float* scratch, int G, int C, int slabs, float* out);
 int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out, float* scratch = nullptr);
 int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out);
@@ -625,8 +627,14 @@ int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const mlsp_defer_t* 
 static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                              const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                              int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
-                             float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st, const mlsp_defer_t* in) {
+                             float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st, const mlsp_defer_t* in,
+                             double* in_stats, const double* pre_stats, int pre_parts) {
+    // in_stats (consumer role, needs `in`): dX is stored MASKED by the producer's activation derivative / dropout and the producer's
+    // BatchNorm-backward column sums are left in in_stats [M / 128][2][in->ld] at column in->col (mlsp_pointmlp_bwd_stats_parts() > 0).
+    // pre_stats (producer role): dZ arrives masked, its sums are in pre_stats [pre_parts][2][Cout]: no reduction pass.
     if (!dZ || !X || !W || !dW || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
+    if (in_stats && (!in || !dX || dx_accumulate)) return MLSP_ERR_ARG;
+    if (pre_stats && (!has_bn || pre_parts <= 0 || M <= 32)) return MLSP_ERR_ARG;
     if (has_bn && (!Y || !bn_save || !dgamma || !dbeta)) return MLSP_ERR_ARG;
     if (dgbias && (n_groups <= 0 || rows_per_group <= 0 || (long)n_groups * rows_per_group != M)) return MLSP_ERR_ARG;
     Workspace w(ws, ws_bytes);
@@ -639,6 +647,7 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     size_t sf = sf1 > sf2 ? sf1 : sf2;
     float* slab = sf ? w.take<float>(sf) : nullptr;
     float* gscratch = dgbias ? w.take<float>((size_t)n_groups * 16 * Cout) : nullptr;
+    const float* Xorig = X; const int ldx_orig = ldx;   // the previous layer's pre-BN output (fused statistics read it as it is)
     GemmXf xf_s; const GemmXf* xf = nullptr;            // chained input: the wgrad reads the previous layer's pre-BN output
     if (in) {
         if (!defer_ok(in) || in->col + Cin > in->ld || M <= 32) return MLSP_ERR_ARG;
@@ -662,11 +671,17 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
         // (the per-cloud bias gradient -- column sums of dY per cloud -- comes out of the same pass when the shape allows)
         CHECK(launch_bn_act_bwd(st, dZ, Y, dY, M, Cout, scale, shift, mean, invstd, training, act, slope,
                                 training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy, dgbias ? gscratch : nullptr,
-                                rows_per_group, &g_slabs));
+                                rows_per_group, &g_slabs, pre_stats, pre_parts));
         g = dY;
     }
+    GemmBs bs_s; const GemmBs* bs = nullptr;
+    if (in_stats) {
+        bs_s = {Xorig, ldx_orig, in->bn_save + in->col, in->ld, in->act, in->slope, dropout_thresh8(in->p_drop), dropout_inv_keep8(in->p_drop), in->seed,
+                in->ld, in->col, in_stats + in->col, in->ld};
+        bs = &bs_s;
+    }
     if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf, nullptr, nullptr,
-                              nullptr, nullptr, dx_accumulate != 0));
+                              nullptr, nullptr, dx_accumulate != 0, nullptr, 0, nullptr, bs));
     CHECK(launch_gemm(st, true, false, Cout, Cin, M, g, Cout, X, ldx, dW, Cin, nullptr, nullptr, 0, slab, sf, nullptr, nullptr, nullptr,
                       nullptr, false, xf));
     if (dbias) {
@@ -688,20 +703,32 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
 int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                           const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                           int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
-                          float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          float* dgamma, float* dbeta, const double* pre_stats, int pre_parts, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     PREC_SCOPE(precision);
     return pointmlp_bwd_impl(dZ, X, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
-                             rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, nullptr);
+                             rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, nullptr, nullptr,
+                             pre_stats, pre_parts);
+}
+
+// Row panels the fused statistics pass of mlsp_pointmlp_bwd_chain_f32(in_stats != NULL) writes for this layer shape (its dgrad
+// dX [M][Cin] = dY [M][Cout] W): M / 128 when the dgrad runs on a kernel with that pass, else 0 (pass in_stats = NULL then).
+int mlsp_pointmlp_bwd_stats_parts(int M, int Cin, int Cout, int ldw, int lddx, int precision) {
+    if (precision < 0 || precision > 2) return 0;
+    GemmPrecisionScope prec_scope_(precision);
+    const int t = thin_bs_parts(M, Cin, Cout);
+    return t ? t : gemm_bs_parts(M, Cin, Cout, Cout, ldw, lddx);
 }
 
 int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const mlsp_defer_t* in, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                                 const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                                 int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
-                                float* dgbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                                float* dgbias, float* dgamma, float* dbeta, double* in_stats, const double* pre_stats, int pre_parts,
+                                int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     PREC_SCOPE(precision);
     if (!in) return MLSP_ERR_ARG;
     return pointmlp_bwd_impl(dZ, Xpre, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
-                             rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, in);
+                             rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, in, in_stats,
+                             pre_stats, pre_parts);
 }
 
 // ---- Linear + BatchNorm + act + max over the k rows of every group (last conv of a set-abstraction MLP + the neighbourhood max) ------

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const TY* __r
                                                                    const float* __restrict__ mean_dz,
                                                                    const float* __restrict__ mean_dzy, int act, float slope,
                                                                    uint32_t thresh, float inv_keep, uint64_t seed,
-                                                                   float* __restrict__ gpart) {
+                                                                   float* __restrict__ gpart, int premasked) {
     // gpart (fp32 storage, 256 % (C / 4) == 0, a block's VROWS rows inside one group): this block's column sums of dY, laid out and
     // summed exactly as colsum_groups_vec_kernel does with one slab per block -- the per-cloud bias gradient of the heads' first
     // layer without reading dY again (colsum_groups_fin_kernel finishes it)
@@ -368,11 +368,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_vec_kernel(const TY* __r
         for (int u = 0; u < 4; ++u) {
             if (rb + u * nrg >= r1) break;
             const size_t i = (size_t)(rb + u * nrg) * C + c;
-            const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;
+            const uint32_t hq = (thresh && !premasked) ? dropout_hash4(seed, i >> 2) : 0u;
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float d = dz_prime_q(dz[u][e], y[u][e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
+                // premasked: dZ already carries the activation derivative and the dropout mask (applied where the consumer's dgrad produced it)
+                float d = premasked ? dz[u][e] : dz_prime_q(dz[u][e], y[u][e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
                 d = d - k1[e] - (y[u][e] - mu[e]) * k2[e];
                 o[e] = sc[e] * d;
             }
@@ -540,10 +541,22 @@ int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int
 int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* scale,
                       const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
                       float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz,
-                      float* mean_dzy, float* gpart, int rows_per_group, int* gpart_slabs) {
+                      float* mean_dzy, float* gpart, int rows_per_group, int* gpart_slabs, const double* pre_stats, int pre_parts) {
     // gpart / gpart_slabs (nullable): ask for the per-group column sums of dY as a by-product; *gpart_slabs is set to the slab count
     // written per group ([G][slabs][C] floats, finish with launch_colsum_groups_fin) or to 0 when this shape does not fuse them
+    // pre_stats (nullable, [pre_parts][2][C]): dZ arrives MASKED and its column sums are already there (the consumer's dgrad left them:
+    // gemm.hip gemm_out_bs) -- no reduction pass, the apply pass only does the BatchNorm part
     if (gpart_slabs) *gpart_slabs = 0;
+    if (pre_stats) {
+        if (!(vec_ok(C, dZ, Y, dY) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)))
+            return MLSP_ERR_UNSUPPORTED;
+        const bool fuse_g = gpart && gpart_slabs && rows_per_group > 0 && rows_per_group % VROWS == 0 && rows_per_group / VROWS <= 16 && M % rows_per_group == 0;
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, pre_stats, pre_parts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy);
+        hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C, scale, shift, mean, invstd,
+                           training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, 0u, 1.f, seed, fuse_g ? gpart : (float*)nullptr, 1);
+        if (fuse_g) *gpart_slabs = rows_per_group / VROWS;
+        return mlsp_launch_status();
+    }
     float inv_keep = dropout_inv_keep8(p_drop);
     uint32_t th = drop_thresh(p_drop);
     int nparts = bn_stat_parts(M);
@@ -564,7 +577,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
     if (vec) {
         hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C,
                            scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th,
-                           inv_keep, seed, fuse_g ? gpart : (float*)nullptr);
+                           inv_keep, seed, fuse_g ? gpart : (float*)nullptr, 0);
         if (fuse_g) *gpart_slabs = rows_per_group / VROWS;
         return mlsp_launch_status();
     }
@@ -811,7 +824,7 @@ int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* d
                        shift, mean, invstd, act, slope, th, inv_keep, seed, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy);
     hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, (__bf16*)dY,
-                       M, C, scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed, (float*)nullptr);
+                       M, C, scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed, (float*)nullptr, 0);
     return mlsp_launch_status();
 }
 int launch_colsum_groups_b16(hipStream_t st, const void* X, int G, int rows_per_group, int C, float* out, float* scratch) {

@@ -83,6 +83,15 @@ struct GemmXf {
     const float* scale; const float* shift; int act; float slope; uint32_t thresh; float inv_keep; uint64_t seed; int ld; int which; int col;
 };
 
+// The previous layer's BatchNorm-backward reduction fused into a dgrad's output pass (gemm.hip GemmArgs bs_*; thin.hip): y / bn point at the
+// column of the dgrad's C column 0 (y: that layer's pre-BN output, row pitch ldy; bn: its scale | shift | mean | invstd rows, pitch bnld);
+// act / slope / thresh / inv_keep / seed: its activation and dropout; ld / col: row pitch of its matrix and C's column 0 in it; part:
+// [row panels of 128][2][stat_ld] fp64 sums of d' and d' * yhat, at C's column 0.
+struct GemmBs {
+    const float* y; int ldy; const float* bn; int bnld; int act; float slope; uint32_t thresh; float inv_keep; uint64_t seed; int ld; int col;
+    double* part; int stat_ld;
+};
+
 // Block-diagonal product in one GEMM launch (gemm.hip GemmArgs groups).  mode 1: output COLUMNS are grouped (forward: A = X + g * a_gs,
 // B = Bg[g] = W_g; dgrad alike); mode 2: output ROWS are grouped (wgrad: B = X + g * b_gs; A and C take the launch-wide row index).
 struct GemmGroups { int G, mode; long a_gs, b_gs; const float* Bg[4]; };

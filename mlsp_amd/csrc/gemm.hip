@@ -47,6 +47,12 @@ struct GemmArgs {
     // [g * gtiles, (g + 1) * gtiles) form group g, whose A columns start at A + g * a_gs and whose B operand is Bg[g]; C, bias and
     // the statistics keep the launch-wide column index.  gmode 2 (wgrad): ROW tiles are grouped, B = B + g * b_gs.
     int gmode, gtiles; long a_gs, b_gs; const float* Bg[4];
+    // bs_y != null (a dgrad whose result C is the gradient w.r.t. the ACTIVATED output of the previous layer, gemm_split_kernel): the output
+    // pass multiplies C by that layer's activation derivative and dropout mask -- from its pre-BatchNorm output bs_y, same coordinates as C,
+    // row pitch bs_ldy -- stores the MASKED gradient d', and leaves per-row-panel column sums of d' and d' * yhat in stat_part: the
+    // streaming reduction of that layer's BatchNorm backward happens here, where the gradient is produced.  bs_bn: its scale | shift |
+    // mean | invstd rows (pitch bs_bnld) at C's column 0; bs_ld / bs_col: row pitch of its matrix and C's column 0 in it (dropout stream).
+    const float* bs_y; int bs_ldy; const float* bs_bn; int bs_bnld; float bs_slope; uint32_t bs_thresh; float bs_ik; uint32_t bs_xH; int bs_ld4; int bs_col;
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][stat_ld] (BN batch statistics)
     int stat_ld;                    // columns of a statistics row (N, or the width of the wider matrix C is a column slice of)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
@@ -180,9 +186,68 @@ __device__ __forceinline__ void gemm_out_fast(const GemmArgs& p, f32x16 (&acc)[2
         }
 }
 
+// ---- output pass of a dgrad with the previous layer's BatchNorm-backward reduction fused in (GemmArgs bs_*) --------------------------
+// Per element: d = dz; dropout (byte of the quad's hash: the lanes of an aligned column quad share it -- each computes the hashes of four
+// of its sixteen rows and takes the others from its neighbours with a DPP quad broadcast); d *= slope where the activation's argument
+// a = y * scale + shift is not positive -- the same expressions, in the same order, as multi_dz_prime / dz_prime_q of the streaming
+// passes this replaces, so the stored d' is bit-identical; cs += d', cq += d' * (y - mean) * invstd in fp32 over the wave's rows, fp64
+// across waves and panels (the streaming reduction summed in fp64 throughout: the sums agree to ~1e-7 relative).
+template <int WM>
+__device__ __forceinline__ void gemm_out_bs(const GemmArgs& p, f32x16 (&acc)[2][2], float* Cw, const float* Yw, int colw, int row0, int l31, int h,
+                                            float (&cs)[2], float (&cq)[2]) {
+    const int ldc4 = p.ldc * 4, ldy4 = p.bs_ldy * 4;
+    const int voff = 4 * h * ldc4 + 4 * l31, voffy = 4 * h * ldy4 + 4 * l31;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cw, 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Yw, 0, 0x7ffffff0, MLSP_BUF_FLAGS);
+    const float slope = p.bs_slope, ik = p.bs_ik;
+    const uint32_t th = p.bs_thresh, xH = p.bs_xH;
+    const int sh8 = 8 * (l31 & 3);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = colw + j * 32 + l31;                                // column of C (launch-wide)
+        const float sc = p.bs_bn[col], sf = p.bs_bn[p.bs_bnld + col], mu = p.bs_bn[2 * p.bs_bnld + col], is = p.bs_bn[3 * p.bs_bnld + col];
+        const uint32_t qcol = (uint32_t)(p.bs_col + col) >> 2;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            float yv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                yv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, voffy, (i * 32 + (r & 3) + 8 * (r >> 2)) * ldy4 + j * 128, 0));
+            uint32_t hs[4] = {0u, 0u, 0u, 0u};
+            if (th) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    hs[t] = mix32(((uint32_t)(row0 + i * 32 + (l31 & 3) + 8 * t + 4 * h) * (uint32_t)p.bs_ld4 + qcol) ^ xH);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float d = acc[i][j][r];
+                if (th) {
+                    const uint32_t own = hs[r >> 2];
+                    const uint32_t hq = (r & 3) == 0 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0x00, 0xf, 0xf, false)
+                                      : (r & 3) == 1 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0x55, 0xf, 0xf, false)
+                                      : (r & 3) == 2 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xaa, 0xf, 0xf, false)
+                                                     : (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xff, 0xf, 0xf, false);
+                    d = ((hq >> sh8) & 255u) >= th ? d * ik : 0.f;
+                }
+                const float a = fmaf(yv[r], sc, sf);
+                if (!(a > 0.f)) d *= slope;
+                cs[j] += d;
+                cq[j] = fmaf(d, (yv[r] - mu) * is, cq[j]);
+                acc[i][j][r] = d;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float vv = acc[i][j][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv), rs, voff, (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4 + j * 128, 0);
+            }
+        }
+    }
+}
+
 // ---- epilogue shared by the fp32 and the bf16-operand kernels --------------------------------------------------------
 // acc: this wave's WM x 2 MFMA tiles of the block tile at (m0, n0); smem: the operand tiles, dead by now (scratch).
-template <int WM, bool FAST, bool CBF = false>
+template <int WM, bool FAST, bool CBF = false, bool BSOK = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* smem, int tm, int m0, int n0, int split,
                                               int tid, int l31, int h, int wm, int wn) {
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -191,7 +256,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
     const bool epi = (p.nsplit == 1);
     float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
     // interior fp32 tiles whose rows share one per-cloud bias row: the lean output pass (launch_gemm sets p.fast_out)
-    if (FAST && !CBF && p.fast_out) {
+    if (BSOK && p.bs_y) {               // (launch_gemm: interior tiles, one K pass, no bias / beta; statistics rows in stat_part)
+        float* Cw = Cout + (size_t)(m0 + wm * (32 * WM)) * p.ldc + n0 + wn * 64;
+        const float* Yw = p.bs_y + (size_t)(m0 + wm * (32 * WM)) * p.bs_ldy + n0 + wn * 64;
+        gemm_out_bs<WM>(p, acc, Cw, Yw, n0 + wn * 64, m0 + wm * (32 * WM), l31, h, cs, cq);
+    } else if (FAST && !CBF && p.fast_out) {
         float bv[2] = {0.f, 0.f}, gv[2] = {0.f, 0.f};
         if (epi && p.bias) { bv[0] = p.bias[n0 + wn * 64 + l31]; bv[1] = p.bias[n0 + wn * 64 + 32 + l31]; }
         const bool gb = epi && p.gbias;
@@ -1031,7 +1100,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
 #undef SX_XF_HASH_A
 #undef SX_XF_HASH_B
 #undef SX_XF_NEXT
-    gemm_epilogue<WM, true, false>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
+    gemm_epilogue<WM, true, false, (!TA && !TB && XF == 0)>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 }
 
 // the calling entry point's `precision` argument for the duration of that call (common.h GemmPrecisionScope): 0: fp32 MFMA (exact fp32
@@ -1329,7 +1398,8 @@ extern "C" int mlsp_profile_split_kinds(double* out) {
 int launch_skinny_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                        float* C, int ldc, const float* bias);
 int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                     int ldc, const float* bias, float* slab, size_t slab_floats, const GemmXf* xf);
+                     int ldc, const float* bias, float* slab, size_t slab_floats, const GemmXf* xf, const GemmBs* bs = nullptr);
+int thin_bs_parts(int M, int N, int K);
 bool thin_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which);
 
 // Can this contraction stage `which` (1: A [M][K] row-major, 2: B [K][N] k-major) through the operand transform?  Interior tiles,
@@ -1349,6 +1419,14 @@ bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, in
     return vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0) && (long)(ta ? M : K) * lda * 4 < (1L << 30) && (long)K * ldb * 4 < (1L << 30);
 }
 
+// Row panels (of 128 rows) a dgrad dX [M][N] = dY [M][K] W with the fused statistics pass (GemmBs) writes partial sums for; 0: this
+// shape does not take the fused pass (the caller runs the streaming reduction instead).  Split kernel, 128-row interior tiles, one K pass.
+int gemm_bs_parts(int M, int N, int K, int lda, int ldb, int ldc) {
+    if (tl_call_precision != 2 || M % 128 || N % BN || K % BK || lda % 4 || ldb % 4 || ldc % 4) return 0;
+    if (gemm_pick_split(M, N, K) != 1 || gemm_pick_bm(M, N, K) != 128 || !gemm_split_pays(M, N, K / BK)) return 0;
+    return M / 128;
+}
+
 // will a transform launch of this shape run on gemm_split_kernel (the only kernel that transforms inside a block-diagonal launch)?
 bool gemm_xf_on_split(bool ta, bool tb, int M, int N, int K, int which) {
     if (tl_call_precision != 2) return false;
@@ -1359,7 +1437,8 @@ bool gemm_xf_on_split(bool ta, bool tb, int M, int N, int K, int which) {
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B,
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                 size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
-                int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0, const GemmGroups* grp = nullptr) {
+                int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0, const GemmGroups* grp = nullptr,
+                const GemmBs* bs = nullptr) {
     // grp (nullable): block-diagonal product in one launch (GemmArgs groups; M / N are the LAUNCH's dimensions, K one group's).
     // Only on the interior-tile fp32 kernel: MLSP_ERR_UNSUPPORTED otherwise (nothing launched; the caller launches group by group).
     // stat_ld (0: N): C is a column slice of a [M][stat_ld] matrix whose BatchNorm statistics are taken as ONE vector (multi.hip):
@@ -1371,11 +1450,11 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (xf && ((xf->ld & 3) || (xf->col & 3) || (((uintptr_t)xf->scale | (uintptr_t)xf->shift) & 15) || (double)(xf->which == 1 ? M : K) * xf->ld >= 17179869184.0))
         return MLSP_ERR_UNSUPPORTED;
     if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && (!xf || tl_call_precision != 1)) {
-        const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats, xf);
+        const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats, xf, bs);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
     if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
-    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && !bias && C && gemm_fold64(ta, tb, M, N, K, lda, ldb) &&
+    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && !bs && !bias && C && gemm_fold64(ta, tb, M, N, K, lda, ldb) &&
         (((uintptr_t)A | (uintptr_t)B) & 15) == 0) {
         const size_t inner = gemm_slab_floats(128, 128, K / 2);
         if (slab && slab_floats >= inner + 128 * 128) {
@@ -1393,7 +1472,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         }
     }
     // per-cloud layers (<= 32 rows, or a 32-deep wgrad): one-pass skinny kernels, no split-K slab (skinny.hip)
-    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
+    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && !bs && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
         const int rc = launch_skinny_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
@@ -1410,6 +1489,16 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
     p.stat_part = stat_part; p.stat_ld = stat_ld > 0 ? stat_ld : N;
     p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
+    p.bs_y = nullptr; p.bs_ldy = 0; p.bs_bn = nullptr; p.bs_bnld = 0; p.bs_slope = 1.f; p.bs_thresh = 0; p.bs_ik = 1.f; p.bs_xH = 0; p.bs_ld4 = 0; p.bs_col = 0;
+    if (bs) {
+        if (ta || tb || xf || bias || gbias || accumulate || stat_part || sel_gamma || !bs->y || !bs->bn || !bs->part || (bs->ld & 3) || (bs->col & 3) ||
+            gemm_bs_parts(M, N, K, lda, ldb, ldc) == 0 || (double)M * bs->ld >= 17179869184.0)
+            return MLSP_ERR_UNSUPPORTED;
+        p.bs_y = bs->y; p.bs_ldy = bs->ldy; p.bs_bn = bs->bn; p.bs_bnld = bs->bnld;
+        p.bs_slope = bs->act == 0 ? 1.f : bs->act == 1 ? 0.f : bs->slope; p.bs_thresh = bs->thresh; p.bs_ik = bs->inv_keep;
+        p.bs_xH = mix32_host((uint32_t)bs->seed) ^ (uint32_t)(bs->seed >> 32) * 0x9e3779b9U; p.bs_ld4 = bs->ld / 4; p.bs_col = bs->col;
+        p.stat_part = bs->part; p.stat_ld = bs->stat_ld;
+    }
     p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0; p.x_col = 0;
     if (xf) {
         p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_thresh = xf->thresh;

@@ -17,7 +17,8 @@
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
                 double* stat_part, const float* sel_gamma, float* sel_val, int* sel_row, bool accumulate, const GemmXf* xf, int stat_ld,
-                const GemmGroups* grp = nullptr);
+                const GemmGroups* grp = nullptr, const GemmBs* bs = nullptr);
+int gemm_bs_parts(int M, int N, int K, int lda, int ldb, int ldc);
 int gemm_panel_rows(int M, int N, int K);
 bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which);
 bool gemm_xf_on_split(bool ta, bool tb, int M, int N, int K, int which);
@@ -140,13 +141,15 @@ __global__ __launch_bounds__(256) void multi_bwd_reduce_kernel(const float* __re
 __global__ __launch_bounds__(256) void multi_bwd_apply_kernel(const float* __restrict__ dZ, const float* __restrict__ Y, float* __restrict__ dY,
                                                               int M, int C, int rpb, const float* __restrict__ bn, const float* __restrict__ chan,
                                                               const float* __restrict__ mean_dz, const float* __restrict__ mean_dzy,
-                                                              uint32_t thresh, float inv_keep, uint64_t seed) {
+                                                              uint32_t thresh, float inv_keep, uint64_t seed, int premasked) {
+    // premasked: dZ already carries the activation derivative and the dropout mask (the consumer's dgrad applied them where it produced
+    // the gradient: gemm.hip gemm_out_bs / thin.hip): only the BatchNorm part is left
     const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
     const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
     if (rg >= nrg) return;
     const f32x4 sc = *(const f32x4*)(bn + c), sh = *(const f32x4*)(bn + C + c);
     const f32x4 sl = *(const f32x4*)(chan + c), dr = *(const f32x4*)(chan + C + c);
-    const bool anyd = thresh && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f);
+    const bool anyd = !premasked && thresh && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f);
     f32x4 mu = {0, 0, 0, 0}, k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0};
     if (mean_dz) {
         mu = *(const f32x4*)(bn + 2 * C + c);
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void multi_bwd_apply_kernel(const float* __res
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float d = multi_dz_prime(dz[u][e], y[u][e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
+                float d = premasked ? dz[u][e] : multi_dz_prime(dz[u][e], y[u][e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
                 d = d - k1[e] - (y[u][e] - mu[e]) * k2[e];
                 o[e] = sc[e] * d;
             }
@@ -370,13 +373,39 @@ int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs
     return mlsp_launch_status();
 }
 
+// Row panels the fused statistics pass of mlsp_multimlp_bwd_f32(in_stats != NULL) writes: M / 128 when EVERY segment's dgrad (single or
+// block-diagonal, as the backward will launch them) runs on a kernel with that pass, else 0.
+int mlsp_multimlp_bwd_stats_parts(int M, const mlsp_seg_t* segs, int nseg, int ldx, int lddx, int precision) {
+    if (precision < 0 || precision > 2 || !segs || nseg < 1 || nseg > 8) return 0;
+    GemmPrecisionScope prec_scope_(precision);
+    int Ctot = 0;
+    for (int s = 0; s < nseg; ++s) Ctot += segs[s].Cout;
+    static const float dummy = 0.f;
+    int run = 1;
+    for (int s = 0; s < nseg; s += run) {
+        run = multi_group_run(&dummy, ldx, M, segs, nseg, s);
+        for (int t = 0; t < s; ++t)
+            if (!(segs[t].x_col + segs[t].Cin <= segs[s].x_col || segs[s].x_col + run * segs[s].Cin <= segs[t].x_col)) return 0;     // overlapping inputs: beta = 1
+        // (the backward may launch the run as one block-diagonal product or segment by segment: both shapes must take the pass)
+        if (gemm_bs_parts(M, run * segs[s].Cin, segs[s].Cout, Ctot, segs[s].ldw, lddx) != M / 128 ||
+            gemm_bs_parts(M, segs[s].Cin, segs[s].Cout, Ctot, segs[s].ldw, lddx) != M / 128) return 0;
+    }
+    return M / 128;
+}
+
 int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const mlsp_seg_t* segs, int nseg, const mlsp_defer_t* in, const float* Y,
                           const float* bn_save, int training, const float* chan, float p_drop, uint64_t seed, float* dX, int lddx,
-                          float* const* dW, float* dbias, float* dgamma, float* dbeta, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          float* const* dW, float* dbias, float* dgamma, float* dbeta, double* in_stats, const double* pre_stats, int pre_parts,
+                          int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+    // in_stats (consumer role, needs `in`): every segment's input gradient is stored MASKED by its producer's activation derivative /
+    // dropout and the producer's BatchNorm-backward column sums are left in in_stats [M / 128][2][in->ld] (gemm.hip gemm_out_bs).
+    // pre_stats (producer role): dZ arrives masked with its sums in pre_stats [pre_parts][2][Ctot]: no reduction pass here.
     PREC_SCOPE(precision);
     int Ctot, xw;
     MCHECK(multi_check(X, ldx, M, segs, nseg, Ctot, xw));
     if (!dZ || !Y || !bn_save || !chan || !dW || !dgamma || !dbeta || (dX && lddx < xw)) return MLSP_ERR_ARG;
+    if (in_stats && (!in || !dX)) return MLSP_ERR_ARG;
+    if (pre_stats && pre_parts <= 0) return MLSP_ERR_ARG;
     if (!mlsp_multimlp_supported(M, segs, nseg, precision)) return MLSP_ERR_UNSUPPORTED;
     if ((((uintptr_t)Y | (uintptr_t)dZ | (uintptr_t)chan | (uintptr_t)bn_save) & 15) != 0) return MLSP_ERR_UNSUPPORTED;
     if (in) for (int s = 0; s < nseg; ++s) if (!multi_defer_ok(in[s], segs[s])) return MLSP_ERR_ARG;
@@ -412,11 +441,15 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
     const float pd = training ? p_drop : 0.f;
     const uint32_t th = dropout_thresh8(pd);
     const float ik = dropout_inv_keep8(pd);
-    hipLaunchKernelGGL(multi_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, Ctot, bn_save, chan, th, ik, seed, part);
-    MCHECK(launch_bn_bwd_finalize(st, part, nparts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy));
+    if (pre_stats) {
+        MCHECK(launch_bn_bwd_finalize(st, pre_stats, pre_parts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy));
+    } else {
+        hipLaunchKernelGGL(multi_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, Ctot, bn_save, chan, th, ik, seed, part);
+        MCHECK(launch_bn_bwd_finalize(st, part, nparts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy));
+    }
     const int rpb = multi_rows_per_block(M, Ctot);
     hipLaunchKernelGGL(multi_bwd_apply_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, st, dZ, Y, dY, M, Ctot, rpb, bn_save, chan,
-                       training ? mean_dz : (const float*)nullptr, mean_dzy, th, ik, seed);
+                       training ? mean_dz : (const float*)nullptr, mean_dzy, th, ik, seed, pre_stats ? 1 : 0);
     MCHECK(mlsp_launch_status());
     int ycol = 0;
     for (int s = 0; s < nseg; s += run[s]) {
@@ -434,8 +467,16 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
                 acc |= same;
             }
             if (acc && G > 1) return MLSP_ERR_UNSUPPORTED;
+            GemmBs bs_s; const GemmBs* bs = nullptr;
+            if (in_stats) {
+                const mlsp_defer_t& d = in[s];
+                bs_s = {X + g.x_col, ldx, d.bn_save + d.col, d.ld, d.act, d.slope, dropout_thresh8(d.p_drop), dropout_inv_keep8(d.p_drop), d.seed,
+                        d.ld, d.col, in_stats + d.col, d.ld};
+                bs = &bs_s;
+                for (int t = 1; t < G; ++t) if (!multi_defer_same(in[s], in[s + t])) return MLSP_ERR_UNSUPPORTED;     // (one producer description per launch)
+            }
             MCHECK(launch_gemm(st, false, false, M, G * g.Cin, g.Cout, dY + ycol, Ctot, g.W, g.ldw, dX + g.x_col, lddx, nullptr, nullptr, 0, slab, sf,
-                               nullptr, nullptr, nullptr, nullptr, acc, nullptr, 0, G > 1 ? &grp : nullptr));
+                               nullptr, nullptr, nullptr, nullptr, acc, nullptr, 0, G > 1 ? &grp : nullptr, bs));
         }
         const float* Xs = X;
         GemmXf xf_s; const GemmXf* xf = nullptr;

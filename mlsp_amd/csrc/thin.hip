@@ -15,20 +15,32 @@
 // ---------------------------------------------------------------------------------------------- small K
 // thread = (row, column quad); lanes of a wave cover consecutive quads of a row (16-byte coalesced stores), the K values of the row
 // are wave-broadcast loads.  B is staged once per workgroup as Bs[k][n].
-template <bool TB>
-__global__ __launch_bounds__(256) void thin_smallk_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+// BS (the dgrad of a head's 3- / 16-channel output layer: C is the gradient w.r.t. the previous layer's ACTIVATED output): the result is
+// multiplied by that layer's activation derivative and dropout mask (BsDev: its pre-BN output and parameters at C's column 0) before it
+// is stored, and the block -- 128 rows -- leaves its column sums of d' and d' * yhat in part [block][2][stat_ld]: see gemm_out_bs.
+struct BsDev { const float* y; int ldy; const float* bn; int bnld; float slope, inv_keep; uint32_t thresh, xH; int ld4, col; double* part; int stat_ld; };
+template <bool TB, bool BS = false, int NT = 256>
+__global__ __launch_bounds__(NT) void thin_smallk_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                           float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
-                                                          int K, int rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float Bs[];          // [K][N]
+                                                          int K, int rows_per_block, BsDev bs) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];          // [K][N]  (BS: + fp64 reduction scratch behind it)
     const int tid = threadIdx.x;
-    for (int i = tid; i < K * N; i += 256) {
+    for (int i = tid; i < K * N; i += NT) {
         const int k = i / N, n = i - k * N;
         Bs[i] = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
     }
     __syncthreads();
     const int nq = N >> 2;
     const int row0 = blockIdx.x * rows_per_block;
-    for (int i = tid; i < rows_per_block * nq; i += 256) {
+    // BS: a thread keeps ONE column quad (NT % nq == 0): its scale / shift / mean / invstd and its running sums live in registers
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sf = sc, mu = sc, is = sc;
+    double ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+    if (BS) {
+        const int c = 4 * (tid % nq);
+        sc = *(const f32x4*)(bs.bn + c); sf = *(const f32x4*)(bs.bn + bs.bnld + c);
+        mu = *(const f32x4*)(bs.bn + 2 * bs.bnld + c); is = *(const f32x4*)(bs.bn + 3 * bs.bnld + c);
+    }
+    for (int i = tid; i < rows_per_block * nq; i += NT) {
         const int r = row0 + i / nq, q = i % nq;
         if (r >= M) break;
         const float* a = A + (size_t)r * lda;
@@ -43,7 +55,38 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(const float* __restric
             const f32x4 bb = *(const f32x4*)(bias + 4 * q);
             acc = acc + bb;
         }
+        if (BS) {
+            const f32x4 y = *(const f32x4*)(bs.y + (size_t)r * bs.ldy + 4 * q);
+            const uint32_t hq = bs.thresh ? mix32(((uint32_t)r * (uint32_t)bs.ld4 + ((uint32_t)(bs.col + 4 * q) >> 2)) ^ bs.xH) : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = acc[e];
+                if (bs.thresh) d = ((hq >> (8 * e)) & 255u) >= bs.thresh ? d * bs.inv_keep : 0.f;
+                const float av = fmaf(y[e], sc[e], sf[e]);
+                if (!(av > 0.f)) d *= bs.slope;
+                ps[e] += d; pq[e] += (double)d * ((y[e] - mu[e]) * is[e]);
+                acc[e] = d;
+            }
+        }
         *(f32x4*)(C + (size_t)r * ldc + 4 * q) = acc;
+    }
+    if (BS) {       // the block's column sums: the NT / nq threads of a quad, in thread order, through LDS
+        __syncthreads();
+        double* red = (double*)(Bs + ((K * N + 1) & ~1));               // [NT][8]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = ps[e]; red[tid * 8 + 4 + e] = pq[e]; }
+        __syncthreads();
+        if (tid < nq) {
+            double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int g2 = 0; g2 < NT / nq; ++g2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s8[e] += red[(g2 * nq + tid) * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bs.part[((size_t)blockIdx.x * 2 + 0) * bs.stat_ld + 4 * tid + e] = s8[e];
+                bs.part[((size_t)blockIdx.x * 2 + 1) * bs.stat_ld + 4 * tid + e] = s8[4 + e];
+            }
+        }
     }
 }
 
@@ -183,8 +226,12 @@ size_t thin_tn_slab_floats(int M, int N, int K) {
 // Returns MLSP_ERR_UNSUPPORTED when the shape is not thin (the caller continues with the MFMA kernels).
 // xf (nullable): operand transform (common.h GemmXf); which == 1: A of the small-N kernel, which == 2: the wide B of the A^T B kernel.
 // Any other combination with a transform: MLSP_ERR_UNSUPPORTED.
+// row panels (128 rows each) the small-K kernel writes partial sums for under a GemmBs; 0: not this kernel's shape
+int thin_bs_parts(int M, int N, int K) {
+    return (K <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && M >= 1024 && 256 % (N / 4) == 0 && M % 128 == 0) ? M / 128 : 0;
+}
 int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                     int ldc, const float* bias, float* slab, size_t slab_floats, const GemmXf* xf) {
+                     int ldc, const float* bias, float* slab, size_t slab_floats, const GemmXf* xf, const GemmBs* bs) {
     auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
     XfDev xd = {nullptr, nullptr, 1.f, 1.f, 0u, 0u, 0, 0};
     if (xf) {
@@ -194,13 +241,30 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
     if (!xf && !ta && K <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && M >= 1024 && ldc % 4 == 0 && al16(C) && al16(bias)) {
         const int nq = N / 4;
         if (256 % nq) return MLSP_ERR_UNSUPPORTED;
-        const int rpb = 4 * 256 / nq;                                     // four passes of the workgroup per block
-        const size_t lds = (size_t)K * N * sizeof(float);
+        BsDev bd = {nullptr, 0, nullptr, 0, 1.f, 1.f, 0u, 0u, 0, 0, nullptr, 0};
+        if (bs) {
+            if (thin_bs_parts(M, N, K) == 0 || !bs->y || !bs->bn || !bs->part || (bs->ld & 3) || (bs->col & 3) || (bs->ldy & 3) || (bs->bnld & 3) ||
+                !al16(bs->y) || !al16(bs->bn) || (double)M * bs->ld >= 17179869184.0) return MLSP_ERR_UNSUPPORTED;
+            bd.y = bs->y; bd.ldy = bs->ldy; bd.bn = bs->bn; bd.bnld = bs->bnld; bd.slope = bs->act == 0 ? 1.f : bs->act == 1 ? 0.f : bs->slope;
+            bd.inv_keep = bs->inv_keep; bd.thresh = bs->thresh; bd.xH = mix32_host((uint32_t)bs->seed) ^ (uint32_t)(bs->seed >> 32) * 0x9e3779b9U;
+            bd.ld4 = bs->ld / 4; bd.col = bs->col; bd.part = bs->part; bd.stat_ld = bs->stat_ld;
+        }
+        const int rpb = bs ? 128 : 4 * 256 / nq;                          // four passes of the workgroup per block (fused statistics: one 128-row panel)
+        // (fused statistics: one block per 128-row panel -- 1024 threads, so that M / 128 blocks still fill the chip)
+        const size_t lds = (size_t)((K * N + 1) & ~1) * sizeof(float) + (bs ? 1024 * 8 * sizeof(double) : 0);
         const dim3 grid((M + rpb - 1) / rpb);
-        if (tb) hipLaunchKernelGGL((thin_smallk_kernel<true>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb);
-        else hipLaunchKernelGGL((thin_smallk_kernel<false>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb);
+        if (bs) {
+            if (lds > 64 * 1024) {
+                hipError_t e_ = mlsp_lds_limit(tb ? (const void*)thin_smallk_kernel<true, true, 1024> : (const void*)thin_smallk_kernel<false, true, 1024>, lds);
+                if (e_ != hipSuccess) return (int)e_;
+            }
+            if (tb) hipLaunchKernelGGL((thin_smallk_kernel<true, true, 1024>), grid, dim3(1024), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb, bd);
+            else hipLaunchKernelGGL((thin_smallk_kernel<false, true, 1024>), grid, dim3(1024), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb, bd);
+        } else if (tb) hipLaunchKernelGGL((thin_smallk_kernel<true, false>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb, bd);
+        else hipLaunchKernelGGL((thin_smallk_kernel<false, false>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb, bd);
         return mlsp_launch_status();
     }
+    if (bs) return MLSP_ERR_UNSUPPORTED;
     if ((!xf || xf->which == 1) && !ta && N <= 16 && K % 4 == 0 && K >= 64 && K <= 1024 && M >= 1024 && lda % 4 == 0 && al16(A)) {
         const size_t lds = (size_t)K * (N + (xf ? 2 : 0)) * sizeof(float);
         int blocks = (M + 31) / 32;

@@ -528,7 +528,7 @@ class _MultiMLP(Function):
     activation pass is left to its consumers: the Function returns Y (pre-BN) in place of Z."""
 
     @staticmethod
-    def forward(ctx, X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, in_defs, defer_out, *wb):
+    def forward(ctx, X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, in_defs, defer_out, in_stats, out_stats, *wb):
         lib = _lib.load()
         prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         n = len(x_cols)
@@ -557,6 +557,15 @@ class _MultiMLP(Function):
         ctx.save_for_backward(X, Y, bn_save, chan, *Ws)
         ctx.cfg = (tuple(x_cols), bool(training), p, seed, [b is not None for b in bs])
         ctx.in_defs = in_defs
+        ctx.in_stats, ctx.out_stats = None, (out_stats if defer_out else None)       # fused BatchNorm-backward sums: see _PointMLP.forward
+        if in_stats is not None and in_defs is not None:
+            parts = 0
+            if _FUSE_BWD_STATS and ctx.needs_input_grad[0]:
+                key = ("m", M, X.stride(0), X.shape[1], prec) + tuple((xc, w.shape[0], w.shape[1], w.stride(0), b is not None) for xc, w, b in zip(x_cols, Ws, bs))
+                parts = _stats_parts(key, lambda: lib.mlsp_multimlp_bwd_stats_parts(M, segs, n, X.stride(0), X.shape[1], prec))
+            for d, w in zip(in_defs, Ws):
+                in_stats.promise(d[2], w.shape[1], parts)
+            ctx.in_stats = in_stats
         ctx.mark_non_differentiable(bn_save)
         ctx.set_materialize_grads(False)
         return (Y.view_as(Y) if defer_out else Z), bn_save
@@ -567,7 +576,7 @@ class _MultiMLP(Function):
         x_cols, training, p, seed, has_b = ctx.cfg
         n = len(x_cols)
         if dZ is None:
-            return (None,) * (14 + 2 * n)
+            return (None,) * (16 + 2 * n)
         lib = _lib.load()
         X, Y, bn_save, chan = ctx.saved_tensors[:4]
         Ws = ctx.saved_tensors[4:]
@@ -596,15 +605,22 @@ class _MultiMLP(Function):
         dgamma = torch.empty((Ctot,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((Ctot,), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
+        pre = ctx.out_stats.take() if ctx.out_stats is not None else None
+        pre_ptr, pre_n = (pre[0].data_ptr(), pre[1]) if pre is not None else (None, 0)
+        ins = None
+        if ctx.in_stats is not None and dX is not None and ctx.in_stats.agreed():
+            ins = ctx.in_stats.buffer(dev)
+            for _ in range(n - 1):
+                ctx.in_stats.buffer(dev)            # (one delivery per promised segment: this call writes all of them)
         _lib.check(lib.mlsp_multimlp_bwd_f32(dZ.data_ptr(), X.data_ptr(), X.stride(0), M, segs, n, defs, Y.data_ptr(), bn_save.data_ptr(),
                                              int(training), chan.data_ptr(), p, seed, _lib.ptr(dX), dX.stride(0) if dX is not None else 0,
-                                             dwp, _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()),
-                   "mlsp_multimlp_bwd_f32")
+                                             dwp, _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(), _lib.ptr(ins), pre_ptr, pre_n, ctx.prec, ws, wsn,
+                                             _lib.stream()), "mlsp_multimlp_bwd_f32")
         dbs, o = [], 0
         for w, hb in zip(Ws, has_b):
             dbs.append(dbias[o:o + w.shape[0]] if hb else None)
             o += w.shape[0]
-        return (dX, dgamma, dbeta) + (None,) * 11 + tuple(dWs) + tuple(dbs)
+        return (dX, dgamma, dbeta) + (None,) * 13 + tuple(dWs) + tuple(dbs)
 
 
 _chan_cache = {}
@@ -645,17 +661,18 @@ def multimlp(X, segs, gamma, beta, run_mean, run_var, chan, training=True, p_dro
     bs = [s[2] for s in segs]
     any_drop = training and p_drop > 0
     seed = _next_seed() if any_drop else 0
-    in_defs = None
+    in_defs = in_stats = None
     if isinstance(X, DeferredAct):
         in_defs = tuple(X.desc(xc, w.shape[1]) for xc, w in zip(x_cols, Ws))
         assert X.col == 0 and X.y.shape[1] == X.ld, "multimlp reads column slices of the producer's whole matrix"
-        X = X.y
+        in_stats, X = X.stats, X.y
     defer_out = bool(chain) and spec is not None and _can_defer(X.shape[0], X.dtype)
+    out_stats = BwdStats(sum(w.shape[0] for w in Ws)) if defer_out else None
     out, bn_save = _MultiMLP.apply(X, gamma, beta, run_mean, run_var, chan, x_cols, training, p_drop, seed, momentum, eps, in_defs, defer_out,
-                                   *Ws, *bs)
+                                   in_stats, out_stats, *Ws, *bs)
     if defer_out:
         p = float(p_drop) if training else 0.0
-        return DeferredAct(out, bn_save, out.shape[1], 0, tuple((c, f, bool(d) and p > 0) for c, f, d in spec), p, seed)
+        return DeferredAct(out, bn_save, out.shape[1], 0, tuple((c, f, bool(d) and p > 0) for c, f, d in spec), p, seed, out_stats)
     return out
 
 
@@ -812,6 +829,53 @@ def tnet_edge_supported(W1, W2, k):
 _DEFER_CHAINS = os.environ.get("MLSP_DEFERRED_ACT", "1") not in ("0", "")
 
 
+# BatchNorm-backward sums of a deferred layer, produced by its consumers' dgrads (csrc/gemm.hip gemm_out_bs, thin.hip): MLSP_BWD_STATS_FUSED=0
+# restores the streaming reduction pass (an A/B switch, read once).
+_FUSE_BWD_STATS = os.environ.get("MLSP_BWD_STATS_FUSED", "1") not in ("0", "")
+
+
+class BwdStats:
+    """Hand-off between the backward passes of a deferred layer (the PRODUCER of a pre-BN matrix [M, ld]) and of its consumers.  The
+    gradient w.r.t. the producer's activated output is written by the consumers' dgrads; each of them can apply the producer's activation
+    derivative and dropout mask in that launch and leave the producer's per-panel column sums here, so the producer needs no reduction
+    pass.  All or nothing: every consumer `promise`s its column range at forward time (with the number of 128-row panels its dgrad
+    would write, 0 = it cannot); only if the promises tile [0, ld) exactly with one common panel count do the consumers do it
+    (`agreed`), and the producer uses the sums only if every range was `deliver`ed in the same backward pass."""
+    __slots__ = ("ld", "promised", "part", "task", "delivered", "_ok")
+
+    def __init__(self, ld):
+        self.ld, self.promised, self.part, self.task, self.delivered, self._ok = int(ld), [], None, None, 0, None
+
+    def promise(self, col, width, parts):
+        self.promised.append((int(col), int(width), int(parts)))
+        self._ok = None
+
+    def agreed(self):
+        if self._ok is None:
+            pr = sorted(self.promised)
+            ok = bool(pr) and pr[0][0] == 0 and pr[-1][0] + pr[-1][1] == self.ld and pr[0][2] > 0 and len({p[2] for p in pr}) == 1
+            ok = ok and all(a[0] + a[1] == b[0] for a, b in zip(pr, pr[1:]))
+            self._ok = ok
+        return self._ok
+
+    def buffer(self, device):
+        """[parts, 2, ld] fp64 partial rows of the current backward pass (every column is written by exactly one consumer)"""
+        task = torch._C._current_graph_task_id()
+        if self.part is None or self.task != task:
+            self.part = torch.empty((self.promised[0][2], 2, self.ld), dtype=torch.float64, device=device)
+            self.task, self.delivered = task, 0
+        self.delivered += 1
+        return self.part
+
+    def take(self):
+        """producer side: (partial rows, panel count) when every consumer delivered in THIS backward pass, else None"""
+        if self.part is None or self.task != torch._C._current_graph_task_id() or self.delivered != len(self.promised) or not self.agreed():
+            self.part = self.task = None
+            return None
+        part, self.part, self.task = self.part, None, None
+        return part, part.shape[0]
+
+
 class DeferredAct:
     """Output of a chained Linear+BN+act layer (pointmlp / multimlp with chain=True, fp32 storage) whose BatchNorm scale / shift,
     activation and dropout have NOT been applied yet.  `y`: columns [col, col + width) of the producer's pre-BN matrix [M, ld] -- an
@@ -819,10 +883,11 @@ class DeferredAct:
     `bn_save` [4, ld]: the producer's scale | shift | mean | invstd; `spec`: ((width, negative-side factor, dropout on), ...) covering
     the columns of `y` in order (factor 0 = ReLU, 0.2 = LeakyReLU(0.2), 1 = no activation); `p`, `seed`: the producer's dropout stream.
     Legal consumers: pointmlp (a slice with ONE spec entry), multimlp (segments inside one spec entry each), split_columns_shared."""
-    __slots__ = ("y", "bn_save", "ld", "col", "spec", "p", "seed")
+    __slots__ = ("y", "bn_save", "ld", "col", "spec", "p", "seed", "stats")
 
-    def __init__(self, y, bn_save, ld, col, spec, p, seed):
+    def __init__(self, y, bn_save, ld, col, spec, p, seed, stats=None):
         self.y, self.bn_save, self.ld, self.col, self.spec, self.p, self.seed = y, bn_save, int(ld), int(col), tuple(spec), float(p), int(seed)
+        self.stats = stats                   # BwdStats of the producer (None: its backward reduces by itself)
         assert sum(w for w, _, _ in self.spec) == y.shape[1], (self.spec, y.shape)
 
     @property
@@ -863,7 +928,7 @@ class DeferredAct:
             if hi > lo:
                 spec.append((hi - lo, fac, drop))
             o += sw
-        return DeferredAct(y_slice, self.bn_save, self.ld, self.col + c0, spec, self.p, self.seed)
+        return DeferredAct(y_slice, self.bn_save, self.ld, self.col + c0, spec, self.p, self.seed, self.stats)
 
 
 def _defer_struct(d):
@@ -879,10 +944,21 @@ def _can_defer(M, dtype):
             and dtype == torch.float32)
 
 
+_stats_parts_cache = {}
+
+
+def _stats_parts(key, query):
+    """memoised mlsp_*_bwd_stats_parts answer (a pure function of the layer shape and the product mode)"""
+    v = _stats_parts_cache.get(key)
+    if v is None:
+        v = _stats_parts_cache[key] = int(query())
+    return v
+
+
 class _PointMLP(Function):
     @staticmethod
     def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,
-                momentum, eps, grad_accum=None, out_bf16=False, in_def=None, defer_out=False, grad_cols=None):
+                momentum, eps, grad_accum=None, out_bf16=False, in_def=None, defer_out=False, grad_cols=None, in_stats=None, out_stats=None):
         lib = _lib.load()
         prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         X = _rows(X, allow_bf16=True)
@@ -934,6 +1010,16 @@ class _PointMLP(Function):
                 int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_fwd_f32")
         ctx.in_def = in_def
+        # fused BatchNorm-backward sums (BwdStats): as a consumer, promise the producer this layer's input columns (with the panel count
+        # the dgrad would write; 0 = it cannot); as a deferred producer, remember where the consumers will leave ours
+        ctx.in_stats, ctx.out_stats = None, (out_stats if defer_out else None)
+        if in_stats is not None and in_def is not None and not mx:
+            parts = 0
+            if _FUSE_BWD_STATS and ctx.needs_input_grad[0] and grad_accum is None:
+                lddx = grad_cols[0].width if grad_cols is not None else Cin
+                parts = _stats_parts(("p", M, Cin, Cout, W.stride(0), lddx, prec), lambda: lib.mlsp_pointmlp_bwd_stats_parts(M, Cin, Cout, W.stride(0), lddx, prec))
+            in_stats.promise(in_def[2], Cin, parts)
+            ctx.in_stats = in_stats
         ctx.save_for_backward(X, W, Y, bn_save)
         ctx.cfg = (has_bn, training, act, slope, p, seed, bias is not None, gbias.shape[0] if gbias is not None else 0,
                    int(rows_per_group))
@@ -949,7 +1035,7 @@ class _PointMLP(Function):
     @once_differentiable
     def backward(ctx, dZ, _dbn=None):
         if dZ is None:
-            return (None,) * 21
+            return (None,) * 23
         lib = _lib.load()
         X, W, Y, bn_save = ctx.saved_tensors
         has_bn, training, act, slope, p, seed, has_bias, G, rpg = ctx.cfg
@@ -976,6 +1062,11 @@ class _PointMLP(Function):
         dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bn else None
         dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bn else None
         ws, wsn = _lib.workspace(dev, M, Cin, Cout)
+        pre = ctx.out_stats.take() if ctx.out_stats is not None else None          # our own sums, left by the consumers' dgrads
+        pre_ptr, pre_n = (pre[0].data_ptr(), pre[1]) if pre is not None else (None, 0)
+        ins = None
+        if ctx.in_stats is not None and dX is not None and ctx.in_stats.agreed():
+            ins = ctx.in_stats.buffer(dev)                                          # the producer's sums: this call's dgrad writes our columns
         if mx:
             _lib.check(lib.mlsp_pointmlp_bwd_mx(
                 dZ.data_ptr(), X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, Y.data_ptr(),
@@ -987,15 +1078,15 @@ class _PointMLP(Function):
             _lib.check(lib.mlsp_pointmlp_bwd_chain_f32(
                 dZ.data_ptr(), X.data_ptr(), X.stride(0), _lib._c.byref(ds), M, Cin, W.data_ptr(), W.stride(0),
                 Cout, _lib.ptr(Y), _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
-                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ctx.prec, ws, wsn, _lib.stream()),
-                "mlsp_pointmlp_bwd_chain_f32")
+                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ins), pre_ptr, pre_n, ctx.prec, ws, wsn,
+                _lib.stream()), "mlsp_pointmlp_bwd_chain_f32")
         else:
             _lib.check(lib.mlsp_pointmlp_bwd_f32(
                 dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
                 _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate, dW.data_ptr(),
-                _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), ctx.prec, ws, wsn, _lib.stream()),
+                _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), pre_ptr, pre_n, ctx.prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_bwd_f32")
-        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 15
+        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 17
 
 
 def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, run_var=None, rows_per_group=0,
@@ -1016,17 +1107,18 @@ def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, 
         # kernels (e.g. a consumer whose GEMM splits K): widen once and run the fp32 layer; autograd narrows the gradient again
         X = X.float()
     out_bf16 = bool(chain) and activation_storage.current == "bf16" and gamma is not None
-    in_def = None
+    in_def = in_stats = None
     if isinstance(X, DeferredAct):
-        in_def, X = X.desc(), X.y
+        in_def, in_stats, X = X.desc(), X.stats, X.y
     # fp32 storage: a chained layer leaves its BN + activation (+ dropout) to its consumers' GEMM operand loads
     defer_out = bool(chain or defer) and gamma is not None and _can_defer(X.shape[0], X.dtype)
+    out_stats = BwdStats(W.shape[0]) if defer_out else None
     out, bn_save = _PointMLP.apply(X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop,
-                                   seed, momentum, eps, grad_accum, out_bf16, in_def, defer_out, grad_cols)
+                                   seed, momentum, eps, grad_accum, out_bf16, in_def, defer_out, grad_cols, in_stats, out_stats)
     if defer_out:
         fac = 1.0 if act == ACT_NONE else 0.0 if act == ACT_RELU else float(slope)
         p = float(p_drop) if training else 0.0
-        return DeferredAct(out, bn_save, out.shape[1], 0, ((out.shape[1], fac, p > 0),), p, seed)
+        return DeferredAct(out, bn_save, out.shape[1], 0, ((out.shape[1], fac, p > 0),), p, seed, out_stats)
     return out
 
 

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
         import ctypes
         for kind, ct in zip(kinds, _lib.SIGNATURES[name]):
             assert (ct is ctypes.c_void_p) == (kind == "p"), (name, args)
-    assert lib.mlsp_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.mlsp_abi_version() == _lib.ABI_VERSION == 10
     assert b"workspace" in lib.mlsp_strerror(-2)
     assert lib.mlsp_workspace_bytes(32768, 512, 1024) > 32768 * 1024 * 4
 
@@ -204,7 +204,7 @@ def test_no_process_wide_dispatch_state_in_the_library():
     assert not hasattr(lib, "mlsp_set_gemm_precision")
     protos = _header_prototypes()
     with_prec = [n for n, (_, _, args) in protos.items() if re.search(r"\bint precision\b", args)]
-    assert len(with_prec) == 19, sorted(with_prec)
+    assert len(with_prec) == 21, sorted(with_prec)     # (19 compute entries + the two *_bwd_stats_parts shape queries)
     for n in ("mlsp_gemm_f32", "mlsp_pointmlp_fwd_f32", "mlsp_pointmlp_bwd_f32", "mlsp_edgeconv_fwd_f32", "mlsp_tnet_edge_fwd_f32",
               "mlsp_multimlp_fwd_f32", "mlsp_pointmlp_colmax_bwd_f32"):
         assert n in with_prec, n
