@@ -45,7 +45,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 10
+#define MLSP_ABI_VERSION 11
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -141,11 +141,13 @@ typedef struct mlsp_defer {
 int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                           const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                           float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
-                          uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                          uint64_t seed, float* Y, float* Z, float* bn_save, float* group_ysum, int precision, void* ws, size_t ws_bytes,
+                          mlsp_stream_t stream);
 int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const mlsp_defer_t* in, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                                 const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                                 float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
-                                uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                                uint64_t seed, float* Y, float* Z, float* bn_save, float* group_ysum, int precision, void* ws, size_t ws_bytes,
+                                mlsp_stream_t stream);
 /* BatchNorm-backward reduction fused into the consumer's dgrad (round 5).  The gradient w.r.t. a chained layer's activated output is
  * produced by its CONSUMER's dgrad; that launch (gemm_split_kernel's output pass, the small-K streaming kernel) can multiply it by the
  * producer's activation derivative and dropout mask right there, store the masked gradient d' and leave the producer's column sums of
@@ -153,18 +155,23 @@ int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const mlsp_defer_t* 
  *   consumer: in_stats != NULL ([M / 128][2][in->ld] doubles, indexed by the producer's column) -- legal when
  *             mlsp_*_bwd_stats_parts() > 0 for the layer; dX then holds d', not dZ;
  *   producer: pre_stats != NULL ([pre_parts][2][Cout]) -- dZ is d', its sums are given: finalisation + the BatchNorm part only.
- * All consumers of a producer must do it or none (they all write columns of the same dX and the same partial rows). */
+ * All consumers of a producer must do it or none (they all write columns of the same dX and the same partial rows).
+ * A producer in that role (training mode) does not form its output gradient dY either when its dgrad and weight-gradient launches run on
+ * gemm_split_kernel: they read d' and Y and apply dY = (d' + y * nk2[c] + c0[c]) * sc[c] in their operand loads (coefficients from the
+ * finalised sums), so the streaming "apply" pass and the dY tensor are gone; the per-cloud bias gradient (gbias) then comes from the panel
+ * sums of d' and the clouds' column sums of Y -- group_ysum [n_groups][Cout], which the forward leaves when asked (nullable on both
+ * sides: without it the backward takes one pass over Y).  Other shapes keep the apply pass (same results to rounding). */
 int mlsp_pointmlp_bwd_stats_parts(int M, int Cin, int Cout, int ldw, int lddx, int precision);
 int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, const mlsp_defer_t* in, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                                 const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                                 int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
                                 float* dgbias, float* dgamma, float* dbeta, double* in_stats, const double* pre_stats, int pre_parts,
-                                int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
+                                const float* group_ysum, int precision, void* ws, size_t ws_bytes, mlsp_stream_t stream);
 int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                           const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                           int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
-                          float* dgamma, float* dbeta, const double* pre_stats, int pre_parts, int precision, void* ws, size_t ws_bytes,
-                          mlsp_stream_t stream);
+                          float* dgamma, float* dbeta, const double* pre_stats, int pre_parts, const float* group_ysum, int precision, void* ws,
+                          size_t ws_bytes, mlsp_stream_t stream);
 
 /* The same layer with its ACTIVATIONS stored as bf16 in HBM (BASELINE.json configs[4]: PointSegDA N=2048 k=40 "bf16 with MFMA edge-MLP";
  * PointSegDA/Models.py:245-385 head stacks).  x_bf16: X and dX are bf16 (else fp32); out_bf16: Y, Z, dZ and the internal dY are bf16.
@@ -307,7 +314,9 @@ int mlsp_ball_query_f32(const float* xyz, int ldx, const float* new_xyz, int ldq
 int mlsp_group_reverse(const int32_t* idx, int B, int S, int N, int ns, int32_t* rev_off, int32_t* rev_ent, mlsp_stream_t stream);
 int mlsp_sa_group_fwd_f32(const float* xyz, int ldx, const float* feat, int D, const float* new_xyz, int ldq, const int32_t* idx, int B,
                           int N, int S, int ns, float* G, mlsp_stream_t stream);
-int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
+/* dfeat [B][N][D] = the sum, over the groups a point sits in, of columns [col, col + D) of the grouped-row gradient dG (row pitch ldg):
+ * col = 3 for the feature columns, col = 0 / D = 3 for the coordinate columns (d xyz of `grouped_xyz - new_xyz`, pointnet_util.py:122-124). */
+int mlsp_sa_group_bwd_f32(const float* dG, int ldg, int col, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
                           float* dfeat, mlsp_stream_t stream);
 
 /* Linear + BatchNorm + activation + max over the k consecutive rows of every group, fused (pointnet_util.py:188-195: the last conv of a

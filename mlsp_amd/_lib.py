@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLSP_HIP_LIB") or os.path.join(_HERE, "libmlsp_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c = ctypes
 _P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
@@ -35,15 +35,15 @@ SIGNATURES = {
     "mlsp_tnet_edge_bwd_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I,
                                _P, _P, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_fwd_f32": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
-                              _P, _P, _P, _I, _P, _SZ, _P],
+                              _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
-                              _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _SZ, _P],
+                              _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_stats_parts": [_I, _I, _I, _I, _I, _I],
     "mlsp_multimlp_bwd_stats_parts": [_I, _P, _I, _I, _I, _I],
     "mlsp_pointmlp_fwd_chain_f32": [_P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
-                                    _P, _P, _P, _I, _P, _SZ, _P],
+                                    _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_bwd_chain_f32": [_P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I,
-                                    _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _SZ, _P],
+                                    _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_mx_supported": [_I, _I, _I, _I, _I, _I, _I],
     "mlsp_pointmlp_fwd_mx": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _I, _F, _F, _U64,
                              _P, _P, _I, _P, _I, _P, _SZ, _P],
@@ -74,7 +74,7 @@ SIGNATURES = {
     "mlsp_ball_query_f32": [_P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _P],
     "mlsp_group_reverse": [_P, _I, _I, _I, _I, _P, _P, _P],
     "mlsp_sa_group_fwd_f32": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P],
-    "mlsp_sa_group_bwd_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mlsp_sa_group_bwd_f32": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P],
     "mlsp_pointmlp_segmax_fwd_f32": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _I, _F, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_pointmlp_segmax_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P],
     "mlsp_sa_fold_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _SZ, _P],

@@ -8,7 +8,16 @@
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
                 double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr, int* sel_row = nullptr,
-                bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0, const GemmGroups* grp = nullptr, const GemmBs* bs = nullptr);
+                bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0, const GemmGroups* grp = nullptr, const GemmBs* bs = nullptr,
+                const GemmDy* dy = nullptr);
+bool gemm_dy_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb);
+int launch_bn_bwd_finalize_coef(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
+                                float* dbeta, float* coef);
+int launch_bn_dy_gbias(hipStream_t st, const float* Y, int G, int rows_per_group, int C, const double* stats, int panel_rows, const float* coef,
+                       float* scratch, float* out, const float* ysum);
+int launch_bn_finalize_groups(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
+                              const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
+                              float* shift, float* save_mean, float* save_invstd, float* gsum, int ppg);
 bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which);
 int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const void* A, int a_bf16, int lda, const void* B, int b_bf16,
                    int ldb, void* C, int c_bf16, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
@@ -43,7 +52,7 @@ int launch_ball_query(hipStream_t st, const float* xyz, int ldx, const float* q,
                       int* idx);
 int launch_sa_group_fwd(hipStream_t st, const float* xyz, int ldx, const float* feat, int D, const float* q, int ldq, const int* idx,
                         int B, int N, int S, int ns, float* G);
-int launch_sa_group_bwd(hipStream_t st, const float* dG, int D, const int* rev_off, const int* rev_ent, int B, int N, int S, int ns,
+int launch_sa_group_bwd(hipStream_t st, const float* dG, int ldg, int col, int D, const int* rev_off, const int* rev_ent, int B, int N, int S, int ns,
                         float* dfeat);
 
 int launch_collapse_to_point(hipStream_t st, float* X, int B, int N, const int* choice, const float* u, const float* noise, float r2,
@@ -296,9 +305,9 @@ int mlsp_sa_group_fwd_f32(const float* xyz, int ldx, const float* feat, int D, c
                           int N, int S, int ns, float* G, mlsp_stream_t st) {
     return launch_sa_group_fwd(st, xyz, ldx, feat, D, new_xyz, ldq, idx, B, N, S, ns, G);
 }
-int mlsp_sa_group_bwd_f32(const float* dG, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
+int mlsp_sa_group_bwd_f32(const float* dG, int ldg, int col, int D, const int32_t* rev_off, const int32_t* rev_ent, int B, int N, int S, int ns,
                           float* dfeat, mlsp_stream_t st) {
-    return launch_sa_group_bwd(st, dG, D, rev_off, rev_ent, B, N, S, ns, dfeat);
+    return launch_sa_group_bwd(st, dG, ldg, col, D, rev_off, rev_ent, B, N, S, ns, dfeat);
 }
 
 
@@ -555,8 +564,12 @@ static int pointmlp_fwd_impl(const float* X, int ldx, int M, int Cin, const floa
                              const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                              float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
                              uint64_t seed, float* Y, float* Z, float* bn_save, void* ws, size_t ws_bytes, mlsp_stream_t st,
-                             const mlsp_defer_t* in) {
+                             const mlsp_defer_t* in, float* group_ysum) {
+    // group_ysum (nullable, [M / rows_per_group][Cout]; needs gbias + BatchNorm): the per-cloud column sums of Y, a by-product of the
+    // statistics (one streaming pass when this shape's GEMM does not leave row-panel sums) -- what the backward needs for the per-cloud
+    // bias gradient when it never forms dY (mlsp_pointmlp_bwd_*: group_ysum)
     if (!X || !W || (!Z && !gamma) || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
+    if (group_ysum && (!gamma || !gbias || rows_per_group <= 0 || M % rows_per_group || M <= 32)) return MLSP_ERR_ARG;
     if (gamma && (!beta || !Y || !bn_save)) return MLSP_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f) return MLSP_ERR_ARG;
     if (in && (!defer_ok(in) || in->col + Cin > in->ld)) return MLSP_ERR_ARG;
@@ -592,13 +605,22 @@ static int pointmlp_fwd_impl(const float* X, int ldx, int M, int Cin, const floa
     float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
     CHECK(launch_gemm(st, false, true, M, Cout, Cin, X, ldx, W, ldw, Y, Cout, bias, gbias, rows_per_group, slab, sf,
                       fused_parts ? part : nullptr, nullptr, nullptr, nullptr, false, xf));
+    const int prow = fused_parts ? M / fused_parts : 0;                    // rows per statistics panel
+    const bool gsum_fin = group_ysum && training && fused_parts && M % fused_parts == 0 && rows_per_group % prow == 0;
     if (training) {
         if (!fused_parts) CHECK(launch_colstats(st, Y, M, Cout, Cout, part));
-        CHECK(launch_bn_finalize(st, part, nparts, (double)M, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale, shift,
-                                 mean, invstd));
+        if (gsum_fin) CHECK(launch_bn_finalize_groups(st, part, nparts, (double)M, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale, shift,
+                                                      mean, invstd, group_ysum, rows_per_group / prow));
+        else CHECK(launch_bn_finalize(st, part, nparts, (double)M, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale, shift,
+                                      mean, invstd));
     } else {
         if (!run_mean || !run_var) return MLSP_ERR_ARG;
         CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
+    }
+    if (group_ysum && !gsum_fin) {
+        float* gscr = w.take<float>((size_t)(M / rows_per_group) * 16 * Cout);
+        if (!w.ok()) return MLSP_ERR_WORKSPACE;
+        CHECK(launch_colsum_groups(st, Y, M / rows_per_group, rows_per_group, Cout, group_ysum, gscr));
     }
     // Z == NULL: the activation is deferred to the consumer (mlsp_pointmlp_*_chain_f32 apply it in their operand loads)
     if (Z) CHECK(launch_bn_act_fwd(st, Y, Z, (size_t)M, Cout, scale, shift, act, slope, training ? p_drop : 0.f, seed));
@@ -608,27 +630,29 @@ static int pointmlp_fwd_impl(const float* X, int ldx, int M, int Cin, const floa
 int mlsp_pointmlp_fwd_f32(const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                           const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                           float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
-                          uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          uint64_t seed, float* Y, float* Z, float* bn_save, float* group_ysum, int precision, void* ws, size_t ws_bytes,
+                          mlsp_stream_t st) {
     PREC_SCOPE(precision);
     return pointmlp_fwd_impl(X, ldx, M, Cin, W, ldw, Cout, bias, gbias, rows_per_group, gamma, beta, run_mean, run_var, momentum, eps,
-                             training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, nullptr);
+                             training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, nullptr, group_ysum);
 }
 
 int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const mlsp_defer_t* in, int M, int Cin, const float* W, int ldw, int Cout, const float* bias,
                                 const float* gbias, int rows_per_group, const float* gamma, const float* beta, float* run_mean,
                                 float* run_var, float momentum, float eps, int training, int act, float slope, float p_drop,
-                                uint64_t seed, float* Y, float* Z, float* bn_save, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                                uint64_t seed, float* Y, float* Z, float* bn_save, float* group_ysum, int precision, void* ws, size_t ws_bytes,
+                                mlsp_stream_t st) {
     PREC_SCOPE(precision);
     if (!in) return MLSP_ERR_ARG;
     return pointmlp_fwd_impl(Xpre, ldx, M, Cin, W, ldw, Cout, bias, gbias, rows_per_group, gamma, beta, run_mean, run_var, momentum, eps,
-                             training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, in);
+                             training, act, slope, p_drop, seed, Y, Z, bn_save, ws, ws_bytes, st, in, group_ysum);
 }
 
 static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                              const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                              int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
                              float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mlsp_stream_t st, const mlsp_defer_t* in,
-                             double* in_stats, const double* pre_stats, int pre_parts) {
+                             double* in_stats, const double* pre_stats, int pre_parts, const float* group_ysum) {
     // in_stats (consumer role, needs `in`): dX is stored MASKED by the producer's activation derivative / dropout and the producer's
     // BatchNorm-backward column sums are left in in_stats [M / 128][2][in->ld] at column in->col (mlsp_pointmlp_bwd_stats_parts() > 0).
     // pre_stats (producer role): dZ arrives masked, its sums are in pre_stats [pre_parts][2][Cout]: no reduction pass.
@@ -647,6 +671,7 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     size_t sf = sf1 > sf2 ? sf1 : sf2;
     float* slab = sf ? w.take<float>(sf) : nullptr;
     float* gscratch = dgbias ? w.take<float>((size_t)n_groups * 16 * Cout) : nullptr;
+    float* coef = has_bn ? w.take<float>((size_t)3 * Cout) : nullptr;
     const float* Xorig = X; const int ldx_orig = ldx;   // the previous layer's pre-BN output (fused statistics read it as it is)
     GemmXf xf_s; const GemmXf* xf = nullptr;            // chained input: the wgrad reads the previous layer's pre-BN output
     if (in) {
@@ -663,7 +688,19 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float* g = dZ;   // gradient wrt the linear output
     int g_slabs = 0;       // > 0: launch_bn_act_bwd already left the per-group partial sums of dY in gscratch
-    if (has_bn && M <= 32) {
+    // masked gradient + its sums in hand (pre_stats): when the dgrad and the weight gradient can form dY = (d' + y * nk2 + c0) * sc in their
+    // A operand loads (gemm.hip gemm_split_kernel<.., DY>) the apply pass and the dY tensor are skipped; the per-cloud bias gradient comes
+    // from the row-panel sums of d' and the clouds' column sums of y (bn.hip launch_bn_dy_gbias)
+    static const bool dy_off = getenv("MLSP_BWD_DY_OFF") != nullptr;        // read-once A/B switch (tools/ab)
+    GemmDy dy_s = {Y, coef, Cout}; const GemmDy* dy = nullptr;
+    if (has_bn && M > 32 && pre_stats && training && !dy_off && (!in || xf) && M % pre_parts == 0 &&
+        (!dX || gemm_dy_supported(false, false, M, Cin, Cout, dZ, Cout, W, ldw)) && gemm_dy_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx) &&
+        (!dgbias || (rows_per_group >= 256 && rows_per_group % (M / pre_parts) == 0 && Cout % 4 == 0 && 256 % (Cout / 4) == 0 && Cout <= 1024)))
+        dy = &dy_s;
+    if (dy) {
+        CHECK(launch_bn_bwd_finalize_coef(st, pre_stats, pre_parts, (double)M, Cout, bn_save, dgamma, dbeta, coef));
+        if (dgbias) CHECK(launch_bn_dy_gbias(st, Y, n_groups, rows_per_group, Cout, pre_stats, M / pre_parts, coef, gscratch, dgbias, group_ysum));
+    } else if (has_bn && M <= 32) {
         CHECK(launch_skinny_bn_bwd(st, dZ, Y, dY, M, Cout, bn_save, training, act, slope, p_drop, seed, dgamma, dbeta));
         g = dY;
     } else if (has_bn) {
@@ -681,9 +718,9 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
         bs = &bs_s;
     }
     if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf, nullptr, nullptr,
-                              nullptr, nullptr, dx_accumulate != 0, nullptr, 0, nullptr, bs));
+                              nullptr, nullptr, dx_accumulate != 0, nullptr, 0, nullptr, bs, dy));
     CHECK(launch_gemm(st, true, false, Cout, Cin, M, g, Cout, X, ldx, dW, Cin, nullptr, nullptr, 0, slab, sf, nullptr, nullptr, nullptr,
-                      nullptr, false, xf));
+                      nullptr, false, xf, 0, nullptr, nullptr, dy));
     if (dbias) {
         if (has_bn && training) {
             // a bias in front of a batch-stat BN has an analytically zero gradient (sum_rows dY == 0)
@@ -693,7 +730,7 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
             CHECK(launch_colsum(st, g, M, Cout, part, dbias));
         }
     }
-    if (dgbias) {
+    if (dgbias && !dy) {
         if (g_slabs > 0) CHECK(launch_colsum_groups_fin(st, gscratch, n_groups, Cout, g_slabs, dgbias));
         else CHECK(launch_colsum_groups(st, g, n_groups, rows_per_group, Cout, dgbias, gscratch));
     }
@@ -703,11 +740,12 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
 int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int Cin, const float* W, int ldw, int Cout, const float* Y,
                           const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                           int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias, float* dgbias,
-                          float* dgamma, float* dbeta, const double* pre_stats, int pre_parts, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                          float* dgamma, float* dbeta, const double* pre_stats, int pre_parts, const float* group_ysum, int precision, void* ws,
+                          size_t ws_bytes, mlsp_stream_t st) {
     PREC_SCOPE(precision);
     return pointmlp_bwd_impl(dZ, X, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
                              rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, nullptr, nullptr,
-                             pre_stats, pre_parts);
+                             pre_stats, pre_parts, group_ysum);
 }
 
 // Row panels the fused statistics pass of mlsp_pointmlp_bwd_chain_f32(in_stats != NULL) writes for this layer shape (its dgrad
@@ -723,12 +761,12 @@ int mlsp_pointmlp_bwd_chain_f32(const float* dZ, const float* Xpre, int ldx, con
                                 const float* bn_save, int has_bn, int training, int act, float slope, float p_drop, uint64_t seed,
                                 int n_groups, int rows_per_group, float* dX, int lddx, int dx_accumulate, float* dW, float* dbias,
                                 float* dgbias, float* dgamma, float* dbeta, double* in_stats, const double* pre_stats, int pre_parts,
-                                int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
+                                const float* group_ysum, int precision, void* ws, size_t ws_bytes, mlsp_stream_t st) {
     PREC_SCOPE(precision);
     if (!in) return MLSP_ERR_ARG;
     return pointmlp_bwd_impl(dZ, Xpre, ldx, M, Cin, W, ldw, Cout, Y, bn_save, has_bn, training, act, slope, p_drop, seed, n_groups,
                              rows_per_group, dX, lddx, dx_accumulate, dW, dbias, dgbias, dgamma, dbeta, ws, ws_bytes, st, in, in_stats,
-                             pre_stats, pre_parts);
+                             pre_stats, pre_parts, group_ysum);
 }
 
 // ---- Linear + BatchNorm + act + max over the k rows of every group (last conv of a set-abstraction MLP + the neighbourhood max) ------

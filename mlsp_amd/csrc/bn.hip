@@ -69,10 +69,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int nparts, 
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ run_mean, float* __restrict__ run_var, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd) {
+                                   float* __restrict__ save_invstd, float* __restrict__ gsum, int ppg) {
     const int c = blockIdx.x;
     double s, q;
     fin_part_sums(part, nparts, C, c, s, q);
+    // gsum (nullable, [nparts / ppg][C]): the column sums of every cloud (ppg row panels each) -- kept for the backward of a layer with a
+    // per-cloud bias whose output gradient is never formed (launch_bn_dy_gbias)
+    if (gsum)
+        for (int g = threadIdx.x; g < nparts / ppg; g += blockDim.x) {
+            double t = 0.0;
+            for (int p = 0; p < ppg; ++p) t += part[((size_t)(g * ppg + p) * 2) * C + c];
+            gsum[(size_t)g * C + c] = (float)t;
+        }
     if (threadIdx.x != 0) return;
     double mean = s / count;
     double var = q / count - mean * mean;
@@ -512,7 +520,17 @@ int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double co
                        const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
                        float* shift, float* save_mean, float* save_invstd) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, gamma, beta,
-                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
+                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd, (float*)nullptr, 1);
+    return mlsp_launch_status();
+}
+
+// the same + gsum [nparts / ppg][C]: the column sums of every ppg consecutive row panels (one cloud)
+int launch_bn_finalize_groups(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
+                              const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
+                              float* shift, float* save_mean, float* save_invstd, float* gsum, int ppg) {
+    if (!gsum || ppg <= 0 || nparts % ppg) return MLSP_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, gamma, beta,
+                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd, gsum, ppg);
     return mlsp_launch_status();
 }
 
@@ -586,6 +604,29 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
     return mlsp_launch_status();
 }
 
+// The same sums turned into the coefficient rows of the on-the-fly BatchNorm backward (gemm.hip gemm_split_kernel<.., DY>):
+//   dY = scale * (d' - mean_dz - (y - mean) * invstd * mean_dzy) = (d' + y * nk2 + c0) * sc,
+//   nk2 = -invstd * mean_dzy,  c0 = mean * invstd * mean_dzy - mean_dz,  sc = scale;   coef: rows c0 | nk2 | sc of pitch C.
+__global__ void bn_bwd_finalize_coef_kernel(const double* __restrict__ part, int nparts, double count, int C, const float* __restrict__ bn,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int c = blockIdx.x;
+    double s, q;
+    fin_part_sums(part, nparts, C, c, s, q);
+    if (threadIdx.x != 0) return;
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    const double k2 = (double)bn[3 * C + c] * (q / count);
+    coef[c] = (float)((double)bn[2 * C + c] * k2 - s / count);
+    coef[C + c] = (float)(-k2);
+    coef[2 * C + c] = bn[c];
+}
+
+int launch_bn_bwd_finalize_coef(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
+                                float* dbeta, float* coef) {
+    hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, bn_save, dgamma, dbeta, coef);
+    return mlsp_launch_status();
+}
+
 int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
                            float* mean_dz, float* mean_dzy) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, dgamma, dbeta,
@@ -647,6 +688,31 @@ int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_gro
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(colsum_groups_kernel, dim3((C + 63) / 64, G), dim3(256), 0, st, X, C, rows_per_group, out);
+    return mlsp_launch_status();
+}
+
+// Per-cloud column sums of that dY without forming it: sc * (sum d' + nk2 * sum y + rows * c0) from the consumer's row-panel sums of d'
+// (stats [panels][2][C], ppg panels per cloud) and the cloud's column sums of y (ys [G][slabs][C], colsum_groups_vec_kernel).
+__global__ void bn_dy_gbias_kernel(const double* __restrict__ stats, int ppg, const float* __restrict__ ys, int slabs, const float* __restrict__ coef,
+                                   int G, int C, int rows, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    double sd = 0.0, sy = 0.0;
+    for (int p = 0; p < ppg; ++p) sd += stats[((size_t)(g * ppg + p) * 2) * C + c];
+    for (int s = 0; s < slabs; ++s) sy += (double)ys[((size_t)g * slabs + s) * C + c];
+    out[i] = (float)((double)coef[2 * C + c] * (sd + (double)coef[C + c] * sy + (double)rows * (double)coef[c]));
+}
+
+// scratch: [G][16][C] floats; stats: [M / panel rows][2][C]
+// ysum (nullable, [G][C]): the clouds' column sums of y kept by the forward (bn_finalize_kernel gsum): no pass over Y here
+int launch_bn_dy_gbias(hipStream_t st, const float* Y, int G, int rows_per_group, int C, const double* stats, int panel_rows, const float* coef,
+                       float* scratch, float* out, const float* ysum) {
+    if (!(vec_ok(C, Y) && 256 % (C / 4) == 0 && rows_per_group >= 256 && panel_rows > 0 && rows_per_group % panel_rows == 0)) return MLSP_ERR_UNSUPPORTED;
+    const int slabs = ysum ? 1 : 16;
+    if (!ysum) hipLaunchKernelGGL((colsum_groups_vec_kernel<float>), dim3(slabs, G), dim3(256), 0, st, Y, C, rows_per_group, slabs, scratch);
+    hipLaunchKernelGGL(bn_dy_gbias_kernel, dim3((G * C + 255) / 256), dim3(256), 0, st, stats, rows_per_group / panel_rows, ysum ? ysum : scratch, slabs, coef,
+                       G, C, rows_per_group, out);
     return mlsp_launch_status();
 }
 

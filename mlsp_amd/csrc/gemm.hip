@@ -53,6 +53,11 @@ struct GemmArgs {
     // streaming reduction of that layer's BatchNorm backward happens here, where the gradient is produced.  bs_bn: its scale | shift |
     // mean | invstd rows (pitch bs_bnld) at C's column 0; bs_ld / bs_col: row pitch of its matrix and C's column 0 in it (dropout stream).
     const float* bs_y; int bs_ldy; const float* bs_bn; int bs_bnld; float bs_slope; uint32_t bs_thresh; float bs_ik; uint32_t bs_xH; int bs_ld4; int bs_col;
+    // dy_y != null (gemm_split_kernel<.., DY>): the A operand is a layer's OUTPUT GRADIENT formed on the fly -- A holds the masked gradient
+    // d' (what the consumer's dgrad left, see bs_*), dy_y the layer's pre-BatchNorm output at the same coordinates (same pitch), and the
+    // BatchNorm backward dY = (d' + y * nk2[c] + c0[c]) * sc[c] is applied while the tile is staged: the streaming "apply" pass and the
+    // dY tensor disappear.  dy_coef: rows c0 | nk2 | sc (pitch dy_cld) at A's channel 0 (dgrad: channel = k; wgrad: channel = m).
+    const float* dy_y; const float* dy_coef; int dy_cld;
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][stat_ld] (BN batch statistics)
     int stat_ld;                    // columns of a statistics row (N, or the width of the wider matrix C is a column slice of)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
@@ -916,15 +921,19 @@ __device__ __forceinline__ f32x4 sx_bufload(__amdgpu_buffer_rsrc_t rs, int voff,
 // one over the materialised tensor.  XF == 1: A row-major [M][K], channel = k (forward of the consumer layer); XF == 2: B k-major [K][N],
 // channel = n (the consumer's weight gradient, X^T side).  Both also in block-diagonal launches (the group's channels start at
 // g * a_gs / g * b_gs).  The vector work rides in the split stream's slots (gen_split_body.py variants xa / xad / xb / xbd).
-template <bool TA, bool TB, int WM, int XF = 0, bool XD = false>
+// DY (GemmArgs dy_*): the A operand is d' and the layer's BatchNorm backward is applied to it while it is staged (two loads per staged
+// quad: d' and y), for the layer's dgrad (A row-major: coefficients per K-tile from LDS) and its weight gradient (A k-major: the thread's
+// channel quad is fixed, coefficients in registers).
+template <bool TA, bool TB, int WM, int XF = 0, bool XD = false, bool DY = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     static_assert(XF == 0 || (XF == 1 && !TA) || (XF == 2 && !TB), "XF == 1: A row-major; XF == 2: B k-major");
     static_assert(XF != 0 || !XD, "dropout only with a transform");
+    static_assert(!(DY && XF == 1), "one transform per operand");
     constexpr bool KA = TA, KB = !TB;                                 // operand's global source is k-major
     constexpr int BMT = 64 * WM, NQA = 2 * WM;                        // A quads (16-byte loads) of a tile per thread; B: 4
     __shared__ __attribute__((aligned(16))) char simg[6 * SX_PLANE];  // 61,440 B
-    constexpr int XFS = XF == 1 ? 2 * SX_XF_KMAX : 4;
-    __shared__ __attribute__((aligned(16))) float xfs[XFS];           // XF == 1: scale | shift of this workgroup's K range (<= SX_XF_KMAX channels)
+    constexpr int XFS = XF == 1 ? 2 * SX_XF_KMAX : (DY && !TA) ? 3 * SX_XF_KMAX : 4;
+    __shared__ __attribute__((aligned(16))) float xfs[XFS];           // XF == 1: scale | shift of this workgroup's K range (<= SX_XF_KMAX channels); DY dgrad: c0 | nk2 | sc
     float* smem = (float*)simg;                                       // epilogue scratch (the images are dead by then)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -981,6 +990,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     int soa = 0, sob = 0;
 #define SX_LOAD_A(q) sx_bufload(rsa, voa, soa + (q) * qa_)
 #define SX_LOAD_B(q) sx_bufload(rsb, vob, sob + (q) * qb_)
+    // DY: the layer's pre-BN output at the coordinates of A (same pitch, same group offset)
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(DY ? (KA ? p.dy_y + (Ap - p.A) + (size_t)kbeg * p.lda + m0 : p.dy_y + (Ap - p.A) + (size_t)m0 * p.lda + kbeg) : Ap), 0, DY ? 0x7ffffff0 : 0, MLSP_BUF_FLAGS);
+#define SX_LOAD_AY(q) sx_bufload(rsy, voa, soa + (q) * qa_)
     // this thread's place in the images
     char* wa = simg + (KA ? (NQA == 4 ? (tid >> 5) * SX_KPITCH + (tid & 31) * 8 : (tid >> 4) * SX_KPITCH + (tid & 15) * 8) : (tid >> 3) * SX_RPITCH + (tid & 7) * 8);
     char* wb = simg + 3 * SX_PLANE + (KB ? (tid >> 5) * SX_KPITCH + (tid & 31) * 8 : (tid >> 3) * SX_RPITCH + (tid & 7) * 8);
@@ -1031,14 +1044,44 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     // after a tile's quads are transformed: on to the tile after it (the stream always stages "tile t+1"; past the end a harmless repeat)
 #define SX_XF_NEXT(tnext_) do { if constexpr (XF != 0) { xq += (uint32_t)xqt; if constexpr (XF == 1) { const int tc_ = min((tnext_), T - 1) * BK + (tid & 7) * 4; \
         xsc = *(const f32x4*)(xfs + tc_); xsh = *(const f32x4*)(xfs + SX_XF_KMAX + tc_); } } } while (0)
+    // ---- DY state: rawy = the y quads of the tile being staged; dc0 / dnk2 / dsc = the coefficient quads of this thread's channels
+    f32x4 rawy[DY ? NQA : 1];
+    f32x4 dc0 = {0.f, 0.f, 0.f, 0.f}, dnk2 = {0.f, 0.f, 0.f, 0.f}, dsc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (DY) {
+        if constexpr (KA) {             // weight gradient: channel = this thread's four tile rows, fixed
+            const int ch = m0 + (NQA == 4 ? (tid & 31) : (tid & 15)) * 4;
+            dc0 = *(const f32x4*)(p.dy_coef + ch); dnk2 = *(const f32x4*)(p.dy_coef + p.dy_cld + ch); dsc = *(const f32x4*)(p.dy_coef + 2 * p.dy_cld + ch);
+        } else {                        // dgrad: channel = k: the K range's coefficients through LDS, one quad per K-tile
+            const int gc0 = (p.gmode == 1 ? (tn / p.gtiles) * (int)p.a_gs : 0) + kbeg;
+            for (int i = tid * 4; i < T * BK; i += 1024) {
+                *(f32x4*)(xfs + i) = *(const f32x4*)(p.dy_coef + gc0 + i);
+                *(f32x4*)(xfs + SX_XF_KMAX + i) = *(const f32x4*)(p.dy_coef + p.dy_cld + gc0 + i);
+                *(f32x4*)(xfs + 2 * SX_XF_KMAX + i) = *(const f32x4*)(p.dy_coef + 2 * p.dy_cld + gc0 + i);
+            }
+            __syncthreads();
+            dc0 = *(const f32x4*)(xfs + (tid & 7) * 4); dnk2 = *(const f32x4*)(xfs + SX_XF_KMAX + (tid & 7) * 4); dsc = *(const f32x4*)(xfs + 2 * SX_XF_KMAX + (tid & 7) * 4);
+        }
+    }
+#define SX_DY_A(q_, hh_) do { if constexpr (DY) { \
+        raw[q_][2 * (hh_)] = (raw[q_][2 * (hh_)] + fmaf(rawy[q_][2 * (hh_)], dnk2[2 * (hh_)], dc0[2 * (hh_)])) * dsc[2 * (hh_)]; \
+        raw[q_][2 * (hh_) + 1] = (raw[q_][2 * (hh_) + 1] + fmaf(rawy[q_][2 * (hh_) + 1], dnk2[2 * (hh_) + 1], dc0[2 * (hh_) + 1])) * dsc[2 * (hh_) + 1]; } } while (0)
+#define SX_DY_LOAD(q_) do { if constexpr (DY) rawy[q_] = SX_LOAD_AY(q_); } while (0)
+#define SX_DY_NEXT(tnext_) do { if constexpr (DY && !KA) { const int tc_ = min((tnext_), T - 1) * BK + (tid & 7) * 4; \
+        dc0 = *(const f32x4*)(xfs + tc_); dnk2 = *(const f32x4*)(xfs + SX_XF_KMAX + tc_); dsc = *(const f32x4*)(xfs + 2 * SX_XF_KMAX + tc_); } } while (0)
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) { raw[q] = SX_LOAD_A(q); SX_XF_HASH_A(q); SX_XF_A(q, 0); SX_XF_A(q, 1); sx_split_store(raw[q], wa + q * WQA); }
+    for (int q = 0; q < NQA; ++q) {
+        raw[q] = SX_LOAD_A(q); SX_DY_LOAD(q); SX_DY_A(q, 0); SX_DY_A(q, 1);
+        SX_XF_HASH_A(q); SX_XF_A(q, 0); SX_XF_A(q, 1); sx_split_store(raw[q], wa + q * WQA);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { raw[NQA + q] = SX_LOAD_B(q); SX_XF_HASH_B(q); SX_XF_B(q, 0); SX_XF_B(q, 1); sx_split_store(raw[NQA + q], wb + q * WQB); }
     SX_XF_NEXT(1);
+    SX_DY_NEXT(1);
     soa = min(soa + sta, enda); sob = min(sob + stb, endb);
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) raw[q] = SX_LOAD_A(q);
+    for (int q = 0; q < NQA; ++q) { raw[q] = SX_LOAD_A(q); SX_DY_LOAD(q); }
+#pragma unroll
+    for (int q = 0; q < 0; ++q) raw[q] = SX_LOAD_A(q);
 #pragma unroll
     for (int q = 0; q < 4; ++q) raw[NQA + q] = SX_LOAD_B(q);
     __syncthreads();
@@ -1059,7 +1102,25 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
         float r0, r1, a1;
         __builtin_amdgcn_sched_barrier(0);
         // (one generated body per (tile height, transformed operand, dropout): gen_split_body.py spreads the vector work over the MFMA slots)
-        if constexpr (XF == 0) {
+        if constexpr (DY && XF == 0) {
+            if (WM == 2) {
+#include "gemm_split_body_wm2_dy.inc"
+            } else {
+#include "gemm_split_body_wm1_dy.inc"
+            }
+        } else if constexpr (DY && !XD) {
+            if (WM == 2) {
+#include "gemm_split_body_wm2_dyxb.inc"
+            } else {
+#include "gemm_split_body_wm1_dyxb.inc"
+            }
+        } else if constexpr (DY) {
+            if (WM == 2) {
+#include "gemm_split_body_wm2_dyxbd.inc"
+            } else {
+#include "gemm_split_body_wm1_dyxbd.inc"
+            }
+        } else if constexpr (XF == 0) {
             if (WM == 2) {
 #include "gemm_split_body_wm2.inc"
             } else {
@@ -1091,6 +1152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
             }
         }
         SX_XF_NEXT(t + 2);
+        SX_DY_NEXT(t + 2);
         __syncthreads();
     }
 #undef SX_LOAD_A
@@ -1099,8 +1161,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
 #undef SX_XF_B
 #undef SX_XF_HASH_A
 #undef SX_XF_HASH_B
+#undef SX_DY_A
+#undef SX_DY_LOAD
+#undef SX_DY_NEXT
+#undef SX_LOAD_AY
 #undef SX_XF_NEXT
-    gemm_epilogue<WM, true, false, (!TA && !TB && XF == 0)>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
+    gemm_epilogue<WM, true, false, (!TA && !TB && XF == 0 && !DY) || (!TA && !TB && DY)>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 }
 
 // the calling entry point's `precision` argument for the duration of that call (common.h GemmPrecisionScope): 0: fp32 MFMA (exact fp32
@@ -1427,6 +1493,19 @@ int gemm_bs_parts(int M, int N, int K, int lda, int ldb, int ldc) {
     return M / 128;
 }
 
+// Can the layer's dgrad (ta = tb = false: dX [M][N] = dY [M][K] W) / weight gradient (ta, !tb: dW [M][N] = dY^T [K][M] X [K][N]) form dY from
+// (d', y) in its A operand loads (GemmDy)?  gemm_split_kernel only: interior tiles, 16-byte loads, the dgrad's K range within SX_XF_KMAX.
+bool gemm_dy_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb) {
+    if (tl_call_precision != 2 || tb) return false;
+    if (M <= 32 || N < 32 || K <= 32) return false;
+    const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    const int ns = gemm_pick_split(M, N, K);
+    const int bm = (ns == 1) ? gemm_pick_bm(M, N, K) : 128;
+    const int ktiles = (K + BK - 1) / BK, kts = (ktiles + ns - 1) / ns;
+    if (!gemm_split_pays(M, N, kts) || (!ta && kts * BK > SX_XF_KMAX)) return false;
+    return vec && (M % bm == 0) && (N % BN == 0) && (K % BK == 0) && (long)(ta ? K : M) * lda * 4 < (1L << 30) && (long)K * ldb * 4 < (1L << 30);
+}
+
 // will a transform launch of this shape run on gemm_split_kernel (the only kernel that transforms inside a block-diagonal launch)?
 bool gemm_xf_on_split(bool ta, bool tb, int M, int N, int K, int which) {
     if (tl_call_precision != 2) return false;
@@ -1438,7 +1517,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
                 int ldb, float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab,
                 size_t slab_floats, double* stat_part = nullptr, const float* sel_gamma = nullptr, float* sel_val = nullptr,
                 int* sel_row = nullptr, bool accumulate = false, const GemmXf* xf = nullptr, int stat_ld = 0, const GemmGroups* grp = nullptr,
-                const GemmBs* bs = nullptr) {
+                const GemmBs* bs = nullptr, const GemmDy* dy = nullptr) {
     // grp (nullable): block-diagonal product in one launch (GemmArgs groups; M / N are the LAUNCH's dimensions, K one group's).
     // Only on the interior-tile fp32 kernel: MLSP_ERR_UNSUPPORTED otherwise (nothing launched; the caller launches group by group).
     // stat_ld (0: N): C is a column slice of a [M][stat_ld] matrix whose BatchNorm statistics are taken as ONE vector (multi.hip):
@@ -1449,12 +1528,15 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     // a transform in a block-diagonal launch: split kernel only; the dropout stream is indexed in 32 bits per aligned quad
     if (xf && ((xf->ld & 3) || (xf->col & 3) || (((uintptr_t)xf->scale | (uintptr_t)xf->shift) & 15) || (double)(xf->which == 1 ? M : K) * xf->ld >= 17179869184.0))
         return MLSP_ERR_UNSUPPORTED;
-    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && (!xf || tl_call_precision != 1)) {
+    if (dy && (!dy->y || !dy->coef || (dy->cld & 3) || (((uintptr_t)dy->y | (uintptr_t)dy->coef) & 15) || gbias || sel_gamma || stat_part ||
+               (xf && xf->which != 2) || !gemm_dy_supported(ta, tb, M, N, K, A, lda, B, ldb)))
+        return MLSP_ERR_UNSUPPORTED;                                         // nothing launched: the caller runs the streaming apply pass
+    if (!dy && !grp && !gbias && !stat_part && !sel_gamma && !accumulate && (!xf || tl_call_precision != 1)) {
         const int rc = launch_thin_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, slab, slab_floats, xf, bs);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
     if (xf && !gemm_xf_supported(ta, tb, M, N, K, A, lda, B, ldb, xf->which)) return MLSP_ERR_UNSUPPORTED;   // nothing launched: caller materialises
-    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && !bs && !bias && C && gemm_fold64(ta, tb, M, N, K, lda, ldb) &&
+    if (!dy && !grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && !bs && !bias && C && gemm_fold64(ta, tb, M, N, K, lda, ldb) &&
         (((uintptr_t)A | (uintptr_t)B) & 15) == 0) {
         const size_t inner = gemm_slab_floats(128, 128, K / 2);
         if (slab && slab_floats >= inner + 128 * 128) {
@@ -1472,7 +1554,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         }
     }
     // per-cloud layers (<= 32 rows, or a 32-deep wgrad): one-pass skinny kernels, no split-K slab (skinny.hip)
-    if (!grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && !bs && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
+    if (!dy && !grp && !gbias && !stat_part && !sel_gamma && !accumulate && !xf && !bs && ((!ta && M <= 32) || (ta && !tb && K <= 32))) {
         const int rc = launch_skinny_gemm(st, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
@@ -1499,6 +1581,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         p.bs_xH = mix32_host((uint32_t)bs->seed) ^ (uint32_t)(bs->seed >> 32) * 0x9e3779b9U; p.bs_ld4 = bs->ld / 4; p.bs_col = bs->col;
         p.stat_part = bs->part; p.stat_ld = bs->stat_ld;
     }
+    p.dy_y = dy ? dy->y : nullptr; p.dy_coef = dy ? dy->coef : nullptr; p.dy_cld = dy ? dy->cld : 0;
     p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0; p.x_col = 0;
     if (xf) {
         p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_thresh = xf->thresh;
@@ -1538,7 +1621,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     }
     const bool xf_split = xf && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && (xf->which != 1 || kts * BK <= SX_XF_KMAX);
     if (grp && xf && !xf_split) return MLSP_ERR_UNSUPPORTED;             // (the fp32 transform kernels take no groups: nothing launched)
-    const bool n64 = !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
+    const bool n64 = !dy && !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
                      (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && tl_call_precision != 1 && (ns == 1 || p.ldc == N);
     if (n64) {
         dim3 g64(M / 128, ns);
@@ -1550,7 +1633,16 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
                                      else if (fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts)) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
-    if (xf_split) {                                                      // operand transform on the split kernel, plain or block-diagonal
+    if (dy) {                                                            // dual A operand (validated above: split kernel, interior tiles)
+        if (!fast || (xf && !xf_split) || (grp && grp->mode != (ta ? 2 : 1))) return MLSP_ERR_UNSUPPORTED;
+#define SPLIT_DY_GO(TA_, XF_, XD_) do { if (bm == 128) hipLaunchKernelGGL((gemm_split_kernel<TA_, false, 2, XF_, XD_, true>), grid, dim3(256), 0, st, p); \
+                                        else hipLaunchKernelGGL((gemm_split_kernel<TA_, false, 1, XF_, XD_, true>), grid, dim3(256), 0, st, p); } while (0)
+        if (!ta) { if (xf) return MLSP_ERR_UNSUPPORTED; SPLIT_DY_GO(false, 0, false); }
+        else if (!xf) SPLIT_DY_GO(true, 0, false);
+        else if (xf->thresh) SPLIT_DY_GO(true, 2, true);
+        else SPLIT_DY_GO(true, 2, false);
+#undef SPLIT_DY_GO
+    } else if (xf_split) {                                               // operand transform on the split kernel, plain or block-diagonal
 #define SPLIT_XF_GO(TA_, TB_, XF_) do { if (bm == 128) { if (xf->thresh) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 2, XF_, true>), grid, dim3(256), 0, st, p); \
                                                           else hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 2, XF_, false>), grid, dim3(256), 0, st, p); } \
                                          else { if (xf->thresh) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 1, XF_, true>), grid, dim3(256), 0, st, p); \

@@ -8,7 +8,8 @@ Per K-tile (32 deep) a wave issues 24 * WM MFMAs (2 k16 steps x WM x 2 accumulat
 issue slots of 4; between two MFMAs sits vector work of the NEXT tile's staging: per staged quad (16-byte load) two element pairs x three
 micro-steps of the three-way bf16 split, then its three image writes and the global load of the quad after next.
 
-VARIANT (operand transform instantiations, gemm_split_kernel<.., XF, XD>): xa / xad = the A quads are transformed before their split
+VARIANT (operand transform instantiations, gemm_split_kernel<.., XF, XD, DY>): dy / dyxb / dyxbd = the A quads are (d', y) pairs turned into
+the layer's output gradient (SX_DY_A) [+ the xb / xbd transform on B]; xa / xad = the A quads are transformed before their split
 (SX_XF_A: scale * x + shift, activation as one max; `d`: + dropout, one hash per quad), xb / xbd = the same on the B quads (SX_XF_B).
 The transform roughly doubles the vector work of the quads it applies to; placing it with the split steps of those quads overflows the MFMA
 shadow of a third of the slots (measured: +27 % per launch).  In the variants the work items keep their ORDER but are spread over the slots
@@ -23,8 +24,9 @@ QA = [1, 0, 2, 0, 1, 0]          # smallest products first, the leading one last
 QB = [1, 2, 0, 1, 0, 0]
 NQA = 2 * WM                      # A quads of a tile per thread (B: 4)
 S = 24 * WM
+DYA = VAR.startswith("dy")        # dy / dyxb / dyxbd: the A quads are d' + y pairs (SX_DY_A: the BatchNorm backward, 3 operations per value; SX_DY_LOAD)
 XA = VAR.startswith("xa")
-XB = VAR.startswith("xb")
+XB = VAR.startswith("xb") or VAR.startswith("dyxb")
 DROP = VAR.endswith("d")
 
 
@@ -40,6 +42,8 @@ def items():
             out.append((10, [f"SX_XF_HASH_{op}({q});"]))
         for hh in range(2):
             x0, x1 = f"raw[{qd}][{2 * hh}]", f"raw[{qd}][{2 * hh + 1}]"
+            if DYA and isA:
+                out.append((6, [f"SX_DY_A({q}, {hh});"]))
             if xf:
                 out.append((10 if DROP else 6, [f"SX_XF_{op}({q}, {hh});"]))
             out.append((4, [f"pk0[{hh}] = sx_cvt_pk({x0}, {x1});", f"a1 = __uint_as_float(pk0[{hh}] & 0xffff0000u);",
@@ -52,6 +56,8 @@ def items():
                 for p in range(3):
                     L.append(f"*(u32x2*)({d} + {p} * SX_PLANE) = (u32x2){{pk{p}[0], pk{p}[1]}};")
                 L.append(f"raw[{qd}] = SX_LOAD_{op}({q});")
+                if DYA and isA:
+                    L.append(f"SX_DY_LOAD({q});")
                 w += 4
             out.append((w, L))
     return out

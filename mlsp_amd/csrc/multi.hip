@@ -17,7 +17,7 @@
 int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, const float* gbias, int rows_per_group, float* slab, size_t slab_floats,
                 double* stat_part, const float* sel_gamma, float* sel_val, int* sel_row, bool accumulate, const GemmXf* xf, int stat_ld,
-                const GemmGroups* grp = nullptr, const GemmBs* bs = nullptr);
+                const GemmGroups* grp = nullptr, const GemmBs* bs = nullptr, const GemmDy* dy = nullptr);
 int gemm_bs_parts(int M, int N, int K, int lda, int ldb, int ldc);
 int gemm_panel_rows(int M, int N, int K);
 bool gemm_xf_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int which);
@@ -32,6 +32,9 @@ int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double co
                        float* shift, float* save_mean, float* save_invstd);
 int launch_bn_eval_prepare(hipStream_t st, int C, const float* gamma, const float* beta, const float* run_mean,
                            const float* run_var, float eps, float* scale, float* shift, float* save_mean, float* save_invstd);
+int launch_bn_bwd_finalize_coef(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
+                                float* dbeta, float* coef);
+bool gemm_dy_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb);
 int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
                            float* mean_dz, float* mean_dzy);
 int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out);
@@ -437,20 +440,35 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
     }
     float* slab = sf ? w.take<float>(sf) : nullptr;
     float* Xa = any_mat ? w.take<float>((size_t)M * ldx) : nullptr;
+    float* coef = w.take<float>((size_t)3 * Ctot);
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float pd = training ? p_drop : 0.f;
     const uint32_t th = dropout_thresh8(pd);
     const float ik = dropout_inv_keep8(pd);
-    if (pre_stats) {
+    // masked gradient + its sums in hand: when every dgrad / weight-gradient launch of this layer can form dY = (d' + y * nk2 + c0) * sc in
+    // its A operand loads (gemm.hip gemm_split_kernel<.., DY>) the apply pass and the dY tensor are skipped altogether
+    static const bool dy_off = getenv("MLSP_BWD_DY_OFF") != nullptr;        // read-once A/B switch (tools/ab)
+    bool use_dy = pre_stats && training && !dy_off && !any_mat;
+    for (int s = 0, yc = 0; s < nseg && use_dy; yc += run[s] * segs[s].Cout, s += run[s]) {
+        const mlsp_seg_t& g = segs[s];
+        if (dX) use_dy = gemm_dy_supported(false, false, M, run[s] * g.Cin, g.Cout, dZ + yc, Ctot, g.W, g.ldw);
+        use_dy = use_dy && gemm_dy_supported(true, false, run[s] * g.Cout, g.Cin, M, dZ + yc, Ctot, X + g.x_col, ldx);
+    }
+    if (use_dy) {
+        MCHECK(launch_bn_bwd_finalize_coef(st, pre_stats, pre_parts, (double)M, Ctot, bn_save, dgamma, dbeta, coef));
+    } else if (pre_stats) {
         MCHECK(launch_bn_bwd_finalize(st, pre_stats, pre_parts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy));
     } else {
         hipLaunchKernelGGL(multi_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, Ctot, bn_save, chan, th, ik, seed, part);
         MCHECK(launch_bn_bwd_finalize(st, part, nparts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy));
     }
     const int rpb = multi_rows_per_block(M, Ctot);
-    hipLaunchKernelGGL(multi_bwd_apply_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, st, dZ, Y, dY, M, Ctot, rpb, bn_save, chan,
-                       training ? mean_dz : (const float*)nullptr, mean_dzy, th, ik, seed, pre_stats ? 1 : 0);
-    MCHECK(mlsp_launch_status());
+    if (!use_dy) {
+        hipLaunchKernelGGL(multi_bwd_apply_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, st, dZ, Y, dY, M, Ctot, rpb, bn_save, chan,
+                           training ? mean_dz : (const float*)nullptr, mean_dzy, th, ik, seed, pre_stats ? 1 : 0);
+        MCHECK(mlsp_launch_status());
+    }
+    const float* gY = use_dy ? dZ : dY;                           // the GEMMs' A operand: d' (+ y, coefficients) or the formed dY
     int ycol = 0;
     for (int s = 0; s < nseg; s += run[s]) {
         const mlsp_seg_t& g = segs[s];
@@ -458,6 +476,7 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
         for (int t = 0; t < G; ++t) if (!dW[s + t]) return MLSP_ERR_ARG;
         GemmGroups grp = {G, 1, g.Cout, 0, {nullptr, nullptr, nullptr, nullptr}};
         for (int t = 0; t < G; ++t) grp.Bg[t] = segs[s + t].W;
+        const GemmDy dy_s = {Y + ycol, coef + ycol, Ctot};
         if (dX) {
             bool acc = false;                                  // an earlier segment on the same input columns: add (partial overlaps: rejected)
             for (int t = 0; t < s; ++t) {
@@ -475,8 +494,8 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
                 bs = &bs_s;
                 for (int t = 1; t < G; ++t) if (!multi_defer_same(in[s], in[s + t])) return MLSP_ERR_UNSUPPORTED;     // (one producer description per launch)
             }
-            MCHECK(launch_gemm(st, false, false, M, G * g.Cin, g.Cout, dY + ycol, Ctot, g.W, g.ldw, dX + g.x_col, lddx, nullptr, nullptr, 0, slab, sf,
-                               nullptr, nullptr, nullptr, nullptr, acc, nullptr, 0, G > 1 ? &grp : nullptr, bs));
+            MCHECK(launch_gemm(st, false, false, M, G * g.Cin, g.Cout, gY + ycol, Ctot, g.W, g.ldw, dX + g.x_col, lddx, nullptr, nullptr, 0, slab, sf,
+                               nullptr, nullptr, nullptr, nullptr, acc, nullptr, 0, G > 1 ? &grp : nullptr, bs, use_dy ? &dy_s : nullptr));
         }
         const float* Xs = X;
         GemmXf xf_s; const GemmXf* xf = nullptr;
@@ -492,8 +511,8 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
             }
         }
         GemmGroups grw = {G, 2, 0, g.Cin, {nullptr, nullptr, nullptr, nullptr}};
-        MCHECK(launch_gemm(st, true, false, G * g.Cout, g.Cin, M, dY + ycol, Ctot, Xs + g.x_col, ldx, dW[s], g.Cin, nullptr, nullptr, 0, slab, sf,
-                           nullptr, nullptr, nullptr, nullptr, false, xf, 0, G > 1 ? &grw : nullptr));
+        MCHECK(launch_gemm(st, true, false, G * g.Cout, g.Cin, M, gY + ycol, Ctot, Xs + g.x_col, ldx, dW[s], g.Cin, nullptr, nullptr, 0, slab, sf,
+                           nullptr, nullptr, nullptr, nullptr, false, xf, 0, G > 1 ? &grw : nullptr, nullptr, use_dy ? &dy_s : nullptr));
         ycol += G * g.Cout;
     }
     if (dbias) {

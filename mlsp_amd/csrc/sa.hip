@@ -175,14 +175,15 @@ __global__ __launch_bounds__(256) void sa_group_fwd_kernel(const float* __restri
     }
 }
 
-// dfeat[b][j][:] = sum over the (i, s) with idx[b][i][s] == j of dG[(b,i,s)][3:]  -- walks the reverse index (fixed order)
-__global__ __launch_bounds__(256) void sa_group_bwd_kernel(const float* __restrict__ dG, int D, const int* __restrict__ rev_off,
+// dfeat[b][j][:] = sum over the (i, s) with idx[b][i][s] == j of dG[(b,i,s)][col : col + D]  (rows of pitch ldg) -- walks the reverse
+// index (fixed order).  col = 3: the feature columns of the grouped rows; col = 0, D = 3: their coordinate columns (d xyz).
+__global__ __launch_bounds__(256) void sa_group_bwd_kernel(const float* __restrict__ dG, int ldg, int col, int D, const int* __restrict__ rev_off,
                                                            const int* __restrict__ rev_ent, int N, int S, int ns, int P,
                                                            float* __restrict__ dfeat) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= P) return;
-    const int b = j / N, C = 3 + D;
+    const int b = j / N;
     const int e0 = rev_off[j], e1 = rev_off[j + 1];
     for (int c0 = 0; c0 < D; c0 += 64) {
         const int c = c0 + lane;
@@ -194,14 +195,14 @@ __global__ __launch_bounds__(256) void sa_group_bwd_kernel(const float* __restri
             for (int u = 0; u < 4; ++u) {
                 const int ent = rev_ent[e + u];
                 const size_t row = ((size_t)b * S + (ent >> 8)) * ns + (ent & 255);
-                t[u] = c < D ? dG[row * C + 3 + c] : 0.f;
+                t[u] = c < D ? dG[row * ldg + col + c] : 0.f;
             }
             acc += (t[0] + t[1]) + (t[2] + t[3]);
         }
         for (; e < e1; ++e) {
             const int ent = rev_ent[e];
             const size_t row = ((size_t)b * S + (ent >> 8)) * ns + (ent & 255);
-            if (c < D) acc += dG[row * C + 3 + c];
+            if (c < D) acc += dG[row * ldg + col + c];
         }
         if (c < D) dfeat[(size_t)j * D + c] = acc;
     }
@@ -242,11 +243,12 @@ int launch_sa_group_fwd(hipStream_t st, const float* xyz, int ldx, const float* 
     return mlsp_launch_status();
 }
 
-int launch_sa_group_bwd(hipStream_t st, const float* dG, int D, const int* rev_off, const int* rev_ent, int B, int N, int S, int ns,
-                        float* dfeat) {
-    if (!dG || !rev_off || !rev_ent || !dfeat || D <= 0 || B <= 0 || N <= 0 || S <= 0 || ns <= 0 || ns > 255) return MLSP_ERR_ARG;
+int launch_sa_group_bwd(hipStream_t st, const float* dG, int ldg, int col, int D, const int* rev_off, const int* rev_ent, int B, int N, int S,
+                        int ns, float* dfeat) {
+    if (!dG || !rev_off || !rev_ent || !dfeat || D <= 0 || col < 0 || ldg < col + D || B <= 0 || N <= 0 || S <= 0 || ns <= 0 || ns > 255)
+        return MLSP_ERR_ARG;
     const int P = B * N;
-    hipLaunchKernelGGL(sa_group_bwd_kernel, dim3((P + 3) / 4), dim3(256), 0, st, dG, D, rev_off, rev_ent, N, S, ns, P, dfeat);
+    hipLaunchKernelGGL(sa_group_bwd_kernel, dim3((P + 3) / 4), dim3(256), 0, st, dG, ldg, col, D, rev_off, rev_ent, N, S, ns, P, dfeat);
     return mlsp_launch_status();
 }
 

@@ -88,25 +88,43 @@ class gemm_precision(metaclass=_PrecisionMeta):
         return False
 
 
-class activation_storage:
+class _StorageMeta(type):
+    @property
+    def current(cls):
+        """the storage mode the calling thread's next forward uses"""
+        return getattr(cls._tls, "mode", None) or cls.default
+
+
+class activation_storage(metaclass=_StorageMeta):
     """Context manager / switch for how the per-point MLP stacks keep their activations in HBM: "fp32" (default; the parity contract
     of the fp32 configs) or "bf16" (BASELINE.json configs[4]: Y / Z of chained Linear+BN+act layers and their gradients are stored as
     bf16, bf16 x bf16 products with fp32 accumulation; weights, BN statistics, kNN distances, reductions, losses stay fp32).
-    Layers opt in with pointmlp(..., chain=True) (their consumer is another pointmlp); shapes the bf16 kernels do not cover stay fp32."""
-    current = "fp32"
+    Layers opt in with pointmlp(..., chain=True) (their consumer is another pointmlp); shapes the bf16 kernels do not cover stay fp32.
+
+    Scoped like gemm_precision: `with activation_storage(mode):` applies to the forwards the CALLING THREAD runs inside the block,
+    `activation_storage.set(mode)` changes the process default (what nn.DataParallel replica threads see) -- the two switches are always
+    read from the same place, so a replica thread never combines one thread's precision with another's storage."""
+    default = "fp32"
+    _tls = threading.local()
 
     def __init__(self, mode):
         if mode not in ("fp32", "bf16"):
             raise ValueError("storage must be 'fp32' or 'bf16'")
         self.mode, self.prev = mode, None
 
+    @classmethod
+    def set(cls, mode):
+        if mode not in ("fp32", "bf16"):
+            raise ValueError("storage must be 'fp32' or 'bf16'")
+        cls.default = mode
+
     def __enter__(self):
-        self.prev = activation_storage.current
-        activation_storage.current = self.mode
+        self.prev = getattr(activation_storage._tls, "mode", None)
+        activation_storage._tls.mode = self.mode
         return self
 
     def __exit__(self, *exc):
-        activation_storage.current = self.prev
+        activation_storage._tls.mode = self.prev
         return False
 
 
@@ -990,6 +1008,10 @@ class _PointMLP(Function):
             bias = bias.contiguous()
         p = float(p_drop) if training else 0.0
         ws, wsn = _lib.workspace(dev, M, Cin, Cout)
+        # a deferred layer with a per-cloud bias whose consumers leave its BatchNorm-backward sums: the backward may never form dY, and
+        # then takes the per-cloud bias gradient from those sums and the clouds' column sums of Y -- which the forward has at hand
+        ysum = (torch.empty((gbias.shape[0], Cout), dtype=torch.float32, device=dev)
+                if (gbias is not None and defer_out and training and out_stats is not None and _FUSE_BWD_STATS and M > 32) else None)
         if mx:
             _lib.check(lib.mlsp_pointmlp_fwd_mx(
                 X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
@@ -1001,13 +1023,13 @@ class _PointMLP(Function):
             _lib.check(lib.mlsp_pointmlp_fwd_chain_f32(
                 X.data_ptr(), X.stride(0), _lib._c.byref(ds), M, Cin, W.data_ptr(), W.stride(0), Cout,
                 _lib.ptr(bias), _lib.ptr(gbias), int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean),
-                _lib.ptr(run_var), momentum, eps, int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), prec, ws, wsn,
-                _lib.stream()), "mlsp_pointmlp_fwd_chain_f32")
+                _lib.ptr(run_var), momentum, eps, int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), _lib.ptr(ysum),
+                prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_fwd_chain_f32")
         else:
             _lib.check(lib.mlsp_pointmlp_fwd_f32(
                 X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
                 int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
-                int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), prec, ws, wsn, _lib.stream()),
+                int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), _lib.ptr(ysum), prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_fwd_f32")
         ctx.in_def = in_def
         # fused BatchNorm-backward sums (BwdStats): as a consumer, promise the producer this layer's input columns (with the panel count
@@ -1020,7 +1042,7 @@ class _PointMLP(Function):
                 parts = _stats_parts(("p", M, Cin, Cout, W.stride(0), lddx, prec), lambda: lib.mlsp_pointmlp_bwd_stats_parts(M, Cin, Cout, W.stride(0), lddx, prec))
             in_stats.promise(in_def[2], Cin, parts)
             ctx.in_stats = in_stats
-        ctx.save_for_backward(X, W, Y, bn_save)
+        ctx.save_for_backward(X, W, Y, bn_save, ysum)
         ctx.cfg = (has_bn, training, act, slope, p, seed, bias is not None, gbias.shape[0] if gbias is not None else 0,
                    int(rows_per_group))
         ctx.grad_accum = grad_accum
@@ -1037,7 +1059,7 @@ class _PointMLP(Function):
         if dZ is None:
             return (None,) * 23
         lib = _lib.load()
-        X, W, Y, bn_save = ctx.saved_tensors
+        X, W, Y, bn_save, ysum = ctx.saved_tensors
         has_bn, training, act, slope, p, seed, has_bias, G, rpg = ctx.cfg
         mx, x_bf16, out_bf16 = ctx.mx
         dZ = dZ.contiguous()
@@ -1078,14 +1100,14 @@ class _PointMLP(Function):
             _lib.check(lib.mlsp_pointmlp_bwd_chain_f32(
                 dZ.data_ptr(), X.data_ptr(), X.stride(0), _lib._c.byref(ds), M, Cin, W.data_ptr(), W.stride(0),
                 Cout, _lib.ptr(Y), _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
-                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ins), pre_ptr, pre_n, ctx.prec, ws, wsn,
-                _lib.stream()), "mlsp_pointmlp_bwd_chain_f32")
+                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ins), pre_ptr, pre_n, _lib.ptr(ysum),
+                ctx.prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_bwd_chain_f32")
         else:
             _lib.check(lib.mlsp_pointmlp_bwd_f32(
                 dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
                 _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate, dW.data_ptr(),
-                _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), pre_ptr, pre_n, ctx.prec, ws, wsn, _lib.stream()),
-                "mlsp_pointmlp_bwd_f32")
+                _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), pre_ptr, pre_n, _lib.ptr(ysum), ctx.prec, ws, wsn,
+                _lib.stream()), "mlsp_pointmlp_bwd_f32")
         return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 17
 
 

@@ -124,6 +124,8 @@ class _Group(Function):
     @staticmethod
     def forward(ctx, xyz, new_xyz, feat, idx):
         lib = _lib.load()
+        # (the reference subtracts every coordinate channel; its callers pass xyz [B, N, 3]: wider coordinates are not implemented)
+        assert xyz.shape[-1] == 3 and new_xyz.shape[-1] == 3, "grouping takes 3-column coordinates"
         x, q = _xyz_rows(xyz), _xyz_rows(new_xyz)
         B, N, _ = x.shape
         S, ns = idx.shape[1], idx.shape[2]
@@ -157,20 +159,15 @@ class _Group(Function):
                        "mlsp_group_reverse")
         if need_f:
             dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
-            _lib.check(lib.mlsp_sa_group_bwd_f32(dG.data_ptr(), D, rev_off.data_ptr(), rev_ent.data_ptr(), B, N, S, ns, dfeat.data_ptr(),
-                                                 _lib.stream()), "mlsp_sa_group_bwd_f32")
+            _lib.check(lib.mlsp_sa_group_bwd_f32(dG.data_ptr(), 3 + D, 3, D, rev_off.data_ptr(), rev_ent.data_ptr(), B, N, S, ns,
+                                                 dfeat.data_ptr(), _lib.stream()), "mlsp_sa_group_bwd_f32")
         if need_x:
-            # d xyz_j = sum of the coordinate columns over the groups j sits in: the same reverse-index gather, with the three
-            # coordinate columns standing where the kernel expects feature columns (rows [. . . | dx dy dz])
-            gx = torch.zeros((B * S * ns, 6), dtype=torch.float32, device=dev)
-            gx[:, 3:] = dG[:, :3]
-            d3 = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
-            _lib.check(lib.mlsp_sa_group_bwd_f32(gx.data_ptr(), 3, rev_off.data_ptr(), rev_ent.data_ptr(), B, N, S, ns, d3.data_ptr(),
-                                                 _lib.stream()), "mlsp_sa_group_bwd_f32")
-            dxyz = d3 if Cx == 3 else torch.nn.functional.pad(d3, (0, Cx - 3))
+            # d xyz_j = sum of the coordinate columns over the groups j sits in: the same reverse-index gather on columns 0..2 of dG, in place
+            dxyz = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+            _lib.check(lib.mlsp_sa_group_bwd_f32(dG.data_ptr(), 3 + D, 0, 3, rev_off.data_ptr(), rev_ent.data_ptr(), B, N, S, ns,
+                                                 dxyz.data_ptr(), _lib.stream()), "mlsp_sa_group_bwd_f32")
         if need_q:
-            d3 = -dG[:, :3].reshape(B, S, ns, 3).sum(2)       # every slot of a group subtracts its centre
-            dq = d3 if Cq == 3 else torch.nn.functional.pad(d3, (0, Cq - 3))
+            dq = -dG[:, :3].reshape(B, S, ns, 3).sum(2)       # every slot of a group subtracts its centre
         return dxyz, dq, dfeat, None
 
 

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
         import ctypes
         for kind, ct in zip(kinds, _lib.SIGNATURES[name]):
             assert (ct is ctypes.c_void_p) == (kind == "p"), (name, args)
-    assert lib.mlsp_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.mlsp_abi_version() == _lib.ABI_VERSION == 11
     assert b"workspace" in lib.mlsp_strerror(-2)
     assert lib.mlsp_workspace_bytes(32768, 512, 1024) > 32768 * 1024 * 4
 
@@ -247,6 +247,35 @@ def test_gemm_precision_is_per_thread_and_saved_per_call():
         assert Fh.gemm_precision.current == "fp32"
     finally:
         Fh.gemm_precision.set(base)
+
+
+def test_activation_storage_is_scoped_like_gemm_precision():
+    """the two switches are read from the same place -- a `with` block is the calling thread's, set() the process default that
+    nn.DataParallel replica threads see -- so a replica never combines one thread's precision with another thread's storage."""
+    import threading
+    from mlsp_amd import functional as Fh
+    seen = {}
+
+    def other():
+        seen["other"] = (Fh.gemm_precision.current, Fh.activation_storage.current)
+    with Fh.gemm_precision("bf16"), Fh.activation_storage("bf16"):
+        assert Fh.activation_storage.current == "bf16"
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+    assert Fh.activation_storage.current == "fp32"
+    assert seen["other"] == (Fh.gemm_precision.default, "fp32")           # neither half of the main thread's block leaked
+    base_p = Fh.gemm_precision.default
+    Fh.gemm_precision.set("bf16"); Fh.activation_storage.set("bf16")
+    try:
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert seen["other"] == ("bf16", "bf16")                          # the defaults reach every thread together
+    finally:
+        Fh.gemm_precision.set(base_p); Fh.activation_storage.set("fp32")
+    with pytest.raises(ValueError):
+        Fh.activation_storage.set("fp16")
 
 
 def test_gemm_precision_default_and_env_override():

@@ -942,14 +942,16 @@ def test_tnet_backward_gram_form_vs_round1_kernel(dev, B, N, k):
 
 @pytest.mark.parametrize("fused_stats", [False, True])
 @pytest.mark.parametrize("mode", ["fp32", "bf16x6"])
-@pytest.mark.parametrize("M,C0,C1,C2,training", [(4096, 128, 256, 128, True), (8192, 512, 256, 256, True), (1000, 96, 80, 64, True),
-                                                 (4096, 128, 256, 128, False), (16384, 256, 1024, 512, True), (2048, 512, 512, 256, True)])
-def test_pointmlp_deferred_activation_chain(dev, M, C0, C1, C2, training, mode, fused_stats, monkeypatch):
+@pytest.mark.parametrize("M,C0,C1,C2,training,clouds", [(4096, 128, 256, 128, True, 0), (8192, 512, 256, 256, True, 0), (1000, 96, 80, 64, True, 0),
+                                                        (4096, 128, 256, 128, False, 0), (16384, 256, 1024, 512, True, 0),
+                                                        (2048, 512, 512, 256, True, 0), (8192, 128, 256, 256, True, 8), (4096, 64, 512, 256, True, 16)])
+def test_pointmlp_deferred_activation_chain(dev, M, C0, C1, C2, training, clouds, mode, fused_stats, monkeypatch):
     """pointmlp(..., chain=True) under fp32 storage hands its PRE-BN output to the next layer, which applies BN + ReLU + dropout in
     its GEMM operand loads (forward: A rows, wgrad: the k-major B operand) -- gemm_split_kernel<.., XF, XD> in mode "bf16x6", the f32
     transform kernels in mode "fp32" and on short K loops, the streaming kernels of thin.hip for the 3-channel output layer --
     BIT-IDENTICAL to the materialised path: the staged values are computed by the same expressions, the products by the same kernels.
-    The third case is outside the interior-tile path (one streaming pass into the workspace instead)."""
+    The third case is outside the interior-tile path (one streaming pass into the workspace instead).  clouds > 0: the first layer takes a
+    per-cloud bias row (the heads' first layer: Models.py:192); with fused statistics its gradient comes from the row-panel sums."""
     Fh = _fh()
     import itertools as it
 
@@ -963,18 +965,20 @@ def test_pointmlp_deferred_activation_chain(dev, M, C0, C1, C2, training, mode, 
         gb = [(_rand((C1,), 5) + 0.3), _rand((C1,), 6), (_rand((C2,), 7) + 0.3), _rand((C2,), 8)]
         leaves = [t.to(dev).requires_grad_(True) for t in ts + gb]
         X, W1, W2, W3, g1, b1, g2, b2 = leaves
+        cb = _rand((clouds, C1), 10).to(dev).requires_grad_(True) if clouds else None
         rs = [torch.zeros(C1, device=dev), torch.ones(C1, device=dev), torch.zeros(C2, device=dev), torch.ones(C2, device=dev)]
-        h = Fh.pointmlp(X, W1, gamma=g1, beta=b1, run_mean=rs[0], run_var=rs[1], training=training, act=Fh.ACT_RELU, p_drop=0.5, chain=True)
+        h = Fh.pointmlp(X, W1, gbias=cb, rows_per_group=M // clouds if clouds else 0, gamma=g1, beta=b1, run_mean=rs[0], run_var=rs[1],
+                        training=training, act=Fh.ACT_RELU, p_drop=0.5, chain=True)
         assert isinstance(h, Fh.DeferredAct) == bool(defer)
         h = Fh.pointmlp(h, W2, gamma=g2, beta=b2, run_mean=rs[2], run_var=rs[3], training=training, act=Fh.ACT_LRELU, slope=0.2, p_drop=0.3,
                         chain=True)
         out = Fh.pointmlp(h, W3, training=training)
         out.backward(_rand((M, 3), 9).to(dev))
-        return [out.detach().cpu()] + [t.grad.cpu() for t in leaves] + [r.cpu() for r in rs]
+        return [out.detach().cpu()] + [t.grad.cpu() for t in leaves] + [r.cpu() for r in rs] + ([cb.grad.cpu()] if clouds else [])
 
     with Fh.gemm_precision(mode):
         a, b = run(True), run(False)
-    names = ["out", "dX", "dW1", "dW2", "dW3", "dg1", "db1", "dg2", "db2", "rm1", "rv1", "rm2", "rv2"]
+    names = ["out", "dX", "dW1", "dW2", "dW3", "dg1", "db1", "dg2", "db2", "rm1", "rv1", "rm2", "rv2", "dcloudbias"]
     for n, x, y in zip(names, a, b):
         if not fused_stats or n in ("out", "rm1", "rv1", "rm2", "rv2"):
             assert torch.equal(x, y), (n, (x - y).abs().max().item())
