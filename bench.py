@@ -123,6 +123,15 @@ def make_seg_args():
                               Density_weight=0.05)
 
 
+def make_adam(params):
+    """optim.Adam(model.parameters(), lr, weight_decay) of PointDA/trainer.py:258-259 -- as mlsp_amd.optim.FlatAdam (the same fused kernel
+    over flat parameter / gradient / moment buffers: one launch, bit-identical parameters); MLSP_BENCH_TORCH_ADAM=1: torch's own, for A/B."""
+    if os.environ.get("MLSP_BENCH_TORCH_ADAM"):
+        return torch.optim.Adam(params, lr=1e-3, weight_decay=5e-5, fused=True)
+    from mlsp_amd.optim import FlatAdam
+    return FlatAdam(params, lr=1e-3, weight_decay=5e-5)
+
+
 def gpu_step(model, mlsp, args, batch, opt):
     """zero_grad -> forward (all three heads) -> position + normal + cardinality losses -> backward -> step
     (PointDA/trainer.py:542-571, target branch)."""
@@ -355,7 +364,7 @@ def secondary_workloads(lib, dev):
     seg = seg_models.DGCNN_DefRec(make_seg_args(), in_size=3, num_classes=8)
     seg.k = seg.shared_layers.k = K
     seg = seg.to(dev).train()
-    opt = torch.optim.Adam(seg.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+    opt = make_adam(seg.parameters())
     x = torch.rand(B, 3, N, device=dev) * 2 - 1
     w = {k: torch.randn(sh, device=dev) for k, sh in (("seg", (B, N, 8)), ("DefRec", (B, N, 3)), ("Normal", (B, N, 3)),
                                                       ("density", (B * N, 16)), ("density_mse", (B * N,)))}
@@ -408,7 +417,7 @@ def trainer_shaped_workload(dev, steps=10, repeats=3):
         torch.manual_seed(0)
         np.random.seed(0)
         model = DGCNN(args).to(dev).train()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+        opt = make_adam(model.parameters())
         criterion = torch.nn.CrossEntropyLoss()
         lookup = torch.Tensor(pc_utils.region_mean(3)).to(dev)
         B, N = B_PER_GPU, NPTS
@@ -641,8 +650,9 @@ def main():
     args = make_args()
     torch.manual_seed(0)                                   # identical replicas on every rank
     model = Models.DGCNN(args).to(dev).train()
-    sync = FlatGradSync(model)
-    opt = sync.wrap(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, fused=True))   # trainer.py:258-259
+    from mlsp_amd.optim import FlatAdam
+    sync = FlatGradSync(model, align=FlatAdam.ALIGN)        # the bucket doubles as the optimizer's flat gradient buffer
+    opt = sync.wrap(make_adam(model.parameters()))                                            # trainer.py:258-259
     batch = synth_batch(b_local, NPTS, dev, seed=1000 + rank)
 
     def one_step():

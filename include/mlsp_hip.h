@@ -400,6 +400,14 @@ int mlsp_profile_classes(double* out, int ncls);
 /* out [3][4]: {ms, launches, algorithmic FLOP, algorithmic bytes} of the bracket's gemm_split_kernel launches by kind (forward, dgrad, wgrad). */
 int mlsp_profile_split_kinds(double* out);
 
+/* Adam step (PointDA/trainer.py:258-259, stepped at :571) over flat parameter / exp_avg / exp_avg_sq buffers P / M / V in ONE launch:
+ * segment s covers elements [off[s], off[s] + numel[s]) of the three buffers (off % 4 == 0, buffers 16-byte aligned) and reads its
+ * gradient where autograd left it (grads[s], contiguous fp32, device).  off / numel / grads are HOST arrays.  step >= 1 numbers this
+ * update (bias corrections 1 - beta^step); step_out (nullable, device float) receives it.  The element-wise arithmetic restates
+ * torch's fused Adam (ATen/native/cuda/fused_adam_utils.cuh, ADAM_MODE::ORIGINAL: weight decay added to the gradient) type by type. */
+int mlsp_adam_flat_f32(float* P, float* M, float* V, const uint32_t* off, const uint32_t* numel, const float* const* grads, int nseg, double lr,
+                       double beta1, double beta2, double weight_decay, double eps, int64_t step, float* step_out, mlsp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

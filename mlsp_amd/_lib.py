@@ -16,10 +16,12 @@ ABI_VERSION = 11
 
 _c = ctypes
 _P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
+_D, _I64 = _c.c_double, _c.c_int64
 
 # name -> argtypes (restype is int unless listed in _RESTYPE)
 SIGNATURES = {
     "mlsp_abi_version": [],
+    "mlsp_adam_flat_f32": [_P, _P, _P, _P, _P, _P, _I, _D, _D, _D, _D, _D, _I64, _P, _P],
     "mlsp_strerror": [_I],
     "mlsp_workspace_bytes": [_I, _I, _I],
     "mlsp_knn_f32": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _SZ, _P],

@@ -45,23 +45,23 @@ class FlatGradSync:
 
     _NCHK = 4                                 # trailing bucket elements of the uniform-presence check: h1, h1^2, h2, h2^2
 
-    def __init__(self, model, process_group=None, force=False, presence="uniform"):
+    def __init__(self, model, process_group=None, force=False, presence="uniform", align=1):
+        # align: every gradient starts on a multiple of `align` elements of the bucket (zero padding between them).  align =
+        # mlsp_amd.optim.FlatAdam.ALIGN gives the bucket the layout of that optimizer's flat buffers: it then steps straight out of it.
         if presence not in ("uniform", "exchange"):
             raise ValueError("presence must be 'uniform' or 'exchange'")
+        from .optim import flat_offsets
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.group = process_group
         self.force = bool(force)
         self.presence_mode = presence
-        self.numel = sum(p.numel() for p in self.params)
+        self.numel = sum(p.numel() for p in self.params)      # gradients exchanged (the bucket may hold padding on top)
+        self.offsets, padded = flat_offsets(self.params, int(align))
         dev = self.params[0].device
-        self._bucket = torch.zeros(self.numel + self._NCHK, dtype=torch.float32, device=dev)
-        self.flat = self._bucket[:self.numel]                 # the gradients; the check words sit behind them in the same allocation
-        self._chk = self._bucket[self.numel:]
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        self._bucket = torch.zeros(padded + self._NCHK, dtype=torch.float32, device=dev)
+        self.flat = self._bucket[:padded]                     # the gradients; the check words sit behind them in the same allocation
+        self._chk = self._bucket[padded:]
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
         self.collectives = 0                  # device all-reduces issued so far (tests count them)
         self.host_group = None
         self._pending = None                  # (host copy of the summed check words, event | None, world size) of the previous step
@@ -162,4 +162,6 @@ class FlatGradSync:
         if not getattr(optimizer, "_mlsp_flat_sync", None):
             optimizer.register_step_pre_hook(lambda *_a, **_k: (self.allreduce(), None)[1])
             optimizer._mlsp_flat_sync = self
+            if hasattr(optimizer, "adopt_grad_buffer"):       # mlsp_amd.optim.FlatAdam: the bucket doubles as its flat gradient buffer
+                optimizer.adopt_grad_buffer(self.flat, self.params, self.offsets)
         return optimizer

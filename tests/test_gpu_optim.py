@@ -1,0 +1,121 @@
+"""mlsp_amd.optim.FlatAdam against torch.optim.Adam(fused=True): the optimizer of PointDA/trainer.py:258-260 (Adam + weight decay +
+CosineAnnealingLR) as one launch over flat buffers -- the same element-wise arithmetic restated type by type: bit-identical."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+class _Net(nn.Module):
+    """a used trunk, a head that never runs (DGCNN.Rec_scan in the default modes: no gradient, never stepped) and a late head"""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(37, 129)
+        self.bn = nn.BatchNorm1d(129)
+        self.unused = nn.Linear(129, 5)
+        self.b = nn.Linear(129, 70001 // 129)       # a tensor that does not end on a chunk boundary
+        self.late = nn.Linear(129, 3)
+
+    def forward(self, x, late=False):
+        h = torch.relu(self.bn(self.a(x)))
+        out = self.b(h).sum()
+        return out + self.late(h).sum() if late else out
+
+
+def _pair(dev):
+    torch.manual_seed(3)
+    m1 = _Net().to(dev)
+    m2 = copy.deepcopy(m1)
+    return m1, m2
+
+
+def _same(m1, m2):
+    """bit-identical: csrc/optim.hip restates torch's element-wise update with its types AND its lowering (tools/r5/adam_probe)"""
+    for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
+        assert torch.equal(p, q), (n, (p != q).sum().item(), p.numel())
+
+
+def test_flat_adam_is_bit_identical_to_fused_adam(dev):
+    from mlsp_amd.optim import FlatAdam
+    m1, m2 = _pair(dev)
+    o1 = FlatAdam(m1.parameters(), lr=1e-3, weight_decay=5e-5)
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+    s1 = torch.optim.lr_scheduler.CosineAnnealingLR(o1, 10)
+    s2 = torch.optim.lr_scheduler.CosineAnnealingLR(o2, 10)
+    for it in range(6):
+        x = torch.randn(64, 37, device=dev, generator=torch.Generator(device=dev).manual_seed(it))
+        for m, o, s in ((m1, o1, s1), (m2, o2, s2)):
+            o.zero_grad()
+            m(x).backward()
+            o.step()
+            s.step()
+        _same(m1, m2)
+    assert o1.flat_steps == 6
+    # the model lives in ONE buffer, the head that never ran has no state and did not move
+    ptrs = sorted((p.data_ptr(), p.numel()) for p in m1.parameters())
+    assert all(a + 4 * n <= b < a + 4 * n + 4 * FlatAdam.ALIGN and b % 256 == 0 for (a, n), (b, _) in zip(ptrs, ptrs[1:]))
+    assert m1.unused.weight not in o1.state or not o1.state[m1.unused.weight]
+    assert m1.late.weight not in o1.state or not o1.state[m1.late.weight]
+    # state_dict round trip through a fresh optimizer, then more steps on both sides
+    sd = copy.deepcopy(o1.state_dict())
+    o3 = FlatAdam(m1.parameters(), lr=1e-3, weight_decay=5e-5)
+    o3.load_state_dict(sd)
+    for it in range(6, 9):
+        x = torch.randn(64, 37, device=dev, generator=torch.Generator(device=dev).manual_seed(it))
+        for m, o in ((m1, o3), (m2, o2)):
+            o.zero_grad()
+            m(x).backward()
+            o.step()
+        _same(m1, m2)
+    assert o3.flat_steps == 3
+    for p, q in zip(m1.parameters(), m2.parameters()):
+        if q in o2.state and o2.state[q]:
+            assert float(o3.state[p]["step"]) == float(o2.state[q]["step"])
+            assert torch.equal(o3.state[p]["exp_avg_sq"], o2.state[q]["exp_avg_sq"])
+
+
+def test_flat_adam_falls_back_when_the_stepped_set_changes(dev):
+    """a head that starts running later gets its own step counter in torch: the flat step (one shared counter) hands over to torch's
+    per-tensor path on the same storage, and stays bit-identical"""
+    from mlsp_amd.optim import FlatAdam
+    m1, m2 = _pair(dev)
+    o1 = FlatAdam(m1.parameters(), lr=2e-3, weight_decay=1e-4)
+    o2 = torch.optim.Adam(m2.parameters(), lr=2e-3, weight_decay=1e-4, fused=True)
+    for it in range(5):
+        x = torch.randn(32, 37, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + it))
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            m(x, late=it >= 2).backward()
+            o.step()
+        _same(m1, m2)
+    assert o1.flat_steps == 2
+    assert float(o1.state[m1.late.weight]["step"]) == 3.0 and float(o1.state[m1.a.weight]["step"]) == 5.0
+
+
+def test_flat_adam_shares_the_exchange_bucket(dev):
+    """with FlatGradSync the exchange's bucket IS the optimizer's gradient buffer: one pack per step, no second copy"""
+    from mlsp_amd.ddp import FlatGradSync
+    from mlsp_amd.optim import FlatAdam
+    m1, m2 = _pair(dev)
+    sync = FlatGradSync(m1, force=True, align=FlatAdam.ALIGN)
+    o1 = sync.wrap(FlatAdam(m1.parameters(), lr=1e-3, weight_decay=5e-5))
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+    for it in range(3):
+        x = torch.randn(64, 37, device=dev, generator=torch.Generator(device=dev).manual_seed(it))
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            m(x).backward()
+            o.step()
+        _same(m1, m2)
+    assert o1.flat_steps == 3 and o1._flat["g"].data_ptr() == sync.flat.data_ptr()
