@@ -38,10 +38,12 @@ def _linear_act(X, W, bias, act):
                        act=act, slope=0.2, eps=0.0)
 
 
-def _edge_linear_max(xp, graph, W, bias):
-    """max over k of (W [x_j - x_i ; x_i] + bias): folded EdgeConv with identity BN, no activation."""
+def _edge_linear_max(xp, graph, W, bias, out=None, grad_accum=None):
+    """max over k of (W [x_j - x_i ; x_i] + bias): folded EdgeConv with identity BN, no activation.  `out` / `grad_accum`: as
+    functional.edgeconv (the result written into a column slice of the concatenation, the input gradient added into a shared buffer)."""
     ones, zeros, rm, rv = _identity_bn(W.shape[0], xp.device)
-    return Fh.edgeconv(xp, graph, W, ones, bias if bias is not None else zeros, rm, rv, False, act=Fh.ACT_NONE, eps=0.0)
+    return Fh.edgeconv(xp, graph, W, ones, bias if bias is not None else zeros, rm, rv, False, act=Fh.ACT_NONE, eps=0.0, out=out,
+                       grad_accum=grad_accum)
 
 
 class conv_2d(nn.Module):
@@ -175,19 +177,36 @@ class shared_layers(nn.Module):
         Wb = cb.weight.view(cb.out_channels, cb.in_channels)
         return Wb @ Wa, Wb @ ca.bias + cb.bias
 
-    def points(self, xp, B, N):
-        g = Fh.knn_graph(xp, B, N, self.k)
-        W, b = self._compose(self.conv1, self.conv2)
-        x1 = _edge_linear_max(xp, g, W, b)
-        g = Fh.knn_graph(x1, B, N, self.k)
-        W, b = self._compose(self.conv3, self.conv4)
-        x2 = _edge_linear_max(x1, g, W, b)
-        g = Fh.knn_graph(x2, B, N, self.k)
-        x3 = _edge_linear_max(x2, g, self.conv5.weight.view(self.of5, -1), self.conv5.bias)
-        x123 = torch.cat((x1, x2, x3), dim=1)                                     # [P,192]
+    def points(self, xp, B, N, consumers=0):
+        """-> (x123 [P,192], x5 [B,1024]); consumers = n > 0: -> ([n aliases of x123], x5, SharedInputGrad) for n heads that take
+        `grad_accum=` -- conv6 and the heads then sum their input gradients in ONE buffer through the beta = 1 epilogue of their dgrad
+        instead of n element-wise adds of the autograd engine (as mlsp_amd/Models.py does for the PointDA model)."""
+        # the three EdgeConv stages write their outputs straight into the column slices of the [P,192] concatenation (Models.py:186): no
+        # torch.cat pass forward, no split copies backward; stage l+1 adds its input gradient into stage l's slice of that gradient
+        stages = ((self.conv1, self.conv2, self.of1), (self.conv3, self.conv4, self.of3), (self.conv5, None, self.of5))
+        buf = torch.empty((xp.shape[0], self.of1 + self.of3 + self.of5), dtype=torch.float32, device=xp.device)
+        feats, accs, h, col, acc_in = [], [], xp, 0, None
+        for li, (ca, cb, w) in enumerate(stages):
+            g = Fh.knn_graph(h, B, N, self.k)
+            W, b = self._compose(ca, cb) if cb is not None else (ca.weight.view(w, -1), ca.bias)
+            out = _edge_linear_max(h, g, W, b, out=buf[:, col:col + w], grad_accum=acc_in)
+            if li + 1 < len(stages):
+                (to_cat, h), acc_in = Fh.fan_out(out, 2)
+            else:
+                to_cat, acc_in = out, None
+            feats.append(to_cat)
+            accs.append(acc_in)
+            col += w
+        x123 = Fh.join_columns(buf, feats, accs)                                   # [P,192]
         ones, zeros, rm, rv = _identity_bn(self.of6, xp.device)
+        acc = None
+        if consumers > 0:
+            aliases, acc = Fh.fan_out(x123, 1 + consumers)
+            x123 = aliases[0]
         x5 = Fh.pointmlp_colmax(x123, self.conv6.weight.view(self.of6, -1), ones, self.conv6.bias, rm, rv, B, N, training=False,
-                                act=Fh.ACT_NONE, eps=0.0)                          # conv6 + adaptive_max_pool1d
+                                act=Fh.ACT_NONE, eps=0.0, grad_accum=acc)          # conv6 + adaptive_max_pool1d
+        if consumers > 0:
+            return list(aliases[1:]), x5, acc
         return x123, x5
 
     def layers_sum(self):
@@ -201,22 +220,25 @@ class shared_layers(nn.Module):
         return x123.view(B, N, -1).permute(0, 2, 1), x5.unsqueeze(2)
 
 
-def _head_bn_layer(X, conv, bn, training, p_drop=0.0, gbias=None, rows_per_group=0, W=None, chain=False):
+def _head_bn_layer(X, conv, bn, training, p_drop=0.0, gbias=None, rows_per_group=0, W=None, chain=False, grad_accum=None):
     rm, rv = _bn_buffers(bn, training)
     if W is None:
         W = conv.weight.view(conv.out_channels, conv.in_channels)
     return Fh.pointmlp(X, W, bias=conv.bias, gbias=gbias, gamma=bn.weight, beta=bn.bias, run_mean=rm, run_var=rv,
                        rows_per_group=rows_per_group, training=training, act=Fh.ACT_RELU, slope=0.2, p_drop=p_drop,
-                       momentum=bn.momentum, eps=bn.eps, chain=chain)
+                       momentum=bn.momentum, eps=bn.eps, chain=chain, grad_accum=grad_accum)
 
 
-def _first_layer(head, x_cat, x5, N, p_drop):
-    """conv1 on cat(x123, x5 repeated): the x5 half enters as a per-cloud bias (see mlsp_amd/Models.py)."""
+def _first_layer(head, x_cat, x5, N, p_drop, grad_accum=None):
+    """conv1 on cat(x123, x5 repeated): the x5 half enters as a per-cloud bias (see mlsp_amd/Models.py).  grad_accum = (SharedInputGrad
+    of x_cat's fan_out, SharedInputGrad of x5's) or None."""
     W = head.conv1.weight.view(head.conv1.out_channels, head.conv1.in_channels)
     Cc = x_cat.shape[1]
     Wc, W5 = Fh.split_columns(W, Cc)
-    gb = Fh.pointmlp(x5, W5, training=head.training)
-    return _head_bn_layer(x_cat, head.conv1, head.bn1, head.training, p_drop=p_drop, gbias=gb, rows_per_group=N, W=Wc, chain=True)
+    acc_cat, acc5 = grad_accum if grad_accum is not None else (None, None)
+    gb = Fh.pointmlp(x5, W5, training=head.training, grad_accum=acc5)
+    return _head_bn_layer(x_cat, head.conv1, head.bn1, head.training, p_drop=p_drop, gbias=gb, rows_per_group=N, W=Wc, chain=True,
+                          grad_accum=acc_cat)
 
 
 class _BnHead(nn.Module):
@@ -241,8 +263,8 @@ class _BnHead(nn.Module):
         h = Fh.pointmlp(h, self.conv4.weight.view(self.conv4.out_channels, self.of3), bias=self.conv4.bias, training=self.training)
         return h.view(B, N, -1)
 
-    def rows(self, x_cat, x5, B, N):
-        return self._tail(_first_layer(self, x_cat, x5, N, self.dp1.p), B, N)
+    def rows(self, x_cat, x5, B, N, grad_accum=None):
+        return self._tail(_first_layer(self, x_cat, x5, N, self.dp1.p, grad_accum), B, N)
 
     @flushing_forward
     def forward(self, x):
@@ -302,8 +324,8 @@ class Density_prediction(nn.Module):
         logits = Fh.pointmlp(h, self.mlp3.weight, bias=self.mlp3.bias, training=self.training)
         return Fh.density_tail(logits, self.fc2.weight)
 
-    def rows(self, x_cat, x5, B, N):
-        return self._tail(_first_layer(self, x_cat, x5, N, self.dp1.p))
+    def rows(self, x_cat, x5, B, N, grad_accum=None):
+        return self._tail(_first_layer(self, x_cat, x5, N, self.dp1.p, grad_accum))
 
     @flushing_forward
     def forward(self, x):
@@ -337,17 +359,29 @@ class DGCNN_DefRec(nn.Module):
         g0 = Fh.knn_graph(xp0, B, N, self.k)
         T = self.input_transform_net.points(xp0, g0, B, N, self.k)                 # [B,3,3]
         xp = Fh.apply_transform(xp0, T) if C == 3 else torch.bmm(xp0.view(B, N, C), T.transpose(1, 2)).view(B * N, C)   # (T @ x)^T
-        x123, x5 = self.shared_layers.points(xp, B, N)
+        # every head reads x123 and x5: the calls below are the reference's (Models.py:226-241, DefRec computed twice when both of its flags
+        # are set, the first result overwritten); each gets its own alias of the two inputs and all of them sum their input gradients in one
+        # buffer per input (functional.fan_out / SharedInputGrad) instead of one element-wise add per head in backward
+        calls = []
         if make_seg:
-            logits["seg"] = self.seg.rows(x123, x5, B, N)
+            calls.append(("seg", self.seg))
         if activate_DefRec:
-            logits["DefRec"] = self.DefRec.rows(x123, x5, B, N)
+            calls.append(("DefRec", self.DefRec))
         if activate_normal:
-            logits["Normal"] = self.Norm_pred.rows(x123, x5, B, N)
+            calls.append(("Normal", self.Norm_pred))
         if activate_density:
-            logits['density'], logits['density_mse'] = self.Density_cls.rows(x123, x5, B, N)
+            calls.append(("density", self.Density_cls))
         if activate_density_normal_ondef:
-            logits["DefRec"] = self.DefRec.rows(x123, x5, B, N)
-            logits['density'], logits['density_mse'] = self.Density_cls.rows(x123, x5, B, N)
-            logits["Normal"] = self.Norm_pred.rows(x123, x5, B, N)
+            calls += [("DefRec", self.DefRec), ("density", self.Density_cls), ("Normal", self.Norm_pred)]
+        if not calls:
+            self.shared_layers.points(xp, B, N)
+            return logits
+        xs, x5, acc = self.shared_layers.points(xp, B, N, consumers=len(calls))
+        x5s, acc5 = Fh.fan_out(x5, len(calls))
+        for (key, head), xa, x5a in zip(calls, xs, x5s):
+            out = head.rows(xa, x5a, B, N, grad_accum=(acc, acc5))
+            if key == "density":
+                logits['density'], logits['density_mse'] = out
+            else:
+                logits[key] = out
         return logits

@@ -13,7 +13,11 @@ B, N, K = int(os.environ.get("C4_B", 16)), 2048, int(os.environ.get("C4_K", 40))
 seg = seg_models.DGCNN_DefRec(gc.make_seg_args(dropout=0.5, gpu=True), in_size=3, num_classes=8)
 seg.k = seg.shared_layers.k = K
 seg = seg.to(dev).train()
-opt = torch.optim.Adam(seg.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+if os.environ.get("MLSP_BENCH_TORCH_ADAM"):
+    opt = torch.optim.Adam(seg.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+else:
+    from mlsp_amd.optim import FlatAdam
+    opt = FlatAdam(seg.parameters(), lr=1e-3, weight_decay=5e-5)       # as bench.py make_adam
 x = torch.rand(B, 3, N, device=dev) * 2 - 1
 w = {k: torch.randn(s, device=dev) for k, s in (("seg", (B, N, 8)), ("DefRec", (B, N, 3)), ("Normal", (B, N, 3)), ("density", (B * N, 16)),
                                                 ("density_mse", (B * N,)))}
