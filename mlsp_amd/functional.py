@@ -168,7 +168,8 @@ class forced_selections:
     the selection they computed with the given one before saving it for the backward, so a gradient comparison against a reference no
     longer depends on which of two candidates that agree to the last bit wins (a re-routed maximum moves a whole gradient row; the
     forward VALUE differs by that last bit only).  Layouts: max over k -> [P, C] slot numbers; max over N -> [B, C] point numbers local
-    to the cloud.  Call order in DGCNN: tnet_edge, its colmax, EdgeConv 1-4, conv5's colmax."""
+    to the cloud.  Call order in DGCNN: tnet_edge, its colmax, EdgeConv 1-4, conv5's colmax; in a set-abstraction stack: the fused last
+    conv + neighbourhood max of every layer ([B*S, C] slot numbers)."""
 
     def __init__(self, sel_list):
         self.sel_list = list(sel_list)
@@ -1268,6 +1269,11 @@ class _PointMLPSegMax(Function):
                                                     float(eps), int(training), int(act), float(slope), int(k), Y.data_ptr(), out.data_ptr(),
                                                     ysel.data_ptr(), argk.data_ptr(), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()),
                    "mlsp_pointmlp_segmax_fwd_f32")
+        if _sel_record is not None or _sel_forced is not None:
+            forced = _sel_forced is not None
+            _selection_hook(argk)              # test hooks (forced_selections): the slot the backward routes each group's gradient to
+            if forced:                         # ... and the pre-BN value at that slot, which the backward's statistics read
+                ysel.copy_(Y.view(G, int(k), Cout).gather(1, argk.long().unsqueeze(1)).squeeze(1))
         ctx.save_for_backward(X, W, Y, ysel, argk, bn_save)
         ctx.cfg = (int(k), bool(training), int(act), float(slope), bias is not None)
         return out

@@ -50,9 +50,11 @@ def gather_rows(points, idx):
     return torch.gather(points, 1, flat[..., None].expand(-1, -1, points.shape[-1])).reshape(*idx.shape, -1)
 
 
-def sa_forward(params, buffers, cfg, xyz, points, start, training=True, momentum=0.1, eps=1e-5):
+def sa_forward(params, buffers, cfg, xyz, points, start, training=True, momentum=0.1, eps=1e-5, sel=None, sel_out=None):
     """PointNetSetAbstraction.forward :181-196.  params: {"mlp_convs.i.weight/bias", "mlp_bns.i.weight/bias"};
-    buffers: {"mlp_bns.i.running_mean/var"}.  Returns new_xyz, new_points, fps_idx, group_idx, new_buffers."""
+    buffers: {"mlp_bns.i.running_mean/var"}.  Returns new_xyz, new_points, fps_idx, group_idx, new_buffers.
+    Test hooks for gradient pins (as oracle/ref_cpu.py's ctx.sel): sel_out (a list) receives the neighbourhood max's arg-max slots
+    [B, S, C]; sel (such a tensor) FORCES the pooling to those slots (a gather), so that two precisions route every gradient alike."""
     B, N, _ = xyz.shape
     new_buffers = dict(buffers)
     if cfg["group_all"]:
@@ -75,7 +77,13 @@ def sa_forward(params, buffers, cfg, xyz, points, start, training=True, momentum
         h = F.batch_norm(h, rm, rv, params["mlp_bns.%d.weight" % i], params["mlp_bns.%d.bias" % i], training, momentum, eps)
         new_buffers["mlp_bns.%d.running_mean" % i], new_buffers["mlp_bns.%d.running_var" % i] = rm, rv
         h = F.relu(h)
-    out = h.max(2)[0].transpose(1, 2)
+    if sel is not None:
+        out = torch.gather(h, 2, sel.permute(0, 2, 1).unsqueeze(2)).squeeze(2).transpose(1, 2)
+    else:
+        val, arg = h.max(2)
+        out = val.transpose(1, 2)
+        if sel_out is not None:
+            sel_out.append(arg.permute(0, 2, 1).contiguous())
     return new_xyz, out, fps_idx, gidx, new_buffers
 
 

@@ -167,6 +167,63 @@ def test_set_abstraction_stack_config3_vs_oracle(dev):
     assert not bad, bad
 
 
+def test_set_abstraction_stack_gradients_forced_selections(dev):
+    """The arithmetic of the stack's backward, with NOTHING discrete left to differ (round-4 verdict item 4c): FPS / ball-query indices are
+    bit-exact, and the arg-max slot of every neighbourhood max is forced to the float64 oracle's on the HIP path and on the fp32 oracle
+    (the yardstick) alike -- so no near-tied maximum is re-routed and every parameter gradient must sit within max(5e-3, 3 x yardstick)
+    relative L2 of float64 (the free-running test above needs 6e-2 for the ~ten re-routed maxima of the B = 32, N = 2048 case)."""
+    from mlsp_amd import functional as Fh, pointnet2 as p2
+    torch.manual_seed(11)
+    B, N = 8, 1024
+    xyz = torch.rand(B, N, 3) * 2 - 1
+    cfgs = [dict(npoint=256, radius=0.25, nsample=32, D=0, mlp=[64, 64, 128], group_all=False),
+            dict(npoint=64, radius=0.5, nsample=64, D=128, mlp=[128, 128, 256], group_all=False),
+            dict(npoint=None, radius=None, nsample=None, D=256, mlp=[256, 512, 1024], group_all=True)]
+    layers = [p2.PointNetSetAbstraction(c["npoint"], c["radius"], c["nsample"], 3 + c["D"], c["mlp"], c["group_all"]) for c in cfgs]
+    starts = [torch.randint(0, N, (B,)), torch.randint(0, 256, (B,)), None]
+    with torch.no_grad():
+        for l in layers:
+            for bn in l.mlp_bns:
+                bn.weight.mul_(1.0 + 0.3 * torch.randn_like(bn.weight))
+                bn.weight[torch.rand_like(bn.weight) < 0.2] *= -1
+                bn.bias.add_(0.2 * torch.randn_like(bn.bias))
+    wgt = torch.randn(B, 1, 1024)
+
+    def oracle(dtype, sels=None):
+        x, f, prs, rec = xyz.to(dtype), None, [], []
+        for li, (l, c, st) in enumerate(zip(layers, cfgs, starts)):
+            pr = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in l.named_parameters()}
+            bf = {k: v.detach().clone().to(dtype) for k, v in l.named_buffers() if not k.endswith("num_batches_tracked")}
+            x, f, _, _, _ = sa.sa_forward(pr, bf, c, x, f, st, sel=None if sels is None else sels[li], sel_out=rec if sels is None else None)
+            prs.append(pr)
+        (f * wgt.to(dtype)).sum().backward()
+        return f.detach(), [{k: v.grad.double().numpy() for k, v in pr.items()} for pr in prs], rec
+
+    out64, g64, sel64 = oracle(torch.float64)
+    _, g32, _ = oracle(torch.float32, sel64)
+    gx, gf = xyz.to(dev), None
+    with Fh.forced_selections([s.reshape(-1, s.shape[-1]) for s in sel64]):
+        for l, st in zip(layers, starts):
+            l.to(dev).train()
+            if st is not None:
+                l.fps_start = st
+            gx, gf = l(gx, gf)
+    np.testing.assert_allclose(gf.detach().cpu().numpy(), out64.numpy(), rtol=1e-3, atol=1e-3)
+    (gf * wgt.to(dev)).sum().backward()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+    report, bad = {}, []
+    for li, l in enumerate(layers):
+        for k, p in l.named_parameters():
+            if "mlp_convs" in k and k.endswith("bias"):
+                continue                                       # analytically zero in front of a batch-statistics BatchNorm
+            hip, yard = rel(p.grad.double().cpu().numpy(), g64[li][k]), rel(g32[li][k], g64[li][k])
+            report["sa%d.%s" % (li + 1, k)] = "%.1e | %.1e" % (hip, yard)
+            if not hip < max(5e-3, 3.0 * yard):
+                bad.append((li, k, hip, yard))
+    print("SA stack, forced selections, gradient rel-L2 vs float64 (HIP fp32 | oracle fp32):", report)
+    assert not bad, bad
+
+
 # ----------------------------------------------------------------------------- round 4: gradients with respect to the coordinates
 @pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("B,N,S,radius,ns,D,mlp", [(3, 256, 48, 0.45, 16, 5, [32, 64]), (2, 200, 40, 0.5, 12, 0, [16, 32, 64])])

@@ -42,6 +42,17 @@ def test_sa_oracle_matches_reference(name):
         np.testing.assert_allclose(v.grad.numpy(), g["grad/" + k], rtol=1e-3, atol=2e-4, err_msg=k)
     for k, v in nb.items():
         np.testing.assert_allclose(v.numpy(), g["state_after/" + k], rtol=1e-5, atol=1e-6, err_msg=k)
+    # the forced-selection hook of the gradient pins (tests/test_gpu_sa.py): forcing the pooling to its own recorded slots is the identity,
+    # for the output and for every gradient -- so the pinned oracle and the forced one are the same function
+    rec = []
+    p2 = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    _, out_a, _, _, _ = sa.sa_forward(p2, buffers, cfg, xyz, points.detach() if cfg["D"] else None, start, sel_out=rec)
+    p3 = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    _, out_b, _, _, _ = sa.sa_forward(p3, buffers, cfg, xyz, points.detach() if cfg["D"] else None, start, sel=rec[0])
+    assert torch.equal(out_a, out_b) and torch.equal(out_a, out.detach())
+    (out_b * torch.from_numpy(g["wgt"])).sum().backward()
+    for k, v in params.items():
+        np.testing.assert_allclose(p3[k].grad.numpy(), v.grad.numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
 
 
 def test_sa_oracle_indices_at_config3_scale():
