@@ -15,6 +15,8 @@ int launch_bn_bwd_finalize_coef(hipStream_t st, const double* part, int nparts, 
                                 float* dbeta, float* coef);
 int launch_bn_dy_gbias(hipStream_t st, const float* Y, int G, int rows_per_group, int C, const double* stats, int panel_rows, const float* coef,
                        float* scratch, float* out, const float* ysum);
+int launch_bn_bwd_finalize_coef_groups(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
+                                       float* dbeta, float* coef, const float* gys, int ppg, int rows, float* gout);
 int launch_bn_finalize_groups(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
                               const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
                               float* shift, float* save_mean, float* save_invstd, float* gsum, int ppg);
@@ -697,7 +699,10 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
         (!dX || gemm_dy_supported(false, false, M, Cin, Cout, dZ, Cout, W, ldw)) && gemm_dy_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx) &&
         (!dgbias || (rows_per_group >= 256 && rows_per_group % (M / pre_parts) == 0 && Cout % 4 == 0 && 256 % (Cout / 4) == 0 && Cout <= 1024)))
         dy = &dy_s;
-    if (dy) {
+    if (dy && dgbias && group_ysum) {          // (the forward kept the clouds' column sums of y: the per-cloud bias gradient rides in the finalizer)
+        CHECK(launch_bn_bwd_finalize_coef_groups(st, pre_stats, pre_parts, (double)M, Cout, bn_save, dgamma, dbeta, coef, group_ysum,
+                                                 rows_per_group / (M / pre_parts), rows_per_group, dgbias));
+    } else if (dy) {
         CHECK(launch_bn_bwd_finalize_coef(st, pre_stats, pre_parts, (double)M, Cout, bn_save, dgamma, dbeta, coef));
         if (dgbias) CHECK(launch_bn_dy_gbias(st, Y, n_groups, rows_per_group, Cout, pre_stats, M / pre_parts, coef, gscratch, dgbias, group_ysum));
     } else if (has_bn && M <= 32) {

@@ -607,23 +607,41 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
 // The same sums turned into the coefficient rows of the on-the-fly BatchNorm backward (gemm.hip gemm_split_kernel<.., DY>):
 //   dY = scale * (d' - mean_dz - (y - mean) * invstd * mean_dzy) = (d' + y * nk2 + c0) * sc,
 //   nk2 = -invstd * mean_dzy,  c0 = mean * invstd * mean_dzy - mean_dz,  sc = scale;   coef: rows c0 | nk2 | sc of pitch C.
+// gout (nullable): the per-cloud column sums of that dY, never formed -- sc * (sum d' + nk2 * sum y + rows * c0) from the row-panel sums of d'
+// (ppg panels per cloud) and the clouds' column sums of y (gys [G][C], kept by the forward: bn_finalize_kernel gsum)
 __global__ void bn_bwd_finalize_coef_kernel(const double* __restrict__ part, int nparts, double count, int C, const float* __restrict__ bn,
-                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
+                                            const float* __restrict__ gys, int ppg, int rows, float* __restrict__ gout) {
     const int c = blockIdx.x;
     double s, q;
     fin_part_sums(part, nparts, C, c, s, q);
+    const double k2 = (double)bn[3 * C + c] * (q / count);
+    const float c0 = (float)((double)bn[2 * C + c] * k2 - s / count), nk2 = (float)(-k2), sc = bn[c];
+    if (gout)
+        for (int g = threadIdx.x; g < nparts / ppg; g += blockDim.x) {
+            double sd = 0.0;
+            for (int p = 0; p < ppg; ++p) sd += part[((size_t)(g * ppg + p) * 2) * C + c];
+            gout[(size_t)g * C + c] = (float)((double)sc * (sd + (double)nk2 * (double)gys[(size_t)g * C + c] + (double)rows * (double)c0));
+        }
     if (threadIdx.x != 0) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
-    const double k2 = (double)bn[3 * C + c] * (q / count);
-    coef[c] = (float)((double)bn[2 * C + c] * k2 - s / count);
-    coef[C + c] = (float)(-k2);
-    coef[2 * C + c] = bn[c];
+    coef[c] = c0;
+    coef[C + c] = nk2;
+    coef[2 * C + c] = sc;
 }
 
 int launch_bn_bwd_finalize_coef(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
                                 float* dbeta, float* coef) {
-    hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, bn_save, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, bn_save, dgamma, dbeta, coef,
+                       (const float*)nullptr, 1, 0, (float*)nullptr);
+    return mlsp_launch_status();
+}
+int launch_bn_bwd_finalize_coef_groups(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
+                                       float* dbeta, float* coef, const float* gys, int ppg, int rows, float* gout) {
+    if (!gys || !gout || ppg <= 0 || nparts % ppg) return MLSP_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, bn_save, dgamma, dbeta, coef, gys,
+                       ppg, rows, gout);
     return mlsp_launch_status();
 }
 

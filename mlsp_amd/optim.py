@@ -143,6 +143,13 @@ class FlatAdam(torch.optim.Adam):
         f = self._flat
         ps, gv = f["params"], f["gviews"]
         act = self._active
+        base, offs = f["p"].data_ptr(), f["offs"]
+        if any(ps[i].data_ptr() != base + 4 * offs[i] for i in act):
+            # the model left the flat buffer (module.to(), a parameter re-assigned): re-home it, moments and step counter stay
+            views = [f["p"][offs[i]:offs[i] + p.numel()].view_as(p) for i, p in enumerate(ps)]
+            torch._foreach_copy_(views, [p.data for p in ps])
+            for p, v in zip(ps, views):
+                p.data = v
         n_with = sum(1 for p in ps if p.grad is not None)
         if n_with != len(act) or any(ps[i].grad is None for i in act):
             self._leave_flat()                            # another set of parameters holds gradients this step: per-tensor semantics

@@ -50,11 +50,13 @@ def gather_rows(points, idx):
     return torch.gather(points, 1, flat[..., None].expand(-1, -1, points.shape[-1])).reshape(*idx.shape, -1)
 
 
-def sa_forward(params, buffers, cfg, xyz, points, start, training=True, momentum=0.1, eps=1e-5, sel=None, sel_out=None):
+def sa_forward(params, buffers, cfg, xyz, points, start, training=True, momentum=0.1, eps=1e-5, sel=None, sel_out=None, groups=None):
     """PointNetSetAbstraction.forward :181-196.  params: {"mlp_convs.i.weight/bias", "mlp_bns.i.weight/bias"};
     buffers: {"mlp_bns.i.running_mean/var"}.  Returns new_xyz, new_points, fps_idx, group_idx, new_buffers.
     Test hooks for gradient pins (as oracle/ref_cpu.py's ctx.sel): sel_out (a list) receives the neighbourhood max's arg-max slots
-    [B, S, C]; sel (such a tensor) FORCES the pooling to those slots (a gather), so that two precisions route every gradient alike."""
+    [B, S, C]; sel (such a tensor) FORCES the pooling to those slots (a gather), so that two precisions route every gradient alike;
+    groups = (fps_idx, group_idx) forces the sampling and grouping (a float64 run decides a handful of radius-boundary neighbours
+    differently from fp32: the discrete choices of the fp32 run are then imposed on it)."""
     B, N, _ = xyz.shape
     new_buffers = dict(buffers)
     if cfg["group_all"]:
@@ -63,9 +65,9 @@ def sa_forward(params, buffers, cfg, xyz, points, start, training=True, momentum
         feat = torch.cat([grouped, points.view(B, 1, N, -1)], -1) if points is not None else grouped
         fps_idx = gidx = None
     else:
-        fps_idx = fps(xyz, cfg["npoint"], start)
+        fps_idx = fps(xyz, cfg["npoint"], start) if groups is None else groups[0]
         new_xyz = gather_rows(xyz, fps_idx)
-        gidx = ball_query(cfg["radius"], cfg["nsample"], xyz, new_xyz)
+        gidx = ball_query(cfg["radius"], cfg["nsample"], xyz, new_xyz) if groups is None else groups[1]
         centred = gather_rows(xyz, gidx) - new_xyz[:, :, None]
         feat = torch.cat([centred, gather_rows(points, gidx)], -1) if points is not None else centred
     h = feat.permute(0, 3, 2, 1)                              # [B, C, nsample, S]

@@ -62,6 +62,14 @@ def test_flat_adam_is_bit_identical_to_fused_adam(dev):
             s.step()
         _same(m1, m2)
     assert o1.flat_steps == 6
+    # a parameter that leaves the flat buffer (module.to(), an assignment to .data) is re-homed at the next step
+    m1.a.weight.data = m1.a.weight.data.clone()
+    x = torch.randn(64, 37, device=dev, generator=torch.Generator(device=dev).manual_seed(99))
+    for m, o in ((m1, o1), (m2, o2)):
+        o.zero_grad()
+        m(x).backward()
+        o.step()
+    _same(m1, m2)
     # the model lives in ONE buffer, the head that never ran has no state and did not move
     ptrs = sorted((p.data_ptr(), p.numel()) for p in m1.parameters())
     assert all(a + 4 * n <= b < a + 4 * n + 4 * FlatAdam.ALIGN and b % 256 == 0 for (a, n), (b, _) in zip(ptrs, ptrs[1:]))

@@ -171,7 +171,9 @@ def test_set_abstraction_stack_gradients_forced_selections(dev):
     """The arithmetic of the stack's backward, with NOTHING discrete left to differ (round-4 verdict item 4c): FPS / ball-query indices are
     bit-exact, and the arg-max slot of every neighbourhood max is forced to the float64 oracle's on the HIP path and on the fp32 oracle
     (the yardstick) alike -- so no near-tied maximum is re-routed and every parameter gradient must sit within max(5e-3, 3 x yardstick)
-    relative L2 of float64 (the free-running test above needs 6e-2 for the ~ten re-routed maxima of the B = 32, N = 2048 case)."""
+    relative L2 of float64 (the free-running test above needs 6e-2 at B = 32, N = 2048).  What is left are the ReLU kinks: see the second
+    yardstick below.  The kernels themselves, one layer at a time under the same forcing, sit at 3e-7 .. 2e-6 -- below the fp32 oracle's
+    5e-7 .. 5e-6 (tools/r5/sa_layer_debug.py)."""
     from mlsp_amd import functional as Fh, pointnet2 as p2
     torch.manual_seed(11)
     B, N = 8, 1024
@@ -189,18 +191,41 @@ def test_set_abstraction_stack_gradients_forced_selections(dev):
                 bn.bias.add_(0.2 * torch.randn_like(bn.bias))
     wgt = torch.randn(B, 1, 1024)
 
-    def oracle(dtype, sels=None):
-        x, f, prs, rec = xyz.to(dtype), None, [], []
+    def oracle(dtype, sels=None, forced_groups=None, noise=0.0, noise_seed=0):
+        gen = torch.Generator().manual_seed(noise_seed)
+        x, f, prs, rec, groups = xyz.detach().clone().to(dtype), None, [], [], []
         for li, (l, c, st) in enumerate(zip(layers, cfgs, starts)):
             pr = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in l.named_parameters()}
             bf = {k: v.detach().clone().to(dtype) for k, v in l.named_buffers() if not k.endswith("num_batches_tracked")}
-            x, f, _, _, _ = sa.sa_forward(pr, bf, c, x, f, st, sel=None if sels is None else sels[li], sel_out=rec if sels is None else None)
+            fg = None if forced_groups is None or forced_groups[li][1] is None else forced_groups[li]
+            x, f, fidx, gidx, _ = sa.sa_forward(pr, bf, c, x, f, st, sel=None if sels is None else sels[li], sel_out=rec if sels is None else None,
+                                                groups=fg)
+            if noise:                                          # a forward error of relative size `noise` on every layer's output
+                f = f * (1.0 + noise * torch.randn(f.shape, generator=gen, dtype=dtype))
             prs.append(pr)
+            groups.append((fidx, gidx))
         (f * wgt.to(dtype)).sum().backward()
-        return f.detach(), [{k: v.grad.double().numpy() for k, v in pr.items()} for pr in prs], rec
+        return f.detach(), [{k: v.grad.double().numpy() for k, v in pr.items()} for pr in prs], rec, groups
 
-    out64, g64, sel64 = oracle(torch.float64)
-    _, g32, _ = oracle(torch.float32, sel64)
+    # the discrete choices of the fp32 run (sampled centres, ball-query groups: bit-exact on the HIP path, tests above) are imposed on the
+    # float64 run: a handful of radius-boundary neighbours fall the other way in float64, which is another network
+    _, _, _, groups32 = oracle(torch.float32)
+    out64, g64, sel64, groups = oracle(torch.float64, forced_groups=groups32)
+    groups = [g[1] for g in groups]
+    # A ball-query group is padded with copies of its first hit (pointnet_util.py:84-86): identical rows, an exact tie that torch.max may
+    # give to any of them.  The HIP path's convention is the FIRST slot (its reverse index leaves the padding slots out: sa.hip), so the
+    # selections are expressed that way -- the same function: a padding slot and slot 0 carry the same value and the same source point.
+    for li, gidx in enumerate(groups):
+        if gidx is not None:
+            pad = gidx == gidx[..., :1]                                          # [B, S, ns]: slot holds the group's first hit
+            sel64[li] = torch.where(torch.gather(pad, 2, sel64[li]), torch.zeros_like(sel64[li]), sel64[li])
+    _, g32, _, _ = oracle(torch.float32, sel64, forced_groups=groups32)
+    # Second yardstick: the float64 oracle itself with a relative forward error of 1e-5 on every layer's output -- the HIP path's measured
+    # forward accuracy (3e-6 .. 9e-6 relative L2 per layer against float64, tools/r5/sa_forced_debug.py).  The loss reaches the weights
+    # through ONE row per (cloud, channel) of the group-all layer, so a single ReLU whose pre-activation lies within that error of zero
+    # (one unit at 1.9e-8 for this seed) moves every upstream gradient by ~1e-2 when it flips: such units set the floor for ANY
+    # implementation whose forward is not bit-identical to float64 (the fp32 oracle happens to keep this one's sign).
+    gn = [oracle(torch.float64, sel64, forced_groups=groups32, noise=1e-5, noise_seed=s)[1] for s in (1, 2)]
     gx, gf = xyz.to(dev), None
     with Fh.forced_selections([s.reshape(-1, s.shape[-1]) for s in sel64]):
         for l, st in zip(layers, starts):
@@ -217,10 +242,11 @@ def test_set_abstraction_stack_gradients_forced_selections(dev):
             if "mlp_convs" in k and k.endswith("bias"):
                 continue                                       # analytically zero in front of a batch-statistics BatchNorm
             hip, yard = rel(p.grad.double().cpu().numpy(), g64[li][k]), rel(g32[li][k], g64[li][k])
-            report["sa%d.%s" % (li + 1, k)] = "%.1e | %.1e" % (hip, yard)
-            if not hip < max(5e-3, 3.0 * yard):
-                bad.append((li, k, hip, yard))
-    print("SA stack, forced selections, gradient rel-L2 vs float64 (HIP fp32 | oracle fp32):", report)
+            yard_eps = max(rel(g[li][k], g64[li][k]) for g in gn)
+            report["sa%d.%s" % (li + 1, k)] = "%.1e | %.1e | %.1e" % (hip, yard, yard_eps)
+            if not hip < max(5e-3, 3.0 * yard, 3.0 * yard_eps):
+                bad.append((li, k, hip, yard, yard_eps))
+    print("SA stack, forced selections, gradient rel-L2 vs float64 (HIP fp32 | oracle fp32 | float64 with 1e-5 forward error):", report)
     assert not bad, bad
 
 
