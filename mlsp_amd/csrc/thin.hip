@@ -19,7 +19,7 @@
 // multiplied by that layer's activation derivative and dropout mask (BsDev: its pre-BN output and parameters at C's column 0) before it
 // is stored, and the block -- 128 rows -- leaves its column sums of d' and d' * yhat in part [block][2][stat_ld]: see gemm_out_bs.
 struct BsDev { const float* y; int ldy; const float* bn; int bnld; float slope, inv_keep; uint32_t thresh, xH; int ld4, col; double* part; int stat_ld; };
-template <bool TB, bool BS = false, int NT = 256>
+template <bool TB, bool BS = false, int NT = 256, int KM = 16>
 __global__ __launch_bounds__(NT) void thin_smallk_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                           float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
                                                           int K, int rows_per_block, BsDev bs) {
@@ -40,6 +40,68 @@ __global__ __launch_bounds__(NT) void thin_smallk_kernel(const float* __restrict
         sc = *(const f32x4*)(bs.bn + c); sf = *(const f32x4*)(bs.bn + bs.bnld + c);
         mu = *(const f32x4*)(bs.bn + 2 * bs.bnld + c); is = *(const f32x4*)(bs.bn + 3 * bs.bnld + c);
     }
+    if constexpr (BS && KM > 0) {
+        // U rows per thread in flight: their A values (K <= KM broadcast loads; KM = 16: 16-byte loads, K % 4 == 0) and y quads are all
+        // issued before the first store (the stores to C may alias bs.y as far as the compiler knows: row by row, every load waited for
+        // the previous row's store).  KM = 0: the row-by-row loop below (K > 4 with an unaligned A).
+        const int q = tid % nq, rstep = NT / nq;
+        constexpr int U = KM == 16 ? 2 : 4;                  // rows in flight (KM = 16: 32 A values per row pair; 128 registers at 1024 threads)
+        for (int rb = tid / nq; rb < rows_per_block; rb += U * rstep) {
+            f32x4 yv[U];
+            float av[U][KM > 0 ? KM : 1];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rl = rb + u * rstep, r = row0 + rl;
+                ok[u] = rl < rows_per_block && r < M;
+                const int rr = ok[u] ? r : row0;
+                yv[u] = *(const f32x4*)(bs.y + (size_t)rr * bs.ldy + 4 * q);
+                if constexpr (KM == 16) {
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                        if (4 * k4 < K) t = *(const f32x4*)(A + (size_t)rr * lda + 4 * k4);
+                        av[u][4 * k4] = t[0]; av[u][4 * k4 + 1] = t[1]; av[u][4 * k4 + 2] = t[2]; av[u][4 * k4 + 3] = t[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) av[u][k] = k < K ? A[(size_t)rr * lda + k] : 0.f;
+                }
+            }
+            f32x4 acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                if (k < K) {
+                    const f32x4 bv = *(const f32x4*)(Bs + k * N + 4 * q);
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[u][e] = fmaf(av[u][k], bv[e], acc[u][e]);
+                }
+            }
+            f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+            if (bias) bb = *(const f32x4*)(bias + 4 * q);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const int r = row0 + rb + u * rstep;
+                const uint32_t hq = bs.thresh ? mix32(((uint32_t)r * (uint32_t)bs.ld4 + ((uint32_t)(bs.col + 4 * q) >> 2)) ^ bs.xH) : 0u;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = acc[u][e] + bb[e];
+                    if (bs.thresh) d = ((hq >> (8 * e)) & 255u) >= bs.thresh ? d * bs.inv_keep : 0.f;
+                    const float a1 = fmaf(yv[u][e], sc[e], sf[e]);
+                    if (!(a1 > 0.f)) d *= bs.slope;
+                    ps[e] += d; pq[e] += (double)d * ((yv[u][e] - mu[e]) * is[e]);
+                    o[e] = d;
+                }
+                *(f32x4*)(C + (size_t)r * ldc + 4 * q) = o;
+            }
+        }
+    } else
     for (int i = tid; i < rows_per_block * nq; i += NT) {
         const int r = row0 + i / nq, q = i % nq;
         if (r >= M) break;
@@ -254,12 +316,15 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
         const size_t lds = (size_t)((K * N + 1) & ~1) * sizeof(float) + (bs ? 1024 * 8 * sizeof(double) : 0);
         const dim3 grid((M + rpb - 1) / rpb);
         if (bs) {
+            const bool av16 = K % 4 == 0 && lda % 4 == 0 && al16(A);
+            auto kern = K <= 4 ? (tb ? thin_smallk_kernel<true, true, 1024, 4> : thin_smallk_kernel<false, true, 1024, 4>)
+                      : av16 ? (tb ? thin_smallk_kernel<true, true, 1024, 16> : thin_smallk_kernel<false, true, 1024, 16>)
+                             : (tb ? thin_smallk_kernel<true, true, 1024, 0> : thin_smallk_kernel<false, true, 1024, 0>);
             if (lds > 64 * 1024) {
-                hipError_t e_ = mlsp_lds_limit(tb ? (const void*)thin_smallk_kernel<true, true, 1024> : (const void*)thin_smallk_kernel<false, true, 1024>, lds);
+                hipError_t e_ = mlsp_lds_limit((const void*)kern, lds);
                 if (e_ != hipSuccess) return (int)e_;
             }
-            if (tb) hipLaunchKernelGGL((thin_smallk_kernel<true, true, 1024>), grid, dim3(1024), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb, bd);
-            else hipLaunchKernelGGL((thin_smallk_kernel<false, true, 1024>), grid, dim3(1024), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb, bd);
+            hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb, bd);
         } else if (tb) hipLaunchKernelGGL((thin_smallk_kernel<true, false>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb, bd);
         else hipLaunchKernelGGL((thin_smallk_kernel<false, false>), grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, rpb, bd);
         return mlsp_launch_status();

@@ -728,16 +728,20 @@ def test_segda_config4_shape_vs_oracle(dev):
         assert torch.isfinite(o16[key]).all().item() and rel(o16[key], o32[key]) < 5e-2, (key, rel(o16[key], o32[key]))
     # gradients: those of a slightly different function (a bf16-rounded pre-activation flips the ReLU mask of the ~0.3 % of
     # activations at the kink: ~5 % relative L2 per layer, tests/test_gpu_kernels.py::test_pointmlp_bf16_activation_storage pins the
-    # kernels against an emulation with the same roundings) -- here: finite, same direction
+    # kernels against an emulation with the same roundings).  Whole-model bound, per module, against the fp32 step on the same graphs:
+    # relative L2 of every parameter gradient <= BF16_GRAD_BOUND[module] (measured values printed; the bounds are ~1.5x what this
+    # shape shows: the head stacks, three bf16 layers deep, and everything upstream of them, which sums the four heads' errors)
+    # measured at this shape: T-Net 0.235, shared_layers 0.251, seg 0.044, DefRec 0.036, Norm_pred 0.032, Density_cls 0.023
+    BF16_GRAD_BOUND = {"input_transform_net": 0.36, "shared_layers": 0.38, "seg": 0.07, "DefRec": 0.06, "Norm_pred": 0.05, "Density_cls": 0.04}
     worst = {}
     for n in g32:
         assert torch.isfinite(g16[n]).all().item(), n
         if g32[n].norm() > 1e-6 and not (n.startswith("shared_layers") and n.endswith(".bias")):     # those are analytically ~0
-            cos = torch.nn.functional.cosine_similarity(g16[n].flatten().double(), g32[n].flatten().double(), dim=0).item()
-            assert cos > 0.9, (n, cos)
             grp = n.split(".")[0]
             worst[grp] = max(worst.get(grp, 0.0), rel(g16[n], g32[n]))
     print("configs[4] bf16 step, worst gradient rel-L2 vs the fp32 step per module:", {k: "%.3f" % v for k, v in worst.items()})
+    for grp, v in worst.items():
+        assert v < BF16_GRAD_BOUND[grp], (grp, v)
     assert Fh.activation_storage.current == "fp32" and Fh.gemm_precision.current == Fh._lib.DEFAULT_GEMM_PRECISION
 
 
