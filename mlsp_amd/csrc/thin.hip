@@ -274,14 +274,23 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ 
 }
 
 int launch_slab_reduce(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int nsplit);
+#ifndef THIN_SN_BLOCKS
+#define THIN_SN_BLOCKS 1024  // workgroups of the small-N kernel at most (512: 24.9 / 8.1 us, 1024: 21.2 / 7.2 us for the 16- / 3-channel layers)
+#endif
+#ifndef THIN_TN_ROWS
 #define THIN_TN_ROWS 64      // rows of the K dimension per workgroup (one partial slab each)
+#endif
 
+// rows of the K dimension per workgroup: 64 with 16 accumulator quads per thread, 32 with 4 (measured: 6.8 -> 6.2 us for the 3-channel
+// layers, 21.4 -> 27.7 us for the 16-channel one at 32)
+static inline int thin_tn_rows(int ns) { return ns <= 4 ? THIN_TN_ROWS / 2 : THIN_TN_ROWS; }
 // slab floats the thin TN path needs for (M, N, K) (0: shape not handled here)
 size_t thin_tn_slab_floats(int M, int N, int K) {
     const bool small_m = M <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && (N & (N - 1)) == 0;
     const bool small_n = N <= 16 && M % 4 == 0 && M >= 64 && M <= 512 && (M & (M - 1)) == 0;
     if (!(small_m || small_n) || K < 2048) return 0;
-    const int chunks = (K + THIN_TN_ROWS - 1) / THIN_TN_ROWS;
+    const int rows = thin_tn_rows(small_m ? M : N);
+    const int chunks = (K + rows - 1) / rows;
     return (size_t)chunks * M * N;
 }
 
@@ -316,6 +325,7 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
         const size_t lds = (size_t)((K * N + 1) & ~1) * sizeof(float) + (bs ? 1024 * 8 * sizeof(double) : 0);
         const dim3 grid((M + rpb - 1) / rpb);
         if (bs) {
+            // (K = 16, N = 256: two rows in flight with 16-byte A loads 25.6 us, the row-by-row loop 32.5 us; K = 3: 14.5 against 15.5)
             const bool av16 = K % 4 == 0 && lda % 4 == 0 && al16(A);
             auto kern = K <= 4 ? (tb ? thin_smallk_kernel<true, true, 1024, 4> : thin_smallk_kernel<false, true, 1024, 4>)
                       : av16 ? (tb ? thin_smallk_kernel<true, true, 1024, 16> : thin_smallk_kernel<false, true, 1024, 16>)
@@ -333,7 +343,7 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
     if ((!xf || xf->which == 1) && !ta && N <= 16 && K % 4 == 0 && K >= 64 && K <= 1024 && M >= 1024 && lda % 4 == 0 && al16(A)) {
         const size_t lds = (size_t)K * (N + (xf ? 2 : 0)) * sizeof(float);
         int blocks = (M + 31) / 32;
-        if (blocks > 512) blocks = 512;                                      // B is staged once per workgroup: keep many rows per workgroup
+        if (blocks > THIN_SN_BLOCKS) blocks = THIN_SN_BLOCKS;                                      // B is staged once per workgroup: keep many rows per workgroup
 #define THIN_SN(TBV, XFV) do { if (N <= 4) hipLaunchKernelGGL((thin_smalln_kernel<TBV, 4, XFV>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, xd); \
                                else hipLaunchKernelGGL((thin_smalln_kernel<TBV, 16, XFV>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, C, ldc, bias, M, N, K, xd); } while (0)
         if (xf) { if (tb) THIN_SN(true, true); else THIN_SN(false, true); }
@@ -345,8 +355,9 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
     if (ta && !tb && !bias) {
         const size_t need = thin_tn_slab_floats(M, N, K);
         if (!need || !slab || slab_floats < need) return MLSP_ERR_UNSUPPORTED;
-        const int chunks = (K + THIN_TN_ROWS - 1) / THIN_TN_ROWS;
         const bool small_m = M <= 16 && N % 4 == 0 && N >= 64;
+        const int tn_rows = thin_tn_rows(small_m ? M : N);
+        const int chunks = (K + tn_rows - 1) / tn_rows;
         if (small_m ? (ldb % 4 || !al16(B)) : (lda % 4 || !al16(A))) return MLSP_ERR_UNSUPPORTED;   // the wide operand is read 16 bytes per lane
         if (xf && !small_m) return MLSP_ERR_UNSUPPORTED;                                            // the transform is on B = the wide side
         // small side S, large side L; partial slabs are written in C's [M][N] layout
@@ -355,7 +366,7 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
         const int ds = small_m ? N : 1, dl = small_m ? 1 : N;
         const int ngr = 256 / (nl / 4);
 #define THIN_TN(NSV, XFV) hipLaunchKernelGGL((thin_tn_kernel<NSV, XFV>), dim3(chunks), dim3(256), (size_t)ngr * NSV * nl * sizeof(float), st, S, lds_, L, ldl, \
-                                             slab, (size_t)M * N, ds, dl, K, ns, nl, THIN_TN_ROWS, xd)
+                                             slab, (size_t)M * N, ds, dl, K, ns, nl, tn_rows, xd)
         if (xf) { if (ns <= 4) THIN_TN(4, true); else THIN_TN(16, true); }
         else if (ns <= 4) THIN_TN(4, false); else THIN_TN(16, false);
 #undef THIN_TN
