@@ -65,7 +65,7 @@ def pmc_split_traffic_by_kind():
     f = max(files, key=lambda p: (int(re.search(r"pmc_r(\d+)", p).group(1)), p))
     acc = {}
     for r in csv.DictReader(open(f)):
-        m = re.search(r"gemm_split_kernel<(false|true), (false|true)", r["kernel"])
+        m = re.search(r"gemm_split_kernel<(false|true)[;,] (false|true)", r["kernel"])
         if not m:
             continue
         kind = "wgrad" if m.group(1) == "true" else ("fwd" if m.group(2) == "true" else "dgrad")
@@ -650,8 +650,7 @@ def main():
     args = make_args()
     torch.manual_seed(0)                                   # identical replicas on every rank
     model = Models.DGCNN(args).to(dev).train()
-    from mlsp_amd.optim import FlatAdam
-    sync = FlatGradSync(model, align=FlatAdam.ALIGN)        # the bucket doubles as the optimizer's flat gradient buffer
+    sync = FlatGradSync(model, align=4)                     # 16-byte aligned gradient views: FlatAdam reads the packed gradients in place
     opt = sync.wrap(make_adam(model.parameters()))                                            # trainer.py:258-259
     batch = synth_batch(b_local, NPTS, dev, seed=1000 + rank)
 

@@ -401,7 +401,7 @@ int mlsp_profile_classes(double* out, int ncls);
 int mlsp_profile_split_kinds(double* out);
 
 /* Adam step (PointDA/trainer.py:258-259, stepped at :571) over flat parameter / exp_avg / exp_avg_sq buffers P / M / V in ONE launch:
- * segment s covers elements [off[s], off[s] + numel[s]) of the three buffers (off % 4 == 0, buffers 16-byte aligned) and reads its
+ * segment s covers elements [off[s], off[s] + numel[s]) of the three buffers (buffers 16-byte aligned; off % 4 == 0 takes the 16-byte path) and reads its
  * gradient where autograd left it (grads[s], contiguous fp32, device).  off / numel / grads are HOST arrays.  step >= 1 numbers this
  * update (bias corrections 1 - beta^step); step_out (nullable, device float) receives it.  The element-wise arithmetic restates
  * torch's fused Adam (ATen/native/cuda/fused_adam_utils.cuh, ADAM_MODE::ORIGINAL: weight decay added to the gradient) type by type. */

@@ -28,7 +28,7 @@
 struct AdamSegs {
     int n;
     int tile_begin[ADAM_MAX_SEGS + 1];      // first tile of every segment; [n] = total
-    unsigned off[ADAM_MAX_SEGS];            // first element of the segment in the flat buffers (multiple of 4)
+    unsigned off[ADAM_MAX_SEGS];            // first element of the segment in the flat buffers (a multiple of 4 takes the 16-byte path)
     unsigned numel[ADAM_MAX_SEGS];
     const float* grad[ADAM_MAX_SEGS];       // the segment's gradient, contiguous
 };
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ P, f
     float* p = P + s.off[lo];
     float* m = M + s.off[lo];
     float* v = V + s.off[lo];
-    const bool gvec = (((uintptr_t)g) & 15) == 0;
+    const bool gvec = (((uintptr_t)g) & 15) == 0 && (s.off[lo] & 3) == 0;      // 16-byte accesses on all four streams
 #pragma unroll
     for (int u = 0; u < ADAM_TILE / 1024; ++u) {
         const unsigned i = e0 + u * 1024 + threadIdx.x * 4;
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ P, f
 extern "C" {
 
 // One Adam step over nseg parameter segments of the flat buffers P / M / V (exp_avg / exp_avg_sq): segment s covers elements
-// [off[s], off[s] + numel[s]) (off % 4 == 0, the buffers 16-byte aligned) and reads its gradient from grads[s] (any fp32 device pointer,
-// contiguous).  step >= 1 is this update's number (bias corrections 1 - beta^step); step_out (nullable, device float) receives it.
+// [off[s], off[s] + numel[s]) (the buffers 16-byte aligned; a segment whose offset and gradient pointer are 16-byte aligned moves 16 bytes per
+// lane, any other one element by element) and reads its gradient from grads[s] (any fp32 device pointer, contiguous).  step >= 1 is this update's number (bias corrections 1 - beta^step); step_out (nullable, device float) receives it.
 // Host arrays; any nseg (launched in groups of 96).
 int mlsp_adam_flat_f32(float* P, float* M, float* V, const uint32_t* off, const uint32_t* numel, const float* const* grads, int nseg, double lr,
                        double beta1, double beta2, double weight_decay, double eps, int64_t step, float* step_out, mlsp_stream_t st) {
@@ -103,7 +103,7 @@ int mlsp_adam_flat_f32(float* P, float* M, float* V, const uint32_t* off, const 
         a.n = nseg - s0 < ADAM_MAX_SEGS ? nseg - s0 : ADAM_MAX_SEGS;
         int tiles = 0;
         for (int i = 0; i < a.n; ++i) {
-            if ((off[s0 + i] & 3) || !grads[s0 + i] || numel[s0 + i] == 0) return MLSP_ERR_ARG;
+            if (!grads[s0 + i] || numel[s0 + i] == 0) return MLSP_ERR_ARG;
             a.tile_begin[i] = tiles;
             a.off[i] = off[s0 + i]; a.numel[i] = numel[s0 + i]; a.grad[i] = grads[s0 + i];
             tiles += (int)((numel[s0 + i] + ADAM_TILE - 1) / ADAM_TILE);

@@ -46,8 +46,8 @@ class FlatGradSync:
     _NCHK = 4                                 # trailing bucket elements of the uniform-presence check: h1, h1^2, h2, h2^2
 
     def __init__(self, model, process_group=None, force=False, presence="uniform", align=1):
-        # align: every gradient starts on a multiple of `align` elements of the bucket (zero padding between them).  align =
-        # mlsp_amd.optim.FlatAdam.ALIGN gives the bucket the layout of that optimizer's flat buffers: it then steps straight out of it.
+        # align: every gradient starts on a multiple of `align` elements of the bucket (zero padding between them; 4 = 16-byte aligned
+        # gradient views: mlsp_amd.optim.FlatAdam, which reads the packed gradients in place, then moves 16 bytes per lane on every stream)
         if presence not in ("uniform", "exchange"):
             raise ValueError("presence must be 'uniform' or 'exchange'")
         from .optim import flat_offsets
@@ -162,6 +162,4 @@ class FlatGradSync:
         if not getattr(optimizer, "_mlsp_flat_sync", None):
             optimizer.register_step_pre_hook(lambda *_a, **_k: (self.allreduce(), None)[1])
             optimizer._mlsp_flat_sync = self
-            if hasattr(optimizer, "adopt_grad_buffer"):       # mlsp_amd.optim.FlatAdam: the bucket doubles as its flat gradient buffer
-                optimizer.adopt_grad_buffer(self.flat, self.params, self.offsets)
         return optimizer

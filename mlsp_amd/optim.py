@@ -1,14 +1,20 @@
-"""Adam over ONE flat parameter buffer: the optimizer step of the hot path as a single multi-tensor launch.
+"""Adam over ONE flat parameter buffer: the optimizer step of the hot path as a single launch.
 
 PointDA/trainer.py:258-259 builds `optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd)`.  torch's fused Adam walks the 77
 parameter tensors of DGCNN + heads in 64 Ki-element chunks, one chunk per workgroup: most tensors end in a mostly empty chunk, five to
-six launches per step, 110 us at 1.2 TB/s for 127 MB of parameter / gradient / moment traffic (profiles/r5_*).  Here the parameters, their
-gradients and both moments live in four flat fp32 buffers (the parameters become views, as in FlatGradSync's bucket), the gradients autograd
-produced are read where they lie through a pointer table, and ONE launch of `mlsp_adam_flat_f32` (csrc/optim.hip: 2048-element tiles,
-~2300 workgroups, the element-wise update of torch's fused kernel restated type by type) steps every parameter that holds a gradient.
-tests/test_gpu_optim.py compares the parameters with `torch.optim.Adam(..., fused=True)` on the unflattened model step by step.
-(MLSP_FLAT_ADAM_TORCH=1: the flat buffers stepped by `torch._fused_adam_` itself after one packing copy -- bit-identical to torch by
-construction, chunk-limited like torch; kept for A/B.)
+six launches per step, 110 us at 1.2 TB/s for 127 MB of parameter / gradient / moment traffic (profiles/r5_*).  Here the parameters and
+both moments live in three flat fp32 buffers (the parameters become views), the gradients autograd produced are read where they lie through a
+pointer table, and ONE launch of `mlsp_adam_flat_f32` (csrc/optim.hip: 2048-element tiles, ~2300 workgroups, the element-wise update of
+torch's fused kernel restated type by type and lowering by lowering) steps every parameter that holds a gradient: 19 us.
+tests/test_gpu_optim.py asserts bit-identity with `torch.optim.Adam(..., fused=True)` on the unflattened model step by step.
+(torch's own fused kernel on the same flat buffers, as one tensor, measured 88 us: its chunking is per 64 Ki elements whatever the
+tensor list looks like.)
+
+Layout.  Parameters that already SHARE a storage keep their relative places: the merged head layers make the parameters they read as one
+operand adjacent in one buffer (functional.rehome_adjacent), and moving them apart again would cost a concatenation per forward.  Every such
+storage -- and every stand-alone parameter -- becomes one unit, placed on a 256-byte boundary (an arbitrary offset into a flat buffer would
+send every GEMM that reads the weight to its unaligned edge-tile instantiation: 4.48 -> 6.10 ms per step measured).  If parameters leave the
+buffer later (module.to(), another rehome_adjacent) the layout is rebuilt at the next step, moments and step counter carried over.
 
 Semantics kept from torch: a parameter whose gradient is None is not stepped (DGCNN.Rec_scan in the default modes, Models.py:150) and gets
 no state; `param_groups[0]["lr"]` is read every step (CosineAnnealingLR, trainer.py:260); `state_dict()` / `load_state_dict()` see per-
@@ -18,20 +24,15 @@ several groups, amsgrad / maximize, a parameter set that changes between steps -
 the same storage, with the state carried over.
 """
 import ctypes
-import os
 
 import torch
 
 from . import _lib
 
-_TORCH_KERNEL = bool(os.environ.get("MLSP_FLAT_ADAM_TORCH"))
-
 
 def flat_offsets(params, align=1):
     """(first element of every parameter, total elements) of a flat buffer that holds `params` back to back, each starting on a multiple
-    of `align` elements.  The library's fast paths want 16-byte aligned weight rows (a torch allocation is; an arbitrary offset into a flat
-    buffer is not: unaligned weights send every GEMM to its slow edge-tile instantiation), so parameter buffers use align = 64 (256 bytes);
-    the padding elements are zeros that stay zeros under Adam (zero gradient, zero value)."""
+    of `align` elements (FlatGradSync's bucket layout)."""
     offs, n = [], 0
     for p in params:
         n = (n + align - 1) // align * align
@@ -40,29 +41,58 @@ def flat_offsets(params, align=1):
     return offs, (n + align - 1) // align * align
 
 
+def storage_unit_offsets(params, align):
+    """Offsets for `params` in a flat buffer in which parameters that share a storage keep their relative byte offsets (one unit per
+    shared storage, spanning its members; stand-alone parameters are units of their own), every unit starting on a multiple of `align`
+    elements.  -> (offsets in elements, total elements), or None when some parameter is not a dense contiguous fp32 tensor."""
+    units, order = {}, []
+    for i, p in enumerate(params):
+        if not p.is_contiguous() or p.dtype != torch.float32:
+            return None
+        key = p.untyped_storage().data_ptr()
+        if key not in units:
+            units[key] = []
+            order.append(key)
+        units[key].append(i)
+    offs, n = [0] * len(params), 0
+    for key in order:
+        members = units[key]
+        lo = min(params[i].data_ptr() for i in members)
+        hi = max(params[i].data_ptr() + 4 * params[i].numel() for i in members)
+        if len(members) == 1 or (hi - lo) > 8 * sum(params[i].numel() for i in members):
+            # a lone parameter -- or members scattered over a big foreign storage (views of something else): place them one by one
+            for i in members:
+                n = (n + align - 1) // align * align
+                offs[i] = n
+                n += params[i].numel()
+            continue
+        n = (n + align - 1) // align * align
+        for i in members:
+            d = params[i].data_ptr() - lo
+            if d % 4:
+                return None
+            offs[i] = n + d // 4
+        n += (hi - lo) // 4
+    # the members of a unit are distinct parameters of one concatenation: they must not overlap
+    spans = sorted((offs[i], offs[i] + p.numel()) for i, p in enumerate(params))
+    if any(a[1] > b[0] for a, b in zip(spans, spans[1:])):
+        return None
+    return offs, (n + align - 1) // align * align
+
+
 class FlatAdam(torch.optim.Adam):
     ALIGN = 64
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_buffer=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         params = list(params)
         on_gpu = any(isinstance(p, torch.Tensor) and p.is_cuda for p in params) or any(
             isinstance(g, dict) and any(p.is_cuda for p in g["params"]) for g in params)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=on_gpu)
-        self._flat = None              # (params, offsets, flat_p, flat_g, flat_m, flat_v, step) once built
-        self._active = None            # indices (into the group's parameter list) of the parameters that step, fixed at the first step
+        self._flat = None              # the flat buffers and their layout once built (dict)
+        self._active = None            # indices (into the trainable parameter list) of the parameters that step, fixed at the first step
         self._disabled = False         # True: torch's per-tensor path from now on
-        self._grad_buffer = grad_buffer
         self.flat_steps = 0            # steps taken on the flat path (tests)
-
-    # ---- layout ---------------------------------------------------------------------------------------------------------------
-    def adopt_grad_buffer(self, flat, params, offsets):
-        """Use `flat` (FlatGradSync's bucket: every trainable parameter's gradient in parameter order, FlatGradSync(align=FlatAdam.ALIGN))
-        as the flat gradient buffer, so the exchange's pack is the only copy of the step.  Ignored when the layouts differ."""
-        mine = [p for p in self.param_groups[0]["params"] if p.requires_grad] if len(self.param_groups) == 1 else None
-        if mine is not None and len(mine) == len(params) and all(a is b for a, b in zip(mine, params)) and self._flat is None:
-            offs, n = flat_offsets(mine, self.ALIGN)
-            if offs == list(offsets) and flat.numel() == n:
-                self._grad_buffer = flat
+        self.layouts_built = 0         # (tests: a rebuild happens only when parameters left the buffer)
 
     def _eligible(self):
         if self._disabled or len(self.param_groups) != 1:
@@ -75,26 +105,28 @@ class FlatAdam(torch.optim.Adam):
         return all(p.dtype == torch.float32 and p.device == dev and p.is_cuda and not p.is_sparse for p in ps)
 
     def _build(self):
+        """Lay the trainable parameters out (storage units, see the module docstring), move them and whatever Adam state exists into
+        fresh flat buffers.  None: the existing state does not fit one shared step counter."""
         ps = [p for p in self.param_groups[0]["params"] if p.requires_grad]
         dev = ps[0].device
-        offs, n = flat_offsets(ps, self.ALIGN)
-        flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
-        views = [flat_p[o:o + p.numel()].view_as(p) for o, p in zip(offs, ps)]
-        torch._foreach_copy_(views, [p.data for p in ps])
-        for p, v in zip(ps, views):
-            p.data = v                                    # the model now lives in the flat buffer (module.to() / load_state_dict copy into it)
-        gb = self._grad_buffer
-        flat_g = gb if (gb is not None and gb.numel() == n and gb.device == dev) else (
-            torch.zeros(n, dtype=torch.float32, device=dev) if _TORCH_KERNEL else flat_p[:0])      # (the own kernel needs no packed gradients)
-        flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
-        flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
-        active = [i for i, p in enumerate(ps) if p.grad is not None]
-        # state that already exists (load_state_dict before the first flat step): carried over when every active parameter is at the same step
+        lay = storage_unit_offsets(ps, self.ALIGN)
+        if lay is None:
+            lay = flat_offsets(ps, self.ALIGN)
+        offs, n = lay
+        active = self._active if self._active is not None else [i for i, p in enumerate(ps) if p.grad is not None]
         steps = {float(self.state[ps[i]]["step"]) for i in active if ps[i] in self.state and "step" in self.state[ps[i]]}
         have = [i for i in active if ps[i] in self.state and "exp_avg" in self.state[ps[i]]]
         if len(steps) > 1 or (have and len(have) != len(active)) or any(p in self.state and self.state[p] for i, p in enumerate(ps) if i not in active):
             return None
+        flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        views = [flat_p[o:o + p.numel()].view_as(p) for o, p in zip(offs, ps)]
+        torch._foreach_copy_(views, [p.data for p in ps])
+        for p, v in zip(ps, views):
+            p.data = v                                    # the model now lives in the flat buffer (load_state_dict copies into it)
         step = torch.full((), steps.pop() if steps else 0.0, dtype=torch.float32, device=dev)
+        host_step = int(round(float(step)))
         for i in active:
             p, o = ps[i], offs[i]
             m, v = flat_m[o:o + p.numel()].view_as(p), flat_v[o:o + p.numel()].view_as(p)
@@ -102,17 +134,11 @@ class FlatAdam(torch.optim.Adam):
                 m.copy_(self.state[p]["exp_avg"])
                 v.copy_(self.state[p]["exp_avg_sq"])
             self.state[p] = {"step": step, "exp_avg": m, "exp_avg_sq": v}
-        # maximal runs of adjacent active parameters: the tensors the one launch walks
-        runs, i = [], 0
-        while i < len(active):
-            j = i
-            while j + 1 < len(active) and active[j + 1] == active[j] + 1:
-                j += 1
-            runs.append((offs[active[i]], offs[active[j]] + ps[active[j]].numel()))
-            i = j + 1
-        gviews = [flat_g[o:o + p.numel()].view_as(p) for o, p in zip(offs, ps)] if flat_g.numel() == n else None
         self._active = active
-        return {"params": ps, "offs": offs, "gviews": gviews, "p": flat_p, "g": flat_g, "m": flat_m, "v": flat_v, "step": step, "runs": runs}
+        self.layouts_built += 1
+        n_act = len(active)
+        seg = ((ctypes.c_uint32 * n_act)(*[offs[i] for i in active]), (ctypes.c_uint32 * n_act)(*[ps[i].numel() for i in active]))
+        return {"params": ps, "offs": offs, "p": flat_p, "m": flat_m, "v": flat_v, "step": step, "host_step": host_step, "seg": seg}
 
     def _leave_flat(self):
         """torch's per-tensor path from now on (same storage): every stepped parameter gets its own step counter."""
@@ -141,52 +167,32 @@ class FlatAdam(torch.optim.Adam):
                 super().step()
                 return loss
         f = self._flat
-        ps, gv = f["params"], f["gviews"]
-        act = self._active
-        base, offs = f["p"].data_ptr(), f["offs"]
-        if any(ps[i].data_ptr() != base + 4 * offs[i] for i in act):
-            # the model left the flat buffer (module.to(), a parameter re-assigned): re-home it, moments and step counter stay
-            views = [f["p"][offs[i]:offs[i] + p.numel()].view_as(p) for i, p in enumerate(ps)]
-            torch._foreach_copy_(views, [p.data for p in ps])
-            for p, v in zip(ps, views):
-                p.data = v
+        ps, act = f["params"], self._active
         n_with = sum(1 for p in ps if p.grad is not None)
         if n_with != len(act) or any(ps[i].grad is None for i in act):
             self._leave_flat()                            # another set of parameters holds gradients this step: per-tensor semantics
             super().step()
             return loss
+        base, offs = f["p"].data_ptr(), f["offs"]
+        if any(p.data_ptr() != base + 4 * offs[i] for i, p in enumerate(ps)):
+            # parameters left the buffer (module.to(), a rehome_adjacent of a head that ran for the first time): lay them out again
+            # around their new storages, moments and step counter carried over
+            f = self._flat = self._build()
+            if f is None:
+                self._disabled = True
+                super().step()
+                return loss
+            ps = f["params"]
         grp = self.param_groups[0]
         b1, b2 = grp["betas"]
-        if not _TORCH_KERNEL:
-            # one launch; every gradient is read where autograd (or the exchange's bucket) left it
-            grads = [ps[i].grad if ps[i].grad.is_contiguous() else ps[i].grad.contiguous() for i in act]
-            n = len(act)
-            if f.get("seg") is None:
-                f["seg"] = ((ctypes.c_uint32 * n)(*[f["offs"][i] for i in act]), (ctypes.c_uint32 * n)(*[ps[i].numel() for i in act]))
-                f["host_step"] = int(round(float(f["step"])))
-            f["host_step"] += 1
-            gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
-            lr = grp["lr"]
-            _lib.check(_lib.load().mlsp_adam_flat_f32(f["p"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(), f["seg"][0], f["seg"][1], gp, n,
-                                                      float(lr), float(b1), float(b2), float(grp["weight_decay"]), float(grp["eps"]),
-                                                      f["host_step"], f["step"].data_ptr(), _lib.stream()), "mlsp_adam_flat_f32")
-            self.flat_steps += 1
-            return loss
-        src, dst = [], []
-        for i in act:
-            g = ps[i].grad
-            if g.data_ptr() != gv[i].data_ptr():
-                src.append(g)
-                dst.append(gv[i])
-        if src:
-            torch._foreach_copy_(dst, src)
-            for i in act:
-                ps[i].grad = gv[i]
-        f["step"] += 1
-        runs = f["runs"]
-        torch._fused_adam_([f["p"][a:b] for a, b in runs], [f["g"][a:b] for a, b in runs], [f["m"][a:b] for a, b in runs],
-                           [f["v"][a:b] for a, b in runs], [], [f["step"]] * len(runs), lr=grp["lr"], beta1=b1, beta2=b2,
-                           weight_decay=grp["weight_decay"], eps=grp["eps"], amsgrad=False, maximize=False, grad_scale=None, found_inf=None)
+        # one launch; every gradient is read where autograd (or the exchange's bucket) left it
+        grads = [ps[i].grad if ps[i].grad.is_contiguous() else ps[i].grad.contiguous() for i in act]
+        n = len(act)
+        f["host_step"] += 1
+        gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+        _lib.check(_lib.load().mlsp_adam_flat_f32(f["p"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(), f["seg"][0], f["seg"][1], gp, n,
+                                                  float(grp["lr"]), float(b1), float(b2), float(grp["weight_decay"]), float(grp["eps"]),
+                                                  f["host_step"], f["step"].data_ptr(), _lib.stream()), "mlsp_adam_flat_f32")
         self.flat_steps += 1
         return loss
 
@@ -197,3 +203,4 @@ class FlatAdam(torch.optim.Adam):
             self._disabled = False
         super().load_state_dict(state_dict)
         self._flat = None
+        self._active = None

@@ -111,12 +111,12 @@ def test_flat_adam_falls_back_when_the_stepped_set_changes(dev):
     assert float(o1.state[m1.late.weight]["step"]) == 3.0 and float(o1.state[m1.a.weight]["step"]) == 5.0
 
 
-def test_flat_adam_shares_the_exchange_bucket(dev):
-    """with FlatGradSync the exchange's bucket IS the optimizer's gradient buffer: one pack per step, no second copy"""
+def test_flat_adam_reads_the_exchange_bucket_in_place(dev):
+    """with FlatGradSync the optimizer reads the packed (all-reduced) gradients where the bucket holds them: no second copy"""
     from mlsp_amd.ddp import FlatGradSync
     from mlsp_amd.optim import FlatAdam
     m1, m2 = _pair(dev)
-    sync = FlatGradSync(m1, force=True, align=FlatAdam.ALIGN)
+    sync = FlatGradSync(m1, force=True, align=4)
     o1 = sync.wrap(FlatAdam(m1.parameters(), lr=1e-3, weight_decay=5e-5))
     o2 = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
     for it in range(3):
@@ -126,4 +126,47 @@ def test_flat_adam_shares_the_exchange_bucket(dev):
             m(x).backward()
             o.step()
         _same(m1, m2)
-    assert o1.flat_steps == 3 and o1._flat["g"].data_ptr() == sync.flat.data_ptr()
+        lo, hi = sync.flat.data_ptr(), sync.flat.data_ptr() + 4 * sync.flat.numel()
+        assert all(p.grad is None or lo <= p.grad.data_ptr() < hi for p in m1.parameters())
+    assert o1.flat_steps == 3
+
+
+def test_flat_adam_keeps_shared_storages_together(dev):
+    """The merged head layers make the parameters they read as ONE operand adjacent in one storage (functional.rehome_adjacent) and check
+    that adjacency every forward; the flat layout moves such a storage as a unit, so the check keeps passing (no concatenation per step),
+    odd-sized members included (element-wise path of the kernel).  A group that is re-homed AFTER the first step -- a head that runs for
+    the first time -- triggers ONE rebuild of the layout, with the moments carried over."""
+    from mlsp_amd import functional as Fh
+    from mlsp_amd.optim import FlatAdam
+
+    class Heads(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.c = nn.Linear(19, 33), nn.Linear(19, 33), nn.Linear(19, 7)      # 627- and 133-element weights: odd offsets
+            self.d, self.e = nn.Linear(33, 5), nn.Linear(33, 5)
+
+        def forward(self, x):
+            h = torch.relu(self.a(x)) + torch.relu(self.b(x))
+            return self.d(h).sum() + self.e(h).sum() + self.c(x).sum()
+
+    torch.manual_seed(5)
+    m1 = Heads().to(dev)
+    m2 = copy.deepcopy(m1)
+    assert Fh.rehome_adjacent([m1.a.weight, m1.b.weight, m1.c.weight]) and Fh.rehome_adjacent([m1.a.bias, m1.b.bias, m1.c.bias])
+    o1 = FlatAdam(m1.parameters(), lr=1e-3, weight_decay=5e-5)
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+    for it in range(6):
+        if it == 3:
+            assert Fh.rehome_adjacent([m1.d.weight, m1.e.weight])          # leaves the flat buffer: rebuilt at the next step
+        x = torch.randn(16, 19, device=dev, generator=torch.Generator(device=dev).manual_seed(it))
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            m(x).backward()
+            o.step()
+        _same(m1, m2)
+        assert Fh._adjacent([m1.a.weight, m1.b.weight, m1.c.weight]) and Fh._adjacent([m1.a.bias, m1.b.bias, m1.c.bias])
+        if it >= 3:
+            assert Fh._adjacent([m1.d.weight, m1.e.weight])
+    assert o1.flat_steps == 6 and o1.layouts_built == 2
+    for p, q in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(o1.state[p]["exp_avg"], o2.state[q]["exp_avg"]) and torch.equal(o1.state[p]["exp_avg_sq"], o2.state[q]["exp_avg_sq"])
