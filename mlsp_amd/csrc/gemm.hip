@@ -940,8 +940,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = blockIdx.x;
-    int tm, tn;
-    if (p.xcd_map) {
+    int tm, tn, split = blockIdx.y;
+    if (p.xcd_map == 2) {
+        // few row panels, many K splits (weight gradients; 1-D grid): the ntn tiles that read the same A panel of the same K range are
+        // consecutive slots of ONE XCD -- dispatched together, they walk their K range in step and the panel is fetched from HBM once
+        // instead of once per XCD (the plain order spread them over ntn XCDs: 1.24 GB HBM-side for 335 MB of operands at 1024 x 512 x 32768)
+        const int xcd = bid & 7, q = bid >> 3;
+        tn = q % p.ntn;
+        const int G = (q / p.ntn) * 8 + xcd;               // (split, row panel) pair
+        tm = G % p.ntm;
+        split = G / p.ntm;
+    } else if (p.xcd_map) {
         const int xcd = bid & 7, q = bid >> 3;
         tn = q % p.ntn;
         tm = (q / p.ntn) * 8 + xcd;
@@ -950,7 +959,6 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
         tn = bid % p.ntn;
         tm = bid / p.ntn;
     }
-    const int split = blockIdx.y;
     const int m0 = tm * BMT, n0 = tn * BN;
     const int kbeg = split * p.ksplit;
     const int kend = min(p.K, kbeg + p.ksplit);
@@ -1045,7 +1053,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
 #define SX_XF_NEXT(tnext_) do { if constexpr (XF != 0) { xq += (uint32_t)xqt; if constexpr (XF == 1) { const int tc_ = min((tnext_), T - 1) * BK + (tid & 7) * 4; \
         xsc = *(const f32x4*)(xfs + tc_); xsh = *(const f32x4*)(xfs + SX_XF_KMAX + tc_); } } } while (0)
     // ---- DY state: rawy = the y quads of the tile being staged; dc0 / dnk2 / dsc = the coefficient quads of this thread's channels
-    f32x4 rawy[DY ? NQA : 1];
+    f32x4 rawy[DY ? 4 : 1];                                  // (sized for WM = 2: both bodies are compiled into every instantiation)
     f32x4 dc0 = {0.f, 0.f, 0.f, 0.f}, dnk2 = {0.f, 0.f, 0.f, 0.f}, dsc = {0.f, 0.f, 0.f, 0.f};
     if constexpr (DY) {
         if constexpr (KA) {             // weight gradient: channel = this thread's four tile rows, fixed
@@ -1599,6 +1607,8 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (ns > 1) { p.C = slab; p.ldc = N; }
     p.xcd_map = p.ntm >= 16 && p.ntn > 1;
     dim3 grid(p.xcd_map ? ((p.ntm + 7) / 8) * 8 * p.ntn : p.ntm * p.ntn, ns);
+    static const bool no_xcd2 = getenv("MLSP_GEMM_NO_XCD2") != nullptr;       // read-once A/B switch (tools/ab)
+    bool xcd2 = false;                                                        // (decided below, once the kernel is known: split kernel only)
     const bool prof = g_prof.on && g_prof.used < PROF_MAX_PAIRS;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
@@ -1621,6 +1631,10 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     }
     const bool xf_split = xf && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && (xf->which != 1 || kts * BK <= SX_XF_KMAX);
     if (grp && xf && !xf_split) return MLSP_ERR_UNSUPPORTED;             // (the fp32 transform kernels take no groups: nothing launched)
+    // split-K launches of gemm_split_kernel with few row panels (weight gradients): XCD-grouped (split, panel) order, see the kernel
+    xcd2 = !no_xcd2 && !p.xcd_map && ns > 1 && p.ntn > 1 && (p.ntm * ns) % 8 == 0 && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) &&
+           (!xf || xf_split);
+    if (xcd2) { p.xcd_map = 2; grid = dim3(p.ntm * p.ntn * ns, 1); }
     const bool n64 = !dy && !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
                      (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && tl_call_precision != 1 && (ns == 1 || p.ldc == N);
     if (n64) {
