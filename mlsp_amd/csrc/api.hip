@@ -38,6 +38,7 @@ int gemm_stat_parts(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K);
 int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws, void* planes, size_t plane_bytes);
 bool knn6_supported(int B, int N, int C, int k);
+bool knn6w_supported(int B, int N, int C, int k);
 size_t knn6_plane_bytes(int P, int C);
 int launch_knn_reverse(hipStream_t st, const int* idx, int B, int N, int k, int* rev_off, int* rev_ent);
 int bn_stat_parts(int M);
@@ -245,7 +246,7 @@ int mlsp_knn_f32(const float* x, int ldx, int B, int N, int C, int k, int32_t* i
     Workspace w(ws, ws_bytes);
     float* xx = w.take<float>((size_t)B * N);
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
-    const size_t pbytes = knn6_supported(B, N, C, k) ? knn6_plane_bytes(B * N, C) : 0;      // bf16 hi / lo images of the points (knn6.hip)
+    const size_t pbytes = (knn6_supported(B, N, C, k) || knn6w_supported(B, N, C, k)) ? knn6_plane_bytes(B * N, C) : 0;      // bf16 hi / lo images of the points (knn6.hip)
     char* planes = pbytes ? w.take<char>(pbytes) : nullptr;          // (a workspace too small for them keeps the call on the v5 kernels)
     {   // bench.py roofline_kernels: C <= 4 priced against HBM (compulsory bytes), C = 64 / 128 against the fp32 matrix peak
         const int cls = C <= 4 ? MLSP_PROF_KNN_C3 : C == 64 ? MLSP_PROF_KNN_C64 : C == 128 ? MLSP_PROF_KNN_C128 : 0;

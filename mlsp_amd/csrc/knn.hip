@@ -712,7 +712,7 @@ __device__ __forceinline__ void knn_split8(const float (&b)[8], kbf16x8& hi, kbf
 
 template <int CT, bool VEC, bool RES, int KB>
 __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict__ x, const float* __restrict__ xx_all,
-                                                        int ld, int N, int C, int k, int* __restrict__ idx, int B) {
+                                                        int ld, int N, int C, int k, int* __restrict__ idx, int B, const int* __restrict__ only_clouds) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TILE = CT * KM_STRIDE;
 #ifndef KNN5_NO_BF16A
@@ -732,6 +732,7 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
     const int qg = wave & 3, ch = wave >> 2, ht = tid & 255;
     int b, chunk;
     xcd_cloud_map(blockIdx.x, N / 128, B, b, chunk);
+    if (only_clouds && only_clouds[b] == 0) return;             // behind knn6w_kernel: only the clouds it flagged (uniform per workgroup)
     const float* xb = x + (size_t)b * N * ld;
     const float* xxb = xx_all + (size_t)b * N;
     const int ntiles = N / 32, nt2 = ntiles / 2;
@@ -1331,12 +1332,13 @@ __global__ __launch_bounds__(512) void knn_mfma5_kernel(const float* __restrict_
 
 template <int CT, bool VEC, bool RES, int KB>
 static int launch_knn_mfma5_ct(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx,
-                               size_t lds) {
+                               size_t lds, const int* only, bool dry) {
+    if (dry) return 0;
     if (lds > 64 * 1024) {
         hipError_t e = mlsp_lds_limit((const void*)knn_mfma5_kernel<CT, VEC, RES, KB>, lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((knn_mfma5_kernel<CT, VEC, RES, KB>), dim3((N / 128) * B), dim3(512), lds, st, x, xx, ld, N, C, k, idx, B);
+    hipLaunchKernelGGL((knn_mfma5_kernel<CT, VEC, RES, KB>), dim3((N / 128) * B), dim3(512), lds, st, x, xx, ld, N, C, k, idx, B, only);
     return mlsp_launch_status();
 }
 
@@ -1350,8 +1352,10 @@ static size_t knn5_lds_bytes(int CT, int N, bool res, bool kb, bool vec = false)
     return fl * sizeof(float);
 }
 
-// returns MLSP_ERR_UNSUPPORTED when the shape is outside v5's fast path (caller falls back to v4 / the list-merge kernel)
-static int launch_knn_mfma5(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx) {
+// returns MLSP_ERR_UNSUPPORTED when the shape is outside v5's fast path (caller falls back to v4 / the list-merge kernel).
+// only: per-cloud flags (device), nullptr = every cloud; dry: launch nothing, just say whether the shape is taken
+static int launch_knn_mfma5(hipStream_t st, const float* x, int ld, const float* xx, int B, int N, int C, int k, int* idx,
+                            const int* only = nullptr, bool dry = false) {
     if (N % 128 != 0 || k > 64 || C > 128) return MLSP_ERR_UNSUPPORTED;
     const bool kb = k > 24;        // k = 25..32 on the 64-maxima bound overflow its 32-key buffers too often (734 us vs 290 at N = 2048)
     const int CT = C <= 4 ? 4 : C <= 16 ? 16 : C <= 64 ? 64 : 128;
@@ -1359,14 +1363,14 @@ static int launch_knn_mfma5(hipStream_t st, const float* x, int ld, const float*
     const bool res = CT <= 16 && knn5_lds_bytes(CT, N, true, kb) <= 160 * 1024;
     const size_t lds = knn5_lds_bytes(CT, N, res, kb, vec);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
-#define KNN5_GO(CTV, VECV, RESV) do { if (kb) return launch_knn_mfma5_ct<CTV, VECV, RESV, 1>(st, x, ld, xx, B, N, C, k, idx, lds); \
-                                      return launch_knn_mfma5_ct<CTV, VECV, RESV, 0>(st, x, ld, xx, B, N, C, k, idx, lds); } while (0)
+#define KNN5_GO(CTV, VECV, RESV) do { if (kb) return launch_knn_mfma5_ct<CTV, VECV, RESV, 1>(st, x, ld, xx, B, N, C, k, idx, lds, only, dry); \
+                                      return launch_knn_mfma5_ct<CTV, VECV, RESV, 0>(st, x, ld, xx, B, N, C, k, idx, lds, only, dry); } while (0)
     if (CT == 4) { if (res) { if (vec) KNN5_GO(4, true, true); KNN5_GO(4, false, true); } if (vec) KNN5_GO(4, true, false); KNN5_GO(4, false, false); }
     if (CT == 16) { if (res) { if (vec) KNN5_GO(16, true, true); KNN5_GO(16, false, true); } if (vec) KNN5_GO(16, true, false); KNN5_GO(16, false, false); }
     if (CT == 64) { if (vec) KNN5_GO(64, true, false); KNN5_GO(64, false, false); }
     if (vec) KNN5_GO(128, true, false);
     if (kb) return MLSP_ERR_UNSUPPORTED;       // k > 24 with 64 < C < 128 or unaligned rows: out of registers, stays on the list-merge kernel
-    return launch_knn_mfma5_ct<128, false, false, 0>(st, x, ld, xx, B, N, C, k, idx, lds);
+    return launch_knn_mfma5_ct<128, false, false, 0>(st, x, ld, xx, B, N, C, k, idx, lds, only, dry);
 #undef KNN5_GO
 }
 
@@ -1399,6 +1403,8 @@ int launch_knn6(hipStream_t st, const float* x, int ld, int B, int N, int C, int
 bool knn6_vex_supported(int B, int N, int C, int k);
 size_t knn6_vex_bytes(int P);
 int launch_knn6_vex(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, void* cand);
+bool knn6w_supported(int B, int N, int C, int k);
+int launch_knn6w(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, void* planes, int** flags_out);
 
 // xx_ws: [B*N] floats of workspace; planes (nullable): knn6_plane_bytes(B*N, C) bytes of workspace for the v6 kernel's bf16 images
 int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws, void* planes, size_t plane_bytes) {
@@ -1415,6 +1421,16 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
     }
     if (!force_v5 && planes && knn6_supported(B, N, C, k) && plane_bytes >= knn6_plane_bytes(P, C) && (C > 16 || v6_all)) {   // (C <= 16 stays on v5 until v6's selection phases beat it there)
         const int rc = launch_knn6(st, x, ld, B, N, C, k, idx, xx_ws, planes);
+        if (rc != MLSP_ERR_UNSUPPORTED) return rc;
+    }
+    // 24 < k <= 40 (PointSegDA's k = 40): the wide v6 kernel, with the v5 kernel behind it for the clouds it flags (list overflow: massive
+    // ties; non-finite bounds) -- v5's workgroups of unflagged clouds return at once.  Only where v5 itself takes the shape.
+    // Every C <= 128: at C = 3 (B = 16, N = 2048, k = 40) 82 us against v5's 117, C = 64 152 / 235, C = 128 210 / 435.
+    if (!force_v5 && planes && knn6w_supported(B, N, C, k) && plane_bytes >= knn6_plane_bytes(P, C) &&
+        launch_knn_mfma5(st, x, ld, xx_ws, B, N, C, k, idx, nullptr, true) == 0) {
+        int* flags = nullptr;
+        const int rc = launch_knn6w(st, x, ld, B, N, C, k, idx, xx_ws, planes, &flags);
+        if (rc == 0) return launch_knn_mfma5(st, x, ld, xx_ws, B, N, C, k, idx, flags, false);
         if (rc != MLSP_ERR_UNSUPPORTED) return rc;
     }
     hipLaunchKernelGGL(sqnorm_kernel, dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, C, xx_ws, idx, k);

@@ -68,9 +68,11 @@ __device__ __forceinline__ size_t k6_piece(size_t T, int nkb, int kb, int p, int
 // EdgeConv output), and bounds in terms of the raw norms would declare most survivors ambiguous.
 template <int CT>
 __global__ __launch_bounds__(256) void knn6_prep_kernel(const float* __restrict__ x, int ld, int P, int N, int C, float* __restrict__ xx,
-                                                        float* __restrict__ xc, char* __restrict__ planes, int* __restrict__ idx, int k) {
+                                                        float* __restrict__ xc, char* __restrict__ planes, int* __restrict__ idx, int k,
+                                                        int* __restrict__ cloud_flag) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
+    if (cloud_flag && i < P / N) cloud_flag[i] = 0;           // (knn6w_kernel: which clouds go to the v5 kernel)
     // Every output row starts as k zeros: a query with fewer than k comparable candidates (NaN coordinates -- its own or its cloud's) keeps
     // index 0 in the positions the main kernel does not write, as oracle/knn_canon.c does; the gathers downstream never see an
     // uninitialised index.
@@ -849,6 +851,562 @@ __global__ __launch_bounds__(512) void knn6_kernel(const float* __restrict__ x, 
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// v6 WIDE (24 < k <= 40, N % 128 == 0, C <= 128): PointSegDA's graphs (k = 40, PointSegDA/Models.py:6-15; BASELINE.json configs[4]).
+// The same two sweeps, lists and final as knn6_kernel with the WORKGROUP re-cut so that the 232-byte survivor lists still fit the CU:
+//   * workgroup = 64 queries (two groups of 32) x all N candidates; wave w: qg = w & 1, ch = w >> 1 sweeps a QUARTER of the candidates.
+//     A query's candidates are cut into 8 sub-ranges (quarter x half-wave lane): 512 lists of K6_CAP = 24 entries as before, but a query
+//     now owns 8 of them.  With k = 40 a query keeps ~50 survivors, ~6 per list: K6_CAP is six standard deviations away.
+//   * pass A leaves 128 running maxima per query; tau = their k-th largest.  Two lanes per query sort 64 each (the bitonic network of
+//     knn6_kernel), exchange them through v_permlane32_swap (max(a[i], b[63 - i]) = the 64 largest of the union, a bitonic sequence) and
+//     merge.  Against 64 maxima the bound is tighter: ~1.2 k survivors instead of ~1.6 k.
+//   * fast final: EIGHT lanes per query (64 rank positions; exchanges at lane distance 8 through DPP row_ror, 16 / 32 through the
+//     permlane swaps); the counting final takes queries with more than 64 survivors.
+//   * no exact path inside: a workgroup whose lists overflow (massive ties: padded clouds) or whose bound is not finite raises its CLOUD's
+//     flag and leaves; the v5 kernel (knn.hip, KB = 1) runs right behind on the flagged clouds only (its workgroups of other clouds return at
+//     once) and overwrites their rows.  Indices bit-exact either way: both kernels rank by the canonical distance under the same total order.
+#define K6W_XS 132          // floats per query of the tau exchange image (128 maxima, 16-byte aligned rows, 4-bank skew)
+#define K6W_KMAX 40
+
+__device__ __forceinline__ unsigned k6w_x8(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true); }     // lane ^ 8 (row_ror:8)
+
+template <int CT>
+__global__ __launch_bounds__(512) void knn6w_kernel(const float* __restrict__ x, int ld, const float* __restrict__ xx_all, const float* __restrict__ xc_all,
+                                                    const char* __restrict__ planes, int N, int C, int k, int* __restrict__ idx, int B,
+                                                    int* __restrict__ cloud_flag) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NKB = CT / 16;
+    constexpr int PF = NKB >= 8 ? 1 : NKB >= 4 ? 2 : 4;
+    constexpr int NR = PF * NKB;
+    constexpr int UNR = NKB >= 8 ? 2 : 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5, qg = wave & 1, ch = wave >> 1;
+    int b, chunk;
+    xcd_cloud_map(blockIdx.x, N / 64, B, b, chunk);
+    const float* xxb = xx_all + (size_t)b * N;
+    const float* xcb = xc_all + (size_t)b * N;
+    const size_t T0 = (size_t)b * (N / 32);
+    const float* xb = x + (size_t)b * N * ld;
+    const int nt4 = N / 128;                                  // 32-candidate tiles of this wave's quarter
+
+    char* lists = (char*)sm;                                  // [512 lists][K6_LSTR]; list = ((qg*4 + ch)*2 + h)*32 + query of the group = (qg*8 + t)*32 + query, t = 2 ch + h
+    float* xch = sm;                                          // tau exchange image [64 queries][K6W_XS], dead before pass B
+    float* nxx = (float*)(lists + 512 * K6_LSTR);             // [N]  -xc_j / 2
+    float* tauv = nxx + N;                                    // [64] (+64 unused)
+    int* cnts = (int*)(tauv + 128);                           // [64 queries][8 sub-ranges]
+    float* red = (float*)(cnts + 512);                        // [16]
+    unsigned* wlbase = (unsigned*)(red + 16);                 // [8 waves][512 words]: fast final [8 queries][64]; counting final: work list
+    float* lmn = (float*)(wlbase + 8 * 512);                  // [64 queries][8 sub-ranges]
+    const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)sm);
+
+    float xcmax, xxmax;
+    {
+        float m = 0.f, mr = 0.f;
+        for (int j = tid; j < N; j += 512) {
+            const float v = xcb[j], w = xxb[j];
+            nxx[j] = -0.5f * v; m = fmaxf(m, v == v ? v : INFINITY); mr = fmaxf(mr, w == w ? w : INFINITY);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); mr = fmaxf(mr, __shfl_xor(mr, o, 64)); }
+        if (lane == 0) { red[wave] = m; red[8 + wave] = mr; }
+        __syncthreads();
+        xcmax = red[0]; xxmax = red[8];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { xcmax = fmaxf(xcmax, red[w]); xxmax = fmaxf(xxmax, red[8 + w]); }
+    }
+    const float K6_CANON = (float)(C + 4) * 1.1920929e-07f;
+    const int q0 = chunk * 64 + qg * 32;                      // first query of this wave's group, local to the cloud
+    const float xxq = xxb[q0 + l31];
+    const float xcq = xcb[q0 + l31];
+    const float Eq = K6_EPS * (xcq + xcmax) + K6_CANON * (xxq + xxmax);      // (error budget: knn6_kernel / the file header)
+
+    k6bf16x8 qh[NKB], ql[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        qh[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (q0 >> 5), NKB, kb, 0, h, l31));
+        ql[kb] = *(const k6bf16x8*)(planes + k6_piece(T0 + (q0 >> 5), NKB, kb, 1, h, l31));
+    }
+    const unsigned voff = (unsigned)(h * 512 + l31 * 16);
+    const char* cand0 = planes + (T0 + (size_t)ch * nt4) * (NKB * 2048);
+    auto frag_load = [&](int tl, int kb, k6bf16x8& ah, k6bf16x8& al) {
+        const char* p = cand0 + (size_t)tl * (NKB * 2048) + kb * 2048;
+        ah = *(const k6bf16x8*)(p + voff);
+        al = *(const k6bf16x8*)(p + 1024 + voff);
+    };
+    // (the sweep of knn6_kernel over nt4 tiles: fragment ring, a scheduling barrier after every refill, UNR tiles per trip)
+    auto sweep = [&](auto&& sel) {
+        k6bf16x8 fh[NR], fl[NR];
+        auto tile = [&](auto SLOT, auto RING, int tl, int tn, auto&& sel_) {
+            constexpr int s0 = decltype(SLOT)::value * NKB;
+            constexpr bool ring = decltype(RING)::value;
+            f32x16 acc;
+            const float* p = nxx + (ch * nt4 + tl) * 32 + 4 * h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 v = *(const f32x4*)(p + 8 * g4);
+                acc[4 * g4] = v[0]; acc[4 * g4 + 1] = v[1]; acc[4 * g4 + 2] = v[2]; acc[4 * g4 + 3] = v[3];
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s0 + kb], qh[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s0 + kb], qh[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s0 + kb], ql[kb], acc, 0, 0, 0);
+                if (ring) {
+                    frag_load(tn, kb, fh[s0 + kb], fl[s0 + kb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            sel_(acc, tl);
+        };
+        const int nmain = (nt4 / UNR) * UNR;
+        if (nmain > 0) {
+#pragma unroll
+            for (int tu = 0; tu < PF; ++tu)
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) frag_load(min(tu, nt4 - 1), kb, fh[tu * NKB + kb], fl[tu * NKB + kb]);
+            for (int t0 = 0; t0 < nmain; t0 += UNR) {
+                k6_static_for<0, UNR>([&](auto TU) {
+                    constexpr int tu = decltype(TU)::value;
+                    const int tl = t0 + tu;
+                    const int tn = min(tl + PF, nt4 - 1);
+                    tile(std::integral_constant<int, tu % PF>{}, std::true_type{}, tl, tn, sel);
+                });
+            }
+        }
+        for (int tl = nmain; tl < nt4; ++tl) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) frag_load(tl, kb, fh[kb], fl[kb]);
+            tile(std::integral_constant<int, 0>{}, std::false_type{}, tl, tl, sel);
+        }
+    };
+
+    // ---- pass A: 16 running maxima per lane -> 128 per query
+    {
+        float cm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
+        sweep([&](const f32x16& acc, int) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cm[r] = fmaxf(cm[r], acc[r]);
+        });
+        float* dst = xch + (qg * 32 + l31) * K6W_XS + (ch * 2 + h) * 16;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) { const f32x4 v = {cm[4 * g4], cm[4 * g4 + 1], cm[4 * g4 + 2], cm[4 * g4 + 3]}; *(f32x4*)(dst + 4 * g4) = v; }
+    }
+    __syncthreads();
+    // tau = k-th largest of the query's 128 maxima: lanes (l31, h = 0 / 1) of the group's ch = 0 wave each sort 64, then merge
+    if (ch == 0) {
+        const int qs = qg * 32 + l31;
+        float v[64];
+        const float* src = xch + qs * K6W_XS + h * 64;
+#pragma unroll
+        for (int i4 = 0; i4 < 16; ++i4) {
+            const f32x4 t = *(const f32x4*)(src + 4 * i4);
+            v[4 * i4] = t[0]; v[4 * i4 + 1] = t[1]; v[4 * i4 + 2] = t[2]; v[4 * i4 + 3] = t[3];
+        }
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1)
+#pragma unroll
+            for (int j = k2 >> 1; j > 0; j >>= 1)
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const float lo = fminf(v[i], v[l]), hi = fmaxf(v[i], v[l]);
+                        if ((i & k2) == 0) { v[i] = hi; v[l] = lo; }           // descending overall
+                        else { v[i] = lo; v[l] = hi; }
+                    }
+                }
+        // the 64 largest of the two sorted halves: w[i] = max(mine[i], other[63 - i]) (a bitonic sequence; the partner lane holds it reversed)
+        float w[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[63 - i]), __float_as_uint(v[63 - i]), false, false);
+            w[i] = fmaxf(v[i], __uint_as_float(h ? r[0] : r[1]));
+        }
+#pragma unroll
+        for (int j = 32; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const int l = i ^ j;
+                if (l > i) { const float lo = fminf(w[i], w[l]), hi = fmaxf(w[i], w[l]); w[i] = hi; w[l] = lo; }
+            }
+        float t = w[0];
+#pragma unroll
+        for (int i = 1; i < K6W_KMAX; ++i) t = (i == k - 1) ? w[i] : t;
+        if (lane < 32) tauv[qs] = t;
+    }
+    __syncthreads();                                          // tau complete; the exchange image (aliases the lists) is dead from here on
+    float thr = tauv[qg * 32 + l31] - Eq;
+    thr = thr == thr ? thr : -INFINITY;
+
+    // ---- pass B: survivors -> this lane's private list
+    const int lid = ((qg * 4 + ch) * 2 + h) * 32 + l31;
+    char* LB = lists + (size_t)lid * K6_LSTR;
+    const unsigned base = lds0 + (unsigned)(lid * K6_LSTR);
+    unsigned ad = base, top = base;
+    sweep([&](const f32x16& acc, int tl) {
+        const int jb = (ch * nt4 + tl) * 32 + 4 * h;
+        int jv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) jv[r] = jb + (r & 3) + 8 * (r >> 2);
+        const float gate = fmaxf(acc[0], acc[15]);            // (MFMA -> VALU wait states: see knn6_kernel)
+#define K6_APPEND(ad_, val_, thr_, j_, gate_) asm volatile("v_cmpx_ge_f32_e32 vcc, %1, %2\n\tds_write2_b32 %0, %1, %3 offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, -1" \
+                                                           : "+v"(ad_) : "v"(val_), "v"(thr_), "v"(j_), "v"(gate_) : "vcc", "memory")
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            K6_APPEND(ad, acc[r], thr, jv[r], gate);
+            if ((r & 3) == 3) { top = max(top, ad); ad = min(ad, base + K6_CAP * 8); }
+        }
+#undef K6_APPEND
+    });
+    const int cnt = (int)(ad - base) >> 3;
+    const int ovf = (top > base + K6_CAP * 8 || !(Eq < INFINITY)) ? 1 : 0;
+    if (__syncthreads_or(ovf)) {                              // overflow / no usable bound: this cloud goes to the v5 kernel launched behind
+        if (tid == 0) cloud_flag[b] = 1;
+        return;
+    }
+    // ---- F0: lists to the pd domain (pd' = 2 a - xc_q), filled to the end with {-inf, 0}
+    {
+        float mn = 0.f;
+#pragma unroll
+        for (int p0 = 0; p0 < K6_LENT; p0 += 4) {
+            k6u32x2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const k6u32x2*)(LB + (p0 + u) * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a = __int_as_float((int)v[u][0]);
+                const float p = fmaf(2.0f, a, -xcq);
+                const bool live = p0 + u < cnt;
+                const k6u32x2 w = {(unsigned)__float_as_int(live ? p : -INFINITY), live ? v[u][1] : 0u};
+                *(k6u32x2*)(LB + (p0 + u) * 8) = w;
+                if (live) mn = fminf(mn, nxx[v[u][1] & 4095u]);
+            }
+        }
+        cnts[(qg * 32 + l31) * 8 + ch * 2 + h] = cnt;
+        lmn[(qg * 32 + l31) * 8 + ch * 2 + h] = mn;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------------------------------------------------------- final: exact ranks
+    const bool xvec = (ld & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (C & 3) == 0;
+    auto list_at = [&](int qlc_, int t) -> char* { return lists + (size_t)(((qg * 8 + t) * 32 + qlc_) * K6_LSTR); };
+    // ---- fast final (every query of the wave has at most 64 survivors): eight lanes per query, lane l serves query l & 7 of the wave's eight
+    // (queries ch * 8 .. + 7 of the group) and holds rank positions 8 m .. 8 m + 7 of its 64 (m = l >> 3)
+    {
+        const int ql8 = lane & 7, m = lane >> 3;
+        const int qlc = ch * 8 + ql8;
+        const int qq = qg * 32 + qlc, qrow = chunk * 64 + qq;
+        const k6i32x4 ca = *(const k6i32x4*)(cnts + qq * 8), cb = *(const k6i32x4*)(cnts + qq * 8 + 4);
+        int pp[9];
+        pp[0] = 0; pp[1] = ca[0]; pp[2] = pp[1] + ca[1]; pp[3] = pp[2] + ca[2]; pp[4] = pp[3] + ca[3];
+        pp[5] = pp[4] + cb[0]; pp[6] = pp[5] + cb[1]; pp[7] = pp[6] + cb[2]; pp[8] = pp[7] + cb[3];
+        const int n = pp[8];
+        int nmaxw = n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nmaxw = max(nmaxw, __shfl_xor(nmaxw, o, 64));
+        if (nmaxw <= 64) {
+            const f32x4 ma = *(const f32x4*)(lmn + qq * 8), mb = *(const f32x4*)(lmn + qq * 8 + 4);
+            const float xm = -2.0f * fminf(fminf(fminf(ma[0], ma[1]), fminf(ma[2], ma[3])), fminf(fminf(mb[0], mb[1]), fminf(mb[2], mb[3])));
+            const float xqr = xxb[qrow], xqc = xcb[qrow];
+            const float E2 = 2.0f * (K6_EPS * (xqc + xm) + K6_CANON * (xqr + xxmax));
+            float pv[8];
+            int jv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 8 * m + i;
+                int t = 0, pb = 0;
+#pragma unroll
+                for (int u = 1; u < 8; ++u) { const bool ge = e >= pp[u]; t = ge ? u : t; pb = ge ? pp[u] : pb; }
+                const k6u32x2 v = *(const k6u32x2*)(list_at(qlc, e < n ? t : 0) + (e < n ? e - pb : 0) * 8);
+                pv[i] = e < n ? __int_as_float((int)v[0]) : -INFINITY;
+                jv[i] = e < n ? (int)v[1] : 0x7fffffff;
+            }
+            auto x16 = [&](unsigned v) -> unsigned { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (m & 2) ? r[0] : r[1]; };
+            auto x32 = [&](unsigned v) -> unsigned { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (m & 4) ? r[0] : r[1]; };
+            auto cex_local = [&](int jj, bool desc) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const int c = a ^ jj;
+                    if (c > a) {
+                        const bool sw = desc ? pv[a] < pv[c] : pv[a] > pv[c];
+                        const float ta = sw ? pv[c] : pv[a], tc = sw ? pv[a] : pv[c];
+                        const int ja = sw ? jv[c] : jv[a], jc = sw ? jv[a] : jv[c];
+                        pv[a] = ta; pv[c] = tc; jv[a] = ja; jv[c] = jc;
+                    }
+                }
+            };
+            auto cex_cross = [&](int bit, bool desc) {       // positions 8 m + i and 8 (m ^ bit) + i: the lane whose m lacks `bit` is the lower position
+                const bool low = (m & bit) == 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned uv = __float_as_uint(pv[i]), uj = (unsigned)jv[i];
+                    const float ov = __uint_as_float(bit == 1 ? k6w_x8(uv) : bit == 2 ? x16(uv) : x32(uv));
+                    const int oj = (int)(bit == 1 ? k6w_x8(uj) : bit == 2 ? x16(uj) : x32(uj));
+                    const bool sw = low ? (desc ? pv[i] < ov : pv[i] > ov) : (desc ? ov < pv[i] : ov > pv[i]);
+                    pv[i] = sw ? ov : pv[i]; jv[i] = sw ? oj : jv[i];
+                }
+            };
+            // bitonic network over positions a = 8 m + i; a pair keeps the larger value at the lower position iff (a & k2) == 0
+#pragma unroll
+            for (int a = 0; a < 8; a += 2) {                    // k2 = 2
+                const bool desc = (a & 2) == 0;
+                const bool sw = desc ? pv[a] < pv[a + 1] : pv[a] > pv[a + 1];
+                const float ta = sw ? pv[a + 1] : pv[a], tc = sw ? pv[a] : pv[a + 1];
+                const int ja = sw ? jv[a + 1] : jv[a], jc = sw ? jv[a] : jv[a + 1];
+                pv[a] = ta; pv[a + 1] = tc; jv[a] = ja; jv[a + 1] = jc;
+            }
+#pragma unroll
+            for (int jj = 2; jj > 0; jj >>= 1)                  // k2 = 4: direction by bit 2 of the position
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const int c = a ^ jj;
+                    if (c > a) {
+                        const bool desc = (a & 4) == 0;
+                        const bool sw = desc ? pv[a] < pv[c] : pv[a] > pv[c];
+                        const float ta = sw ? pv[c] : pv[a], tc = sw ? pv[a] : pv[c];
+                        const int ja = sw ? jv[c] : jv[a], jc = sw ? jv[a] : jv[c];
+                        pv[a] = ta; pv[c] = tc; jv[a] = ja; jv[c] = jc;
+                    }
+                }
+            { const bool d = (m & 1) == 0; cex_local(4, d); cex_local(2, d); cex_local(1, d); }                                              // k2 = 8
+            { const bool d = (m & 2) == 0; cex_cross(1, d); cex_local(4, d); cex_local(2, d); cex_local(1, d); }                             // k2 = 16
+            { const bool d = (m & 4) == 0; cex_cross(2, d); cex_cross(1, d); cex_local(4, d); cex_local(2, d); cex_local(1, d); }            // k2 = 32
+            { cex_cross(4, true); cex_cross(2, true); cex_cross(1, true); cex_local(4, true); cex_local(2, true); cex_local(1, true); }      // k2 = 64
+            // flag: gap to the next survivor in rank not provably larger than 2 E
+            const float nxt0 = __shfl(pv[0], lane + 8, 64), prv7 = __shfl(pv[7], lane - 8, 64);
+            unsigned amb = 0u;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) amb |= (8 * m + i + 1 < n && !(pv[i] - pv[i + 1] > E2)) ? (3u << i) : 0u;
+            amb |= (m < 7 && 8 * m + 8 < n && !(pv[7] - nxt0 > E2)) ? 0x80u : 0u;
+            amb |= (m > 0 && 8 * m < n && !(prv7 - pv[0] > E2)) ? 1u : 0u;
+            const int nfl = __builtin_popcount(amb);
+            int nflag = 0, foff = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const int f = __shfl(nfl, ql8 + 8 * t, 64); nflag += f; foff += t < m ? f : 0; }
+            unsigned* slots = wlbase + wave * 512 + ql8 * 64 + foff;     // this lane's part of the query's [64]: candidate index in, canonical distance out
+            {
+                int c = 0;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    if ((amb >> a) & 1u) { slots[c] = (unsigned)jv[a]; ++c; }
+                }
+            }
+            int fmaxw = nflag;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) fmaxw = max(fmaxw, __shfl_xor(fmaxw, o, 64));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (fmaxw > 0) {                                    // canonical distances of the flagged pairs, densely packed over the wave's lanes
+                int offs[9];
+                offs[0] = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) offs[q + 1] = offs[q] + __builtin_amdgcn_readlane(nflag, q);
+                const int total = offs[8];
+                unsigned* wslots = wlbase + wave * 512;
+                const int qbase = chunk * 64 + qg * 32 + ch * 8;
+                for (int i0 = 0; i0 < total; i0 += 64) {
+                    const int i = i0 + lane;
+                    if (i < total) {
+                        int q = 0, ob = 0;
+#pragma unroll
+                        for (int t = 1; t < 8; ++t) { const bool ge = i >= offs[t]; q = ge ? t : q; ob = ge ? offs[t] : ob; }
+                        unsigned* sp = wslots + q * 64 + (i - ob);
+                        const int j = (int)*sp;
+                        const int qr = qbase + q;
+                        const float* rq = xb + (size_t)qr * ld;
+                        const float* rj = xb + (size_t)j * ld;
+                        float acc = 0.f;
+                        if (!xvec) {
+                            for (int c = 0; c < C; ++c) acc = fmaf(rq[c], rj[c], acc);
+                        } else {
+                            constexpr int CHV = CT >= 128 ? 8 : 16;
+                            for (int c = 0; c < C; c += 4 * CHV) {
+                                f32x4 a4[CHV], b4[CHV];
+#pragma unroll
+                                for (int u = 0; u < CHV; ++u)
+                                    if (c + 4 * u < C) { a4[u] = *(const f32x4*)(rq + c + 4 * u); b4[u] = *(const f32x4*)(rj + c + 4 * u); }
+#pragma unroll
+                                for (int u = 0; u < CHV; ++u)
+                                    if (c + 4 * u < C) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) acc = fmaf(a4[u][e], b4[u][e], acc);
+                                    }
+                            }
+                        }
+                        const float t2 = fmaf(2.0f, acc, -xxb[j]);
+                        *sp = (unsigned)__float_as_int(t2 - xxb[qr]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            {
+                int c = 0;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    if ((amb >> a) & 1u) { pv[a] = __int_as_float((int)slots[c]); ++c; }
+                }
+            }
+            if (fmaxw > 0) {                                    // settle the flagged runs under the full order (value desc, index asc)
+                for (int pass = 0; pass < 64; ++pass) {
+                    bool moved = false;
+#pragma unroll
+                    for (int a = 0; a < 7; a += 2) {
+                        const bool sw = k6_beats(pv[a + 1], jv[a + 1], pv[a], jv[a]);
+                        const float ta = sw ? pv[a + 1] : pv[a], tc = sw ? pv[a] : pv[a + 1];
+                        const int ja = sw ? jv[a + 1] : jv[a], jc = sw ? jv[a] : jv[a + 1];
+                        pv[a] = ta; pv[a + 1] = tc; jv[a] = ja; jv[a + 1] = jc;
+                        moved |= sw;
+                    }
+#pragma unroll
+                    for (int a = 1; a < 7; a += 2) {
+                        const bool sw = k6_beats(pv[a + 1], jv[a + 1], pv[a], jv[a]);
+                        const float ta = sw ? pv[a + 1] : pv[a], tc = sw ? pv[a] : pv[a + 1];
+                        const int ja = sw ? jv[a + 1] : jv[a], jc = sw ? jv[a] : jv[a + 1];
+                        pv[a] = ta; pv[a + 1] = tc; jv[a] = ja; jv[a + 1] = jc;
+                        moved |= sw;
+                    }
+                    {                                            // the odd pair across the lane boundary: (8 m + 7, 8 (m + 1))
+                        const float nv = __shfl(pv[0], lane + 8, 64), pvv = __shfl(pv[7], lane - 8, 64);
+                        const int nj = __shfl(jv[0], lane + 8, 64), pj = __shfl(jv[7], lane - 8, 64);
+                        const bool swh = m < 7 && k6_beats(nv, nj, pv[7], jv[7]);
+                        const bool swl = m > 0 && k6_beats(pv[0], jv[0], pvv, pj);
+                        pv[7] = swh ? nv : pv[7]; jv[7] = swh ? nj : jv[7];
+                        pv[0] = swl ? pvv : pv[0]; jv[0] = swl ? pj : jv[0];
+                        moved |= swh | swl;
+                    }
+                    if (!__any(moved)) break;
+                }
+            }
+            {
+                int* out = idx + ((size_t)b * N + qrow) * k;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const int pos = 8 * m + a;
+                    if (pos < k && pos < n) out[pos] = jv[a];
+                }
+            }
+            return;
+        }
+    }
+    // ---- counting final (a query of the wave has more than 64 survivors): two queries per trip (one per half-wave), lane l31 owns entries
+    // l31 + 32 s of the query's eight concatenated lists; logic as in knn6_kernel
+    unsigned* wl = wlbase + wave * 512;
+    int wcnt = 0;
+    auto flush = [&]() {
+        for (int i0 = 0; i0 < wcnt; i0 += 64) {
+            const int i = i0 + lane;
+            if (i < wcnt) {
+                const unsigned item = wl[i];
+                const int qq_ = (int)(item >> 16);
+                char* ent = lists + (size_t)(item & 0xffffu) * 8;
+                const int j = *(const int*)(ent + 4);
+                const int qrow_ = chunk * 64 + qq_;
+                const float* rq = xb + (size_t)qrow_ * ld;
+                const float* rj = xb + (size_t)j * ld;
+                float acc = 0.f;
+                if (xvec) {
+                    for (int c = 0; c < C; c += 32) {
+                        f32x4 a4[8], b4[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (c + 4 * u < C) { a4[u] = *(const f32x4*)(rq + c + 4 * u); b4[u] = *(const f32x4*)(rj + c + 4 * u); }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (c + 4 * u < C) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc = fmaf(a4[u][e], b4[u][e], acc);
+                            }
+                    }
+                } else {
+                    for (int c = 0; c < C; ++c) acc = fmaf(rq[c], rj[c], acc);
+                }
+                const float t2 = fmaf(2.0f, acc, -xxb[j]);
+                *(float*)ent = t2 - xxb[qrow_];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i0 = 0; i0 < wcnt; i0 += 64) {
+            const int i = i0 + lane;
+            const bool on = i < wcnt;
+            const unsigned item = on ? wl[i] : 0u;
+            const int qq_ = (int)(item >> 16), qlc_ = qq_ & 31;
+            const k6u32x2 me = *(const k6u32x2*)(lists + (size_t)(item & 0xffffu) * 8);
+            const float pm = __int_as_float((int)me[0]);
+            const int jm = (int)me[1];
+            int rank = 0;
+            for (int t = 0; t < 8; ++t) {
+                const char* Lq = list_at(qlc_, t);
+#pragma unroll
+                for (int p0 = 0; p0 < K6_CAP; p0 += 8) {
+                    k6u32x2 ke[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ke[u] = *(const k6u32x2*)(Lq + (p0 + u) * 8);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rank += k6_beats(__int_as_float((int)ke[u][0]), (int)ke[u][1], pm, jm) ? 1 : 0;
+                }
+            }
+            if (on && rank < k) idx[((size_t)b * N + chunk * 64 + qq_) * k + rank] = jm;
+        }
+        wcnt = 0;
+    };
+    for (int it = 0; it < 4; ++it) {
+        const int qlc = ch * 8 + it * 2 + h;                   // query of the group
+        const int qq = qg * 32 + qlc;                          // query of the workgroup
+        const int qrow = chunk * 64 + qq;                      // query of the cloud
+        const float xq = xxb[qrow], xqc = xcb[qrow];
+        const k6i32x4 ca = *(const k6i32x4*)(cnts + qq * 8), cb = *(const k6i32x4*)(cnts + qq * 8 + 4);
+        const f32x4 ma = *(const f32x4*)(lmn + qq * 8), mb = *(const f32x4*)(lmn + qq * 8 + 4);
+        const float xm = -2.0f * fminf(fminf(fminf(ma[0], ma[1]), fminf(ma[2], ma[3])), fminf(fminf(mb[0], mb[1]), fminf(mb[2], mb[3])));
+        const float E2 = 2.0f * (K6_EPS * (xqc + xm) + K6_CANON * (xq + xxmax));
+        int pp[9];
+        pp[0] = 0; pp[1] = ca[0]; pp[2] = pp[1] + ca[1]; pp[3] = pp[2] + ca[2]; pp[4] = pp[3] + ca[3];
+        pp[5] = pp[4] + cb[0]; pp[6] = pp[5] + cb[1]; pp[7] = pp[6] + cb[2]; pp[8] = pp[7] + cb[3];
+        const int n = pp[8];
+        const int nmax = max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 32));
+        int cmx = max(max(max(ca[0], ca[1]), max(ca[2], ca[3])), max(max(cb[0], cb[1]), max(cb[2], cb[3])));
+        cmx = max(__builtin_amdgcn_readlane(cmx, 0), __builtin_amdgcn_readlane(cmx, 32));
+        const char* Lq0 = list_at(qlc, 0);                     // list t of the query: Lq0 + t * 32 * K6_LSTR
+        for (int s0 = 0; s0 < nmax; s0 += 32) {
+            const int e = s0 + l31;
+            const bool valid = e < n;
+            int t = 0, pb = 0;
+#pragma unroll
+            for (int u = 1; u < 8; ++u) { const bool ge = e >= pp[u]; t = ge ? u : t; pb = ge ? pp[u] : pb; }
+            const char* mine = Lq0 + (size_t)(valid ? t : 0) * (32 * K6_LSTR) + (valid ? e - pb : 0) * 8;
+            const k6u32x2 me = *(const k6u32x2*)mine;
+            const float pm = __int_as_float((int)me[0]);
+            const int j = (int)me[1];
+            int rank = 0, near = 0;
+            for (int p0 = 0; p0 < cmx; ++p0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float a0 = *(const float*)(Lq0 + (size_t)u * (32 * K6_LSTR) + p0 * 8);
+                    rank += a0 > pm ? 1 : 0;
+                    near += fabsf(a0 - pm) <= E2 ? 1 : 0;
+                }
+            }
+            const bool amb = valid && !(near <= 1);
+            if (valid && !amb && rank < k) idx[((size_t)b * N + qrow) * k + rank] = j;
+            const unsigned long long mm = __ballot(amb);
+            if (mm) {
+                const int before = __builtin_popcountll(mm & ((1ull << lane) - 1ull));
+                if (amb) wl[wcnt + before] = (unsigned)((mine - lists) >> 3) | ((unsigned)qq << 16);
+                wcnt += __builtin_popcountll(mm);
+            }
+        }
+        if (wcnt > 512 - 384 || (it == 3 && wcnt > 0)) {       // (a trip adds at most 2 x 192 items)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            flush();
+        }
+    }
+}
+
 size_t knn6_lds_bytes(int N) { return (size_t)512 * K6_LSTR + (size_t)N * 4 + 128 * 4 + 512 * 4 + 64 + (size_t)8 * 512 * 4 + 512 * 4; }
 
 // shapes v6 takes (the rest stays on knn.hip's kernels)
@@ -873,17 +1431,44 @@ bool knn6_supported(int B, int N, int C, int k) {
            knn6_lds_bytes(N) <= 160 * 1024;
 }
 int knn6_padded_channels(int C) { return C <= 16 ? 16 : C <= 64 ? 64 : 128; }
-size_t knn6_plane_bytes(int P, int C) { return (size_t)P * 2 * knn6_padded_channels(C) * sizeof(__bf16) + (size_t)P * sizeof(float); }    // image + centred norms
+// image + centred norms + the wide kernel's cloud flags (B <= P / 128 ints)
+size_t knn6_plane_bytes(int P, int C) { return (size_t)P * 2 * knn6_padded_channels(C) * sizeof(__bf16) + (size_t)P * sizeof(float) + ((size_t)P / 128 + 4) * sizeof(int); }
+bool knn6w_supported(int B, int N, int C, int k) {
+    return B > 0 && N >= 128 && N % 128 == 0 && N <= 4096 && C >= 1 && C <= 128 && k > K6_KMAX && k <= K6W_KMAX && k <= N &&
+           knn6_lds_bytes(N) <= 160 * 1024;
+}
 
 template <int CT>
 static int knn6_go(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, float* xc, char* planes) {
     const int P = B * N;
-    hipLaunchKernelGGL((knn6_prep_kernel<CT>), dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, N, C, xx, xc, planes, idx, k);
+    hipLaunchKernelGGL((knn6_prep_kernel<CT>), dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, N, C, xx, xc, planes, idx, k, (int*)nullptr);
     const size_t lds = knn6_lds_bytes(N);
     hipError_t e = mlsp_lds_limit((const void*)knn6_kernel<CT>, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((knn6_kernel<CT>), dim3((N / 128) * B), dim3(512), lds, st, x, ld, xx, xc, planes, N, C, k, idx, B);
     return mlsp_launch_status();
+}
+
+template <int CT>
+static int knn6w_go(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, float* xc, char* planes, int* flags) {
+    const int P = B * N;
+    hipLaunchKernelGGL((knn6_prep_kernel<CT>), dim3((P + 255) / 256), dim3(256), 0, st, x, ld, P, N, C, xx, xc, planes, idx, k, flags);
+    const size_t lds = knn6_lds_bytes(N);
+    hipError_t e = mlsp_lds_limit((const void*)knn6w_kernel<CT>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((knn6w_kernel<CT>), dim3((N / 64) * B), dim3(512), lds, st, x, ld, xx, xc, planes, N, C, k, idx, B, flags);
+    return mlsp_launch_status();
+}
+// 24 < k <= 40: prep + knn6w_kernel; *flags_out = the per-cloud flags ([B] ints inside `planes`) the caller hands to the v5 launch behind it
+int launch_knn6w(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx, void* planes, int** flags_out) {
+    if (!knn6w_supported(B, N, C, k) || !planes || (((uintptr_t)planes) & 15)) return MLSP_ERR_UNSUPPORTED;
+    const int CT = knn6_padded_channels(C);
+    float* xc = (float*)((char*)planes + (size_t)B * N * CT * 4);
+    int* flags = (int*)(xc + (size_t)B * N);
+    *flags_out = flags;
+    if (CT == 16) return knn6w_go<16>(st, x, ld, B, N, C, k, idx, xx, xc, (char*)planes, flags);
+    if (CT == 64) return knn6w_go<64>(st, x, ld, B, N, C, k, idx, xx, xc, (char*)planes, flags);
+    return knn6w_go<128>(st, x, ld, B, N, C, k, idx, xx, xc, (char*)planes, flags);
 }
 
 // xx [B*N] floats and planes (knn6_plane_bytes) are workspace; both are written here (xx = canonical squared norms, as sqnorm_kernel)

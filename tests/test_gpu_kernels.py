@@ -46,6 +46,8 @@ def _rand(shape, seed, scale=1.0):
                                      # v6 (knn6.hip: k <= 24, N % 128 == 0): fewest tiles, ragged tile-ring tails, k = 1 / 24, unaligned rows
                                      (1, 128, 3, 1), (2, 128, 64, 24), (2, 256, 3, 24), (3, 384, 5, 20), (2, 1152, 64, 20), (1, 1152, 3, 20),
                                      (2, 640, 33, 7), (1, 2048, 128, 24), (16, 128, 16, 20),
+                                     # v6 wide (knn6w_kernel: 24 < k <= 40, N % 128 == 0, C > 16): one tile per quarter, ragged rings, the configs[4] shape
+                                     (2, 128, 64, 40), (3, 256, 64, 25), (2, 640, 128, 40), (1, 1152, 33, 37), (16, 2048, 64, 40), (1, 4096, 64, 40),
                                      # the VALU kernel: 32 < k <= 40 on shapes outside the two-pass kernel (ragged N, N < 128, 64 < C < 128, C > 128)
                                      (2, 150, 200, 40), (1, 96, 200, 36), (2, 100, 24, 33)])
 def test_knn_bit_exact_vs_oracle(dev, B, N, C, k):
@@ -82,14 +84,16 @@ def test_knn_duplicates_and_strided_input(dev):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("k", [20, 40])
 @pytest.mark.parametrize("C,scale", [(3, 1e-6), (64, 1e-6), (3, 3e-4), (128, 1e-5), (64, 0.0)])
-def test_knn_near_duplicates_need_exact_distances(dev, C, scale):
+def test_knn_near_duplicates_need_exact_distances(dev, C, scale, k):
     """v6 ranks survivors by split-bf16 distances and recomputes the canonical fp32 distance only where two survivors are closer than
     the error bound.  Clouds made of 32 tight clusters (copies of a point + noise of 1e-6 .. 3e-4, or exact copies) put MANY candidates
     inside that bound -- some queries overflow their survivor lists (exact path), the rest resolve dozens of ambiguous pairs per query:
-    indices must still be bit-exact."""
+    indices must still be bit-exact.  k = 40: the wide kernel (knn6w_kernel) with the v5 kernel behind it on the clouds whose lists
+    overflowed."""
     Fh = _fh()
-    B, N, k = 3, 512, 20
+    B, N = 3, 512
     g = torch.Generator().manual_seed(77 + C)
     centres = torch.rand(B, 32, C, generator=g) * 2 - 1
     x = centres[:, torch.arange(N) % 32, :] + scale * torch.randn(B, N, C, generator=g)
@@ -98,14 +102,14 @@ def test_knn_near_duplicates_need_exact_distances(dev, C, scale):
     assert np.array_equal(got, want), "mismatching rows: %d" % int((got != want).any(-1).sum())
 
 
+@pytest.mark.parametrize("k", [20, 40])
 @pytest.mark.parametrize("C,offset,B,N", [(64, 3.0, 4, 1024), (128, 1.5, 2, 1024), (64, 50.0, 2, 512), (3, 20.0, 2, 1024)])
-def test_knn_clouds_far_from_the_origin(dev, C, offset, B, N):
+def test_knn_clouds_far_from_the_origin(dev, C, offset, B, N, k):
     """Graph-stage features sit far from the origin compared with their spread (BatchNorm + LeakyReLU + max over k).  v6 sweeps the
     cloud in coordinates relative to its first point (error of the split products ~ the centred norms) and budgets the canonical
     arithmetic's own rounding on the raw coordinates separately; with a large offset the canonical fp32 distances are coarse (many exact
     ties): indices must still be bit-exact."""
     Fh = _fh()
-    k = 20
     x = _rand((B, N, C), 300 + C) * 0.5 + offset
     want = knn_canon.knn_point_major(x, k)
     got = Fh.knn_graph(x.view(B * N, C).to(dev), B, N, k).idx.view(B, N, k).cpu().numpy()
