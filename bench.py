@@ -375,21 +375,36 @@ def secondary_workloads(lib, dev):
         sum((o[k].float() * w[k]).mean() for k in w).backward()
         opt.step()
 
+    # the same step with the backward SEEDED by fixed output gradients (the gradients the weighted means above produce) instead of
+    # ~40 torch element-wise / reduction launches per step of synthetic loss arithmetic: model forward + backward + Adam only.  At B = 16
+    # this step is bound by the HOST's enqueue time (B = 8 runs as long as B = 16: tools/r5/host_profile_c4.py), so the launches count.
+    wg = {k: w[k] / w[k].numel() for k in w}
+
+    def seg_step_seeded():
+        opt.zero_grad()
+        o = seg(x, make_seg=True, activate_DefRec=True, activate_density_normal_ondef=True)
+        torch.autograd.backward([o[k] for k in w], [wg[k] for k in w])
+        opt.step()
+
     with Fh.gemm_precision("bf16"), Fh.activation_storage("bf16"):
         ms = median_block_ms(seg_step, 20, 5, 4)
         seg_blocks = median_block_ms.last_blocks
+        ms_seeded = median_block_ms(seg_step_seeded, 20, 3, 2)
         rows, g, _ = profiled_steps(lib, seg_step, 2)
     gbs = g[3] / (g[0] * 1e-3) / 1e9 if g[0] > 0 else 0.0
     tfs = g[2] / (g[0] * 1e-3) / 1e12 if g[0] > 0 else 0.0
     out.append({"workload": "PointSegDA DGCNN_DefRec + seg + 3 MLSP heads, fwd+bwd+Adam, B=16 N=2048 k=40 (BASELINE.json configs[4], one GPU)",
                 "ms_per_step": ms, "blocks_ms_per_step": seg_blocks, "points_per_s": B * N / ms * 1e3, "dtype": "bf16 GEMM operands + bf16 activation storage, fp32 accumulate",
+                "seeded_backward": {"ms_per_step": ms_seeded, "points_per_s": B * N / ms_seeded * 1e3,
+                                    "note": "same forward / backward / Adam, the backward seeded with the fixed output gradients of the synthetic loss "
+                                            "(torch.autograd.backward) instead of computing that loss with torch ops: the step is host-enqueue bound at B = 16"},
                 "roofline": {"kernel": "gemm_bf16_kernel<*> / gemm_f32_kernel<*> (every MFMA GEMM launch)", "bound": "hbm", "achieved": gbs,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "mfma_tflops": tfs,
                              "mfma_frac_of_bf16_dense_peak": tfs / PEAK_BF16_TFLOPS, "share_of_step": g[0] / 2 / ms,
                              "launches_per_step": g[1] / 2,
                              "note": "achieved = algorithmic operand + result bytes of the launches (A + B + C in their storage types) / "
                                      "HIP-event time: at bf16 the contractions sit under the HBM roof, not the 2.5 PF matrix roof"},
-                "knn": [e for e in (_kernel_entry("kNN C=3, k=40, N=2048 (knn_mfma5 + row norms)", "hbm", rows[1], 2, "compulsory (C+k)*4 B/pt"),
+                "knn": [e for e in (_kernel_entry("kNN C=3, k=40, N=2048 (knn6w_kernel + prep + v5 on flagged clouds)", "hbm", rows[1], 2, "compulsory (C+k)*4 B/pt"),
                                     _kernel_entry("kNN C=64, k=40, N=2048", "mfma", rows[2], 2, "2*N*C FLOP per point, one pass")) if e]})
     return out
 

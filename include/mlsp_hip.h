@@ -45,7 +45,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 11
+#define MLSP_ABI_VERSION 12
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -369,6 +369,15 @@ int mlsp_deform_regions_f32(float* X, int B, int C, int N, const int32_t* region
  * points of cloud b; x [B*N][3] point-major, T [B][3][3].  Backward: dx (nullable) [B*N][3] and dT [B][3][3] (fixed reduction order). */
 int mlsp_transform3_fwd_f32(const float* x, const float* T, int B, int N, float* out, mlsp_stream_t stream);
 int mlsp_transform3_bwd_f32(const float* x, const float* T, const float* dout, int B, int N, float* dx, float* dT, mlsp_stream_t stream);
+
+/* Two 1x1 convolutions with nothing in between (PointSegDA/Models.py:176-178, :180-182 `x = self.conv2(self.conv1(x))`) are ONE linear map:
+ * W [Co][Ci] = Wb Wa, b [Co] = Wb ba + bb with Wa [Cm][Ci], ba [Cm], Wb [Co][Cm], bb [Co] (row-major, fmaf chains over m ascending).
+ * Backward: dWa [Cm][Ci] = Wb^T dW, dba [Cm] = Wb^T db, dWb [Co][Cm] = dW Wa^T + db ba^T (the gradient of bb is db itself).
+ * Ci, Cm, Co <= 1024. */
+int mlsp_compose_linear_fwd_f32(const float* Wa, const float* ba, const float* Wb, const float* bb, int Cm, int Ci, int Co, float* W, float* b,
+                                mlsp_stream_t stream);
+int mlsp_compose_linear_bwd_f32(const float* dW, const float* db, const float* Wa, const float* ba, const float* Wb, int Cm, int Ci, int Co,
+                                float* dWa, float* dba, float* dWb, mlsp_stream_t stream);
 
 /* deform_input(..., 'volume_based_radius') = pc_utils.collapse_to_point (MLSP/mlsp.py:33-36, utils/pc_utils.py:76-111): per cloud one
  * point with >= min_pts points within sqrt(radius2) is picked (uniformly by u[b] in [0,1) among the candidates in index order, or

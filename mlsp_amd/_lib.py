@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLSP_HIP_LIB") or os.path.join(_HERE, "libmlsp_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c = ctypes
 _P, _I, _F, _U64, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64, _c.c_size_t
@@ -86,6 +86,8 @@ SIGNATURES = {
     "mlsp_deform_regions_f32": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P],
     "mlsp_transform3_fwd_f32": [_P, _P, _I, _I, _P, _P],
     "mlsp_transform3_bwd_f32": [_P, _P, _P, _I, _I, _P, _P, _P],
+    "mlsp_compose_linear_fwd_f32": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "mlsp_compose_linear_bwd_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "mlsp_collapse_to_point_f32": [_P, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P],
     "mlsp_scan_select_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _P],
     "mlsp_multimlp_supported": [_I, _P, _I, _I],

@@ -37,6 +37,9 @@ int launch_xf_materialize(hipStream_t st, const float* X, int ldx, int M, int C,
 int gemm_stat_parts(int M, int N, int K);
 size_t gemm_slab_floats(int M, int N, int K);
 int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int k, int* idx, float* xx_ws, void* planes, size_t plane_bytes);
+int launch_compose_fwd(hipStream_t st, const float* Wa, const float* ba, const float* Wb, const float* bb, int Cm, int Ci, int Co, float* W, float* b);
+int launch_compose_bwd(hipStream_t st, const float* dW, const float* db, const float* Wa, const float* ba, const float* Wb, int Cm, int Ci, int Co,
+                       float* dWa, float* dba, float* dWb);
 bool knn6_supported(int B, int N, int C, int k);
 bool knn6w_supported(int B, int N, int C, int k);
 size_t knn6_plane_bytes(int P, int C);
@@ -281,6 +284,17 @@ int mlsp_interp3_bwd_f32(const float* dout, const float* dist, const int32_t* re
                          float* dfeat, mlsp_stream_t st) {
     return launch_interp3_bwd(st, dout, dist, rev_off, rev_ent, B, N, S, D, dfeat);
 }
+int mlsp_compose_linear_fwd_f32(const float* Wa, const float* ba, const float* Wb, const float* bb, int Cm, int Ci, int Co, float* W, float* b,
+                                mlsp_stream_t st) {
+    if (!Wa || !ba || !Wb || !bb || !W || !b || Cm <= 0 || Ci <= 0 || Co <= 0 || Cm > 1024 || Ci > 1024 || Co > 1024) return MLSP_ERR_ARG;
+    return launch_compose_fwd((hipStream_t)st, Wa, ba, Wb, bb, Cm, Ci, Co, W, b);
+}
+int mlsp_compose_linear_bwd_f32(const float* dW, const float* db, const float* Wa, const float* ba, const float* Wb, int Cm, int Ci, int Co,
+                                float* dWa, float* dba, float* dWb, mlsp_stream_t st) {
+    if (!dW || !db || !Wa || !ba || !Wb || !dWa || !dba || !dWb || Cm <= 0 || Ci <= 0 || Co <= 0 || Cm > 1024 || Ci > 1024 || Co > 1024) return MLSP_ERR_ARG;
+    return launch_compose_bwd((hipStream_t)st, dW, db, Wa, ba, Wb, Cm, Ci, Co, dWa, dba, dWb);
+}
+
 int mlsp_transform3_fwd_f32(const float* x, const float* T, int B, int N, float* out, mlsp_stream_t st) {
     return launch_transform3_fwd(st, x, T, B, N, out);
 }

@@ -308,3 +308,58 @@ int launch_skinny_bn_bwd(hipStream_t st, const float* dZ, const float* Y, float*
                        sk_drop_thresh(pd), dropout_inv_keep8(pd), seed, dgamma, dbeta);
     return mlsp_launch_status();
 }
+
+
+// ---- composition of two linear maps (PointSegDA's conv pairs without an activation in between: include/mlsp_hip.h mlsp_compose_linear_*) ----
+// forward: workgroup = output row o; thread c < Ci: W[o][c] = sum_m Wb[o][m] Wa[m][c]; thread Ci: b[o] = sum_m Wb[o][m] ba[m] + bb[o]
+__global__ __launch_bounds__(256) void compose_fwd_kernel(const float* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ Wb,
+                                                          const float* __restrict__ bb, int Cm, int Ci, float* __restrict__ W, float* __restrict__ b) {
+    const int o = blockIdx.x;
+    for (int c = threadIdx.x; c <= Ci; c += blockDim.x) {
+        float acc = 0.f;
+        if (c < Ci) {
+            for (int m = 0; m < Cm; ++m) acc = fmaf(Wb[(size_t)o * Cm + m], Wa[(size_t)m * Ci + c], acc);
+            W[(size_t)o * Ci + c] = acc;
+        } else {
+            for (int m = 0; m < Cm; ++m) acc = fmaf(Wb[(size_t)o * Cm + m], ba[m], acc);
+            b[o] = acc + bb[o];
+        }
+    }
+}
+// backward: workgroups [0, Cm): row m of dWa | dba (sums over o ascending); workgroups [Cm, Cm + Co): row o of dWb (sums over c ascending, then
+// the bias term)
+__global__ __launch_bounds__(256) void compose_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ db, const float* __restrict__ Wa,
+                                                          const float* __restrict__ ba, const float* __restrict__ Wb, int Cm, int Ci, int Co,
+                                                          float* __restrict__ dWa, float* __restrict__ dba, float* __restrict__ dWb) {
+    const int blk = blockIdx.x;
+    if (blk < Cm) {
+        const int m = blk;
+        for (int c = threadIdx.x; c <= Ci; c += blockDim.x) {
+            float acc = 0.f;
+            if (c < Ci) {
+                for (int o = 0; o < Co; ++o) acc = fmaf(Wb[(size_t)o * Cm + m], dW[(size_t)o * Ci + c], acc);
+                dWa[(size_t)m * Ci + c] = acc;
+            } else {
+                for (int o = 0; o < Co; ++o) acc = fmaf(Wb[(size_t)o * Cm + m], db[o], acc);
+                dba[m] = acc;
+            }
+        }
+    } else {
+        const int o = blk - Cm;
+        for (int m = threadIdx.x; m < Cm; m += blockDim.x) {
+            float acc = 0.f;
+            for (int c = 0; c < Ci; ++c) acc = fmaf(dW[(size_t)o * Ci + c], Wa[(size_t)m * Ci + c], acc);
+            dWb[(size_t)o * Cm + m] = fmaf(db[o], ba[m], acc);
+        }
+    }
+}
+int launch_compose_fwd(hipStream_t st, const float* Wa, const float* ba, const float* Wb, const float* bb, int Cm, int Ci, int Co, float* W, float* b) {
+    hipLaunchKernelGGL(compose_fwd_kernel, dim3(Co), dim3(Ci + 1 <= 64 ? 64 : Ci + 1 <= 128 ? 128 : 256), 0, st, Wa, ba, Wb, bb, Cm, Ci, W, b);
+    return mlsp_launch_status();
+}
+int launch_compose_bwd(hipStream_t st, const float* dW, const float* db, const float* Wa, const float* ba, const float* Wb, int Cm, int Ci, int Co,
+                       float* dWa, float* dba, float* dWb) {
+    const int mx = Ci + 1 > Cm ? Ci + 1 : Cm;
+    hipLaunchKernelGGL(compose_bwd_kernel, dim3(Cm + Co), dim3(mx <= 64 ? 64 : mx <= 128 ? 128 : 256), 0, st, dW, db, Wa, ba, Wb, Cm, Ci, Co, dWa, dba, dWb);
+    return mlsp_launch_status();
+}

@@ -1378,6 +1378,44 @@ def apply_transform(xp, T):
     return _Transform3.apply(xp, T)
 
 
+class _ComposeLinear(Function):
+    @staticmethod
+    def forward(ctx, Wa, ba, Wb, bb):
+        lib = _lib.load()
+        Wa, ba, Wb, bb = Wa.contiguous(), ba.contiguous(), Wb.contiguous(), bb.contiguous()
+        _lib.require_gpu(Wa, ba, Wb, bb)
+        Cm, Ci = Wa.shape
+        Co = Wb.shape[0]
+        W = torch.empty((Co, Ci), dtype=torch.float32, device=Wa.device)
+        b = torch.empty((Co,), dtype=torch.float32, device=Wa.device)
+        _lib.check(lib.mlsp_compose_linear_fwd_f32(Wa.data_ptr(), ba.data_ptr(), Wb.data_ptr(), bb.data_ptr(), Cm, Ci, Co, W.data_ptr(),
+                                                   b.data_ptr(), _lib.stream()), "mlsp_compose_linear_fwd_f32")
+        ctx.save_for_backward(Wa, ba, Wb)
+        return W, b
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dW, db):
+        lib = _lib.load()
+        Wa, ba, Wb = ctx.saved_tensors
+        Cm, Ci = Wa.shape
+        Co = Wb.shape[0]
+        dW = dW.contiguous() if dW is not None else torch.zeros((Co, Ci), dtype=torch.float32, device=Wa.device)
+        db = db.contiguous() if db is not None else torch.zeros((Co,), dtype=torch.float32, device=Wa.device)
+        dWa, dba, dWb = torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wb)
+        _lib.check(lib.mlsp_compose_linear_bwd_f32(dW.data_ptr(), db.data_ptr(), Wa.data_ptr(), ba.data_ptr(), Wb.data_ptr(), Cm, Ci, Co,
+                                                   dWa.data_ptr(), dba.data_ptr(), dWb.data_ptr(), _lib.stream()), "mlsp_compose_linear_bwd_f32")
+        return dWa, dba, dWb, db
+
+
+def compose_linear(Wa, ba, Wb, bb):
+    """conv_b(conv_a(f)) with nothing in between (PointSegDA/Models.py:176-182) as ONE linear map: -> (Wb Wa [Co,Ci], Wb ba + bb [Co]).
+    One launch forward, one backward (the gradient of the composite goes back to all four parameters); fp32 fmaf chains."""
+    assert Wa.dim() == 2 and Wb.dim() == 2 and Wb.shape[1] == Wa.shape[0] and ba.shape == (Wa.shape[0],) and bb.shape == (Wb.shape[0],)
+    assert Wa.dtype == torch.float32 and Wb.dtype == torch.float32
+    return _ComposeLinear.apply(Wa, ba, Wb, bb)
+
+
 class _Chamfer(Function):
     @staticmethod
     def forward(ctx, pred, gold, mask, scale):

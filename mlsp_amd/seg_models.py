@@ -171,11 +171,11 @@ class shared_layers(nn.Module):
 
     @staticmethod
     def _compose(ca, cb):
-        """conv_b(conv_a(f)) with no activation in between == one linear map (tiny matmuls; autograd carries the
-        gradient of the composite back to both layers)."""
+        """conv_b(conv_a(f)) with no activation in between == one linear map (functional.compose_linear: one launch forward, one
+        backward; the gradient of the composite goes back to both layers)."""
         Wa = ca.weight.view(ca.out_channels, ca.in_channels)
         Wb = cb.weight.view(cb.out_channels, cb.in_channels)
-        return Wb @ Wa, Wb @ ca.bias + cb.bias
+        return Fh.compose_linear(Wa, ca.bias, Wb, cb.bias)
 
     def points(self, xp, B, N, consumers=0):
         """-> (x123 [P,192], x5 [B,1024]); consumers = n > 0: -> ([n aliases of x123], x5, SharedInputGrad) for n heads that take

@@ -1268,3 +1268,24 @@ def test_tnet_forward_accuracy_both_product_kernels(dev):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "tnet_acc.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
         print(env_extra, r.stdout.strip().splitlines()[-2:])
         assert r.returncode == 0, (env_extra, r.stdout[-500:], r.stderr[-500:])
+
+
+@pytest.mark.parametrize("Cm,Ci,Co", [(64, 6, 64), (64, 128, 64), (7, 3, 5), (130, 257, 33)])
+def test_compose_linear_fwd_bwd(dev, Cm, Ci, Co):
+    """PointSegDA/Models.py:176-182: conv_b(conv_a(f)) as one linear map; values and all four parameter gradients against float64."""
+    Fh = _fh()
+    Wa, ba, Wb, bb = (_rand(sh, 900 + i).to(dev).requires_grad_() for i, sh in enumerate(((Cm, Ci), (Cm,), (Co, Cm), (Co,))))
+    W, b = Fh.compose_linear(Wa, ba, Wb, bb)
+    gW, gb = _rand((Co, Ci), 910).to(dev), _rand((Co,), 911).to(dev)
+    torch.autograd.backward([W, b], [gW, gb])
+    ref = [t.detach().double().cpu().requires_grad_() for t in (Wa, ba, Wb, bb)]
+    Wr, br = ref[2] @ ref[0], ref[2] @ ref[1] + ref[3]
+    torch.autograd.backward([Wr, br], [gW.double().cpu(), gb.double().cpu()])
+    for got, want in ((W, Wr), (b, br), (Wa.grad, ref[0].grad), (ba.grad, ref[1].grad), (Wb.grad, ref[2].grad), (bb.grad, ref[3].grad)):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-5)
+    # only the composite weight carries a gradient (the bias output unused)
+    Wa.grad = ba.grad = Wb.grad = bb.grad = None
+    W, b = Fh.compose_linear(Wa, ba, Wb, bb)
+    (W * gW).sum().backward()
+    np.testing.assert_allclose(Wb.grad.cpu().numpy(), (gW.double().cpu() @ ref[0].detach().T).numpy(), rtol=1e-5, atol=1e-5)
+    assert float(bb.grad.abs().max()) == 0.0

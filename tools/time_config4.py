@@ -9,6 +9,7 @@ import golden_common as gc
 from mlsp_amd import seg_models, functional as Fh
 
 dev = torch.device("cuda:0")
+torch.autograd.set_multithreading_enabled(False)      # as bench.py: the backward on the calling thread (host-side settings)
 B, N, K = int(os.environ.get("C4_B", 16)), 2048, int(os.environ.get("C4_K", 40))
 seg = seg_models.DGCNN_DefRec(gc.make_seg_args(dropout=0.5, gpu=True), in_size=3, num_classes=8)
 seg.k = seg.shared_layers.k = K
@@ -23,10 +24,17 @@ w = {k: torch.randn(s, device=dev) for k, s in (("seg", (B, N, 8)), ("DefRec", (
                                                 ("density_mse", (B * N,)))}
 
 
+wg = {k: w[k] / w[k].numel() for k in w}
+SEEDED = bool(os.environ.get("C4_SEEDED"))        # backward seeded with the synthetic loss' output gradients (no loss kernels): bench.py `seeded_backward`
+
+
 def step():
     opt.zero_grad()
     out = seg(x, make_seg=True, activate_DefRec=True, activate_density_normal_ondef=True)
-    sum((out[k].float() * w[k]).mean() for k in w).backward()
+    if SEEDED:
+        torch.autograd.backward([out[k] for k in w], [wg[k] for k in w])
+    else:
+        sum((out[k].float() * w[k]).mean() for k in w).backward()
     opt.step()
 
 
