@@ -1492,14 +1492,19 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     if (tid == 0) nbig = 0;
     __syncthreads();
     int below = 0;
-    for (int eb = tid; eb < E; eb += nt * 8) {           // 8 index loads in flight per thread (the atomics would serialise them)
-        int jv[8];
+    // RV_B index loads in flight per thread (the atomics would serialise them): a pass is a chain of ceil(E / (RV_B nt)) load latencies, ONE
+    // at the DGCNN shape (E = 20 Ki entries, 1024 threads) -- and then the fill pass below reuses the registers instead of reading idx again
+    constexpr int RV_B = 20;
+    const bool one_trip = E <= nt * RV_B;
+    int jk[RV_B];
+    for (int eb = tid; eb < E; eb += nt * RV_B) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) jv[u] = eb + u * nt < E ? ib[eb + u * nt] : -1;
+        for (int u = 0; u < RV_B; ++u) jk[u] = eb + u * nt < E ? ib[eb + u * nt] : -1;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int j = jv[u];
+        for (int u = 0; u < RV_B; ++u) {
+            int j = jk[u];
             if (skip_pad && j >= 0) { const int e = eb + u * nt, sl = e % k; if (sl != 0 && j == ib[e - sl]) j = -1; }
+            jk[u] = j;
             below += j >= 0 && j < d0;
             if (j >= d0 && j < d1) atomicAdd(&cnt[j - d0], 1);
         }
@@ -1547,15 +1552,16 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     // (a slice with more than RV_CAP entries orders in place in global memory instead)
     const bool in_lds = sn <= RV_CAP;
     int* ent = in_lds ? lent : rev_ent + gbase + s0;
-    for (int eb = tid; eb < E; eb += nt * 8) {
-        int jv[8];
+    for (int eb = tid; eb < E; eb += nt * RV_B) {
+        if (!one_trip) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) jv[u] = eb + u * nt < E ? ib[eb + u * nt] : -1;
+            for (int u = 0; u < RV_B; ++u) jk[u] = eb + u * nt < E ? ib[eb + u * nt] : -1;
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int j = jv[u];
+        for (int u = 0; u < RV_B; ++u) {
+            int j = jk[u];
             const int e = eb + u * nt;
-            if (skip_pad && j >= 0) { const int sl = e % k; if (sl != 0 && j == ib[e - sl]) j = -1; }
+            if (!one_trip && skip_pad && j >= 0) { const int sl = e % k; if (sl != 0 && j == ib[e - sl]) j = -1; }
             if (j >= d0 && j < d1) {
                 const int pos = atomicAdd(&cnt[j - d0], 1);
                 ent[off[j - d0] + pos] = ((e / k) << 8) | (e % k);

@@ -1,0 +1,5 @@
+set -e
+cd $GRAFT_REPO_ROOT
+python tools/time_reverse.py 2>/dev/null; TN_B=16 TN_N=2048 TN_K=40 python tools/time_reverse.py 2>/dev/null
+timeout -k 10 700 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_sa.py -x -q -k "knn or reverse or sa or group or ball" > gpurun_out/rev_tests.log 2>&1 || (tail -40 gpurun_out/rev_tests.log; exit 1)
+tail -3 gpurun_out/rev_tests.log
