@@ -31,7 +31,7 @@ int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* d
                           double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy);
 int launch_colsum_groups_b16(hipStream_t st, const void* X, int G, int rows_per_group, int C, float* out, float* scratch);
 int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, int panel_rows,
-                         float* ysel, int* arg);
+                         float* ysel, int* arg, const float* bn, int act, float slope, float* out);
 int gemm_panel_rows(int M, int N, int K);
 int launch_xf_materialize(hipStream_t st, const float* X, int ldx, int M, int C, const GemmXf& xf, float* out);   // multi.hip
 int gemm_stat_parts(int M, int N, int K);
@@ -40,6 +40,16 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 int launch_compose_fwd(hipStream_t st, const float* Wa, const float* ba, const float* Wb, const float* bb, int Cm, int Ci, int Co, float* W, float* b);
 int launch_compose_bwd(hipStream_t st, const float* dW, const float* db, const float* Wa, const float* ba, const float* Wb, int Cm, int Ci, int Co,
                        float* dWa, float* dba, float* dWb);
+int launch_skinny_bwd_pair(hipStream_t st, const float* G, int ldg, const float* W, int ldw, const float* X, int ldx, float* dX, int lddx,
+                           float* dW, int M, int Cin, int Cout);
+int launch_wt_vec_neg_scale_rows(hipStream_t st, const float* W, int ldw, const float* v, const float* rowscale, int Cout, int Cin, float* negr,
+                                 float* Wb);
+int launch_bn_bwd_finalize_coef_z(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
+                                  float* dbeta, float* coef, float* zero_vec);
+int launch_skinny_bn_bwd_z(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* bn_save, int training,
+                           int act, float slope, float p_drop, uint64_t seed, float* dgamma, float* dbeta, float* zero_vec);
+void gemm_unfold_request(float* dW);
+bool gemm_unfold_take();
 bool knn6_supported(int B, int N, int C, int k);
 bool knn6w_supported(int B, int N, int C, int k);
 size_t knn6_plane_bytes(int P, int C);
@@ -437,8 +447,11 @@ int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, 
     if (!Wdc && dx) { CHECK(launch_build_wd(st, W, Cout, C, Wd)); Wdc = Wd; }
     if (dx) CHECK(launch_gemm(st, false, false, P, C, 2 * Cout, duv, 2 * Cout, Wdc, C, dx, lddx, nullptr, nullptr, 0, slab, sf, nullptr,
                               nullptr, nullptr, nullptr, dx_accumulate != 0));
-    CHECK(launch_gemm(st, true, false, 2 * Cout, C, P, duv, 2 * Cout, x, ldx, dWd, C, nullptr, nullptr, 0, slab, sf));
-    CHECK(launch_unbuild_wd(st, dWd, Cout, C, dW));
+    gemm_unfold_request(dW);          // a split-K launch sums its slabs straight into the reference layout (gemm.hip splitk_reduce_unfold_kernel)
+    const int rcw = launch_gemm(st, true, false, 2 * Cout, C, P, duv, 2 * Cout, x, ldx, dWd, C, nullptr, nullptr, 0, slab, sf);
+    const bool unfolded = gemm_unfold_take();
+    if (rcw != MLSP_OK) return rcw;
+    if (!unfolded) CHECK(launch_unbuild_wd(st, dWd, Cout, C, dW));
     return MLSP_OK;
 }
 
@@ -714,14 +727,18 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
         (!dX || gemm_dy_supported(false, false, M, Cin, Cout, dZ, Cout, W, ldw)) && gemm_dy_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx) &&
         (!dgbias || (rows_per_group >= 256 && rows_per_group % (M / pre_parts) == 0 && Cout % 4 == 0 && 256 % (Cout / 4) == 0 && Cout <= 1024)))
         dy = &dy_s;
+    float* zb = (dbias && has_bn && training) ? dbias : nullptr;   // a bias in front of a batch-statistics BatchNorm: analytically zero gradient,
+    bool dbias_zeroed = false;                                     // written by the layer's finalizer where it has one per channel (no memset launch)
     if (dy && dgbias && group_ysum) {          // (the forward kept the clouds' column sums of y: the per-cloud bias gradient rides in the finalizer)
         CHECK(launch_bn_bwd_finalize_coef_groups(st, pre_stats, pre_parts, (double)M, Cout, bn_save, dgamma, dbeta, coef, group_ysum,
                                                  rows_per_group / (M / pre_parts), rows_per_group, dgbias));
     } else if (dy) {
-        CHECK(launch_bn_bwd_finalize_coef(st, pre_stats, pre_parts, (double)M, Cout, bn_save, dgamma, dbeta, coef));
+        CHECK(launch_bn_bwd_finalize_coef_z(st, pre_stats, pre_parts, (double)M, Cout, bn_save, dgamma, dbeta, coef, zb));
+        dbias_zeroed = zb != nullptr;
         if (dgbias) CHECK(launch_bn_dy_gbias(st, Y, n_groups, rows_per_group, Cout, pre_stats, M / pre_parts, coef, gscratch, dgbias, group_ysum));
     } else if (has_bn && M <= 32) {
-        CHECK(launch_skinny_bn_bwd(st, dZ, Y, dY, M, Cout, bn_save, training, act, slope, p_drop, seed, dgamma, dbeta));
+        CHECK(launch_skinny_bn_bwd_z(st, dZ, Y, dY, M, Cout, bn_save, training, act, slope, p_drop, seed, dgamma, dbeta, zb));
+        dbias_zeroed = zb != nullptr;
         g = dY;
     } else if (has_bn) {
         const float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
@@ -737,15 +754,23 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
                 in->ld, in->col, in_stats + in->col, in->ld};
         bs = &bs_s;
     }
+    static const bool no_pair = getenv("MLSP_SKINNY_NO_PAIR") != nullptr;          // read-once A/B switch
+    if (M <= 32 && dX && !dx_accumulate && !bs && !dy && !xf && !no_pair) {
+        // per-cloud layer (rows = batch): input gradient and weight gradient in one launch (skinny.hip)
+        CHECK(launch_skinny_bwd_pair(st, g, Cout, W, ldw, X, ldx, dX, lddx, dW, M, Cin, Cout));
+    } else {
     if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf, nullptr, nullptr,
                               nullptr, nullptr, dx_accumulate != 0, nullptr, 0, nullptr, bs, dy));
     CHECK(launch_gemm(st, true, false, Cout, Cin, M, g, Cout, X, ldx, dW, Cin, nullptr, nullptr, 0, slab, sf, nullptr, nullptr, nullptr,
                       nullptr, false, xf, 0, nullptr, nullptr, dy));
+    }
     if (dbias) {
         if (has_bn && training) {
             // a bias in front of a batch-stat BN has an analytically zero gradient (sum_rows dY == 0)
-            hipError_t e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
+            if (!dbias_zeroed) {
+                hipError_t e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+                if (e != hipSuccess) return (int)e;
+            }
         } else {
             CHECK(launch_colsum(st, g, M, Cout, part, dbias));
         }
@@ -975,9 +1000,11 @@ int mlsp_pointmlp_colmax_fwd_f32(const float* X, int ldx, int B, int N, int Cin,
         CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, bn_save, bn_save + Cout, bn_save + 2 * Cout,
                                      bn_save + 3 * Cout));
     }
-    if (fuse_sel) CHECK(launch_colsel_panels(st, pv, pr, gamma, B, N, Cout, prow, ysel, arg));
-    else CHECK(launch_colsel(st, Y, gamma, B, N, Cout, ysel, arg));
-    CHECK(launch_colsel_out(st, ysel, bn_save, B, Cout, act, slope, out));
+    if (fuse_sel) CHECK(launch_colsel_panels(st, pv, pr, gamma, B, N, Cout, prow, ysel, arg, bn_save, act, slope, out));   // selection + BN + activation: one pass
+    else {
+        CHECK(launch_colsel(st, Y, gamma, B, N, Cout, ysel, arg));
+        CHECK(launch_colsel_out(st, ysel, bn_save, B, Cout, act, slope, out));
+    }
     return MLSP_OK;
 }
 
@@ -1020,9 +1047,8 @@ int mlsp_pointmlp_colmax_bwd_f32(const float* dOut, const float* X, int ldx, int
     }
     if (dX) {
         if (training) {
-            CHECK(launch_scale_rows(st, W, ldw, coef + 3 * Cout, Cout, Cin, Wb));                     // -Bc * W
+            CHECK(launch_wt_vec_neg_scale_rows(st, W, ldw, coef + 2 * Cout, coef + 3 * Cout, Cout, Cin, negr, Wb));    // negr; Wb = -Bc * W
             CHECK(launch_gemm(st, true, false, Cin, Cin, Cout, Wb, Cin, W, ldw, Mneg, Cin, nullptr, nullptr, 0, slab, sf));
-            CHECK(launch_wt_vec_neg(st, W, ldw, coef + 2 * Cout, Cout, Cin, negr));
             CHECK(launch_gemm(st, false, false, P, Cin, Cin, X, ldx, Mneg, Cin, dX, Cin, negr, nullptr, 0, slab, sf, nullptr, nullptr,
                               nullptr, nullptr, dx_accumulate != 0));
         } else if (!dx_accumulate) {

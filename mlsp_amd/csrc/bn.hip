@@ -181,11 +181,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
 // dgamma = sum dz'*yhat, dbeta = sum dz'; coefficient vectors for the apply pass
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nparts, double count, int C,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ mean_dz, float* __restrict__ mean_dzy) {
+                                       float* __restrict__ mean_dz, float* __restrict__ mean_dzy, float* __restrict__ zero_vec = nullptr) {
     const int c = blockIdx.x;
     double s, q;
     fin_part_sums(part, nparts, C, c, s, q);
     if (threadIdx.x != 0) return;
+    if (zero_vec) zero_vec[c] = 0.f;          // the gradient of a bias in front of a batch-statistics BatchNorm: analytically zero (no memset launch)
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
     mean_dz[c] = (float)(s / count);
@@ -569,7 +570,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
         if (!(vec_ok(C, dZ, Y, dY) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)))
             return MLSP_ERR_UNSUPPORTED;
         const bool fuse_g = gpart && gpart_slabs && rows_per_group > 0 && rows_per_group % VROWS == 0 && rows_per_group / VROWS <= 16 && M % rows_per_group == 0;
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, pre_stats, pre_parts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, pre_stats, pre_parts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy, (float*)nullptr);
         hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C, scale, shift, mean, invstd,
                            training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, 0u, 1.f, seed, fuse_g ? gpart : (float*)nullptr, 1);
         if (fuse_g) *gpart_slabs = rows_per_group / VROWS;
@@ -590,7 +591,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
                            mean, invstd, act, slope, th, inv_keep, seed, part);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma,
-                       dbeta, mean_dz, mean_dzy);
+                       dbeta, mean_dz, mean_dzy, (float*)nullptr);
     size_t total = (size_t)M * C;
     if (vec) {
         hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C,
@@ -611,7 +612,8 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
 // (ppg panels per cloud) and the clouds' column sums of y (gys [G][C], kept by the forward: bn_finalize_kernel gsum)
 __global__ void bn_bwd_finalize_coef_kernel(const double* __restrict__ part, int nparts, double count, int C, const float* __restrict__ bn,
                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
-                                            const float* __restrict__ gys, int ppg, int rows, float* __restrict__ gout) {
+                                            const float* __restrict__ gys, int ppg, int rows, float* __restrict__ gout,
+                                            float* __restrict__ zero_vec = nullptr) {
     const int c = blockIdx.x;
     double s, q;
     fin_part_sums(part, nparts, C, c, s, q);
@@ -624,6 +626,7 @@ __global__ void bn_bwd_finalize_coef_kernel(const double* __restrict__ part, int
             gout[(size_t)g * C + c] = (float)((double)sc * (sd + (double)nk2 * (double)gys[(size_t)g * C + c] + (double)rows * (double)c0));
         }
     if (threadIdx.x != 0) return;
+    if (zero_vec) zero_vec[c] = 0.f;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
     coef[c] = c0;
@@ -631,25 +634,33 @@ __global__ void bn_bwd_finalize_coef_kernel(const double* __restrict__ part, int
     coef[2 * C + c] = sc;
 }
 
+int launch_bn_bwd_finalize_coef_z(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
+                                  float* dbeta, float* coef, float* zero_vec) {
+    hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, bn_save, dgamma, dbeta, coef,
+                       (const float*)nullptr, 1, 0, (float*)nullptr, zero_vec);
+    return mlsp_launch_status();
+}
 int launch_bn_bwd_finalize_coef(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
                                 float* dbeta, float* coef) {
-    hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, bn_save, dgamma, dbeta, coef,
-                       (const float*)nullptr, 1, 0, (float*)nullptr);
-    return mlsp_launch_status();
+    return launch_bn_bwd_finalize_coef_z(st, part, nparts, count, C, bn_save, dgamma, dbeta, coef, nullptr);
 }
 int launch_bn_bwd_finalize_coef_groups(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
                                        float* dbeta, float* coef, const float* gys, int ppg, int rows, float* gout) {
     if (!gys || !gout || ppg <= 0 || nparts % ppg) return MLSP_ERR_ARG;
     hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, bn_save, dgamma, dbeta, coef, gys,
-                       ppg, rows, gout);
+                       ppg, rows, gout, (float*)nullptr);
     return mlsp_launch_status();
 }
 
+int launch_bn_bwd_finalize_z(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
+                             float* mean_dz, float* mean_dzy, float* zero_vec) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, dgamma, dbeta,
+                       mean_dz, mean_dzy, zero_vec);
+    return mlsp_launch_status();
+}
 int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
                            float* mean_dz, float* mean_dzy) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, dgamma, dbeta,
-                       mean_dz, mean_dzy);
-    return mlsp_launch_status();
+    return launch_bn_bwd_finalize_z(st, part, nparts, count, C, dgamma, dbeta, mean_dz, mean_dzy, nullptr);
 }
 
 // out[c] = sum over partial blocks of the column sums (first plane of colstats partials)
@@ -674,8 +685,23 @@ __global__ __launch_bounds__(256) void colsum_groups_vec_kernel(const TY* __rest
     const int rows_per_slab = (rows_per_group + slabs - 1) / slabs;
     const int r0 = slab * rows_per_slab, r1 = min(rows_per_group, r0 + rows_per_slab);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (rg < nrg)
-        for (int r = r0 + rg; r < r1; r += nrg) s = s + ld4<TY>(X + ((size_t)g * rows_per_group + r) * C + c);
+    if (rg < nrg) {
+        // four rows in flight per thread, four accumulators (a single chain waited for each 16-byte load: 2.4 TB/s on the [32768, 512]
+        // input of conv5's backward), combined in a fixed order
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
+        const TY* base = X + (size_t)g * rows_per_group * C + c;
+        int r = r0 + rg;
+        // (whole-matrix sums only: the per-cloud form keeps the single chain that the fused BatchNorm-backward pass restates element by
+        // element -- bn_act_bwd_apply_vec_kernel's per-group partial sums)
+        if (gridDim.y == 1)
+        for (; r + 3 * nrg < r1; r += 4 * nrg) {
+            const f32x4 a0 = ld4<TY>(base + (size_t)r * C), a1 = ld4<TY>(base + (size_t)(r + nrg) * C);
+            const f32x4 a2 = ld4<TY>(base + (size_t)(r + 2 * nrg) * C), a3 = ld4<TY>(base + (size_t)(r + 3 * nrg) * C);
+            s = s + a0; s1 = s1 + a1; s2 = s2 + a2; s3 = s3 + a3;
+        }
+        for (; r < r1; r += nrg) s = s + ld4<TY>(base + (size_t)r * C);
+        s = (s + s1) + (s2 + s3);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) shd[tid * 4 + e] = s[e];
     __syncthreads();
@@ -688,21 +714,40 @@ __global__ __launch_bounds__(256) void colsum_groups_vec_kernel(const TY* __rest
         for (int e = 0; e < 4; ++e) part[((size_t)g * slabs + slab) * C + tid * 4 + e] = a[e];
     }
 }
-__global__ void colsum_groups_fin_kernel(const float* __restrict__ part, int G, int C, int slabs, float* __restrict__ out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= G * C) return;
-    int g = t / C, c = t % C;
+// 16 lanes per output: lane l adds slabs l, l + 16, ... (four loads in flight), the sixteen partial sums are added in lane order (one
+// thread walked all the slabs before: up to 1,024 dependent loads, 10-12 us for 512 outputs)
+__global__ __launch_bounds__(256) void colsum_groups_fin_kernel(const float* __restrict__ part, int G, int C, int slabs, float* __restrict__ out) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x, l = tid & 15;
+    const int t = blockIdx.x * 16 + (tid >> 4);
     float s = 0.f;
-#pragma unroll 8
-    for (int u = 0; u < slabs; ++u) s += part[((size_t)g * slabs + u) * C + c];
-    out[t] = s;
+    if (t < G * C) {
+        const int g = t / C, c = t % C;
+        const float* p = part + (size_t)g * slabs * C + c;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int u = l;
+        for (; u + 48 < slabs; u += 64) {
+            const float a0 = p[(size_t)u * C], a1 = p[(size_t)(u + 16) * C], a2 = p[(size_t)(u + 32) * C], a3 = p[(size_t)(u + 48) * C];
+            s += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; u < slabs; u += 16) s += p[(size_t)u * C];
+        s = (s + s1) + (s2 + s3);
+    }
+    sh[tid] = s;
+    __syncthreads();
+    if (l == 0 && t < G * C) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += sh[tid + q];
+        out[t] = a;
+    }
 }
 
 int launch_colsum_groups(hipStream_t st, const float* X, int G, int rows_per_group, int C, float* out, float* scratch = nullptr) {
     if (scratch && vec_ok(C, X) && 256 % (C / 4) == 0 && rows_per_group >= 256) {
         const int slabs = 16;                       // scratch: [G][16][C] floats
         hipLaunchKernelGGL((colsum_groups_vec_kernel<float>), dim3(slabs, G), dim3(256), 0, st, X, C, rows_per_group, slabs, scratch);
-        hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 255) / 256), dim3(256), 0, st, scratch, G, C, slabs, out);
+        hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 15) / 16), dim3(256), 0, st, scratch, G, C, slabs, out);
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(colsum_groups_kernel, dim3((C + 63) / 64, G), dim3(256), 0, st, X, C, rows_per_group, out);
@@ -736,7 +781,7 @@ int launch_bn_dy_gbias(hipStream_t st, const float* Y, int G, int rows_per_group
 
 // second half of launch_colsum_groups alone: scratch [G][slabs][C] written by bn_act_bwd_apply_vec_kernel (launch_bn_act_bwd, gpart)
 int launch_colsum_groups_fin(hipStream_t st, const float* scratch, int G, int C, int slabs, float* out) {
-    hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 255) / 256), dim3(256), 0, st, scratch, G, C, slabs, out);
+    hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 15) / 16), dim3(256), 0, st, scratch, G, C, slabs, out);
     return mlsp_launch_status();
 }
 
@@ -748,7 +793,7 @@ int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, fl
         const int slabs = 4 * nparts;
         float* scratch = (float*)part;
         hipLaunchKernelGGL((colsum_groups_vec_kernel<float>), dim3(slabs, 1), dim3(256), 0, st, X, C, M, slabs, scratch);
-        hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, 1, C, slabs, out);
+        hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((C + 15) / 16), dim3(256), 0, st, scratch, 1, C, slabs, out);
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(colstats_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, X, M, C, C, part);
@@ -906,7 +951,7 @@ int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* d
     const int nparts = bn_vec_parts(M);
     hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, M, C, scale,
                        shift, mean, invstd, act, slope, th, inv_keep, seed, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy, (float*)nullptr);
     hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, (__bf16*)dY,
                        M, C, scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed, (float*)nullptr, 0);
     return mlsp_launch_status();
@@ -915,6 +960,6 @@ int launch_colsum_groups_b16(hipStream_t st, const void* X, int G, int rows_per_
     if (!scratch || !vec_ok_b16(C, X) || rows_per_group < 256) return MLSP_ERR_UNSUPPORTED;
     const int slabs = 16;
     hipLaunchKernelGGL((colsum_groups_vec_kernel<__bf16>), dim3(slabs, G), dim3(256), 0, st, (const __bf16*)X, C, rows_per_group, slabs, scratch);
-    hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 255) / 256), dim3(256), 0, st, scratch, G, C, slabs, out);
+    hipLaunchKernelGGL(colsum_groups_fin_kernel, dim3((G * C + 15) / 16), dim3(256), 0, st, scratch, G, C, slabs, out);
     return mlsp_launch_status();
 }

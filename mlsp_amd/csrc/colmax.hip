@@ -45,8 +45,10 @@ __global__ __launch_bounds__(256) void colsel_kernel(const float* __restrict__ Y
 }
 
 // reduce the per-panel extremes written by the GEMM epilogue over the N/128 panels of each cloud
+// (bn != null: the BatchNorm + activation of the selected value -- colsel_out_kernel's arithmetic -- in the same pass)
 __global__ void colsel_panels_kernel(const float* __restrict__ pv, const int* __restrict__ pr, const float* __restrict__ gamma,
-                                     int B, int N, int C, int panels_per_cloud, float* __restrict__ ysel, int* __restrict__ arg) {
+                                     int B, int N, int C, int panels_per_cloud, float* __restrict__ ysel, int* __restrict__ arg,
+                                     const float* __restrict__ bn, int act, float slope, float* __restrict__ out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * C) return;
     int b = t / C, c = t % C;
@@ -61,6 +63,7 @@ __global__ void colsel_panels_kernel(const float* __restrict__ pv, const int* __
     }
     ysel[t] = best;
     arg[t] = brow - b * N;
+    if (bn) out[t] = lrelu_or_relu(fmaf(best, bn[c], bn[C + c]), act, slope);
 }
 
 // out = act(scale*ysel + shift)      [B][C]
@@ -111,9 +114,18 @@ __global__ void scale_rows_kernel(const float* __restrict__ W, int ldw, const fl
 }
 
 // negr[i] = - sum_c v[c] * W[c][i]        block: 64 columns x 16 row groups (one wave each), LDS reduce in fixed order
+// (Wb != null: the workgroups past the first ceil(Cin / 64) are scale_rows_kernel's -- Wb[c][:] = rowscale[c] * W[c][:] -- so that the two
+// weight-sized preparations of the colmax backward's input-gradient half are one launch)
 __global__ __launch_bounds__(1024) void wt_vec_neg_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ v, int Cout,
-                                                          int Cin, float* __restrict__ negr) {
+                                                          int Cin, float* __restrict__ negr, const float* __restrict__ rowscale,
+                                                          float* __restrict__ Wb) {
     __shared__ float red[16][64];
+    const int nvb = (Cin + 63) / 64;
+    if ((int)blockIdx.x >= nvb) {
+        const int t = ((int)blockIdx.x - nvb) * 1024 + threadIdx.x;
+        if (t < Cout * Cin) { const int c = t / Cin, i = t % Cin; Wb[t] = rowscale[c] * W[(size_t)c * ldw + i]; }
+        return;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     float acc = 0.f;
@@ -278,9 +290,9 @@ int launch_colsel(hipStream_t st, const float* Y, const float* gamma, int B, int
     return mlsp_launch_status();
 }
 int launch_colsel_panels(hipStream_t st, const float* pv, const int* pr, const float* gamma, int B, int N, int C, int panel_rows,
-                         float* ysel, int* arg) {
+                         float* ysel, int* arg, const float* bn, int act, float slope, float* out) {
     hipLaunchKernelGGL(colsel_panels_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, pv, pr, gamma, B, N, C, N / panel_rows, ysel,
-                       arg);
+                       arg, bn, act, slope, out);
     return mlsp_launch_status();
 }
 int launch_colsel_out(hipStream_t st, const float* ysel, const float* bn, int B, int C, int act, float slope, float* out) {
@@ -298,7 +310,14 @@ int launch_scale_rows(hipStream_t st, const float* W, int ldw, const float* rows
     return mlsp_launch_status();
 }
 int launch_wt_vec_neg(hipStream_t st, const float* W, int ldw, const float* v, int Cout, int Cin, float* negr) {
-    hipLaunchKernelGGL(wt_vec_neg_kernel, dim3((Cin + 63) / 64), dim3(1024), 0, st, W, ldw, v, Cout, Cin, negr);
+    hipLaunchKernelGGL(wt_vec_neg_kernel, dim3((Cin + 63) / 64), dim3(1024), 0, st, W, ldw, v, Cout, Cin, negr, (const float*)nullptr, (float*)nullptr);
+    return mlsp_launch_status();
+}
+// negr = -W^T v and Wb = diag(rowscale) W in one launch
+int launch_wt_vec_neg_scale_rows(hipStream_t st, const float* W, int ldw, const float* v, const float* rowscale, int Cout, int Cin, float* negr,
+                                 float* Wb) {
+    hipLaunchKernelGGL(wt_vec_neg_kernel, dim3((Cin + 63) / 64 + (Cout * Cin + 1023) / 1024), dim3(1024), 0, st, W, ldw, v, Cout, Cin, negr,
+                       rowscale, Wb);
     return mlsp_launch_status();
 }
 int launch_colmax_gather_rows(hipStream_t st, const float* g, const int* arg, const float* X, int ldx, int B, int N, int Cout,

@@ -1269,10 +1269,67 @@ __global__ __launch_bounds__(256) void splitk_reduce_wave_kernel(const float* __
     }
 }
 
+// The split-K sum of an EdgeConv weight gradient dWd = [dWd_u ; dWd_v] ([2 Cout][C], edge.hip build_wd_kernel's layout) written straight in
+// the reference layout dW [Cout][2 C] = [dWd_u - dWd_v | dWd_v] (unbuild_wd_kernel's arithmetic on the same two sums, each taken in
+// splitk_reduce_vec_kernel's order): the reduce and the unfold are one launch.  v indexes the float4s of the U half.
+template <int ZG>
+__global__ __launch_bounds__(256) void splitk_reduce_unfold_kernel(const float* __restrict__ slab, float* __restrict__ dW, size_t half4, int C4,
+                                                                   int nsplit) {
+    constexpr int EPB = 256 / ZG;
+    __shared__ f32x4 part[ZG > 1 ? 512 : 1];
+    const int e = threadIdx.x % EPB, g = threadIdx.x / EPB;
+    const size_t v = (size_t)blockIdx.x * EPB + e;
+    const size_t total4 = 2 * half4;
+    f32x4 su = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+    if (v < half4) {
+        const f32x4* p = (const f32x4*)slab + v;
+        int z = g;
+        for (; z + 3 * ZG < nsplit; z += 4 * ZG) {
+            f32x4 t[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { t[u] = p[(size_t)(z + u * ZG) * total4]; w[u] = p[(size_t)(z + u * ZG) * total4 + half4]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { su = su + t[u]; sv = sv + w[u]; }
+        }
+        for (; z < nsplit; z += ZG) { su = su + p[(size_t)z * total4]; sv = sv + p[(size_t)z * total4 + half4]; }
+    }
+    if (ZG > 1) {
+        part[threadIdx.x] = su; part[256 + threadIdx.x] = sv;
+        __syncthreads();
+        if (g != 0) return;
+#pragma unroll
+        for (int q = 1; q < ZG; ++q) { su = su + part[q * EPB + e]; sv = sv + part[256 + q * EPB + e]; }
+    }
+    if (v >= half4) return;
+    const size_t o = v / C4, c4 = v % C4;
+    f32x4* out = (f32x4*)dW + o * 2 * C4 + c4;
+    out[0] = su - sv;
+    out[C4] = sv;
+}
+// request of the NEXT split-K reduction on this thread (launch_gemm of an EdgeConv weight gradient): consumed by launch_splitk_reduce_any,
+// which clears it; gemm_unfold_take() tells the caller whether the reduce did the unfold (a launch without K splits did not)
+static thread_local float* tl_unfold_dw = nullptr;
+static thread_local bool tl_unfold_done = false;
+void gemm_unfold_request(float* dW) { tl_unfold_dw = dW; tl_unfold_done = false; }
+bool gemm_unfold_take() { const bool d = tl_unfold_done; tl_unfold_dw = nullptr; tl_unfold_done = false; return d; }
+
 static void launch_splitk_reduce_any(hipStream_t st, const float* slab, float* C, int M, int N, int ldc, int ns, const float* bias,
                                      const float* gbias, int rows_per_group) {
     size_t total = (size_t)M * N;
     const bool vec = (N % 4 == 0) && ldc == N && ((((uintptr_t)slab | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)gbias) & 15) == 0);
+    if (tl_unfold_dw && vec && !bias && !gbias && M % 2 == 0 && (((uintptr_t)tl_unfold_dw) & 15) == 0) {
+        float* dW = tl_unfold_dw;
+        tl_unfold_dw = nullptr; tl_unfold_done = true;
+        const size_t h4 = total / 8;
+        if (ns >= 32 && 2 * h4 <= 64 * 1024)
+            hipLaunchKernelGGL((splitk_reduce_unfold_kernel<8>), dim3((unsigned)((h4 + 31) / 32)), dim3(256), 0, st, slab, dW, h4, N / 4, ns);
+        else if (ns >= 8)
+            hipLaunchKernelGGL((splitk_reduce_unfold_kernel<4>), dim3((unsigned)((h4 + 63) / 64)), dim3(256), 0, st, slab, dW, h4, N / 4, ns);
+        else
+            hipLaunchKernelGGL((splitk_reduce_unfold_kernel<1>), dim3((unsigned)((h4 + 255) / 256)), dim3(256), 0, st, slab, dW, h4, N / 4, ns);
+        return;
+    }
+    tl_unfold_dw = nullptr;
     if (vec) {
         size_t t4 = total / 4;
         // enough workgroups to fill the chip: more slab groups per workgroup when the output is small

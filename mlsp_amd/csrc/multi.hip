@@ -37,6 +37,10 @@ int launch_bn_bwd_finalize_coef(hipStream_t st, const double* part, int nparts, 
 bool gemm_dy_supported(bool ta, bool tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb);
 int launch_bn_bwd_finalize(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
                            float* mean_dz, float* mean_dzy);
+int launch_bn_bwd_finalize_z(hipStream_t st, const double* part, int nparts, double count, int C, float* dgamma, float* dbeta,
+                             float* mean_dz, float* mean_dzy, float* zero_vec);
+int launch_bn_bwd_finalize_coef_z(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
+                                  float* dbeta, float* coef, float* zero_vec);
 int launch_colsum(hipStream_t st, const float* X, int M, int C, double* part, float* out);
 
 #define MROWS 64          // rows per workgroup of the streaming passes (== VROWS of bn.hip: bn_vec_parts)
@@ -454,13 +458,14 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
         if (dX) use_dy = gemm_dy_supported(false, false, M, run[s] * g.Cin, g.Cout, dZ + yc, Ctot, g.W, g.ldw);
         use_dy = use_dy && gemm_dy_supported(true, false, run[s] * g.Cout, g.Cin, M, dZ + yc, Ctot, X + g.x_col, ldx);
     }
+    float* zb = (dbias && training) ? dbias : nullptr;      // a bias in front of a batch-statistics BatchNorm: analytically zero gradient, written by the finalizer
     if (use_dy) {
-        MCHECK(launch_bn_bwd_finalize_coef(st, pre_stats, pre_parts, (double)M, Ctot, bn_save, dgamma, dbeta, coef));
+        MCHECK(launch_bn_bwd_finalize_coef_z(st, pre_stats, pre_parts, (double)M, Ctot, bn_save, dgamma, dbeta, coef, zb));
     } else if (pre_stats) {
-        MCHECK(launch_bn_bwd_finalize(st, pre_stats, pre_parts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy));
+        MCHECK(launch_bn_bwd_finalize_z(st, pre_stats, pre_parts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy, zb));
     } else {
         hipLaunchKernelGGL(multi_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, Ctot, bn_save, chan, th, ik, seed, part);
-        MCHECK(launch_bn_bwd_finalize(st, part, nparts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy));
+        MCHECK(launch_bn_bwd_finalize_z(st, part, nparts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy, zb));
     }
     const int rpb = multi_rows_per_block(M, Ctot);
     if (!use_dy) {
@@ -515,14 +520,7 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
                            nullptr, nullptr, nullptr, nullptr, false, xf, 0, G > 1 ? &grw : nullptr, nullptr, use_dy ? &dy_s : nullptr));
         ycol += G * g.Cout;
     }
-    if (dbias) {
-        if (training) {      // a bias in front of a batch-statistics BatchNorm: analytically zero gradient
-            hipError_t e = hipMemsetAsync(dbias, 0, (size_t)Ctot * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
-        } else {
-            MCHECK(launch_colsum(st, dY, M, Ctot, part, dbias));
-        }
-    }
+    if (dbias && !training) MCHECK(launch_colsum(st, dY, M, Ctot, part, dbias));      // (training: zeroed by the finalizer above)
     return MLSP_OK;
 }
 

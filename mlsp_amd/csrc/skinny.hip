@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_fwd_kernel(SkinnyFwdArgs
 __global__ __launch_bounds__(256) void skinny_bn_bwd_kernel(const float* __restrict__ dZ, const float* __restrict__ Y, float* __restrict__ dY,
                                                             int M, int C, const float* __restrict__ bn_save, int training, int act,
                                                             float slope, uint32_t thresh, float inv_keep, uint64_t seed,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ zero_vec) {
     __shared__ float ss[4][64], sq[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void skinny_bn_bwd_kernel(const float* __restr
     __syncthreads();
     s = ((ss[0][lane] + ss[1][lane]) + ss[2][lane]) + ss[3][lane];
     q = ((sq[0][lane] + sq[1][lane]) + sq[2][lane]) + sq[3][lane];
-    if (wave == 0 && cok) { dgamma[c] = q; dbeta[c] = s; }
+    if (wave == 0 && cok) { dgamma[c] = q; dbeta[c] = s; if (zero_vec) zero_vec[c] = 0.f; }      // (zero_vec: the bias gradient in front of a batch-statistics BatchNorm)
     const float k1 = training ? s / (float)M : 0.f, k2 = training ? q / (float)M : 0.f;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -194,11 +194,10 @@ __global__ __launch_bounds__(256) void skinny_bn_bwd_kernel(const float* __restr
 }
 
 // ---- dgrad: C[M<=32][N] = A[M][K] * B[K][N]   (A row-major, B k-major).  Same 4-wave K split as the forward.
-__global__ __launch_bounds__(64 * SK_WAVES) void skinny_nn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                                  float* __restrict__ Cm, int ldc, int M, int N, int K) {
-    __shared__ float red[SK_WAVES - 1][16][64];
+__device__ __forceinline__ void sk_nn_body(int blk, float (*red)[16][64], const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                           float* __restrict__ Cm, int ldc, int M, int N, int K) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 32, col = n0 + l31;
+    const int n0 = blk * 32, col = n0 + l31;
     const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
     const int chunks = (K + 7) / 8, cper = (chunks + SK_WAVES - 1) / SK_WAVES;
     const int c0 = wave * cper, c1 = min(chunks, c0 + cper);
@@ -229,12 +228,17 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_nn_kernel(const float* _
     }
 }
 
+__global__ __launch_bounds__(64 * SK_WAVES) void skinny_nn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                                  float* __restrict__ Cm, int ldc, int M, int N, int K) {
+    __shared__ float red[SK_WAVES - 1][16][64];
+    sk_nn_body(blockIdx.x, red, A, lda, B, ldb, Cm, ldc, M, N, K);
+}
+
 // ---- wgrad: C[Mo][No] = A^T B with A [K<=32][Mo], B [K][No] (both k-major).  One wave per 32x32 output tile.
-__global__ __launch_bounds__(256) void skinny_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                        float* __restrict__ Cm, int ldc, int Mo, int No, int K) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void sk_tn_body(int tile, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                           float* __restrict__ Cm, int ldc, int Mo, int No, int K) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
     const int ntn = (No + 31) / 32;
-    const int tile = blockIdx.x * 4 + wave;
     if (tile >= ((Mo + 31) / 32) * ntn) return;
     const int m0 = (tile / ntn) * 32, n0 = (tile % ntn) * 32;
     const int arow = m0 + l31, bcol = n0 + l31;
@@ -256,6 +260,28 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const float* __restrict_
         const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < Mo) Cm[(size_t)row * ldc + bcol] = acc[r];
     }
+}
+__global__ __launch_bounds__(256) void skinny_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                        float* __restrict__ Cm, int ldc, int Mo, int No, int K) {
+    sk_tn_body(blockIdx.x * 4 + (threadIdx.x >> 6), A, lda, B, ldb, Cm, ldc, Mo, No, K);
+}
+// ---- both gradients of a per-cloud Linear layer (rows = batch <= 32) in ONE launch: workgroups [0, nb_nn) run the dgrad dX = G W
+// (skinny_nn_kernel's body), the rest the weight gradient dW = G^T X (skinny_tn_kernel's body, eight tiles per workgroup).  Same arithmetic,
+// same summation order as the two launches it replaces.
+__global__ __launch_bounds__(64 * SK_WAVES) void skinny_bwd_pair_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ W, int ldw,
+                                                                        const float* __restrict__ X, int ldx, float* __restrict__ dX, int lddx,
+                                                                        float* __restrict__ dW, int M, int Cin, int Cout, int nb_nn) {
+    __shared__ float red[SK_WAVES - 1][16][64];
+    if ((int)blockIdx.x < nb_nn) sk_nn_body(blockIdx.x, red, G, ldg, W, ldw, dX, lddx, M, Cin, Cout);
+    else sk_tn_body(((int)blockIdx.x - nb_nn) * SK_WAVES + (threadIdx.x >> 6), G, ldg, X, ldx, dW, Cin, Cout, Cin, M);
+}
+int launch_skinny_bwd_pair(hipStream_t st, const float* G, int ldg, const float* W, int ldw, const float* X, int ldx, float* dX, int lddx,
+                           float* dW, int M, int Cin, int Cout) {
+    if (M > 32 || !G || !W || !X || !dX || !dW) return MLSP_ERR_UNSUPPORTED;
+    const int nb_nn = (Cin + 31) / 32, tiles = ((Cout + 31) / 32) * ((Cin + 31) / 32);
+    hipLaunchKernelGGL(skinny_bwd_pair_kernel, dim3(nb_nn + (tiles + SK_WAVES - 1) / SK_WAVES), dim3(64 * SK_WAVES), 0, st, G, ldg, W, ldw, X, ldx,
+                       dX, lddx, dW, M, Cin, Cout, nb_nn);
+    return mlsp_launch_status();
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -300,13 +326,17 @@ int launch_skinny_linear_bn_act(hipStream_t st, const float* X, int ldx, int M, 
     return mlsp_launch_status();
 }
 
-int launch_skinny_bn_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* bn_save, int training,
-                         int act, float slope, float p_drop, uint64_t seed, float* dgamma, float* dbeta) {
+int launch_skinny_bn_bwd_z(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* bn_save, int training,
+                           int act, float slope, float p_drop, uint64_t seed, float* dgamma, float* dbeta, float* zero_vec) {
     if (M > 32) return MLSP_ERR_ARG;
     const float pd = training ? p_drop : 0.f;
     hipLaunchKernelGGL(skinny_bn_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, st, dZ, Y, dY, M, C, bn_save, training, act, slope,
-                       sk_drop_thresh(pd), dropout_inv_keep8(pd), seed, dgamma, dbeta);
+                       sk_drop_thresh(pd), dropout_inv_keep8(pd), seed, dgamma, dbeta, zero_vec);
     return mlsp_launch_status();
+}
+int launch_skinny_bn_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* bn_save, int training,
+                         int act, float slope, float p_drop, uint64_t seed, float* dgamma, float* dbeta) {
+    return launch_skinny_bn_bwd_z(st, dZ, Y, dY, M, C, bn_save, training, act, slope, p_drop, seed, dgamma, dbeta, nullptr);
 }
 
 
