@@ -36,8 +36,12 @@ struct SkinnyFwdArgs {
     float* Z; float* bn_save;          // Z [M][N]; bn_save = scale | shift | mean | invstd, N floats each
 };
 
+#ifndef SK_WAVES
 #define SK_WAVES 8           // waves per workgroup (2 per SIMD -> 256 VGPRs each): the K range is cut 8 ways
+#endif
+#ifndef SK_BATCH
 #define SK_BATCH 8           // chunks (of 8 k) whose loads are all in flight before the first MFMA of the batch
+#endif
 
 // sum of the SK_WAVES partial tiles in wave order; result in wave 0 (other waves return false)
 __device__ __forceinline__ bool sk_reduce_tiles(f32x16& acc, float (*red)[16][64], int wave, int lane) {

@@ -1289,3 +1289,19 @@ def test_compose_linear_fwd_bwd(dev, Cm, Ci, Co):
     (W * gW).sum().backward()
     np.testing.assert_allclose(Wb.grad.cpu().numpy(), (gW.double().cpu() @ ref[0].detach().T).numpy(), rtol=1e-5, atol=1e-5)
     assert float(bb.grad.abs().max()) == 0.0
+
+
+def test_knn_wide_mixed_clouds_flag_handover(dev):
+    """knn6w_kernel (24 < k <= 40) hands a cloud to the v5 kernel behind it when one of its workgroups overflows a survivor list or has no
+    finite bound; the other clouds of the same call keep its own rows.  One call with all four kinds of cloud: random, N identical points
+    (every list overflows), random far from the origin, one with a NaN point -- every row must equal the oracle's."""
+    Fh = _fh()
+    B, N, C, k = 4, 256, 64, 40
+    x = _rand((B, N, C), 515)
+    x[1] = 0.25
+    x[2] = x[2] * 0.1 + 7.0
+    x[3, 100, 5] = float("nan")
+    want = knn_canon.knn_point_major(x, k)
+    got = Fh.knn_graph(x.view(B * N, C).to(dev), B, N, k).idx.view(B, N, k).cpu().numpy()
+    assert got.min() >= 0 and got.max() < N
+    assert np.array_equal(got, want), "mismatching rows per cloud: %s" % [(int((got[b] != want[b]).any(-1).sum())) for b in range(B)]
