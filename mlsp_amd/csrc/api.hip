@@ -50,6 +50,11 @@ int launch_skinny_bn_bwd_z(hipStream_t st, const float* dZ, const float* Y, floa
                            int act, float slope, float p_drop, uint64_t seed, float* dgamma, float* dbeta, float* zero_vec);
 void gemm_unfold_request(float* dW);
 bool gemm_unfold_take();
+void bn_zero_vec_request(float* v);
+bool bn_zero_vec_take();
+int launch_build_wd_eval(hipStream_t st, const float* W, int Cout, int C, float* Wd, int Ca, const float* ga, const float* ba, const float* rma,
+                         const float* rva, float* sva, int Cb, const float* gb, const float* bb, const float* rmb, const float* rvb, float* svb,
+                         float eps);
 bool knn6_supported(int B, int N, int C, int k);
 bool knn6w_supported(int B, int N, int C, int k);
 size_t knn6_plane_bytes(int P, int C);
@@ -392,7 +397,10 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
     float* slab = sf ? w.take<float>(sf) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
-    CHECK(launch_build_wd(st, W, Cout, C, Wd));
+    if (!training) {                  // eval mode: the BatchNorm vectors do not depend on the batch -- prepared by the weight-fold launch
+        if (!run_mean || !run_var) return MLSP_ERR_ARG;
+        CHECK(launch_build_wd_eval(st, W, Cout, C, Wd, Cout, gamma, beta, run_mean, run_var, bn_save, 0, nullptr, nullptr, nullptr, nullptr, nullptr, eps));
+    } else CHECK(launch_build_wd(st, W, Cout, C, Wd));
     CHECK(launch_gemm(st, false, true, P, 2 * Cout, C, x, ldx, Wd, C, uv, 2 * Cout, nullptr, nullptr, 0, slab, sf));
     {   // the neighbour gather + max/min + BN sums: compulsory bytes = u half + indices in, msel + s1 + arg slot out
         const int tok = prof_cls_begin(st, MLSP_PROF_EDGE_REDUCE);
@@ -403,9 +411,6 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
     if (training) {
         CHECK(launch_bn_finalize(st, part, nparts, (double)P * k, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale,
                                  shift, mean, invstd));
-    } else {
-        if (!run_mean || !run_var) return MLSP_ERR_ARG;
-        CHECK(launch_bn_eval_prepare(st, Cout, gamma, beta, run_mean, run_var, eps, scale, shift, mean, invstd));
     }
     CHECK(launch_edge_select_act(st, msel, uv, P, Cout, scale, shift, act, slope, out, ldo));
     return MLSP_OK;
@@ -476,16 +481,15 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
     size_t sf = gemm_slab_floats(P, 2 * C1, C);
     float* slab = sf ? w.take<float>(sf) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
-    CHECK(launch_build_wd(st, W1, C1, C, Wd));
+    if (!training) {                  // eval mode: both BatchNorm stages' vectors ride in the weight-fold launch
+        if (!run_mean1 || !run_var1 || !run_mean2 || !run_var2) return MLSP_ERR_ARG;
+        CHECK(launch_build_wd_eval(st, W1, C1, C, Wd, C1, gamma1, beta1, run_mean1, run_var1, bn1_save, C2, gamma2, beta2, run_mean2, run_var2, bn2_save, eps));
+    } else CHECK(launch_build_wd(st, W1, C1, C, Wd));
     CHECK(launch_gemm(st, false, true, P, 2 * C1, C, x, ldx, Wd, C, uv, 2 * C1, nullptr, nullptr, 0, slab, sf));
     CHECK(launch_edge_reduce(st, uv, idx, gamma1, P, N, C1, k, msel, arg1, s1, part, &np1));
     if (training) {
         CHECK(launch_bn_finalize(st, part, np1, (double)P * k, C1, gamma1, beta1, run_mean1, run_var1, momentum, eps, bn1_save,
                                  bn1_save + C1, bn1_save + 2 * C1, bn1_save + 3 * C1));
-    } else {
-        if (!run_mean1 || !run_var1 || !run_mean2 || !run_var2) return MLSP_ERR_ARG;
-        CHECK(launch_bn_eval_prepare(st, C1, gamma1, beta1, run_mean1, run_var1, eps, bn1_save, bn1_save + C1, bn1_save + 2 * C1,
-                                     bn1_save + 3 * C1));
     }
     {
         const int tok = prof_cls_begin(st, MLSP_PROF_TNET_FWD);
@@ -496,9 +500,6 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
     if (training) {
         CHECK(launch_bn_finalize(st, part, np2, (double)P * k, C2, gamma2, beta2, run_mean2, run_var2, momentum, eps, bn2_save,
                                  bn2_save + C2, bn2_save + 2 * C2, bn2_save + 3 * C2));
-    } else {
-        CHECK(launch_bn_eval_prepare(st, C2, gamma2, beta2, run_mean2, run_var2, eps, bn2_save, bn2_save + C2, bn2_save + 2 * C2,
-                                     bn2_save + 3 * C2));
     }
     CHECK(launch_tnet_out(st, zsel, bn2_save, P, slope, out));
     return MLSP_OK;
@@ -743,9 +744,12 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     } else if (has_bn) {
         const float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
         // (the per-cloud bias gradient -- column sums of dY per cloud -- comes out of the same pass when the shape allows)
-        CHECK(launch_bn_act_bwd(st, dZ, Y, dY, M, Cout, scale, shift, mean, invstd, training, act, slope,
-                                training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy, dgbias ? gscratch : nullptr,
-                                rows_per_group, &g_slabs, pre_stats, pre_parts));
+        bn_zero_vec_request(zb);
+        const int rcb = launch_bn_act_bwd(st, dZ, Y, dY, M, Cout, scale, shift, mean, invstd, training, act, slope,
+                                          training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy, dgbias ? gscratch : nullptr,
+                                          rows_per_group, &g_slabs, pre_stats, pre_parts);
+        dbias_zeroed = bn_zero_vec_take();
+        if (rcb != MLSP_OK) return rcb;
         g = dY;
     }
     GemmBs bs_s; const GemmBs* bs = nullptr;
@@ -947,16 +951,17 @@ int mlsp_pointmlp_bwd_mx(const void* dZ, const void* X, int x_bf16, int ldx, int
     float* gscratch = dgbias ? w.take<float>((size_t)n_groups * 16 * Cout) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float* scale = bn_save, *shift = bn_save + Cout, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
-    if (out_bf16)
-        CHECK(launch_bn_act_bwd_b16(st, dZ, Y, dY, M, Cout, scale, shift, mean, invstd, training, act, slope, training ? p_drop : 0.f, seed,
-                                    part, dgamma, dbeta, mean_dz, mean_dzy));
-    else
-        CHECK(launch_bn_act_bwd(st, (const float*)dZ, (const float*)Y, (float*)dY, M, Cout, scale, shift, mean, invstd, training, act, slope,
-                                training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy));
+    bn_zero_vec_request(dbias);       // (a bias in front of a batch-stat BN: zero gradient, written by the finalizer of the pass below)
+    const int rcb = out_bf16 ? launch_bn_act_bwd_b16(st, dZ, Y, dY, M, Cout, scale, shift, mean, invstd, training, act, slope, training ? p_drop : 0.f, seed,
+                                                     part, dgamma, dbeta, mean_dz, mean_dzy)
+                             : launch_bn_act_bwd(st, (const float*)dZ, (const float*)Y, (float*)dY, M, Cout, scale, shift, mean, invstd, training, act, slope,
+                                                 training ? p_drop : 0.f, seed, part, dgamma, dbeta, mean_dz, mean_dzy);
+    const bool dbias_zeroed = bn_zero_vec_take();
+    if (rcb != MLSP_OK) return rcb;
     if (dX) CHECK(launch_gemm_mx(st, false, false, M, Cin, Cout, dY, out_bf16, Cout, W, 0, ldw, dX, x_bf16, lddx, nullptr, nullptr, 0, nullptr, 0,
                                  nullptr, dx_accumulate != 0));
     CHECK(launch_gemm_mx(st, true, false, Cout, Cin, M, dY, out_bf16, Cout, X, x_bf16, ldx, dW, 0, Cin, nullptr, nullptr, 0, slab, sf, nullptr, false));
-    if (dbias) {     // a bias in front of a batch-stat BN has an analytically zero gradient (sum_rows dY == 0)
+    if (dbias && !dbias_zeroed) {     // a bias in front of a batch-stat BN has an analytically zero gradient (sum_rows dY == 0)
         hipError_t e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }

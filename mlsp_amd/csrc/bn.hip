@@ -557,6 +557,7 @@ int launch_bn_act_fwd(hipStream_t st, const float* Y, float* Z, size_t rows, int
     return mlsp_launch_status();
 }
 
+static float* bn_zero_vec_consume();
 int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* scale,
                       const float* shift, const float* mean, const float* invstd, int training, int act, float slope,
                       float p_drop, uint64_t seed, double* part, float* dgamma, float* dbeta, float* mean_dz,
@@ -570,7 +571,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
         if (!(vec_ok(C, dZ, Y, dY) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)))
             return MLSP_ERR_UNSUPPORTED;
         const bool fuse_g = gpart && gpart_slabs && rows_per_group > 0 && rows_per_group % VROWS == 0 && rows_per_group / VROWS <= 16 && M % rows_per_group == 0;
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, pre_stats, pre_parts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy, (float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, pre_stats, pre_parts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy, bn_zero_vec_consume());
         hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C, scale, shift, mean, invstd,
                            training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, 0u, 1.f, seed, fuse_g ? gpart : (float*)nullptr, 1);
         if (fuse_g) *gpart_slabs = rows_per_group / VROWS;
@@ -591,7 +592,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
                            mean, invstd, act, slope, th, inv_keep, seed, part);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma,
-                       dbeta, mean_dz, mean_dzy, (float*)nullptr);
+                       dbeta, mean_dz, mean_dzy, bn_zero_vec_consume());
     size_t total = (size_t)M * C;
     if (vec) {
         hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C,
@@ -941,6 +942,15 @@ int launch_bn_act_fwd_b16(hipStream_t st, const void* Y, void* Z, int rows, int 
                        scale, shift, act, slope, drop_thresh(p_drop), inv_keep, seed);
     return mlsp_launch_status();
 }
+// A [C] vector the NEXT BatchNorm-backward finalizer launched on this thread also zero-fills (the gradient of a bias in front of a
+// batch-statistics BatchNorm): bn_zero_vec_request() before launch_bn_act_bwd / launch_bn_act_bwd_b16, bn_zero_vec_take() afterwards says
+// whether a finalizer took it (the caller memsets otherwise).
+static thread_local float* tl_zero_vec = nullptr;
+static thread_local bool tl_zero_done = false;
+void bn_zero_vec_request(float* v) { tl_zero_vec = v; tl_zero_done = false; }
+bool bn_zero_vec_take() { const bool d = tl_zero_done; tl_zero_vec = nullptr; tl_zero_done = false; return d; }
+static float* bn_zero_vec_consume() { float* v = tl_zero_vec; if (v) { tl_zero_vec = nullptr; tl_zero_done = true; } return v; }
+
 int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* dY, int M, int C, const float* scale, const float* shift,
                           const float* mean, const float* invstd, int training, int act, float slope, float p_drop, uint64_t seed,
                           double* part, float* dgamma, float* dbeta, float* mean_dz, float* mean_dzy) {
@@ -951,7 +961,7 @@ int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* d
     const int nparts = bn_vec_parts(M);
     hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, M, C, scale,
                        shift, mean, invstd, act, slope, th, inv_keep, seed, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy, (float*)nullptr);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy, bn_zero_vec_consume());
     hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, (__bf16*)dY,
                        M, C, scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed, (float*)nullptr, 0);
     return mlsp_launch_status();

@@ -28,6 +28,25 @@ __global__ void build_wd_kernel(const float* __restrict__ W, int Cout, int C, fl
     Wd[(size_t)o * C + c] = wa;
     Wd[(size_t)(Cout + o) * C + c] = wb - wa;
 }
+// the same + the eval-mode BatchNorm vectors of up to two BatchNorm stages of the calling entry point (scale | shift | mean | invstd from the
+// running statistics: bn_eval_prepare_kernel's arithmetic) -- an eval-mode EdgeConv / T-Net forward folds its weight and prepares its
+// BatchNorm in ONE launch (PointSegDA's layers have no BatchNorm: they run as identity-BN eval layers, three + two such launches a step)
+struct EvalPrep { int C; const float* gamma; const float* beta; const float* rm; const float* rv; float eps; float* save; };
+__device__ __forceinline__ void eval_prep_one(const EvalPrep& e, int c) {
+    const float invstd = 1.0f / sqrtf(e.rv[c] + e.eps);
+    const float sc = e.gamma[c] * invstd;
+    e.save[c] = sc; e.save[e.C + c] = e.beta[c] - e.rm[c] * sc; e.save[2 * e.C + c] = e.rm[c]; e.save[3 * e.C + c] = invstd;
+}
+__global__ void build_wd_eval_kernel(const float* __restrict__ W, int Cout, int C, float* __restrict__ Wd, EvalPrep a, EvalPrep b) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < a.C) eval_prep_one(a, t);
+    if (t < b.C) eval_prep_one(b, t);
+    if (t >= Cout * C) return;
+    int o = t / C, c = t % C;
+    float wa = W[(size_t)o * 2 * C + c], wb = W[(size_t)o * 2 * C + C + c];
+    Wd[(size_t)o * C + c] = wa;
+    Wd[(size_t)(Cout + o) * C + c] = wb - wa;
+}
 // dW from dWd:  dWa = dWd_u - dWd_v,  dWb = dWd_v
 __global__ void unbuild_wd_kernel(const float* __restrict__ dWd, int Cout, int C, float* __restrict__ dW) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -679,6 +698,15 @@ int edge_reduce_parts(int P) { return (P + 4 * EDGE_PTS_PER_WAVE - 1) / (4 * EDG
 
 int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd) {
     hipLaunchKernelGGL(build_wd_kernel, dim3((Cout * C + 255) / 256), dim3(256), 0, st, W, Cout, C, Wd);
+    return mlsp_launch_status();
+}
+// Ca / Cb = 0: that stage is absent
+int launch_build_wd_eval(hipStream_t st, const float* W, int Cout, int C, float* Wd, int Ca, const float* ga, const float* ba, const float* rma,
+                         const float* rva, float* sva, int Cb, const float* gb, const float* bb, const float* rmb, const float* rvb, float* svb,
+                         float eps) {
+    const EvalPrep a = {Ca, ga, ba, rma, rva, eps, sva}, b = {Cb, gb, bb, rmb, rvb, eps, svb};
+    int n = Cout * C; if (Ca > n) n = Ca; if (Cb > n) n = Cb;
+    hipLaunchKernelGGL(build_wd_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, Cout, C, Wd, a, b);
     return mlsp_launch_status();
 }
 int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW) {
