@@ -376,8 +376,8 @@ def secondary_workloads(lib, dev):
         opt.step()
 
     # the same step with the backward SEEDED by fixed output gradients (the gradients the weighted means above produce) instead of
-    # ~40 torch element-wise / reduction launches per step of synthetic loss arithmetic: model forward + backward + Adam only.  At B = 16
-    # this step is bound by the HOST's enqueue time (B = 8 runs as long as B = 16: tools/r5/host_profile_c4.py), so the launches count.
+    # ~25 small torch element-wise / reduction launches per step of synthetic loss arithmetic: model forward + backward + Adam only
+    # (0.1-0.15 ms of device time at this shape; the step is device-bound: tools/r5/enqueue_c4.py).
     wg = {k: w[k] / w[k].numel() for k in w}
 
     def seg_step_seeded():
@@ -397,7 +397,7 @@ def secondary_workloads(lib, dev):
                 "ms_per_step": ms, "blocks_ms_per_step": seg_blocks, "points_per_s": B * N / ms * 1e3, "dtype": "bf16 GEMM operands + bf16 activation storage, fp32 accumulate",
                 "seeded_backward": {"ms_per_step": ms_seeded, "points_per_s": B * N / ms_seeded * 1e3,
                                     "note": "same forward / backward / Adam, the backward seeded with the fixed output gradients of the synthetic loss "
-                                            "(torch.autograd.backward) instead of computing that loss with torch ops: the step is host-enqueue bound at B = 16"},
+                                            "(torch.autograd.backward) instead of computing that loss with ~25 small torch launches"},
                 "roofline": {"kernel": "gemm_bf16_kernel<*> / gemm_f32_kernel<*> (every MFMA GEMM launch)", "bound": "hbm", "achieved": gbs,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "mfma_tflops": tfs,
                              "mfma_frac_of_bf16_dense_peak": tfs / PEAK_BF16_TFLOPS, "share_of_step": g[0] / 2 / ms,
