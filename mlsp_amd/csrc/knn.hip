@@ -1496,7 +1496,15 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     // at the DGCNN shape (E = 20 Ki entries, 1024 threads) -- and then the fill pass below reuses the registers instead of reading idx again
     constexpr int RV_B = 20;
     const bool one_trip = E <= nt * RV_B;
+    // Several trips (PointSegDA: N = 2048, k = 40 -> 80 entries per thread): the entries that fall into this workgroup's slice (E / nsplit of
+    // them on average) are COMPACTED into `lord` as (destination, source entry) pairs while they are counted -- `lord` is free until the
+    // lists are ordered -- and the fill pass walks those pairs instead of scanning the cloud's E indices again.  More than RV_CAP / 2 pairs:
+    // the fill pass scans again as before.
+    __shared__ int ncomp;
+    if (tid == 0) ncomp = 0;
+    const int comp_cap = RV_CAP / 2;
     int jk[RV_B];
+    __syncthreads();
     for (int eb = tid; eb < E; eb += nt * RV_B) {
 #pragma unroll
         for (int u = 0; u < RV_B; ++u) jk[u] = eb + u * nt < E ? ib[eb + u * nt] : -1;
@@ -1506,7 +1514,19 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
             if (skip_pad && j >= 0) { const int e = eb + u * nt, sl = e % k; if (sl != 0 && j == ib[e - sl]) j = -1; }
             jk[u] = j;
             below += j >= 0 && j < d0;
-            if (j >= d0 && j < d1) atomicAdd(&cnt[j - d0], 1);
+            const bool mine = j >= d0 && j < d1;
+            if (mine) atomicAdd(&cnt[j - d0], 1);
+            if (!one_trip) {                             // (uniform) one LDS atomic per wave and entry slot: the wave's matches take consecutive places
+                const unsigned long long mm = __ballot(mine);
+                if (mm) {
+                    const int lane_ = tid & 63;
+                    int base_ = 0;
+                    if (lane_ == 0) base_ = atomicAdd(&ncomp, __builtin_popcountll(mm));
+                    base_ = __shfl(base_, 0, 64);
+                    const int at = base_ + __builtin_popcountll(mm & ((1ull << lane_) - 1ull));
+                    if (mine && at < comp_cap) { lord[2 * at] = j - d0; lord[2 * at + 1] = eb + u * nt; }
+                }
+            }
         }
     }
 #pragma unroll
@@ -1552,6 +1572,14 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     // (a slice with more than RV_CAP entries orders in place in global memory instead)
     const bool in_lds = sn <= RV_CAP;
     int* ent = in_lds ? lent : rev_ent + gbase + s0;
+    const bool compacted = !one_trip && in_lds && ncomp <= comp_cap;       // (ncomp == sn: every pair is there)
+    if (compacted) {
+        for (int i = tid; i < sn; i += nt) {
+            const int jl = lord[2 * i], e = lord[2 * i + 1];
+            const int pos = atomicAdd(&cnt[jl], 1);
+            ent[off[jl] + pos] = ((e / k) << 8) | (e % k);
+        }
+    } else
     for (int eb = tid; eb < E; eb += nt * RV_B) {
         if (!one_trip) {
 #pragma unroll
