@@ -1470,10 +1470,11 @@ int launch_knn(hipStream_t st, const float* x, int ld, int B, int N, int C, int 
 // skip_pad: the padding slots of a ball-query group (copies of its first hit: slot s > 0 with idx[i][s] == idx[i][0]) are left out of the
 // lists -- their rows are identical, the consumer adds them as a multiple of one row (sa.hip, sa_fold_bwd_point_kernel).  The lists of a
 // cloud then no longer fill its E entries, so the list LENGTHS are returned as well (rev_cnt, nullable otherwise).
+typedef int knn_i32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict__ idx, int N, int k,
                                                            int* __restrict__ rev_off, int* __restrict__ rev_ent,
                                                            int B, int S, int nsplit, int skip_pad, int* __restrict__ rev_cnt) {
-    extern __shared__ int ism[];
+    extern __shared__ __attribute__((aligned(16))) int ism[];
     __shared__ int wsum[16];
     __shared__ int nbig;                  // lists of more than 64 entries: queued (cnt is free by then) for the whole-workgroup loop
     int b, part;
@@ -1482,8 +1483,9 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     const int dper = (N + nsplit - 1) / nsplit, d0 = min(N, part * dper), d1 = min(N, d0 + dper), nd = d1 - d0;
     int* cnt = ism;            // [dper]
     int* off = ism + dper;     // [dper + 1]  offsets inside the slice
-    int* lent = off + dper + 1;   // [RV_CAP] as filled
-    int* lord = lent + RV_CAP;    // [RV_CAP] ordered
+    int* offp = off + dper + 1;   // [dper + 1]  the same with every list padded to a multiple of 4 entries: where the lists lie in `lent`
+    int* lent = ism + ((3 * dper + 2 + 3) & ~3);   // [RV_CAP] as filled; 16-byte aligned lists (pads hold INT_MAX): the ordering reads four entries per LDS instruction
+    int* lord = lent + RV_CAP;    // [RV_CAP] ordered (unpadded: the slice's part of rev_ent)
     // S source rows of k slots per cloud point at N destinations (S == N for the kNN graph; the set-abstraction grouping has
     // S sampled centres gathering from N points)
     const int* ib = idx + (size_t)b * S * k;
@@ -1543,41 +1545,46 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
     if (tid < 64) {
         const int chunk = (nd + 63) / 64;
         const int beg = min(nd, tid * chunk), end = min(nd, beg + chunk);
-        int sm = 0;
-        for (int j = beg; j < end; ++j) sm += cnt[j];
-        int incl = sm;
+        int sm = 0, smp = 0;
+        for (int j = beg; j < end; ++j) { sm += cnt[j]; smp += (cnt[j] + 3) & ~3; }
+        int incl = sm, inclp = smp;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (tid >= o) incl += t;
+            const int t = __shfl_up(incl, o, 64), tp = __shfl_up(inclp, o, 64);
+            if (tid >= o) { incl += t; inclp += tp; }
         }
-        int run = incl - sm;
-        for (int j = beg; j < end; ++j) { off[j] = run; run += cnt[j]; }
-        if (tid == 63) off[nd] = incl;
+        int run = incl - sm, runp = inclp - smp;
+        for (int j = beg; j < end; ++j) { off[j] = run; run += cnt[j]; offp[j] = runp; runp += (cnt[j] + 3) & ~3; }
+        if (tid == 63) { off[nd] = incl; offp[nd] = inclp; }
     }
     __syncthreads();
     const int gbase = b * E;
+    const int sn = off[nd];
+    const bool in_lds = offp[nd] <= RV_CAP;
     for (int j = tid; j < nd; j += nt) {
         rev_off[(size_t)b * N + d0 + j] = gbase + s0 + off[j];
         if (rev_cnt) rev_cnt[(size_t)b * N + d0 + j] = off[j + 1] - off[j];
+        if (in_lds) {
+            const int c = off[j + 1] - off[j];
+            for (int q = c; q < ((c + 3) & ~3); ++q) lent[offp[j] + q] = 0x7fffffff;       // pads: never below a real entry
+        }
         cnt[j] = 0;
     }
     if (b == B - 1 && part == nsplit - 1 && tid == 0) rev_off[(size_t)B * N] = gbase + E;
-    const int sn = off[nd];
     __syncthreads();
 #if defined(RV_PROBE) && RV_PROBE == 2
     return;
 #endif
     // fill + order this slice's lists in LDS, then one coalesced copy out: the ordering never touches global memory
     // (a slice with more than RV_CAP entries orders in place in global memory instead)
-    const bool in_lds = sn <= RV_CAP;
     int* ent = in_lds ? lent : rev_ent + gbase + s0;
+    const int* eoff = in_lds ? offp : off;                                 // where list j starts in `ent`
     const bool compacted = !one_trip && in_lds && ncomp <= comp_cap;       // (ncomp == sn: every pair is there)
     if (compacted) {
         for (int i = tid; i < sn; i += nt) {
             const int jl = lord[2 * i], e = lord[2 * i + 1];
             const int pos = atomicAdd(&cnt[jl], 1);
-            ent[off[jl] + pos] = ((e / k) << 8) | (e % k);
+            ent[eoff[jl] + pos] = ((e / k) << 8) | (e % k);
         }
     } else
     for (int eb = tid; eb < E; eb += nt * RV_B) {
@@ -1592,12 +1599,13 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
             if (!one_trip && skip_pad && j >= 0) { const int sl = e % k; if (sl != 0 && j == ib[e - sl]) j = -1; }
             if (j >= d0 && j < d1) {
                 const int pos = atomicAdd(&cnt[j - d0], 1);
-                ent[off[j - d0] + pos] = ((e / k) << 8) | (e % k);
+                ent[eoff[j - d0] + pos] = ((e / k) << 8) | (e % k);
             }
         }
     }
     __syncthreads();
 #if defined(RV_PROBE) && RV_PROBE == 3
+    if (ent[tid] == -12345) rev_off[0] = 1;            // (keeps the fill pass alive in the probe build)
     return;
 #endif
     if (in_lds) {
@@ -1613,23 +1621,44 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
                 if (ll == 0) cnt[atomicAdd(&nbig, 1)] = j;
                 continue;
             }
-            const int* a = ent + e0;
+            const int* a = ent + offp[j];                  // 16-byte aligned, padded with INT_MAX to a multiple of 4
             for (int q = ll; q < n; q += 16) {
                 const int v = a[q];
-                int rank = 0, e = 0;
-                for (; e + 4 <= n; e += 4) {
-                    const int a0 = a[e], a1 = a[e + 1], a2 = a[e + 2], a3 = a[e + 3];
-                    rank += (a0 < v) + (a1 < v) + (a2 < v) + (a3 < v);
+                int rank = 0;
+                for (int e = 0; e < n; e += 4) {
+                    const knn_i32x4 t = *(const knn_i32x4*)(a + e);
+                    rank += (t[0] < v) + (t[1] < v) + (t[2] < v) + (t[3] < v);
                 }
-                for (; e < n; ++e) rank += a[e] < v;
                 out[e0 + rank] = v;
             }
         }
         __syncthreads();
+        // lists of 65 .. 512 entries (the tail of a kNN graph's in-degree distribution: a dozen per workgroup at k = 40, a few at k = 20):
+        // ONE WAVE per list, sixteen lists at a time -- the whole workgroup walking them one after the other was the longest phase of the
+        // kernel (8 of 21 us at k = 20, 29 of 61 us at k = 40, N = 2048).  Longer ones (ball-query hubs): the whole workgroup per list.
+        {
+            const int wv = tid >> 6, ln = tid & 63;
+            for (int bi = wv; bi < nbig; bi += nt >> 6) {
+                const int j = cnt[bi];
+                const int e0 = off[j], n = off[j + 1] - e0;
+                if (n > 512) continue;
+                const int* a = ent + offp[j];
+                for (int q = ln; q < n; q += 64) {
+                    const int v = a[q];
+                    int rank = 0;
+                    for (int e = 0; e < n; e += 4) {
+                        const knn_i32x4 t = *(const knn_i32x4*)(a + e);
+                        rank += (t[0] < v) + (t[1] < v) + (t[2] < v) + (t[3] < v);
+                    }
+                    out[e0 + rank] = v;
+                }
+            }
+        }
         for (int bi = 0; bi < nbig; ++bi) {
             const int j = cnt[bi];
             const int e0 = off[j], n = off[j + 1] - e0;
-            const int* a = ent + e0;
+            if (n <= 512) continue;
+            const int* a = ent + offp[j];
             for (int q = tid; q < n; q += nt) {
                 const int v = a[q];
                 int rank = 0;
@@ -1638,6 +1667,10 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int* __restrict
             }
         }
         __syncthreads();
+#if defined(RV_PROBE) && RV_PROBE == 4
+        if (lord[tid] == -12345) rev_off[0] = 1;
+        return;
+#endif
         for (int i = tid; i < sn; i += nt) rev_ent[gbase + s0 + i] = lord[i];      // one coalesced copy out
         return;
     }
@@ -1660,7 +1693,7 @@ static int launch_reverse(hipStream_t st, const int* idx, int B, int S, int N, i
     if (!idx || !rev_off || !rev_ent || B <= 0 || N <= 0 || S <= 0 || k <= 0 || k > 256 || N > (1 << 22) || S > (1 << 22)) return MLSP_ERR_ARG;
     const int nsplit = B * 8 >= 256 || N < 1024 ? 8 : RV_SPLIT_MAX;
     const int dper = (N + nsplit - 1) / nsplit;
-    const size_t lds = (size_t)(2 * dper + 1 + 2 * RV_CAP) * sizeof(int);
+    const size_t lds = (size_t)(((3 * dper + 2 + 3) & ~3) + 2 * RV_CAP) * sizeof(int);
     if (lds > 160 * 1024) return MLSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = mlsp_lds_limit((const void*)knn_reverse_kernel, lds);
