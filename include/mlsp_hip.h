@@ -45,7 +45,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 
-#define MLSP_ABI_VERSION 12
+#define MLSP_ABI_VERSION 13
 #define MLSP_OK 0
 #define MLSP_ERR_ARG (-1)
 #define MLSP_ERR_WORKSPACE (-2)
@@ -154,8 +154,12 @@ int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const mlsp_defer_t* 
  * d' and d' * yhat per 128-row panel: the producer's streaming reduction pass (a full read of dZ and Y) disappears.
  *   consumer: in_stats != NULL ([M / 128][2][in->ld] doubles, indexed by the producer's column) -- legal when
  *             mlsp_*_bwd_stats_parts() > 0 for the layer; dX then holds d', not dZ;
- *   producer: pre_stats != NULL ([pre_parts][2][Cout]) -- dZ is d', its sums are given: finalisation + the BatchNorm part only.
- * All consumers of a producer must do it or none (they all write columns of the same dX and the same partial rows).
+ *   producer: pre_stats != NULL ([pre_parts][2][Cout]) -- dZ is d', its sums are given: finalisation + the BatchNorm part only;
+ *             pre_stats == NULL with pre_parts < 0 (ABI v13) -- dZ is d' but its sums are INCOMPLETE: only some consumers took part in this
+ *             backward pass (a loss on a subset of the heads, PointDA/trainer.py:551-565), the columns of the others are zero.  The
+ *             call reduces the sums itself and does not apply the activation derivative / dropout mask a second time.
+ * All consumers of a producer must be ABLE to do it or none does (they write columns of the same dX and of the same partial rows); the
+ * ones that run in a given backward pass then all do it.
  * A producer in that role (training mode) does not form its output gradient dY either when its dgrad and weight-gradient launches run on
  * gemm_split_kernel: they read d' and Y and apply dY = (d' + y * nk2[c] + c0[c]) * sc[c] in their operand loads (coefficients from the
  * finalised sums), so the streaming "apply" pass and the dY tensor are gone; the per-cloud bias gradient (gbias) then comes from the panel

@@ -687,9 +687,12 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     // in_stats (consumer role, needs `in`): dX is stored MASKED by the producer's activation derivative / dropout and the producer's
     // BatchNorm-backward column sums are left in in_stats [M / 128][2][in->ld] at column in->col (mlsp_pointmlp_bwd_stats_parts() > 0).
     // pre_stats (producer role): dZ arrives masked, its sums are in pre_stats [pre_parts][2][Cout]: no reduction pass.
+    // pre_stats == NULL with pre_parts < 0: dZ arrives masked WITHOUT complete sums (only some consumers took part in this backward pass,
+    // the other columns are zero): the reduction runs here and the mask is not applied a second time.
     if (!dZ || !X || !W || !dW || M <= 0 || Cin <= 0 || Cout <= 0 || ldx < Cin || ldw < Cin) return MLSP_ERR_ARG;
     if (in_stats && (!in || !dX || dx_accumulate)) return MLSP_ERR_ARG;
     if (pre_stats && (!has_bn || pre_parts <= 0 || M <= 32)) return MLSP_ERR_ARG;
+    if (!pre_stats && pre_parts < 0 && (!has_bn || M <= 32)) return MLSP_ERR_ARG;
     if (has_bn && (!Y || !bn_save || !dgamma || !dbeta)) return MLSP_ERR_ARG;
     if (dgbias && (n_groups <= 0 || rows_per_group <= 0 || (long)n_groups * rows_per_group != M)) return MLSP_ERR_ARG;
     Workspace w(ws, ws_bytes);

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_vec_kernel(const TY* __
                                                                     const float* __restrict__ mean,
                                                                     const float* __restrict__ invstd, int act, float slope,
                                                                     uint32_t thresh, float inv_keep, uint64_t seed,
-                                                                    double* __restrict__ part) {
+                                                                    double* __restrict__ part, int premasked) {
+    // premasked: dZ already carries the activation derivative and the dropout mask (see bn_act_bwd_apply_vec_kernel)
     __shared__ double shd[256 * 8];
     const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
     const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
@@ -280,10 +281,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_vec_kernel(const TY* __
             for (int u = 0; u < 4; ++u) {
                 if (rb + u * nrg >= r1) break;
                 const size_t i = (size_t)(rb + u * nrg) * C + c;
-                const uint32_t hq = thresh ? dropout_hash4(seed, i >> 2) : 0u;
+                const uint32_t hq = (thresh && !premasked) ? dropout_hash4(seed, i >> 2) : 0u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float d = dz_prime_q(dz[u][e], y[u][e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
+                    float d = premasked ? dz[u][e] : dz_prime_q(dz[u][e], y[u][e], sc[e], sh[e], act, slope, thresh, inv_keep, hq, e);
                     s[e] += d; q[e] += (double)d * ((y[u][e] - mu[e]) * is[e]);
                 }
             }
@@ -581,12 +582,19 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
     uint32_t th = drop_thresh(p_drop);
     int nparts = bn_stat_parts(M);
     const bool vec = vec_ok(C, dZ, Y, dY) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0);
+    // pre_parts < 0 without pre_stats: dZ arrives MASKED (some consumers' dgrads applied the activation derivative / dropout mask, the
+    // columns of the others are zero) but the sums are incomplete: reduce here, without applying the mask a second time
+    const int premasked = pre_parts < 0 ? 1 : 0;
+    if (premasked) {
+        if (!vec) return MLSP_ERR_UNSUPPORTED;
+        th = 0u; inv_keep = 1.f;
+    }
     const bool fuse_g = vec && gpart && gpart_slabs && rows_per_group > 0 && rows_per_group % VROWS == 0 && rows_per_group / VROWS <= 16 &&
                         M % rows_per_group == 0;
     if (vec) {
         nparts = bn_vec_parts(M);
         hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<float>), dim3(nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift, mean, invstd,
-                           act, slope, th, inv_keep, seed, part);
+                           act, slope, th, inv_keep, seed, part, premasked);
     } else {
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, st, dZ, Y, M, C, scale, shift,
                            mean, invstd, act, slope, th, inv_keep, seed, part);
@@ -597,7 +605,7 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
     if (vec) {
         hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, dY, M, C,
                            scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th,
-                           inv_keep, seed, fuse_g ? gpart : (float*)nullptr, 0);
+                           inv_keep, seed, fuse_g ? gpart : (float*)nullptr, premasked);
         if (fuse_g) *gpart_slabs = rows_per_group / VROWS;
         return mlsp_launch_status();
     }
@@ -809,7 +817,7 @@ int launch_bn_act_bwd_partials_vec(hipStream_t st, const float* dZ, const float*
     if (!(vec_ok(C, dZ, Y) && 256 % (C / 4) == 0 && ((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)))
         return MLSP_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<float>), dim3(bn_vec_parts(M)), dim3(256), 0, st, dZ, Y, M, C, scale, shift, mean, invstd, act,
-                       slope, 0u, 1.f, (uint64_t)0, part);
+                       slope, 0u, 1.f, (uint64_t)0, part, 0);
     return mlsp_launch_status();
 }
 
@@ -960,7 +968,7 @@ int launch_bn_act_bwd_b16(hipStream_t st, const void* dZ, const void* Y, void* d
     const uint32_t th = drop_thresh(p_drop);
     const int nparts = bn_vec_parts(M);
     hipLaunchKernelGGL((bn_act_bwd_reduce_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, M, C, scale,
-                       shift, mean, invstd, act, slope, th, inv_keep, seed, part);
+                       shift, mean, invstd, act, slope, th, inv_keep, seed, part, 0);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, (double)M, C, dgamma, dbeta, mean_dz, mean_dzy, bn_zero_vec_consume());
     hipLaunchKernelGGL((bn_act_bwd_apply_vec_kernel<__bf16>), dim3(nparts), dim3(256), 0, st, (const __bf16*)dZ, (const __bf16*)Y, (__bf16*)dY,
                        M, C, scale, shift, mean, invstd, training ? mean_dz : (const float*)nullptr, mean_dzy, act, slope, th, inv_keep, seed, (float*)nullptr, 0);

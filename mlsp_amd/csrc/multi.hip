@@ -95,7 +95,9 @@ __device__ __forceinline__ float multi_dz_prime(float dz, float y, float sc, flo
 
 __global__ __launch_bounds__(256) void multi_bwd_reduce_kernel(const float* __restrict__ dZ, const float* __restrict__ Y, int M, int C,
                                                                const float* __restrict__ bn, const float* __restrict__ chan,
-                                                               uint32_t thresh, float inv_keep, uint64_t seed, double* __restrict__ part) {
+                                                               uint32_t thresh, float inv_keep, uint64_t seed, double* __restrict__ part,
+                                                               int premasked) {
+    // premasked: as in multi_bwd_apply_kernel (dZ already carries the activation derivative and the dropout mask)
     __shared__ double shd[256 * 8];
     const int tid = threadIdx.x, tpr = C >> 2, nrg = 256 / tpr;
     const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void multi_bwd_reduce_kernel(const float* __re
         const f32x4 sc = *(const f32x4*)(bn + c), sh = *(const f32x4*)(bn + C + c);
         const f32x4 mu = *(const f32x4*)(bn + 2 * C + c), is = *(const f32x4*)(bn + 3 * C + c);
         const f32x4 sl = *(const f32x4*)(chan + c), dr = *(const f32x4*)(chan + C + c);
-        const bool anyd = thresh && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f);
+        const bool anyd = !premasked && thresh && (dr[0] != 0.f || dr[1] != 0.f || dr[2] != 0.f || dr[3] != 0.f);
         const int r0 = blockIdx.x * MROWS, r1 = min(M, r0 + MROWS);
         for (int rb = r0 + rg; rb < r1; rb += 4 * nrg) {      // four rows in flight per thread; summed in row order
             f32x4 y[4], dz[4];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void multi_bwd_reduce_kernel(const float* __re
                 const uint32_t hq = anyd ? dropout_hash4(seed, i >> 2) : 0u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d = multi_dz_prime(dz[u][e], y[u][e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
+                    const float d = premasked ? dz[u][e] : multi_dz_prime(dz[u][e], y[u][e], sc[e], sh[e], sl[e], dr[e], thresh, inv_keep, hq, e);
                     s[e] += d; q[e] += (double)d * ((y[u][e] - mu[e]) * is[e]);
                 }
             }
@@ -407,12 +409,15 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
     // in_stats (consumer role, needs `in`): every segment's input gradient is stored MASKED by its producer's activation derivative /
     // dropout and the producer's BatchNorm-backward column sums are left in in_stats [M / 128][2][in->ld] (gemm.hip gemm_out_bs).
     // pre_stats (producer role): dZ arrives masked with its sums in pre_stats [pre_parts][2][Ctot]: no reduction pass here.
+    // pre_stats == NULL with pre_parts < 0: dZ arrives masked but WITHOUT complete sums (only some of the consumers took part in this
+    // backward pass; the other columns are zero): this call reduces them itself and does not apply the mask a second time.
     PREC_SCOPE(precision);
     int Ctot, xw;
     MCHECK(multi_check(X, ldx, M, segs, nseg, Ctot, xw));
     if (!dZ || !Y || !bn_save || !chan || !dW || !dgamma || !dbeta || (dX && lddx < xw)) return MLSP_ERR_ARG;
     if (in_stats && (!in || !dX)) return MLSP_ERR_ARG;
     if (pre_stats && pre_parts <= 0) return MLSP_ERR_ARG;
+    const int premasked = (pre_stats || pre_parts < 0) ? 1 : 0;
     if (!mlsp_multimlp_supported(M, segs, nseg, precision)) return MLSP_ERR_UNSUPPORTED;
     if ((((uintptr_t)Y | (uintptr_t)dZ | (uintptr_t)chan | (uintptr_t)bn_save) & 15) != 0) return MLSP_ERR_UNSUPPORTED;
     if (in) for (int s = 0; s < nseg; ++s) if (!multi_defer_ok(in[s], segs[s])) return MLSP_ERR_ARG;
@@ -464,13 +469,13 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
     } else if (pre_stats) {
         MCHECK(launch_bn_bwd_finalize_z(st, pre_stats, pre_parts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy, zb));
     } else {
-        hipLaunchKernelGGL(multi_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, Ctot, bn_save, chan, th, ik, seed, part);
+        hipLaunchKernelGGL(multi_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, st, dZ, Y, M, Ctot, bn_save, chan, th, ik, seed, part, premasked);
         MCHECK(launch_bn_bwd_finalize_z(st, part, nparts, (double)M, Ctot, dgamma, dbeta, mean_dz, mean_dzy, zb));
     }
     const int rpb = multi_rows_per_block(M, Ctot);
     if (!use_dy) {
         hipLaunchKernelGGL(multi_bwd_apply_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, st, dZ, Y, dY, M, Ctot, rpb, bn_save, chan,
-                           training ? mean_dz : (const float*)nullptr, mean_dzy, th, ik, seed, pre_stats ? 1 : 0);
+                           training ? mean_dz : (const float*)nullptr, mean_dzy, th, ik, seed, premasked);
         MCHECK(mlsp_launch_status());
     }
     const float* gY = use_dy ? dZ : dY;                           // the GEMMs' A operand: d' (+ y, coefficients) or the formed dY

@@ -625,7 +625,7 @@ class _MultiMLP(Function):
         dbeta = torch.empty((Ctot,), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
         pre = ctx.out_stats.take() if ctx.out_stats is not None else None
-        pre_ptr, pre_n = (pre[0].data_ptr(), pre[1]) if pre is not None else (None, 0)
+        pre_ptr, pre_n = (pre[0].data_ptr() if pre[0] is not None else None, pre[1]) if pre is not None else (None, 0)
         ins = None
         if ctx.in_stats is not None and dX is not None and ctx.in_stats.agreed():
             ins = ctx.in_stats.buffer(dev)
@@ -859,7 +859,7 @@ class BwdStats:
     derivative and dropout mask in that launch and leave the producer's per-panel column sums here, so the producer needs no reduction
     pass.  All or nothing: every consumer `promise`s its column range at forward time (with the number of 128-row panels its dgrad
     would write, 0 = it cannot); only if the promises tile [0, ld) exactly with one common panel count do the consumers do it
-    (`agreed`), and the producer uses the sums only if every range was `deliver`ed in the same backward pass."""
+    (`agreed`), and the producer uses the sums only if every range was `deliver`ed in the same backward pass (`take`)."""
     __slots__ = ("ld", "promised", "part", "task", "delivered", "_ok")
 
     def __init__(self, ld):
@@ -887,11 +887,16 @@ class BwdStats:
         return self.part
 
     def take(self):
-        """producer side: (partial rows, panel count) when every consumer delivered in THIS backward pass, else None"""
-        if self.part is None or self.task != torch._C._current_graph_task_id() or self.delivered != len(self.promised) or not self.agreed():
+        """producer side, three outcomes: (partial rows, panel count) when EVERY consumer delivered in this backward pass; None when none
+        did (the incoming gradient is unmasked: the producer masks and reduces); (None, -1) when only SOME did -- a loss on a subset of
+        the heads (PointDA/trainer.py:551-565): the delivered columns of the incoming gradient already carry the activation derivative
+        and the dropout mask, the others are zero, the sums are incomplete -> the producer reduces without masking a second time."""
+        if self.part is None or self.task != torch._C._current_graph_task_id() or not self.agreed():
             self.part = self.task = None
             return None
         part, self.part, self.task = self.part, None, None
+        if self.delivered != len(self.promised):
+            return None, -1
         return part, part.shape[0]
 
 
@@ -1086,7 +1091,7 @@ class _PointMLP(Function):
         dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev) if has_bn else None
         ws, wsn = _lib.workspace(dev, M, Cin, Cout)
         pre = ctx.out_stats.take() if ctx.out_stats is not None else None          # our own sums, left by the consumers' dgrads
-        pre_ptr, pre_n = (pre[0].data_ptr(), pre[1]) if pre is not None else (None, 0)
+        pre_ptr, pre_n = (pre[0].data_ptr() if pre[0] is not None else None, pre[1]) if pre is not None else (None, 0)
         ins = None
         if ctx.in_stats is not None and dX is not None and ctx.in_stats.agreed():
             ins = ctx.in_stats.buffer(dev)                                          # the producer's sums: this call's dgrad writes our columns

@@ -356,7 +356,7 @@ class DGCNN_DefRec(nn.Module):
         logits = {}
         x = x.float()
         xp0 = x.transpose(2, 1).contiguous().view(B * N, C)
-        g0 = Fh.knn_graph(xp0, B, N, self.k, need_reverse=xp0.requires_grad)    # (the T-Net of a cloud without a gradient needs no reverse index)
+        g0 = Fh.knn_graph(xp0, B, N, self.k, need_reverse=xp0.requires_grad or C > 4)   # (the T-Net of a 3-channel cloud without a gradient needs no reverse index; wider inputs take the fold path, which does)
         T = self.input_transform_net.points(xp0, g0, B, N, self.k)                 # [B,3,3]
         xp = Fh.apply_transform(xp0, T) if C == 3 else torch.bmm(xp0.view(B, N, C), T.transpose(1, 2)).view(B * N, C)   # (T @ x)^T
         # every head reads x123 and x5: the calls below are the reference's (Models.py:226-241, DefRec computed twice when both of its flags

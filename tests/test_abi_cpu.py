@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
         import ctypes
         for kind, ct in zip(kinds, _lib.SIGNATURES[name]):
             assert (ct is ctypes.c_void_p) == (kind == "p"), (name, args)
-    assert lib.mlsp_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.mlsp_abi_version() == _lib.ABI_VERSION == 13
     assert b"workspace" in lib.mlsp_strerror(-2)
     assert lib.mlsp_workspace_bytes(32768, 512, 1024) > 32768 * 1024 * 4
 

@@ -1062,6 +1062,60 @@ def test_merged_layers_deferred_activation_chain(dev, M, training, mode, fused_s
             assert rel < (1e-5 if i < 3 or i >= len(a) - 6 else 5e-3), (i, tuple(x.shape), rel)
 
 
+@pytest.mark.parametrize("subset", [(0,), (2,), (0, 2), (0, 1)])
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+def test_deferred_chain_loss_on_a_subset_of_the_consumers(dev, subset, mode, monkeypatch):
+    """The reference trainer runs all three heads (activate_density_normal_ondef=True) and gates the Normal / density losses on
+    args.Normal_ondef / args.Density_ondef (PointDA/trainer.py:551-565): the backward then reaches only SOME of the final Linear layers.
+    The consumers that do run store their input gradient masked by the producer's activation derivative and dropout (fused
+    BatchNorm-backward statistics, BwdStats); the producer must neither apply the mask a second time (dropout columns would carry
+    1 / (1 - p)^2, LeakyReLU slopes squared) nor use the incomplete sums: it takes the masked-without-sums path (pre_parts = -1,
+    include/mlsp_hip.h).  Against the materialised, unfused chain (the bit-identical path of the two tests above)."""
+    Fh = _fh()
+    import itertools as it
+    M, C0, training = 4096, 512, True
+    torch.manual_seed(4321)
+
+    def run(defer, fused):
+        monkeypatch.setattr(Fh, "_FUSE_BWD_STATS", fused)
+        monkeypatch.setattr(Fh, "_DEFER_CHAINS", defer)
+        monkeypatch.setattr(Fh, "_seed_counter", it.count(99), raising=False)
+        g = torch.Generator().manual_seed(6)
+        def r(*shape, s=1.0):
+            return ((torch.rand(shape, generator=g) * 2 - 1) * s).to(dev).requires_grad_(True)
+        X = r(M, C0)
+        W1, g1, b1 = r(1024, C0, s=0.1), r(1024), r(1024)
+        d0 = [(r(256, 256, s=0.1), None), (r(256, 256, s=0.1), None), (r(256, 512, s=0.1), r(256))]
+        d1 = [(r(128, 256, s=0.1), None), (r(128, 256, s=0.1), None), (r(256, 256, s=0.1), r(256))]
+        gb0, gb1 = (r(768), r(768)), (r(512), r(512))
+        fin = [(r(3, 128, s=0.2), None), (r(3, 128, s=0.2), None), (r(16, 256, s=0.2), r(16))]
+        stats = [torch.zeros(1024, device=dev), torch.ones(1024, device=dev), torch.zeros(768, device=dev), torch.ones(768, device=dev),
+                 torch.zeros(512, device=dev), torch.ones(512, device=dev)]
+        h = Fh.pointmlp(X, W1, gamma=g1, beta=b1, run_mean=stats[0], run_var=stats[1], training=training, act=Fh.ACT_RELU, p_drop=0.5, chain=True)
+        spec0 = ((256, 0.0, True), (256, 0.0, True), (256, 0.2, True))
+        spec1 = ((128, 0.2, True), (128, 0.0, True), (256, 0.2, True))      # (dropout + LeakyReLU in front of the final layers: the double mask would show)
+        h = Fh.multimlp(h, [(0, d0[0][0], d0[0][1]), (256, d0[1][0], d0[1][1]), (512, d0[2][0], d0[2][1])], gb0[0], gb0[1], stats[2], stats[3],
+                        Fh.channel_params(dev, spec0), training=training, p_drop=0.5, chain=True, spec=spec0)
+        h = Fh.multimlp(h, [(0, d1[0][0], d1[0][1]), (256, d1[1][0], d1[1][1]), (512, d1[2][0], d1[2][1])], gb1[0], gb1[1], stats[4], stats[5],
+                        Fh.channel_params(dev, spec1), training=training, p_drop=0.5, chain=True, spec=spec1)
+        assert isinstance(h, Fh.DeferredAct) == bool(defer)
+        slices, cols = Fh.split_columns_shared(h, [128, 128, 256])
+        outs, col = [], 0
+        for sl, (W, b) in zip(slices, fin):
+            outs.append(Fh.pointmlp(sl, W, bias=b, training=training, grad_cols=(cols, col)))
+            col += sl.shape[1]
+        loss = sum((outs[i] * _rand(tuple(outs[i].shape), 40 + i).to(dev)).sum() for i in subset)
+        loss.backward()
+        leaves = [X, W1, g1, b1] + [t for pair in d0 + d1 for t in pair if t is not None] + list(gb0) + list(gb1)
+        return [t.grad.cpu() for t in leaves]
+
+    with Fh.gemm_precision(mode):
+        a, b = run(True, True), run(False, False)
+    for i, (x, y) in enumerate(zip(a, b)):
+        rel = ((x - y).double().norm() / (y.double().norm() + 1e-30)).item()
+        assert rel < (1e-4 if mode == "bf16x6" else 5e-3), (i, tuple(x.shape), rel)
+
+
 # ----------------------------------------------------------------------------- conv + BN + act + max over N (Gram backward)
 @pytest.mark.parametrize("B,N,Cin,Cout,training", [(4, 100, 64, 96, True), (3, 128, 128, 256, True), (2, 64, 512, 1024, True),
                                                    (3, 50, 40, 70, False)])

@@ -343,8 +343,10 @@ def test_gemm_product_modes_agree_on_bench_step(dev, monkeypatch):
 # 3-D coordinates: 363 rows at the transformed-cloud stage) and the HIP path does so exactly as often as the reference's operators do.
 # Bars: at the FIRST stage where the HIP graph differs, at most max(FREE_RUN_MIN_ROWS, FREE_RUN_FLIP_FACTOR x the yardstick's count)
 # rows (independent events); downstream (inherited flips) at most max(FACTOR x yardstick, FREE_RUN_CASCADE_CAP of the rows); outputs:
-# 1e-3 element-wise when nothing flipped, else rel-L2 from the truth <= max(1e-3, FACTOR x the yardstick's, sqrt(flipped fraction)).
+# 1e-3 element-wise when nothing flipped, else rel-L2 from the truth <= max(1e-3, FREE_RUN_DIST_FACTOR x the yardstick's): the flip
+# counts equal the yardstick's, so must the distance (the measured B = 32 pairs are in DESIGN.md section 12).
 FREE_RUN_FLIP_FACTOR = 3
+FREE_RUN_DIST_FACTOR = 1.5
 FREE_RUN_MIN_ROWS = 2
 FREE_RUN_CASCADE_CAP = 0.03
 
@@ -412,7 +414,7 @@ def test_dgcnn_free_running_vs_oracle(dev, seed, B, N):
         if sum(hip_f) == 0:
             np.testing.assert_allclose(got[key].cpu().numpy(), t.float().numpy(), rtol=1e-3, atol=1e-3, err_msg=key)
         else:
-            assert rel_h <= max(1e-3, FREE_RUN_FLIP_FACTOR * rel_y, worst ** 0.5), (key, rel_h, rel_y, worst)
+            assert rel_h <= max(1e-3, FREE_RUN_DIST_FACTOR * rel_y), (key, rel_h, rel_y, worst)
 
 
 def test_module_api_surface(dev):
@@ -455,6 +457,52 @@ def test_module_api_surface(dev):
     assert m.DefRec(head_in).shape == (2, 64, 3)
     pv, dn = m.Density_cls(head_in)
     assert pv.shape == (128, 16) and dn.shape == (128,)
+
+
+@pytest.mark.parametrize("heads", [("DefRec",), ("DefRec", "density"), ("DefRec", "Normal"), ("Normal", "density")])
+def test_loss_on_a_subset_of_the_heads_fused_vs_unfused(dev, heads, monkeypatch):
+    """The reference trainer's default step: all three heads run (activate_density_normal_ondef=True), the Normal / density losses are
+    gated by args.Normal_ondef / args.Density_ondef (PointDA/trainer.py:551-565) -- the backward reaches a SUBSET of the heads.  With
+    deferred activations + fused BatchNorm-backward statistics (the defaults) the consumers that run store masked gradients; the
+    producers must not mask them again (functional.BwdStats.take, the pre_parts = -1 path of include/mlsp_hip.h).  Dropout 0.5, same
+    dropout streams: every gradient against the materialised, unfused path."""
+    import itertools as it
+    from mlsp_amd import functional as Fh, mlsp
+    args = gc.make_args(cuda=True)
+    inp = {k: v.to(dev) for k, v in gc.make_inputs(7, 4, 256).items()}
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(Fh, "_FUSE_BWD_STATS", fused)
+        monkeypatch.setattr(Fh, "_DEFER_CHAINS", fused)
+        monkeypatch.setattr(Fh, "_seed_counter", it.count(777), raising=False)
+        torch.manual_seed(11)
+        m = _model(7, dev, dropout=0.5).train()
+        torch.manual_seed(11)               # (the dropout streams are keyed by torch.initial_seed())
+        logits = m(inp["x"], activate_density_normal_ondef=True)     # (the encoder runs the same kernels in both passes: same graphs)
+        loss = 0.0
+        mask_cord = inp["mask"].permute(0, 2, 1)[:, :, 0] * 26 + 1
+        if "DefRec" in heads:
+            loss = loss + mlsp.calc_loss(args, logits, inp["gold"], inp["mask"])
+        if "Normal" in heads:
+            loss = loss + mlsp.calc_masked_normal_loss(args, logits["Normal"], inp["normal_gt"], mask_cord)
+        if "density" in heads:
+            kl, mae = mlsp.densityloss(args, logits, inp["dens_val"], inp["dens_vec"], mask=mask_cord.reshape(-1))
+            loss = loss + kl + mae
+        loss.backward()
+        res[fused] = ({k: v.detach().clone() for k, v in logits.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    (la, ga), (lb, gb_) = res[True], res[False]
+    for k in la:
+        np.testing.assert_allclose(la[k].cpu().numpy(), lb[k].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+    assert set(ga) == set(gb_)
+    worst = {}
+    for k in ga:
+        rel = ((ga[k] - gb_[k]).double().norm() / (gb_[k].double().norm() + 1e-30)).item()
+        worst[k.split(".")[0]] = max(worst.get(k.split(".")[0], 0.0), rel)
+        # heads: the same masked gradients, column sums in another order; upstream of x_cat the gradients are ill-conditioned (DESIGN.md
+        # section 2) -- a doubled mask (the defect this test pins) shows as O(1) on the head layers themselves
+        direct = k.split(".")[0] in ("DefRec", "Norm_pred", "Density_cls")
+        assert rel < (2e-4 if direct else 5e-2), (k, rel, heads)
+    print("subset %s: worst rel-L2 per module %s" % (heads, {k: "%.1e" % v for k, v in worst.items()}))
 
 
 def test_merged_head_first_layers_equal_separate(dev):
