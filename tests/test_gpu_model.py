@@ -343,8 +343,9 @@ def test_gemm_product_modes_agree_on_bench_step(dev, monkeypatch):
 # 3-D coordinates: 363 rows at the transformed-cloud stage) and the HIP path does so exactly as often as the reference's operators do.
 # Bars: at the FIRST stage where the HIP graph differs, at most max(FREE_RUN_MIN_ROWS, FREE_RUN_FLIP_FACTOR x the yardstick's count)
 # rows (independent events); downstream (inherited flips) at most max(FACTOR x yardstick, FREE_RUN_CASCADE_CAP of the rows); outputs:
-# 1e-3 element-wise when nothing flipped, else rel-L2 from the truth <= max(1e-3, FREE_RUN_DIST_FACTOR x the yardstick's): the flip
-# counts equal the yardstick's, so must the distance (the measured B = 32 pairs are in DESIGN.md section 12).
+# 1e-3 element-wise when nothing flipped, else rel-L2 from the truth <= max(1e-3, FREE_RUN_DIST_FACTOR x the yardstick's + sqrt(the
+# fraction of rows flipped BEYOND the yardstick's count)): where the flip counts equal the yardstick's, so must the distance (the
+# measured B = 32 pairs are in DESIGN.md section 12).
 FREE_RUN_FLIP_FACTOR = 3
 FREE_RUN_DIST_FACTOR = 1.5
 FREE_RUN_MIN_ROWS = 2
@@ -405,7 +406,7 @@ def test_dgcnn_free_running_vs_oracle(dev, seed, B, N):
     for s, (h, y) in enumerate(zip(hip_f, yard_f)):
         bar = max(FREE_RUN_MIN_ROWS, FREE_RUN_FLIP_FACTOR * y) if s == first else max(FREE_RUN_FLIP_FACTOR * y, FREE_RUN_CASCADE_CAP * B * N)
         assert h <= bar, (s, hip_f, yard_f)
-    worst = max(hip_f) / float(B * N)
+    excess = max(max(0, h - y) for h, y in zip(hip_f, yard_f)) / float(B * N)
     for key in HEAD_KEYS:
         t = truth[key].double()
         rel_h = ((got[key].cpu().double() - t).norm() / t.norm()).item()
@@ -414,7 +415,9 @@ def test_dgcnn_free_running_vs_oracle(dev, seed, B, N):
         if sum(hip_f) == 0:
             np.testing.assert_allclose(got[key].cpu().numpy(), t.float().numpy(), rtol=1e-3, atol=1e-3, err_msg=key)
         else:
-            assert rel_h <= max(1e-3, FREE_RUN_DIST_FACTOR * rel_y), (key, rel_h, rel_y, worst)
+            # rows the HIP path flipped BEYOND the yardstick's count (independent events inside the allowance above, and their cascade)
+            # each move their output row by O(1): sqrt(excess fraction) on top of the yardstick's own distance
+            assert rel_h <= max(1e-3, FREE_RUN_DIST_FACTOR * rel_y + excess ** 0.5), (key, rel_h, rel_y, excess)
 
 
 def test_module_api_surface(dev):
@@ -469,7 +472,7 @@ def test_loss_on_a_subset_of_the_heads_fused_vs_unfused(dev, heads, monkeypatch)
     import itertools as it
     from mlsp_amd import functional as Fh, mlsp
     args = gc.make_args(cuda=True)
-    inp = {k: v.to(dev) for k, v in gc.make_inputs(7, 4, 256).items()}
+    inp = {k: v.to(dev) for k, v in gc.make_inputs(7, 8, 512).items()}    # (4,096 rows: the GEMM dgrads of the merged layers fuse the sums too)
     res = {}
     for fused in (True, False):
         monkeypatch.setattr(Fh, "_FUSE_BWD_STATS", fused)
