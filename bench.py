@@ -30,39 +30,56 @@ PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6     # fp32-accurate product = six bf16 piece products (gemm_split_kernel)
 
 
-def pmc_gemm_traffic(kernel="gemm_f32_kernel"):
-    """HBM-side bytes per launch of the kernels whose name contains `kernel`, from the newest committed rocprofv3 --pmc summary (profiles/pmc_r<round>/summary*.csv,
-    produced by tools/prof/run_profiles.sh with FETCH_SIZE / WRITE_SIZE in separate passes): launch-weighted mean of
-    2*FETCH_SIZE + WRITE_SIZE (the gfx950 correction of MI355X_MICROARCH.md).  None when no summary is committed."""
-    import csv, glob, re
-    root = os.path.dirname(os.path.abspath(__file__))
-    files = glob.glob(os.path.join(root, "profiles", "pmc_r*", "summary*.csv"))
+PMC_WORKLOAD_FILES = {"configs1": r"summary(_v\d+)?\.csv$", "configs4": r"summary_config4(_v\d+)?\.csv$"}
+
+
+def pmc_summary_file(workload="configs1", root=None):
+    """The committed rocprofv3 --pmc summary OF THIS WORKLOAD (profiles/pmc_r<round>/summary[_vN].csv for the headline step,
+    summary_config4[_vN].csv for the configs[4] step): newest round, then newest version.  The file is chosen by workload, never by name
+    order (round 5's line read the configs[4] profile for the headline because `summary_config4.csv` sorts after `summary.csv`)."""
+    import glob, re
+    root = root or os.path.dirname(os.path.abspath(__file__))
+    pat = re.compile(PMC_WORKLOAD_FILES[workload])
+    files = [p for p in glob.glob(os.path.join(root, "profiles", "pmc_r*", "summary*.csv")) if pat.search(os.path.basename(p))]
     if not files:
-        return None, None
+        return None
 
     def order(path):
-        rnd = int(re.search(r"pmc_r(\d+)", path).group(1))
-        ver = re.search(r"summary_v(\d+)", path)
-        return (rnd, int(ver.group(1)) if ver else 0)
-    f = max(files, key=order)
+        ver = re.search(r"_v(\d+)\.csv$", path)
+        return (int(re.search(r"pmc_r(\d+)", path).group(1)), int(ver.group(1)) if ver else 0)
+    return max(files, key=order)
+
+
+def pmc_gemm_traffic(kernel="gemm_split_kernel", workload="configs1", root=None):
+    """(HBM-side bytes per launch of the kernels whose name contains `kernel`, source file, launches counted) from the committed --pmc
+    summary of `workload` (tools/prof/run_profiles.sh: FETCH_SIZE / WRITE_SIZE in separate passes): launch-weighted mean of
+    2*FETCH_SIZE + WRITE_SIZE (the gfx950 correction of MI355X_MICROARCH.md).  (None, None, 0) when no summary of the workload is
+    committed; RuntimeError when the chosen file holds NO row of the priced kernel (a traffic figure of another kernel is worse than none)."""
+    import csv
+    root = root or os.path.dirname(os.path.abspath(__file__))
+    f = pmc_summary_file(workload, root)
+    if f is None:
+        return None, None, 0
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
         if kernel in r["kernel"]:
             l = int(r["launches"])
             tot += l * (2 * float(r["fetch_KB_per_launch_raw"]) + float(r["write_KB_per_launch"])) * 1024
             n += l
-    return (tot / n if n else None), os.path.relpath(f, root)
+    if n == 0:
+        raise RuntimeError("bench.py: %s holds no row of %s -- the committed counter profile does not cover the priced kernel; re-run "
+                           "tools/prof/run_profiles.sh for this workload" % (os.path.relpath(f, root), kernel))
+    return tot / n, os.path.relpath(f, root), n
 
 
-def pmc_split_traffic_by_kind():
+def pmc_split_traffic_by_kind(workload="configs1", root=None):
     """HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE) of gemm_split_kernel by kind -- forward <false, true, ..>, dgrad <false, false, ..>,
-    wgrad <true, false, ..> -- from the newest committed rocprofv3 --pmc summary: ({kind: (bytes per launch, launches)}, source)."""
-    import csv, glob, re
-    root = os.path.dirname(os.path.abspath(__file__))
-    files = glob.glob(os.path.join(root, "profiles", "pmc_r*", "summary*.csv"))
-    if not files:
+    wgrad <true, false, ..> -- from the committed --pmc summary of `workload`: ({kind: (bytes per launch, launches)}, source)."""
+    import csv, re
+    root = root or os.path.dirname(os.path.abspath(__file__))
+    f = pmc_summary_file(workload, root)
+    if f is None:
         return {}, None
-    f = max(files, key=lambda p: (int(re.search(r"pmc_r(\d+)", p).group(1)), p))
     acc = {}
     for r in csv.DictReader(open(f)):
         m = re.search(r"gemm_split_kernel<(false|true)[;,] (false|true)", r["kernel"])
@@ -75,22 +92,38 @@ def pmc_split_traffic_by_kind():
     return {k: (t / n, n) for k, (t, n) in acc.items() if n}, os.path.relpath(f, root)
 
 
-def committed_launch_count():
-    """(kernel launches per step, launches under 8 us per step, source) from the newest committed rocprofv3 kernel statistics of this
-    bench (profiles/r<round>_bench_kernel_stats.csv; steps in the trace = calls of tnet_edge_bwds_kernel, once per step)."""
-    import csv, glob, re
-    root = os.path.dirname(os.path.abspath(__file__))
-    files = [p for p in glob.glob(os.path.join(root, "profiles", "r*_bench_kernel_stats*.csv")) if re.search(r"r(\d+)_bench_kernel_stats", p)]
-    if not files:
-        return None, None, None
-    f = max(files, key=lambda p: (int(re.search(r"r(\d+)_bench_kernel_stats", p).group(1)), p))
-    rows = list(csv.DictReader(open(f)))
-    steps = next((int(r["Calls"]) for r in rows if r["Name"].startswith("tnet_edge_bwds_kernel")), 0)
-    if not steps:
-        return None, None, os.path.relpath(f, root)
-    n = sum(int(r["Calls"]) for r in rows) / steps
-    small = sum(int(r["Calls"]) for r in rows if float(r["AverageNs"]) < 8000.0) / steps
-    return n, small, os.path.relpath(f, root)
+def count_launches(step_fn, nsteps):
+    """Device launches of `nsteps` steps COUNTED IN THIS RUN (an untimed block): torch.profiler's device-side kernel records (roctracer /
+    rocprofiler-sdk underneath: every kernel of the process, the library's and torch's alike, with its duration) -> dict with launches
+    per step, launches under 8 us per step and their device time, memset / memcpy records separately, and the ten most frequent
+    kernels under 8 us.  None when the profiler delivers no device records on this box (the line then says so)."""
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        from torch.autograd import DeviceType
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=False) as prof:
+            for _ in range(nsteps):
+                step_fn()
+            torch.cuda.synchronize()
+        evs = [e for e in prof.events() if e.device_type == DeviceType.CUDA]
+    except Exception as exc:                      # (profiler unavailable: report, do not guess)
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if not evs:
+        return None
+    kern = [e for e in evs if not (e.name.startswith("Memcpy") or e.name.startswith("Memset"))]
+    other = len(evs) - len(kern)
+    dur = [e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total for e in kern]     # microseconds
+    small = [(e.name, d) for e, d in zip(kern, dur) if d < 8.0]
+    freq = {}
+    for name, d in small:
+        key = name.split("(")[0][:80]
+        c, t = freq.get(key, (0, 0.0))
+        freq[key] = (c + 1, t + d)
+    top = sorted(freq.items(), key=lambda kv: -kv[1][0])[:10]
+    return {"launches_per_step": len(kern) / nsteps, "launches_under_8us_per_step": len(small) / nsteps,
+            "us_under_8us_per_step": sum(d for _, d in small) / nsteps, "kernel_us_per_step": sum(dur) / nsteps,
+            "memset_memcpy_records_per_step": other / nsteps, "steps_counted": nsteps,
+            "most_frequent_under_8us": [{"kernel": k, "per_step": c / nsteps, "us_per_step": t / nsteps} for k, (c, t) in top]}
 
 
 def synth_batch(B, N, device, seed=0):
@@ -393,6 +426,10 @@ def secondary_workloads(lib, dev):
         rows, g, _ = profiled_steps(lib, seg_step, 2)
     gbs = g[3] / (g[0] * 1e-3) / 1e9 if g[0] > 0 else 0.0
     tfs = g[2] / (g[0] * 1e-3) / 1e12 if g[0] > 0 else 0.0
+    try:                # HBM-side bytes of the bf16 GEMM launches from the counter profile OF THIS WORKLOAD (summary_config4*.csv)
+        c4_traffic, c4_src, _ = pmc_gemm_traffic("gemm_bf16_kernel", "configs4")
+    except RuntimeError as exc:
+        c4_traffic, c4_src = None, str(exc)
     out.append({"workload": "PointSegDA DGCNN_DefRec + seg + 3 MLSP heads, fwd+bwd+Adam, B=16 N=2048 k=40 (BASELINE.json configs[4], one GPU)",
                 "ms_per_step": ms, "blocks_ms_per_step": seg_blocks, "points_per_s": B * N / ms * 1e3, "dtype": "bf16 GEMM operands + bf16 activation storage, fp32 accumulate",
                 "seeded_backward": {"ms_per_step": ms_seeded, "points_per_s": B * N / ms_seeded * 1e3,
@@ -401,7 +438,8 @@ def secondary_workloads(lib, dev):
                 "roofline": {"kernel": "gemm_bf16_kernel<*> / gemm_f32_kernel<*> (every MFMA GEMM launch)", "bound": "hbm", "achieved": gbs,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "mfma_tflops": tfs,
                              "mfma_frac_of_bf16_dense_peak": tfs / PEAK_BF16_TFLOPS, "share_of_step": g[0] / 2 / ms,
-                             "launches_per_step": g[1] / 2,
+                             "launches_per_step": g[1] / 2, "traffic": c4_traffic, "traffic_source": c4_src,
+                             "algorithmic_bytes_per_launch": g[3] / g[1] if g[1] else None,
                              "note": "achieved = algorithmic operand + result bytes of the launches (A + B + C in their storage types) / "
                                      "HIP-event time: at bf16 the contractions sit under the HBM roof, not the 2.5 PF matrix roof"},
                 "knn": [e for e in (_kernel_entry("kNN C=3, k=40, N=2048 (knn6w_kernel + prep + v5 on flagged clouds)", "hbm", rows[1], 2, "compulsory (C+k)*4 B/pt"),
@@ -639,7 +677,10 @@ def main():
         return stub_ranks(a, world, rank)
 
     import torch.distributed as dist
-    distributed = world > 1
+    # MLSP_BENCH_FORCE_DIST=1: a one-rank RCCL group with the exchange forced on (pack -> all-reduce -> divide at world size 1), so that the
+    # whole N > 1 code path of this file -- and its `distributed` self-check record -- runs on a single-GPU box
+    force_dist = world == 1 and bool(os.environ.get("MLSP_BENCH_FORCE_DIST"))
+    distributed = world > 1 or force_dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -665,7 +706,7 @@ def main():
     args = make_args()
     torch.manual_seed(0)                                   # identical replicas on every rank
     model = Models.DGCNN(args).to(dev).train()
-    sync = FlatGradSync(model, align=4)                     # 16-byte aligned gradient views: FlatAdam reads the packed gradients in place
+    sync = FlatGradSync(model, align=4, force=force_dist)   # 16-byte aligned gradient views: FlatAdam reads the packed gradients in place
     opt = sync.wrap(make_adam(model.parameters()))                                            # trainer.py:258-259
     batch = synth_batch(b_local, NPTS, dev, seed=1000 + rank)
 
@@ -728,6 +769,44 @@ def main():
     prof_steps = 3
     rows, prof, prof_dt = profiled_steps(lib, one_step, prof_steps)
 
+    # launches counted in THIS run (torch.profiler device records; untimed, rank 0 only -- no collectives skipped: every rank runs the steps)
+    counted = None
+    count_steps = 4
+    if rank == 0:
+        counted = count_launches(one_step, count_steps)
+    else:
+        for _ in range(count_steps):
+            one_step()
+    torch.cuda.synchronize()
+
+    # N > 1: what a SCALE record needs to verify itself -- the world as RCCL sees it, collectives per optimizer step, the gradient
+    # all-reduce timed alone (HIP events on the stream the collective is enqueued from), the device of every rank
+    dist_info = None
+    if distributed:
+        steps_so_far = getattr(opt, "flat_steps", None)
+        names = [None] * world
+        dist.all_gather_object(names, "%s (cuda:%d)" % (torch.cuda.get_device_name(dev), local_rank))
+        ar = []
+        for _ in range(12):
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(sync._bucket, op=dist.ReduceOp.SUM)
+            e1.record()
+            e1.synchronize()
+            ar.append(e0.elapsed_time(e1))
+        t_ar = torch.tensor([sorted(ar[2:])[len(ar[2:]) // 2]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+        nbytes = sync._bucket.numel() * 4
+        dist_info = {"backend": dist.get_backend(), "world_size_seen_by_backend": dist.get_world_size(), "devices": names,
+                     "collectives_per_step": sync.collectives / max(1, sync.steps),
+                     "collectives": sync.collectives, "optimizer_steps": sync.steps, "optimizer_flat_steps": steps_so_far,
+                     "allreduce_bytes": nbytes, "allreduce_alone_ms": t_ar.item(),
+                     "allreduce_alone_busbw_GBs": 2.0 * (world - 1) / world * nbytes / (t_ar.item() * 1e-3) / 1e9,
+                     "note": "all-reduce of the %d-byte gradient bucket alone: median of 10 (after 2 warm-up), HIP events around the call on "
+                             "the enqueueing stream, max over ranks; bus bandwidth = 2 (n - 1) / n x bytes / time" % nbytes}
+
     # the same step with every GEMM on the f32 MFMA, for the record (not the headline): one settle block + the same number of blocks
     f32_leg, f32_blocks = None, []
     if Fh.gemm_precision.current == "bf16x6" and not a.no_fp32_leg:
@@ -763,10 +842,8 @@ def main():
             # prof = [total ms of the GEMM family, launches, algorithmic FLOP summed over launches, algorithmic bytes];
             # rows[7] = the subset that ran on the bf16-split kernel (default mode "bf16x6"), the rest ran on the f32 MFMA kernels
             sp = rows[7]
-            traffic, traffic_src = pmc_gemm_traffic("gemm_split_kernel" if sp[1] > 0 else "gemm_f32_kernel")
-            if traffic is None and sp[1] > 0:
-                traffic, traffic_src = pmc_gemm_traffic("gemm_f32_kernel")
-                traffic_src = "%s (gemm_f32_kernel rows: no split-kernel pass committed yet)" % traffic_src
+            # counter profile OF THIS WORKLOAD and OF THE PRICED KERNEL (raises when the committed file has no row of it)
+            traffic, traffic_src, _ = pmc_gemm_traffic("gemm_split_kernel" if sp[1] > 0 else "gemm_f32_kernel", "configs1")
             step_ms = 1e3 * dt / a.steps
             common_note = ("achieved = sum(2*M*N*K of the launches: algorithmic fp32 FLOP) / sum(HIP-event time of the launches), events on "
                            "the launch stream, %d untimed steps after the timed blocks (%.2f ms/step with the events armed)"
@@ -784,7 +861,7 @@ def main():
                 ach = sp[2] / (sp[0] * 1e-3) / 1e12
                 # HBM-side bytes (committed --pmc passes) and algorithmic bytes over the SAME launches: the split kernel's, by instantiation
                 kinds = getattr(profiled_steps, "split_kinds", {})
-                pmc_kind, pmc_src = pmc_split_traffic_by_kind()
+                pmc_kind, pmc_src = pmc_split_traffic_by_kind("configs1")
                 by_kind, alg_all, tr_all, n_all = {}, 0.0, 0.0, 0.0
                 for kname, (kms, kn, kflop, kbytes) in kinds.items():
                     if kn <= 0:
@@ -869,11 +946,16 @@ def main():
         out["executed_mfma_frac"] = out["executed_tflops"] / PEAK_FP32_TFLOPS
         out["executed_bf16_tflops"] = 6 * split_flop / step_s / 1e12          # the split GEMMs' piece products
         out["reference_flop_equivalent_frac"] = value / n_gpus * FLOP_PER_POINT / 1e12 / PEAK_FP32_TFLOPS
-        nl, nsmall, lsrc = committed_launch_count()
-        if nl is not None:
-            out["launches_per_step"] = nl
-            out["launches_under_8us_per_step"] = nsmall
-            out["launches_source"] = "committed rocprofv3 kernel statistics (%s), not counted in this run" % lsrc
+        if counted and "launches_per_step" in counted:
+            out["launches_per_step"] = counted["launches_per_step"]
+            out["launches_under_8us_per_step"] = counted["launches_under_8us_per_step"]
+            out["launches_source"] = "counted"
+            out["launches_counted"] = dict(counted, note="device kernel records of torch.profiler over %d untimed steps of THIS run, after the "
+                                                         "timed blocks: every kernel of the process (libmlsp_hip.so's and torch's)" % counted["steps_counted"])
+        else:
+            out["launches_source"] = "not counted: torch.profiler delivered no device records on this box (%r)" % (counted,)
+        if distributed:
+            out["distributed"] = dist_info
         if n_gpus == 1 and not a.no_secondary:
             del model, opt, sync, batch
             out["secondary"] = secondary_workloads(lib, dev)

@@ -66,6 +66,7 @@ class FlatGradSync:
         self._chk = self._bucket[padded:]
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
         self.collectives = 0                  # device all-reduces issued so far (tests count them)
+        self.steps = 0                        # optimizer steps this exchange ran in front of (bench.py: collectives / steps == 1)
         self.host_group = None
         self._pending = None                  # (host copy of the summed check words, event | None, world size) of the previous step
         if presence == "uniform" and self.world_size > self._MAX_UNIFORM_WORLD:
@@ -135,6 +136,7 @@ class FlatGradSync:
 
     def allreduce(self):
         ws = self.world_size
+        self.steps += 1
         if ws > 1 or self.force:
             uniform = self.presence_mode == "uniform"
             if uniform:
