@@ -123,7 +123,7 @@ class MlspLibraryError(RuntimeError):
 # GEMM products (include/mlsp_hip.h `precision`, a per-call argument; functional.gemm_precision chooses what the mirror passes).  Default "bf16x6": fp32-accurate
 # products on the bf16 matrix cores (three-way exact operand split, six piece products, fp32 accumulation; measured error below the
 # f32-MFMA chain's).  MLSP_GEMM_PRECISION=fp32 selects the f32 MFMA for every launch; an unknown name fails loudly at import.
-GEMM_PRECISION_MODES = {"fp32": 0, "bf16": 1, "bf16x6": 2}
+GEMM_PRECISION_MODES = {"fp32": 0, "bf16": 1, "bf16x6": 2, "f16x3": 3}
 DEFAULT_GEMM_PRECISION = os.environ.get("MLSP_GEMM_PRECISION", "bf16x6")
 if DEFAULT_GEMM_PRECISION not in GEMM_PRECISION_MODES:
     raise ValueError("MLSP_GEMM_PRECISION=%r: expected one of %s" % (DEFAULT_GEMM_PRECISION, sorted(GEMM_PRECISION_MODES)))

@@ -245,7 +245,7 @@ size_t mlsp_workspace_bytes(int rows, int cin, int cout) {
                + r * ci * sizeof(float);                                    // a chained layer's activated input, shapes outside the fused path
     size_t parts = (r / 64 + 2) * 2 * co * sizeof(double);                  // stat partials
     size_t wts = 4 * co * ci * sizeof(float) * 2 + 8 * co * sizeof(float);  // Wd, dWd, coefficient vectors
-    return act + parts + wts + SLAB_BOUND_FLOATS * sizeof(float) + (32 << 20);       // + fixed-size per-workgroup partial slabs
+    return act + parts + wts + SLAB_BOUND_FLOATS * sizeof(float) + (32 << 20) + MLSP_AMAX_TAIL_BYTES;       // + fixed-size per-workgroup partial slabs + the tail PREC_SCOPE reserves
 }
 
 int mlsp_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
@@ -582,10 +582,12 @@ int mlsp_tnet_edge_bwd_f32(const float* dOut, const float* x, int ldx, const int
 static bool defer_ok(const mlsp_defer_t* in) {
     return in->bn_save && in->ld > 0 && in->col >= 0 && in->p_drop >= 0.f && in->p_drop < 1.f && in->act >= 0 && in->act <= 2;
 }
-static GemmXf chain_xf(const mlsp_defer_t& in, int which) {
+static GemmXf chain_xf(const mlsp_defer_t& in, int which, int batch_stats) {
+    // batch_stats: the producer's bn_save rows 2 / 3 are the BATCH mean / invstd of the matrix X points into (training mode)
     GemmXf x;
     x.scale = in.bn_save + in.col; x.shift = in.bn_save + in.ld + in.col; x.act = in.act; x.slope = in.slope; x.thresh = dropout_thresh8(in.p_drop);
     x.inv_keep = dropout_inv_keep8(in.p_drop); x.seed = in.seed; x.ld = in.ld; x.col = in.col; x.which = which;
+    if (batch_stats) { x.mean = in.bn_save + 2 * in.ld + in.col; x.invstd = in.bn_save + 3 * in.ld + in.col; }
     return x;
 }
 // a LeakyReLU slope outside [0, 1] takes the streaming pass: the fused transform writes the activation as one max
@@ -617,7 +619,7 @@ static int pointmlp_fwd_impl(const float* X, int ldx, int M, int Cin, const floa
     float* slab = sf ? w.take<float>(sf) : nullptr;
     GemmXf xf_s; const GemmXf* xf = nullptr;
     if (in) {
-        xf_s = chain_xf(*in, 1);
+        xf_s = chain_xf(*in, 1, training);
         if (defer_fusable(*in) && gemm_xf_supported(false, true, M, Cout, Cin, X, ldx, W, ldw, 1)) xf = &xf_s;
         else {                                             // shape outside the fused path: materialise the activated input once
             float* Xa = w.take<float>((size_t)M * Cin);
@@ -710,7 +712,7 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     GemmXf xf_s; const GemmXf* xf = nullptr;            // chained input: the wgrad reads the previous layer's pre-BN output
     if (in) {
         if (!defer_ok(in) || in->col + Cin > in->ld || M <= 32) return MLSP_ERR_ARG;
-        xf_s = chain_xf(*in, 2);
+        xf_s = chain_xf(*in, 2, training);
         if (defer_fusable(*in) && gemm_xf_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx, 2)) xf = &xf_s;
         else {
             float* Xa = w.take<float>((size_t)M * Cin);
@@ -803,7 +805,7 @@ int mlsp_pointmlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, int C
 // Row panels the fused statistics pass of mlsp_pointmlp_bwd_chain_f32(in_stats != NULL) writes for this layer shape (its dgrad
 // dX [M][Cin] = dY [M][Cout] W): M / 128 when the dgrad runs on a kernel with that pass, else 0 (pass in_stats = NULL then).
 int mlsp_pointmlp_bwd_stats_parts(int M, int Cin, int Cout, int ldw, int lddx, int precision) {
-    if (precision < 0 || precision > 2) return 0;
+    if (precision < 0 || precision > 3) return 0;
     GemmPrecisionScope prec_scope_(precision);
     const int t = thin_bs_parts(M, Cin, Cout);
     return t ? t : gemm_bs_parts(M, Cin, Cout, Cout, ldw, lddx);
@@ -898,7 +900,7 @@ int mlsp_pointmlp_segmax_bwd_f32(const float* dOut, const float* X, int ldx, int
 // bf16 x bf16 with fp32 accumulation (v_mfma_f32_32x32x16_bf16).  BN layers with fused statistics only (interior GEMM tiles):
 // MLSP_ERR_UNSUPPORTED otherwise -- mlsp_pointmlp_mx_supported() tells the caller beforehand, which then keeps that layer in fp32.
 int mlsp_pointmlp_mx_supported(int M, int Cin, int Cout, int ldx, int x_bf16, int training, int precision) {
-    if (precision < 0 || precision > 2) return 0;
+    if (precision < 0 || precision > 3) return 0;
     GemmPrecisionScope prec_scope_(precision);
     if (M <= 32 || Cin % 32 || Cout % 128 || M % 128) return 0;
     if (x_bf16 ? (ldx % 8) : (ldx % 4)) return 0;

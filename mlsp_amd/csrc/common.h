@@ -30,15 +30,19 @@ void prof_cls_end(hipStream_t st, int token, double work);
 // 1 bf16-rounded operands, 2 fp32-accurate six-product bf16 split.  An entry point opens a GemmPrecisionScope from its argument; the
 // launch helpers below it read gemm_precision_mode().  The value lives in a thread-local for the duration of that one call (restored on
 // exit, so nested / concurrent calls on any threads never see each other's mode): nothing outlives a call, the library keeps no switch.
+#define MLSP_AMAX_TAIL_BYTES 65536
 struct GemmPrecisionScope {
     int prev;
-    explicit GemmPrecisionScope(int mode);
+    void* prev_tail;
+    // ws / ws_bytes: the call's workspace -- its last MLSP_AMAX_TAIL_BYTES hold the operand-magnitude partials of the two-piece f16 products
+    // (mode 3; gemm.hip amax_partials); Workspace below never hands that tail out
+    explicit GemmPrecisionScope(int mode, void* ws = nullptr, size_t ws_bytes = 0);
     ~GemmPrecisionScope();
     GemmPrecisionScope(const GemmPrecisionScope&) = delete;
     GemmPrecisionScope& operator=(const GemmPrecisionScope&) = delete;
 };
 int gemm_precision_mode();
-#define PREC_SCOPE(mode_) if ((mode_) < 0 || (mode_) > 2) return MLSP_ERR_ARG; GemmPrecisionScope prec_scope_(mode_)
+#define PREC_SCOPE(mode_) if ((mode_) < 0 || (mode_) > 3) return MLSP_ERR_ARG; GemmPrecisionScope prec_scope_(mode_, ws, ws_bytes)
 
 // Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) -- at most once per (device, kernel, size): the host call
 // costs tens of microseconds, a dozen of them per step put the enqueue thread behind the GPU on slower hosts.  (api.hip; a cache of
@@ -51,7 +55,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 struct Workspace {
     char* base;
     size_t size, off;
-    Workspace(void* p, size_t n) : base((char*)p), size(n), off(0) {}
+    Workspace(void* p, size_t n) : base((char*)p), size(n > MLSP_AMAX_TAIL_BYTES ? n - MLSP_AMAX_TAIL_BYTES : 0), off(0) {}     // (the tail: see PREC_SCOPE)
     template <typename T>
     T* take(size_t count) {
         size_t bytes = align_up(count * sizeof(T), 256);
@@ -79,8 +83,11 @@ __device__ __forceinline__ void xcd_cloud_map(int bid, int bpc, int B, int& clou
 // and that layer's dropout are applied while the tile is staged.  which: 1 = A ([M][K] row-major, c = k), 2 = B ([K][N] k-major, c = n).
 // scale / shift point at the operand's FIRST channel; ld / col: row pitch of the matrix the previous layer wrote and the operand's first
 // column in it (the dropout stream is indexed by the element's place in that matrix: a column slice of a merged layer keeps its mask).
+// mean / invstd (nullable): the previous layer's BATCH statistics rows (training mode), at the operand's first channel -- with them the
+// transformed values are bounded analytically (|yhat| <= sqrt(rows)), which the two-piece f16 products need (gemm.hip GemmArgs a_amax).
 struct GemmXf {
     const float* scale; const float* shift; int act; float slope; uint32_t thresh; float inv_keep; uint64_t seed; int ld; int which; int col;
+    const float* mean = nullptr; const float* invstd = nullptr;
 };
 
 // The previous layer's BatchNorm-backward reduction fused into a dgrad's output pass (gemm.hip GemmArgs bs_*; thin.hip): y / bn point at the

@@ -58,6 +58,11 @@ struct GemmArgs {
     // BatchNorm backward dY = (d' + y * nk2[c] + c0[c]) * sc[c] is applied while the tile is staged: the streaming "apply" pass and the
     // dY tensor disappear.  dy_coef: rows c0 | nk2 | sc (pitch dy_cld) at A's channel 0 (dgrad: channel = k; wgrad: channel = m).
     const float* dy_y; const float* dy_coef; int dy_cld;
+    // gemm_split_kernel<.., NPC = 2> (two f16 pieces): device-side upper bounds of |A| and |B| (after the operand transforms), nullable = scale 1
+    // Partial maxima of |A| / |B| as they lie in memory (amax_partials_kernel; null / 0 where the bound is analytic), and what the analytic
+    // bounds need: a transformed operand (XF, batch statistics over stat_rows rows) is bounded per channel by |scale| sqrt(rows) / invstd +
+    // |shift + mean scale| (|yhat| <= sqrt(rows)), a gradient formed on the fly (DY) by max|sc| amax(d') (2 + sqrt(rows)).
+    const float* a_amax; int a_amax_n; const float* b_amax[4]; int b_amax_n; const float* x_mean; const float* x_invstd; float stat_sqrt_rows;   // b_amax[g]: group g's B (gmode 1), else [0]
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][stat_ld] (BN batch statistics)
     int stat_ld;                    // columns of a statistics row (N, or the width of the wider matrix C is a column slice of)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
@@ -897,6 +902,42 @@ __device__ __forceinline__ uint32_t sx_cvt_pk(float lo, float hi) {       // one
     const bf16x2 b = __builtin_convertvector(v, bf16x2);
     return __builtin_bit_cast(uint32_t, b);
 }
+// ---- two f16 pieces, three products (gemm_split_kernel<.., NPC = 2>; `precision` = MLSP_PREC_F16X3) ----------------------------------
+// x s = h0 + h1 + e with h0 = f16(x s), h1 = f16(x s - h0) (RNE; the remainder is exact in fp32), |e| <= 2^-22 |x s|: 11 + 11 significand
+// bits; x y ~ h0 h0' + (h0 h1' + h1 h0') on v_mfma_f32_32x32x16_f16 -- three MFMAs per product instead of six -- with fp32 accumulation;
+// every piece product is exact (11 x 11 bits), the dropped term h1 h1' is < 2^-22 |x y|.  s is a per-OPERAND power of two (exact) that
+// places the operand's largest magnitude in [2^14, 2^15) of the f16 range (max 65504): elements down to 2^-17 of the largest keep all 22
+// bits, smaller ones an absolute error < 2^-40 of the largest (f16 subnormal spacing) -- nothing against the 2^-24 of every fp32
+// accumulation.  The scale comes from a device-side bound of the operand's magnitude (GemmArgs a_amax / b_amax; launch_gemm computes it
+// with one streaming pass when the caller has none), the accumulators are multiplied by 2^-(ea + eb) before the epilogue.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define SXH(v_) __builtin_bit_cast(f16x8, (v_))
+__device__ __forceinline__ uint32_t sx_cvt_pk_h(float lo, float hi) {     // one v_cvt_pk_f16_f32 (RNE)
+    const f32x2 v = {lo, hi};
+    const f16x2 b = __builtin_convertvector(v, f16x2);
+    return __builtin_bit_cast(uint32_t, b);
+}
+__device__ __forceinline__ float sx_h_lo(uint32_t pk) { return (float)__builtin_bit_cast(f16x2, pk)[0]; }
+__device__ __forceinline__ float sx_h_hi(uint32_t pk) { return (float)__builtin_bit_cast(f16x2, pk)[1]; }
+__device__ __forceinline__ void sx_split_store_h(const f32x4& x, float s, char* d) {
+    uint32_t pk[2][2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const float x0 = x[2 * hh] * s, x1 = x[2 * hh + 1] * s;
+        pk[0][hh] = sx_cvt_pk_h(x0, x1);
+        pk[1][hh] = sx_cvt_pk_h(x0 - sx_h_lo(pk[0][hh]), x1 - sx_h_hi(pk[0][hh]));
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *(u32x2*)(d + q * SX_PLANE) = (u32x2){pk[q][0], pk[q][1]};
+}
+// biased exponent field of the power-of-two scale for an operand whose magnitudes are bounded by `bound`:
+// bound in [2^e, 2^(e+1)) -> s = 2^(14 - e), clamped to [2^-62, 2^62]; zero / denormal / non-finite bound -> 1.0
+__device__ __forceinline__ int sx_scale_exp(float bound) {
+    const int e = (int)((__float_as_uint(bound) >> 23) & 255u);
+    if (e == 0 || e == 255) return 127;
+    return min(max(268 - e, 127 - 62), 127 + 62);
+}
 // three-way split of one staged quad into the three images (prologue only: the K loop uses the hand-placed stream)
 __device__ __forceinline__ void sx_split_store(const f32x4& x, char* d) {
     uint32_t pk[3][2];
@@ -924,14 +965,15 @@ __device__ __forceinline__ f32x4 sx_bufload(__amdgpu_buffer_rsrc_t rs, int voff,
 // DY (GemmArgs dy_*): the A operand is d' and the layer's BatchNorm backward is applied to it while it is staged (two loads per staged
 // quad: d' and y), for the layer's dgrad (A row-major: coefficients per K-tile from LDS) and its weight gradient (A k-major: the thread's
 // channel quad is fixed, coefficients in registers).
-template <bool TA, bool TB, int WM, int XF = 0, bool XD = false, bool DY = false>
+template <bool TA, bool TB, int WM, int XF = 0, bool XD = false, bool DY = false, int NPC = 3>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
+    static_assert(NPC == 3 || NPC == 2, "three bf16 pieces (six products) or two f16 pieces (three products)");
     static_assert(XF == 0 || (XF == 1 && !TA) || (XF == 2 && !TB), "XF == 1: A row-major; XF == 2: B k-major");
     static_assert(XF != 0 || !XD, "dropout only with a transform");
     static_assert(!(DY && XF == 1), "one transform per operand");
     constexpr bool KA = TA, KB = !TB;                                 // operand's global source is k-major
     constexpr int BMT = 64 * WM, NQA = 2 * WM;                        // A quads (16-byte loads) of a tile per thread; B: 4
-    __shared__ __attribute__((aligned(16))) char simg[6 * SX_PLANE];  // 61,440 B
+    __shared__ __attribute__((aligned(16))) char simg[2 * NPC * SX_PLANE];  // 61,440 B (NPC = 3) / 40,960 B
     constexpr int XFS = XF == 1 ? 2 * SX_XF_KMAX : (DY && !TA) ? 3 * SX_XF_KMAX : 4;
     __shared__ __attribute__((aligned(16))) float xfs[XFS];           // XF == 1: scale | shift of this workgroup's K range (<= SX_XF_KMAX channels); DY dgrad: c0 | nk2 | sc
     float* smem = (float*)simg;                                       // epilogue scratch (the images are dead by then)
@@ -1004,11 +1046,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
 #define SX_LOAD_AY(q) sx_bufload(rsy, voa, soa + (q) * qa_)
     // this thread's place in the images
     char* wa = simg + (KA ? (NQA == 4 ? (tid >> 5) * SX_KPITCH + (tid & 31) * 8 : (tid >> 4) * SX_KPITCH + (tid & 15) * 8) : (tid >> 3) * SX_RPITCH + (tid & 7) * 8);
-    char* wb = simg + 3 * SX_PLANE + (KB ? (tid >> 5) * SX_KPITCH + (tid & 31) * 8 : (tid >> 3) * SX_RPITCH + (tid & 7) * 8);
+    char* wb = simg + NPC * SX_PLANE + (KB ? (tid >> 5) * SX_KPITCH + (tid & 31) * 8 : (tid >> 3) * SX_RPITCH + (tid & 7) * 8);
     constexpr int WQA = KA ? (NQA == 4 ? 8 : 16) * SX_KPITCH : 32 * SX_RPITCH, WQB = KB ? 8 * SX_KPITCH : 32 * SX_RPITCH;
     const char* fa = simg + sx_frag_base<KA>(lane) + (wm * 32 * WM) * (KA ? 2 : SX_RPITCH);
-    const char* fb = simg + 3 * SX_PLANE + sx_frag_base<KB>(lane) + (wn * 64) * (KB ? 2 : SX_RPITCH);
+    const char* fb = simg + NPC * SX_PLANE + sx_frag_base<KB>(lane) + (wn * 64) * (KB ? 2 : SX_RPITCH);
     constexpr int FWA = 32 * (KA ? 2 : SX_RPITCH), FWB = 32 * (KB ? 2 : SX_RPITCH);               // next 32-row window
+    int sxe_a = 127, sxe_b = 127;                                     // NPC == 2: the operands' power-of-two scales (exponent fields; uniform)
+    float sxs_a = 1.f, sxs_b = 1.f;
     f32x4 raw[8];                                                     // [0, NQA) A quads, then 4 B quads of the tile being staged
     // ---- operand transform state (XF): xsc / xsh = scale / shift of this thread's channel quad of the tile being staged (XF == 1: reloaded
     // from LDS per K-tile; XF == 2: fixed), xq = index of the aligned element quad (row * x_ld + x_col + channel) / 4 of this thread's
@@ -1077,12 +1121,63 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
 #define SX_DY_NEXT(tnext_) do { if constexpr (DY && !KA) { const int tc_ = min((tnext_), T - 1) * BK + (tid & 7) * 4; \
         dc0 = *(const f32x4*)(xfs + tc_); dnk2 = *(const f32x4*)(xfs + SX_XF_KMAX + tc_); dsc = *(const f32x4*)(xfs + 2 * SX_XF_KMAX + tc_); } } while (0)
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) {
-        raw[q] = SX_LOAD_A(q); SX_DY_LOAD(q); SX_DY_A(q, 0); SX_DY_A(q, 1);
-        SX_XF_HASH_A(q); SX_XF_A(q, 0); SX_XF_A(q, 1); sx_split_store(raw[q], wa + q * WQA);
+    for (int q = 0; q < NQA; ++q) { raw[q] = SX_LOAD_A(q); SX_DY_LOAD(q); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[NQA + q] = SX_LOAD_B(q);
+    if constexpr (NPC == 2) {
+        // bounds of the two operands as the split sees them (see GemmArgs a_amax) -> per-workgroup power-of-two scales; the first tile's
+        // loads above are in flight meanwhile
+        __shared__ float sred[12];
+        float va = 0.f, vb = 0.f, ca = 0.f;
+        if (XF != 1) for (int i = tid; i < p.a_amax_n; i += 256) va = fmaxf(va, p.a_amax[i]);
+        if (XF != 2) {
+            const int gb = p.gmode == 1 ? tn / p.gtiles : 0;
+            const float* bam = gb == 0 ? p.b_amax[0] : gb == 1 ? p.b_amax[1] : gb == 2 ? p.b_amax[2] : p.b_amax[3];
+            for (int i = tid; i < p.b_amax_n; i += 256) vb = fmaxf(vb, bam[i]);
+        }
+        const float sqr = p.stat_sqrt_rows;
+        if constexpr (XF == 1) {
+            for (int i = tid * 4; i < T * BK; i += 1024) {
+                const f32x4 sc = *(const f32x4*)(xfs + i), sh = *(const f32x4*)(xfs + SX_XF_KMAX + i);
+                const f32x4 mu = *(const f32x4*)(p.x_mean + xgc + kbeg + i), is = *(const f32x4*)(p.x_invstd + xgc + kbeg + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) va = fmaxf(va, fabsf(sc[e]) * sqr / is[e] + fabsf(fmaf(mu[e], sc[e], sh[e])));
+            }
+            if (XD) va *= xik;
+        } else if constexpr (XF == 2) {
+            const int ch = xgc + n0b + (tid & 31) * 4;
+            const f32x4 mu = *(const f32x4*)(p.x_mean + ch), is = *(const f32x4*)(p.x_invstd + ch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vb = fmaxf(vb, fabsf(xsc[e]) * sqr / is[e] + fabsf(fmaf(mu[e], xsc[e], xsh[e])));
+            if (XD) vb *= xik;
+        }
+        if constexpr (DY) {
+            if constexpr (KA) { ca = fmaxf(fmaxf(fabsf(dsc[0]), fabsf(dsc[1])), fmaxf(fabsf(dsc[2]), fabsf(dsc[3]))); }
+            else for (int i = tid; i < T * BK; i += 256) ca = fmaxf(ca, fabsf(xfs[2 * SX_XF_KMAX + i]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { va = fmaxf(va, __shfl_xor(va, o, 64)); vb = fmaxf(vb, __shfl_xor(vb, o, 64)); ca = fmaxf(ca, __shfl_xor(ca, o, 64)); }
+        if (lane == 0) { sred[wave * 3] = va; sred[wave * 3 + 1] = vb; sred[wave * 3 + 2] = ca; }
+        __syncthreads();
+        va = fmaxf(fmaxf(sred[0], sred[3]), fmaxf(sred[6], sred[9]));
+        vb = fmaxf(fmaxf(sred[1], sred[4]), fmaxf(sred[7], sred[10]));
+        ca = fmaxf(fmaxf(sred[2], sred[5]), fmaxf(sred[8], sred[11]));
+        if constexpr (DY) va = ca * va * (2.f + sqr);
+        sxe_a = __builtin_amdgcn_readfirstlane(sx_scale_exp(va));
+        sxe_b = __builtin_amdgcn_readfirstlane(sx_scale_exp(vb));
+        sxs_a = __uint_as_float((uint32_t)sxe_a << 23); sxs_b = __uint_as_float((uint32_t)sxe_b << 23);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { raw[NQA + q] = SX_LOAD_B(q); SX_XF_HASH_B(q); SX_XF_B(q, 0); SX_XF_B(q, 1); sx_split_store(raw[NQA + q], wb + q * WQB); }
+    for (int q = 0; q < NQA; ++q) {
+        SX_DY_A(q, 0); SX_DY_A(q, 1);
+        SX_XF_HASH_A(q); SX_XF_A(q, 0); SX_XF_A(q, 1);
+        if constexpr (NPC == 2) sx_split_store_h(raw[q], sxs_a, wa + q * WQA); else sx_split_store(raw[q], wa + q * WQA);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        SX_XF_HASH_B(q); SX_XF_B(q, 0); SX_XF_B(q, 1);
+        if constexpr (NPC == 2) sx_split_store_h(raw[NQA + q], sxs_b, wb + q * WQB); else sx_split_store(raw[NQA + q], wb + q * WQB);
+    }
     SX_XF_NEXT(1);
     SX_DY_NEXT(1);
     soa = min(soa + sta, enda); sob = min(sob + stb, endb);
@@ -1094,11 +1189,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     for (int q = 0; q < 4; ++q) raw[NQA + q] = SX_LOAD_B(q);
     __syncthreads();
     for (int t = 0; t < T; ++t) {
-        bf16x8 a[2][2][3], b[2][2][3];                               // [k16 step][32-row window][piece]
+        bf16x8 a[2][2][NPC], b[2][2][NPC];                           // [k16 step][32-row window][piece] (NPC == 2: f16 bit patterns)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NPC; ++q) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i) a[s2][i][q] = sx_frag<KA>(fa + q * SX_PLANE + i * FWA, s2);
 #pragma unroll
@@ -1110,7 +1205,57 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
         float r0, r1, a1;
         __builtin_amdgcn_sched_barrier(0);
         // (one generated body per (tile height, transformed operand, dropout): gen_split_body.py spreads the vector work over the MFMA slots)
-        if constexpr (DY && XF == 0) {
+        if constexpr (NPC == 2) {
+            if constexpr (DY && XF == 0) {
+                if (WM == 2) {
+#include "gemm_split_body_h_wm2_dy.inc"
+                } else {
+#include "gemm_split_body_h_wm1_dy.inc"
+                }
+            } else if constexpr (DY && !XD) {
+                if (WM == 2) {
+#include "gemm_split_body_h_wm2_dyxb.inc"
+                } else {
+#include "gemm_split_body_h_wm1_dyxb.inc"
+                }
+            } else if constexpr (DY) {
+                if (WM == 2) {
+#include "gemm_split_body_h_wm2_dyxbd.inc"
+                } else {
+#include "gemm_split_body_h_wm1_dyxbd.inc"
+                }
+            } else if constexpr (XF == 0) {
+                if (WM == 2) {
+#include "gemm_split_body_h_wm2.inc"
+                } else {
+#include "gemm_split_body_h_wm1.inc"
+                }
+            } else if constexpr (XF == 1 && !XD) {
+                if (WM == 2) {
+#include "gemm_split_body_h_wm2_xa.inc"
+                } else {
+#include "gemm_split_body_h_wm1_xa.inc"
+                }
+            } else if constexpr (XF == 1 && XD) {
+                if (WM == 2) {
+#include "gemm_split_body_h_wm2_xad.inc"
+                } else {
+#include "gemm_split_body_h_wm1_xad.inc"
+                }
+            } else if constexpr (XF == 2 && !XD) {
+                if (WM == 2) {
+#include "gemm_split_body_h_wm2_xb.inc"
+                } else {
+#include "gemm_split_body_h_wm1_xb.inc"
+                }
+            } else {
+                if (WM == 2) {
+#include "gemm_split_body_h_wm2_xbd.inc"
+                } else {
+#include "gemm_split_body_h_wm1_xbd.inc"
+                }
+            }
+        } else if constexpr (DY && XF == 0) {
             if (WM == 2) {
 #include "gemm_split_body_wm2_dy.inc"
             } else {
@@ -1174,15 +1319,105 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
 #undef SX_DY_NEXT
 #undef SX_LOAD_AY
 #undef SX_XF_NEXT
+    if constexpr (NPC == 2) {                                        // undo the operand scales (a power of two: exact)
+        const float inv = __uint_as_float((uint32_t)(127 - (sxe_a - 127) - (sxe_b - 127)) << 23);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+    }
     gemm_epilogue<WM, true, false, (!TA && !TB && XF == 0 && !DY) || (!TA && !TB && DY)>(p, acc, smem, tm, m0, n0, split, tid, l31, h, wm, wn);
 }
 
 // the calling entry point's `precision` argument for the duration of that call (common.h GemmPrecisionScope): 0: fp32 MFMA (exact fp32
 // products); 1: bf16 operands, fp32 accumulation; 2: fp32-accurate six-product bf16 split (gemm_split_kernel)
+// 3 (MLSP_PREC_F16X3): as 2, with two f16 pieces / three products on the launches gemm_split_kernel<.., NPC = 2> covers (tl_split_half); the
+// rest of the dispatch sees mode 2.
 static thread_local int tl_call_precision = 0;
+static thread_local bool tl_split_half = false;
 int gemm_precision_mode() { return tl_call_precision; }
-GemmPrecisionScope::GemmPrecisionScope(int mode) : prev(tl_call_precision) { tl_call_precision = mode; }
-GemmPrecisionScope::~GemmPrecisionScope() { tl_call_precision = prev; }
+
+// ---- operand magnitudes for the two-piece f16 products (mode 3) ------------------------------------------------------------------
+// AMAX_PARTS partial maxima of |X| per operand, written by ONE streaming launch (no atomics, nothing to initialise) into a slot of the
+// call's workspace tail (MLSP_AMAX_TAIL_BYTES, common.h); every workgroup of the consuming GEMM reduces the partials in its prologue.
+// Within one API call an operand is measured once (thread-local cache keyed by pointer and shape: dgrad and weight gradient share dY);
+// the cache and the slot ring die with the call (GemmPrecisionScope).
+#define AMAX_PARTS 256
+#define AMAX_SLOTS ((MLSP_AMAX_TAIL_BYTES - 256) / (AMAX_PARTS * 4))
+struct AmaxOp { const float* X; long rows; int cols, ld; float* out; };
+struct AmaxArgs { AmaxOp op[5]; };
+__global__ __launch_bounds__(512) void amax_partials_kernel(AmaxArgs a) {
+    const AmaxOp o = a.op[blockIdx.x / AMAX_PARTS];
+    const int b = blockIdx.x % AMAX_PARTS, tid = threadIdx.x;
+    float m = 0.f;
+    const int c4 = o.cols >> 2;
+    const long nq = o.rows * c4;                                   // aligned quads (host: cols % 4 == 0, ld % 4 == 0, 16-byte aligned base)
+    const long per = (nq + AMAX_PARTS - 1) / AMAX_PARTS;
+    const long q0 = (long)b * per, q1 = min(nq, q0 + per);
+    if (o.ld == o.cols) {
+        const f32x4* p = (const f32x4*)o.X;
+        long q = q0 + tid;
+        for (; q + 3 * 512 < q1; q += 4 * 512) {                   // four 16-byte loads in flight per thread
+            const f32x4 v0 = p[q], v1 = p[q + 512], v2 = p[q + 1024], v3 = p[q + 1536];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))), fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3])))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v2[0]), fabsf(v2[1])), fmaxf(fabsf(v2[2]), fabsf(v2[3]))), fmaxf(fmaxf(fabsf(v3[0]), fabsf(v3[1])), fmaxf(fabsf(v3[2]), fabsf(v3[3])))));
+        }
+        for (; q < q1; q += 512) { const f32x4 v = p[q]; m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])))); }
+    } else {
+        for (long q = q0 + tid; q < q1; q += 512) {
+            const long r = q / c4; const int c = (int)(q - r * c4);
+            const f32x4 v = *(const f32x4*)(o.X + r * o.ld + 4 * c);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+    __shared__ float sm[8];
+#pragma unroll
+    for (int s_ = 32; s_ > 0; s_ >>= 1) m = fmaxf(m, __shfl_xor(m, s_, 64));
+    if ((tid & 63) == 0) sm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) o.out[b] = fmaxf(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), fmaxf(fmaxf(sm[4], sm[5]), fmaxf(sm[6], sm[7])));
+}
+static thread_local struct AmaxScratch {
+    float* base = nullptr;          // the workspace tail of the current API call (null: none, mode 3 falls back to the bf16 pieces)
+    int next = 0, ncache = 0;
+    struct { const float* X; long rows; int cols, ld; float* out; } cache[AMAX_SLOTS];
+} tl_amax;
+// queue of operands to measure with the next launch (launch_gemm batches A and B -- and the groups' B operands -- into one launch)
+struct AmaxBatch { AmaxArgs args; int n = 0; };
+// -> the partials of X [rows][cols] (pitch ld), measured now (queued into `batch`) or earlier in this API call; null: cannot (no tail,
+// unaligned, the batch is full)
+static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, int ld) {
+    if (!tl_amax.base || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3) || (((uintptr_t)X) & 15)) return nullptr;
+    for (int i = 0; i < tl_amax.ncache; ++i) {
+        const auto& c = tl_amax.cache[i];
+        if (c.X == X && c.rows == rows && c.cols == cols && c.ld == ld) return c.out;
+    }
+    if (batch.n >= 5) return nullptr;
+    const int slot = tl_amax.next;
+    tl_amax.next = (tl_amax.next + 1) % AMAX_SLOTS;
+    float* out = tl_amax.base + (size_t)slot * AMAX_PARTS;
+    int k = 0;                                                   // the slot's previous tenant leaves the cache
+    for (int i = 0; i < tl_amax.ncache; ++i) if (tl_amax.cache[i].out != out) tl_amax.cache[k++] = tl_amax.cache[i];
+    tl_amax.ncache = k;
+    tl_amax.cache[tl_amax.ncache++] = {X, rows, cols, ld, out};
+    batch.args.op[batch.n++] = {X, rows, cols, ld, out};
+    return out;
+}
+static void amax_flush(hipStream_t st, AmaxBatch& batch) {
+    if (batch.n) hipLaunchKernelGGL(amax_partials_kernel, dim3(batch.n * AMAX_PARTS), dim3(512), 0, st, batch.args);
+    batch.n = 0;
+}
+GemmPrecisionScope::GemmPrecisionScope(int mode, void* ws, size_t ws_bytes) : prev(tl_call_precision | (tl_split_half ? 4 : 0)), prev_tail(tl_amax.base) {
+    tl_split_half = mode == 3; tl_call_precision = mode == 3 ? 2 : mode;
+    tl_amax.base = (mode == 3 && ws && ws_bytes >= 2 * MLSP_AMAX_TAIL_BYTES) ? (float*)((char*)ws + align_up(ws_bytes - MLSP_AMAX_TAIL_BYTES, 256)) : nullptr;
+    tl_amax.next = tl_amax.ncache = 0;
+}
+GemmPrecisionScope::~GemmPrecisionScope() {
+    tl_call_precision = prev & 3; tl_split_half = (prev & 4) != 0;
+    tl_amax.base = (float*)prev_tail; tl_amax.next = tl_amax.ncache = 0;
+}
 
 // sum the split-K slabs (fixed order -> bitwise reproducible) and apply the epilogue
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N, int ldc,
@@ -1647,6 +1882,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         p.stat_part = bs->part; p.stat_ld = bs->stat_ld;
     }
     p.dy_y = dy ? dy->y : nullptr; p.dy_coef = dy ? dy->coef : nullptr; p.dy_cld = dy ? dy->cld : 0;
+    p.a_amax = nullptr; p.a_amax_n = 0; p.b_amax[0] = p.b_amax[1] = p.b_amax[2] = p.b_amax[3] = nullptr; p.b_amax_n = 0; p.x_mean = p.x_invstd = nullptr; p.stat_sqrt_rows = 0.f;
     p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0; p.x_col = 0;
     if (xf) {
         p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_thresh = xf->thresh;
@@ -1667,7 +1903,6 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     static const bool no_xcd2 = getenv("MLSP_GEMM_NO_XCD2") != nullptr;       // read-once A/B switch (tools/ab)
     bool xcd2 = false;                                                        // (decided below, once the kernel is known: split kernel only)
     const bool prof = g_prof.on && g_prof.used < PROF_MAX_PAIRS;
-    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // FAST: every tile interior (M, N, K-range multiples of the tile), 16-byte loads legal on both operands
     // (byte offsets inside an operand tile's K range are 32-bit buffer offsets)
     const long a_span = ta ? (long)p.ksplit * lda * 4 : 128L * lda * 4 + (long)p.ksplit * 4;
@@ -1694,6 +1929,34 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (xcd2) { p.xcd_map = 2; grid = dim3(p.ntm * p.ntn * ns, 1); }
     const bool n64 = !dy && !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
                      (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && tl_call_precision != 1 && (ns == 1 || p.ldc == N);
+    // two-piece f16 products (mode 3) on this launch?  The split kernel, and a bound for both operands: partial maxima of the operands as
+    // they lie in memory (measured by ONE streaming launch here, or earlier in this API call), the analytic bound for a transformed one
+    // (batch statistics at hand).  Anything missing: the three-piece bf16 products (same kernel family, same accuracy class).
+    bool half = false;
+    if (tl_split_half && tl_amax.base && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && (!xf || xf_split) && !(ta && tb)) {
+        AmaxBatch batch;
+        bool ok = true;
+        if (xf && xf->which == 1) ok = xf->mean && xf->invstd;
+        else {
+            const int acols = (ta ? M : K) + ((grp && grp->mode == 1) ? (int)((grp->G - 1) * grp->a_gs) : 0);
+            p.a_amax = amax_get(batch, A, ta ? K : M, acols, lda); p.a_amax_n = AMAX_PARTS;
+            ok = p.a_amax != nullptr;
+        }
+        if (xf && xf->which == 2) ok = ok && xf->mean && xf->invstd;
+        else if (grp && grp->mode == 1) {
+            for (int g = 0; g < grp->G && ok; ++g) { p.b_amax[g] = amax_get(batch, grp->Bg[g], tb ? N / grp->G : K, tb ? K : N / grp->G, ldb); ok = p.b_amax[g] != nullptr; }
+            p.b_amax_n = AMAX_PARTS;
+        } else {
+            const int bcols = (tb ? K : N) + ((grp && grp->mode == 2) ? (int)((grp->G - 1) * grp->b_gs) : 0);
+            p.b_amax[0] = amax_get(batch, B, tb ? N : K, bcols, ldb); p.b_amax_n = AMAX_PARTS;
+            ok = ok && p.b_amax[0] != nullptr;
+        }
+        amax_flush(st, batch);                 // (whatever was queued is in the cache: measure it even if this launch ends up on the bf16 pieces)
+        if (xf) { p.x_mean = xf->mean; p.x_invstd = xf->invstd; }
+        p.stat_sqrt_rows = sqrtf((float)(ta ? K : M));
+        half = ok;
+    }
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     if (n64) {
         dim3 g64(M / 128, ns);
         if (!ta && tb) hipLaunchKernelGGL((gemm_f32_n64_kernel<false, true>), g64, dim3(256), 0, st, p);
@@ -1701,12 +1964,15 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         else hipLaunchKernelGGL((gemm_f32_n64_kernel<true, false>), g64, dim3(256), 0, st, p);
     } else
 #define GEMM_GO(TA_, TB_, WM_) do { if (fast && tl_call_precision == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, WM_, false, false, false>), grid, dim3(256), 0, st, p); \
+                                     else if (half) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, WM_, 0, false, false, 2>), grid, dim3(256), 0, st, p); \
                                      else if (fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts)) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, WM_>), grid, dim3(256), 0, st, p); \
                                      else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, true>), grid, dim3(256), 0, st, p); \
                                      else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, WM_, false>), grid, dim3(256), 0, st, p); } while (0)
     if (dy) {                                                            // dual A operand (validated above: split kernel, interior tiles)
         if (!fast || (xf && !xf_split) || (grp && grp->mode != (ta ? 2 : 1))) return MLSP_ERR_UNSUPPORTED;
-#define SPLIT_DY_GO(TA_, XF_, XD_) do { if (bm == 128) hipLaunchKernelGGL((gemm_split_kernel<TA_, false, 2, XF_, XD_, true>), grid, dim3(256), 0, st, p); \
+#define SPLIT_DY_GO(TA_, XF_, XD_) do { if (half) { if (bm == 128) hipLaunchKernelGGL((gemm_split_kernel<TA_, false, 2, XF_, XD_, true, 2>), grid, dim3(256), 0, st, p); \
+                                                    else hipLaunchKernelGGL((gemm_split_kernel<TA_, false, 1, XF_, XD_, true, 2>), grid, dim3(256), 0, st, p); } \
+                                        else if (bm == 128) hipLaunchKernelGGL((gemm_split_kernel<TA_, false, 2, XF_, XD_, true>), grid, dim3(256), 0, st, p); \
                                         else hipLaunchKernelGGL((gemm_split_kernel<TA_, false, 1, XF_, XD_, true>), grid, dim3(256), 0, st, p); } while (0)
         if (!ta) { if (xf) return MLSP_ERR_UNSUPPORTED; SPLIT_DY_GO(false, 0, false); }
         else if (!xf) SPLIT_DY_GO(true, 0, false);
@@ -1714,7 +1980,11 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         else SPLIT_DY_GO(true, 2, false);
 #undef SPLIT_DY_GO
     } else if (xf_split) {                                               // operand transform on the split kernel, plain or block-diagonal
-#define SPLIT_XF_GO(TA_, TB_, XF_) do { if (bm == 128) { if (xf->thresh) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 2, XF_, true>), grid, dim3(256), 0, st, p); \
+#define SPLIT_XF_GO(TA_, TB_, XF_) do { if (half) { if (bm == 128) { if (xf->thresh) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 2, XF_, true, false, 2>), grid, dim3(256), 0, st, p); \
+                                                                      else hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 2, XF_, false, false, 2>), grid, dim3(256), 0, st, p); } \
+                                                     else { if (xf->thresh) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 1, XF_, true, false, 2>), grid, dim3(256), 0, st, p); \
+                                                            else hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 1, XF_, false, false, 2>), grid, dim3(256), 0, st, p); } } \
+                                         else if (bm == 128) { if (xf->thresh) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 2, XF_, true>), grid, dim3(256), 0, st, p); \
                                                           else hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 2, XF_, false>), grid, dim3(256), 0, st, p); } \
                                          else { if (xf->thresh) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 1, XF_, true>), grid, dim3(256), 0, st, p); \
                                                 else hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 1, XF_, false>), grid, dim3(256), 0, st, p); } } while (0)

@@ -19,11 +19,15 @@ The plain body (no VARIANT) is the round-3 placement, unchanged.
 Names used: acc, a[s2][i][q], b[s2][j][q], raw[8], pk0/pk1/pk2[2], r0, r1, a1, wa, wb, WQA, WQB, SX_LOAD_A/B, SX_XF_A/B, SX_XF_HASH_A/B (see the kernel)."""
 import sys
 WM = int(sys.argv[1])
-VAR = sys.argv[2] if len(sys.argv) > 2 else ""
+VAR = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else ""
+HALF = len(sys.argv) > 3 and sys.argv[3] == "h"      # two f16 pieces, three products (gemm_split_kernel<.., NPC = 2>): see items()
 QA = [1, 0, 2, 0, 1, 0]          # smallest products first, the leading one last
 QB = [1, 2, 0, 1, 0, 0]
+if HALF:
+    QA, QB = [1, 0, 0], [0, 1, 0]
+NP6 = len(QA)
 NQA = 2 * WM                      # A quads of a tile per thread (B: 4)
-S = 24 * WM
+S = 4 * NP6 * WM
 DYA = VAR.startswith("dy")        # dy / dyxb / dyxbd: the A quads are d' + y pairs (SX_DY_A: the BatchNorm backward, 3 operations per value; SX_DY_LOAD)
 XA = VAR.startswith("xa")
 XB = VAR.startswith("xb") or VAR.startswith("dyxb")
@@ -46,6 +50,23 @@ def items():
                 out.append((6, [f"SX_DY_A({q}, {hh});"]))
             if xf:
                 out.append((10 if DROP else 6, [f"SX_XF_{op}({q}, {hh});"]))
+            if HALF:
+                # x * s = h0 + h1 (+ < 2^-22 |x s|): h0 = f16(x s), h1 = f16(x s - h0) (the remainder is exact in fp32); s: the operand's
+                # power-of-two scale (sxs_a / sxs_b).  Per pair: v_pk_mul, v_cvt_pk_f16_f32, 2 v_cvt_f32_f16, v_pk_add, v_cvt_pk_f16_f32
+                sc = "sxs_a" if isA else "sxs_b"
+                out.append((4, [f"r0 = {x0} * {sc}; r1 = {x1} * {sc};", f"pk0[{hh}] = sx_cvt_pk_h(r0, r1);"]))
+                L = [f"pk1[{hh}] = sx_cvt_pk_h(r0 - sx_h_lo(pk0[{hh}]), r1 - sx_h_hi(pk0[{hh}]));"]
+                w = 4
+                if hh == 1:
+                    d = f"wa + {qd} * WQA" if isA else f"wb + {q} * WQB"
+                    for p in range(2):
+                        L.append(f"*(u32x2*)({d} + {p} * SX_PLANE) = (u32x2){{pk{p}[0], pk{p}[1]}};")
+                    L.append(f"raw[{qd}] = SX_LOAD_{op}({q});")
+                    if DYA and isA:
+                        L.append(f"SX_DY_LOAD({q});")
+                    w += 3
+                out.append((w, L))
+                continue
             out.append((4, [f"pk0[{hh}] = sx_cvt_pk({x0}, {x1});", f"a1 = __uint_as_float(pk0[{hh}] & 0xffff0000u);",
                             f"r0 = {x0} - __uint_as_float(pk0[{hh}] << 16);"]))
             out.append((2, [f"r1 = {x1} - a1;", f"pk1[{hh}] = sx_cvt_pk(r0, r1);"]))
@@ -64,14 +85,17 @@ def items():
 
 
 def mfma(c):
-    s2, rest = c // (12 * WM), c % (12 * WM)
-    ij, p6 = rest // 6, rest % 6
+    s2, rest = c // (2 * NP6 * WM), c % (2 * NP6 * WM)
+    ij, p6 = rest // NP6, rest % NP6
     i, j = ij >> 1, ij & 1
+    if HALF:
+        return (f"acc[{i}][{j}] = __builtin_amdgcn_mfma_f32_32x32x16_f16(SXH(a[{s2}][{i}][{QA[p6]}]), SXH(b[{s2}][{j}][{QB[p6]}]), "
+                f"acc[{i}][{j}], 0, 0, 0);")
     return f"acc[{i}][{j}] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[{s2}][{i}][{QA[p6]}], b[{s2}][{j}][{QB[p6]}], acc[{i}][{j}], 0, 0, 0);"
 
 
 out = []
-if not VAR:
+if not VAR and not HALF:
     # the round-3 placement: 3 * 2 * (NQA + 4) micro-steps spread evenly BY COUNT (one per slot at WM = 2, one or two at WM = 1);
     # SX_XF_A / SX_XF_B (which expand to nothing in the plain kernel) ride with the first micro-step of their pair
     def micro(m):

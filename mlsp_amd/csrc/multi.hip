@@ -242,10 +242,11 @@ int launch_xf_materialize(hipStream_t st, const float* X, int ldx, int M, int C,
 static bool multi_defer_ok(const mlsp_defer_t& d, const mlsp_seg_t& g) {
     return d.bn_save && d.ld > 0 && d.col == g.x_col && d.col + g.Cin <= d.ld && d.p_drop >= 0.f && d.p_drop < 1.f && d.act >= 0 && d.act <= 2;
 }
-static GemmXf multi_xf(const mlsp_defer_t& in, int which) {
+static GemmXf multi_xf(const mlsp_defer_t& in, int which, int batch_stats) {
     GemmXf x;
     x.scale = in.bn_save + in.col; x.shift = in.bn_save + in.ld + in.col; x.act = in.act; x.slope = in.slope; x.thresh = dropout_thresh8(in.p_drop);
     x.inv_keep = dropout_inv_keep8(in.p_drop); x.seed = in.seed; x.ld = in.ld; x.col = in.col; x.which = which;
+    if (batch_stats) { x.mean = in.bn_save + 2 * in.ld + in.col; x.invstd = in.bn_save + 3 * in.ld + in.col; }     // (api.hip chain_xf)
     return x;
 }
 static bool multi_defer_same(const mlsp_defer_t& a, const mlsp_defer_t& b) {
@@ -294,7 +295,7 @@ static int multi_group_run(const float* X, int ldx, int M, const mlsp_seg_t* seg
 extern "C" {
 
 int mlsp_multimlp_supported(int M, const mlsp_seg_t* segs, int nseg, int precision) {
-    if (precision < 0 || precision > 2) return 0;
+    if (precision < 0 || precision > 3) return 0;
     GemmPrecisionScope prec_scope_(precision);
     int Ctot = 0, xw = 0;
     if (!segs || nseg < 1) return 0;
@@ -353,11 +354,11 @@ int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs
         const float* Xs = X;
         GemmXf xf_s; const GemmXf* xf = nullptr;
         if (in) {
-            xf_s = multi_xf(in[s], 1);
+            xf_s = multi_xf(in[s], 1, training);
             if (fuse[s]) xf = &xf_s;
             else {
                 for (int t = 0; t < run[s]; ++t) {              // (a run without a fused transform: slice by slice into the activated copy)
-                    const GemmXf xt = multi_xf(in[s + t], 1);
+                    const GemmXf xt = multi_xf(in[s + t], 1, training);
                     MCHECK(launch_xf_materialize_ld(st, X + segs[s + t].x_col, ldx, M, segs[s + t].Cin, xt, Xa + segs[s + t].x_col, ldx));
                 }
                 Xs = Xa;
@@ -385,7 +386,7 @@ int mlsp_multimlp_fwd_f32(const float* X, int ldx, int M, const mlsp_seg_t* segs
 // Row panels the fused statistics pass of mlsp_multimlp_bwd_f32(in_stats != NULL) writes: M / 128 when EVERY segment's dgrad (single or
 // block-diagonal, as the backward will launch them) runs on a kernel with that pass, else 0.
 int mlsp_multimlp_bwd_stats_parts(int M, const mlsp_seg_t* segs, int nseg, int ldx, int lddx, int precision) {
-    if (precision < 0 || precision > 2 || !segs || nseg < 1 || nseg > 8) return 0;
+    if (precision < 0 || precision > 3 || !segs || nseg < 1 || nseg > 8) return 0;
     GemmPrecisionScope prec_scope_(precision);
     int Ctot = 0;
     for (int s = 0; s < nseg; ++s) Ctot += segs[s].Cout;
@@ -510,11 +511,11 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
         const float* Xs = X;
         GemmXf xf_s; const GemmXf* xf = nullptr;
         if (in) {
-            xf_s = multi_xf(in[s], 2);
+            xf_s = multi_xf(in[s], 2, training);
             if (fuse[s]) xf = &xf_s;
             else {
                 for (int t = 0; t < G; ++t) {
-                    const GemmXf xt = multi_xf(in[s + t], 2);
+                    const GemmXf xt = multi_xf(in[s + t], 2, training);
                     MCHECK(launch_xf_materialize_ld(st, X + segs[s + t].x_col, ldx, M, segs[s + t].Cin, xt, Xa + segs[s + t].x_col, ldx));
                 }
                 Xs = Xa;

@@ -64,13 +64,13 @@ class gemm_precision(metaclass=_PrecisionMeta):
 
     def __init__(self, mode):
         if mode not in self._MODES:
-            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x6'")
+            raise ValueError("precision must be 'fp32', 'bf16', 'bf16x6' or 'f16x3'")
         self.mode, self.prev = mode, None
 
     @classmethod
     def set(cls, mode):
         if mode not in cls._MODES:
-            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x6'")
+            raise ValueError("precision must be 'fp32', 'bf16', 'bf16x6' or 'f16x3'")
         cls.default = mode
 
     @classmethod
@@ -964,7 +964,7 @@ def _defer_struct(d):
 
 
 def _can_defer(M, dtype):
-    return (_DEFER_CHAINS and activation_storage.current == "fp32" and gemm_precision.current in ("fp32", "bf16x6") and M > 32
+    return (_DEFER_CHAINS and activation_storage.current == "fp32" and gemm_precision.current in ("fp32", "bf16x6", "f16x3") and M > 32
             and dtype == torch.float32)
 
 

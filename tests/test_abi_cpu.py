@@ -283,7 +283,7 @@ def test_gemm_precision_default_and_env_override():
     an unknown name fails at import, loudly."""
     import subprocess, sys
     from mlsp_amd import _lib, functional as Fh
-    assert _lib.GEMM_PRECISION_MODES == {"fp32": 0, "bf16": 1, "bf16x6": 2}
+    assert _lib.GEMM_PRECISION_MODES == {"fp32": 0, "bf16": 1, "bf16x6": 2, "f16x3": 3}
     assert Fh.gemm_precision.current == _lib.DEFAULT_GEMM_PRECISION
     code = "from mlsp_amd import functional as Fh; print(Fh.gemm_precision.current)"
     env = dict(os.environ, PYTHONPATH=ROOT)

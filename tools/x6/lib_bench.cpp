@@ -38,9 +38,9 @@ int main(int argc, char** argv) {
         const size_t wsz = wsb(s.M, s.K, s.N) + (64u << 20);
         CK(hipMalloc(&dA, na * 4)); CK(hipMalloc(&dB, nb * 4)); CK(hipMalloc(&dC, nc * 4)); CK(hipMalloc(&ws, wsz));
         CK(hipMemcpy(dA, A.data(), na * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), nb * 4, hipMemcpyHostToDevice));
-        double us[3] = {0, 0, 0};
+        double us[4] = {0, 0, 0, 0};
         const int reps = argc > 2 ? atoi(argv[2]) : 20;
-        for (int mode = 0; mode <= 2; ++mode) {
+        for (int mode = 0; mode <= 3; ++mode) {
             const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
             for (int i = 0; i < 3; ++i) { int rc = gemm(s.ta, s.tb, s.M, s.N, s.K, dA, lda, dB, ldb, dC, s.N, nullptr, mode, ws, wsz, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
             CK(hipDeviceSynchronize());
@@ -50,8 +50,8 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             us[mode] = ms * 1000.0 / reps;
         }
-        printf("%s M=%6d N=%5d K=%6d   fp32 %7.1f us %6.1f TF | bf16x6 %7.1f us %6.1f TF   %.2fx | bf16 operands %7.1f us %6.1f TF\n", s.name, s.M, s.N, s.K, us[0],
-               2.0 * s.M * s.N * s.K / us[0] * 1e-6, us[2], 2.0 * s.M * s.N * s.K / us[2] * 1e-6, us[0] / us[2], us[1], 2.0 * s.M * s.N * s.K / us[1] * 1e-6);
+        printf("%s M=%6d N=%5d K=%6d   fp32 %7.1f us %6.1f TF | bf16x6 %7.1f us %6.1f TF   %.2fx | f16x3 %7.1f us %6.1f TF  %.2fx of bf16x6 | bf16 operands %7.1f us %6.1f TF\n", s.name, s.M, s.N, s.K, us[0],
+               2.0 * s.M * s.N * s.K / us[0] * 1e-6, us[2], 2.0 * s.M * s.N * s.K / us[2] * 1e-6, us[0] / us[2], us[3], 2.0 * s.M * s.N * s.K / us[3] * 1e-6, us[2] / us[3], us[1], 2.0 * s.M * s.N * s.K / us[1] * 1e-6);
         fflush(stdout);
         CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(ws));
     }
