@@ -27,7 +27,20 @@ FLOP_PER_POINT = 28.19e6        # algorithmic fwd+bwd FLOP per p
 PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md)
-PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6     # fp32-accurate product = six bf16 piece products (gemm_split_kernel)
+PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6     # fp32-accurate product = six bf16 piece products (gemm_split_kernel, mode "bf16x6")
+PEAK_SPLIT3_TFLOPS = PEAK_BF16_TFLOPS / 3    # ... = three f16 piece products (mode "f16x3"; the dense f16 MFMA peak equals the bf16 one)
+
+
+def split_peak(half_launches, split_launches):
+    """(peak TFLOP/s fp32-equivalent, piece products per fp32 product, note) of the launches that ran on gemm_split_kernel: priced against
+    the three-product peak only when EVERY one of them ran on the two-piece f16 products, else against the launch-weighted harmonic mix."""
+    if split_launches <= 0 or half_launches <= 0:
+        return PEAK_SPLIT_TFLOPS, 6.0, "dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product"
+    if half_launches >= split_launches:
+        return PEAK_SPLIT3_TFLOPS, 3.0, "dense f16 MFMA peak 2500 TFLOP/s / 3 piece products per fp32 product (every launch on the two-piece f16 split)"
+    f = half_launches / split_launches
+    pp = 3.0 * f + 6.0 * (1.0 - f)
+    return PEAK_BF16_TFLOPS / pp, pp, "dense 16-bit MFMA peak 2500 TFLOP/s / %.2f piece products per fp32 product (%.0f %% of the launches on the two-piece f16 split, the rest on three bf16 pieces)" % (pp, 100 * f)
 
 
 PMC_WORKLOAD_FILES = {"configs1": r"summary(_v\d+)?\.csv$", "configs4": r"summary_config4(_v\d+)?\.csv$"}
@@ -290,9 +303,10 @@ def profiled_steps(lib, step_fn, nsteps):
     cls = (ctypes.c_double * (3 * PROF_CLASSES))()
     lib.mlsp_profile_classes(cls, PROF_CLASSES)
     rows = [list(cls[3 * c:3 * c + 3]) for c in range(PROF_CLASSES)]
-    kinds = (ctypes.c_double * 12)()
+    kinds = (ctypes.c_double * 16)()
     lib.mlsp_profile_split_kinds(kinds)
     profiled_steps.split_kinds = {k: list(kinds[4 * i:4 * i + 4]) for i, k in enumerate(("fwd", "dgrad", "wgrad"))}    # [ms, launches, FLOP, bytes]
+    profiled_steps.split_half = list(kinds[12:16])                  # the launches of all kinds on the two-piece f16 products
     return rows, list(buf), dt
 
 
@@ -378,8 +392,9 @@ def secondary_workloads(lib, dev):
     f32_ms, f32_flop = g[0] - sp[0], g[2] - sp[2]
     ach_sp = sp[2] / (sp[0] * 1e-3) / 1e12 if sp[0] > 0 else 0.0
     ach32 = f32_flop / (f32_ms * 1e-3) / 1e12 if f32_ms > 0 else 0.0
-    roof = ({"kernel": "gemm_split_kernel<*> (SA-MLP contractions, six bf16 piece products per fp32 product)", "bound": "mfma", "achieved": ach_sp,
-             "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach_sp / PEAK_SPLIT_TFLOPS, "vs_f32_mfma_peak": ach_sp / PEAK_FP32_TFLOPS,
+    sa_peak, _, sa_peak_note = split_peak(profiled_steps.split_half[1], sp[1])
+    roof = ({"kernel": "gemm_split_kernel<*> (SA-MLP contractions, fp32-accurate piece products on the 16-bit matrix cores)", "bound": "mfma", "achieved": ach_sp,
+             "peak": sa_peak, "peak_note": sa_peak_note, "unit": "TFLOP/s", "frac": ach_sp / sa_peak, "vs_f32_mfma_peak": ach_sp / PEAK_FP32_TFLOPS,
              "share_of_step": sp[0] / 2 / ms, "launches_per_step": sp[1] / 2,
              "f32_mfma_launches": {"achieved": ach32, "frac": ach32 / PEAK_FP32_TFLOPS, "share_of_step": f32_ms / 2 / ms,
                                    "launches_per_step": (g[1] - sp[1]) / 2}} if sp[1] > 0 else
@@ -808,12 +823,17 @@ def main():
                              "the enqueueing stream, max over ranks; bus bandwidth = 2 (n - 1) / n x bytes / time" % nbytes}
 
     # the same step with every GEMM on the f32 MFMA, for the record (not the headline): one settle block + the same number of blocks
-    f32_leg, f32_blocks = None, []
-    if Fh.gemm_precision.current == "bf16x6" and not a.no_fp32_leg:
+    f32_leg, f32_blocks, x6_leg, x6_blocks = None, [], None, []
+    if Fh.gemm_precision.current in ("bf16x6", "f16x3") and not a.no_fp32_leg:
         with Fh.gemm_precision("fp32"):
             timed_block()
             f32_blocks = [timed_block()[0] for _ in range(max(1, a.repeats))]
         f32_leg = sorted(f32_blocks)[len(f32_blocks) // 2]
+        if Fh.gemm_precision.current == "f16x3":                     # ... and on the six-product bf16 split (the round 3-5 default)
+            with Fh.gemm_precision("bf16x6"):
+                timed_block()
+                x6_blocks = [timed_block()[0] for _ in range(max(1, a.repeats))]
+            x6_leg = sorted(x6_blocks)[len(x6_blocks) // 2]
 
     if rank == 0:
         pts = b_local * NPTS * n_gpus * a.steps
@@ -829,10 +849,15 @@ def main():
                                       "(BASELINE.json configs[1]), dropout 0.5, BN train" % b_local,
                           "global_batch": b_local * n_gpus, "points_per_cloud": NPTS, "k": K_NN,
                           "parallelism": "dp%d" % n_gpus, "grad_allreduce": "1 x flat 18.2 MB fp32 per step (RCCL); no host-side exchange (presence='uniform', verified in-band)",
-                          "gemm_products": "%s (bf16x6 = fp32 operands split exactly into three bf16 pieces, six piece products, fp32 "
-                                           "accumulation: error vs float64 below the f32-MFMA chain's, tests/test_gpu_kernels.py::"
-                                           "test_gemm_split_bf16_accuracy; MLSP_GEMM_PRECISION=fp32 runs every GEMM on the f32 MFMA)"
-                                           % Fh.gemm_precision.current}}
+                          "gemm_products": "%s (f16x3 = fp32 operands, scaled by a per-workgroup power of two, split into two f16 pieces (11 + 11 "
+                                           "bits), three piece products, fp32 accumulation; bf16x6 = three bf16 pieces, six piece products.  "
+                                           "Either way an fp32 computation: error vs float64 below the f32-MFMA chain's, tests/test_gpu_kernels.py::"
+                                           "test_gemm_split_bf16_accuracy holds both to the same bar; MLSP_GEMM_PRECISION=fp32 runs every GEMM on "
+                                           "the f32 MFMA, =bf16x6 on the six-product split)" % Fh.gemm_precision.current}}
+        if x6_leg is not None:
+            out["bf16x6_split"] = {"ms_per_step": 1e3 * x6_leg / a.steps, "value": pts / x6_leg,
+                                   "note": "the same step with the GEMM family on the six-product bf16 split (gemm_precision('bf16x6'), the "
+                                           "round 3-5 default): median of %d blocks of %d steps, same process" % (len(x6_blocks), a.steps)}
         if f32_leg is not None:
             out["fp32_mfma"] = {"ms_per_step": 1e3 * f32_leg / a.steps, "value": pts / f32_leg,
                                 "note": "the same step with every GEMM on the f32 MFMA (gemm_precision('fp32')): median of %d blocks "
@@ -877,7 +902,9 @@ def main():
                     by_kind[kname] = e
                 if pmc_kind and n_all:
                     traffic, traffic_src = tr_all / n_all, pmc_src
-                out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
+                half = getattr(profiled_steps, "split_half", [0.0, 0.0, 0.0, 0.0])
+                sp_peak, sp_pp, sp_peak_note = split_peak(half[1], sp[1])
+                out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": sp_peak, "unit": "TFLOP/s", "frac": ach / sp_peak,
                                    "traffic": traffic, "traffic_source": "committed profile (%s), not measured in this run" % traffic_src,
                                    "algorithmic_bytes_per_launch": alg_all / n_all if n_all else None,
                                    "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, %s) and algorithmic bytes per launch (A + B + C, "
@@ -885,9 +912,9 @@ def main():
                                                    "gemm_split_kernel, weighted by this run's launch mix; `by_kind` has them per instantiation "
                                                    "(fwd / dgrad / wgrad)" % traffic_src,
                                    "by_kind": by_kind,
-                                   "kernel": "gemm_split_kernel<*> (fp32-accurate products as six bf16 MFMA piece products: fwd, dgrad, wgrad)",
-                                   "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product",
-                                   "executed_bf16_tflops": 6 * ach, "vs_f32_mfma_peak": ach / PEAK_FP32_TFLOPS,
+                                   "kernel": "gemm_split_kernel<*> (fp32-accurate products as 16-bit MFMA piece products: fwd, dgrad, wgrad)",
+                                   "peak_note": sp_peak_note, "launches_on_f16_pieces_per_step": half[1] / prof_steps,
+                                   "executed_16bit_tflops": sp_pp * ach, "vs_f32_mfma_peak": ach / PEAK_FP32_TFLOPS,
                                    "launches": int(sp[1]), "launches_per_step": sp[1] / prof_steps, "avg_us": 1e3 * sp[0] / sp[1],
                                    "share_of_step": sp[0] / prof_steps / step_ms,
                                    "note": common_note + "; the kernel is clock(DVFS)-limited on real operands: the same launches on zero-filled "
@@ -944,7 +971,8 @@ def main():
         step_s = dt / a.steps
         out["executed_tflops"] = exec_flop / step_s / 1e12
         out["executed_mfma_frac"] = out["executed_tflops"] / PEAK_FP32_TFLOPS
-        out["executed_bf16_tflops"] = 6 * split_flop / step_s / 1e12          # the split GEMMs' piece products
+        half_ = getattr(profiled_steps, "split_half", [0.0, 0.0, 0.0, 0.0]) if prof and prof[1] > 0 else [0.0, 0.0, 0.0, 0.0]
+        out["executed_16bit_tflops"] = (6 * (split_flop - half_[2] / prof_steps) + 3 * half_[2] / prof_steps) / step_s / 1e12   # the split GEMMs' piece products
         out["reference_flop_equivalent_frac"] = value / n_gpus * FLOP_PER_POINT / 1e12 / PEAK_FP32_TFLOPS
         if counted and "launches_per_step" in counted:
             out["launches_per_step"] = counted["launches_per_step"]

@@ -53,6 +53,13 @@ typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
 #define MLSP_PREC_F32 0
 #define MLSP_PREC_BF16 1
 #define MLSP_PREC_BF16X6 2
+/* ABI v13.  fp32-accurate products on the f16 matrix cores with HALF the matrix work of MLSP_PREC_BF16X6: every fp32 operand value, times a
+ * per-workgroup power of two, is split into two f16 pieces (11 + 11 significand bits) and a product is three piece products with fp32
+ * accumulation.  The scale comes from a bound of the operand's magnitude: measured (one streaming launch per operand and call, partial
+ * maxima in the last 64 KiB of the call's workspace) or analytic (an operand that is transformed by batch-statistics BatchNorm on the fly);
+ * a launch without a bound (no workspace tail, eval-mode transform) runs the six-product bf16 split instead.  Same accuracy class as
+ * MLSP_PREC_BF16X6 (tests/test_gpu_kernels.py::test_gemm_split_bf16_accuracy holds both to the same bar against float64). */
+#define MLSP_PREC_F16X3 3
 
 int mlsp_abi_version(void);
 const char* mlsp_strerror(int code);
@@ -410,7 +417,8 @@ int mlsp_profile_end(double* out);
  * bf16-split kernel (mode 2; algorithmic FLOP, each executed as six bf16 MFMA products). */
 #define MLSP_PROF_CLASSES 8
 int mlsp_profile_classes(double* out, int ncls);
-/* out [3][4]: {ms, launches, algorithmic FLOP, algorithmic bytes} of the bracket's gemm_split_kernel launches by kind (forward, dgrad, wgrad). */
+/* out [4][4]: {ms, launches, algorithmic FLOP, algorithmic bytes} of the bracket's gemm_split_kernel launches by kind (forward, dgrad, wgrad);
+ * row 3 (ABI v13): those of all kinds that ran on the two-piece f16 products (MLSP_PREC_F16X3). */
 int mlsp_profile_split_kinds(double* out);
 
 /* Adam step (PointDA/trainer.py:258-259, stepped at :571) over flat parameter / exp_avg / exp_avg_sq buffers P / M / V in ONE launch:

@@ -120,11 +120,13 @@ class MlspLibraryError(RuntimeError):
     pass
 
 
-# GEMM products (include/mlsp_hip.h `precision`, a per-call argument; functional.gemm_precision chooses what the mirror passes).  Default "bf16x6": fp32-accurate
-# products on the bf16 matrix cores (three-way exact operand split, six piece products, fp32 accumulation; measured error below the
-# f32-MFMA chain's).  MLSP_GEMM_PRECISION=fp32 selects the f32 MFMA for every launch; an unknown name fails loudly at import.
+# GEMM products (include/mlsp_hip.h `precision`, a per-call argument; functional.gemm_precision chooses what the mirror passes).  Default "f16x3"
+# (round 6): fp32-accurate products on the f16 matrix cores -- every operand value, scaled by a per-workgroup power of two, split into two
+# f16 pieces, three piece products, fp32 accumulation; "bf16x6": the same on the bf16 cores with three pieces / six products (no scale
+# needed; the round 3-5 default).  Both measure below the f32-MFMA chain's error against float64.  MLSP_GEMM_PRECISION=fp32 selects the f32
+# MFMA for every launch; an unknown name fails loudly at import.
 GEMM_PRECISION_MODES = {"fp32": 0, "bf16": 1, "bf16x6": 2, "f16x3": 3}
-DEFAULT_GEMM_PRECISION = os.environ.get("MLSP_GEMM_PRECISION", "bf16x6")
+DEFAULT_GEMM_PRECISION = os.environ.get("MLSP_GEMM_PRECISION", "f16x3")
 if DEFAULT_GEMM_PRECISION not in GEMM_PRECISION_MODES:
     raise ValueError("MLSP_GEMM_PRECISION=%r: expected one of %s" % (DEFAULT_GEMM_PRECISION, sorted(GEMM_PRECISION_MODES)))
 

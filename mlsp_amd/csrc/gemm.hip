@@ -1742,21 +1742,24 @@ extern "C" int mlsp_profile_classes(double* out, int ncls) {
     return MLSP_OK;
 }
 
-// out [3][4] = {milliseconds, launches, algorithmic FLOP, algorithmic A + B + C bytes (split-K slabs: written and read once more)} of the
+// out [4][4] = {milliseconds, launches, algorithmic FLOP, algorithmic A + B + C bytes (split-K slabs: written and read once more)} of the
 // launches of the last bracket that ran on gemm_split_kernel, by kind: 0 forward (A row-major, B = W as stored), 1 dgrad, 2 wgrad
-// (k-major A).  bench.py prices each kind's HBM-side bytes (rocprofv3 --pmc, per template instantiation) against these.
+// (k-major A); row 3: the subset of all kinds that ran on the two-piece f16 products (mode 3).  bench.py prices each kind's HBM-side bytes
+// (rocprofv3 --pmc, per template instantiation) against these.
 extern "C" int mlsp_profile_split_kinds(double* out) {
     if (!out || g_prof.on) return MLSP_ERR_ARG;
-    for (int i = 0; i < 12; ++i) out[i] = 0.0;
+    for (int i = 0; i < 16; ++i) out[i] = 0.0;
     for (size_t i = 0; i < g_prof.used; ++i) {
         const auto& r = g_prof.rec[i];
         if (!r.split) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
         const int kind = r.ta ? 2 : (r.tb ? 0 : 1);
+        const double fl = 2.0 * r.M * (double)r.N * r.K;
+        const double by = 4.0 * ((double)r.M * r.K + (double)r.K * r.N + (double)r.M * r.N * (r.ns > 1 ? 2.0 * r.ns + 1.0 : 1.0));
         double* o = out + 4 * kind;
-        o[0] += t; o[1] += 1.0; o[2] += 2.0 * r.M * (double)r.N * r.K;
-        o[3] += 4.0 * ((double)r.M * r.K + (double)r.K * r.N + (double)r.M * r.N * (r.ns > 1 ? 2.0 * r.ns + 1.0 : 1.0));
+        o[0] += t; o[1] += 1.0; o[2] += fl; o[3] += by;
+        if (r.split == 2) { out[12] += t; out[13] += 1.0; out[14] += fl; out[15] += by; }     // (row 3: those on the two-piece f16 products)
     }
     return MLSP_OK;
 }
@@ -1933,7 +1936,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     // they lie in memory (measured by ONE streaming launch here, or earlier in this API call), the analytic bound for a transformed one
     // (batch statistics at hand).  Anything missing: the three-piece bf16 products (same kernel family, same accuracy class).
     bool half = false;
-    if (tl_split_half && tl_amax.base && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && (!xf || xf_split) && !(ta && tb)) {
+    if (tl_split_half && tl_amax.base && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && (!xf || xf_split)) {
         AmaxBatch batch;
         bool ok = true;
         if (xf && xf->which == 1) ok = xf->mean && xf->invstd;
@@ -2031,7 +2034,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
         const bool on_split = fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && (!xf || xf_split);
-        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0), on_split ? 1 : 0};
+        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0), on_split ? (half ? 2 : 1) : 0};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;
         g_prof.bytes += 4.0 * ((double)M * K + (double)K * N + (C ? (double)M * N : 0.0));

@@ -279,7 +279,7 @@ def test_activation_storage_is_scoped_like_gemm_precision():
 
 
 def test_gemm_precision_default_and_env_override():
-    """The Python mirror passes "bf16x6" (fp32-accurate split products) unless told otherwise; MLSP_GEMM_PRECISION overrides the process default and
+    """The Python mirror passes "f16x3" (fp32-accurate split products, two f16 pieces) unless told otherwise; MLSP_GEMM_PRECISION overrides the process default and
     an unknown name fails at import, loudly."""
     import subprocess, sys
     from mlsp_amd import _lib, functional as Fh
@@ -288,7 +288,7 @@ def test_gemm_precision_default_and_env_override():
     code = "from mlsp_amd import functional as Fh; print(Fh.gemm_precision.current)"
     env = dict(os.environ, PYTHONPATH=ROOT)
     env.pop("MLSP_GEMM_PRECISION", None)
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "bf16x6"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "f16x3"
     env["MLSP_GEMM_PRECISION"] = "fp32"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "fp32"
     env["MLSP_GEMM_PRECISION"] = "fp16"

@@ -80,8 +80,8 @@ def test_one_rccl_allreduce_per_step_bit_identical(rccl_world1):
         syncs.append(sync)
 
     sync = syncs[1]
-    # (the bucket carries four check words behind the gradients: the pattern hashes of the uniform-presence verification, ddp.py)
-    assert sync.world_size == 1 and sync.collectives == 3 and calls == [sync.numel + 4] * 3, (sync.collectives, calls)
+    # (the bucket carries the check words behind the gradients: the pattern hashes of the uniform-presence verification, ddp.py)
+    assert sync.world_size == 1 and sync.collectives == 3 and calls == [sync.numel + sync._NCHK] * 3, (sync.collectives, calls)
     assert sync.numel == sum(p.numel() for p in models[1].parameters() if p.requires_grad) == 4548899   # 18.2 MB
     absent = [n for n, p in models[1].named_parameters() if p.requires_grad and p.grad is None]
     assert absent and all(n.startswith("Rec_scan.") for n in absent), absent       # the head that never runs is skipped, not zero-stepped

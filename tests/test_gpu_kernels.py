@@ -296,8 +296,12 @@ def test_gemm_matches_fma_chain_bitwise(dev):
                                           (False, True, 4096, 1024, 128), (False, True, 32768, 1024, 512), (False, False, 65536, 1024, 128),
                                           (True, True, 256, 256, 16384), (True, False, 1024, 512, 32768), (True, False, 2048, 2048, 512),
                                           (True, True, 2048, 2560, 256), (False, False, 2048, 2048, 512)])
-def test_gemm_split_bf16_accuracy(dev, ta, tb, M, N, K):
-    """gemm_precision("bf16x6"): products as six bf16 piece products on the bf16 matrix cores.  Against float64 its error must be at the
+@pytest.mark.parametrize("mode,scale", [("bf16x6", 1.0), ("f16x3", 1.0), ("f16x3", 1e-6), ("f16x3", 3e5)])
+def test_gemm_split_bf16_accuracy(dev, ta, tb, M, N, K, mode, scale):
+    """gemm_precision("bf16x6"): products as six bf16 piece products on the bf16 matrix cores; gemm_precision("f16x3"): as THREE f16 piece
+    products (two 11-bit pieces per operand, scaled by a per-workgroup power of two taken from the operands' measured magnitudes -- also
+    with the operands at 1e-6 and 3e5 of their size: the scale, not the f16 range, decides).  The bar is the same for both.
+    Against float64 its error must be at the
     level of the exact-fp32 MFMA kernel's (both are fp32 accumulations of products exact to <= 2^-25): <= 2x that error and
     <= 2e-6 relative L2 on random operands with a wide dynamic range.  The shapes cover both tile heights (64 / 128 rows), split-K, and
     all four operand layouts (row-major images read with ds_read_b128, k-major images read with ds_read_b64_tr_b16), the last three with a
@@ -305,18 +309,18 @@ def test_gemm_split_bf16_accuracy(dev, ta, tb, M, N, K):
     Fh = _fh()
     g = torch.Generator().manual_seed(11)
     shpA, shpB = ((K, M) if ta else (M, K)), ((N, K) if tb else (K, N))
-    A = (torch.randn(shpA, generator=g) * torch.exp(2.0 * torch.randn(shpA, generator=g))).to(dev)
-    B = (torch.randn(shpB, generator=g) * torch.exp(2.0 * torch.randn(shpB, generator=g))).to(dev)
+    A = (torch.randn(shpA, generator=g) * torch.exp(2.0 * torch.randn(shpA, generator=g))).to(dev) * scale
+    B = (torch.randn(shpB, generator=g) * torch.exp(2.0 * torch.randn(shpB, generator=g))).to(dev) * scale
     ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
     with Fh.gemm_precision("fp32"):
         exact = Fh.gemm(A, B, ta, tb).double()
-    with Fh.gemm_precision("bf16x6"):
+    with Fh.gemm_precision(mode):
         split = Fh.gemm(A, B, ta, tb).double()
     e32 = ((exact - ref).norm() / ref.norm()).item()
     e6 = ((split - ref).norm() / ref.norm()).item()
     m32 = ((exact - ref).abs().max() / ref.abs().max()).item()
     m6 = ((split - ref).abs().max() / ref.abs().max()).item()
-    print("rel-L2 vs float64: fp32 MFMA %.2e, bf16x6 %.2e | max-abs / max: %.2e, %.2e" % (e32, e6, m32, m6))
+    print("rel-L2 vs float64: fp32 MFMA %.2e, %s %.2e | max-abs / max: %.2e, %.2e" % (e32, mode, e6, m32, m6))
     assert not torch.equal(exact, split)                               # it really ran the other kernel
     assert e6 < 2e-6 and e6 < 2.0 * e32 + 1e-8, (e6, e32)
     assert m6 < 2.0 * m32 + 1e-7, (m6, m32)
@@ -945,7 +949,7 @@ def test_tnet_backward_gram_form_vs_round1_kernel(dev, B, N, k):
 
 
 @pytest.mark.parametrize("fused_stats", [False, True])
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("M,C0,C1,C2,training,clouds", [(4096, 128, 256, 128, True, 0), (8192, 512, 256, 256, True, 0), (1000, 96, 80, 64, True, 0),
                                                         (4096, 128, 256, 128, False, 0), (16384, 256, 1024, 512, True, 0),
                                                         (2048, 512, 512, 256, True, 0), (8192, 128, 256, 256, True, 8), (4096, 64, 512, 256, True, 16)])
@@ -984,7 +988,13 @@ def test_pointmlp_deferred_activation_chain(dev, M, C0, C1, C2, training, clouds
         a, b = run(True), run(False)
     names = ["out", "dX", "dW1", "dW2", "dW3", "dg1", "db1", "dg2", "db2", "rm1", "rv1", "rm2", "rv2", "dcloudbias"]
     for n, x, y in zip(names, a, b):
-        if not fused_stats or n in ("out", "rm1", "rv1", "rm2", "rv2"):
+        if mode == "f16x3":
+            # two-piece f16 products: the deferred path scales a transformed operand by its ANALYTIC bound (batch statistics), the
+            # materialised path by the measured magnitude -- another power of two: the same pieces except for elements that reach the f16
+            # subnormals under one scale and not the other (< 2^-40 of the operand's largest magnitude).  Rounding-level agreement.
+            err = (x - y).double().norm().item()
+            assert err <= 2e-5 * max(y.double().norm().item(), 1e-3 * a[names.index("dg" + n[-1])].double().norm().item() if n.startswith("db") else 1e-30), (n, err)
+        elif not fused_stats or n in ("out", "rm1", "rv1", "rm2", "rv2"):
             assert torch.equal(x, y), (n, (x - y).abs().max().item())
         else:
             # fused statistics (the consumers' dgrads leave the producer's BatchNorm-backward sums: gemm_out_bs): the masked gradient is
@@ -995,7 +1005,7 @@ def test_pointmlp_deferred_activation_chain(dev, M, C0, C1, C2, training, clouds
 
 
 @pytest.mark.parametrize("fused_stats", [False, True])
-@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32", "f16x3"])
 @pytest.mark.parametrize("M,training", [(2048, True), (16384, True), (4096, False), (1100, True)])
 def test_merged_layers_deferred_activation_chain(dev, M, training, mode, fused_stats, monkeypatch):
     """The head stack of PointDA/Models.py:192-197, 226-231, 272-285 as the model runs it: one wide first layer (pointmlp), two merged
@@ -1053,6 +1063,11 @@ def test_merged_layers_deferred_activation_chain(dev, M, training, mode, fused_s
             # fused BatchNorm-backward statistics: same masked gradients, column sums in another order (see the test above)
             rel = ((x - y).double().norm() / (y.double().norm() + 1e-30)).item()
             assert rel < 1e-4, (i, tuple(x.shape), rel)
+        elif mode == "f16x3":
+            # (another power-of-two operand scale on the deferred path: see test_pointmlp_deferred_activation_chain; a last-bit difference
+            # in a pre-activation can flip a ReLU unit, as in mode "fp32" below)
+            rel = ((x - y).double().norm() / (y.double().norm() + 1e-30)).item()
+            assert rel < (1e-5 if i < 3 or i >= len(a) - 6 else 5e-3), (i, tuple(x.shape), rel)
         else:
             # mode "fp32": the f32 transform kernels take no block-diagonal launch, so the deferred path runs the two region-head segments
             # one by one -- with another row-panel height, i.e. another grouping of the BatchNorm partial sums: last-bit differences
@@ -1063,7 +1078,7 @@ def test_merged_layers_deferred_activation_chain(dev, M, training, mode, fused_s
 
 
 @pytest.mark.parametrize("subset", [(0,), (2,), (0, 2), (0, 1)])
-@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32", "f16x3"])
 def test_deferred_chain_loss_on_a_subset_of_the_consumers(dev, subset, mode, monkeypatch):
     """The reference trainer runs all three heads (activate_density_normal_ondef=True) and gates the Normal / density losses on
     args.Normal_ondef / args.Density_ondef (PointDA/trainer.py:551-565): the backward then reaches only SOME of the final Linear layers.

@@ -299,8 +299,8 @@ def _run_recording_graphs(monkeypatch, Fh, fn):
 
 
 def test_gemm_product_modes_agree_on_bench_step(dev, monkeypatch):
-    """BASELINE.json configs[1] size, the same step under gemm_precision "bf16x6" (default: fp32-accurate products on the bf16 cores)
-    and "fp32" (f32 MFMA) with the first mode's neighbour graphs forced on the second: both are fp32 computations of the same network,
+    """BASELINE.json configs[1] size, the same step under gemm_precision "bf16x6" (fp32-accurate products on the bf16 cores), "f16x3"
+    (the same on the f16 cores with two pieces) and "fp32" (f32 MFMA) with the first mode's neighbour graphs forced on the second: both are fp32 computations of the same network,
     so the logits agree to 1e-4 relative L2 (measured 2.5e-5 on the deepest output, cls: two different fp32 rounding sequences through
     ten BatchNorm'd layers; the parity contract against the oracle is 1e-3), the losses to 1e-4."""
     from mlsp_amd import functional as Fh
@@ -310,7 +310,7 @@ def test_gemm_product_modes_agree_on_bench_step(dev, monkeypatch):
     m.train()
     out = {}
     graphs = None
-    for mode in ("bf16x6", "fp32"):
+    for mode in ("bf16x6", "fp32", "f16x3"):
         mm = copy.deepcopy(m)
         with Fh.gemm_precision(mode):
             if graphs is None:
@@ -320,15 +320,16 @@ def test_gemm_product_modes_agree_on_bench_step(dev, monkeypatch):
                     logits = mm(ginp["x"], activate_density_normal_ondef=True)
             loss, parts = _gpu_total_loss(gc.make_args(cuda=True), logits, ginp)
         out[mode] = ({k: logits[k].detach().double() for k in HEAD_KEYS}, loss.item(), {k: v.item() for k, v in parts.items()})
-    for k in HEAD_KEYS:
-        a, b = out["bf16x6"][0][k], out["fp32"][0][k]
-        rel = ((a - b).norm() / b.norm()).item()
-        print("%s: rel-L2 between the product modes %.2e" % (k, rel))
-        assert rel < 1e-4, (k, rel)
-        assert (a - b).abs().max().item() < 1e-3 * max(1.0, b.abs().max().item()), k
-    np.testing.assert_allclose(out["bf16x6"][1], out["fp32"][1], rtol=1e-4)
-    for k, v in out["bf16x6"][2].items():
-        np.testing.assert_allclose(v, out["fp32"][2][k], rtol=1e-4, atol=1e-6, err_msg=k)
+    for other in ("bf16x6", "f16x3"):
+        for k in HEAD_KEYS:
+            a, b = out[other][0][k], out["fp32"][0][k]
+            rel = ((a - b).norm() / b.norm()).item()
+            print("%s: rel-L2 between the product modes %s and fp32 %.2e" % (k, other, rel))
+            assert rel < 1e-4, (other, k, rel)
+            assert (a - b).abs().max().item() < 1e-3 * max(1.0, b.abs().max().item()), (other, k)
+        np.testing.assert_allclose(out[other][1], out["fp32"][1], rtol=1e-4)
+        for k, v in out[other][2].items():
+            np.testing.assert_allclose(v, out["fp32"][2][k], rtol=1e-4, atol=1e-6, err_msg=other + " " + k)
 
 
 # Free-running parity (nothing forced): the dynamic graph is discontinuous -- a last-bit difference in a feature flips a near-tied
