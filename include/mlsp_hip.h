@@ -159,9 +159,11 @@ int mlsp_pointmlp_fwd_chain_f32(const float* Xpre, int ldx, const mlsp_defer_t* 
  * produced by its CONSUMER's dgrad; that launch (gemm_split_kernel's output pass, the small-K streaming kernel) can multiply it by the
  * producer's activation derivative and dropout mask right there, store the masked gradient d' and leave the producer's column sums of
  * d' and d' * yhat per 128-row panel: the producer's streaming reduction pass (a full read of dZ and Y) disappears.
- *   consumer: in_stats != NULL ([M / 128][2][in->ld] doubles, indexed by the producer's column) -- legal when
+ *   consumer: in_stats != NULL ([M / 128][2][in->ld] doubles, indexed by the producer's column, FOLLOWED (ABI v13) by [M / 128][in->ld]
+ *             floats: the panels' column maxima of |d'|, a bound the producer's two-piece f16 products need) -- legal when
  *             mlsp_*_bwd_stats_parts() > 0 for the layer; dX then holds d', not dZ;
- *   producer: pre_stats != NULL ([pre_parts][2][Cout]) -- dZ is d', its sums are given: finalisation + the BatchNorm part only;
+ *   producer: pre_stats != NULL ([pre_parts][2][Cout] doubles + [pre_parts][Cout] floats, as the consumers left them) -- dZ is d', its sums
+ *             are given: finalisation + the BatchNorm part only;
  *             pre_stats == NULL with pre_parts < 0 (ABI v13) -- dZ is d' but its sums are INCOMPLETE: only some consumers took part in this
  *             backward pass (a loss on a subset of the heads, PointDA/trainer.py:551-565), the columns of the others are zero.  The
  *             call reduces the sums itself and does not apply the activation derivative / dropout mask a second time.

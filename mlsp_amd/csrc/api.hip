@@ -707,7 +707,7 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     size_t sf = sf1 > sf2 ? sf1 : sf2;
     float* slab = sf ? w.take<float>(sf) : nullptr;
     float* gscratch = dgbias ? w.take<float>((size_t)n_groups * 16 * Cout) : nullptr;
-    float* coef = has_bn ? w.take<float>((size_t)3 * Cout) : nullptr;
+    float* coef = has_bn ? w.take<float>((size_t)4 * Cout) : nullptr;      // c0 | nk2 | sc | max |d'| (bn.hip bn_bwd_finalize_coef_kernel)
     const float* Xorig = X; const int ldx_orig = ldx;   // the previous layer's pre-BN output (fused statistics read it as it is)
     GemmXf xf_s; const GemmXf* xf = nullptr;            // chained input: the wgrad reads the previous layer's pre-BN output
     if (in) {
@@ -728,7 +728,7 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     // A operand loads (gemm.hip gemm_split_kernel<.., DY>) the apply pass and the dY tensor are skipped; the per-cloud bias gradient comes
     // from the row-panel sums of d' and the clouds' column sums of y (bn.hip launch_bn_dy_gbias)
     static const bool dy_off = getenv("MLSP_BWD_DY_OFF") != nullptr;        // read-once A/B switch (tools/ab)
-    GemmDy dy_s = {Y, coef, Cout}; const GemmDy* dy = nullptr;
+    GemmDy dy_s = {Y, coef, Cout, 1}; const GemmDy* dy = nullptr;          // (the finalizers below fill the fourth coefficient row)
     if (has_bn && M > 32 && pre_stats && training && !dy_off && (!in || xf) && M % pre_parts == 0 &&
         (!dX || gemm_dy_supported(false, false, M, Cin, Cout, dZ, Cout, W, ldw)) && gemm_dy_supported(true, false, Cout, Cin, M, dZ, Cout, X, ldx) &&
         (!dgbias || (rows_per_group >= 256 && rows_per_group % (M / pre_parts) == 0 && Cout % 4 == 0 && 256 % (Cout / 4) == 0 && Cout <= 1024)))
@@ -761,6 +761,7 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
     if (in_stats) {
         bs_s = {Xorig, ldx_orig, in->bn_save + in->col, in->ld, in->act, in->slope, dropout_thresh8(in->p_drop), dropout_inv_keep8(in->p_drop), in->seed,
                 in->ld, in->col, in_stats + in->col, in->ld};
+        bs_s.amax = (float*)(in_stats + (size_t)(M / 128) * 2 * in->ld) + in->col;      // the maxima plane behind the [M / 128][2][ld] sums
         bs = &bs_s;
     }
     static const bool no_pair = getenv("MLSP_SKINNY_NO_PAIR") != nullptr;          // read-once A/B switch

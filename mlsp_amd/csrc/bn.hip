@@ -622,10 +622,23 @@ int launch_bn_act_bwd(hipStream_t st, const float* dZ, const float* Y, float* dY
 __global__ void bn_bwd_finalize_coef_kernel(const double* __restrict__ part, int nparts, double count, int C, const float* __restrict__ bn,
                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
                                             const float* __restrict__ gys, int ppg, int rows, float* __restrict__ gout,
-                                            float* __restrict__ zero_vec = nullptr) {
+                                            float* __restrict__ zero_vec = nullptr, int with_amax = 0) {
+    // with_amax: behind the nparts x 2 x C sums lie nparts x C floats -- the panels' column maxima of |d'| (gemm.hip gemm_out_bs, thin.hip):
+    // their maximum becomes the FOURTH coefficient row (a bound of d' per channel for the two-piece f16 products of the layer's GEMMs)
     const int c = blockIdx.x;
     double s, q;
     fin_part_sums(part, nparts, C, c, s, q);
+    if (with_amax) {
+        __shared__ float amred[FIN_THREADS / 64];
+        const float* plane = (const float*)(part + (size_t)nparts * 2 * C);
+        float m = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += FIN_THREADS) m = fmaxf(m, plane[(size_t)i * C + c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) amred[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) coef[3 * C + c] = fmaxf(fmaxf(amred[0], amred[1]), fmaxf(amred[2], amred[3]));
+    }
     const double k2 = (double)bn[3 * C + c] * (q / count);
     const float c0 = (float)((double)bn[2 * C + c] * k2 - s / count), nk2 = (float)(-k2), sc = bn[c];
     if (gout)
@@ -643,10 +656,11 @@ __global__ void bn_bwd_finalize_coef_kernel(const double* __restrict__ part, int
     coef[2 * C + c] = sc;
 }
 
+// (coef: FOUR rows of pitch C -- c0 | nk2 | sc | max |d'| per channel, the last from the maxima plane behind the sums: include/mlsp_hip.h)
 int launch_bn_bwd_finalize_coef_z(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
                                   float* dbeta, float* coef, float* zero_vec) {
     hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, bn_save, dgamma, dbeta, coef,
-                       (const float*)nullptr, 1, 0, (float*)nullptr, zero_vec);
+                       (const float*)nullptr, 1, 0, (float*)nullptr, zero_vec, 1);
     return mlsp_launch_status();
 }
 int launch_bn_bwd_finalize_coef(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
@@ -657,7 +671,7 @@ int launch_bn_bwd_finalize_coef_groups(hipStream_t st, const double* part, int n
                                        float* dbeta, float* coef, const float* gys, int ppg, int rows, float* gout) {
     if (!gys || !gout || ppg <= 0 || nparts % ppg) return MLSP_ERR_ARG;
     hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, bn_save, dgamma, dbeta, coef, gys,
-                       ppg, rows, gout, (float*)nullptr);
+                       ppg, rows, gout, (float*)nullptr, 1);
     return mlsp_launch_status();
 }
 

@@ -97,12 +97,13 @@ struct GemmXf {
 struct GemmBs {
     const float* y; int ldy; const float* bn; int bnld; int act; float slope; uint32_t thresh; float inv_keep; uint64_t seed; int ld; int col;
     double* part; int stat_ld;
+    float* amax = nullptr;          // nullable: [row panels][stat_ld] floats at C's column 0: column maxima of |d'| per panel (a by-product for the producer)
 };
 
 // A layer's BatchNorm backward applied to a GEMM's A operand while it is staged (gemm.hip GemmArgs dy_*, gemm_split_kernel<.., DY>): A holds the
 // masked gradient d' that the consumer's dgrad left (GemmBs), y the layer's pre-BN output at the same coordinates and pitch, coef the rows
 // c0 | nk2 | sc (pitch cld; bn.hip bn_bwd_finalize_kernel) at A's channel 0:  dY = (d' + y * nk2 + c0) * sc.
-struct GemmDy { const float* y; const float* coef; int cld; };
+struct GemmDy { const float* y; const float* coef; int cld; int amax = 0; };       // amax: coef has a FOURTH row, max |d'| per channel
 
 // Block-diagonal product in one GEMM launch (gemm.hip GemmArgs groups).  mode 1: output COLUMNS are grouped (forward: A = X + g * a_gs,
 // B = Bg[g] = W_g; dgrad alike); mode 2: output ROWS are grouped (wgrad: B = X + g * b_gs; A and C take the launch-wide row index).

@@ -58,6 +58,9 @@ struct GemmArgs {
     // BatchNorm backward dY = (d' + y * nk2[c] + c0[c]) * sc[c] is applied while the tile is staged: the streaming "apply" pass and the
     // dY tensor disappear.  dy_coef: rows c0 | nk2 | sc (pitch dy_cld) at A's channel 0 (dgrad: channel = k; wgrad: channel = m).
     const float* dy_y; const float* dy_coef; int dy_cld;
+    // bs_amax (with bs_y; nullable): per-row-panel column maxima of |d'| [ntm][stat_ld] floats at C's column 0 -- a by-product for the
+    // PRODUCER's backward, whose two-piece f16 products need a bound of d' (dy_amax: its coefficient rows carry a fourth row, max |d'| per channel)
+    float* bs_amax; int dy_amax;
     // gemm_split_kernel<.., NPC = 2> (two f16 pieces): device-side upper bounds of |A| and |B| (after the operand transforms), nullable = scale 1
     // Partial maxima of |A| / |B| as they lie in memory (amax_partials_kernel; null / 0 where the bound is analytic), and what the analytic
     // bounds need: a transformed operand (XF, batch statistics over stat_rows rows) is bounded per channel by |scale| sqrt(rows) / invstd +
@@ -204,7 +207,7 @@ __device__ __forceinline__ void gemm_out_fast(const GemmArgs& p, f32x16 (&acc)[2
 // across waves and panels (the streaming reduction summed in fp64 throughout: the sums agree to ~1e-7 relative).
 template <int WM>
 __device__ __forceinline__ void gemm_out_bs(const GemmArgs& p, f32x16 (&acc)[2][2], float* Cw, const float* Yw, int colw, int row0, int l31, int h,
-                                            float (&cs)[2], float (&cq)[2]) {
+                                            float (&cs)[2], float (&cq)[2], float (&cm)[2]) {
     const int ldc4 = p.ldc * 4, ldy4 = p.bs_ldy * 4;
     const int voff = 4 * h * ldc4 + 4 * l31, voffy = 4 * h * ldy4 + 4 * l31;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cw, 0, 0x7ffffff0, MLSP_BUF_FLAGS);
@@ -244,6 +247,7 @@ __device__ __forceinline__ void gemm_out_bs(const GemmArgs& p, f32x16 (&acc)[2][
                 if (!(a > 0.f)) d *= slope;
                 cs[j] += d;
                 cq[j] = fmaf(d, (yv[r] - mu) * is, cq[j]);
+                cm[j] = fmaxf(cm[j], fabsf(d));
                 acc[i][j][r] = d;
             }
 #pragma unroll
@@ -265,11 +269,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
     __bf16* Cb = (__bf16*)p.C;                            // CBF: bf16 output (never split: the slab is fp32)
     const bool epi = (p.nsplit == 1);
     float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};     // column sums of this wave's 64 rows (BN statistics)
+    float cm[2] = {0.f, 0.f};                         // column maxima of |d'| (gemm_out_bs only)
     // interior fp32 tiles whose rows share one per-cloud bias row: the lean output pass (launch_gemm sets p.fast_out)
     if (BSOK && p.bs_y) {               // (launch_gemm: interior tiles, one K pass, no bias / beta; statistics rows in stat_part)
         float* Cw = Cout + (size_t)(m0 + wm * (32 * WM)) * p.ldc + n0 + wn * 64;
         const float* Yw = p.bs_y + (size_t)(m0 + wm * (32 * WM)) * p.bs_ldy + n0 + wn * 64;
-        gemm_out_bs<WM>(p, acc, Cw, Yw, n0 + wn * 64, m0 + wm * (32 * WM), l31, h, cs, cq);
+        gemm_out_bs<WM>(p, acc, Cw, Yw, n0 + wn * 64, m0 + wm * (32 * WM), l31, h, cs, cq, cm);
     } else if (FAST && !CBF && p.fast_out) {
         float bv[2] = {0.f, 0.f}, gv[2] = {0.f, 0.f};
         if (epi && p.bias) { bv[0] = p.bias[n0 + wn * 64 + l31]; bv[1] = p.bias[n0 + wn * 64 + 32 + l31]; }
@@ -356,15 +361,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
         for (int j = 0; j < 2; ++j) {
             cs[j] += __shfl_xor(cs[j], 32, 64);
             cq[j] += __shfl_xor(cq[j], 32, 64);
+            if (BSOK) cm[j] = fmaxf(cm[j], __shfl_xor(cm[j], 32, 64));
             if (h == 0) {
                 red[(wm * 2 + 0) * 128 + wn * 64 + j * 32 + l31] = cs[j];
                 red[(wm * 2 + 1) * 128 + wn * 64 + j * 32 + l31] = cq[j];
+                if (BSOK) red[(4 + wm) * 128 + wn * 64 + j * 32 + l31] = cm[j];
             }
         }
         __syncthreads();
         if (tid < 128 && n0 + tid < p.N) {
             p.stat_part[((size_t)tm * 2 + 0) * p.stat_ld + n0 + tid] = (double)red[0 * 128 + tid] + (double)red[2 * 128 + tid];
             p.stat_part[((size_t)tm * 2 + 1) * p.stat_ld + n0 + tid] = (double)red[1 * 128 + tid] + (double)red[3 * 128 + tid];
+            if (BSOK && p.bs_y && p.bs_amax) p.bs_amax[(size_t)tm * p.stat_ld + n0 + tid] = fmaxf(red[4 * 128 + tid], red[5 * 128 + tid]);
         }
     }
 }
@@ -1152,7 +1160,18 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
             if (XD) vb *= xik;
         }
         if constexpr (DY) {
-            if constexpr (KA) { ca = fmaxf(fmaxf(fabsf(dsc[0]), fabsf(dsc[1])), fmaxf(fabsf(dsc[2]), fabsf(dsc[3]))); }
+            if (p.dy_amax) {                               // per channel: |sc| max|d'| (the fourth coefficient row)
+                if constexpr (KA) {
+                    const int ch = m0 + (NQA == 4 ? (tid & 31) : (tid & 15)) * 4;
+                    const f32x4 am = *(const f32x4*)(p.dy_coef + 3 * p.dy_cld + ch);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ca = fmaxf(ca, fabsf(dsc[e]) * am[e]);
+                } else {
+                    const int gc0 = (p.gmode == 1 ? (tn / p.gtiles) * (int)p.a_gs : 0) + kbeg;
+                    for (int i = tid; i < T * BK; i += 256) ca = fmaxf(ca, fabsf(xfs[2 * SX_XF_KMAX + i]) * p.dy_coef[3 * p.dy_cld + gc0 + i]);
+                }
+                va = 1.f;
+            } else if constexpr (KA) { ca = fmaxf(fmaxf(fabsf(dsc[0]), fabsf(dsc[1])), fmaxf(fabsf(dsc[2]), fabsf(dsc[3]))); }
             else for (int i = tid; i < T * BK; i += 256) ca = fmaxf(ca, fabsf(xfs[2 * SX_XF_KMAX + i]));
         }
 #pragma unroll
@@ -1406,6 +1425,12 @@ static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, in
     return out;
 }
 static void amax_flush(hipStream_t st, AmaxBatch& batch) {
+    static const bool dump = getenv("MLSP_AMAX_DUMP") != nullptr;          // read-once diagnostic (tools/r6): what each measuring launch reads
+    if (dump && batch.n) {
+        fprintf(stderr, "amax launch:");
+        for (int i = 0; i < batch.n; ++i) fprintf(stderr, " [%ld x %d ld %d = %.1f MB]", batch.args.op[i].rows, batch.args.op[i].cols, batch.args.op[i].ld, batch.args.op[i].rows * 4e-6 * batch.args.op[i].cols);
+        fprintf(stderr, "\n");
+    }
     if (batch.n) hipLaunchKernelGGL(amax_partials_kernel, dim3(batch.n * AMAX_PARTS), dim3(512), 0, st, batch.args);
     batch.n = 0;
 }
@@ -1874,6 +1899,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (stat_part && gemm_pick_split(M, N, K) != 1) return MLSP_ERR_ARG;  // caller must check gemm_stat_parts()
     p.stat_part = stat_part; p.stat_ld = stat_ld > 0 ? stat_ld : N;
     p.sel_gamma = sel_gamma; p.sel_val = sel_val; p.sel_row = sel_row;
+    p.bs_amax = nullptr; p.dy_amax = 0;
     p.bs_y = nullptr; p.bs_ldy = 0; p.bs_bn = nullptr; p.bs_bnld = 0; p.bs_slope = 1.f; p.bs_thresh = 0; p.bs_ik = 1.f; p.bs_xH = 0; p.bs_ld4 = 0; p.bs_col = 0;
     if (bs) {
         if (ta || tb || xf || bias || gbias || accumulate || stat_part || sel_gamma || !bs->y || !bs->bn || !bs->part || (bs->ld & 3) || (bs->col & 3) ||
@@ -1882,9 +1908,9 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         p.bs_y = bs->y; p.bs_ldy = bs->ldy; p.bs_bn = bs->bn; p.bs_bnld = bs->bnld;
         p.bs_slope = bs->act == 0 ? 1.f : bs->act == 1 ? 0.f : bs->slope; p.bs_thresh = bs->thresh; p.bs_ik = bs->inv_keep;
         p.bs_xH = mix32_host((uint32_t)bs->seed) ^ (uint32_t)(bs->seed >> 32) * 0x9e3779b9U; p.bs_ld4 = bs->ld / 4; p.bs_col = bs->col;
-        p.stat_part = bs->part; p.stat_ld = bs->stat_ld;
+        p.stat_part = bs->part; p.stat_ld = bs->stat_ld; p.bs_amax = bs->amax;
     }
-    p.dy_y = dy ? dy->y : nullptr; p.dy_coef = dy ? dy->coef : nullptr; p.dy_cld = dy ? dy->cld : 0;
+    p.dy_y = dy ? dy->y : nullptr; p.dy_coef = dy ? dy->coef : nullptr; p.dy_cld = dy ? dy->cld : 0; p.dy_amax = (dy && dy->amax) ? 1 : 0;
     p.a_amax = nullptr; p.a_amax_n = 0; p.b_amax[0] = p.b_amax[1] = p.b_amax[2] = p.b_amax[3] = nullptr; p.b_amax_n = 0; p.x_mean = p.x_invstd = nullptr; p.stat_sqrt_rows = 0.f;
     p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0; p.x_col = 0;
     if (xf) {
@@ -1940,6 +1966,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         AmaxBatch batch;
         bool ok = true;
         if (xf && xf->which == 1) ok = xf->mean && xf->invstd;
+        else if (dy && dy->amax) { /* bound from the coefficient rows (max |d'| per channel, left by the consumers' dgrads): nothing to measure */ }
         else {
             const int acols = (ta ? M : K) + ((grp && grp->mode == 1) ? (int)((grp->G - 1) * grp->a_gs) : 0);
             p.a_amax = amax_get(batch, A, ta ? K : M, acols, lda); p.a_amax_n = AMAX_PARTS;

@@ -450,7 +450,7 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
     }
     float* slab = sf ? w.take<float>(sf) : nullptr;
     float* Xa = any_mat ? w.take<float>((size_t)M * ldx) : nullptr;
-    float* coef = w.take<float>((size_t)3 * Ctot);
+    float* coef = w.take<float>((size_t)4 * Ctot);           // c0 | nk2 | sc | max |d'| (bn.hip bn_bwd_finalize_coef_kernel)
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float pd = training ? p_drop : 0.f;
     const uint32_t th = dropout_thresh8(pd);
@@ -487,7 +487,7 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
         for (int t = 0; t < G; ++t) if (!dW[s + t]) return MLSP_ERR_ARG;
         GemmGroups grp = {G, 1, g.Cout, 0, {nullptr, nullptr, nullptr, nullptr}};
         for (int t = 0; t < G; ++t) grp.Bg[t] = segs[s + t].W;
-        const GemmDy dy_s = {Y + ycol, coef + ycol, Ctot};
+        const GemmDy dy_s = {Y + ycol, coef + ycol, Ctot, 1};
         if (dX) {
             bool acc = false;                                  // an earlier segment on the same input columns: add (partial overlaps: rejected)
             for (int t = 0; t < s; ++t) {
@@ -502,6 +502,7 @@ int mlsp_multimlp_bwd_f32(const float* dZ, const float* X, int ldx, int M, const
                 const mlsp_defer_t& d = in[s];
                 bs_s = {X + g.x_col, ldx, d.bn_save + d.col, d.ld, d.act, d.slope, dropout_thresh8(d.p_drop), dropout_inv_keep8(d.p_drop), d.seed,
                         d.ld, d.col, in_stats + d.col, d.ld};
+                bs_s.amax = (float*)(in_stats + (size_t)(M / 128) * 2 * d.ld) + d.col;       // the maxima plane behind the [M / 128][2][ld] sums
                 bs = &bs_s;
                 for (int t = 1; t < G; ++t) if (!multi_defer_same(in[s], in[s + t])) return MLSP_ERR_UNSUPPORTED;     // (one producer description per launch)
             }

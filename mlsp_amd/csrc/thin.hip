@@ -18,7 +18,7 @@
 // BS (the dgrad of a head's 3- / 16-channel output layer: C is the gradient w.r.t. the previous layer's ACTIVATED output): the result is
 // multiplied by that layer's activation derivative and dropout mask (BsDev: its pre-BN output and parameters at C's column 0) before it
 // is stored, and the block -- 128 rows -- leaves its column sums of d' and d' * yhat in part [block][2][stat_ld]: see gemm_out_bs.
-struct BsDev { const float* y; int ldy; const float* bn; int bnld; float slope, inv_keep; uint32_t thresh, xH; int ld4, col; double* part; int stat_ld; };
+struct BsDev { const float* y; int ldy; const float* bn; int bnld; float slope, inv_keep; uint32_t thresh, xH; int ld4, col; double* part; int stat_ld; float* amax; };
 template <bool TB, bool BS = false, int NT = 256, int KM = 16>
 __global__ __launch_bounds__(NT) void thin_smallk_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                           float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(NT) void thin_smallk_kernel(const float* __restrict
     // BS: a thread keeps ONE column quad (NT % nq == 0): its scale / shift / mean / invstd and its running sums live in registers
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sf = sc, mu = sc, is = sc;
     double ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+    float pm[4] = {0.f, 0.f, 0.f, 0.f};                              // BS: column maxima of |d'|
     if (BS) {
         const int c = 4 * (tid % nq);
         sc = *(const f32x4*)(bs.bn + c); sf = *(const f32x4*)(bs.bn + bs.bnld + c);
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(NT) void thin_smallk_kernel(const float* __restrict
                     const float a1 = fmaf(yv[u][e], sc[e], sf[e]);
                     if (!(a1 > 0.f)) d *= bs.slope;
                     ps[e] += d; pq[e] += (double)d * ((yv[u][e] - mu[e]) * is[e]);
+                    pm[e] = fmaxf(pm[e], fabsf(d));
                     o[e] = d;
                 }
                 *(f32x4*)(C + (size_t)r * ldc + 4 * q) = o;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(NT) void thin_smallk_kernel(const float* __restrict
                 const float av = fmaf(y[e], sc[e], sf[e]);
                 if (!(av > 0.f)) d *= bs.slope;
                 ps[e] += d; pq[e] += (double)d * ((y[e] - mu[e]) * is[e]);
+                pm[e] = fmaxf(pm[e], fabsf(d));
                 acc[e] = d;
             }
         }
@@ -147,6 +150,21 @@ __global__ __launch_bounds__(NT) void thin_smallk_kernel(const float* __restrict
             for (int e = 0; e < 4; ++e) {
                 bs.part[((size_t)blockIdx.x * 2 + 0) * bs.stat_ld + 4 * tid + e] = s8[e];
                 bs.part[((size_t)blockIdx.x * 2 + 1) * bs.stat_ld + 4 * tid + e] = s8[4 + e];
+            }
+        }
+        if (bs.amax) {      // the block's column maxima of |d'| (a by-product for the producer's two-piece f16 products: gemm.hip GemmArgs bs_amax)
+            __syncthreads();
+            float* redf = (float*)red;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) redf[tid * 4 + e] = pm[e];
+            __syncthreads();
+            if (tid < nq) {
+                float m4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int g2 = 0; g2 < NT / nq; ++g2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m4[e] = fmaxf(m4[e], redf[(g2 * nq + tid) * 4 + e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bs.amax[(size_t)blockIdx.x * bs.stat_ld + 4 * tid + e] = m4[e];
             }
         }
     }
@@ -312,13 +330,13 @@ int launch_thin_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, cons
     if (!xf && !ta && K <= 16 && N % 4 == 0 && N >= 64 && N <= 512 && M >= 1024 && ldc % 4 == 0 && al16(C) && al16(bias)) {
         const int nq = N / 4;
         if (256 % nq) return MLSP_ERR_UNSUPPORTED;
-        BsDev bd = {nullptr, 0, nullptr, 0, 1.f, 1.f, 0u, 0u, 0, 0, nullptr, 0};
+        BsDev bd = {nullptr, 0, nullptr, 0, 1.f, 1.f, 0u, 0u, 0, 0, nullptr, 0, nullptr};
         if (bs) {
             if (thin_bs_parts(M, N, K) == 0 || !bs->y || !bs->bn || !bs->part || (bs->ld & 3) || (bs->col & 3) || (bs->ldy & 3) || (bs->bnld & 3) ||
                 !al16(bs->y) || !al16(bs->bn) || (double)M * bs->ld >= 17179869184.0) return MLSP_ERR_UNSUPPORTED;
             bd.y = bs->y; bd.ldy = bs->ldy; bd.bn = bs->bn; bd.bnld = bs->bnld; bd.slope = bs->act == 0 ? 1.f : bs->act == 1 ? 0.f : bs->slope;
             bd.inv_keep = bs->inv_keep; bd.thresh = bs->thresh; bd.xH = mix32_host((uint32_t)bs->seed) ^ (uint32_t)(bs->seed >> 32) * 0x9e3779b9U;
-            bd.ld4 = bs->ld / 4; bd.col = bs->col; bd.part = bs->part; bd.stat_ld = bs->stat_ld;
+            bd.ld4 = bs->ld / 4; bd.col = bs->col; bd.part = bs->part; bd.stat_ld = bs->stat_ld; bd.amax = bs->amax;
         }
         const int rpb = bs ? 128 : 4 * 256 / nq;                          // four passes of the workgroup per block (fused statistics: one 128-row panel)
         // (fused statistics: one block per 128-row panel -- 1024 threads, so that M / 128 blocks still fill the chip)

@@ -860,10 +860,10 @@ class BwdStats:
     pass.  All or nothing: every consumer `promise`s its column range at forward time (with the number of 128-row panels its dgrad
     would write, 0 = it cannot); only if the promises tile [0, ld) exactly with one common panel count do the consumers do it
     (`agreed`), and the producer uses the sums only if every range was `deliver`ed in the same backward pass (`take`)."""
-    __slots__ = ("ld", "promised", "part", "task", "delivered", "_ok")
+    __slots__ = ("ld", "promised", "part", "parts", "task", "delivered", "_ok")
 
     def __init__(self, ld):
-        self.ld, self.promised, self.part, self.task, self.delivered, self._ok = int(ld), [], None, None, 0, None
+        self.ld, self.promised, self.part, self.parts, self.task, self.delivered, self._ok = int(ld), [], None, 0, None, 0, None
 
     def promise(self, col, width, parts):
         self.promised.append((int(col), int(width), int(parts)))
@@ -878,11 +878,13 @@ class BwdStats:
         return self._ok
 
     def buffer(self, device):
-        """[parts, 2, ld] fp64 partial rows of the current backward pass (every column is written by exactly one consumer)"""
+        """The partial rows of the current backward pass: [parts][2][ld] fp64 column sums (every column written by exactly one consumer),
+        followed by [parts][ld] fp32 column maxima of |d'| (ABI v13: the producer's GEMMs bound their two-piece f16 products with them)."""
         task = torch._C._current_graph_task_id()
         if self.part is None or self.task != task:
-            self.part = torch.empty((self.promised[0][2], 2, self.ld), dtype=torch.float64, device=device)
-            self.task, self.delivered = task, 0
+            parts = self.promised[0][2]
+            self.part = torch.empty((parts * 2 * self.ld + (parts * self.ld + 1) // 2,), dtype=torch.float64, device=device)
+            self.parts, self.task, self.delivered = parts, task, 0
         self.delivered += 1
         return self.part
 
@@ -897,7 +899,7 @@ class BwdStats:
         part, self.part, self.task = self.part, None, None
         if self.delivered != len(self.promised):
             return None, -1
-        return part, part.shape[0]
+        return part, self.parts
 
 
 class DeferredAct:
