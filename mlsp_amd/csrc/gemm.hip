@@ -991,7 +991,16 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = blockIdx.x;
     int tm, tn, split = blockIdx.y;
-    if (p.xcd_map == 2) {
+    if (p.xcd_map == 3) {
+        // several row panels AND column tiles per K split (weight gradients of the wide layers; 1-D grid): ALL tiles of a split are
+        // consecutive slots of ONE XCD -- they walk the same K range in step, so both the A range and the B range of a split come out of HBM
+        // once (under the (split, panel) order below every B range was fetched by each of the ntm XCDs that held one of its panels:
+        // 820 MB HBM-side for 335 MB of operands at 1024 x 512 x 32768, profiles/pmc_r6)
+        const int xcd = bid & 7, q = bid >> 3, tps = p.ntm * p.ntn;
+        const int t = q % tps;
+        split = (q / tps) * 8 + xcd;
+        tm = t / p.ntn; tn = t - tm * p.ntn;
+    } else if (p.xcd_map == 2) {
         // few row panels, many K splits (weight gradients; 1-D grid): the ntn tiles that read the same A panel of the same K range are
         // consecutive slots of ONE XCD -- dispatched together, they walk their K range in step and the panel is fetched from HBM once
         // instead of once per XCD (the plain order spread them over ntn XCDs: 1.24 GB HBM-side for 335 MB of operands at 1024 x 512 x 32768)
@@ -1634,6 +1643,8 @@ static int gemm_pick_bm(int M, int N, int K) {
     long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN);
     // the split kernel amortises its operand split over the tile: 128 rows unless the grid would not fill the 512 workgroup slots
     const long few = (tl_call_precision == 2 && gemm_split_pays(M, N, (K + BK - 1) / BK)) ? 512 : 1536;
+    static const bool force64 = getenv("MLSP_GEMM_BM64") != nullptr;            // read-once experiment switch (tools/x6/lib_bench): 64-row tiles wherever K is not split
+    if (force64 && gemm_pick_split(M, N, K) == 1 && M >= 256) return 64;
     return (gemm_pick_split(M, N, K) == 1 && tiles128 < few && M >= 256) ? 64 : 128;
 }
 int gemm_stat_parts(int M, int N, int K) {
@@ -1955,7 +1966,10 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     // split-K launches of gemm_split_kernel with few row panels (weight gradients): XCD-grouped (split, panel) order, see the kernel
     xcd2 = !no_xcd2 && !p.xcd_map && ns > 1 && p.ntn > 1 && (p.ntm * ns) % 8 == 0 && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) &&
            (!xf || xf_split);
-    if (xcd2) { p.xcd_map = 2; grid = dim3(p.ntm * p.ntn * ns, 1); }
+    static const bool no_xcd3 = getenv("MLSP_GEMM_NO_XCD3") != nullptr;       // read-once A/B switch (tools/ab)
+    const bool xcd3 = !no_xcd3 && !p.xcd_map && ns > 1 && ns % 8 == 0 && p.ntm > 1 && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && (!xf || xf_split);
+    if (xcd3) { p.xcd_map = 3; grid = dim3(p.ntm * p.ntn * ns, 1); }       // (all tiles of a split on one XCD: see the kernel)
+    else if (xcd2) { p.xcd_map = 2; grid = dim3(p.ntm * p.ntn * ns, 1); }
     const bool n64 = !dy && !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
                      (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && tl_call_precision != 1 && (ns == 1 || p.ldc == N);
     // two-piece f16 products (mode 3) on this launch?  The split kernel, and a bound for both operands: partial maxima of the operands as
