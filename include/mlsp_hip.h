@@ -60,6 +60,15 @@ typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
  * a launch without a bound (no workspace tail, eval-mode transform) runs the six-product bf16 split instead.  Same accuracy class as
  * MLSP_PREC_BF16X6 (tests/test_gpu_kernels.py::test_gemm_split_bf16_accuracy holds both to the same bar against float64). */
 #define MLSP_PREC_F16X3 3
+/* Caller-owned operand bounds for MLSP_PREC_F16X3 (optional; ABI v13).  partials: 256 floats on the device -- partial maxima of |X| over X
+ * [rows][cols] (row pitch ld, fp32, 16-byte aligned, cols % 4 == 0).  mlsp_operand_bounds_next(tab, n) hands `n` entries to the NEXT entry
+ * point this thread calls that takes a `precision` (and to that call only; the table must stay alive until it returns): a GEMM operand of
+ * that call with the same pointer and shape uses the entry's partials instead of measuring into the workspace -- as they are when
+ * valid != 0; when valid == 0 the call measures INTO them (its one measuring launch) and sets valid = 1 in the caller's table.  The caller
+ * keeps such a buffer for as long as the tensor's contents do not change: an activation that several layers read, a weight that its
+ * layer's backward reads again.  Purely an optimisation: without it every call measures what it needs. */
+typedef struct { const float* ptr; long rows; int cols, ld; float* partials; int valid; } mlsp_bound_t;
+int mlsp_operand_bounds_next(mlsp_bound_t* tab, int n);
 
 int mlsp_abi_version(void);
 const char* mlsp_strerror(int code);

@@ -42,7 +42,7 @@ def _first_head_layer(head, x_cat, x5, N, act, p_drop, grad_accum=None):
                      W=Wc, grad_accum=grad_accum, chain=True)
 
 
-def merged_first_layers(heads, x_cat, x5, N, grad_accum=None):
+def merged_first_layers(heads, x_cat, x5, N, grad_accum=None, x_bounds=None):
     """conv1 + bn1 + ReLU + dropout of SEVERAL heads on the same input (Models.py:156-160 feeds every head the same concatenation;
     :192, :226, :273 are the three first layers) as ONE layer of sum(of1) output channels: one wide GEMM over x_cat instead of one
     per head, one per-cloud-bias product with x5, one BatchNorm pass over all the channels (BatchNorm is per channel, so running the
@@ -68,7 +68,7 @@ def merged_first_layers(heads, x_cat, x5, N, grad_accum=None):
     bn = mods[0].bn1
     h1 = Fh.pointmlp(x_cat, Wc, bias=bias, gbias=gb, gamma=gamma, beta=beta, run_mean=rm.tensor, run_var=rv.tensor, rows_per_group=N,
                      training=training, act=Fh.ACT_RELU, slope=0.2, p_drop=p_drop, momentum=bn.momentum, eps=bn.eps,
-                     grad_accum=grad_accum, chain=True)
+                     grad_accum=grad_accum, chain=True, x_bounds=x_bounds)
     if training:
         rm.writeback()
         rv.writeback()
@@ -383,10 +383,13 @@ class DGCNN(nn.Module):
         heads.sort(key=lambda kh: 0 if isinstance(kh[1], _RegionHead) else 1)
         merge = can_merge_first_layers([h for _, h in heads])
         aliases, acc = Fh.fan_out(x_cat, 2 if merge else 1 + len(heads))
+        # conv5 and the heads' first layer read x_cat forward and backward (four GEMM operands per step): ONE measurement of its magnitude
+        # for the two-piece f16 products (functional.OperandBounds; a no-op in the other product modes)
+        xb = Fh.OperandBounds(x_cat.device) if Fh.gemm_precision.current == "f16x3" else None
         rm5, rv5 = _bn_buffers(self.bn5, self.training)                             # conv5+bn5+LReLU+max (Models.py:132-136)
         x5 = Fh.pointmlp_colmax(aliases[0], self.conv5.weight.view(1024, -1), self.bn5.weight, self.bn5.bias, rm5, rv5, B, N,
                                 training=self.training, act=Fh.ACT_LRELU, slope=0.2, momentum=self.bn5.momentum,
-                                eps=self.bn5.eps, grad_accum=acc)                  # [B,1024]
+                                eps=self.bn5.eps, grad_accum=acc, x_bounds=xb)     # [B,1024]
 
         logits["cls"] = self.C(x5)
         if visualization:
@@ -395,7 +398,7 @@ class DGCNN(nn.Module):
             # every head's first layer reads the same [x_cat | x5]: ONE wide layer; then the heads continue depth by depth in shared
             # wide matrices (merged_tails), or one by one on their column slices of h1 where that does not apply
             mods = [h for _, h in heads]
-            h1, widths = merged_first_layers(mods, aliases[1], x5, N, grad_accum=acc)
+            h1, widths = merged_first_layers(mods, aliases[1], x5, N, grad_accum=acc, x_bounds=xb)
             outs = merged_tails(mods, h1, widths, B, N) if MERGE_HEAD_TAILS else None
             if outs is None:
                 slices, cols = Fh.split_columns_shared(h1, widths)

@@ -98,12 +98,18 @@ SIGNATURES = {
     "mlsp_profile_classes": [_P, _I],
     "mlsp_profile_split_kinds": [_P],
     "mlsp_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _SZ, _P],
+    "mlsp_operand_bounds_next": [_P, _I],
 }
 
 
 class Seg(_c.Structure):
     """mlsp_seg_t of include/mlsp_hip.h"""
     _fields_ = [("W", _P), ("bias", _P), ("ldw", _I), ("x_col", _I), ("Cin", _I), ("Cout", _I)]
+
+
+class Bound(_c.Structure):
+    """mlsp_bound_t of include/mlsp_hip.h: caller-owned partial maxima of one GEMM operand (functional.OperandBounds)"""
+    _fields_ = [("ptr", _P), ("rows", _c.c_long), ("cols", _I), ("ld", _I), ("partials", _P), ("valid", _I)]
 
 
 class Defer(_c.Structure):

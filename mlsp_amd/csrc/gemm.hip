@@ -19,6 +19,7 @@
 // Block -> tile mapping keeps all column tiles of one 128-row panel on one XCD (blockIdx % 8 is the
 // XCD label under round-robin dispatch), so the activation panel is fetched into one L2 only.
 #include "common.h"
+#include "../../include/mlsp_hip.h"
 #include <cstdlib>
 
 #define BM 128
@@ -1411,13 +1412,33 @@ static thread_local struct AmaxScratch {
     float* base = nullptr;          // the workspace tail of the current API call (null: none, mode 3 falls back to the bf16 pieces)
     int next = 0, ncache = 0;
     struct { const float* X; long rows; int cols, ld; float* out; } cache[AMAX_SLOTS];
+    // caller-owned bounds of the current call (mlsp_operand_bounds_next): an operand that matches an entry uses the entry's partials --
+    // as they are when `valid`, else this call measures INTO them and sets `valid` (the caller keeps them for later calls: the same
+    // activation read by several layers, a weight read again by its layer's backward)
+    mlsp_bound_t* offered = nullptr; int noffered = 0;
+    mlsp_bound_t* pending = nullptr; int npending = 0;     // set by mlsp_operand_bounds_next, adopted by the next GemmPrecisionScope
 } tl_amax;
+extern "C" int mlsp_operand_bounds_next(mlsp_bound_t* tab, int n) {
+    if (n < 0 || (n > 0 && !tab)) return MLSP_ERR_ARG;
+    tl_amax.pending = n ? tab : nullptr; tl_amax.npending = n;
+    return MLSP_OK;
+}
 // queue of operands to measure with the next launch (launch_gemm batches A and B -- and the groups' B operands -- into one launch)
 struct AmaxBatch { AmaxArgs args; int n = 0; };
 // -> the partials of X [rows][cols] (pitch ld), measured now (queued into `batch`) or earlier in this API call; null: cannot (no tail,
 // unaligned, the batch is full)
 static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, int ld) {
     if (!tl_amax.base || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3) || (((uintptr_t)X) & 15)) return nullptr;
+    for (int i = 0; i < tl_amax.noffered; ++i) {
+        mlsp_bound_t& o = tl_amax.offered[i];
+        if (o.ptr != X || o.rows != rows || o.cols != cols || o.ld != ld || !o.partials) continue;
+        if (!o.valid) {
+            if (batch.n >= 5) return nullptr;
+            batch.args.op[batch.n++] = {X, rows, cols, ld, o.partials};
+            o.valid = 1;
+        }
+        return o.partials;
+    }
     for (int i = 0; i < tl_amax.ncache; ++i) {
         const auto& c = tl_amax.cache[i];
         if (c.X == X && c.rows == rows && c.cols == cols && c.ld == ld) return c.out;
@@ -1447,10 +1468,13 @@ GemmPrecisionScope::GemmPrecisionScope(int mode, void* ws, size_t ws_bytes) : pr
     tl_split_half = mode == 3; tl_call_precision = mode == 3 ? 2 : mode;
     tl_amax.base = (mode == 3 && ws && ws_bytes >= 2 * MLSP_AMAX_TAIL_BYTES) ? (float*)((char*)ws + align_up(ws_bytes - MLSP_AMAX_TAIL_BYTES, 256)) : nullptr;
     tl_amax.next = tl_amax.ncache = 0;
+    tl_amax.offered = tl_amax.pending; tl_amax.noffered = tl_amax.npending;        // (consumed by this call, whatever its mode)
+    tl_amax.pending = nullptr; tl_amax.npending = 0;
 }
 GemmPrecisionScope::~GemmPrecisionScope() {
     tl_call_precision = prev & 3; tl_split_half = (prev & 4) != 0;
     tl_amax.base = (float*)prev_tail; tl_amax.next = tl_amax.ncache = 0;
+    tl_amax.offered = nullptr; tl_amax.noffered = 0;
 }
 
 // sum the split-K slabs (fixed order -> bitwise reproducible) and apply the epilogue

@@ -40,6 +40,47 @@ def _rows(t, allow_bf16=False):
     return t
 
 
+_SHARE_BOUNDS = os.environ.get("MLSP_NO_OPERAND_BOUNDS") is None       # read-once A/B switch: off = every C call measures what it needs
+
+
+class OperandBounds:
+    """Caller-owned bound of ONE tensor's magnitude for the two-piece f16 products (include/mlsp_hip.h mlsp_bound_t): 256 partial
+    maxima on the tensor's device, measured by the first C call that needs them (one streaming launch) and reused by every later call
+    that is offered the same object -- the layers that read one activation (conv5 and the heads read the concatenated encoder features
+    four times per step), a layer's backward that reads its weight again.  Valid for as long as the tensor's CONTENTS do not change:
+    create one per forward for an activation, one per forward call for a weight (the optimizer changes it between steps)."""
+    __slots__ = ("buf", "valid")
+
+    def __init__(self, device):
+        self.buf, self.valid = torch.empty(256, dtype=torch.float32, device=device), False
+
+
+class _offer_bounds:
+    """`with _offer_bounds((tensor, bounds), ...):` around ONE C call: hands the call the bounds of those of its 2-D fp32 operands the
+    caller keeps bounds for (None entries are skipped; nothing happens outside mode "f16x3"), and records which ones the call measured."""
+    __slots__ = ("pairs", "tab")
+
+    def __init__(self, prec, *pairs):
+        self.pairs = ([(t, b) for t, b in pairs if b is not None and t is not None and t.dim() == 2 and t.dtype == torch.float32]
+                      if prec == 3 and _SHARE_BOUNDS else [])
+        self.tab = None
+
+    def __enter__(self):
+        if self.pairs:
+            self.tab = (_lib.Bound * len(self.pairs))()
+            for e, (t, b) in zip(self.tab, self.pairs):
+                e.ptr, e.rows, e.cols, e.ld, e.partials, e.valid = t.data_ptr(), t.shape[0], t.shape[1], t.stride(0), b.buf.data_ptr(), int(b.valid)
+            _lib.load().mlsp_operand_bounds_next(self.tab, len(self.pairs))
+        return self
+
+    def __exit__(self, *exc):
+        if self.tab is not None:
+            _lib.load().mlsp_operand_bounds_next(None, 0)          # (a call that failed before its precision scope leaves nothing behind)
+            for e, (_, b) in zip(self.tab, self.pairs):
+                b.valid = bool(e.valid)
+        return False
+
+
 class _PrecisionMeta(type):
     @property
     def current(cls):
@@ -570,9 +611,12 @@ class _MultiMLP(Function):
         bn_save = torch.empty((4, Ctot), dtype=torch.float32, device=dev)
         p = float(p_drop) if training else 0.0
         ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
-        _lib.check(lib.mlsp_multimlp_fwd_f32(X.data_ptr(), X.stride(0), M, segs, n, defs, gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean),
-                                             _lib.ptr(run_var), momentum, eps, int(training), chan.data_ptr(), p, seed, Y.data_ptr(),
-                                             _lib.ptr(Z), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_multimlp_fwd_f32")
+        # (mode "f16x3": the weights' magnitude bounds measured by this call are read again by the backward)
+        ctx.w_bounds = [OperandBounds(dev) for _ in Ws] if prec == 3 else []
+        with _offer_bounds(prec, *zip(Ws, ctx.w_bounds)):
+            _lib.check(lib.mlsp_multimlp_fwd_f32(X.data_ptr(), X.stride(0), M, segs, n, defs, gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean),
+                                                 _lib.ptr(run_var), momentum, eps, int(training), chan.data_ptr(), p, seed, Y.data_ptr(),
+                                                 _lib.ptr(Z), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_multimlp_fwd_f32")
         ctx.save_for_backward(X, Y, bn_save, chan, *Ws)
         ctx.cfg = (tuple(x_cols), bool(training), p, seed, [b is not None for b in bs])
         ctx.in_defs = in_defs
@@ -631,10 +675,11 @@ class _MultiMLP(Function):
             ins = ctx.in_stats.buffer(dev)
             for _ in range(n - 1):
                 ctx.in_stats.buffer(dev)            # (one delivery per promised segment: this call writes all of them)
-        _lib.check(lib.mlsp_multimlp_bwd_f32(dZ.data_ptr(), X.data_ptr(), X.stride(0), M, segs, n, defs, Y.data_ptr(), bn_save.data_ptr(),
-                                             int(training), chan.data_ptr(), p, seed, _lib.ptr(dX), dX.stride(0) if dX is not None else 0,
-                                             dwp, _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(), _lib.ptr(ins), pre_ptr, pre_n, ctx.prec, ws, wsn,
-                                             _lib.stream()), "mlsp_multimlp_bwd_f32")
+        with _offer_bounds(ctx.prec, *zip(Ws, ctx.w_bounds)):
+            _lib.check(lib.mlsp_multimlp_bwd_f32(dZ.data_ptr(), X.data_ptr(), X.stride(0), M, segs, n, defs, Y.data_ptr(), bn_save.data_ptr(),
+                                                 int(training), chan.data_ptr(), p, seed, _lib.ptr(dX), dX.stride(0) if dX is not None else 0,
+                                                 dwp, _lib.ptr(dbias), dgamma.data_ptr(), dbeta.data_ptr(), _lib.ptr(ins), pre_ptr, pre_n, ctx.prec, ws, wsn,
+                                                 _lib.stream()), "mlsp_multimlp_bwd_f32")
         dbs, o = [], 0
         for w, hb in zip(Ws, has_b):
             dbs.append(dbias[o:o + w.shape[0]] if hb else None)
@@ -984,7 +1029,8 @@ def _stats_parts(key, query):
 class _PointMLP(Function):
     @staticmethod
     def forward(ctx, X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop, seed,
-                momentum, eps, grad_accum=None, out_bf16=False, in_def=None, defer_out=False, grad_cols=None, in_stats=None, out_stats=None):
+                momentum, eps, grad_accum=None, out_bf16=False, in_def=None, defer_out=False, grad_cols=None, in_stats=None, out_stats=None,
+                x_bounds=None):
         lib = _lib.load()
         prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         X = _rows(X, allow_bf16=True)
@@ -1020,6 +1066,12 @@ class _PointMLP(Function):
         # then takes the per-cloud bias gradient from those sums and the clouds' column sums of Y -- which the forward has at hand
         ysum = (torch.empty((gbias.shape[0], Cout), dtype=torch.float32, device=dev)
                 if (gbias is not None and defer_out and training and out_stats is not None and _FUSE_BWD_STATS and M > 32) else None)
+        # mode "f16x3": bounds of the operands as they lie in memory, measured once by this call and read again by the backward (a deferred
+        # input is bounded analytically; x_bounds: the caller shares X's with the other layers that read X)
+        ctx.bounds = ((x_bounds if x_bounds is not None else OperandBounds(dev)) if in_def is None and not x_bf16 else None,
+                      OperandBounds(dev)) if prec == 3 and M > 32 else (None, None)
+        ctx_offer = _offer_bounds(prec, (X, ctx.bounds[0]), (W, ctx.bounds[1]))
+        ctx_offer.__enter__()
         if mx:
             _lib.check(lib.mlsp_pointmlp_fwd_mx(
                 X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
@@ -1039,6 +1091,7 @@ class _PointMLP(Function):
                 int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
                 int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), _lib.ptr(ysum), prec, ws, wsn, _lib.stream()),
                 "mlsp_pointmlp_fwd_f32")
+        ctx_offer.__exit__(None, None, None)
         ctx.in_def = in_def
         # fused BatchNorm-backward sums (BwdStats): as a consumer, promise the producer this layer's input columns (with the panel count
         # the dgrad would write; 0 = it cannot); as a deferred producer, remember where the consumers will leave ours
@@ -1065,7 +1118,7 @@ class _PointMLP(Function):
     @once_differentiable
     def backward(ctx, dZ, _dbn=None):
         if dZ is None:
-            return (None,) * 23
+            return (None,) * 24
         lib = _lib.load()
         X, W, Y, bn_save, ysum = ctx.saved_tensors
         has_bn, training, act, slope, p, seed, has_bias, G, rpg = ctx.cfg
@@ -1097,6 +1150,8 @@ class _PointMLP(Function):
         ins = None
         if ctx.in_stats is not None and dX is not None and ctx.in_stats.agreed():
             ins = ctx.in_stats.buffer(dev)                                          # the producer's sums: this call's dgrad writes our columns
+        ctx_offer = _offer_bounds(ctx.prec, (X, ctx.bounds[0]), (W, ctx.bounds[1]))
+        ctx_offer.__enter__()
         if mx:
             _lib.check(lib.mlsp_pointmlp_bwd_mx(
                 dZ.data_ptr(), X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, Y.data_ptr(),
@@ -1116,17 +1171,19 @@ class _PointMLP(Function):
                 _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate, dW.data_ptr(),
                 _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), pre_ptr, pre_n, _lib.ptr(ysum), ctx.prec, ws, wsn,
                 _lib.stream()), "mlsp_pointmlp_bwd_f32")
-        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 17
+        ctx_offer.__exit__(None, None, None)
+        return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 18
 
 
 def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, run_var=None, rows_per_group=0,
              training=True, act=ACT_NONE, slope=0.2, p_drop=0.0, momentum=0.1, eps=1e-5, grad_accum=None, chain=False, grad_cols=None,
-             defer=False):
+             defer=False, x_bounds=None):
     """Linear/1x1-conv (+bias, +per-group bias) [+ BatchNorm + act + dropout] on a [M,Cin] row matrix.
     `grad_accum`: the SharedInputGrad of a fan_out(X, n) whose alias this X is.  `chain=True`: the only consumer of the output is
     another pointmlp BN layer, so under activation_storage("bf16") Y / Z may be stored as bf16.  `grad_cols` = (SharedColumnGrad, first
     column): X is that column slice of a split_columns_shared() matrix.  `defer=True`: every consumer of the output is a GEMM layer
-    (pointmlp / multimlp, with or without BatchNorm): under fp32 storage the result may be a DeferredAct (`chain=True` implies it)."""
+    (pointmlp / multimlp, with or without BatchNorm): under fp32 storage the result may be a DeferredAct (`chain=True` implies it).
+    `x_bounds` (OperandBounds of X, optional): shared with the other layers that read X."""
     seed = _next_seed() if (training and p_drop > 0) else 0
     if isinstance(X, DeferredAct) and grad_cols is not None:
         assert grad_cols[0].width == X.ld and grad_cols[1] == X.col, "grad_cols of a deferred slice: its columns in the producer's matrix"
@@ -1144,7 +1201,7 @@ def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, 
     defer_out = bool(chain or defer) and gamma is not None and _can_defer(X.shape[0], X.dtype)
     out_stats = BwdStats(W.shape[0]) if defer_out else None
     out, bn_save = _PointMLP.apply(X, W, bias, gbias, gamma, beta, run_mean, run_var, rows_per_group, training, act, slope, p_drop,
-                                   seed, momentum, eps, grad_accum, out_bf16, in_def, defer_out, grad_cols, in_stats, out_stats)
+                                   seed, momentum, eps, grad_accum, out_bf16, in_def, defer_out, grad_cols, in_stats, out_stats, x_bounds)
     if defer_out:
         fac = 1.0 if act == ACT_NONE else 0.0 if act == ACT_RELU else float(slope)
         p = float(p_drop) if training else 0.0
@@ -1154,7 +1211,7 @@ def pointmlp(X, W, bias=None, gbias=None, gamma=None, beta=None, run_mean=None, 
 
 class _PointMLPColMax(Function):
     @staticmethod
-    def forward(ctx, X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps, grad_accum=None):
+    def forward(ctx, X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps, grad_accum=None, x_bounds=None):
         lib = _lib.load()
         prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         ctx.grad_accum = grad_accum
@@ -1171,10 +1228,13 @@ class _PointMLPColMax(Function):
         arg = torch.empty((B, Cout), dtype=torch.int32, device=dev)
         bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, P, Cin, Cout)
-        _lib.check(lib.mlsp_pointmlp_colmax_fwd_f32(
-            X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, gamma.data_ptr(), beta.data_ptr(),
-            _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, int(training), act, slope, out.data_ptr(), ysel.data_ptr(),
-            arg.data_ptr(), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_fwd_f32")
+        # (mode "f16x3": the operand bounds this call measures are kept for the backward, which reads X and W again)
+        ctx.bounds = (x_bounds if x_bounds is not None else OperandBounds(dev), OperandBounds(dev)) if prec == 3 else (None, None)
+        with _offer_bounds(prec, (X, ctx.bounds[0]), (W, ctx.bounds[1])):
+            _lib.check(lib.mlsp_pointmlp_colmax_fwd_f32(
+                X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, gamma.data_ptr(), beta.data_ptr(),
+                _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, int(training), act, slope, out.data_ptr(), ysel.data_ptr(),
+                arg.data_ptr(), bn_save.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_fwd_f32")
         if _sel_record is not None or _sel_forced is not None:
             _selection_hook(arg)
         ctx.save_for_backward(X, W, out, ysel, arg, bn_save)
@@ -1201,18 +1261,20 @@ class _PointMLPColMax(Function):
         dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, max(P, Cout), Cin, max(Cout, Cin))
-        _lib.check(lib.mlsp_pointmlp_colmax_bwd_f32(
-            dOut.data_ptr(), X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, out.data_ptr(),
-            ysel.data_ptr(), arg.data_ptr(), bn_save.data_ptr(), int(training), act, slope, _lib.ptr(dX), accumulate, dW.data_ptr(),
-            dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_bwd_f32")
-        return (dX, dW, dgamma, dbeta) + (None,) * 10
+        with _offer_bounds(ctx.prec, (X, ctx.bounds[0]), (W, ctx.bounds[1])):
+            _lib.check(lib.mlsp_pointmlp_colmax_bwd_f32(
+                dOut.data_ptr(), X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, out.data_ptr(),
+                ysel.data_ptr(), arg.data_ptr(), bn_save.data_ptr(), int(training), act, slope, _lib.ptr(dX), accumulate, dW.data_ptr(),
+                dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_colmax_bwd_f32")
+        return (dX, dW, dgamma, dbeta) + (None,) * 11
 
 
 def pointmlp_colmax(X, W, gamma, beta, run_mean, run_var, B, N, training=True, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5,
-                    grad_accum=None):
+                    grad_accum=None, x_bounds=None):
     """conv (bias-free) + BN + act + max over the N rows of each of the B clouds: [B*N, Cin] -> [B, Cout]
-    (Models.py:132-136; model_utils.py:116-117).  Closed-form backward through the Gram matrix (colmax.hip)."""
-    return _PointMLPColMax.apply(X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps, grad_accum)
+    (Models.py:132-136; model_utils.py:116-117).  Closed-form backward through the Gram matrix (colmax.hip).
+    `x_bounds` (OperandBounds of X, optional): shared with the other layers that read X."""
+    return _PointMLPColMax.apply(X, W, gamma, beta, run_mean, run_var, B, N, training, act, slope, momentum, eps, grad_accum, x_bounds)
 
 
 class _SegMax(Function):
