@@ -929,13 +929,25 @@ __device__ __forceinline__ uint32_t sx_cvt_pk_h(float lo, float hi) {     // one
 }
 __device__ __forceinline__ float sx_h_lo(uint32_t pk) { return (float)__builtin_bit_cast(f16x2, pk)[0]; }
 __device__ __forceinline__ float sx_h_hi(uint32_t pk) { return (float)__builtin_bit_cast(f16x2, pk)[1]; }
+// x * s - (low / high f16 half of pk) in ONE instruction (v_fma_mix_f32 reads the f16 operand as it lies in the packed register): the
+// remainder of the first piece, exact in fp32 (s a power of two, pk's half = f16(x * s)).  The compiler's own lowering of the same
+// expression is v_cvt_f32_f16 + v_add per element (tools/r6: 120 -> 88 vector instructions per K-tile).
+__device__ __forceinline__ float sx_rem_lo(float x, float s, uint32_t pk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "s"(s), "v"(pk));
+    return r;
+}
+__device__ __forceinline__ float sx_rem_hi(float x, float s, uint32_t pk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "s"(s), "v"(pk));
+    return r;
+}
 __device__ __forceinline__ void sx_split_store_h(const f32x4& x, float s, char* d) {
     uint32_t pk[2][2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-        const float x0 = x[2 * hh] * s, x1 = x[2 * hh + 1] * s;
-        pk[0][hh] = sx_cvt_pk_h(x0, x1);
-        pk[1][hh] = sx_cvt_pk_h(x0 - sx_h_lo(pk[0][hh]), x1 - sx_h_hi(pk[0][hh]));
+        pk[0][hh] = sx_cvt_pk_h(x[2 * hh] * s, x[2 * hh + 1] * s);
+        pk[1][hh] = sx_cvt_pk_h(sx_rem_lo(x[2 * hh], s, pk[0][hh]), sx_rem_hi(x[2 * hh + 1], s, pk[0][hh]));
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) *(u32x2*)(d + q * SX_PLANE) = (u32x2){pk[q][0], pk[q][1]};

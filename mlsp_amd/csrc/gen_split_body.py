@@ -52,11 +52,12 @@ def items():
                 out.append((10 if DROP else 6, [f"SX_XF_{op}({q}, {hh});"]))
             if HALF:
                 # x * s = h0 + h1 (+ < 2^-22 |x s|): h0 = f16(x s), h1 = f16(x s - h0) (the remainder is exact in fp32); s: the operand's
-                # power-of-two scale (sxs_a / sxs_b).  Per pair: v_pk_mul, v_cvt_pk_f16_f32, 2 v_cvt_f32_f16, v_pk_add, v_cvt_pk_f16_f32
+                # power-of-two scale (sxs_a / sxs_b).  Per pair: v_pk_mul (or 2 v_mul), v_cvt_pk_f16_f32, 2 v_fma_mix_f32 (x s - h0, reading the f16
+                # half in place), v_cvt_pk_f16_f32
                 sc = "sxs_a" if isA else "sxs_b"
-                out.append((4, [f"r0 = {x0} * {sc}; r1 = {x1} * {sc};", f"pk0[{hh}] = sx_cvt_pk_h(r0, r1);"]))
-                L = [f"pk1[{hh}] = sx_cvt_pk_h(r0 - sx_h_lo(pk0[{hh}]), r1 - sx_h_hi(pk0[{hh}]));"]
-                w = 4
+                out.append((3, [f"pk0[{hh}] = sx_cvt_pk_h({x0} * {sc}, {x1} * {sc});"]))
+                L = [f"pk1[{hh}] = sx_cvt_pk_h(sx_rem_lo({x0}, {sc}, pk0[{hh}]), sx_rem_hi({x1}, {sc}, pk0[{hh}]));"]
+                w = 3
                 if hh == 1:
                     d = f"wa + {qd} * WQA" if isA else f"wb + {q} * WQB"
                     for p in range(2):
