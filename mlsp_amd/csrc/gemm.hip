@@ -1240,9 +1240,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[s2][j][q] = sx_frag<KB>(fb + q * SX_PLANE + j * FWB, s2);
             }
-        __syncthreads();                                              // every wave holds its fragments: the images may be overwritten
+        // every wave holds its fragments: the images may be overwritten.  (NPC == 2: that barrier sits in the MIDDLE of the generated body
+        // -- the first k16 step's MFMAs run while the second step's fragments are still arriving, and only stage into registers)
+        if constexpr (NPC == 3) __syncthreads();
         soa = min(soa + sta, enda); sob = min(sob + stb, endb);      // tile t+2 (past the end: a harmless repeat of the last tile)
         uint32_t pk0[2], pk1[2], pk2[2];
+        uint32_t pkd[5][2][2];                                        // NPC == 2: the pieces of the quads staged before the barrier
         float r0, r1, a1;
         __builtin_amdgcn_sched_barrier(0);
         // (one generated body per (tile height, transformed operand, dropout): gen_split_body.py spreads the vector work over the MFMA slots)

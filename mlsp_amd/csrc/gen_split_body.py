@@ -32,6 +32,12 @@ DYA = VAR.startswith("dy")        # dy / dyxb / dyxbd: the A quads are d' + y pa
 XA = VAR.startswith("xa")
 XB = VAR.startswith("xb") or VAR.startswith("dyxb")
 DROP = VAR.endswith("d")
+# HALF: the K-tile body is cut in two phases by a barrier.  The fragments of BOTH k16 steps are requested before the body; phase 1 (the
+# MFMAs of step 0) only waits for step 0's and stages the first Q1 quads in registers while step 1's fragments arrive; at the barrier every
+# wave holds all its fragments, and phase 2 (the MFMAs of step 1) writes the images -- the deferred quads' first.  (Before: all 16 fragment
+# reads were waited for in front of the first MFMA.)
+Q1 = (3 * (NQA + 4) + 4) // 5 if HALF else 0
+WRITES = []
 
 
 def items():
@@ -43,34 +49,42 @@ def items():
         q = qd if isA else qd - NQA
         op = "A" if isA else "B"
         if xf and DROP:
-            out.append((10, [f"SX_XF_HASH_{op}({q});"]))
+            out.append((10, [f"SX_XF_HASH_{op}({q});"], qd))
         for hh in range(2):
             x0, x1 = f"raw[{qd}][{2 * hh}]", f"raw[{qd}][{2 * hh + 1}]"
             if DYA and isA:
-                out.append((6, [f"SX_DY_A({q}, {hh});"]))
+                out.append((6, [f"SX_DY_A({q}, {hh});"], qd))
             if xf:
-                out.append((10 if DROP else 6, [f"SX_XF_{op}({q}, {hh});"]))
+                out.append((10 if DROP else 6, [f"SX_XF_{op}({q}, {hh});"], qd))
             if HALF:
                 # x * s = h0 + h1 (+ < 2^-22 |x s|): h0 = f16(x s), h1 = f16(x s - h0) (the remainder is exact in fp32); s: the operand's
                 # power-of-two scale (sxs_a / sxs_b).  Per pair: v_pk_mul (or 2 v_mul), v_cvt_pk_f16_f32, 2 v_fma_mix_f32 (x s - h0, reading the f16
                 # half in place), v_cvt_pk_f16_f32
                 sc = "sxs_a" if isA else "sxs_b"
-                out.append((3, [f"pk0[{hh}] = sx_cvt_pk_h({x0} * {sc}, {x1} * {sc});"]))
-                L = [f"pk1[{hh}] = sx_cvt_pk_h(sx_rem_lo({x0}, {sc}, pk0[{hh}]), sx_rem_hi({x1}, {sc}, pk0[{hh}]));"]
+                # quads staged in phase 1 (before the mid-body barrier: see the placement below) keep their pieces in pkd[qd] and are
+                # written to the images in phase 2; the others use the scratch pair pk0 / pk1 and are written at once
+                early = qd < Q1
+                P0, P1 = (f"pkd[{qd}][0]", f"pkd[{qd}][1]") if early else ("pk0", "pk1")
+                out.append((3, [f"{P0}[{hh}] = sx_cvt_pk_h({x0} * {sc}, {x1} * {sc});"], qd))
+                L = [f"{P1}[{hh}] = sx_cvt_pk_h(sx_rem_lo({x0}, {sc}, {P0}[{hh}]), sx_rem_hi({x1}, {sc}, {P0}[{hh}]));"]
                 w = 3
                 if hh == 1:
                     d = f"wa + {qd} * WQA" if isA else f"wb + {q} * WQB"
-                    for p in range(2):
-                        L.append(f"*(u32x2*)({d} + {p} * SX_PLANE) = (u32x2){{pk{p}[0], pk{p}[1]}};")
+                    W = [f"*(u32x2*)({d} + {p} * SX_PLANE) = (u32x2){{{(P0, P1)[p]}[0], {(P0, P1)[p]}[1]}};" for p in range(2)]
+                    if early:
+                        WRITES.append((2, W))
+                    else:
+                        L += W
+                        w += 2
                     L.append(f"raw[{qd}] = SX_LOAD_{op}({q});")
                     if DYA and isA:
                         L.append(f"SX_DY_LOAD({q});")
-                    w += 3
-                out.append((w, L))
+                    w += 1
+                out.append((w, L, qd))
                 continue
             out.append((4, [f"pk0[{hh}] = sx_cvt_pk({x0}, {x1});", f"a1 = __uint_as_float(pk0[{hh}] & 0xffff0000u);",
-                            f"r0 = {x0} - __uint_as_float(pk0[{hh}] << 16);"]))
-            out.append((2, [f"r1 = {x1} - a1;", f"pk1[{hh}] = sx_cvt_pk(r0, r1);"]))
+                            f"r0 = {x0} - __uint_as_float(pk0[{hh}] << 16);"], qd))
+            out.append((2, [f"r1 = {x1} - a1;", f"pk1[{hh}] = sx_cvt_pk(r0, r1);"], qd))
             L = [f"pk2[{hh}] = sx_cvt_pk(r0 - __uint_as_float(pk1[{hh}] << 16), r1 - __uint_as_float(pk1[{hh}] & 0xffff0000u));"]
             w = 5
             if hh == 1:
@@ -81,7 +95,7 @@ def items():
                 if DYA and isA:
                     L.append(f"SX_DY_LOAD({q});")
                 w += 4
-            out.append((w, L))
+            out.append((w, L, qd))
     return out
 
 
@@ -124,9 +138,28 @@ if not VAR and not HALF:
         for m in range(c * MS // S, (c + 1) * MS // S):
             out += micro(m)
         out.append("__builtin_amdgcn_sched_barrier(0);")
+elif HALF:
+    its = items()
+    ph = [[(w, L) for w, L, qd in its if qd < Q1], WRITES + [(w, L) for w, L, qd in its if qd >= Q1]]
+    H = S // 2
+    for phase in range(2):
+        if phase == 1:
+            out.append("__syncthreads();     // every wave holds the fragments of both k16 steps: the images may be overwritten")
+        lst = ph[phase]
+        total = sum(w for w, _ in lst)
+        k, done = 0, 0
+        for c in range(H):
+            out.append(f"// slot {phase * H + c}")
+            out.append(mfma(phase * H + c))
+            while k < len(lst) and (done + lst[k][0] / 2.0) * H < (c + 1) * total:
+                out += lst[k][1]
+                done += lst[k][0]
+                k += 1
+            out.append("__builtin_amdgcn_sched_barrier(0);")
+        assert k == len(lst)
 else:
     its = items()
-    total = sum(w for w, _ in its)
+    total = sum(w for w, _, _ in its)
     k, done = 0, 0
     for c in range(S):
         out.append(f"// slot {c}")
