@@ -66,8 +66,10 @@ typedef struct ihipStream_t* mlsp_stream_t; /* == hipStream_t */
  * that call with the same pointer and shape uses the entry's partials instead of measuring into the workspace -- as they are when
  * valid != 0; when valid == 0 the call measures INTO them (its one measuring launch) and sets valid = 1 in the caller's table.  The caller
  * keeps such a buffer for as long as the tensor's contents do not change: an activation that several layers read, a weight that its
- * layer's backward reads again.  Purely an optimisation: without it every call measures what it needs. */
-typedef struct { const float* ptr; long rows; int cols, ld; float* partials; int valid; } mlsp_bound_t;
+ * layer's backward reads again.  A VALID entry may hold any number n <= 4096 of partials from any source whose maximum bounds |X| -- e.g. the
+ * per-tile maxima mlsp_adam_flat_f32 leaves of the parameters it just updated.  Purely an optimisation: without it every call measures
+ * what it needs. */
+typedef struct { const float* ptr; long rows; int cols, ld; float* partials; int valid; int n; } mlsp_bound_t;   /* n: partials held (0 = 256); an entry to be measured (valid == 0) holds 256 */
 int mlsp_operand_bounds_next(mlsp_bound_t* tab, int n);
 
 int mlsp_abi_version(void);
@@ -436,9 +438,13 @@ int mlsp_profile_split_kinds(double* out);
  * segment s covers elements [off[s], off[s] + numel[s]) of the three buffers (buffers 16-byte aligned; off % 4 == 0 takes the 16-byte path) and reads its
  * gradient where autograd left it (grads[s], contiguous fp32, device).  off / numel / grads are HOST arrays.  step >= 1 numbers this
  * update (bias corrections 1 - beta^step); step_out (nullable, device float) receives it.  The element-wise arithmetic restates
- * torch's fused Adam (ATen/native/cuda/fused_adam_utils.cuh, ADAM_MODE::ORIGINAL: weight decay added to the gradient) type by type. */
+ * torch's fused Adam (ATen/native/cuda/fused_adam_utils.cuh, ADAM_MODE::ORIGINAL: weight decay added to the gradient) type by type.
+ * tile_amax (nullable; ABI v13): one float per 2048-element tile -- tiles numbered segment by segment in the order given, ceil(numel[s] /
+ * 2048) per segment -- receives the largest magnitude of the tile's UPDATED parameters: a free bound for the GEMMs that read the
+ * parameters next (mlsp_bound_t: partials = tile_amax + first tile of the weight, n = its tiles). */
 int mlsp_adam_flat_f32(float* P, float* M, float* V, const uint32_t* off, const uint32_t* numel, const float* const* grads, int nseg, double lr,
-                       double beta1, double beta2, double weight_decay, double eps, int64_t step, float* step_out, mlsp_stream_t stream);
+                       double beta1, double beta2, double weight_decay, double eps, int64_t step, float* step_out, float* tile_amax,
+                       mlsp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ _D, _I64 = _c.c_double, _c.c_int64
 # name -> argtypes (restype is int unless listed in _RESTYPE)
 SIGNATURES = {
     "mlsp_abi_version": [],
-    "mlsp_adam_flat_f32": [_P, _P, _P, _P, _P, _P, _I, _D, _D, _D, _D, _D, _I64, _P, _P],
+    "mlsp_adam_flat_f32": [_P, _P, _P, _P, _P, _P, _I, _D, _D, _D, _D, _D, _I64, _P, _P, _P],
     "mlsp_strerror": [_I],
     "mlsp_workspace_bytes": [_I, _I, _I],
     "mlsp_knn_f32": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _SZ, _P],
@@ -109,7 +109,13 @@ class Seg(_c.Structure):
 
 class Bound(_c.Structure):
     """mlsp_bound_t of include/mlsp_hip.h: caller-owned partial maxima of one GEMM operand (functional.OperandBounds)"""
-    _fields_ = [("ptr", _P), ("rows", _c.c_long), ("cols", _I), ("ld", _I), ("partials", _P), ("valid", _I)]
+    _fields_ = [("ptr", _P), ("rows", _c.c_long), ("cols", _I), ("ld", _I), ("partials", _P), ("valid", _I), ("n", _I)]
+
+
+# Sources of ready-made bounds for weight operands (objects with .weight_bounds(tensor) -> (device pointer, n) | None): mlsp_amd.optim.FlatAdam
+# registers itself -- its step kernel leaves the per-tile maxima of the parameters it just updated (functional._weight_bounds asks them).
+import weakref as _weakref
+weight_bound_providers = _weakref.WeakSet()
 
 
 class Defer(_c.Structure):

@@ -66,7 +66,7 @@ struct GemmArgs {
     // Partial maxima of |A| / |B| as they lie in memory (amax_partials_kernel; null / 0 where the bound is analytic), and what the analytic
     // bounds need: a transformed operand (XF, batch statistics over stat_rows rows) is bounded per channel by |scale| sqrt(rows) / invstd +
     // |shift + mean scale| (|yhat| <= sqrt(rows)), a gradient formed on the fly (DY) by max|sc| amax(d') (2 + sqrt(rows)).
-    const float* a_amax; int a_amax_n; const float* b_amax[4]; int b_amax_n; const float* x_mean; const float* x_invstd; float stat_sqrt_rows;   // b_amax[g]: group g's B (gmode 1), else [0]
+    const float* a_amax; int a_amax_n; const float* b_amax[4]; int b_amax_n[4]; const float* x_mean; const float* x_invstd; float stat_sqrt_rows;   // b_amax[g]: group g's B (gmode 1), else [0]
     double* stat_part;              // nullable: per-row-panel column sums of C and C^2, [ntm][2][stat_ld] (BN batch statistics)
     int stat_ld;                    // columns of a statistics row (N, or the width of the wider matrix C is a column slice of)
     const float* sel_gamma;         // nullable: per-column sign selects max (>= 0) or min; enables the fused column-extreme epilogue
@@ -1163,7 +1163,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p) {
         if (XF != 2) {
             const int gb = p.gmode == 1 ? tn / p.gtiles : 0;
             const float* bam = gb == 0 ? p.b_amax[0] : gb == 1 ? p.b_amax[1] : gb == 2 ? p.b_amax[2] : p.b_amax[3];
-            for (int i = tid; i < p.b_amax_n; i += 256) vb = fmaxf(vb, bam[i]);
+            const int bn_ = gb == 0 ? p.b_amax_n[0] : gb == 1 ? p.b_amax_n[1] : gb == 2 ? p.b_amax_n[2] : p.b_amax_n[3];
+            for (int i = tid; i < bn_; i += 256) vb = fmaxf(vb, bam[i]);
         }
         const float sqr = p.stat_sqrt_rows;
         if constexpr (XF == 1) {
@@ -1442,16 +1443,18 @@ extern "C" int mlsp_operand_bounds_next(mlsp_bound_t* tab, int n) {
 struct AmaxBatch { AmaxArgs args; int n = 0; };
 // -> the partials of X [rows][cols] (pitch ld), measured now (queued into `batch`) or earlier in this API call; null: cannot (no tail,
 // unaligned, the batch is full)
-static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, int ld) {
+static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, int ld, int* n_out) {
+    *n_out = AMAX_PARTS;
     if (!tl_amax.base || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3) || (((uintptr_t)X) & 15)) return nullptr;
     for (int i = 0; i < tl_amax.noffered; ++i) {
         mlsp_bound_t& o = tl_amax.offered[i];
-        if (o.ptr != X || o.rows != rows || o.cols != cols || o.ld != ld || !o.partials) continue;
+        if (o.ptr != X || o.rows != rows || o.cols != cols || o.ld != ld || !o.partials || o.n < 0 || o.n > 4096) continue;
         if (!o.valid) {
-            if (batch.n >= 5) return nullptr;
+            if (batch.n >= 5 || (o.n != 0 && o.n != AMAX_PARTS)) return nullptr;
             batch.args.op[batch.n++] = {X, rows, cols, ld, o.partials};
-            o.valid = 1;
+            o.valid = 1; o.n = AMAX_PARTS;
         }
+        *n_out = o.n ? o.n : AMAX_PARTS;
         return o.partials;
     }
     for (int i = 0; i < tl_amax.ncache; ++i) {
@@ -1961,7 +1964,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         p.stat_part = bs->part; p.stat_ld = bs->stat_ld; p.bs_amax = bs->amax;
     }
     p.dy_y = dy ? dy->y : nullptr; p.dy_coef = dy ? dy->coef : nullptr; p.dy_cld = dy ? dy->cld : 0; p.dy_amax = (dy && dy->amax) ? 1 : 0;
-    p.a_amax = nullptr; p.a_amax_n = 0; p.b_amax[0] = p.b_amax[1] = p.b_amax[2] = p.b_amax[3] = nullptr; p.b_amax_n = 0; p.x_mean = p.x_invstd = nullptr; p.stat_sqrt_rows = 0.f;
+    p.a_amax = nullptr; p.a_amax_n = 0; p.b_amax[0] = p.b_amax[1] = p.b_amax[2] = p.b_amax[3] = nullptr; p.b_amax_n[0] = p.b_amax_n[1] = p.b_amax_n[2] = p.b_amax_n[3] = 0; p.x_mean = p.x_invstd = nullptr; p.stat_sqrt_rows = 0.f;
     p.x_scale = p.x_shift = nullptr; p.x_act = 0; p.x_slope = 0.f; p.x_thresh = 0; p.x_inv_keep = 1.f; p.x_seed = 0; p.x_ld = 0; p.x_col = 0;
     if (xf) {
         p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_act = xf->act; p.x_thresh = xf->thresh;
@@ -2022,16 +2025,15 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
         else if (dy && dy->amax) { /* bound from the coefficient rows (max |d'| per channel, left by the consumers' dgrads): nothing to measure */ }
         else {
             const int acols = (ta ? M : K) + ((grp && grp->mode == 1) ? (int)((grp->G - 1) * grp->a_gs) : 0);
-            p.a_amax = amax_get(batch, A, ta ? K : M, acols, lda); p.a_amax_n = AMAX_PARTS;
+            p.a_amax = amax_get(batch, A, ta ? K : M, acols, lda, &p.a_amax_n);
             ok = p.a_amax != nullptr;
         }
         if (xf && xf->which == 2) ok = ok && xf->mean && xf->invstd;
         else if (grp && grp->mode == 1) {
-            for (int g = 0; g < grp->G && ok; ++g) { p.b_amax[g] = amax_get(batch, grp->Bg[g], tb ? N / grp->G : K, tb ? K : N / grp->G, ldb); ok = p.b_amax[g] != nullptr; }
-            p.b_amax_n = AMAX_PARTS;
+            for (int g = 0; g < grp->G && ok; ++g) { p.b_amax[g] = amax_get(batch, grp->Bg[g], tb ? N / grp->G : K, tb ? K : N / grp->G, ldb, &p.b_amax_n[g]); ok = p.b_amax[g] != nullptr; }
         } else {
             const int bcols = (tb ? K : N) + ((grp && grp->mode == 2) ? (int)((grp->G - 1) * grp->b_gs) : 0);
-            p.b_amax[0] = amax_get(batch, B, tb ? N : K, bcols, ldb); p.b_amax_n = AMAX_PARTS;
+            p.b_amax[0] = amax_get(batch, B, tb ? N : K, bcols, ldb, &p.b_amax_n[0]);
             ok = ok && p.b_amax[0] != nullptr;
         }
         amax_flush(st, batch);                 // (whatever was queued is in the cache: measure it even if this launch ends up on the bf16 pieces)

@@ -45,7 +45,10 @@ __device__ __forceinline__ void adam_one(float& param, float grad, float& ea, fl
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V, AdamSegs s, double lr,
                                                         double b1, double b2, double wd, double eps, float bc1, float bc2s, float step,
-                                                        float* __restrict__ step_out) {
+                                                        float* __restrict__ step_out, float* __restrict__ tile_amax) {
+    // tile_amax (nullable, [gridDim.x]): max |updated parameter| of this workgroup's tile -- a by-product for the GEMMs that read the
+    // parameters next (the two-piece f16 products scale every operand by a bound of its magnitude: include/mlsp_hip.h mlsp_bound_t)
+    float pmx = 0.f;
     if (blockIdx.x == 0 && threadIdx.x == 0 && step_out) *step_out = step;     // the optimizer's device-side step counter (state_dict)
     // which segment owns this tile: binary search over <= 96 tile offsets in the kernel arguments
     int lo = 0, hi = s.n - 1;
@@ -73,6 +76,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ P, f
                 float p1 = pp[e], m1 = mm[e], v1 = vv[e];
                 adam_one(p1, gg[e], m1, v1, lr, b1, b2, wd, eps, bc1, bc2s);
                 pp[e] = p1; mm[e] = m1; vv[e] = v1;
+                pmx = fmaxf(pmx, fabsf(p1));
             }
             *(f32x4*)(p + i) = pp; *(f32x4*)(m + i) = mm; *(f32x4*)(v + i) = vv;
         } else {
@@ -80,8 +84,17 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ P, f
                 float pp = p[j], mm = m[j], vv = v[j];
                 adam_one(pp, g[j], mm, vv, lr, b1, b2, wd, eps, bc1, bc2s);
                 p[j] = pp; m[j] = mm; v[j] = vv;
+                pmx = fmaxf(pmx, fabsf(pp));
             }
         }
+    }
+    if (tile_amax) {                    // (uniform: a kernel argument)
+        __shared__ float smx[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pmx = fmaxf(pmx, __shfl_xor(pmx, o, 64));
+        if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = pmx;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_amax[t] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
     }
 }
 
@@ -91,13 +104,17 @@ extern "C" {
 // [off[s], off[s] + numel[s]) (the buffers 16-byte aligned; a segment whose offset and gradient pointer are 16-byte aligned moves 16 bytes per
 // lane, any other one element by element) and reads its gradient from grads[s] (any fp32 device pointer, contiguous).  step >= 1 is this update's number (bias corrections 1 - beta^step); step_out (nullable, device float) receives it.
 // Host arrays; any nseg (launched in groups of 96).
+// tile_amax (nullable; ABI v13): one float per 2048-element tile, tiles numbered segment by segment in the order given
+// (ceil(numel[s] / 2048) tiles per segment): the largest magnitude of the UPDATED parameters of the tile.
 int mlsp_adam_flat_f32(float* P, float* M, float* V, const uint32_t* off, const uint32_t* numel, const float* const* grads, int nseg, double lr,
-                       double beta1, double beta2, double weight_decay, double eps, int64_t step, float* step_out, mlsp_stream_t st) {
+                       double beta1, double beta2, double weight_decay, double eps, int64_t step, float* step_out, float* tile_amax,
+                       mlsp_stream_t st) {
     if (!P || !M || !V || !off || !numel || !grads || nseg <= 0 || step < 1) return MLSP_ERR_ARG;
     if ((((uintptr_t)P | (uintptr_t)M | (uintptr_t)V) & 15) != 0) return MLSP_ERR_ARG;
     // (as the reference kernel: pow in double, the corrections handed on as floats)
     const float bc1 = (float)(1.0 - pow(beta1, (double)(float)step));
     const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)(float)step));
+    size_t tile_base = 0;
     for (int s0 = 0; s0 < nseg; s0 += ADAM_MAX_SEGS) {
         AdamSegs a;
         a.n = nseg - s0 < ADAM_MAX_SEGS ? nseg - s0 : ADAM_MAX_SEGS;
@@ -110,7 +127,8 @@ int mlsp_adam_flat_f32(float* P, float* M, float* V, const uint32_t* off, const 
         }
         a.tile_begin[a.n] = tiles;
         hipLaunchKernelGGL(adam_flat_kernel, dim3(tiles), dim3(256), 0, st, P, M, V, a, lr, beta1, beta2, weight_decay, eps, bc1, bc2s, (float)step,
-                           s0 == 0 ? step_out : (float*)nullptr);
+                           s0 == 0 ? step_out : (float*)nullptr, tile_amax ? tile_amax + tile_base : (float*)nullptr);
+        tile_base += tiles;
     }
     return mlsp_launch_status();
 }

@@ -55,6 +55,25 @@ class OperandBounds:
         self.buf, self.valid = torch.empty(256, dtype=torch.float32, device=device), False
 
 
+class ProvidedBounds:
+    """bounds that already exist somewhere (n partial maxima at a device pointer): what _lib.weight_bound_providers hand out"""
+    __slots__ = ("ptr", "n", "valid", "keep")
+
+    def __init__(self, ptr, n, keep=None):
+        self.ptr, self.n, self.valid, self.keep = int(ptr), int(n), True, keep
+
+
+def _weight_bounds(W, device):
+    """bounds object for a weight operand of the next C call: ready-made ones when a registered provider covers W (FlatAdam: the maxima
+    its step kernel left), else a fresh OperandBounds that the call measures into"""
+    if _SHARE_BOUNDS:
+        for prov in _lib.weight_bound_providers:
+            r = prov.weight_bounds(W)
+            if r is not None:
+                return ProvidedBounds(r[0], r[1], prov)
+    return OperandBounds(device)
+
+
 class _offer_bounds:
     """`with _offer_bounds((tensor, bounds), ...):` around ONE C call: hands the call the bounds of those of its 2-D fp32 operands the
     caller keeps bounds for (None entries are skipped; nothing happens outside mode "f16x3"), and records which ones the call measured."""
@@ -69,7 +88,10 @@ class _offer_bounds:
         if self.pairs:
             self.tab = (_lib.Bound * len(self.pairs))()
             for e, (t, b) in zip(self.tab, self.pairs):
-                e.ptr, e.rows, e.cols, e.ld, e.partials, e.valid = t.data_ptr(), t.shape[0], t.shape[1], t.stride(0), b.buf.data_ptr(), int(b.valid)
+                if isinstance(b, ProvidedBounds):
+                    e.ptr, e.rows, e.cols, e.ld, e.partials, e.valid, e.n = t.data_ptr(), t.shape[0], t.shape[1], t.stride(0), b.ptr, 1, b.n
+                else:
+                    e.ptr, e.rows, e.cols, e.ld, e.partials, e.valid, e.n = t.data_ptr(), t.shape[0], t.shape[1], t.stride(0), b.buf.data_ptr(), int(b.valid), 0
             _lib.load().mlsp_operand_bounds_next(self.tab, len(self.pairs))
         return self
 
@@ -77,7 +99,8 @@ class _offer_bounds:
         if self.tab is not None:
             _lib.load().mlsp_operand_bounds_next(None, 0)          # (a call that failed before its precision scope leaves nothing behind)
             for e, (_, b) in zip(self.tab, self.pairs):
-                b.valid = bool(e.valid)
+                if not isinstance(b, ProvidedBounds):
+                    b.valid = bool(e.valid)
         return False
 
 
@@ -612,7 +635,7 @@ class _MultiMLP(Function):
         p = float(p_drop) if training else 0.0
         ws, wsn = _lib.workspace(dev, M, X.stride(0), Ctot)
         # (mode "f16x3": the weights' magnitude bounds measured by this call are read again by the backward)
-        ctx.w_bounds = [OperandBounds(dev) for _ in Ws] if prec == 3 else []
+        ctx.w_bounds = [_weight_bounds(w, dev) for w in Ws] if prec == 3 else []
         with _offer_bounds(prec, *zip(Ws, ctx.w_bounds)):
             _lib.check(lib.mlsp_multimlp_fwd_f32(X.data_ptr(), X.stride(0), M, segs, n, defs, gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean),
                                                  _lib.ptr(run_var), momentum, eps, int(training), chan.data_ptr(), p, seed, Y.data_ptr(),
@@ -1069,7 +1092,7 @@ class _PointMLP(Function):
         # mode "f16x3": bounds of the operands as they lie in memory, measured once by this call and read again by the backward (a deferred
         # input is bounded analytically; x_bounds: the caller shares X's with the other layers that read X)
         ctx.bounds = ((x_bounds if x_bounds is not None else OperandBounds(dev)) if in_def is None and not x_bf16 else None,
-                      OperandBounds(dev)) if prec == 3 and M > 32 else (None, None)
+                      _weight_bounds(W, dev)) if prec == 3 and M > 32 else (None, None)
         ctx_offer = _offer_bounds(prec, (X, ctx.bounds[0]), (W, ctx.bounds[1]))
         ctx_offer.__enter__()
         if mx:
@@ -1229,7 +1252,7 @@ class _PointMLPColMax(Function):
         bn_save = torch.empty((4, Cout), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, P, Cin, Cout)
         # (mode "f16x3": the operand bounds this call measures are kept for the backward, which reads X and W again)
-        ctx.bounds = (x_bounds if x_bounds is not None else OperandBounds(dev), OperandBounds(dev)) if prec == 3 else (None, None)
+        ctx.bounds = (x_bounds if x_bounds is not None else OperandBounds(dev), _weight_bounds(W, dev)) if prec == 3 else (None, None)
         with _offer_bounds(prec, (X, ctx.bounds[0]), (W, ctx.bounds[1])):
             _lib.check(lib.mlsp_pointmlp_colmax_fwd_f32(
                 X.data_ptr(), X.stride(0), B, N, Cin, W.data_ptr(), W.stride(0), Cout, gamma.data_ptr(), beta.data_ptr(),

@@ -139,7 +139,14 @@ class FlatAdam(torch.optim.Adam):
         self.layouts_built += 1
         n_act = len(active)
         seg = ((ctypes.c_uint32 * n_act)(*[offs[i] for i in active]), (ctypes.c_uint32 * n_act)(*[ps[i].numel() for i in active]))
-        return {"params": ps, "offs": offs, "p": flat_p, "m": flat_m, "v": flat_v, "step": step, "host_step": host_step, "seg": seg}
+        # per-tile maxima of the updated parameters (csrc/optim.hip tile_amax): tiles run segment by segment in the order of `active`
+        tile_begin, t = [], 0
+        for i in active:
+            tile_begin.append(t)
+            t += (ps[i].numel() + 2047) // 2048
+        tile_begin.append(t)
+        return {"params": ps, "offs": offs, "p": flat_p, "m": flat_m, "v": flat_v, "step": step, "host_step": host_step, "seg": seg,
+                "tile_amax": torch.zeros(t, dtype=torch.float32, device=dev), "tile_begin": tile_begin, "amax_versions": None, "amax_map": {}}
 
     def _leave_flat(self, why=None):
         """torch's per-tensor path from now on (same storage): every stepped parameter gets its own step counter.  `why`: warn once --
@@ -199,9 +206,56 @@ class FlatAdam(torch.optim.Adam):
         gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
         _lib.check(_lib.load().mlsp_adam_flat_f32(f["p"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(), f["seg"][0], f["seg"][1], gp, n,
                                                   float(grp["lr"]), float(b1), float(b2), float(grp["weight_decay"]), float(grp["eps"]),
-                                                  f["host_step"], f["step"].data_ptr(), _lib.stream()), "mlsp_adam_flat_f32")
+                                                  f["host_step"], f["step"].data_ptr(), f["tile_amax"].data_ptr(), _lib.stream()), "mlsp_adam_flat_f32")
+        # the kernel left the magnitude of every updated parameter tile: valid for as long as nobody else writes the parameters (an
+        # in-place torch operation bumps the tensor's version counter -- the raw update above does not)
+        f["amax_versions"] = [ps[i]._version for i in act]
+        _lib.weight_bound_providers.add(self)
         self.flat_steps += 1
         return loss
+
+    def invalidate_bounds(self):
+        """Forget the parameter magnitudes the last step left (call after writing parameters in a way torch's version counters do not
+        see: in-place operations on `.data`); the GEMMs measure their weights again until the next step."""
+        if self._flat is not None:
+            self._flat["amax_versions"] = None
+
+    def weight_bounds(self, W):
+        """(device pointer, n) of ready-made partial maxima bounding |W| for a GEMM operand W that lies inside the flat parameter buffer --
+        the tiles of the parameters it overlaps, as the last step's kernel left them -- or None (not in the buffer, a parameter without
+        a gradient in between, or written by someone else since the step: the caller measures)."""
+        f = self._flat
+        if f is None or f.get("amax_versions") is None or W.dim() != 2 or W.dtype != torch.float32 or W.stride(1) != 1:
+            return None
+        base, nbytes = f["p"].data_ptr(), f["p"].numel() * 4
+        a = W.data_ptr() - base
+        if a < 0 or a >= nbytes or a % 4:
+            return None
+        key = (a, W.shape[0], W.shape[1], W.stride(0))
+        hit = f["amax_map"].get(key)
+        if hit is None:
+            a //= 4
+            b = a + (W.shape[0] - 1) * W.stride(0) + W.shape[1]            # one past the last element W touches
+            ps, offs, act = f["params"], f["offs"], self._active
+            cover = [j for j, i in enumerate(act) if offs[i] < b and offs[i] + ps[i].numel() > a]
+            ok = bool(cover) and cover == list(range(cover[0], cover[-1] + 1)) and a >= offs[act[cover[0]]] and b <= offs[act[cover[-1]]] + ps[act[cover[-1]]].numel()
+            # (every element of W must lie inside some ACTIVE parameter: alignment gaps between units hold zeros, which is fine, but a
+            # parameter that is not stepped has no tile)
+            if ok:
+                spans = sorted((offs[act[j]], offs[act[j]] + ps[act[j]].numel()) for j in cover)
+                inactive = [(offs[i], offs[i] + p.numel()) for i, p in enumerate(ps) if i not in set(act)]
+                ok = not any(lo < b and hi > a for lo, hi in inactive)
+            hit = f["amax_map"][key] = (cover[0], cover[-1]) if ok else False
+        if hit is False:
+            return None
+        j0, j1 = hit
+        ps, act, ver = f["params"], self._active, f["amax_versions"]
+        if any(ps[act[j]]._version != ver[j] for j in range(j0, j1 + 1)):
+            return None
+        t0, t1 = f["tile_begin"][j0], f["tile_begin"][j1 + 1]
+        if t1 - t0 > 4096:
+            return None
+        return f["tile_amax"].data_ptr() + 4 * t0, t1 - t0
 
     def load_state_dict(self, state_dict):
         # loaded moments are fresh tensors: rebuild the flat buffers from them at the next step (parameters stay where they are)
