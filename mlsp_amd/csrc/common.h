@@ -33,7 +33,7 @@ void prof_cls_end(hipStream_t st, int token, double work);
 #define MLSP_AMAX_TAIL_BYTES 65536
 struct GemmPrecisionScope {
     int prev;
-    void* prev_tail;
+    void* prev_tail; void* prev_offered; int prev_noffered;
     // ws / ws_bytes: the call's workspace -- its last MLSP_AMAX_TAIL_BYTES hold the operand-magnitude partials of the two-piece f16 products
     // (mode 3; gemm.hip amax_partials); Workspace below never hands that tail out
     explicit GemmPrecisionScope(int mode, void* ws = nullptr, size_t ws_bytes = 0);

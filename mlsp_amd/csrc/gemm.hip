@@ -1486,13 +1486,15 @@ GemmPrecisionScope::GemmPrecisionScope(int mode, void* ws, size_t ws_bytes) : pr
     tl_split_half = mode == 3; tl_call_precision = mode == 3 ? 2 : mode;
     tl_amax.base = (mode == 3 && ws && ws_bytes >= 2 * MLSP_AMAX_TAIL_BYTES) ? (float*)((char*)ws + align_up(ws_bytes - MLSP_AMAX_TAIL_BYTES, 256)) : nullptr;
     tl_amax.next = tl_amax.ncache = 0;
-    tl_amax.offered = tl_amax.pending; tl_amax.noffered = tl_amax.npending;        // (consumed by this call, whatever its mode)
-    tl_amax.pending = nullptr; tl_amax.npending = 0;
+    // the caller's bounds table is consumed by the OUTERMOST scope of the call (a nested scope -- an entry point asking one of the
+    // shape queries -- leaves it, and the outer scope's measuring state, alone)
+    prev_offered = tl_amax.offered; prev_noffered = tl_amax.noffered;
+    if (tl_amax.pending) { tl_amax.offered = tl_amax.pending; tl_amax.noffered = tl_amax.npending; tl_amax.pending = nullptr; tl_amax.npending = 0; }
 }
 GemmPrecisionScope::~GemmPrecisionScope() {
     tl_call_precision = prev & 3; tl_split_half = (prev & 4) != 0;
     tl_amax.base = (float*)prev_tail; tl_amax.next = tl_amax.ncache = 0;
-    tl_amax.offered = nullptr; tl_amax.noffered = 0;
+    tl_amax.offered = (mlsp_bound_t*)prev_offered; tl_amax.noffered = prev_noffered;
 }
 
 // sum the split-K slabs (fixed order -> bitwise reproducible) and apply the epilogue

@@ -115,6 +115,9 @@ class FlatAdam(torch.optim.Adam):
             lay = flat_offsets(ps, self.ALIGN)
         offs, n = lay
         active = self._active if self._active is not None else [i for i, p in enumerate(ps) if p.grad is not None]
+        # (segments -- and with them the step kernel's tiles -- in ADDRESS order: parameters that one GEMM reads as a single operand, adjacent
+        # in the buffer but not in model.parameters(), then own one contiguous run of tile maxima: weight_bounds)
+        active = sorted(active, key=lambda i: offs[i])
         steps = {float(self.state[ps[i]]["step"]) for i in active if ps[i] in self.state and "step" in self.state[ps[i]]}
         have = [i for i in active if ps[i] in self.state and "exp_avg" in self.state[ps[i]]]
         if len(steps) > 1 or (have and len(have) != len(active)) or any(p in self.state and self.state[p] for i, p in enumerate(ps) if i not in active):
