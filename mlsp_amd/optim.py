@@ -199,7 +199,7 @@ class FlatAdam(torch.optim.Adam):
                 self._disabled = True
                 super().step()
                 return loss
-            ps = f["params"]
+            ps, act = f["params"], self._active            # (the rebuild orders the segments by their NEW addresses)
         grp = self.param_groups[0]
         b1, b2 = grp["betas"]
         # one launch; every gradient is read where autograd (or the exchange's bucket) left it

@@ -170,3 +170,49 @@ def test_flat_adam_keeps_shared_storages_together(dev):
     assert o1.flat_steps == 6 and o1.layouts_built == 2
     for p, q in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(o1.state[p]["exp_avg"], o2.state[q]["exp_avg"]) and torch.equal(o1.state[p]["exp_avg_sq"], o2.state[q]["exp_avg_sq"])
+
+
+def test_flat_adam_publishes_weight_bounds(dev):
+    """Round 6: the step kernel leaves the largest magnitude of every updated 2048-element parameter tile (mlsp_adam_flat_f32 tile_amax);
+    FlatAdam.weight_bounds hands a GEMM the run of tiles of the parameters its weight operand overlaps -- a bound of |W| that costs no
+    measuring launch (functional._weight_bounds, the two-piece f16 products).  The maxima are exact for a whole parameter, an upper bound
+    for a strided view; they are withdrawn when torch sees somebody else write the parameter, and by invalidate_bounds()."""
+    from mlsp_amd import Models, functional as Fh, _lib
+    from mlsp_amd.optim import FlatAdam
+    torch.manual_seed(3)
+    m = Models.DGCNN(gc.make_args(cuda=True)).to(dev).train()
+    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+    x = (torch.rand(4, 3, 256, device=dev) * 2 - 1)
+    W5 = m.conv5.weight.view(1024, -1)
+    assert opt.weight_bounds(W5) is None                                   # nothing published before the first step
+    for _ in range(2):
+        opt.zero_grad()
+        out = m(x, activate_density_normal_ondef=True)
+        sum(v.float().sum() for v in out.values()).backward()
+        opt.step()
+    assert opt in _lib.weight_bound_providers
+    W5 = m.conv5.weight.view(1024, -1)
+    ptr, n = opt.weight_bounds(W5)
+    f = opt._flat
+    t0 = (ptr - f["tile_amax"].data_ptr()) // 4
+    assert n == (W5.numel() + 2047) // 2048 and 0 <= t0 and t0 + n <= f["tile_amax"].numel()
+    assert f["tile_amax"][t0:t0 + n].max().item() == W5.abs().max().item()      # exact for a whole parameter
+    # the three heads' first-layer weights as ONE strided operand (Models.merged_first_layers): adjacent in the buffer -> one run of tiles
+    Wm = Fh.row_blocks([h.conv1.weight.view(h.conv1.out_channels, -1) for h in (m.DefRec, m.Norm_pred, m.Density_cls)], rehome=False)
+    r = opt.weight_bounds(Wm[:, :512])
+    assert r is not None
+    t0 = (r[0] - f["tile_amax"].data_ptr()) // 4
+    assert f["tile_amax"][t0:t0 + r[1]].max().item() >= Wm[:, :512].abs().max().item()
+    assert opt.weight_bounds(torch.zeros(64, 64, device=dev)) is None      # not a view of the flat buffer
+    with torch.no_grad():
+        m.conv5.weight.mul_(1.5)                                            # torch sees this write: the bounds of conv5 are withdrawn ...
+    assert opt.weight_bounds(m.conv5.weight.view(1024, -1)) is None
+    assert opt.weight_bounds(Wm[:, :512]) is not None                       # ... the others stand
+    opt.invalidate_bounds()
+    assert opt.weight_bounds(Wm[:, :512]) is None
+    # and the step after republishes, the forward in between having measured its weights itself
+    opt.zero_grad()
+    out = m(x, activate_density_normal_ondef=True)
+    sum(v.float().sum() for v in out.values()).backward()
+    opt.step()
+    assert opt.weight_bounds(m.conv5.weight.view(1024, -1)) is not None
