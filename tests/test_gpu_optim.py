@@ -6,6 +6,8 @@ import pytest
 import torch
 from torch import nn
 
+import golden_common as gc
+
 pytestmark = pytest.mark.gpu
 
 
