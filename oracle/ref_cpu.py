@@ -55,6 +55,9 @@ class _Ctx:
         self.knn_idx = []
         self.sel = []          # arg-max of every max-pool, in call order (tests: mlsp_amd.functional.forced_selections)
         self.feats = {}
+        self.force_sel = None  # tests: an iterator over selections recorded by ANOTHER evaluation -- the pools take those entries instead of
+                               # their own arg-max (float64 truth, a rounding emulation and the HIP path then differ in arithmetic only)
+        self.q = None          # tests: operand rounding emulation (oracle/ref_seg_cpu.py bf16 yardstick); None = exact
 
     def bn(self, y, prefix, reduce_dims):
         """torch BatchNorm semantics (model_utils.py:56-58): biased var to normalise, unbiased
@@ -82,13 +85,21 @@ class _Ctx:
 
     def max_k(self, x):
         """max over the k neighbours of [B, C, N, k]; records the winning slot as [B*N, C] (the HIP path's point-major layout)"""
-        v, a = x.max(dim=-1)
+        if self.force_sel is not None:
+            a = next(self.force_sel).view(x.shape[0], x.shape[2], x.shape[1]).permute(0, 2, 1)
+            v = x.gather(-1, a.unsqueeze(-1)).squeeze(-1)
+        else:
+            v, a = x.max(dim=-1)
         self.sel.append(a.permute(0, 2, 1).reshape(-1, a.shape[1]))
         return v
 
     def max_n(self, x):
         """max over the N points of [B, C, N]; records the winning point (local to its cloud) as [B, C]"""
-        v, a = x.max(dim=2)
+        if self.force_sel is not None:
+            a = next(self.force_sel)
+            v = x.gather(2, a.unsqueeze(2)).squeeze(2)
+        else:
+            v, a = x.max(dim=2)
         self.sel.append(a)
         return v
 

@@ -13,15 +13,26 @@ import torch.nn.functional as F
 from .ref_cpu import _Ctx, graph_feature, knn_reference_formula, K_DEFAULT
 
 
+def round_bf16_ste(t):
+    """t rounded to bf16 (RNE) in t's own dtype, gradient passed straight through: the rounding a bf16 GEMM operand / a bf16-stored
+    activation sees, for the YARDSTICK of tests/test_gpu_model.py::test_segda_config4_bf16_step_vs_oracle (how far does this network move
+    when its contractions read bf16 operands -- evaluated in float64, so nothing else differs from the truth)"""
+    return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
+
+def _q(c, t):
+    return t if c.q is None else c.q(t)
+
+
 def _conv2d(c, x, key):
-    y = torch.einsum("oc,bcnk->bonk", c.p[key + ".weight"][:, :, 0, 0], x)
+    y = torch.einsum("oc,bcnk->bonk", _q(c, c.p[key + ".weight"][:, :, 0, 0]), _q(c, x))
     if key + ".bias" in c.p:
         y = y + c.p[key + ".bias"].view(1, -1, 1, 1)
     return y
 
 
 def _conv1d(c, x, key):
-    y = torch.einsum("oc,bcn->bon", c.p[key + ".weight"][:, :, 0], x)
+    y = torch.einsum("oc,bcn->bon", _q(c, c.p[key + ".weight"][:, :, 0]), _q(c, x))
     if key + ".bias" in c.p:
         y = y + c.p[key + ".bias"].view(1, -1, 1)
     return y
@@ -34,9 +45,9 @@ def _transform_net(c, x0, prefix="input_transform_net"):
     x = c.max_k(x).unsqueeze(-1)                     # (max pools through the context: their arg-max is recorded, ref_cpu._Ctx.sel)
     x = F.leaky_relu(_conv2d(c, x, prefix + ".conv2d3.conv.0"), 0.2)
     x = c.max_n(x[..., 0]).reshape(x.shape[0], -1)
-    x = F.leaky_relu(x @ c.p[prefix + ".fc1.fc.0.weight"].t() + c.p[prefix + ".fc1.fc.0.bias"], 0.2)
-    x = F.leaky_relu(x @ c.p[prefix + ".fc2.fc.0.weight"].t() + c.p[prefix + ".fc2.fc.0.bias"], 0.2)
-    x = x @ c.p[prefix + ".fc3.weight"].t() + c.p[prefix + ".fc3.bias"]
+    x = F.leaky_relu(_q(c, x) @ _q(c, c.p[prefix + ".fc1.fc.0.weight"]).t() + c.p[prefix + ".fc1.fc.0.bias"], 0.2)
+    x = F.leaky_relu(_q(c, x) @ _q(c, c.p[prefix + ".fc2.fc.0.weight"]).t() + c.p[prefix + ".fc2.fc.0.bias"], 0.2)
+    x = _q(c, x) @ _q(c, c.p[prefix + ".fc3.weight"]).t() + c.p[prefix + ".fc3.bias"]
     return (x + torch.eye(3).reshape(1, 9)).view(-1, 3, 3)
 
 
@@ -49,7 +60,7 @@ def _bn_head(c, x, prefix, nout_key="conv4"):
 
 
 def _fc_bn_lrelu(c, x, prefix):
-    y = x @ c.p[prefix + ".fc.0.weight"].t()
+    y = _q(c, x) @ _q(c, c.p[prefix + ".fc.0.weight"]).t()
     if prefix + ".fc.0.bias" in c.p:
         y = y + c.p[prefix + ".fc.0.bias"]
     return F.leaky_relu(c.bn(y, prefix + ".fc.1", (0,)), 0.2)
@@ -61,16 +72,20 @@ def _density_head(c, x, prefix="Density_cls"):
     x = x.permute(0, 2, 1).reshape(-1, x.shape[1])
     x = c.drop(_fc_bn_lrelu(c, x, prefix + ".mlp1"))
     x = c.drop(_fc_bn_lrelu(c, x, prefix + ".mlp2"))
-    logits = x @ c.p[prefix + ".mlp3.weight"].t() + c.p[prefix + ".mlp3.bias"]
+    logits = _q(c, x) @ _q(c, c.p[prefix + ".mlp3.weight"]).t() + c.p[prefix + ".mlp3.bias"]
     p_vec = F.softmax(logits, dim=1)
     return p_vec, (p_vec @ c.p[prefix + ".fc2.weight"].t())[:, 0]
 
 
 def dgcnn_defrec_forward(params, x, training=True, dropout_p=0.0, k=K_DEFAULT, knn_fn=knn_reference_formula, make_seg=True,
                          activate_DefRec=True, activate_normal=False, activate_density=False,
-                         activate_density_normal_ondef=False, return_ctx=False):
-    """DGCNN_DefRec.forward (PointSegDA/Models.py:212-242).  Returns (logits dict, new BN buffers)."""
+                         activate_density_normal_ondef=False, return_ctx=False, force_sel=None, quant=None):
+    """DGCNN_DefRec.forward (PointSegDA/Models.py:212-242).  Returns (logits dict, new BN buffers).
+    Tests only: `force_sel` (selections recorded by another evaluation, in call order) pins every max-pool; `quant` (e.g. round_bf16_ste)
+    is applied to both operands of every contraction -- the rounding emulation behind the bf16 yardstick."""
     c = _Ctx(params, training, dropout_p, knn_fn)
+    c.force_sel = iter(force_sel) if force_sel is not None else None
+    c.q = quant
     B, _, N = x.shape
 
     def graph(xin):
