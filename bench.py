@@ -907,7 +907,8 @@ def main():
                 out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": sp_peak, "unit": "TFLOP/s", "frac": ach / sp_peak,
                                    "traffic": traffic, "traffic_source": "committed profile (%s), not measured in this run" % traffic_src,
                                    "algorithmic_bytes_per_launch": alg_all / n_all if n_all else None,
-                                   "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, %s) and algorithmic bytes per launch (A + B + C, "
+                                   "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, %s) and algorithmic bytes per launch (A + B + C as the "
+                                                   "formulation reads them: a gradient formed on the fly is a (d', y) operand PAIR, a beta = 1 launch reads C too; "
                                                    "split-K slabs written once and read once by the reduce) over the SAME launches: the ones that ran on "
                                                    "gemm_split_kernel, weighted by this run's launch mix; `by_kind` has them per instantiation "
                                                    "(fwd / dgrad / wgrad)" % traffic_src,

@@ -1733,7 +1733,7 @@ static struct GemmProf {
     std::vector<hipEvent_t> ev;     // pairs
     size_t used = 0;
     double flop = 0.0, bytes = 0.0;   // algorithmic: 2*M*N*K and the A + B + C bytes in their storage types
-    struct Rec { int M, N, K, ta, tb, ns, bm, fused, split; };
+    struct Rec { int M, N, K, ta, tb, ns, bm, fused, split, extra; };       // extra: bit 0 = the A operand is a (d', y) PAIR (DY), bit 1 = C is read too (beta = 1)
     std::vector<Rec> rec;           // one per pair, for the MLSP_PROF_DUMP listing
 } g_prof;
 #define PROF_MAX_PAIRS 4096
@@ -1836,7 +1836,8 @@ extern "C" int mlsp_profile_split_kinds(double* out) {
         if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MLSP_ERR_UNSUPPORTED;
         const int kind = r.ta ? 2 : (r.tb ? 0 : 1);
         const double fl = 2.0 * r.M * (double)r.N * r.K;
-        const double by = 4.0 * ((double)r.M * r.K + (double)r.K * r.N + (double)r.M * r.N * (r.ns > 1 ? 2.0 * r.ns + 1.0 : 1.0));
+        // A + B + C as this formulation reads / writes them: a (d', y) pair is two A operands, a beta = 1 launch reads C as well
+        const double by = 4.0 * ((double)r.M * r.K * ((r.extra & 1) ? 2.0 : 1.0) + (double)r.K * r.N + (double)r.M * r.N * ((r.ns > 1 ? 2.0 * r.ns + 1.0 : 1.0) + ((r.extra & 2) ? 1.0 : 0.0)));
         double* o = out + 4 * kind;
         o[0] += t; o[1] += 1.0; o[2] += fl; o[3] += by;
         if (r.split == 2) { out[12] += t; out[13] += 1.0; out[14] += fl; out[15] += by; }     // (row 3: those on the two-piece f16 products)
@@ -2118,7 +2119,7 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
         const bool on_split = fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && (!xf || xf_split);
-        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0), on_split ? (half ? 2 : 1) : 0};
+        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + (sel_gamma ? 2 : 0), on_split ? (half ? 2 : 1) : 0, (dy ? 1 : 0) + (accumulate ? 2 : 0)};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;
         g_prof.bytes += 4.0 * ((double)M * K + (double)K * N + (C ? (double)M * N : 0.0));
@@ -2199,7 +2200,7 @@ int launch_gemm_mx(hipStream_t st, bool ta, bool tb, int M, int N, int K, const 
 #undef MX_GO
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
-        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + 4, 0};
+        g_prof.rec[g_prof.used] = {M, N, K, ta, tb, ns, bm, (stat_part ? 1 : 0) + 4, 0, 0};
         g_prof.used++;
         g_prof.flop += 2.0 * M * (double)N * K;
         g_prof.bytes += (a_bf16 ? 2.0 : 4.0) * M * K + (b_bf16 ? 2.0 : 4.0) * K * N + (c_bf16 ? 2.0 : 4.0) * M * N;
