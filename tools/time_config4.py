@@ -38,9 +38,11 @@ def step():
     opt.step()
 
 
-MODES = (("fp32", "fp32", "fp32"), ("bf16 operands", "bf16", "fp32"), ("bf16 operands + bf16 activation storage", "bf16", "bf16"))
+MODES = (("fp32 (f32 MFMA)", "fp32", "fp32"), ("fp32-accurate split products bf16x6, fp32 storage (deferred activations)", "bf16x6", "fp32"),
+         ("fp32-accurate split products f16x3, fp32 storage (deferred activations)", "f16x3", "fp32"),
+         ("bf16 operands", "bf16", "fp32"), ("bf16 operands + bf16 activation storage", "bf16", "bf16"))
 if os.environ.get("C4_MODE") == "bf16":          # profiling: the configs[4] mode only
-    MODES = MODES[2:]
+    MODES = MODES[4:]
 for name, prec, store in MODES:
     with Fh.gemm_precision(prec), Fh.activation_storage(store):
         for _ in range(5):
