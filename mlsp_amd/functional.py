@@ -790,11 +790,15 @@ class _EdgeConv(Function):
         keep_wd = bool(ctx.needs_input_grad[0])
         Wd = torch.empty((2 * Cout, C), dtype=torch.float32, device=dev) if keep_wd else None
         ws, wsn = _lib.workspace(dev, P, C, 2 * Cout)
-        _lib.check(lib.mlsp_edgeconv_fwd_f32(
-            xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-            _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, act, slope, int(training), graph.B, graph.N, C, Cout,
-            graph.k, out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
-            bn_save.data_ptr(), _lib.ptr(Wd), prec, ws, wsn, _lib.stream()), "mlsp_edgeconv_fwd_f32")
+        # (mode "f16x3", the layers whose [u|v] GEMM runs on the split kernel: the input's and the folded weight's bounds, measured by this
+        # call, are read again by the backward's weight gradient and dgrad)
+        ctx.bounds = (OperandBounds(dev), OperandBounds(dev) if Wd is not None else None) if prec == 3 and C >= 128 else (None, None)
+        with _offer_bounds(prec, (xp, ctx.bounds[0]), (Wd, ctx.bounds[1])):
+            _lib.check(lib.mlsp_edgeconv_fwd_f32(
+                xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, act, slope, int(training), graph.B, graph.N, C, Cout,
+                graph.k, out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
+                bn_save.data_ptr(), _lib.ptr(Wd), prec, ws, wsn, _lib.stream()), "mlsp_edgeconv_fwd_f32")
         if _sel_record is not None or _sel_forced is not None:
             _selection_hook(argsel)
         if out_buf is not None:
@@ -825,12 +829,13 @@ class _EdgeConv(Function):
         dgamma = torch.empty((Cout,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((Cout,), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, P, C, 2 * Cout)
-        _lib.check(lib.mlsp_edgeconv_bwd_f32(
-            dOut.data_ptr(), dOut.stride(0), xp.data_ptr(), xp.stride(0), graph.rev_off.data_ptr(), graph.rev_ent.data_ptr(),
-            W2d.data_ptr(), out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
-            bn_save.data_ptr(), _lib.ptr(Wd), act, slope, int(training), graph.B, graph.N, C, Cout, graph.k, _lib.ptr(dx),
-            dx.stride(0) if dx is not None else C, accumulate, dW.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn,
-            _lib.stream()), "mlsp_edgeconv_bwd_f32")
+        with _offer_bounds(ctx.prec, (xp, ctx.bounds[0]), (Wd, ctx.bounds[1])):
+            _lib.check(lib.mlsp_edgeconv_bwd_f32(
+                dOut.data_ptr(), dOut.stride(0), xp.data_ptr(), xp.stride(0), graph.rev_off.data_ptr(), graph.rev_ent.data_ptr(),
+                W2d.data_ptr(), out.data_ptr(), out.stride(0), uv.data_ptr(), msel.data_ptr(), argsel.data_ptr(), s1.data_ptr(),
+                bn_save.data_ptr(), _lib.ptr(Wd), act, slope, int(training), graph.B, graph.N, C, Cout, graph.k, _lib.ptr(dx),
+                dx.stride(0) if dx is not None else C, accumulate, dW.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn,
+                _lib.stream()), "mlsp_edgeconv_bwd_f32")
         return (dx, dW, dgamma, dbeta) + (None,) * 10
 
 
