@@ -1100,26 +1100,28 @@ class _PointMLP(Function):
                       _weight_bounds(W, dev)) if prec == 3 and M > 32 else (None, None)
         ctx_offer = _offer_bounds(prec, (X, ctx.bounds[0]), (W, ctx.bounds[1]))
         ctx_offer.__enter__()
-        if mx:
-            _lib.check(lib.mlsp_pointmlp_fwd_mx(
-                X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
-                int(rows_per_group), gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
-                int(training), act, slope, p, seed, Y.data_ptr(), Z.data_ptr(), int(out_bf16), bn_save.data_ptr(), prec, ws, wsn,
-                _lib.stream()), "mlsp_pointmlp_fwd_mx")
-        elif in_def is not None:
-            ds = _defer_struct(in_def)
-            _lib.check(lib.mlsp_pointmlp_fwd_chain_f32(
-                X.data_ptr(), X.stride(0), _lib._c.byref(ds), M, Cin, W.data_ptr(), W.stride(0), Cout,
-                _lib.ptr(bias), _lib.ptr(gbias), int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean),
-                _lib.ptr(run_var), momentum, eps, int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), _lib.ptr(ysum),
-                prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_fwd_chain_f32")
-        else:
-            _lib.check(lib.mlsp_pointmlp_fwd_f32(
-                X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
-                int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
-                int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), _lib.ptr(ysum), prec, ws, wsn, _lib.stream()),
-                "mlsp_pointmlp_fwd_f32")
-        ctx_offer.__exit__(None, None, None)
+        try:
+            if mx:
+                _lib.check(lib.mlsp_pointmlp_fwd_mx(
+                    X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
+                    int(rows_per_group), gamma.data_ptr(), beta.data_ptr(), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
+                    int(training), act, slope, p, seed, Y.data_ptr(), Z.data_ptr(), int(out_bf16), bn_save.data_ptr(), prec, ws, wsn,
+                    _lib.stream()), "mlsp_pointmlp_fwd_mx")
+            elif in_def is not None:
+                ds = _defer_struct(in_def)
+                _lib.check(lib.mlsp_pointmlp_fwd_chain_f32(
+                    X.data_ptr(), X.stride(0), _lib._c.byref(ds), M, Cin, W.data_ptr(), W.stride(0), Cout,
+                    _lib.ptr(bias), _lib.ptr(gbias), int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean),
+                    _lib.ptr(run_var), momentum, eps, int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), _lib.ptr(ysum),
+                    prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_fwd_chain_f32")
+            else:
+                _lib.check(lib.mlsp_pointmlp_fwd_f32(
+                    X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(bias), _lib.ptr(gbias),
+                    int(rows_per_group), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps,
+                    int(training), act, slope, p, seed, _lib.ptr(Y), _lib.ptr(Z), _lib.ptr(bn_save), _lib.ptr(ysum), prec, ws, wsn, _lib.stream()),
+                    "mlsp_pointmlp_fwd_f32")
+        finally:
+            ctx_offer.__exit__(None, None, None)
         ctx.in_def = in_def
         # fused BatchNorm-backward sums (BwdStats): as a consumer, promise the producer this layer's input columns (with the panel count
         # the dgrad would write; 0 = it cannot); as a deferred producer, remember where the consumers will leave ours
@@ -1180,26 +1182,28 @@ class _PointMLP(Function):
             ins = ctx.in_stats.buffer(dev)                                          # the producer's sums: this call's dgrad writes our columns
         ctx_offer = _offer_bounds(ctx.prec, (X, ctx.bounds[0]), (W, ctx.bounds[1]))
         ctx_offer.__enter__()
-        if mx:
-            _lib.check(lib.mlsp_pointmlp_bwd_mx(
-                dZ.data_ptr(), X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, Y.data_ptr(),
-                int(out_bf16), bn_save.data_ptr(), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
-                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()),
-                "mlsp_pointmlp_bwd_mx")
-        elif ctx.in_def is not None:
-            ds = _defer_struct(ctx.in_def)
-            _lib.check(lib.mlsp_pointmlp_bwd_chain_f32(
-                dZ.data_ptr(), X.data_ptr(), X.stride(0), _lib._c.byref(ds), M, Cin, W.data_ptr(), W.stride(0),
-                Cout, _lib.ptr(Y), _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
-                dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ins), pre_ptr, pre_n, _lib.ptr(ysum),
-                ctx.prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_bwd_chain_f32")
-        else:
-            _lib.check(lib.mlsp_pointmlp_bwd_f32(
-                dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
-                _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate, dW.data_ptr(),
-                _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), pre_ptr, pre_n, _lib.ptr(ysum), ctx.prec, ws, wsn,
-                _lib.stream()), "mlsp_pointmlp_bwd_f32")
-        ctx_offer.__exit__(None, None, None)
+        try:
+            if mx:
+                _lib.check(lib.mlsp_pointmlp_bwd_mx(
+                    dZ.data_ptr(), X.data_ptr(), int(x_bf16), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, Y.data_ptr(),
+                    int(out_bf16), bn_save.data_ptr(), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
+                    dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn, _lib.stream()),
+                    "mlsp_pointmlp_bwd_mx")
+            elif ctx.in_def is not None:
+                ds = _defer_struct(ctx.in_def)
+                _lib.check(lib.mlsp_pointmlp_bwd_chain_f32(
+                    dZ.data_ptr(), X.data_ptr(), X.stride(0), _lib._c.byref(ds), M, Cin, W.data_ptr(), W.stride(0),
+                    Cout, _lib.ptr(Y), _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate,
+                    dW.data_ptr(), _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ins), pre_ptr, pre_n, _lib.ptr(ysum),
+                    ctx.prec, ws, wsn, _lib.stream()), "mlsp_pointmlp_bwd_chain_f32")
+            else:
+                _lib.check(lib.mlsp_pointmlp_bwd_f32(
+                    dZ.data_ptr(), X.data_ptr(), X.stride(0), M, Cin, W.data_ptr(), W.stride(0), Cout, _lib.ptr(Y),
+                    _lib.ptr(bn_save), int(has_bn), int(training), act, slope, p, seed, G, rpg, _lib.ptr(dX), lddx, accumulate, dW.data_ptr(),
+                    _lib.ptr(dbias), _lib.ptr(dgbias), _lib.ptr(dgamma), _lib.ptr(dbeta), pre_ptr, pre_n, _lib.ptr(ysum), ctx.prec, ws, wsn,
+                    _lib.stream()), "mlsp_pointmlp_bwd_f32")
+        finally:
+            ctx_offer.__exit__(None, None, None)
         return (dX, dW, dbias, dgbias, dgamma, dbeta) + (None,) * 18
 
 
