@@ -282,3 +282,53 @@ def test_uniform_presence_is_verified_world2():
         assert p.exitcode == 0
     for r in res:
         assert all(r[1:]), r
+
+
+def _worker_verify_last_step(rank, world, port, q):
+    """FlatGradSync.verify(): the in-band presence check runs one step late, so a divergence in the LAST step of a run is only seen by
+    an explicit verify() (before a checkpoint / at the end of training).  Three 8-bit hashes: sums exact in fp32 for any reduction order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mlsp_amd.ddp import FlatGradSync
+    torch.manual_seed(0)
+    model = torch.nn.ModuleDict({"enc": torch.nn.Linear(8, 8), "head_a": torch.nn.Linear(8, 4), "head_b": torch.nn.Linear(8, 4)})
+    sync = FlatGradSync(model)
+    assert sync._NCHK == 6 and all(0.0 <= h <= 255.0 for h in sync._local_hashes())
+    opt = sync.wrap(torch.optim.SGD(model.parameters(), lr=1e-2))
+    g = torch.Generator().manual_seed(500 + rank)
+    ok_clean, raised = False, False
+    for step in range(3):
+        x = torch.randn(6, 8, generator=g)
+        opt.zero_grad()
+        h = torch.relu(model["enc"](x))
+        loss = model["head_a"](h).pow(2).mean()
+        if not (step == 2 and rank == 1):                     # the LAST step: rank 1 skips head_b
+            loss = loss + model["head_b"](h).pow(2).mean()
+        loss.backward()
+        opt.step()                                            # (checks the step before: nothing to report yet)
+        if step == 1:
+            sync.verify()                                     # uniform so far: passes, and consumes the pending check
+            ok_clean = True
+    try:
+        sync.verify()
+    except RuntimeError as e:
+        raised = "presence='exchange'" in str(e)
+    q.put((rank, ok_clean, raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_verify_reports_a_divergence_in_the_last_step_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_verify_last_step, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
