@@ -13,8 +13,9 @@
  *   - every compute call is asynchronous on `stream`, re-entrant, never throws, and returns 0 on
  *     success, a negative MLSP_ERR_* code for bad arguments, or a positive hipError_t.  The compute
  *     entry points keep no mutable state: what a call does is a function of its arguments alone, from any thread, on any stream
- *     (ABI v8: the products of the GEMM family are the per-call `precision` argument below, not a library switch).  The only
- *     process-wide object is the measurement hook mlsp_profile_begin/_end (HIP events around launches while armed; bench.py only,
+ *     (ABI v8: the products of the GEMM family are the per-call `precision` argument below, not a library switch; ABI v13:
+ *     mlsp_operand_bounds_next hands ONE following call an optional table through a thread-local slot that the call empties -- an
+ *     out-of-band argument of that call, not state).  The only process-wide object is the measurement hook mlsp_profile_begin/_end (HIP events around launches while armed; bench.py only,
  *     never armed in a production step).  Environment variables read once per process, all A/B measurement switches:
  *     MLSP_TNET_BWD_OLD=1 (round-1 T-Net backward kernel), MLSP_GEMM_SPLIT_ALWAYS, MLSP_GEMM_OLD_EPILOGUE.
  *   - `precision` (every entry point that reaches a matrix-core contraction takes it, just before its workspace):
@@ -23,8 +24,11 @@
  *       MLSP_PREC_BF16X6 2  fp32-ACCURATE products on the bf16 matrix cores: every operand value split exactly into three bf16 pieces
  *                           (8 + 8 + 8 significand bits), six piece products per multiply, fp32 accumulation.  Against float64 its error
  *                           is below the f32-MFMA chain's (tests/test_gpu_kernels.py::test_gemm_split_bf16_accuracy), 1.55-1.65x faster
- *                           on the 32768-row layers.  THE MODE OF EVERY NUMBER bench.py REPORTS and the default of the Python mirror
- *                           (MLSP_GEMM_PRECISION overrides it there).  An infinite operand becomes NaN (the f32 MFMA would give +-inf).
+ *                           on the 32768-row layers.  The mode of every number bench.py reported in rounds 3-5 (its `bf16x6_split`
+ *                           leg since).  An infinite operand becomes NaN (the f32 MFMA would give +-inf).
+ *       MLSP_PREC_F16X3  3  (ABI v13) the same accuracy class with HALF the matrix work: two f16 pieces per operand value under a
+ *                           per-workgroup power-of-two scale, three piece products (see the definition below).  THE MODE OF EVERY NUMBER
+ *                           bench.py REPORTS since round 6 and the default of the Python mirror (MLSP_GEMM_PRECISION overrides it there).
  *     Launches off the interior-tile path, short K loops, operand-transform and N = 64 launches run on the f32 kernels in every mode
  *     (exact fp32 either way); kNN distances, BatchNorm statistics, reductions and losses are fp32 in every mode.  A backward call
  *     normally passes the precision of its forward (the Python mirror keeps it in the autograd context); nothing breaks if it differs.
