@@ -352,10 +352,19 @@ class DGCNN(nn.Module):
         # A layer's output has two consumers: its slice of x_cat and the next layer.  The next layer ADDS its input gradient into
         # that slice of x_cat's gradient (fan_out + join_columns(accs=)): no separate accumulation pass per layer in backward.
         feats, accs, h, col, acc_in = [], [], xp, 0, None
+        # mode "f16x3": every layer leaves the analytic bound of its output slice (|gamma| sqrt(P k) + |beta| per channel, from its BatchNorm
+        # finalizer: training mode only) in one [512] vector -- the bound of x_cat for conv5 and the heads, and of each slice for the
+        # next layer, without a pass over the data (functional.SliceBounds)
+        f16 = Fh.gemm_precision.current == "f16x3"
+        bvec = torch.empty(x_cat_buf.shape[1], dtype=torch.float32, device=x.device) if f16 else None
+        slices, hb = [], None
         for li, conv in enumerate(convs):
             g = Fh.knn_graph(h, B, N, k)
             w = conv.conv[0].out_channels
-            out = conv.edge(h, g, out=x_cat_buf[:, col:col + w], grad_accum=acc_in)
+            ob = Fh.SliceBounds(bvec, col, w) if f16 else None
+            out = conv.edge(h, g, out=x_cat_buf[:, col:col + w], grad_accum=acc_in, out_bounds=ob, x_bounds=hb)
+            slices.append(ob)
+            hb = ob
             if li + 1 < len(convs) and EDGE_GRAD_INTO_SLICE:
                 (to_cat, h), acc_in = Fh.fan_out(out, 2)
             else:
@@ -385,7 +394,9 @@ class DGCNN(nn.Module):
         aliases, acc = Fh.fan_out(x_cat, 2 if merge else 1 + len(heads))
         # conv5 and the heads' first layer read x_cat forward and backward (four GEMM operands per step): ONE measurement of its magnitude
         # for the two-piece f16 products (functional.OperandBounds; a no-op in the other product modes)
-        xb = Fh.OperandBounds(x_cat.device) if Fh.gemm_precision.current == "f16x3" else None
+        xb = None
+        if f16:      # (the layers' analytic bounds when all four were left; else measured once by the first layer that reads x_cat)
+            xb = Fh.SliceBounds(bvec, 0, bvec.numel(), valid=True) if all(b.valid for b in slices) else Fh.OperandBounds(x_cat.device)
         rm5, rv5 = _bn_buffers(self.bn5, self.training)                             # conv5+bn5+LReLU+max (Models.py:132-136)
         x5 = Fh.pointmlp_colmax(aliases[0], self.conv5.weight.view(1024, -1), self.bn5.weight, self.bn5.bias, rm5, rv5, B, N,
                                 training=self.training, act=Fh.ACT_LRELU, slope=0.2, momentum=self.bn5.momentum,

@@ -49,6 +49,8 @@ int launch_bn_bwd_finalize_coef_z(hipStream_t st, const double* part, int nparts
 int launch_skinny_bn_bwd_z(hipStream_t st, const float* dZ, const float* Y, float* dY, int M, int C, const float* bn_save, int training,
                            int act, float slope, float p_drop, uint64_t seed, float* dgamma, float* dbeta, float* zero_vec);
 void gemm_unfold_request(float* dW);
+void bn_bound_request(float* out);
+float* amax_offered_output(const float* out, long rows, int cols, int ld, int need);
 bool gemm_unfold_take();
 void bn_zero_vec_request(float* v);
 bool bn_zero_vec_take();
@@ -409,6 +411,9 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
         if (rc != MLSP_OK) return rc;
     }
     if (training) {
+        // (mode 3, the caller offered bounds for `out`: the finalizer leaves |gamma| sqrt(P k) + |beta| per channel -- a bound of the layer's
+        // output for the GEMMs that read it, instead of a streaming pass over it)
+        bn_bound_request(amax_offered_output(out, P, Cout, ldo, Cout));
         CHECK(launch_bn_finalize(st, part, nparts, (double)P * k, Cout, gamma, beta, run_mean, run_var, momentum, eps, scale,
                                  shift, mean, invstd));
     }

@@ -69,10 +69,15 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int nparts, 
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ run_mean, float* __restrict__ run_var, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd, float* __restrict__ gsum, int ppg) {
+                                   float* __restrict__ save_invstd, float* __restrict__ gsum, int ppg,
+                                   float* __restrict__ bound_out = nullptr, float sqrt_count = 0.f) {
+    // bound_out (nullable, [C]): |gamma| sqrt(count) + |beta| -- a bound of every value act(BN(y)) of the channel (|yhat| <= sqrt(count) for
+    // batch statistics over exactly these `count` values; |act(z)| <= |z|): what the two-piece f16 products of the layers that READ this
+    // layer's output need (gemm.hip GemmArgs a_amax), at no pass over the data
     const int c = blockIdx.x;
     double s, q;
     fin_part_sums(part, nparts, C, c, s, q);
+    if (bound_out && threadIdx.x == 0) bound_out[c] = fabsf(gamma[c]) * sqrt_count + fabsf(beta[c]);
     // gsum (nullable, [nparts / ppg][C]): the column sums of every cloud (ppg row panels each) -- kept for the backward of a layer with a
     // per-cloud bias whose output gradient is never formed (launch_bn_dy_gbias)
     if (gsum)
@@ -518,11 +523,17 @@ int launch_colstats(hipStream_t st, const float* Y, int M, int C, int ld, double
     return mlsp_launch_status();
 }
 
+// request of the NEXT launch_bn_finalize on this thread: also write the channels' output bounds (bn_finalize_kernel bound_out); consumed
+// (cleared) by that launch -- the pattern of gemm_unfold_request
+static thread_local float* tl_bound_out = nullptr;
+void bn_bound_request(float* out) { tl_bound_out = out; }
 int launch_bn_finalize(hipStream_t st, const double* part, int nparts, double count, int C, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
                        float* shift, float* save_mean, float* save_invstd) {
+    float* bo = tl_bound_out;
+    tl_bound_out = nullptr;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, st, part, nparts, count, C, gamma, beta,
-                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd, (float*)nullptr, 1);
+                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd, (float*)nullptr, 1, bo, (float)sqrt(count));
     return mlsp_launch_status();
 }
 

@@ -1450,7 +1450,8 @@ static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, in
         mlsp_bound_t& o = tl_amax.offered[i];
         if (o.ptr != X || o.rows != rows || o.cols != cols || o.ld != ld || !o.partials || o.n < 0 || o.n > 4096) continue;
         if (!o.valid) {
-            if (batch.n >= 5 || (o.n != 0 && o.n != AMAX_PARTS)) return nullptr;
+            if (o.n != 0 && o.n != AMAX_PARTS) continue;            // (an unfilled OUTPUT-bounds buffer of another size: not ours to measure into)
+            if (batch.n >= 5) return nullptr;
             batch.args.op[batch.n++] = {X, rows, cols, ld, o.partials};
             o.valid = 1; o.n = AMAX_PARTS;
         }
@@ -1471,6 +1472,18 @@ static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, in
     tl_amax.cache[tl_amax.ncache++] = {X, rows, cols, ld, out};
     batch.args.op[batch.n++] = {X, rows, cols, ld, out};
     return out;
+}
+// An entry of the caller's table that describes an OUTPUT of the current call (same pointer / shape, valid == 0, room for `need` floats):
+// the call fills its partials with a bound of what it writes -- e.g. the per-channel analytic bound of a BatchNorm'd layer -- and the
+// caller hands them to the layers that read the tensor.  -> the partials (entry marked valid, n = need), or null.
+float* amax_offered_output(const float* out, long rows, int cols, int ld, int need) {
+    for (int i = 0; i < tl_amax.noffered; ++i) {
+        mlsp_bound_t& o = tl_amax.offered[i];
+        if (o.ptr != out || o.rows != rows || o.cols != cols || o.ld != ld || !o.partials || o.valid || o.n < need) continue;
+        o.valid = 1; o.n = need;
+        return o.partials;
+    }
+    return nullptr;
 }
 static void amax_flush(hipStream_t st, AmaxBatch& batch) {
     static const bool dump = getenv("MLSP_AMAX_DUMP") != nullptr;          // read-once diagnostic (tools/r6): what each measuring launch reads

@@ -55,6 +55,20 @@ class OperandBounds:
         self.buf, self.valid = torch.empty(256, dtype=torch.float32, device=device), False
 
 
+class SliceBounds:
+    """`n` floats at element `offset` of a caller-owned device buffer: either ROOM for a bound that a C call leaves of one of its outputs
+    (valid False: the EdgeConv layers fill their column slices of the concatenation's bound vector with |gamma| sqrt(P k) + |beta| per
+    channel), or -- once filled -- the bound itself, for the layers that read the tensor (a run of slices is again a SliceBounds)."""
+    __slots__ = ("buf", "offset", "n", "valid")
+
+    def __init__(self, buf, offset, n, valid=False):
+        self.buf, self.offset, self.n, self.valid = buf, int(offset), int(n), bool(valid)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + 4 * self.offset
+
+
 class ProvidedBounds:
     """bounds that already exist somewhere (n partial maxima at a device pointer): what _lib.weight_bound_providers hand out"""
     __slots__ = ("ptr", "n", "valid", "keep")
@@ -88,7 +102,9 @@ class _offer_bounds:
         if self.pairs:
             self.tab = (_lib.Bound * len(self.pairs))()
             for e, (t, b) in zip(self.tab, self.pairs):
-                if isinstance(b, ProvidedBounds):
+                if isinstance(b, SliceBounds):
+                    e.ptr, e.rows, e.cols, e.ld, e.partials, e.valid, e.n = t.data_ptr(), t.shape[0], t.shape[1], t.stride(0), b.ptr, int(b.valid), b.n
+                elif isinstance(b, ProvidedBounds):
                     e.ptr, e.rows, e.cols, e.ld, e.partials, e.valid, e.n = t.data_ptr(), t.shape[0], t.shape[1], t.stride(0), b.ptr, 1, b.n
                 else:
                     e.ptr, e.rows, e.cols, e.ld, e.partials, e.valid, e.n = t.data_ptr(), t.shape[0], t.shape[1], t.stride(0), b.buf.data_ptr(), int(b.valid), 0
@@ -765,7 +781,8 @@ def multimlp(X, segs, gamma, beta, run_mean, run_var, chan, training=True, p_dro
 
 class _EdgeConv(Function):
     @staticmethod
-    def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out_buf=None, grad_accum=None):
+    def forward(ctx, xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out_buf=None, grad_accum=None,
+                out_bounds=None, x_bounds=None):
         lib = _lib.load()
         prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         xp = _rows(xp)
@@ -792,8 +809,11 @@ class _EdgeConv(Function):
         ws, wsn = _lib.workspace(dev, P, C, 2 * Cout)
         # (mode "f16x3", the layers whose [u|v] GEMM runs on the split kernel: the input's and the folded weight's bounds, measured by this
         # call, are read again by the backward's weight gradient and dgrad)
-        ctx.bounds = (OperandBounds(dev), OperandBounds(dev) if Wd is not None else None) if prec == 3 and C >= 128 else (None, None)
-        with _offer_bounds(prec, (xp, ctx.bounds[0]), (Wd, ctx.bounds[1])):
+        # out_bounds (SliceBounds, optional): room for the analytic bound of this layer's output, which the call fills in training mode;
+        # x_bounds: the input's bound when the caller has one (the previous layer's out_bounds)
+        ctx.bounds = ((x_bounds if x_bounds is not None and x_bounds.valid else OperandBounds(dev)),
+                      OperandBounds(dev) if Wd is not None else None) if prec == 3 and C >= 128 else (None, None)
+        with _offer_bounds(prec, (xp, ctx.bounds[0]), (Wd, ctx.bounds[1]), (out, out_bounds)):
             _lib.check(lib.mlsp_edgeconv_fwd_f32(
                 xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                 _lib.ptr(run_mean), _lib.ptr(run_var), momentum, eps, act, slope, int(training), graph.B, graph.N, C, Cout,
@@ -836,15 +856,17 @@ class _EdgeConv(Function):
                 bn_save.data_ptr(), _lib.ptr(Wd), act, slope, int(training), graph.B, graph.N, C, Cout, graph.k, _lib.ptr(dx),
                 dx.stride(0) if dx is not None else C, accumulate, dW.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ctx.prec, ws, wsn,
                 _lib.stream()), "mlsp_edgeconv_bwd_f32")
-        return (dx, dW, dgamma, dbeta) + (None,) * 10
+        return (dx, dW, dgamma, dbeta) + (None,) * 12
 
 
 def edgeconv(xp, graph, W2d, gamma, beta, run_mean, run_var, training, act=ACT_LRELU, slope=0.2, momentum=0.1, eps=1e-5, out=None,
-             grad_accum=None):
+             grad_accum=None, out_bounds=None, x_bounds=None):
     """Fused get_graph_feature + conv_2d + max over k (Models.py:115-129).  xp [P,C] -> [P,Cout].  `out`: a [P,Cout] column
     slice of a wider buffer to write the result into (see join_columns).  `grad_accum`: the SharedInputGrad of a fan_out whose alias
-    xp is (join_columns(..., accs=) points it at xp's slice of the concatenation's gradient: the input gradient is added there)."""
-    return _EdgeConv.apply(xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out, grad_accum)
+    xp is (join_columns(..., accs=) points it at xp's slice of the concatenation's gradient: the input gradient is added there).
+    `out_bounds` / `x_bounds` (SliceBounds, mode "f16x3"): room for the analytic bound of the output / the input's bound."""
+    return _EdgeConv.apply(xp, W2d, gamma, beta, run_mean, run_var, graph, training, act, slope, momentum, eps, out, grad_accum,
+                           out_bounds, x_bounds)
 
 
 class _TnetEdge(Function):

@@ -132,7 +132,7 @@ class conv_2d(nn.Module):
         return Fh.pointmlp_colmax(X, conv.weight.view(conv.out_channels, conv.in_channels), bn.weight, bn.bias, rm, rv, B, N,
                                   training=self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps)
 
-    def edge(self, xp, graph, out=None, grad_accum=None):
+    def edge(self, xp, graph, out=None, grad_accum=None, out_bounds=None, x_bounds=None):
         """Fused get_graph_feature + this conv + max over k.  xp [P,C] -> [P,Cout] (written into `out` when given: a column
         slice of the caller's concatenation buffer)."""
         conv, bn = self.conv[0], self.conv[1]
@@ -140,7 +140,7 @@ class conv_2d(nn.Module):
         W = conv.weight.view(conv.out_channels, conv.in_channels)
         if conv.bias is None:
             return Fh.edgeconv(xp, graph, W, bn.weight, bn.bias, rm, rv, self.training, act=self.act, slope=0.2,
-                               momentum=bn.momentum, eps=bn.eps, out=out, grad_accum=grad_accum)
+                               momentum=bn.momentum, eps=bn.eps, out=out, grad_accum=grad_accum, out_bounds=out_bounds, x_bounds=x_bounds)
         # conv_2d(bias=True) (model_utils.py:45-63 default): a per-channel constant in front of the BatchNorm.  Training: the batch
         # mean absorbs it (output unchanged, its gradient is exactly zero), only the running mean sees it.  Eval: it shifts the
         # normalised value by scale * bias, i.e. it is the same as evaluating with running_mean - bias.
