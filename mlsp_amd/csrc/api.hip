@@ -503,6 +503,7 @@ int mlsp_tnet_edge_fwd_f32(const float* x, int ldx, const int32_t* idx, const fl
         if (rc != MLSP_OK) return rc;
     }
     if (training) {
+        bn_bound_request(amax_offered_output(out, P, C2, C2, C2));     // (mode 3: the analytic bound of the stage's output, as mlsp_edgeconv_fwd_f32)
         CHECK(launch_bn_finalize(st, part, np2, (double)P * k, C2, gamma2, beta2, run_mean2, run_var2, momentum, eps, bn2_save,
                                  bn2_save + C2, bn2_save + 2 * C2, bn2_save + 3 * C2));
     }

@@ -871,7 +871,7 @@ def edgeconv(xp, graph, W2d, gamma, beta, run_mean, run_var, training, act=ACT_L
 
 class _TnetEdge(Function):
     @staticmethod
-    def forward(ctx, xp, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, graph, training, slope, momentum, eps):
+    def forward(ctx, xp, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, graph, training, slope, momentum, eps, out_bounds=None):
         lib = _lib.load()
         prec = ctx.prec = gemm_precision.code()     # the backward gets the same products, whenever it runs
         xp = _rows(xp)
@@ -889,11 +889,12 @@ class _TnetEdge(Function):
         argsel = torch.empty((P, C2), dtype=torch.uint8, device=dev)
         bn2 = torch.empty((4, C2), dtype=torch.float32, device=dev)
         ws, wsn = _lib.workspace(dev, P * graph.k, C1, C1)
-        _lib.check(lib.mlsp_tnet_edge_fwd_f32(
-            xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W1.data_ptr(), g1.data_ptr(), b1.data_ptr(), _lib.ptr(rm1),
-            _lib.ptr(rv1), W2.data_ptr(), g2.data_ptr(), b2.data_ptr(), _lib.ptr(rm2), _lib.ptr(rv2), momentum, eps, slope,
-            int(training), graph.B, graph.N, C, C1, C2, graph.k, out.data_ptr(), uv.data_ptr(), s1.data_ptr(), bn1.data_ptr(),
-            zsel.data_ptr(), argsel.data_ptr(), bn2.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_tnet_edge_fwd_f32")
+        with _offer_bounds(prec, (out, out_bounds)):          # (out_bounds: room for the analytic bound of the stage's output, see _EdgeConv)
+            _lib.check(lib.mlsp_tnet_edge_fwd_f32(
+                xp.data_ptr(), xp.stride(0), graph.idx.data_ptr(), W1.data_ptr(), g1.data_ptr(), b1.data_ptr(), _lib.ptr(rm1),
+                _lib.ptr(rv1), W2.data_ptr(), g2.data_ptr(), b2.data_ptr(), _lib.ptr(rm2), _lib.ptr(rv2), momentum, eps, slope,
+                int(training), graph.B, graph.N, C, C1, C2, graph.k, out.data_ptr(), uv.data_ptr(), s1.data_ptr(), bn1.data_ptr(),
+                zsel.data_ptr(), argsel.data_ptr(), bn2.data_ptr(), prec, ws, wsn, _lib.stream()), "mlsp_tnet_edge_fwd_f32")
         if _sel_record is not None or _sel_forced is not None:
             _selection_hook(argsel)
         ctx.save_for_backward(xp, W1, W2, out, uv, s1, bn1, zsel, argsel, bn2)
@@ -924,12 +925,12 @@ class _TnetEdge(Function):
             zsel.data_ptr(), argsel.data_ptr(), bn2.data_ptr(), slope, int(training), graph.B, graph.N, C, C1, C2, graph.k,
             _lib.ptr(dx), dW1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
             ctx.prec, ws, wsn, _lib.stream()), "mlsp_tnet_edge_bwd_f32")
-        return (dx, dW1, dg1, db1, None, None, dW2, dg2, db2) + (None,) * 7
+        return (dx, dW1, dg1, db1, None, None, dW2, dg2, db2) + (None,) * 8
 
 
-def tnet_edge(xp, graph, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, training, slope=0.2, momentum=0.1, eps=1e-5):
+def tnet_edge(xp, graph, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, training, slope=0.2, momentum=0.1, eps=1e-5, out_bounds=None):
     """Fused T-Net per-edge stage (model_utils.py:111-115): [P,C] -> [P,128]; needs C1 = 64, C2 = 128."""
-    return _TnetEdge.apply(xp, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, graph, training, slope, momentum, eps)
+    return _TnetEdge.apply(xp, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, graph, training, slope, momentum, eps, out_bounds)
 
 
 def tnet_edge_supported(W1, W2, k):

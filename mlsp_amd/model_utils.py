@@ -123,14 +123,14 @@ class conv_2d(nn.Module):
                            beta=bn.bias, run_mean=rm, run_var=rv, training=self.training, act=self.act, slope=0.2,
                            momentum=bn.momentum, eps=bn.eps)
 
-    def rows_colmax(self, X, B, N):
+    def rows_colmax(self, X, B, N, x_bounds=None):
         """[B*N, Cin] -> [B, Cout]: this conv + BN + act followed by the max over the N rows of each cloud."""
         conv, bn = self.conv[0], self.conv[1]
         if conv.bias is not None:
             return Fh.colmax(self.rows(X), B, N)
         rm, rv = _bn_buffers(bn, self.training)
         return Fh.pointmlp_colmax(X, conv.weight.view(conv.out_channels, conv.in_channels), bn.weight, bn.bias, rm, rv, B, N,
-                                  training=self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps)
+                                  training=self.training, act=self.act, slope=0.2, momentum=bn.momentum, eps=bn.eps, x_bounds=x_bounds)
 
     def edge(self, xp, graph, out=None, grad_accum=None, out_bounds=None, x_bounds=None):
         """Fused get_graph_feature + this conv + max over k.  xp [P,C] -> [P,Cout] (written into `out` when given: a column
@@ -243,12 +243,14 @@ class transform_net(nn.Module):
             return self.rows(Fh.graph_feature(xp, graph), B, N, k)
         rm1, rv1 = _bn_buffers(b1, self.training)
         rm2, rv2 = _bn_buffers(b2, self.training)
+        # (mode "f16x3": the stage leaves the analytic bound of its output for conv2d3's GEMMs, as the EdgeConv layers do: Models.py)
+        hb = Fh.SliceBounds(torch.empty(W2.shape[0], dtype=torch.float32, device=xp.device), 0, W2.shape[0]) if Fh.gemm_precision.current == "f16x3" else None
         h = Fh.tnet_edge(xp, graph, W1, b1.weight, b1.bias, rm1, rv1, W2, b2.weight, b2.bias, rm2, rv2, self.training,
-                         slope=0.2, momentum=b1.momentum, eps=b1.eps)
-        return self._tail(h, B, N)
+                         slope=0.2, momentum=b1.momentum, eps=b1.eps, out_bounds=hb)
+        return self._tail(h, B, N, x_bounds=hb if hb is not None and hb.valid else None)
 
-    def _tail(self, h, B, rows_per_cloud):
-        h = self.conv2d3.rows_colmax(h, B, rows_per_cloud)       # conv2d3 + max over points (model_utils.py:116-117)
+    def _tail(self, h, B, rows_per_cloud, x_bounds=None):
+        h = self.conv2d3.rows_colmax(h, B, rows_per_cloud, x_bounds=x_bounds)       # conv2d3 + max over points (model_utils.py:116-117)
         h = self.fc1(h)
         h = self.fc2(h)
         h = Fh.pointmlp(h, self.fc3.weight, bias=self.fc3.bias, training=self.training)
