@@ -51,6 +51,7 @@ int launch_skinny_bn_bwd_z(hipStream_t st, const float* dZ, const float* Y, floa
 void gemm_unfold_request(float* dW);
 void bn_bound_request(float* out);
 float* amax_offered_output(const float* out, long rows, int cols, int ld, int need);
+float* amax_reserve(const float* X, long rows, int cols, int ld);
 bool gemm_unfold_take();
 void bn_zero_vec_request(float* v);
 bool bn_zero_vec_take();
@@ -138,13 +139,17 @@ int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const fl
 int launch_edge_select_act(hipStream_t st, const float* msel, const float* uv, int P, int Cout, const float* scale,
                            const float* shift, int act, float slope, float* out, int ldo);
 int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, const float* msel, const float* uv, int P,
-                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part, int lddo, int ldo);
+                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part, int lddo, int ldo,
+                           float* duv_amax);
+bool edge_bwd_leaves_duv_bound(const float* dOut, const float* out, const float* msel, const float* uv, const float* s1, const uint8_t* argsel,
+                               int Cout, const float* scale, const float* mean, const float* invstd, const float* gz, const float* duv,
+                               int lddo, int ldo);
 int launch_edge_bwd_point(hipStream_t st, const float* dOut, const float* out, const float* uv, const float* s1, int P,
                           int Cout, int k, const float* scale, const float* mean, const float* invstd, const float* mean_dz,
-                          const float* mean_dzy, int act, float slope, float* gz, float* duv, int lddo, int ldo);
+                          const float* mean_dzy, int act, float slope, float* gz, float* duv, int lddo, int ldo, float* duv_amax);
 int launch_edge_bwd_gather(hipStream_t st, const float* gz, const uint8_t* argsel, const float* uv, const int* rev_off,
                            const int* rev_ent, int P, int N, int Cout, const float* scale, const float* mean,
-                           const float* invstd, const float* mean_dz, const float* mean_dzy, float* duv);
+                           const float* invstd, const float* mean_dz, const float* mean_dzy, float* duv, float* duv_amax);
 int launch_graph_feature_fwd(hipStream_t st, const float* x, const int* idx, int P, int N, int C, int k, float* F);
 int launch_graph_feature_bwd(hipStream_t st, const float* dF, const int* rev_off, const int* rev_ent, int P, int N, int C,
                              int k, float* dx);
@@ -446,12 +451,16 @@ int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, 
     float* slab = sf ? w.take<float>(sf) : nullptr;
     if (!w.ok()) return MLSP_ERR_WORKSPACE;
     const float* scale = bn_save, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
-    CHECK(launch_edge_bwd_reduce(st, dOut, out, msel, uv, P, Cout, mean, invstd, act, slope, part, lddo, ldo));
+    // f16x3: the passes that write duv leave its bound (256 partial maxima in a slot of the workspace tail, found again by both products
+    // below) instead of a measuring pass over the finished tensor
+    float* duv_amax = edge_bwd_leaves_duv_bound(dOut, out, msel, uv, s1, argsel, Cout, scale, mean, invstd, gz, duv, lddo, ldo)
+                          ? amax_reserve(duv, P, 2 * Cout, 2 * Cout) : nullptr;
+    CHECK(launch_edge_bwd_reduce(st, dOut, out, msel, uv, P, Cout, mean, invstd, act, slope, part, lddo, ldo, duv_amax));
     CHECK(launch_bn_bwd_finalize(st, part, edge_bwd_reduce_parts(P, Cout, dOut, out, msel, uv, mean, invstd, lddo, ldo), (double)P * k, Cout,
                                  dgamma, dbeta, mean_dz, mean_dzy));
     const float* mdz = training ? mean_dz : nullptr;
-    CHECK(launch_edge_bwd_point(st, dOut, out, uv, s1, P, Cout, k, scale, mean, invstd, mdz, mean_dzy, act, slope, gz, duv, lddo, ldo));
-    CHECK(launch_edge_bwd_gather(st, gz, argsel, uv, rev_off, rev_ent, P, N, Cout, scale, mean, invstd, mdz, mean_dzy, duv));
+    CHECK(launch_edge_bwd_point(st, dOut, out, uv, s1, P, Cout, k, scale, mean, invstd, mdz, mean_dzy, act, slope, gz, duv, lddo, ldo, duv_amax));
+    CHECK(launch_edge_bwd_gather(st, gz, argsel, uv, rev_off, rev_ent, P, N, Cout, scale, mean, invstd, mdz, mean_dzy, duv, duv_amax));
     // (the forward's [Wa ; Wb - Wa] is reused when the caller kept it; beta = 1: dx is added into a slice of a wider gradient)
     const float* Wdc = Wd_in;
     if (!Wdc && dx) { CHECK(launch_build_wd(st, W, Cout, C, Wd)); Wdc = Wd; }

@@ -390,6 +390,14 @@ __global__ __launch_bounds__(NT, 4) void edge_reduce_wide_kernel(const float* __
     }
 }
 
+// By-product bound of duv for the f16x3 products that read it (gemm.hip amax_reserve): every wave raises one of 256 partial maxima
+// (non-negative floats order like their bit patterns; the slot was zeroed by edge_bwd_reduce_vec_kernel, earlier on the stream).
+__device__ __forceinline__ void edge_amax_raise(float* __restrict__ amax, float m) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255), __float_as_uint(m));
+}
+
 // vectorised reverse gather (same lane layout): du_j over rev(j)
 template <int LR>
 __global__ __launch_bounds__(256) void edge_bwd_gather_vec_kernel(const float* __restrict__ gz, const uint8_t* __restrict__ argsel,
@@ -398,7 +406,8 @@ __global__ __launch_bounds__(256) void edge_bwd_gather_vec_kernel(const float* _
                                                                   const float* __restrict__ scale, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd,
                                                                   const float* __restrict__ mean_dz,
-                                                                  const float* __restrict__ mean_dzy, float* __restrict__ duv) {
+                                                                  const float* __restrict__ mean_dzy, float* __restrict__ duv,
+                                                                  float* __restrict__ duv_amax) {
     constexpr int Cout = LR * 4, NP = 64 / LR;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -441,13 +450,15 @@ __global__ __launch_bounds__(256) void edge_bwd_gather_vec_kernel(const float* _
     for (int o = LR; o < 64; o <<= 1)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    float pm = 0.f;
     if (sub == 0) {
         const f32x4 u = *(const f32x4*)(uv + (size_t)j * ld + c);
         f32x4 o4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] = acc[e] - (float)(e1 - e0) * (A[e] + Bc[e] * (u[e] - mean[c + e]));
+        for (int e = 0; e < 4; ++e) { o4[e] = acc[e] - (float)(e1 - e0) * (A[e] + Bc[e] * (u[e] - mean[c + e])); pm = fmaxf(pm, fabsf(o4[e])); }
         *(f32x4*)(duv + (size_t)j * ld + c) = o4;
     }
+    if (duv_amax) edge_amax_raise(duv_amax, pm);
 }
 
 // out = act(scale*(msel + v) + shift)
@@ -527,9 +538,11 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_vec_kernel(const float* _
                                                                   const float* __restrict__ msel, const float* __restrict__ uv,
                                                                   int P, int Cout, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, int act, float slope,
-                                                                  double* __restrict__ part, int lddo, int ldo) {
+                                                                  double* __restrict__ part, int lddo, int ldo,
+                                                                  float* __restrict__ duv_amax) {
     __shared__ double shd[256 * 8];
     const int tid = threadIdx.x, tpr = Cout >> 2, nrg = 256 / tpr;
+    if (duv_amax && blockIdx.x == 0) duv_amax[tid] = 0.f;       // the 256 partial maxima the two passes below raise (edge_amax_raise)
     const int cg = tid % tpr, rg = tid / tpr, c = cg * 4;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
@@ -583,8 +596,10 @@ __global__ __launch_bounds__(256) void edge_bwd_point_vec_kernel(const float* __
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  const float* __restrict__ mean_dz, const float* __restrict__ mean_dzy,
                                                                  int act, float slope, float* __restrict__ gz,
-                                                                 float* __restrict__ duv, int lddo, int ldo) {
+                                                                 float* __restrict__ duv, int lddo, int ldo,
+                                                                 float* __restrict__ duv_amax) {
     const float fk = (float)k;
+    float pm = 0.f;
     for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
         const size_t i = v / C4; const int c = (int)(v % C4) * 4;
         const f32x4 d4 = *(const f32x4*)(dOut + i * lddo + c), o4 = *(const f32x4*)(out + i * ldo + c);
@@ -606,7 +621,10 @@ __global__ __launch_bounds__(256) void edge_bwd_point_vec_kernel(const float* __
         }
         *(f32x4*)(gz + v * 4) = g;
         *(f32x4*)(duv + i * 8 * C4 + 4 * C4 + c) = dv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pm = fmaxf(pm, fabsf(dv[e]));
     }
+    if (duv_amax) edge_amax_raise(duv_amax, pm);
 }
 
 // backward pass 3 (reverse gather, wave per destination j):
@@ -786,13 +804,34 @@ int launch_edge_select_act(hipStream_t st, const float* msel, const float* uv, i
                        shift, act, slope, out, ldo);
     return mlsp_launch_status();
 }
+static bool edge_bwd_reduce_vec_ok(const float* dOut, const float* out, const float* msel, const float* uv, int Cout, const float* mean,
+                                   const float* invstd, int lddo, int ldo) {
+    return Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 && lddo % 4 == 0 && ldo % 4 == 0 &&
+           ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)msel | (uintptr_t)uv | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0);
+}
+static bool edge_bwd_point_vec_ok(const float* dOut, const float* out, const float* uv, const float* s1, int Cout, const float* scale,
+                                  const float* gz, const float* duv, int lddo, int ldo) {
+    return Cout % 4 == 0 && lddo % 4 == 0 && ldo % 4 == 0 &&
+           ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)uv | (uintptr_t)s1 | (uintptr_t)gz | (uintptr_t)duv | (uintptr_t)scale) & 15) == 0);
+}
+static bool edge_bwd_gather_vec_ok(const float* gz, const uint8_t* argsel, const float* uv, int Cout, const float* duv) {
+    return (((uintptr_t)uv | (uintptr_t)gz | (uintptr_t)duv) & 15) == 0 && (((uintptr_t)argsel) & 3) == 0 && (Cout == 64 || Cout == 128 || Cout == 256);
+}
+// all three backward passes take their vectorised form for these operands: they can leave the bound of duv as a by-product
+// (`duv_amax` of the launchers below; the scalar forms ignore it)
+bool edge_bwd_leaves_duv_bound(const float* dOut, const float* out, const float* msel, const float* uv, const float* s1, const uint8_t* argsel,
+                               int Cout, const float* scale, const float* mean, const float* invstd, const float* gz, const float* duv,
+                               int lddo, int ldo) {
+    return edge_bwd_reduce_vec_ok(dOut, out, msel, uv, Cout, mean, invstd, lddo, ldo) &&
+           edge_bwd_point_vec_ok(dOut, out, uv, s1, Cout, scale, gz, duv, lddo, ldo) && edge_bwd_gather_vec_ok(gz, argsel, uv, Cout, duv);
+}
 int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, const float* msel, const float* uv, int P,
-                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part, int lddo, int ldo) {
-    if (Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 && lddo % 4 == 0 && ldo % 4 == 0 &&
-        ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)msel | (uintptr_t)uv | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0)) {
+                           int Cout, const float* mean, const float* invstd, int act, float slope, double* part, int lddo, int ldo,
+                           float* duv_amax) {
+    if (edge_bwd_reduce_vec_ok(dOut, out, msel, uv, Cout, mean, invstd, lddo, ldo)) {
         // NOTE: writes (P+1023)/1024 partial rows -- callers size `part` for (P+511)/512 and pass the count below
         hipLaunchKernelGGL(edge_bwd_reduce_vec_kernel, dim3((P + EVROWS - 1) / EVROWS), dim3(256), 0, st, dOut, out, msel, uv, P, Cout,
-                           mean, invstd, act, slope, part, lddo, ldo);
+                           mean, invstd, act, slope, part, lddo, ldo, duv_amax);
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3((Cout + 63) / 64, (P + 511) / 512), dim3(256), 0, st, dOut, out, msel, uv,
@@ -801,12 +840,11 @@ int launch_edge_bwd_reduce(hipStream_t st, const float* dOut, const float* out, 
 }
 int launch_edge_bwd_point(hipStream_t st, const float* dOut, const float* out, const float* uv, const float* s1, int P,
                           int Cout, int k, const float* scale, const float* mean, const float* invstd, const float* mean_dz,
-                          const float* mean_dzy, int act, float slope, float* gz, float* duv, int lddo, int ldo) {
-    if (Cout % 4 == 0 && lddo % 4 == 0 && ldo % 4 == 0 && ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)uv | (uintptr_t)s1 | (uintptr_t)gz | (uintptr_t)duv |
-                            (uintptr_t)scale) & 15) == 0)) {
+                          const float* mean_dzy, int act, float slope, float* gz, float* duv, int lddo, int ldo, float* duv_amax) {
+    if (edge_bwd_point_vec_ok(dOut, out, uv, s1, Cout, scale, gz, duv, lddo, ldo)) {
         size_t t4 = (size_t)P * Cout / 4;
         hipLaunchKernelGGL(edge_bwd_point_vec_kernel, dim3(ew_blocks2(t4)), dim3(256), 0, st, dOut, out, uv, s1, t4, Cout / 4, k, scale,
-                           mean, invstd, mean_dz, mean_dzy, act, slope, gz, duv, lddo, ldo);
+                           mean, invstd, mean_dz, mean_dzy, act, slope, gz, duv, lddo, ldo, duv_amax);
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(edge_bwd_point_kernel, dim3(ew_blocks2((size_t)P * Cout)), dim3(256), 0, st, dOut, out, uv, s1, P, Cout,
@@ -815,13 +853,12 @@ int launch_edge_bwd_point(hipStream_t st, const float* dOut, const float* out, c
 }
 int launch_edge_bwd_gather(hipStream_t st, const float* gz, const uint8_t* argsel, const float* uv, const int* rev_off,
                            const int* rev_ent, int P, int N, int Cout, const float* scale, const float* mean,
-                           const float* invstd, const float* mean_dz, const float* mean_dzy, float* duv) {
-    const bool al = (((uintptr_t)uv | (uintptr_t)gz | (uintptr_t)duv) & 15) == 0 && (((uintptr_t)argsel) & 3) == 0;
-    if (al && (Cout == 64 || Cout == 128 || Cout == 256)) {
+                           const float* invstd, const float* mean_dz, const float* mean_dzy, float* duv, float* duv_amax) {
+    if (edge_bwd_gather_vec_ok(gz, argsel, uv, Cout, duv)) {
         dim3 g((P + 3) / 4), b(256);
-        if (Cout == 64) hipLaunchKernelGGL((edge_bwd_gather_vec_kernel<16>), g, b, 0, st, gz, argsel, uv, rev_off, rev_ent, P, N, scale, mean, invstd, mean_dz, mean_dzy, duv);
-        else if (Cout == 128) hipLaunchKernelGGL((edge_bwd_gather_vec_kernel<32>), g, b, 0, st, gz, argsel, uv, rev_off, rev_ent, P, N, scale, mean, invstd, mean_dz, mean_dzy, duv);
-        else hipLaunchKernelGGL((edge_bwd_gather_vec_kernel<64>), g, b, 0, st, gz, argsel, uv, rev_off, rev_ent, P, N, scale, mean, invstd, mean_dz, mean_dzy, duv);
+        if (Cout == 64) hipLaunchKernelGGL((edge_bwd_gather_vec_kernel<16>), g, b, 0, st, gz, argsel, uv, rev_off, rev_ent, P, N, scale, mean, invstd, mean_dz, mean_dzy, duv, duv_amax);
+        else if (Cout == 128) hipLaunchKernelGGL((edge_bwd_gather_vec_kernel<32>), g, b, 0, st, gz, argsel, uv, rev_off, rev_ent, P, N, scale, mean, invstd, mean_dz, mean_dzy, duv, duv_amax);
+        else hipLaunchKernelGGL((edge_bwd_gather_vec_kernel<64>), g, b, 0, st, gz, argsel, uv, rev_off, rev_ent, P, N, scale, mean, invstd, mean_dz, mean_dzy, duv, duv_amax);
         return mlsp_launch_status();
     }
     hipLaunchKernelGGL(edge_bwd_gather_kernel, dim3((P + 3) / 4), dim3(256), 0, st, gz, argsel, uv, rev_off, rev_ent, P, N,

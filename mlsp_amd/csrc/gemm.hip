@@ -1441,6 +1441,16 @@ extern "C" int mlsp_operand_bounds_next(mlsp_bound_t* tab, int n) {
 }
 // queue of operands to measure with the next launch (launch_gemm batches A and B -- and the groups' B operands -- into one launch)
 struct AmaxBatch { AmaxArgs args; int n = 0; };
+static float* amax_take_slot(const float* X, long rows, int cols, int ld) {
+    const int slot = tl_amax.next;
+    tl_amax.next = (tl_amax.next + 1) % AMAX_SLOTS;
+    float* out = tl_amax.base + (size_t)slot * AMAX_PARTS;
+    int k = 0;                                                   // the slot's previous tenant leaves the cache
+    for (int i = 0; i < tl_amax.ncache; ++i) if (tl_amax.cache[i].out != out) tl_amax.cache[k++] = tl_amax.cache[i];
+    tl_amax.ncache = k;
+    tl_amax.cache[tl_amax.ncache++] = {X, rows, cols, ld, out};
+    return out;
+}
 // -> the partials of X [rows][cols] (pitch ld), measured now (queued into `batch`) or earlier in this API call; null: cannot (no tail,
 // unaligned, the batch is full)
 static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, int ld, int* n_out) {
@@ -1463,15 +1473,20 @@ static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, in
         if (c.X == X && c.rows == rows && c.cols == cols && c.ld == ld) return c.out;
     }
     if (batch.n >= 5) return nullptr;
-    const int slot = tl_amax.next;
-    tl_amax.next = (tl_amax.next + 1) % AMAX_SLOTS;
-    float* out = tl_amax.base + (size_t)slot * AMAX_PARTS;
-    int k = 0;                                                   // the slot's previous tenant leaves the cache
-    for (int i = 0; i < tl_amax.ncache; ++i) if (tl_amax.cache[i].out != out) tl_amax.cache[k++] = tl_amax.cache[i];
-    tl_amax.ncache = k;
-    tl_amax.cache[tl_amax.ncache++] = {X, rows, cols, ld, out};
+    float* out = amax_take_slot(X, rows, cols, ld);
     batch.args.op[batch.n++] = {X, rows, cols, ld, out};
     return out;
+}
+// A slot for the partial maxima of X, FILLED BY THE CALLER's own kernels (the passes that write X, e.g. edge.hip edge_amax_raise) before
+// the product that reads X is launched in this same API call: that product finds the slot like a measured one.  null: no f16x3 scope /
+// X is not an operand the products would look up.
+float* amax_reserve(const float* X, long rows, int cols, int ld) {
+    if (!tl_amax.base || !tl_split_half || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3) || (((uintptr_t)X) & 15)) return nullptr;
+    for (int i = 0; i < tl_amax.noffered; ++i) {                 // (a caller's own entry for X wins in amax_get: leave it to that path)
+        const mlsp_bound_t& o = tl_amax.offered[i];
+        if (o.ptr == X && o.rows == rows && o.cols == cols && o.ld == ld) return nullptr;
+    }
+    return amax_take_slot(X, rows, cols, ld);
 }
 // An entry of the caller's table that describes an OUTPUT of the current call (same pointer / shape, valid == 0, room for `need` floats):
 // the call fills its partials with a bound of what it writes -- e.g. the per-channel analytic bound of a BatchNorm'd layer -- and the
