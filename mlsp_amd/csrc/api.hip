@@ -132,7 +132,8 @@ int launch_segsel_act_fwd(hipStream_t st, const float* Y, int G, int k, int C, c
                           float* out, float* ysel, uint8_t* argk);
 int launch_segsel_bwd_apply(hipStream_t st, const float* dOut, const float* Y, const float* ysel, const uint8_t* argk, size_t M, int k, int C,
                             const float* bn, const float* m1, const float* m2, int act, float slope, float* dY);
-int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd);
+int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd, float* amax = nullptr);
+bool build_wd_leaves_bound(int Cout, int C);
 int launch_unbuild_wd(hipStream_t st, const float* dWd, int Cout, int C, float* dW);
 int launch_edge_reduce(hipStream_t st, const float* uv, const int* idx, const float* gamma, int P, int N, int Cout, int k,
                        float* msel, uint8_t* argsel, float* s1, double* part, int* nparts_used);
@@ -407,7 +408,7 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
     if (!training) {                  // eval mode: the BatchNorm vectors do not depend on the batch -- prepared by the weight-fold launch
         if (!run_mean || !run_var) return MLSP_ERR_ARG;
         CHECK(launch_build_wd_eval(st, W, Cout, C, Wd, Cout, gamma, beta, run_mean, run_var, bn_save, 0, nullptr, nullptr, nullptr, nullptr, nullptr, eps));
-    } else CHECK(launch_build_wd(st, W, Cout, C, Wd));
+    } else CHECK(launch_build_wd(st, W, Cout, C, Wd, build_wd_leaves_bound(Cout, C) ? amax_reserve(Wd, 2 * Cout, C, C) : nullptr));   // (mode 3: the fold leaves the bound of what it writes)
     CHECK(launch_gemm(st, false, true, P, 2 * Cout, C, x, ldx, Wd, C, uv, 2 * Cout, nullptr, nullptr, 0, slab, sf));
     {   // the neighbour gather + max/min + BN sums: compulsory bytes = u half + indices in, msel + s1 + arg slot out
         const int tok = prof_cls_begin(st, MLSP_PROF_EDGE_REDUCE);

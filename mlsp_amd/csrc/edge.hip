@@ -19,14 +19,26 @@
 
 #define EDGE_PTS_PER_WAVE 16
 
-// Wd = [Wa ; Wb - Wa]  ([2*Cout, C]) from the reference-layout weight W [Cout, 2C]
-__global__ void build_wd_kernel(const float* __restrict__ W, int Cout, int C, float* __restrict__ Wd) {
+// Wd = [Wa ; Wb - Wa]  ([2*Cout, C]) from the reference-layout weight W [Cout, 2C].  amax (nullable, <= 256 workgroups): the 256 partial
+// maxima of |Wd| for the f16x3 product that reads it (gemm.hip amax_reserve) -- one per workgroup, the rest zero.
+__global__ __launch_bounds__(256) void build_wd_kernel(const float* __restrict__ W, int Cout, int C, float* __restrict__ Wd, float* __restrict__ amax) {
+    __shared__ float sm[4];
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Cout * C) return;
-    int o = t / C, c = t % C;
-    float wa = W[(size_t)o * 2 * C + c], wb = W[(size_t)o * 2 * C + C + c];
-    Wd[(size_t)o * C + c] = wa;
-    Wd[(size_t)(Cout + o) * C + c] = wb - wa;
+    float m = 0.f;
+    if (t < Cout * C) {
+        int o = t / C, c = t % C;
+        float wa = W[(size_t)o * 2 * C + c], wb = W[(size_t)o * 2 * C + C + c];
+        Wd[(size_t)o * C + c] = wa;
+        Wd[(size_t)(Cout + o) * C + c] = wb - wa;
+        m = fmaxf(fabsf(wa), fabsf(wb - wa));
+    }
+    if (!amax) return;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x) amax[threadIdx.x] = 0.f;
 }
 // the same + the eval-mode BatchNorm vectors of up to two BatchNorm stages of the calling entry point (scale | shift | mean | invstd from the
 // running statistics: bn_eval_prepare_kernel's arithmetic) -- an eval-mode EdgeConv / T-Net forward folds its weight and prepares its
@@ -714,8 +726,10 @@ int edge_bwd_reduce_parts(int P, int Cout, const void* a, const void* b, const v
 }
 int edge_reduce_parts(int P) { return (P + 4 * EDGE_PTS_PER_WAVE - 1) / (4 * EDGE_PTS_PER_WAVE); }
 
-int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd) {
-    hipLaunchKernelGGL(build_wd_kernel, dim3((Cout * C + 255) / 256), dim3(256), 0, st, W, Cout, C, Wd);
+bool build_wd_leaves_bound(int Cout, int C) { return (Cout * C + 255) / 256 <= 256; }
+int launch_build_wd(hipStream_t st, const float* W, int Cout, int C, float* Wd, float* amax) {
+    if (amax && (Cout * C + 255) / 256 > 256) return MLSP_ERR_ARG;          // (callers ask build_wd_leaves_bound first)
+    hipLaunchKernelGGL(build_wd_kernel, dim3((Cout * C + 255) / 256), dim3(256), 0, st, W, Cout, C, Wd, amax);
     return mlsp_launch_status();
 }
 // Ca / Cb = 0: that stage is absent

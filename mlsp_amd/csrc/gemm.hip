@@ -1478,13 +1478,17 @@ static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, in
     return out;
 }
 // A slot for the partial maxima of X, FILLED BY THE CALLER's own kernels (the passes that write X, e.g. edge.hip edge_amax_raise) before
-// the product that reads X is launched in this same API call: that product finds the slot like a measured one.  null: no f16x3 scope /
-// X is not an operand the products would look up.
+// the product that reads X is launched in this same API call: that product finds the slot like a measured one (an entry of the caller's
+// table for X is filled instead and marked valid: the caller hands it to later calls).  null: no f16x3 scope / X is not an operand the
+// products would look up / the caller's entry is valid already.
 float* amax_reserve(const float* X, long rows, int cols, int ld) {
     if (!tl_amax.base || !tl_split_half || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3) || (((uintptr_t)X) & 15)) return nullptr;
-    for (int i = 0; i < tl_amax.noffered; ++i) {                 // (a caller's own entry for X wins in amax_get: leave it to that path)
-        const mlsp_bound_t& o = tl_amax.offered[i];
-        if (o.ptr == X && o.rows == rows && o.cols == cols && o.ld == ld) return nullptr;
+    for (int i = 0; i < tl_amax.noffered; ++i) {                 // the caller's own entry for X: filled there (and handed on by the caller), or already valid
+        mlsp_bound_t& o = tl_amax.offered[i];
+        if (o.ptr != X || o.rows != rows || o.cols != cols || o.ld != ld) continue;
+        if (!o.partials || o.valid || (o.n != 0 && o.n != AMAX_PARTS)) return nullptr;
+        o.valid = 1; o.n = AMAX_PARTS;
+        return o.partials;
     }
     return amax_take_slot(X, rows, cols, ld);
 }

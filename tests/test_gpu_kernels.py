@@ -794,6 +794,61 @@ def test_edgeconv_fwd_bwd(dev, B, N, C, Cout, training, k):
         np.testing.assert_allclose(rv_g.cpu().numpy(), rv_c.numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("gscale", [1e-6, 1.0, 3e4])
+def test_edgeconv_backward_f16x3_follows_the_gradient_magnitude(dev, gscale):
+    """Mode "f16x3" at the headline's conv4 (P = 32768, 128 -> 256, k = 20): the passes that write the point-space gradient duv leave its
+    bound as a by-product (edge.hip edge_amax_raise) and the two products that read it scale their pieces by it.  A bound that is too
+    small overflows the f16 pieces, one that is far too large costs significand bits: both show against a float64 evaluation of the
+    layer (torch ops on the GPU), at three magnitudes of the incoming gradient.  Bar: the error of the f32-MFMA mode of the same call
+    (x 2, as test_gemm_split_bf16_accuracy), on the output and on the median row of dx.  The products must really run on the two-piece kernel (profile hook).
+    Figures: profiles/r6_edge_bwd_probe.txt (tools/r6/edge_bwd_probe.py)."""
+    import ctypes
+    from mlsp_amd import _lib
+    Fh = _fh()
+    B, N, C, Cout, k = 32, 1024, 128, 256, 20
+    P = B * N
+    g = torch.Generator().manual_seed(5)
+    xp = torch.randn(P, C, generator=g).to(dev)
+    W = (torch.randn(Cout, 2 * C, generator=g) * 0.1).to(dev)
+    gamma, beta = (torch.randn(Cout, generator=g) + 0.3).to(dev), torch.randn(Cout, generator=g).to(dev)
+    dOut = (torch.randn(P, Cout, generator=g) * gscale).to(dev)
+    graph = Fh.knn_graph(xp, B, N, k)
+    idx = graph.idx.view(B, N, k).long()
+    # float64: get_graph_feature -> 1x1 conv -> BatchNorm2d (batch statistics) -> LeakyReLU -> max over k (PointDA/Models.py:115-129)
+    x64, W64 = xp.double().requires_grad_(True), W.double().requires_grad_(True)
+    xb = x64.view(B, N, C)
+    nb = torch.gather(xb.unsqueeze(1).expand(B, N, N, C), 2, idx.unsqueeze(-1).expand(B, N, k, C))
+    y = torch.cat((nb - xb.unsqueeze(2), xb.unsqueeze(2).expand(B, N, k, C)), dim=-1) @ W64.t()
+    y = (y - y.mean(dim=(0, 1, 2))) / torch.sqrt(y.var(dim=(0, 1, 2), unbiased=False) + 1e-5) * gamma.double() + beta.double()
+    o64 = F.leaky_relu(y, 0.2).max(dim=2)[0].reshape(P, Cout)
+    o64.backward(dOut.double())
+    want = (o64.detach(), x64.grad, W64.grad)
+    del y, nb
+    err, lib = {}, _lib.load()
+    for mode in ("fp32", "f16x3"):
+        xg, Wg, gg, bg = [t.clone().requires_grad_(True) for t in (xp, W, gamma, beta)]
+        rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        with Fh.gemm_precision(mode):
+            lib.mlsp_profile_begin()
+            out = Fh.edgeconv(xg, graph, Wg, gg, bg, rm, rv, True)
+            out.backward(dOut)
+            torch.cuda.synchronize()
+            buf, kinds = (ctypes.c_double * 4)(), (ctypes.c_double * 16)()
+            lib.mlsp_profile_end(buf)
+            lib.mlsp_profile_split_kinds(kinds)
+        assert int(kinds[13]) == (3 if mode == "f16x3" else 0), (mode, list(kinds))        # forward, dgrad, wgrad on f16 pieces
+        got = (out.detach(), xg.grad, Wg.grad)
+        assert all(torch.isfinite(t).all() for t in got), mode
+        rows = ((got[1].double() - want[1]).norm(dim=1) / want[1].norm(dim=1)).median().item()
+        err[mode] = [((a.double() - b).norm() / b.norm()).item() for a, b in zip(got, want)] + [rows]
+    # A max over k that flips between two nearly equal candidates moves two rows of dx by O(1) of their size (and dW by ~1e-5 of its
+    # norm) in ANY mode -- tools/r6/edge_bwd_probe.py shows 1e-5 .. 7e-4 in the f32-MFMA, bf16x6 and f16x3 modes alike, depending on the
+    # data --, so dx is held by its MEDIAN row (a loose bound costs bits in every row, an overflow is not finite), dW loosely.
+    assert err["f16x3"][0] <= 2 * err["fp32"][0] and err["f16x3"][0] < 1e-6, (gscale, err)
+    assert err["f16x3"][3] <= 2 * err["fp32"][3] and err["f16x3"][3] < 2e-6, (gscale, err)
+    assert err["f16x3"][2] < 2e-3, (gscale, err)
+
+
 # ----------------------------------------------------------------------------- losses
 @pytest.mark.parametrize("fname", ["loss_s0_N256.npz", "loss_s1_N1024.npz"])
 def test_losses_vs_golden(dev, golden_dir, fname):
