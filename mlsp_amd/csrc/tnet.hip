@@ -420,7 +420,9 @@ __device__ __forceinline__ tbf16x8 tn_pack8(const uint32_t (&p)[4]) {
     const u32x4 v = {p[0], p[1], p[2], p[3]};
     return __builtin_bit_cast(tbf16x8, v);
 }
-template <int K>
+// ONEP (`precision` = MLSP_PREC_BF16: operands ROUNDED to bf16): only the leading pieces are staged and multiplied -- one MFMA per k16 step
+// instead of six; everything else (walk, gather, epilogue, sums) is the same code.
+template <int K, bool ONEP = false>
 __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
     constexpr int PT = TF_ROWS / K;                  // points per tile
     constexpr int GP = K / 4;                        // aligned 4-row groups per point
@@ -520,8 +522,10 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
                     tn_split2(hv[0], hv[1], pa[0], pb[0], pc[0]);
                     tn_split2(hv[2], hv[3], pa[1], pb[1], pc[1]);
                     *(uint2*)(dst + 8 * e) = make_uint2(pa[0], pa[1]);                      // four channels = 8 bytes of each image
-                    *(uint2*)(dst + TF3_PLANE + 8 * e) = make_uint2(pb[0], pb[1]);
-                    *(uint2*)(dst + 2 * TF3_PLANE + 8 * e) = make_uint2(pc[0], pc[1]);
+                    if (!ONEP) {
+                        *(uint2*)(dst + TF3_PLANE + 8 * e) = make_uint2(pb[0], pb[1]);
+                        *(uint2*)(dst + 2 * TF3_PLANE + 8 * e) = make_uint2(pc[0], pc[1]);
+                    }
                 }
             }
         }
@@ -572,6 +576,13 @@ __global__ __launch_bounds__(256, 2) void tnet_edge_fwd3_kernel(TnetFwdArgs p) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 tbf16x8 a_cur[3];
+                if constexpr (ONEP) {
+                    a_cur[0] = *(const tbf16x8*)(hrow + 32 * s);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0], w2p[s][0], acc[b], 0, 0, 0);
+                    if (b > 0) { epi(b - 1, 4 * s); epi(b - 1, 4 * s + 1); epi(b - 1, 4 * s + 2); epi(b - 1, 4 * s + 3); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a_cur[q] = *(const tbf16x8*)(hrow + q * TF3_PLANE + 32 * s);
                 // six piece products, smallest first; the register epilogue of block b - 1 rides between them (four entries per k16 step)
@@ -1336,6 +1347,9 @@ struct TbWalk {
     }
 };
 
+// ONEP (`precision` = MLSP_PREC_BF16): the contractions multiply the leading pieces only (one MFMA where the fp32-accurate form has six);
+// H' for the epilogue is still recovered from all three (its sign and value enter the BatchNorm-backward sums).
+template <bool ONEP>
 __global__ __launch_bounds__(512) void tnet_edge_bwds_kernel(
     const float* __restrict__ uv, const int* __restrict__ idx, const float* __restrict__ bn1, const float* __restrict__ W2,
     const float* __restrict__ Mc, const float* __restrict__ g, const uint8_t* __restrict__ argsel, float* __restrict__ dhp,
@@ -1599,7 +1613,7 @@ __global__ __launch_bounds__(512) void tnet_edge_bwds_kernel(
                     u32x4 gpn[3]; tu32x2 awn; tbf16x8 bn_[3], an[3];
 #pragma unroll
                     for (int i2 = 0; i2 < 6; ++i2) {
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[i2]], bc[PB[i2]], acc[ct], 0, 0, 0);
+                        if (!ONEP || i2 == 5) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[i2]], bc[PB[i2]], acc[ct], 0, 0, 0);
                         if (i2 == 0) {                         // requests of step s + 1
                             if (s + 1 < 8) { ld_g(s + 1, gpn, awn); ld_b(wlo, s + 1, bn_); }
                             else if (s + 1 < 12) { ld_h(s + 1 - 8, an); ld_b(mlo, s + 1 - 8, bn_); }
@@ -1685,7 +1699,11 @@ __global__ __launch_bounds__(512) void tnet_edge_bwds_kernel(
                 }
                 tbf16x8 a[3];
                 a[0] = tn_pack8(d[0]); a[1] = tn_pack8(d[1]); a[2] = tn_pack8(d[2]);
-                tb_mac6x3(acc[0], acc[1], acch[0], a, bhc[0], a, bhc[1], gi ? bhc[1] : bhc[0], gj ? bhc[1] : bhc[0]);
+                if constexpr (ONEP) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bhc[0][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bhc[1][0], acc[1], 0, 0, 0);
+                    acch[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((gi ? bhc[1] : bhc[0])[0], (gj ? bhc[1] : bhc[0])[0], acch[0], 0, 0, 0);
+                } else tb_mac6x3(acc[0], acc[1], acch[0], a, bhc[0], a, bhc[1], gi ? bhc[1] : bhc[0], gj ? bhc[1] : bhc[0]);
                 if (s + 1 < 8) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
@@ -1842,8 +1860,12 @@ int launch_tnet_edge_fwd(hipStream_t st, const float* uv, const int* idx, const 
             if (k == 20) hipLaunchKernelGGL((tnet_edge_fwd2_kernel<20>), dim3(grid), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((tnet_edge_fwd2_kernel<40>), dim3(grid), dim3(256), 0, st, a);
         } else {
-            if (k == 20) hipLaunchKernelGGL((tnet_edge_fwd3_kernel<20>), dim3(grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((tnet_edge_fwd3_kernel<40>), dim3(grid), dim3(256), 0, st, a);
+            static const bool six_env = getenv("MLSP_TNET_BF16_SIX") != nullptr;      // A/B: mode 1 on the six-product kernels (rounds 3-5)
+            const bool onep = gemm_precision_mode() == 1 && !split_env && !six_env;
+            if (k == 20 && !onep) hipLaunchKernelGGL((tnet_edge_fwd3_kernel<20>), dim3(grid), dim3(256), 0, st, a);
+            else if (k == 20) hipLaunchKernelGGL((tnet_edge_fwd3_kernel<20, true>), dim3(grid), dim3(256), 0, st, a);
+            else if (!onep) hipLaunchKernelGGL((tnet_edge_fwd3_kernel<40>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((tnet_edge_fwd3_kernel<40, true>), dim3(grid), dim3(256), 0, st, a);
         }
         return mlsp_launch_status();
     }
@@ -1903,9 +1925,11 @@ int launch_tnet_edge_bwd(hipStream_t st, const float* uv, const int* idx, const 
         static const bool f32_env = getenv("MLSP_TNET_BWD_F32") != nullptr;
         if (!f32_env && gemm_precision_mode() != 0 && k % 2 == 0 && k >= 8 && k <= 64) {
             const size_t lds = sizeof(TnetBwdSLds);
-            hipError_t e = mlsp_lds_limit((const void*)tnet_edge_bwds_kernel, lds);
+            static const bool six_env = getenv("MLSP_TNET_BF16_SIX") != nullptr;      // A/B: mode 1 on the six-product kernel (rounds 4-5)
+            auto kern = (gemm_precision_mode() == 1 && !six_env) ? tnet_edge_bwds_kernel<true> : tnet_edge_bwds_kernel<false>;
+            hipError_t e = mlsp_lds_limit((const void*)kern, lds);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(tnet_edge_bwds_kernel, dim3(nb), dim3(512), lds, st, uv, idx, bn1, W2, Mc, g, argsel, dhp, slabs, part1, P, N, k, TP, slope);
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, st, uv, idx, bn1, W2, Mc, g, argsel, dhp, slabs, part1, P, N, k, TP, slope);
         } else {
             const size_t lds = sizeof(TnetBwdGLds);
             auto kern = k <= 20 ? tnet_edge_bwdg_kernel<0, 20> : k <= 24 ? tnet_edge_bwdg_kernel<0, 24> : k <= 32 ? tnet_edge_bwdg_kernel<0, 32>

@@ -990,6 +990,48 @@ def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
         assert (a - b).abs().max().item() / scale < (2e-4 if name == "dW1" else 1e-7), (name, (a - b).abs().max().item() / scale)
 
 
+@pytest.mark.parametrize("B,N,k", [(4, 512, 20), (2, 1024, 40)])
+def test_tnet_edge_bf16_operands_vs_fp32_products(dev, B, N, k):
+    """`precision` "bf16" (BASELINE.json configs[4]): the per-edge stage multiplies operands ROUNDED to bf16 -- one MFMA per k16 step of the
+    64 -> 128 contraction and of the backward's Gram-form products (tnet.hip, ONEP instantiations) where the fp32-accurate modes spend six.
+    Forward: against the fp32-accurate mode of the same call.  Backward: the SAME forward (bf16 mode: same saved pre-activations and
+    arg-max slots) taken back once with the single products and once with the six -- a rounding of both operands apart (2^-9 per value),
+    without the max-over-k selections a rounded forward moves (those are what tests/test_gpu_model.py's yardstick prices at model level).
+    Not less than a rounding leaves either: the operands really were rounded."""
+    from mlsp_amd import _lib
+    Fh = _fh()
+    P = B * N
+    g = torch.Generator().manual_seed(21)
+    xp = torch.randn(P, 3, generator=g).to(dev)
+    W1, W2 = (torch.randn(64, 6, generator=g) * 0.5).to(dev), (torch.randn(128, 64, generator=g) * 0.2).to(dev)
+    g1, b1 = (torch.randn(64, generator=g) * 0.3 + 1).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+    g2, b2 = (torch.randn(128, generator=g) * 0.3 + 1).to(dev), (torch.randn(128, generator=g) * 0.3).to(dev)
+    dOut = torch.randn(P, 128, generator=g).to(dev)
+    graph = Fh.knn_graph(xp, B, N, k)
+
+    def run(fwd_mode, bwd_mode):
+        leaves = [t.clone().requires_grad_(True) for t in (W1, g1, b1, W2, g2, b2)]
+        rm1, rv1, rm2, rv2 = torch.zeros(64, device=dev), torch.ones(64, device=dev), torch.zeros(128, device=dev), torch.ones(128, device=dev)
+        with Fh.gemm_precision(fwd_mode):
+            out = Fh.tnet_edge(xp, graph, leaves[0], leaves[1], leaves[2], rm1, rv1, leaves[3], leaves[4], leaves[5], rm2, rv2, True)
+        assert out.grad_fn.prec == _lib.GEMM_PRECISION_MODES[fwd_mode]
+        out.grad_fn.prec = _lib.GEMM_PRECISION_MODES[bwd_mode]        # (the Function hands its forward's mode to its backward: overridden here)
+        out.backward(dOut)
+        return [out.detach()] + [t.grad for t in leaves]
+
+    ref_f, one, six = run("bf16x6", "bf16x6"), run("bf16", "bf16"), run("bf16", "bf16x6")
+    rel_out = ((one[0].double() - ref_f[0].double()).norm() / ref_f[0].double().norm()).item()
+    assert 1e-5 < rel_out < 1e-2, rel_out
+    assert torch.equal(one[0], six[0])
+    for i, name in enumerate(("dW1", "dg1", "db1", "dW2", "dg2", "db2"), 1):
+        a, b = one[i].double(), six[i].double()
+        assert torch.isfinite(a).all(), name
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel < 1e-2, (name, rel)
+        if name == "dW2":
+            assert rel > 1e-5, (name, rel)
+
+
 @pytest.mark.parametrize("B,N,k", [(8, 512, 20), (4, 512, 40)])
 def test_tnet_backward_gram_form_vs_round1_kernel(dev, B, N, k):
     """Three independent backward kernels of the fused stage: the dense split-product Gram form (the default), the f32 Gram form with the
