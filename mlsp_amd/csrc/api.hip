@@ -41,7 +41,7 @@ int launch_compose_fwd(hipStream_t st, const float* Wa, const float* ba, const f
 int launch_compose_bwd(hipStream_t st, const float* dW, const float* db, const float* Wa, const float* ba, const float* Wb, int Cm, int Ci, int Co,
                        float* dWa, float* dba, float* dWb);
 int launch_skinny_bwd_pair(hipStream_t st, const float* G, int ldg, const float* W, int ldw, const float* X, int ldx, float* dX, int lddx,
-                           float* dW, int M, int Cin, int Cout);
+                           float* dW, int M, int Cin, int Cout, int dx_accumulate = 0);
 int launch_wt_vec_neg_scale_rows(hipStream_t st, const float* W, int ldw, const float* v, const float* rowscale, int Cout, int Cin, float* negr,
                                  float* Wb);
 int launch_bn_bwd_finalize_coef_z(hipStream_t st, const double* part, int nparts, double count, int C, const float* bn_save, float* dgamma,
@@ -781,9 +781,10 @@ static int pointmlp_bwd_impl(const float* dZ, const float* X, int ldx, int M, in
         bs = &bs_s;
     }
     static const bool no_pair = getenv("MLSP_SKINNY_NO_PAIR") != nullptr;          // read-once A/B switch
-    if (M <= 32 && dX && !dx_accumulate && !bs && !dy && !xf && !no_pair) {
-        // per-cloud layer (rows = batch): input gradient and weight gradient in one launch (skinny.hip)
-        CHECK(launch_skinny_bwd_pair(st, g, Cout, W, ldw, X, ldx, dX, lddx, dW, M, Cin, Cout));
+    if (M <= 32 && dX && !bs && !dy && !xf && !no_pair) {
+        // per-cloud layer (rows = batch): input gradient (added into dX under dx_accumulate: the x5 halves of the PointSegDA heads share one
+        // gradient buffer) and weight gradient in one launch (skinny.hip)
+        CHECK(launch_skinny_bwd_pair(st, g, Cout, W, ldw, X, ldx, dX, lddx, dW, M, Cin, Cout, dx_accumulate));
     } else {
     if (dX) CHECK(launch_gemm(st, false, false, M, Cin, Cout, g, Cout, W, ldw, dX, lddx, nullptr, nullptr, 0, slab, sf, nullptr, nullptr,
                               nullptr, nullptr, dx_accumulate != 0, nullptr, 0, nullptr, bs, dy));

@@ -2047,8 +2047,11 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     const bool xcd3 = !no_xcd3 && !p.xcd_map && ns > 1 && ns % 8 == 0 && p.ntm > 1 && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && (!xf || xf_split);
     if (xcd3) { p.xcd_map = 3; grid = dim3(p.ntm * p.ntn * ns, 1); }       // (all tiles of a split on one XCD: see the kernel)
     else if (xcd2) { p.xcd_map = 2; grid = dim3(p.ntm * p.ntn * ns, 1); }
+    // (mode 1, N = 64: the bf16 kernel's tiles are 128 columns wide, so these launches used to fall to the bounds-checked f32 kernel at half-empty
+    // tiles -- 33 us where the 64-column f32 kernel takes 12; exact products are within what mode 1 promises.  Read-once A/B switch.)
+    static const bool no_n64_bf16 = getenv("MLSP_GEMM_NO_N64_BF16") != nullptr;
     const bool n64 = !dy && !grp && !xf && N == 64 && p.a_vec && p.b_vec && M % 128 == 0 && K % BK == 0 && !(ta && tb) && !gbias && (!stat_part || (bm == 128 && ns == 1)) && !sel_gamma &&
-                     (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && tl_call_precision != 1 && (ns == 1 || p.ldc == N);
+                     (!bias || (ns == 1 && (((uintptr_t)bias) & 3) == 0)) && (tl_call_precision != 1 || !no_n64_bf16) && (ns == 1 || p.ldc == N);
     // two-piece f16 products (mode 3) on this launch?  The split kernel, and a bound for both operands: partial maxima of the operands as
     // they lie in memory (measured by ONE streaming launch here, or earlier in this API call), the analytic bound for a transformed one
     // (batch statistics at hand).  Anything missing: the three-piece bf16 products (same kernel family, same accuracy class).

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void skinny_bn_bwd_kernel(const float* __restr
 
 // ---- dgrad: C[M<=32][N] = A[M][K] * B[K][N]   (A row-major, B k-major).  Same 4-wave K split as the forward.
 __device__ __forceinline__ void sk_nn_body(int blk, float (*red)[16][64], const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                           float* __restrict__ Cm, int ldc, int M, int N, int K) {
+                                           float* __restrict__ Cm, int ldc, int M, int N, int K, bool accumulate = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int n0 = blk * 32, col = n0 + l31;
     const bool vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
@@ -228,7 +228,7 @@ __device__ __forceinline__ void sk_nn_body(int blk, float (*red)[16][64], const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < M) Cm[(size_t)row * ldc + col] = acc[r];
+        if (row < M) Cm[(size_t)row * ldc + col] = accumulate ? Cm[(size_t)row * ldc + col] + acc[r] : acc[r];      // (beta = 1: the input gradient is summed into a shared buffer)
     }
 }
 
@@ -274,17 +274,17 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const float* __restrict_
 // same summation order as the two launches it replaces.
 __global__ __launch_bounds__(64 * SK_WAVES) void skinny_bwd_pair_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ W, int ldw,
                                                                         const float* __restrict__ X, int ldx, float* __restrict__ dX, int lddx,
-                                                                        float* __restrict__ dW, int M, int Cin, int Cout, int nb_nn) {
+                                                                        float* __restrict__ dW, int M, int Cin, int Cout, int nb_nn, int dx_accumulate) {
     __shared__ float red[SK_WAVES - 1][16][64];
-    if ((int)blockIdx.x < nb_nn) sk_nn_body(blockIdx.x, red, G, ldg, W, ldw, dX, lddx, M, Cin, Cout);
+    if ((int)blockIdx.x < nb_nn) sk_nn_body(blockIdx.x, red, G, ldg, W, ldw, dX, lddx, M, Cin, Cout, dx_accumulate != 0);
     else sk_tn_body(((int)blockIdx.x - nb_nn) * SK_WAVES + (threadIdx.x >> 6), G, ldg, X, ldx, dW, Cin, Cout, Cin, M);
 }
 int launch_skinny_bwd_pair(hipStream_t st, const float* G, int ldg, const float* W, int ldw, const float* X, int ldx, float* dX, int lddx,
-                           float* dW, int M, int Cin, int Cout) {
+                           float* dW, int M, int Cin, int Cout, int dx_accumulate) {
     if (M > 32 || !G || !W || !X || !dX || !dW) return MLSP_ERR_UNSUPPORTED;
     const int nb_nn = (Cin + 31) / 32, tiles = ((Cout + 31) / 32) * ((Cin + 31) / 32);
     hipLaunchKernelGGL(skinny_bwd_pair_kernel, dim3(nb_nn + (tiles + SK_WAVES - 1) / SK_WAVES), dim3(64 * SK_WAVES), 0, st, G, ldg, W, ldw, X, ldx,
-                       dX, lddx, dW, M, Cin, Cout, nb_nn);
+                       dX, lddx, dW, M, Cin, Cout, nb_nn, dx_accumulate);
     return mlsp_launch_status();
 }
 

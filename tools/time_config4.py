@@ -48,6 +48,10 @@ for name, prec, store in MODES:
         for _ in range(5):
             step()
         torch.cuda.synchronize()
+        if os.environ.get("MLSP_PROF_DUMP"):               # one line per GEMM-family launch of one step (gemm.hip mlsp_profile_end)
+            from mlsp_amd import _lib
+            import ctypes
+            _lib.load().mlsp_profile_begin(); step(); torch.cuda.synchronize(); _lib.load().mlsp_profile_end((ctypes.c_double * 4)())
         ts = []
         for _ in range(5):
             t0 = time.perf_counter()
