@@ -352,9 +352,11 @@ __global__ __launch_bounds__(256) void compose_fwd_kernel(const float* __restric
     for (int c = threadIdx.x; c <= Ci; c += blockDim.x) {
         float acc = 0.f;
         if (c < Ci) {
-            for (int m = 0; m < Cm; ++m) acc = fmaf(Wb[(size_t)o * Cm + m], Wa[(size_t)m * Ci + c], acc);
+#pragma unroll 16
+            for (int m = 0; m < Cm; ++m) acc = fmaf(Wb[(size_t)o * Cm + m], Wa[(size_t)m * Ci + c], acc);      // (sixteen loads in flight: the chain of Cm load latencies was the launch's 14 us)
             W[(size_t)o * Ci + c] = acc;
         } else {
+#pragma unroll 16
             for (int m = 0; m < Cm; ++m) acc = fmaf(Wb[(size_t)o * Cm + m], ba[m], acc);
             b[o] = acc + bb[o];
         }
@@ -371,9 +373,11 @@ __global__ __launch_bounds__(256) void compose_bwd_kernel(const float* __restric
         for (int c = threadIdx.x; c <= Ci; c += blockDim.x) {
             float acc = 0.f;
             if (c < Ci) {
+#pragma unroll 16
                 for (int o = 0; o < Co; ++o) acc = fmaf(Wb[(size_t)o * Cm + m], dW[(size_t)o * Ci + c], acc);
                 dWa[(size_t)m * Ci + c] = acc;
             } else {
+#pragma unroll 16
                 for (int o = 0; o < Co; ++o) acc = fmaf(Wb[(size_t)o * Cm + m], db[o], acc);
                 dba[m] = acc;
             }
