@@ -1477,6 +1477,18 @@ static float* amax_get(AmaxBatch& batch, const float* X, long rows, int cols, in
     batch.args.op[batch.n++] = {X, rows, cols, ld, out};
     return out;
 }
+// Is a bound of X at hand (a valid entry of the caller's table, or measured / produced earlier in this API call)?  No side effects.
+static bool amax_at_hand(const float* X, long rows, int cols, int ld) {
+    for (int i = 0; i < tl_amax.noffered; ++i) {
+        const mlsp_bound_t& o = tl_amax.offered[i];
+        if (o.ptr == X && o.rows == rows && o.cols == cols && o.ld == ld && o.partials && o.valid && o.n > 0 && o.n <= 4096) return true;
+    }
+    for (int i = 0; i < tl_amax.ncache; ++i) {
+        const auto& c = tl_amax.cache[i];
+        if (c.X == X && c.rows == rows && c.cols == cols && c.ld == ld) return true;
+    }
+    return false;
+}
 // A slot for the partial maxima of X, FILLED BY THE CALLER's own kernels (the passes that write X, e.g. edge.hip edge_amax_raise) before
 // the product that reads X is launched in this same API call: that product finds the slot like a measured one (an entry of the caller's
 // table for X is filled instead and marked valid: the caller hands it to later calls).  null: no f16x3 scope / X is not an operand the
@@ -2059,14 +2071,32 @@ int launch_gemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, const flo
     if (tl_split_half && tl_amax.base && fast && tl_call_precision == 2 && gemm_split_pays(M, N, kts) && !n64 && (!xf || xf_split)) {
         AmaxBatch batch;
         bool ok = true;
-        if (xf && xf->which == 1) ok = xf->mean && xf->invstd;
+        // Does MEASURING what is not at hand pay?  The three-product kernel saves about a third of the six-product launch (~150 TF on
+        // these shapes); a measuring pass streams the operand at ~3 TB/s plus a launch.  Long K loops win easily (conv5: 76 us against
+        // 25 for its 67 MB input); the set-abstraction layers' K = 128 contractions over 262144 rows do not (tools/x6/lib_bench: 90 us with
+        // the pass against 70 on six products; configs[3] 3.58 -> 3.46 ms) and stay on the six products unless their bounds are free.
+        {
+            static const bool always = getenv("MLSP_AMAX_ALWAYS") != nullptr;          // read-once A/B switch
+            double mbytes = 0.0;
+            auto need = [&](const float* X, long rows, int cols, int ld) { if (!amax_at_hand(X, rows, cols, ld)) mbytes += (double)rows * cols * 4.0; };
+            if (!(xf && xf->which == 1) && !(dy && dy->amax))
+                need(A, ta ? K : M, (ta ? M : K) + ((grp && grp->mode == 1) ? (int)((grp->G - 1) * grp->a_gs) : 0), lda);
+            if (xf && xf->which == 2) { }
+            else if (grp && grp->mode == 1) { for (int g = 0; g < grp->G; ++g) need(grp->Bg[g], tb ? N / grp->G : K, tb ? K : N / grp->G, ldb); }
+            else need(B, tb ? N : K, (tb ? K : N) + ((grp && grp->mode == 2) ? (int)((grp->G - 1) * grp->b_gs) : 0), ldb);
+            const double gain_us = 0.33 * (2.0 * M * N * K) / 150e6, cost_us = 3.0 + mbytes / 3e6;
+            if (mbytes > 0.0 && gain_us < cost_us && !always) ok = false;
+        }
+        if (!ok) { }
+        else if (xf && xf->which == 1) ok = xf->mean && xf->invstd;
         else if (dy && dy->amax) { /* bound from the coefficient rows (max |d'| per channel, left by the consumers' dgrads): nothing to measure */ }
         else {
             const int acols = (ta ? M : K) + ((grp && grp->mode == 1) ? (int)((grp->G - 1) * grp->a_gs) : 0);
             p.a_amax = amax_get(batch, A, ta ? K : M, acols, lda, &p.a_amax_n);
             ok = p.a_amax != nullptr;
         }
-        if (xf && xf->which == 2) ok = ok && xf->mean && xf->invstd;
+        if (!ok) { }
+        else if (xf && xf->which == 2) ok = ok && xf->mean && xf->invstd;
         else if (grp && grp->mode == 1) {
             for (int g = 0; g < grp->G && ok; ++g) { p.b_amax[g] = amax_get(batch, grp->Bg[g], tb ? N / grp->G : K, tb ? K : N / grp->G, ldb, &p.b_amax_n[g]); ok = p.b_amax[g] != nullptr; }
         } else {
