@@ -408,7 +408,7 @@ int mlsp_edgeconv_fwd_f32(const float* x, int ldx, const int32_t* idx, const flo
     if (!training) {                  // eval mode: the BatchNorm vectors do not depend on the batch -- prepared by the weight-fold launch
         if (!run_mean || !run_var) return MLSP_ERR_ARG;
         CHECK(launch_build_wd_eval(st, W, Cout, C, Wd, Cout, gamma, beta, run_mean, run_var, bn_save, 0, nullptr, nullptr, nullptr, nullptr, nullptr, eps));
-    } else CHECK(launch_build_wd(st, W, Cout, C, Wd, build_wd_leaves_bound(Cout, C) ? amax_reserve(Wd, 2 * Cout, C, C) : nullptr));   // (mode 3: the fold leaves the bound of what it writes)
+    } else CHECK(launch_build_wd(st, W, Cout, C, Wd, (C >= 128 && C % 32 == 0 && build_wd_leaves_bound(Cout, C)) ? amax_reserve(Wd, 2 * Cout, C, C) : nullptr));   // (mode 3: the fold leaves the bound of what it writes)
     CHECK(launch_gemm(st, false, true, P, 2 * Cout, C, x, ldx, Wd, C, uv, 2 * Cout, nullptr, nullptr, 0, slab, sf));
     {   // the neighbour gather + max/min + BN sums: compulsory bytes = u half + indices in, msel + s1 + arg slot out
         const int tok = prof_cls_begin(st, MLSP_PROF_EDGE_REDUCE);
@@ -454,7 +454,8 @@ int mlsp_edgeconv_bwd_f32(const float* dOut, int lddo, const float* x, int ldx, 
     const float* scale = bn_save, *mean = bn_save + 2 * Cout, *invstd = bn_save + 3 * Cout;
     // f16x3: the passes that write duv leave its bound (256 partial maxima in a slot of the workspace tail, found again by both products
     // below) instead of a measuring pass over the finished tensor
-    float* duv_amax = edge_bwd_leaves_duv_bound(dOut, out, msel, uv, s1, argsel, Cout, scale, mean, invstd, gz, duv, lddo, ldo)
+    // (only where those products can take the two-piece kernel at all: C a multiple of its 128-column tile -- conv4 of the DGCNN encoder)
+    float* duv_amax = (C % 128 == 0 && edge_bwd_leaves_duv_bound(dOut, out, msel, uv, s1, argsel, Cout, scale, mean, invstd, gz, duv, lddo, ldo))
                           ? amax_reserve(duv, P, 2 * Cout, 2 * Cout) : nullptr;
     CHECK(launch_edge_bwd_reduce(st, dOut, out, msel, uv, P, Cout, mean, invstd, act, slope, part, lddo, ldo, duv_amax));
     CHECK(launch_bn_bwd_finalize(st, part, edge_bwd_reduce_parts(P, Cout, dOut, out, msel, uv, mean, invstd, lddo, ldo), (double)P * k, Cout,

@@ -402,12 +402,17 @@ __global__ __launch_bounds__(NT, 4) void edge_reduce_wide_kernel(const float* __
     }
 }
 
-// By-product bound of duv for the f16x3 products that read it (gemm.hip amax_reserve): every wave raises one of 256 partial maxima
-// (non-negative floats order like their bit patterns; the slot was zeroed by edge_bwd_reduce_vec_kernel, earlier on the stream).
+// By-product bound of duv for the f16x3 products that read it (gemm.hip amax_reserve): every WORKGROUP raises one of 256 partial maxima
+// (non-negative floats order like their bit patterns; the slot was zeroed by edge_bwd_reduce_vec_kernel, earlier on the stream).  One
+// atomic per workgroup: one per wave -- 32768 of them on 256 addresses -- cost the gather 15 us per launch.  Every thread of the
+// workgroup must call it (barrier inside).
 __device__ __forceinline__ void edge_amax_raise(float* __restrict__ amax, float m) {
+    __shared__ float wm[4];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax((unsigned int*)amax + (blockIdx.x & 255), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
 // vectorised reverse gather (same lane layout): du_j over rev(j)
@@ -429,46 +434,47 @@ __global__ __launch_bounds__(256) void edge_bwd_gather_vec_kernel(const float* _
         xcd_cloud_map(blockIdx.x, N / 4, P / N, cloud, chunk);
         j = cloud * N + chunk * 4 + w;
     }
-    if (j >= P) return;
-    const int sub = lane / LR, c = (lane % LR) * 4;
-    const int base = (j / N) * N;
-    const int e0 = rev_off[j], e1 = rev_off[j + 1];
-    const int ld = 2 * Cout;
-    float A[4] = {0, 0, 0, 0}, Bc[4] = {0, 0, 0, 0};
-    if (mean_dz) {
+    float pm = 0.f;
+    if (j < P) {                                         // (wave-uniform; no early return: the workgroup meets in edge_amax_raise)
+        const int sub = lane / LR, c = (lane % LR) * 4;
+        const int base = (j / N) * N;
+        const int e0 = rev_off[j], e1 = rev_off[j + 1];
+        const int ld = 2 * Cout;
+        float A[4] = {0, 0, 0, 0}, Bc[4] = {0, 0, 0, 0};
+        if (mean_dz) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { float sc = scale[c + e]; A[e] = sc * mean_dz[c + e]; Bc[e] = sc * invstd[c + e] * mean_dzy[c + e]; }
-    }
-    float acc[4] = {0, 0, 0, 0};
-    for (int ec = e0; ec < e1; ec += 64) {              // chunks of 64 reverse entries: one coalesced load, then shuffles
-        const int nent = min(64, e1 - ec);
-        const int entv = lane < nent ? rev_ent[ec + lane] : 0;
-        for (int t0 = 0; t0 < nent; t0 += NP) {          // wave-uniform trip count (see edge_reduce_vec_kernel)
-            const int t = t0 + sub;
-            const bool ok = t < nent;
-            const int ent = __shfl(entv, ok ? t : 0, 64);
-            const int i = base + (ent >> 8), slot = ent & 255;
-            const f32x4 g = *(const f32x4*)(gz + (size_t)i * Cout + c);
-            const uint32_t a4 = *(const uint32_t*)(argsel + (size_t)i * Cout + c);
-            const f32x4 v = *(const f32x4*)(uv + (size_t)i * ld + Cout + c);
+            for (int e = 0; e < 4; ++e) { float sc = scale[c + e]; A[e] = sc * mean_dz[c + e]; Bc[e] = sc * invstd[c + e] * mean_dzy[c + e]; }
+        }
+        float acc[4] = {0, 0, 0, 0};
+        for (int ec = e0; ec < e1; ec += 64) {              // chunks of 64 reverse entries: one coalesced load, then shuffles
+            const int nent = min(64, e1 - ec);
+            const int entv = lane < nent ? rev_ent[ec + lane] : 0;
+            for (int t0 = 0; t0 < nent; t0 += NP) {          // wave-uniform trip count (see edge_reduce_vec_kernel)
+                const int t = t0 + sub;
+                const bool ok = t < nent;
+                const int ent = __shfl(entv, ok ? t : 0, 64);
+                const int i = base + (ent >> 8), slot = ent & 255;
+                const f32x4 g = *(const f32x4*)(gz + (size_t)i * Cout + c);
+                const uint32_t a4 = *(const uint32_t*)(argsel + (size_t)i * Cout + c);
+                const f32x4 v = *(const f32x4*)(uv + (size_t)i * ld + Cout + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float ge = (((a4 >> (8 * e)) & 255) == (uint32_t)slot) ? g[e] : 0.f;
-                acc[e] += ok ? (ge - Bc[e] * v[e]) : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    float ge = (((a4 >> (8 * e)) & 255) == (uint32_t)slot) ? g[e] : 0.f;
+                    acc[e] += ok ? (ge - Bc[e] * v[e]) : 0.f;
+                }
             }
         }
-    }
 #pragma unroll
-    for (int o = LR; o < 64; o <<= 1)
+        for (int o = LR; o < 64; o <<= 1)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-    float pm = 0.f;
-    if (sub == 0) {
-        const f32x4 u = *(const f32x4*)(uv + (size_t)j * ld + c);
-        f32x4 o4;
+            for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+        if (sub == 0) {
+            const f32x4 u = *(const f32x4*)(uv + (size_t)j * ld + c);
+            f32x4 o4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o4[e] = acc[e] - (float)(e1 - e0) * (A[e] + Bc[e] * (u[e] - mean[c + e])); pm = fmaxf(pm, fabsf(o4[e])); }
-        *(f32x4*)(duv + (size_t)j * ld + c) = o4;
+            for (int e = 0; e < 4; ++e) { o4[e] = acc[e] - (float)(e1 - e0) * (A[e] + Bc[e] * (u[e] - mean[c + e])); pm = fmaxf(pm, fabsf(o4[e])); }
+            *(f32x4*)(duv + (size_t)j * ld + c) = o4;
+        }
     }
     if (duv_amax) edge_amax_raise(duv_amax, pm);
 }
