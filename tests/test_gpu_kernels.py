@@ -990,6 +990,33 @@ def test_tnet_edge_fused_vs_materialised(dev, B, N, k, training):
         assert (a - b).abs().max().item() / scale < (2e-4 if name == "dW1" else 1e-7), (name, (a - b).abs().max().item() / scale)
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16"])
+@pytest.mark.parametrize("M", [16, 32, 7])
+def test_per_cloud_layers_sharing_an_input_gradient(dev, M, mode):
+    """The x5 halves of the PointSegDA heads' first layers (PointSegDA/Models.py:226-241: every head reads the same [B, 1024] global
+    feature): per-cloud Linear layers (rows = clouds <= 32) whose input gradients are SUMMED in one buffer (functional.fan_out /
+    grad_accum: beta = 1 in the dgrad).  Round 6: that dgrad runs on skinny_bwd_pair_kernel (dx_accumulate) instead of the bounds-checked
+    128 x 128 tile kernel.  Against torch: outputs, the summed input gradient, every weight gradient."""
+    Fh = _fh()
+    x = _rand((M, 1024), 31)
+    Ws = [_rand((n, 1024), 32 + i, 0.05) for i, n in enumerate((256, 256, 512))]
+    dYs = [_rand((M, W.shape[0]), 40 + i) for i, W in enumerate(Ws)]
+    xc = x.clone().requires_grad_(True)
+    Wc = [W.clone().requires_grad_(True) for W in Ws]
+    torch.autograd.backward([xc @ W.t() for W in Wc], dYs)
+    xg = x.to(dev).requires_grad_(True)
+    Wg = [W.to(dev).requires_grad_(True) for W in Ws]
+    with Fh.gemm_precision(mode):
+        aliases, acc = Fh.fan_out(xg, len(Wg))
+        outs = [Fh.pointmlp(a, W, grad_accum=acc) for a, W in zip(aliases, Wg)]
+        torch.autograd.backward(outs, [d.to(dev) for d in dYs])
+    for o, W in zip(outs, Wc):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), (x @ W.detach().t()).numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-4, atol=1e-4)
+    for a, b in zip(Wg, Wc):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("B,N,k", [(4, 512, 20), (2, 1024, 40)])
 def test_tnet_edge_bf16_operands_vs_fp32_products(dev, B, N, k):
     """`precision` "bf16" (BASELINE.json configs[4]): the per-edge stage multiplies operands ROUNDED to bf16 -- one MFMA per k16 step of the
